@@ -1,0 +1,218 @@
+/* tdr.h -- C ABI of libtdr_hip.so: the MI355X (gfx950) kernels behind the
+ * guided-restoration train step of TextualDegRemoval (NAFNet-ref path).
+ *
+ * The reference has no FFI for this path (it is pure PyTorch); each entry point
+ * below replaces the ATen call sites of one SURVEY.md section-8a row and cites
+ * them (paths relative to the reference checkout).  Conventions:
+ *   - caller allocates every buffer (device pointers, fp32 contiguous NCHW,
+ *     int32/int64 where stated); the library never owns or frees memory;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and are
+ *     asynchronous; no global mutable state;
+ *   - return 0 on success, negative error code otherwise, never throws;
+ *     tdr_last_error() returns a thread-local message.
+ *   - "ns" arguments are per-image strides in floats (so channel slices /
+ *     concat halves of a bigger buffer can be addressed without copies).
+ */
+#ifndef TDR_H
+#define TDR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int tdr_version(void);
+const char* tdr_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32,
+ * exact fp32).  One kernel family serves every dense conv on the path:
+ *   1x1 (NAFBlock conv1/3/4/5, sca)      network_nafnet_guided_arch.py:183-205
+ *   3x3 s1/s2 (+ReLU)  Encoder/ResidualBlock/intro/ending   :44-59,116-129,429-434
+ *   2x2 s2 (downs) / 1x1+PixelShuffle (ups)                 :449-451,468-473
+ *   dilated 3x3 correlation of `search`, 3x3 correlation of `search_org` :495-536
+ * and their data-gradients (same kernel, weights packed transposed/flipped).
+ * out[n,m,oy,ox] = epi( sum_{c,ky,kx} Wp[m,(c,ky,kx)] * B[n,c,oy*s+ky*d-pad,ox*s+kx*d-pad] )
+ *   B = in            (gate=0)
+ *   B = in[c]*in[c+Cin]   (gate=1: SimpleGate fused into the operand load, :170-175)
+ *   B *= kscale[n*kscale_ns + c]       (SCA channel scale / beta / gamma folded in)
+ * epi STD    : v=acc; +bias[n*bias_ns+m]; *scale[n*scale_ns+m]; +bias2_mul*bias2[n*bias2_ns+m];
+ *              +res[n,m,oy,ox]; relu; zero where mask[n,m,oy,ox]<=0
+ * epi GATEBWD: out[m]=acc*aux[m+Cout], out[m+Cout]=acc*aux[m]   (SimpleGate backward)
+ * epi PSHUF  : out[m/4, 2oy+(m%4)/2, 2ox+m%2] = acc (+res there)  (PixelShuffle(2) / stride-2 dgrad)
+ * ------------------------------------------------------------------------- */
+typedef struct TdrConvDesc {
+    int N, Cin, H, W;            /* input tensor (Cin = K-channels actually contracted) */
+    int Cout, OH, OW;            /* GEMM rows and output grid (before PSHUF) */
+    int KH, stride, dil, pad;    /* square kernel, pad = low-side padding */
+    const float* in;  int64_t in_ns;
+    int gate;
+    const float* kscale; int64_t kscale_ns;
+    const float* wp;  int64_t wp_ns;  int Mpad;   /* packed weights, see tdr_pack_weights */
+    float* out; int64_t out_ns;
+    int epi;                     /* 0 STD, 1 GATEBWD, 2 PSHUF */
+    const float* bias;  int64_t bias_ns;
+    const float* scale; int64_t scale_ns;
+    const float* bias2; int64_t bias2_ns; float bias2_mul;
+    const float* res;   int64_t res_ns;
+    const float* mask;  int64_t mask_ns;
+    const float* aux;   int64_t aux_ns;
+    int relu;
+} TdrConvDesc;
+
+int tdr_conv_forward(const TdrConvDesc* d, void* stream);
+
+/* Packed weight layout consumed by tdr_conv_forward:
+ *   Wp[chunk][tap][ck][Mpad],  chunk = c / CK, ck = c % CK, CK = tdr_conv_ck(KH_eff)
+ * mode 0 FWD      : M=Cout, c=ci,  Wp = W[m][c][tap]
+ * mode 1 DGRAD_S1 : M=Cin,  c=co,  Wp = W[c][m][taps-1-tap]        (stride-1 data gradient)
+ * mode 2 DGRAD_2x2S2 : M=4*Cin (m=ci*4+a*2+b), c=co, 1x1: Wp = W[c][ci][a][b]  (use with PSHUF)
+ * mode 3 DGRAD_3x3S2 : M=4*Cin, c=co, 2x2 taps (u,v): W[c][ci][ky(a,u)][kx(b,v)] or 0 (use with PSHUF)
+ * w is the standard contiguous (Cout,Cin,KH,KH) tensor. */
+int tdr_conv_ck(int KH_eff);
+int64_t tdr_packed_weight_floats(int M, int Kch, int KH_eff);
+int tdr_pack_weights(const float* w, int Cout, int Cin, int KH, int mode, float* wp, void* stream);
+/* Per-image "filters" of search / search_org: 3x3 patches cut from LR blocks become GEMM rows.
+ * blk [B][G][C][BH][BW]; M = G*PH*PW rows, m = g*PH*PW + py*PW + px;
+ * Wp[b][c][tap] = blk[b,g,c, py*pstep+ky*dil+off, px*pstep+kx*dil+off]  (3x3 taps, CK=8 layout,
+ * per-image stride = tdr_packed_weight_floats(M, C, 3)). */
+int tdr_pack_patches(const float* blk, int B, int G, int C, int BH, int BW, int PH, int PW, int pstep, int dil,
+                     int off, float* wp, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Weight gradient GEMM (K = pixels) on the fp32 matrix cores.
+ *   G[g][co][ci][tap] = sum_{n in group g} sum_{oy,ox} dout[n,co,oy,ox] * B[n,ci,oy*s+ky-pad,ox*s+kx-pad]
+ * groups = 1 (sum over the batch) or N (per-image, needed by the SCA/beta chain).
+ * Deterministic: split-K partials in `ws` are reduced in fixed order.
+ * ------------------------------------------------------------------------- */
+typedef struct TdrWgradDesc {
+    int N, Cin, H, W, Cout, OH, OW, KH, stride, pad;
+    const float* in;   int64_t in_ns;  int gate;
+    const float* dout; int64_t dout_ns;
+    float* g;          /* [groups][Cout][Cin][KH*KH] */
+    int per_image;
+    float* ws; int64_t ws_floats;      /* split-K workspace */
+} TdrWgradDesc;
+int64_t tdr_wgrad_ws_floats(const TdrWgradDesc* d);
+int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Streaming (HBM-bound) kernels.
+ * ------------------------------------------------------------------------- */
+/* LayerNorm2d fwd/bwd -- models/archs/nafnet_arch_utils.py:264-300.
+ * y = w*(x-mu)*rstd+b ; mu,rstd [N,H*W] saved for backward.
+ * bwd: gx = rstd*(g - yhat*mean_c(g*yhat) - mean_c(g)) (+add), g=go*w;
+ *      gw = sum go*yhat, gb = sum go  (deterministic two-stage; ws >= tdr_ln_ws_floats) */
+int tdr_layernorm2d_fwd(const float* x, int64_t x_ns, const float* w, const float* b, float eps,
+                        int N, int C, int HW, float* y, float* mu, float* rstd, void* stream);
+int64_t tdr_ln_ws_floats(int N, int C, int HW);
+int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns, const float* mu, const float* rstd,
+                        const float* w, const float* add, int64_t add_ns, int add_C,
+                        int N, int C, int HW, float* gx, float* gw, float* gb, float* ws, void* stream);
+
+/* depthwise 3x3 (+bias) + SimpleGate + global-average-pool partials
+ *   network_nafnet_guided_arch.py:185-187,170-175,192-196
+ * t [N,2C,H,W] -> g [N,C,H,W] = dw(t)[:C]*dw(t)[C:],  pooled[N,C] = mean_hw g */
+int64_t tdr_dwsg_ws_floats(int N, int C, int H, int W);
+int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W,
+                 float* g, float* pooled, float* ws, void* stream);
+/* backward: dg [N,C,H,W] -> dt [N,2C,H,W], dw [2C,9], db [2C] */
+int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
+                 float* dt, float* dw, float* db, float* ws, void* stream);
+
+/* SCA 1x1 on the pooled vector: s[n,co] = sum_ci Wsca[co,ci]*pooled[n,ci] + bsca[co] (:192-196) */
+int tdr_sca_fwd(const float* pooled, const float* wsca, const float* bsca, int N, int C, float* s, void* stream);
+/* Per-block parameter-gradient epilogue of the conv3/SCA/beta chain.  Inputs:
+ * G3 [N,C,C] per-image sum_pix dy[co]*g[ci], S3[C]=sum dy.  Outputs dW3,db3,dbeta,
+ * dWsca,dbsca and dpooled[N,C] (to be added /HW to dg). */
+int tdr_sca_bwd(const float* G3, const float* S3, const float* w3, const float* b3, const float* beta,
+                const float* s, const float* pooled, const float* wsca, int N, int C,
+                float* dw3, float* db3, float* dbeta, float* dwsca, float* dbsca, float* dpooled,
+                float* ws /* N*C floats */, void* stream);
+/* conv5/gamma chain: G5 [Cout,C] = sum dout*g2 (unscaled), S5[Cout]:
+ * dW5=gamma*G5, db5=gamma*S5, dgamma=sum_ci W5*G5 + b5*S5 */
+int tdr_scaled_conv_param_grads(const float* G, const float* S, const float* w, const float* b,
+                                const float* gamma, int Cout, int Cin, float* dw, float* db, float* dgamma,
+                                void* stream);
+
+/* per-channel sum over N*HW of x [N,C,HW] (bias gradients); deterministic */
+int64_t tdr_chansum_ws_floats(int N, int C, int HW);
+int tdr_channel_sum(const float* x, int64_t x_ns, int N, int C, int HW, float* out, float* ws, void* stream);
+
+/* strided row copy: dst[n*dst_ns + i] = src[n*src_ns + i], i < len (concat / slice glue, :719,727) */
+int tdr_copy_rows(const float* src, int64_t src_ns, float* dst, int64_t dst_ns, int N, int64_t len, void* stream);
+/* dst += src (same addressing) */
+int tdr_add_rows(const float* src, int64_t src_ns, float* dst, int64_t dst_ns, int N, int64_t len, void* stream);
+/* PixelUnshuffle(2) of a gradient: in [N,C,2H,2W] -> out [N,4C,H,W] */
+int tdr_pixel_unshuffle2(const float* in, int N, int C, int H, int W, float* out, void* stream);
+/* zero-pad / crop: dst[N,C,Hd,Wd] <- src[N,C,Hs,Ws] top-left aligned, zero fill (:576-585,740) */
+int tdr_pad_crop(const float* src, int N, int C, int Hs, int Ws, float* dst, int Hd, int Wd, void* stream);
+
+/* ReLU backward: out = act > 0 ? go : 0 (Encoder/ResidualBlock nn.ReLU, :52,132) */
+int tdr_relu_bwd(const float* go, const float* act, int64_t numel, float* out, void* stream);
+
+/* L1 loss fwd+bwd -- losses/losses.py:11-13,52-53.  loss (1 float) = w*mean|p-t|, dpred = w*sign/numel */
+int tdr_l1_loss(const float* pred, const float* target, int64_t numel, float loss_weight,
+                float* loss, float* dpred, float* ws, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * MASA match-and-transfer (network_nafnet_guided_arch.py:495-707)
+ * ------------------------------------------------------------------------- */
+/* replicate-pad(1) + overlapping block cut (:627-629): feat [N,C,H,W] -> blk [N*py*px, C, ky+2, kx+2] */
+int tdr_lr_blocks_fwd(const float* feat, int N, int C, int H, int W, int py, int px, int ky, int kx,
+                      float* blk, void* stream);
+int tdr_lr_blocks_bwd(const float* dblk, int N, int C, int H, int W, int py, int px, int ky, int kx,
+                      float* dfeat, void* stream);
+/* inverse L2 norms of 3x3 (dilated, zero padded by `pad`) neighbourhood patches over all channels:
+ * inv[b, y, x] = 1/max(||patch||, 1e-12), output grid OHxOW (F.normalize eps, :506-507,529-530) */
+int tdr_patch_inv_norm(const float* x, int B, int C, int H, int W, int OH, int OW, int dil, int pad,
+                       int step, int off, float* inv, void* stream);
+/* coarse arg-max (:534, :635-657): corr_sum[n,p,r] = sum_d dot_d[n,p,r]*invq_d[n,p]*invk_d[n,r];
+ * index = argmax_r; box starts y1,x1 (int32) */
+int tdr_coarse_argmax_box(const float* dots, const float* invq, const float* invk, int ND, int N, int P, int Hr,
+                          int Wr, int diameter, int* index, int* y1, int* x1, void* stream);
+/* gather ref block with python-style negative wrap (:672-678): out [N*P, C, side*s, side*s] */
+int tdr_gather_ref_block(const float* feat, int N, int C, int H, int W, const int* y1, const int* x1, int P,
+                         int side, int s, float* out, void* stream);
+/* fine arg-max (:509-511): corr[b,p,r] = dot*invq[b,p]*invk[b,r] -> index_all[b,p] (int32), soft_att[b,p] */
+int tdr_fine_argmax(const float* dots, const float* invq, const float* invk, int B, int P, int R,
+                    int* index_all, float* soft_att, void* stream);
+/* gradient of soft_att wrt the LR block and the ref block (through F.normalize and the selected dot) */
+int tdr_fine_search_bwd(const float* datt, const float* soft_att, const int* index_all, const float* lrb,
+                        const float* refb, const float* invq, const float* invk, int B, int C, int K, int D,
+                        float* dlrb, float* drefb, void* stream);
+/* fused transfer (:538-555 + :672-678 + :695-707): reads the ref feature map directly
+ * (no block materialisation), writes the re-tiled warped map out [N,C,py*K*s,px*K*s] with n-stride out_ns. */
+int tdr_transfer_fwd(const float* feat, int N, int C, int H, int W, const int* y1, const int* x1,
+                     const int* index_all, const float* soft_att, int py, int px, int K, int side, int s,
+                     float* out, int64_t out_ns, void* stream);
+/* backward: dfeat (accumulated with atomics, caller zeroes) and datt[B,K,K] partial for this scale (+=) */
+int tdr_transfer_bwd(const float* dout, int64_t dout_ns, const float* feat, int N, int C, int H, int W,
+                     const int* y1, const int* x1, const int* index_all, const float* soft_att, int py, int px,
+                     int K, int side, int s, float* dfeat, float* datt, float* ws /* N*OH*OW floats */, void* stream);
+/* scatter-add of the ref-block gradient back into the deepest ref feature (wrap-aware) */
+int tdr_scatter_ref_block(const float* dblk, int N, int C, int H, int W, const int* y1, const int* x1, int P,
+                          int side, float* dfeat, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Optimiser: global-norm clip (max_norm 0.01) + AdamW, multi-tensor
+ *   models/image_restoration_ref_model.py:172-178,276-279
+ * ------------------------------------------------------------------------- */
+/* Work is cut into tdr_optim_chunk()-element chunks by a host-built table:
+ * chunk k covers elements [chunk_index[k]*CHUNK, +CHUNK) of tensor chunk_tensor[k].
+ * grads/params/...: device arrays of n_tensors device pointers; sizes: device int64[n_tensors].
+ * sumsq[0] = sum g^2 over all tensors (double, deterministic two-stage; partial: n_chunks doubles). */
+int tdr_optim_chunk(void);
+int tdr_grad_sumsq(const float* const* grads, const int64_t* sizes, const int* chunk_tensor, const int* chunk_index,
+                   int n_chunks, double* partial, double* sumsq, void* stream);
+/* p,m,v updated in place.  coef = min(1, max_norm/(sqrt(sumsq)+1e-6)) computed on device when
+ * use_clip (torch.nn.utils.clip_grad_norm_); lr = group_lr[group[t]] (host array, <= 4 groups);
+ * torch.optim.AdamW update (decoupled decay, bias correction by `step`). */
+int tdr_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const int64_t* sizes, const int* group, const int* chunk_tensor, const int* chunk_index, int n_chunks,
+                   const double* sumsq, const float* group_lr, int n_groups, float max_norm, int use_clip, float beta1,
+                   float beta2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,153 @@
+"""GPU parity of blocks / encoder / whole NAFNet-ref forward+backward against
+(a) golden vectors produced by the reference itself and (b) the oracle on the
+same seeded inputs.  Path target: 1e-4 max-abs on fp32 outputs (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nafnet_ref_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def E():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import engine
+    return engine
+
+
+def gold(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def cuda_params(P):
+    return {k: v.detach().cuda().contiguous() for k, v in P.items()}
+
+
+def test_nafblock_vs_reference_golden(E):
+    g = gold('per_op')
+    P = {str(k): T(g['naf_p_' + str(k)]) for k in g['naf_names']}
+    out, saved = E.naf_fwd(T(g['naf_x']).cuda(), cuda_params(P))
+    assert maxdiff(out, T(g['naf_y'])) < 5e-5
+    dx, G = E.naf_bwd(T(g['naf_go']).cuda(), cuda_params(P), saved)
+    assert maxdiff(dx, T(g['naf_gx'])) < 5e-5
+    for k in P:
+        ref = T(g['naf_g_' + k])
+        assert maxdiff(G[k].view_as(ref), ref) < 1e-4 * max(1.0, ref.abs().max().item()), k
+
+
+def test_nafblock_sliced_output_matches_oracle(E):
+    """last fusion block: only the first c/2 output channels are kept (:719)."""
+    c, N, H, W = 32, 2, 16, 24
+    cfgP = {k[len('b.'):]: v for k, v in O.synth_params(O.default_cfg(), seed=9).items() if False}
+    g = torch.Generator().manual_seed(5)
+    shapes = dict(beta=(1, c, 1, 1), gamma=(1, c, 1, 1))
+    P = {}
+    for name, shp in [('beta', (1, c, 1, 1)), ('gamma', (1, c, 1, 1)), ('conv1.weight', (2 * c, c, 1, 1)), ('conv1.bias', (2 * c,)),
+                      ('conv2.weight', (2 * c, 1, 3, 3)), ('conv2.bias', (2 * c,)), ('conv3.weight', (c, c, 1, 1)),
+                      ('conv3.bias', (c,)), ('sca.1.weight', (c, c, 1, 1)), ('sca.1.bias', (c,)),
+                      ('conv4.weight', (2 * c, c, 1, 1)), ('conv4.bias', (2 * c,)), ('conv5.weight', (c, c, 1, 1)),
+                      ('conv5.bias', (c,)), ('norm1.weight', (c,)), ('norm1.bias', (c,)), ('norm2.weight', (c,)),
+                      ('norm2.bias', (c,))]:
+        P[name] = (torch.randn(shp, generator=g) * 0.2 + (1.0 if name.endswith('norm1.weight') or name.endswith('norm2.weight') else 0.0))
+    x = torch.randn(N, c, H, W, generator=g)
+    go = torch.randn(N, c // 2, H, W, generator=g)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.naf_block(xr, Pr, '')[:, :c // 2]
+    ref.backward(go)
+    out, saved = E.naf_fwd(x.cuda(), cuda_params(P), c_out=c // 2)
+    assert maxdiff(out, ref) < 5e-5
+    dx, G = E.naf_bwd(go.cuda(), cuda_params(P), saved)
+    assert maxdiff(dx, xr.grad) < 5e-5
+    for k in P:
+        r = Pr[k].grad
+        assert maxdiff(G[k].view_as(r), r) < 1e-4 * max(1.0, r.abs().max().item()), k
+
+
+def test_masa_encoder_vs_reference_golden(E):
+    g = gold('per_op')
+    P = {str(k): T(g['enc_p_' + str(k)]) for k in g['enc_names']}
+    Pc = cuda_params(P)
+    feats, saved = E.encoder_fwd(T(g['enc_x']).cuda(), Pc, '', [1, 1, 1, 1])
+    for i, f in enumerate(feats):
+        assert maxdiff(f, T(g[f'enc_f{i}'])) < 3e-5
+    # loss = sum_i (i+1) * mean(f_i^2)  ->  df_i = 2 (i+1) f_i / numel
+    dfe = [(2.0 * (i + 1) / f.numel()) * f for i, f in enumerate(feats)]
+    G = {}
+    E.encoder_bwd(dfe, Pc, '', [1, 1, 1, 1], saved, G)
+    for k in P:
+        ref = T(g['enc_g_' + k])
+        assert maxdiff(G[k].view_as(ref), ref) < 3e-5 * max(1.0, ref.abs().max().item()), k
+
+
+CASES = [('net_w8_128_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+         ('net_w8_256_b2', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+         ('net_w8_120x100_pad', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+         ('net_cfg1_w16_128', dict(width=16, nf=16, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2]))]
+
+
+@pytest.mark.parametrize('name,kw', CASES)
+def test_whole_net_vs_reference_golden(E, name, kw):
+    from textualdegremoval_amd import kernels as K
+    g = gold(name)
+    cfg = O.default_cfg(**kw)
+    seed = int(g['seed'])
+    P = O.synth_params(cfg, seed=seed)
+    Pc = cuda_params(P)
+    lq, gt, ref = O.synth_pair(int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), seed=1234 + seed)
+    out, saved = E.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
+    sv_masa = saved[6]
+    index, index_all, soft_att = sv_masa[4], sv_masa[7], sv_masa[8]
+    gi = g['index'][..., 0] if g['index'].ndim == 3 else g['index']
+    assert np.array_equal(index.cpu().numpy().reshape(gi.shape), gi)
+    ia = index_all.cpu().numpy().reshape(g['index_all'].shape)
+    agree = (ia == g['index_all']).mean()
+    assert agree == 1.0, f'fine-search index agreement {agree}'
+    assert maxdiff(soft_att.view(-1), T(g['soft_att']).reshape(-1)) < 1e-5
+    assert maxdiff(out, T(g['out'])) < 1e-4
+    loss, dpred = K.l1_loss(out.contiguous(), gt.cuda().contiguous())
+    assert abs(loss.item() - float(g['loss'])) < 2e-6
+    G = E.net_bwd(dpred, Pc, cfg, saved)
+    assert set(G.keys()) == set(P.keys())
+    gn = np.array([G[k].double().norm().item() for k in P])
+    assert np.allclose(gn, g['grad_norm'], rtol=5e-3, atol=5e-6), np.abs(gn - g['grad_norm']).max()
+    tot = np.sqrt((gn ** 2).sum())
+    assert abs(tot - float(g['total_grad_norm'])) < 2e-4 * float(g['total_grad_norm'])
+    # element samples of every gradient (same strided sampling as make_golden.sample)
+    for i, k in enumerate(P):
+        f = G[k].reshape(-1)
+        step = max(1, f.numel() // 8)
+        s = f[::step][:8].cpu().numpy()
+        ref_s = g['grad_sample'][i][:len(s)]
+        assert np.allclose(s, ref_s, rtol=2e-3, atol=2e-6 + 2e-4 * np.abs(g['grad_sample'][i]).max()), k
+
+
+def test_module_surface_forward_backward_and_state_dict(E):
+    """nn.Module surface: load a reference-keyed state dict, forward(inp, ref), autograd backward."""
+    from textualdegremoval_amd.models.archs import define_network
+    g = gold('net_w8_128_wrap')
+    kw = dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
+    cfg = O.default_cfg(**kw)
+    net = define_network(dict(type='NAFNetRefFusion', enc_blk_nums=[1, 1, 1, 1], dec_blk_nums=[1, 1, 1, 1], **kw))
+    net.load_state_dict(O.synth_params(cfg, seed=int(g['seed'])), strict=True)
+    net = net.cuda()
+    lq, gt, ref = O.synth_pair(1, 128, 128, seed=1234 + int(g['seed']))
+    out = net(lq.cuda(), ref.cuda())
+    assert maxdiff(out, T(g['out'])) < 1e-4
+    (out - gt.cuda()).abs().mean().backward()
+    gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
+    assert np.allclose(gn, g['grad_norm'], rtol=5e-3, atol=5e-6)

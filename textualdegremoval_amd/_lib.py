@@ -1,0 +1,122 @@
+"""ctypes binding of libtdr_hip.so (the C ABI declared in include/tdr.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, this module raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C textualdegremoval_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtdr_hip.so')
+
+c_fp = C.c_void_p      # device pointers travel as integers
+i32, i64, f32 = C.c_int, C.c_int64, C.c_float
+
+
+class TdrConvDesc(C.Structure):
+    _fields_ = [
+        ('N', i32), ('Cin', i32), ('H', i32), ('W', i32),
+        ('Cout', i32), ('OH', i32), ('OW', i32),
+        ('KH', i32), ('stride', i32), ('dil', i32), ('pad', i32),
+        ('inp', c_fp), ('in_ns', i64),
+        ('gate', i32),
+        ('kscale', c_fp), ('kscale_ns', i64),
+        ('wp', c_fp), ('wp_ns', i64), ('Mpad', i32),
+        ('out', c_fp), ('out_ns', i64),
+        ('epi', i32),
+        ('bias', c_fp), ('bias_ns', i64),
+        ('scale', c_fp), ('scale_ns', i64),
+        ('bias2', c_fp), ('bias2_ns', i64), ('bias2_mul', f32),
+        ('res', c_fp), ('res_ns', i64),
+        ('mask', c_fp), ('mask_ns', i64),
+        ('aux', c_fp), ('aux_ns', i64),
+        ('relu', i32),
+    ]
+
+
+class TdrWgradDesc(C.Structure):
+    _fields_ = [
+        ('N', i32), ('Cin', i32), ('H', i32), ('W', i32), ('Cout', i32), ('OH', i32), ('OW', i32),
+        ('KH', i32), ('stride', i32), ('pad', i32),
+        ('inp', c_fp), ('in_ns', i64), ('gate', i32),
+        ('dout', c_fp), ('dout_ns', i64),
+        ('g', c_fp),
+        ('per_image', i32),
+        ('ws', c_fp), ('ws_floats', i64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/tdr.h declares
+SIGNATURES = {
+    'tdr_version': (i32, []),
+    'tdr_last_error': (C.c_char_p, []),
+    'tdr_conv_forward': (i32, [C.POINTER(TdrConvDesc), c_fp]),
+    'tdr_conv_ck': (i32, [i32]),
+    'tdr_packed_weight_floats': (i64, [i32, i32, i32]),
+    'tdr_pack_weights': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_pack_patches': (i32, [c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_wgrad_ws_floats': (i64, [C.POINTER(TdrWgradDesc)]),
+    'tdr_conv_wgrad': (i32, [C.POINTER(TdrWgradDesc), c_fp]),
+    'tdr_layernorm2d_fwd': (i32, [c_fp, i64, c_fp, c_fp, f32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_ln_ws_floats': (i64, [i32, i32, i32]),
+    'tdr_layernorm2d_bwd': (i32, [c_fp, c_fp, i64, c_fp, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp,
+                                  c_fp, c_fp]),
+    'tdr_dwsg_ws_floats': (i64, [i32, i32, i32, i32]),
+    'tdr_dwsg_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_dwsg_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_sca_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, c_fp, c_fp]),
+    'tdr_sca_bwd': (i32, [c_fp] * 8 + [i32, i32] + [c_fp] * 7 + [c_fp]),
+    'tdr_scaled_conv_param_grads': (i32, [c_fp] * 5 + [i32, i32] + [c_fp] * 3 + [c_fp]),
+    'tdr_chansum_ws_floats': (i64, [i32, i32, i32]),
+    'tdr_channel_sum': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_copy_rows': (i32, [c_fp, i64, c_fp, i64, i32, i64, c_fp]),
+    'tdr_add_rows': (i32, [c_fp, i64, c_fp, i64, i32, i64, c_fp]),
+    'tdr_pixel_unshuffle2': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_pad_crop': (i32, [c_fp, i32, i32, i32, i32, c_fp, i32, i32, c_fp]),
+    'tdr_relu_bwd': (i32, [c_fp, c_fp, i64, c_fp, c_fp]),
+    'tdr_l1_loss': (i32, [c_fp, c_fp, i64, f32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_lr_blocks_fwd': (i32, [c_fp] + [i32] * 8 + [c_fp, c_fp]),
+    'tdr_lr_blocks_bwd': (i32, [c_fp] + [i32] * 8 + [c_fp, c_fp]),
+    'tdr_patch_inv_norm': (i32, [c_fp] + [i32] * 10 + [c_fp, c_fp]),
+    'tdr_coarse_argmax_box': (i32, [c_fp, c_fp, c_fp] + [i32] * 6 + [c_fp, c_fp, c_fp, c_fp]),
+    'tdr_gather_ref_block': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp, i32, i32, i32, c_fp, c_fp]),
+    'tdr_scatter_ref_block': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp, i32, i32, c_fp, c_fp]),
+    'tdr_fine_argmax': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_fine_search_bwd': (i32, [c_fp] * 7 + [i32] * 4 + [c_fp, c_fp, c_fp]),
+    'tdr_transfer_fwd': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
+    'tdr_transfer_bwd': (i32, [c_fp, i64, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32,
+                               c_fp, c_fp, c_fp, c_fp]),
+    'tdr_optim_chunk': (i32, []),
+    'tdr_grad_sumsq': (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp]),
+    'tdr_adamw_step': (i32, [c_fp] * 8 + [i32, c_fp, C.POINTER(f32), i32, f32, i32, f32, f32, f32, f32, i32, c_fp]),
+}
+
+_lib = None
+
+
+class TdrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtdr_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TdrError(f'{LIB_PATH} is missing: build it first (python -c "import __graft_entry__ as g; g.build()"). '
+                       'There is no CPU fallback on the product path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().tdr_last_error().decode('utf-8', 'replace')
+        raise TdrError(f'{what} failed (code {rc}): {msg}')

@@ -1,0 +1,113 @@
+// Global-norm gradient clip + AdamW as two multi-tensor kernels
+// (models/image_restoration_ref_model.py:172-178, 276-279: AdamW with the
+// "masa" LR split, clip_grad_norm_(params, 0.01)).
+// Tensors are addressed through device pointer tables; work is cut into
+// CHUNK-element pieces by a host-built (tensor, chunk) table, so one launch
+// covers all ~900 parameter tensors.  The norm is accumulated in double with a
+// fixed two-stage order (deterministic).
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+namespace {
+constexpr int CHUNK = 4096;   // elements per chunk (must match tdr_optim_chunk())
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* const* __restrict__ grads, const int64_t* __restrict__ sizes,
+                                                   const int* __restrict__ chunk_tensor, const int* __restrict__ chunk_index,
+                                                   double* __restrict__ partial) {
+    __shared__ double red[4];
+    const int t = chunk_tensor[blockIdx.x];
+    const long base = (long)chunk_index[blockIdx.x] * CHUNK;
+    const long n = sizes[t];
+    const float* g = grads[t];
+    double s = 0.0;
+    for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) {
+        const float v = g[i];
+        s += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+struct AdamArgs {
+    float lr[4];
+    float max_norm, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;
+    int use_clip;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ params, const float* const* __restrict__ grads,
+                                                   float* const* __restrict__ exp_avg, float* const* __restrict__ exp_avg_sq,
+                                                   const int64_t* __restrict__ sizes, const int* __restrict__ group,
+                                                   const int* __restrict__ chunk_tensor, const int* __restrict__ chunk_index,
+                                                   const double* __restrict__ sumsq, AdamArgs a) {
+    const int t = chunk_tensor[blockIdx.x];
+    const long base = (long)chunk_index[blockIdx.x] * CHUNK;
+    const long n = sizes[t];
+    float* p = params[t];
+    const float* g = grads[t];
+    float* m = exp_avg[t];
+    float* v = exp_avg_sq[t];
+    const float lr = a.lr[group[t]];
+    float coef = 1.f;
+    if (a.use_clip) {
+        const float total = (float)sqrt(sumsq[0]);
+        coef = fminf(a.max_norm / (total + 1e-6f), 1.f);
+    }
+    const float step = lr / a.bc1;
+    for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) {
+        const float gv = g[i] * coef;
+        float pv = p[i] * (1.f - lr * a.weight_decay);
+        const float mv = m[i] + (1.f - a.beta1) * (gv - m[i]);            // lerp, as torch.optim
+        const float vv = a.beta2 * v[i] + (1.f - a.beta2) * gv * gv;
+        const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
+        pv -= step * (mv / denom);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+}  // namespace
+
+extern "C" int tdr_optim_chunk(void) { return CHUNK; }
+
+extern "C" int tdr_grad_sumsq(const float* const* grads, const int64_t* sizes, const int* chunk_tensor, const int* chunk_index,
+                              int n_chunks, double* partial, double* sumsq, void* stream) {
+    TDR_REQUIRE(grads && sizes && chunk_tensor && chunk_index && partial && sumsq && n_chunks > 0, "tdr_grad_sumsq: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, grads, sizes, chunk_tensor, chunk_index, partial);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, st, partial, n_chunks, sumsq);
+    TDR_LAUNCH_CHECK("grad_sumsq");
+    return TDR_OK;
+}
+
+extern "C" int tdr_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                              const int64_t* sizes, const int* group, const int* chunk_tensor, const int* chunk_index,
+                              int n_chunks, const double* sumsq, const float* group_lr, int n_groups, float max_norm,
+                              int use_clip, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    TDR_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes && group && chunk_tensor && chunk_index && sumsq && group_lr,
+                "tdr_adamw_step: null pointer");
+    TDR_REQUIRE(n_groups >= 1 && n_groups <= 4 && step >= 1, "tdr_adamw_step: n_groups in 1..4 and step >= 1");
+    AdamArgs a;
+    for (int i = 0; i < 4; ++i) a.lr[i] = i < n_groups ? group_lr[i] : 0.f;
+    a.max_norm = max_norm; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    a.use_clip = use_clip;
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes,
+                       group, chunk_tensor, chunk_index, sumsq, a);
+    TDR_LAUNCH_CHECK("adamw_step");
+    return TDR_OK;
+}

@@ -1,0 +1,800 @@
+// HBM-bound streaming kernels of the NAFNet-ref train step (gfx950).
+// All tensors fp32 NCHW; lanes run along W/HW so every wave-instruction touches
+// contiguous 256-B segments.  Reductions are two-stage with fixed order
+// (deterministic, no float atomics).
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+namespace {
+
+// ===========================================================================
+// LayerNorm2d  (models/archs/nafnet_arch_utils.py:264-300)
+// block = 64 pixels x SLICES channel slices; thread keeps its CPT channels in
+// registers (two-pass variance like the reference: mean first, then (x-mu)^2).
+// ===========================================================================
+template <int SLICES, int CPT>
+__global__ __launch_bounds__(64 * SLICES) void ln_fwd_kernel(const float* __restrict__ x, long x_ns,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float eps, int C, int HW, float* __restrict__ y,
+                                                            float* __restrict__ mu, float* __restrict__ rstd) {
+    __shared__ float red[SLICES][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
+    const bool pok = px < HW;
+    const float* xn = x + (long)n * x_ns + px;
+    float v[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + SLICES * i;
+        v[i] = (pok && c < C) ? xn[(long)c * HW] : 0.f;
+        s += v[i];
+    }
+    red[slice][lane] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < SLICES; ++k) tot += red[k][lane];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + SLICES * i;
+        const float d = v[i] - mean;
+        if (c < C) q += d * d;
+    }
+    red[slice][lane] = q;
+    __syncthreads();
+    float vt = 0.f;
+#pragma unroll
+    for (int k = 0; k < SLICES; ++k) vt += red[k][lane];
+    const float rs = 1.0f / sqrtf(vt / (float)C + eps);
+    if (!pok) return;
+    float* yn = y + ((long)n * C) * HW + px;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + SLICES * i;
+        if (c < C) yn[(long)c * HW] = (v[i] - mean) * rs * w[c] + b[c];
+    }
+    if (slice == 0) {
+        mu[(long)n * HW + px] = mean;
+        rstd[(long)n * HW + px] = rs;
+    }
+}
+
+// any C: re-reads x (L2-resident for the small deep maps this serves)
+__global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __restrict__ x, long x_ns,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float eps, int C, int HW, float* __restrict__ y,
+                                                            float* __restrict__ mu, float* __restrict__ rstd) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
+    const bool pok = px < HW;
+    const float* xn = x + (long)n * x_ns + px;
+    float s = 0.f;
+    for (int c = slice; c < C; c += 4) s += pok ? xn[(long)c * HW] : 0.f;
+    red[slice][lane] = s;
+    __syncthreads();
+    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = slice; c < C; c += 4) {
+        const float d = (pok ? xn[(long)c * HW] : 0.f) - mean;
+        q += d * d;
+    }
+    red[slice][lane] = q;
+    __syncthreads();
+    const float rs = 1.0f / sqrtf((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C + eps);
+    if (!pok) return;
+    float* yn = y + ((long)n * C) * HW + px;
+    for (int c = slice; c < C; c += 4) yn[(long)c * HW] = (xn[(long)c * HW] - mean) * rs * w[c] + b[c];
+    if (slice == 0) {
+        mu[(long)n * HW + px] = mean;
+        rstd[(long)n * HW + px] = rs;
+    }
+}
+
+// backward, register path.  grid.x blocks walk pixel tiles (n, 64 px); per-channel
+// sum(go*yhat), sum(go) are kept in registers and reduced across lanes once.
+template <int SLICES, int CPT>
+__global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
+    const float* __restrict__ go, const float* __restrict__ x, long x_ns, const float* __restrict__ mu,
+    const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ add, long add_ns, int add_C,
+    int N, int C, int HW, float* __restrict__ gx, float* __restrict__ part /*[grid][2][C]*/) {
+    __shared__ float red[2][SLICES][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int tiles = (HW + 63) / 64;
+    float aw[CPT], ab[CPT], wv[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        aw[i] = 0.f; ab[i] = 0.f;
+        const int c = slice + SLICES * i;
+        wv[i] = c < C ? w[c] : 0.f;
+    }
+    for (int t = blockIdx.x; t < N * tiles; t += gridDim.x) {
+        const int n = t / tiles, px = (t % tiles) * 64 + lane;
+        const bool pok = px < HW;
+        const float m = pok ? mu[(long)n * HW + px] : 0.f, rs = pok ? rstd[(long)n * HW + px] : 0.f;
+        float yh[CPT], g[CPT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = slice + SLICES * i;
+            const bool ok = pok && c < C;
+            const float xv = ok ? x[(long)n * x_ns + (long)c * HW + px] : 0.f;
+            const float g0 = ok ? go[((long)n * C + c) * HW + px] : 0.f;
+            yh[i] = ok ? (xv - m) * rs : 0.f;
+            g[i] = g0 * wv[i];
+            s1 += g[i];
+            s2 += g[i] * yh[i];
+            aw[i] += g0 * yh[i];
+            ab[i] += g0;
+        }
+        red[0][slice][lane] = s1;
+        red[1][slice][lane] = s2;
+        __syncthreads();
+        float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SLICES; ++k) { S1 += red[0][k][lane]; S2 += red[1][k][lane]; }
+        __syncthreads();
+        const float mg = S1 / (float)C, mgy = S2 / (float)C;
+        if (pok) {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int c = slice + SLICES * i;
+                if (c < C) {
+                    float v = rs * (g[i] - yh[i] * mgy - mg);
+                    if (add && c < add_C) v += add[(long)n * add_ns + (long)c * HW + px];
+                    gx[((long)n * C + c) * HW + px] = v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + SLICES * i;
+        const float sw = wave_sum(aw[i]), sb = wave_sum(ab[i]);
+        if (lane == 0 && c < C) {
+            part[((long)blockIdx.x * 2 + 0) * C + c] = sw;
+            part[((long)blockIdx.x * 2 + 1) * C + c] = sb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_generic_kernel(
+    const float* __restrict__ go, const float* __restrict__ x, long x_ns, const float* __restrict__ mu,
+    const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ add, long add_ns, int add_C,
+    int C, int HW, float* __restrict__ gx) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
+    const bool pok = px < HW;
+    const float m = pok ? mu[(long)n * HW + px] : 0.f, rs = pok ? rstd[(long)n * HW + px] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = slice; c < C; c += 4) {
+        if (pok) {
+            const float g = go[((long)n * C + c) * HW + px] * w[c];
+            const float yh = (x[(long)n * x_ns + (long)c * HW + px] - m) * rs;
+            s1 += g; s2 += g * yh;
+        }
+    }
+    red[0][slice][lane] = s1; red[1][slice][lane] = s2;
+    __syncthreads();
+    const float mg = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
+    const float mgy = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
+    if (!pok) return;
+    for (int c = slice; c < C; c += 4) {
+        const float g = go[((long)n * C + c) * HW + px] * w[c];
+        const float yh = (x[(long)n * x_ns + (long)c * HW + px] - m) * rs;
+        float v = rs * (g - yh * mgy - mg);
+        if (add && c < add_C) v += add[(long)n * add_ns + (long)c * HW + px];
+        gx[((long)n * C + c) * HW + px] = v;
+    }
+}
+
+// generic path parameter grads: block (c, split) walks channel c's pixels; part[split][2][C]
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ go, const float* __restrict__ x,
+                                                           long x_ns, const float* __restrict__ mu,
+                                                           const float* __restrict__ rstd, int N, int C, int HW,
+                                                           float* __restrict__ part) {
+    __shared__ float red[2][4];
+    const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const long total = (long)N * HW;
+    float sw = 0.f, sb = 0.f;
+    for (long i = (long)split * 256 + threadIdx.x; i < total; i += (long)nsplit * 256) {
+        const int n = (int)(i / HW), px = (int)(i % HW);
+        const float g0 = go[((long)n * C + c) * HW + px];
+        const float yh = (x[(long)n * x_ns + (long)c * HW + px] - mu[i]) * rstd[i];
+        sw += g0 * yh; sb += g0;
+    }
+    sw = wave_sum(sw); sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sw; red[1][threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((long)split * 2 + 0) * C + c] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[((long)split * 2 + 1) * C + c] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+// out0[c] = sum_k part[k][0][c], out1[c] = sum_k part[k][1][c]
+__global__ void pair_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ o0,
+                                   float* __restrict__ o1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nparts; ++k) {
+        a += part[((long)k * 2 + 0) * C + c];
+        b += part[((long)k * 2 + 1) * C + c];
+    }
+    o0[c] = a; o1[c] = b;
+}
+
+constexpr int LN_BWD_GRID = 1024;
+constexpr int LN_GEN_SPLITS = 16;
+
+// ===========================================================================
+// depthwise 3x3 + bias + SimpleGate (+ pool partials)
+//   network_nafnet_guided_arch.py:185-187, 170-175, 192-196
+// block = (band of BR rows, channel c, image n); thread = 4 consecutive x.
+// ===========================================================================
+__device__ __forceinline__ void load_row6(const float* __restrict__ row, int x0, int W, bool rok, float (&r)[6]) {
+    if (!rok) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = 0.f;
+        return;
+    }
+    const float4 m = *reinterpret_cast<const float4*>(row + x0);
+    r[0] = x0 > 0 ? row[x0 - 1] : 0.f;
+    r[1] = m.x; r[2] = m.y; r[3] = m.z; r[4] = m.w;
+    r[5] = x0 + 4 < W ? row[x0 + 4] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void dwsg_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w,
+                                                      const float* __restrict__ b, int C, int H, int W, int BR,
+                                                      float* __restrict__ g, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int band = blockIdx.x, c = blockIdx.y, n = blockIdx.z, nb = gridDim.x;
+    const long HW = (long)H * W;
+    const float* t1 = t + ((long)n * 2 * C + c) * HW;
+    const float* t2 = t1 + (long)C * HW;
+    float w1[9], w2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w1[i] = w[c * 9 + i]; w2[i] = w[(c + C) * 9 + i]; }
+    const float b1 = b[c], b2 = b[c + C];
+    const int W4 = W >> 2;
+    const int y0 = band * BR, y1 = min(y0 + BR, H);
+    float psum = 0.f;
+    for (int idx = threadIdx.x; idx < (y1 - y0) * W4; idx += 256) {
+        const int y = y0 + idx / W4, x0 = (idx % W4) * 4;
+        float o1[4] = {b1, b1, b1, b1}, o2[4] = {b2, b2, b2, b2};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            const bool rok = yy >= 0 && yy < H;
+            float r1[6], r2[6];
+            load_row6(t1 + (long)yy * W, x0, W, rok, r1);
+            load_row6(t2 + (long)yy * W, x0, W, rok, r2);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o1[i] += w1[ky * 3 + kx] * r1[i + kx];
+                    o2[i] += w2[ky * 3 + kx] * r2[i + kx];
+                }
+        }
+        const float4 o = make_float4(o1[0] * o2[0], o1[1] * o2[1], o1[2] * o2[2], o1[3] * o2[3]);
+        *reinterpret_cast<float4*>(g + ((long)n * C + c) * HW + (long)y * W + x0) = o;
+        psum += (o.x + o.y) + (o.z + o.w);
+    }
+    psum = wave_sum(psum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = psum;
+    __syncthreads();
+    if (threadIdx.x == 0) part[((long)n * C + c) * nb + band] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void pool_finish_kernel(const float* __restrict__ part, int NC, int nb, float inv_hw,
+                                   float* __restrict__ pooled) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    float s = 0.f;
+    for (int k = 0; k < nb; ++k) s += part[(long)i * nb + k];
+    pooled[i] = s * inv_hw;
+}
+
+// backward: LDS tile.  Output tile TBY x 32; du needs a 1-halo, t a 2-halo.
+constexpr int TBX = 32, TBY = 16;
+__global__ __launch_bounds__(256) void dwsg_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ t,
+                                                      const float* __restrict__ w, const float* __restrict__ b, int C,
+                                                      int H, int W, int tiles_x, int tiles_per_group, int ntiles,
+                                                      float* __restrict__ dt, float* __restrict__ part /*[N][C][groups][20]*/) {
+    constexpr int TW2 = TBX + 4, TH2 = TBY + 4;     // t tile (2-halo)
+    constexpr int TW1 = TBX + 2, TH1 = TBY + 2;     // du tile (1-halo)
+    __shared__ float st1[TH2][TW2 + 1], st2[TH2][TW2 + 1];
+    __shared__ float sd1[TH1][TW1 + 1], sd2[TH1][TW1 + 1];
+    __shared__ float red[4][20];
+    const int grp = blockIdx.x, c = blockIdx.y, n = blockIdx.z, ngrp = gridDim.x;
+    const long HW = (long)H * W;
+    const float* t1 = t + ((long)n * 2 * C + c) * HW;
+    const float* t2 = t1 + (long)C * HW;
+    const float* dgp = dg + ((long)n * C + c) * HW;
+    float w1[9], w2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w1[i] = w[c * 9 + i]; w2[i] = w[(c + C) * 9 + i]; }
+    const float b1 = b[c], b2 = b[c + C];
+    float acc[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) acc[i] = 0.f;
+    const int tl0 = grp * tiles_per_group, tl1 = min(tl0 + tiles_per_group, ntiles);
+    for (int tl = tl0; tl < tl1; ++tl) {
+        const int ty0 = (tl / tiles_x) * TBY, tx0 = (tl % tiles_x) * TBX;
+        __syncthreads();
+        for (int i = threadIdx.x; i < TH2 * TW2; i += 256) {
+            const int r = i / TW2, q = i % TW2;
+            const int y = ty0 + r - 2, x = tx0 + q - 2;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            st1[r][q] = ok ? t1[(long)y * W + x] : 0.f;
+            st2[r][q] = ok ? t2[(long)y * W + x] : 0.f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TH1 * TW1; i += 256) {
+            const int r = i / TW1, q = i % TW1;
+            const int y = ty0 + r - 1, x = tx0 + q - 1;
+            float d1 = 0.f, d2 = 0.f;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                float u1 = b1, u2 = b2;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    u1 += w1[k] * st1[r + k / 3][q + k % 3];
+                    u2 += w2[k] * st2[r + k / 3][q + k % 3];
+                }
+                const float gv = dgp[(long)y * W + x];
+                d1 = gv * u2; d2 = gv * u1;
+                const bool interior = r >= 1 && r <= TBY && q >= 1 && q <= TBX;
+                if (interior) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        acc[k] += d1 * st1[r + k / 3][q + k % 3];
+                        acc[10 + k] += d2 * st2[r + k / 3][q + k % 3];
+                    }
+                    acc[9] += d1; acc[19] += d2;
+                }
+            }
+            sd1[r][q] = d1; sd2[r][q] = d2;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TBY * TBX; i += 256) {
+            const int r = i / TBX, q = i % TBX;
+            const int y = ty0 + r, x = tx0 + q;
+            if (y < H && x < W) {
+                float o1 = 0.f, o2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {       // dt[y][x] = sum_k w[k] * du[y - ky + 1][x - kx + 1]
+                    o1 += w1[k] * sd1[r + 2 - k / 3][q + 2 - k % 3];
+                    o2 += w2[k] * sd2[r + 2 - k / 3][q + 2 - k % 3];
+                }
+                dt[((long)n * 2 * C + c) * HW + (long)y * W + x] = o1;
+                dt[((long)n * 2 * C + c + C) * HW + (long)y * W + x] = o2;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        const float s = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 20)
+        part[(((long)n * C + c) * ngrp + grp) * 20 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dw[ch][9], db[ch] from part[N][C][groups][20]  (ch<C -> first half, ch>=C -> second)
+__global__ void dwsg_param_finish_kernel(const float* __restrict__ part, int N, int C, int ngrp,
+                                         float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over C*20
+    if (i >= C * 20) return;
+    const int c = i / 20, k = i % 20;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n)
+        for (int g = 0; g < ngrp; ++g) s += part[(((long)n * C + c) * ngrp + g) * 20 + k];
+    const int ch = k < 10 ? c : c + C, kk = k % 10;
+    if (kk < 9) dw[ch * 9 + kk] = s; else db[ch] = s;
+}
+
+// ===========================================================================
+// SCA 1x1 on pooled vectors and the tiny parameter-gradient chains
+// ===========================================================================
+__global__ __launch_bounds__(256) void sca_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ wsca,
+                                                     const float* __restrict__ bsca, int C, float* __restrict__ s) {
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y, lane = threadIdx.x & 63;
+    if (co >= C) return;
+    float a = 0.f;
+    for (int ci = lane; ci < C; ci += 64) a += wsca[(long)co * C + ci] * pooled[(long)n * C + ci];
+    a = wave_sum(a);
+    if (lane == 0) s[(long)n * C + co] = a + bsca[co];
+}
+
+// one block per co row: dW3 row, db3, dbeta
+__global__ __launch_bounds__(256) void sca_bwd_rows_kernel(const float* __restrict__ G3, const float* __restrict__ S3,
+                                                          const float* __restrict__ w3, const float* __restrict__ b3,
+                                                          const float* __restrict__ beta, const float* __restrict__ s,
+                                                          int N, int C, float* __restrict__ dw3, float* __restrict__ db3,
+                                                          float* __restrict__ dbeta) {
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    const float bt = beta[co];
+    float acc = 0.f;
+    for (int ci = threadIdx.x; ci < C; ci += 256) {
+        float sg = 0.f;
+        for (int n = 0; n < N; ++n) sg += s[(long)n * C + ci] * G3[((long)n * C + co) * C + ci];
+        dw3[(long)co * C + ci] = bt * sg;
+        acc += w3[(long)co * C + ci] * sg;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        db3[co] = bt * S3[co];
+        dbeta[co] = tot + b3[co] * S3[co];
+    }
+}
+
+// ds[n][ci] = sum_co beta[co] W3[co][ci] G3[n][co][ci]; thread per (n,ci)
+__global__ void sca_bwd_ds_kernel(const float* __restrict__ G3, const float* __restrict__ w3,
+                                  const float* __restrict__ beta, int N, int C, float* __restrict__ ds) {
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (ci >= C) return;
+    float a = 0.f;
+    for (int co = 0; co < C; ++co) a += beta[co] * w3[(long)co * C + ci] * G3[((long)n * C + co) * C + ci];
+    ds[(long)n * C + ci] = a;
+}
+
+// dpooled[n][cj] = sum_ci Wsca[ci][cj] ds[n][ci];  dWsca[ci][cj] = sum_n ds[n][ci] pooled[n][cj]; dbsca[ci] = sum_n ds
+__global__ void sca_bwd_tail_kernel(const float* __restrict__ ds, const float* __restrict__ pooled,
+                                    const float* __restrict__ wsca, int N, int C, float* __restrict__ dwsca,
+                                    float* __restrict__ dbsca, float* __restrict__ dpooled) {
+    const int cj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cj >= C) return;
+    const int ci_row = blockIdx.y;                 // rows of dWsca handled by grid.y
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += ds[(long)n * C + ci_row] * pooled[(long)n * C + cj];
+    dwsca[(long)ci_row * C + cj] = a;
+    if (ci_row == 0) {
+        for (int n = 0; n < N; ++n) {
+            float p = 0.f;
+            for (int ci = 0; ci < C; ++ci) p += wsca[(long)ci * C + cj] * ds[(long)n * C + ci];
+            dpooled[(long)n * C + cj] = p;
+        }
+        float sb = 0.f;
+        for (int n = 0; n < N; ++n) sb += ds[(long)n * C + cj];
+        dbsca[cj] = sb;
+    }
+}
+
+__global__ __launch_bounds__(256) void scaled_conv_param_kernel(const float* __restrict__ G, const float* __restrict__ S,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               const float* __restrict__ gamma, int Cin,
+                                                               float* __restrict__ dw, float* __restrict__ db,
+                                                               float* __restrict__ dgamma) {
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    const float gm = gamma[co];
+    float acc = 0.f;
+    for (int ci = threadIdx.x; ci < Cin; ci += 256) {
+        const float gv = G[(long)co * Cin + ci];
+        dw[(long)co * Cin + ci] = gm * gv;
+        acc += w[(long)co * Cin + ci] * gv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        db[co] = gm * S[co];
+        dgamma[co] = (red[0] + red[1]) + (red[2] + red[3]) + b[co] * S[co];
+    }
+}
+
+// ===========================================================================
+// reductions / glue
+// ===========================================================================
+constexpr int CS_SPLITS = 32;
+__global__ __launch_bounds__(256) void chansum_kernel(const float* __restrict__ x, long x_ns, int N, int C, int HW,
+                                                     float* __restrict__ part) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, split = blockIdx.y;
+    const long total = (long)N * HW;
+    float s = 0.f;
+    for (long i = (long)split * 256 + threadIdx.x; i < total; i += (long)CS_SPLITS * 256) {
+        const int n = (int)(i / HW), px = (int)(i % HW);
+        s += x[(long)n * x_ns + (long)c * HW + px];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)c * CS_SPLITS + split] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void chansum_finish_kernel(const float* __restrict__ part, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < CS_SPLITS; ++k) s += part[(long)c * CS_SPLITS + k];
+    out[c] = s;
+}
+
+template <bool ADD>
+__global__ void rows_kernel(const float* __restrict__ src, long src_ns, float* __restrict__ dst, long dst_ns, long len4) {
+    const int n = blockIdx.y;
+    const float4* s = reinterpret_cast<const float4*>(src + (long)n * src_ns);
+    float4* d = reinterpret_cast<float4*>(dst + (long)n * dst_ns);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < len4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = s[i];
+        if (ADD) { const float4 o = d[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        d[i] = v;
+    }
+}
+
+__global__ void pixel_unshuffle2_kernel(const float* __restrict__ in, int C, int H, int W, long total,
+                                        float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W); long r = i / W;
+        const int y = (int)(r % H); r /= H;
+        const int m = (int)(r % (4 * C)); const long n = r / (4 * C);
+        const int c = m >> 2, a = (m >> 1) & 1, b = m & 1;
+        out[i] = in[((n * C + c) * (2L * H) + 2 * y + a) * (2L * W) + 2 * x + b];
+    }
+}
+
+__global__ void pad_crop_kernel(const float* __restrict__ src, int Hs, int Ws, int Hd, int Wd, long total,
+                                float* __restrict__ dst) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wd); long r = i / Wd;
+        const int y = (int)(r % Hd); const long nc = r / Hd;
+        dst[i] = (y < Hs && x < Ws) ? src[(nc * Hs + y) * Ws + x] : 0.f;
+    }
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ go, const float* __restrict__ act, long n4,
+                                float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 g = reinterpret_cast<const float4*>(go)[i], a = reinterpret_cast<const float4*>(act)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f, a.z > 0.f ? g.z : 0.f,
+                                                        a.w > 0.f ? g.w : 0.f);
+    }
+}
+
+constexpr int L1_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ p, const float* __restrict__ t, long numel,
+                                                float gscale, float* __restrict__ dpred, double* __restrict__ part) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
+        const float d = p[i] - t[i];
+        s += (double)fabsf(d);
+        dpred[i] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void l1_finish_kernel(const double* __restrict__ part, int nparts, double scale, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < nparts; ++k) s += part[k];
+        loss[0] = (float)(s * scale);
+    }
+}
+
+inline int grid1d(long total, int cap = 8192) {
+    long b = (total + 255) / 256;
+    return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int tdr_layernorm2d_fwd(const float* x, int64_t x_ns, const float* w, const float* b, float eps, int N, int C,
+                                   int HW, float* y, float* mu, float* rstd, void* stream) {
+    TDR_REQUIRE(x && w && b && y && mu && rstd, "tdr_layernorm2d_fwd: null pointer");
+    TDR_REQUIRE(N > 0 && C > 0 && HW > 0, "tdr_layernorm2d_fwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(tdr_cdiv(HW, 64), N);
+#define LN_FWD(S, P) hipLaunchKernelGGL((ln_fwd_kernel<S, P>), grid, dim3(64 * S), 0, st, x, (long)x_ns, w, b, eps, C, HW, y, mu, rstd)
+    if (C <= 32) LN_FWD(4, 8);
+    else if (C <= 64) LN_FWD(4, 16);
+    else if (C <= 128) LN_FWD(4, 32);
+    else if (C <= 256) LN_FWD(8, 32);
+    else if (C <= 512) LN_FWD(16, 32);
+    else hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, dim3(256), 0, st, x, (long)x_ns, w, b, eps, C, HW, y, mu, rstd);
+#undef LN_FWD
+    TDR_LAUNCH_CHECK("ln_fwd");
+    return TDR_OK;
+}
+
+extern "C" int64_t tdr_ln_ws_floats(int N, int C, int HW) {
+    (void)N; (void)HW;
+    return (int64_t)LN_BWD_GRID * 2 * C;
+}
+
+extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns, const float* mu, const float* rstd,
+                                   const float* w, const float* add, int64_t add_ns, int add_C, int N, int C, int HW,
+                                   float* gx, float* gw, float* gb, float* ws, void* stream) {
+    TDR_REQUIRE(go && x && mu && rstd && w && gx && gw && gb && ws, "tdr_layernorm2d_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = tdr_cdiv(HW, 64) * N;
+    int nparts;
+    if (C <= 256) {
+        const int grid = tiles < LN_BWD_GRID ? tiles : LN_BWD_GRID;
+        nparts = grid;
+#define LN_BWD(S, P) hipLaunchKernelGGL((ln_bwd_kernel<S, P>), dim3(grid), dim3(64 * S), 0, st, go, x, (long)x_ns, mu, rstd, w, add, (long)add_ns, add_C, N, C, HW, gx, ws)
+        if (C <= 32) LN_BWD(4, 8);
+        else if (C <= 64) LN_BWD(4, 16);
+        else if (C <= 128) LN_BWD(4, 32);
+        else LN_BWD(8, 32);
+#undef LN_BWD
+    } else {
+        hipLaunchKernelGGL(ln_bwd_generic_kernel, dim3(tdr_cdiv(HW, 64), N), dim3(256), 0, st, go, x, (long)x_ns, mu, rstd,
+                           w, add, (long)add_ns, add_C, C, HW, gx);
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3(C, LN_GEN_SPLITS), dim3(256), 0, st, go, x, (long)x_ns, mu, rstd, N, C,
+                           HW, ws);
+        nparts = LN_GEN_SPLITS;
+    }
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3(tdr_cdiv(C, 256)), dim3(256), 0, st, ws, nparts, C, gw, gb);
+    TDR_LAUNCH_CHECK("ln_bwd");
+    return TDR_OK;
+}
+
+static int dwsg_band_rows(int H, int W) {
+    int br = 4096 / W;           // ~1024 float4 per block
+    if (br < 1) br = 1;
+    if (br > H) br = H;
+    return br;
+}
+static int dwsg_bwd_groups(int H, int W, int* tiles_x, int* ntiles, int* tpg) {
+    *tiles_x = tdr_cdiv(W, 32);
+    *ntiles = *tiles_x * tdr_cdiv(H, 16);
+    *tpg = *ntiles >= 64 ? 8 : (*ntiles >= 8 ? 2 : 1);
+    return tdr_cdiv(*ntiles, *tpg);
+}
+
+extern "C" int64_t tdr_dwsg_ws_floats(int N, int C, int H, int W) {
+    const long fwd = (long)N * C * tdr_cdiv(H, dwsg_band_rows(H, W));
+    int tx, nt, tpg;
+    const long bwd = (long)N * C * dwsg_bwd_groups(H, W, &tx, &nt, &tpg) * 20;
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, float* g,
+                            float* pooled, float* ws, void* stream) {
+    TDR_REQUIRE(t && w && b && g && pooled && ws, "tdr_dwsg_fwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0, "tdr_dwsg_fwd: W must be a multiple of 4 (got %d)", W);
+    hipStream_t st = (hipStream_t)stream;
+    const int BR = dwsg_band_rows(H, W), nb = tdr_cdiv(H, BR);
+    hipLaunchKernelGGL(dwsg_fwd_kernel, dim3(nb, C, N), dim3(256), 0, st, t, w, b, C, H, W, BR, g, ws);
+    hipLaunchKernelGGL(pool_finish_kernel, dim3(tdr_cdiv(N * C, 256)), dim3(256), 0, st, ws, N * C, nb,
+                       1.0f / (float)((long)H * W), pooled);
+    TDR_LAUNCH_CHECK("dwsg_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
+                            float* dt, float* dw, float* db, float* ws, void* stream) {
+    TDR_REQUIRE(dg && t && w && b && dt && dw && db && ws, "tdr_dwsg_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int tx, nt, tpg;
+    const int ngrp = dwsg_bwd_groups(H, W, &tx, &nt, &tpg);
+    hipLaunchKernelGGL(dwsg_bwd_kernel, dim3(ngrp, C, N), dim3(256), 0, st, dg, t, w, b, C, H, W, tx, tpg, nt, dt, ws);
+    hipLaunchKernelGGL(dwsg_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, ws, N, C, ngrp, dw, db);
+    TDR_LAUNCH_CHECK("dwsg_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_sca_fwd(const float* pooled, const float* wsca, const float* bsca, int N, int C, float* s,
+                           void* stream) {
+    TDR_REQUIRE(pooled && wsca && bsca && s, "tdr_sca_fwd: null pointer");
+    hipLaunchKernelGGL(sca_fwd_kernel, dim3(tdr_cdiv(C, 4), N), dim3(256), 0, (hipStream_t)stream, pooled, wsca, bsca, C, s);
+    TDR_LAUNCH_CHECK("sca_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_sca_bwd(const float* G3, const float* S3, const float* w3, const float* b3, const float* beta,
+                           const float* s, const float* pooled, const float* wsca, int N, int C, float* dw3, float* db3,
+                           float* dbeta, float* dwsca, float* dbsca, float* dpooled, float* ws, void* stream) {
+    TDR_REQUIRE(G3 && S3 && w3 && b3 && beta && s && pooled && wsca && dw3 && db3 && dbeta && dwsca && dbsca && dpooled && ws,
+                "tdr_sca_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    float* ds = ws;          // [N][C]
+    hipLaunchKernelGGL(sca_bwd_rows_kernel, dim3(C), dim3(256), 0, st, G3, S3, w3, b3, beta, s, N, C, dw3, db3, dbeta);
+    hipLaunchKernelGGL(sca_bwd_ds_kernel, dim3(tdr_cdiv(C, 256), N), dim3(256), 0, st, G3, w3, beta, N, C, ds);
+    hipLaunchKernelGGL(sca_bwd_tail_kernel, dim3(tdr_cdiv(C, 256), C), dim3(256), 0, st, ds, pooled, wsca, N, C, dwsca,
+                       dbsca, dpooled);
+    TDR_LAUNCH_CHECK("sca_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_scaled_conv_param_grads(const float* G, const float* S, const float* w, const float* b,
+                                           const float* gamma, int Cout, int Cin, float* dw, float* db, float* dgamma,
+                                           void* stream) {
+    TDR_REQUIRE(G && S && w && b && gamma && dw && db && dgamma, "tdr_scaled_conv_param_grads: null pointer");
+    hipLaunchKernelGGL(scaled_conv_param_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, G, S, w, b, gamma, Cin, dw,
+                       db, dgamma);
+    TDR_LAUNCH_CHECK("scaled_conv_param_kernel");
+    return TDR_OK;
+}
+
+extern "C" int64_t tdr_chansum_ws_floats(int N, int C, int HW) {
+    (void)N; (void)HW;
+    return (int64_t)C * CS_SPLITS;
+}
+
+extern "C" int tdr_channel_sum(const float* x, int64_t x_ns, int N, int C, int HW, float* out, float* ws, void* stream) {
+    TDR_REQUIRE(x && out && ws, "tdr_channel_sum: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chansum_kernel, dim3(C, CS_SPLITS), dim3(256), 0, st, x, (long)x_ns, N, C, HW, ws);
+    hipLaunchKernelGGL(chansum_finish_kernel, dim3(tdr_cdiv(C, 256)), dim3(256), 0, st, ws, C, out);
+    TDR_LAUNCH_CHECK("channel_sum");
+    return TDR_OK;
+}
+
+extern "C" int tdr_copy_rows(const float* src, int64_t src_ns, float* dst, int64_t dst_ns, int N, int64_t len,
+                             void* stream) {
+    TDR_REQUIRE(src && dst, "tdr_copy_rows: null pointer");
+    TDR_REQUIRE(len % 4 == 0 && src_ns % 4 == 0 && dst_ns % 4 == 0, "tdr_copy_rows: lengths/strides must be multiples of 4");
+    hipLaunchKernelGGL(rows_kernel<false>, dim3(grid1d(len / 4, 2048), N), dim3(256), 0, (hipStream_t)stream, src,
+                       (long)src_ns, dst, (long)dst_ns, (long)(len / 4));
+    TDR_LAUNCH_CHECK("copy_rows");
+    return TDR_OK;
+}
+
+extern "C" int tdr_add_rows(const float* src, int64_t src_ns, float* dst, int64_t dst_ns, int N, int64_t len,
+                            void* stream) {
+    TDR_REQUIRE(src && dst, "tdr_add_rows: null pointer");
+    TDR_REQUIRE(len % 4 == 0 && src_ns % 4 == 0 && dst_ns % 4 == 0, "tdr_add_rows: lengths/strides must be multiples of 4");
+    hipLaunchKernelGGL(rows_kernel<true>, dim3(grid1d(len / 4, 2048), N), dim3(256), 0, (hipStream_t)stream, src,
+                       (long)src_ns, dst, (long)dst_ns, (long)(len / 4));
+    TDR_LAUNCH_CHECK("add_rows");
+    return TDR_OK;
+}
+
+extern "C" int tdr_pixel_unshuffle2(const float* in, int N, int C, int H, int W, float* out, void* stream) {
+    TDR_REQUIRE(in && out, "tdr_pixel_unshuffle2: null pointer");
+    const long total = (long)N * 4 * C * H * W;
+    hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, in, C, H, W, total, out);
+    TDR_LAUNCH_CHECK("pixel_unshuffle2");
+    return TDR_OK;
+}
+
+extern "C" int tdr_pad_crop(const float* src, int N, int C, int Hs, int Ws, float* dst, int Hd, int Wd, void* stream) {
+    TDR_REQUIRE(src && dst, "tdr_pad_crop: null pointer");
+    const long total = (long)N * C * Hd * Wd;
+    hipLaunchKernelGGL(pad_crop_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, src, Hs, Ws, Hd, Wd, total, dst);
+    TDR_LAUNCH_CHECK("pad_crop");
+    return TDR_OK;
+}
+
+extern "C" int tdr_relu_bwd(const float* go, const float* act, int64_t numel, float* out, void* stream) {
+    TDR_REQUIRE(go && act && out, "tdr_relu_bwd: null pointer");
+    TDR_REQUIRE(numel % 4 == 0, "tdr_relu_bwd: numel must be a multiple of 4");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid1d(numel / 4)), dim3(256), 0, (hipStream_t)stream, go, act, (long)(numel / 4), out);
+    TDR_LAUNCH_CHECK("relu_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_l1_loss(const float* pred, const float* target, int64_t numel, float loss_weight, float* loss,
+                           float* dpred, float* ws, void* stream) {
+    TDR_REQUIRE(pred && target && loss && dpred && ws, "tdr_l1_loss: null pointer (ws needs 2*1024 floats)");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = grid1d(numel, L1_BLOCKS);
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(l1_kernel, dim3(blocks), dim3(256), 0, st, pred, target, (long)numel,
+                       loss_weight / (float)numel, dpred, part);
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, st, part, blocks, (double)loss_weight / (double)numel, loss);
+    TDR_LAUNCH_CHECK("l1_loss");
+    return TDR_OK;
+}

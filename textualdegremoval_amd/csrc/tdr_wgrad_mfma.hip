@@ -1,0 +1,286 @@
+// Weight-gradient GEMM on the gfx950 fp32 matrix cores (K = output pixels).
+//
+//   G[co][ci][tap] = sum_{n,oy,ox} dout[n][co][oy][ox] * B[n][ci][oy*S+ky-pad][ox*S+kx-pad]
+//
+// MFMA view: A[i=co][k=pixel] (dout), B[k=pixel][j=ci] (input, shifted per tap),
+// one 32x32 accumulator tile per (co-tile, ci-tile, tap).  A workgroup (4 waves)
+// walks 64-pixel tiles (64/TW rows x TW cols); per tile it stages
+//   s_d[BMc][65]        dout rows (pitch 65 -> conflict-free A reads across co)
+//   s_i[BNc][plane|1]   input halo tiles (odd pitch -> conflict-free B reads across ci)
+// through registers (next tile's global loads in flight under the MFMAs).
+// Waves are arranged WMw x WNw x WKw: for narrow layers (32 channels) the four
+// waves split the K (pixel) range instead of the output tile.  Split-K partials
+// go to a workspace and are reduced in a fixed order (deterministic).
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+namespace {
+
+struct WgArgs {
+    const float* in; long in_ns; int Cin, H, W; long gate_off;
+    const float* dout; long dout_ns; int Cout, OH, OW;
+    int pad, tw_log2, tiles_x, tpi /*tiles per image*/, tps /*tiles per split*/, spi /*splits per image*/;
+    float* part;
+};
+
+constexpr int wg_plane(int TW, int KH, int S) { return (((64 / TW) - 1) * S + KH) * ((TW - 1) * S + KH); }
+constexpr int wg_cmax(int a, int b) { return a > b ? a : b; }
+constexpr int wg_max_plane(int KH, int S) {
+    return wg_cmax(wg_plane(8, KH, S), wg_cmax(wg_plane(16, KH, S), wg_plane(32, KH, S)));
+}
+
+template <int KH, int S, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
+    static_assert(WMw * WNw * WKw == 4, "4 waves");
+    constexpr int TAPS = KH * KH;
+    constexpr int BMc = 32 * TMW * WMw, BNc = 32 * TNW * WNw;
+    constexpr int MAXPIT = (wg_max_plane(KH, S) + 63) / 64;
+    constexpr int DPT = BMc / 4;          // dout rows per wave
+    constexpr int IPT = BNc / 4;          // input channels per wave
+    constexpr int KPW = 32 / WKw;         // k-pairs per wave per tile
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WKw, wn = (wave / WKw) % WNw, wm = wave / (WKw * WNw);
+    const int j = lane & 31, kk = lane >> 5;
+    const int TW = 1 << a.tw_log2;
+    const int LH = ((64 >> a.tw_log2) - 1) * S + KH, LW = (TW - 1) * S + KH;
+    const int plane = LH * LW, planeP = plane | 1;
+    float* s_d = smem;
+    float* s_i = smem + BMc * 65;
+
+    const int split = blockIdx.x;
+    const int n = split / a.spi;
+    const int t_begin = (split % a.spi) * a.tps;
+    const int t_end = min(t_begin + a.tps, a.tpi);
+    const int co0 = blockIdx.y * BMc, ci0 = blockIdx.z * BNc;
+    const long HWin = (long)a.H * a.W, HWo = (long)a.OH * a.OW;
+    const float* in_n = a.in + (long)n * a.in_ns;
+    const float* do_n = a.dout + (long)n * a.dout_ns;
+
+    // lane's pixel inside the 64-pixel tile (dout staging) and halo positions (input staging)
+    const int dpy = lane >> a.tw_log2, dpx = lane & (TW - 1);
+    int pr[MAXPIT], pc[MAXPIT];
+#pragma unroll
+    for (int it = 0; it < MAXPIT; ++it) {
+        const int p = lane + 64 * it;
+        pr[it] = p < plane ? p / LW : -1;
+        pc[it] = p - (p / LW) * LW;
+    }
+
+    float rd[DPT];
+    float ri[IPT][MAXPIT];
+    auto load_tile = [&](int t) {
+        const int ty = t / a.tiles_x, tx = t % a.tiles_x;
+        const int oy0 = ty * (64 >> a.tw_log2), ox0 = tx * TW;
+        const int oy = oy0 + dpy, ox = ox0 + dpx;
+        const bool dok = oy < a.OH && ox < a.OW;
+        const long doff = (long)oy * a.OW + ox;
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) {
+            const int co = co0 + wave + 4 * i;
+            rd[i] = (dok && co < a.Cout) ? do_n[(long)co * HWo + doff] : 0.f;
+        }
+        const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+#pragma unroll
+        for (int it = 0; it < MAXPIT; ++it) {
+            const int gy = iy0 + pr[it], gx = ix0 + pc[it];
+            const bool ok = pr[it] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const long off = (long)gy * a.W + gx;
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int ci = ci0 + wave + 4 * i;
+                float v = 0.f;
+                if (ok && ci < a.Cin) {
+                    v = in_n[(long)ci * HWin + off];
+                    if (GATE) v *= in_n[(long)ci * HWin + off + a.gate_off];
+                }
+                ri[i][it] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) s_d[(wave + 4 * i) * 65 + lane] = rd[i];
+#pragma unroll
+        for (int it = 0; it < MAXPIT; ++it)
+            if (pr[it] >= 0) {
+#pragma unroll
+                for (int i = 0; i < IPT; ++i) s_i[(wave + 4 * i) * planeP + lane + 64 * it] = ri[i][it];
+            }
+    };
+
+    f32x16 acc[TMW][TNW][TAPS];
+#pragma unroll
+    for (int x = 0; x < TMW; ++x)
+#pragma unroll
+        for (int y = 0; y < TNW; ++y)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][t][r] = 0.f;
+
+    const int abase = (wm * TMW * 32 + j) * 65 + kk;
+    const int bbase = (wn * TNW * 32 + j) * planeP + kk * S;
+
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (t + 1 < t_end) load_tile(t + 1);
+#pragma unroll
+        for (int q = 0; q < KPW; ++q) {
+            const int k2 = wk * KPW + q;
+            const int p0 = 2 * k2;
+            const int py0 = p0 >> a.tw_log2, px0 = p0 & (TW - 1);
+            const int pixoff = py0 * S * LW + px0 * S;
+            float af[TMW];
+#pragma unroll
+            for (int x = 0; x < TMW; ++x) af[x] = s_d[abase + x * 32 * 65 + p0];
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int toff = pixoff + (tap / KH) * LW + (tap % KH);
+#pragma unroll
+                for (int y = 0; y < TNW; ++y) {
+                    const float bf = s_i[bbase + y * 32 * planeP + toff];
+#pragma unroll
+                    for (int x = 0; x < TMW; ++x)
+                        acc[x][y][tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x], bf, acc[x][y][tap], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // partial[(split*WKw + wk)][co][ci][tap]
+    float* part = a.part + ((long)split * WKw + wk) * a.Cout * a.Cin * TAPS;
+#pragma unroll
+    for (int x = 0; x < TMW; ++x)
+#pragma unroll
+        for (int y = 0; y < TNW; ++y) {
+            const int ci = ci0 + (wn * TNW + y) * 32 + j;
+            if (ci >= a.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * TMW + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (co >= a.Cout) continue;
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) part[((long)co * a.Cin + ci) * TAPS + tap] = acc[x][y][tap][r];
+            }
+        }
+}
+
+// out[g][e] = sum_{s < per_group} part[(g*per_group + s)][e]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, long elems, int per_group, int groups,
+                                    float* __restrict__ out) {
+    const long total = elems * groups;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / elems, e = i % elems;
+        const float* p = part + g * per_group * elems + e;
+        float s = 0.f;
+        for (int k = 0; k < per_group; ++k) s += p[(long)k * elems];
+        out[i] = s;
+    }
+}
+
+struct WgPlan { int tw_log2, tiles_x, tiles_y, tpi, tps, spi, cfg, WKw, BMc, BNc; };
+
+// cfg: 0 = waves 2x2x1 tile 2x2 (128x128) | 1 = waves 1x1x4 tile 2x1 (64x32) | 2 = 2x2x1 tile 1x1 (64x64)
+//      3 = waves 1x1x4 tile 1x1 (32x32)
+WgPlan make_plan(const TdrWgradDesc* d) {
+    WgPlan p;
+    p.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);
+    const int TW = 1 << p.tw_log2, TH = 64 >> p.tw_log2;
+    p.tiles_x = tdr_cdiv(d->OW, TW);
+    p.tiles_y = tdr_cdiv(d->OH, TH);
+    p.tpi = p.tiles_x * p.tiles_y;
+    if (d->KH == 1) {
+        if (d->Cout >= 128 && d->Cin >= 128) p.cfg = 0;
+        else if (d->Cin <= 32) p.cfg = d->Cout <= 32 ? 3 : 1;
+        else p.cfg = 2;
+    } else if (d->KH == 3 && d->stride == 1) {
+        p.cfg = (d->Cin <= 32 && d->Cout <= 32) ? 3 : 2;
+    } else {
+        p.cfg = 2;
+    }
+    static const int bm[4] = {128, 64, 64, 32}, bn[4] = {128, 32, 64, 32}, wk[4] = {1, 4, 1, 4};
+    p.BMc = bm[p.cfg]; p.BNc = bn[p.cfg]; p.WKw = wk[p.cfg];
+    const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
+    long want = 768 / out_tiles;                      // target ~3 blocks per CU in total
+    if (want < 1) want = 1;
+    long spi = (want + d->N - 1) / d->N;              // splits per image
+    if (spi > p.tpi) spi = p.tpi;
+    if (spi < 1) spi = 1;
+    p.tps = tdr_cdiv(p.tpi, spi);
+    p.spi = tdr_cdiv(p.tpi, p.tps);
+    return p;
+}
+
+template <int KH, int S, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE>
+int launch_wg(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
+    constexpr int BMc = 32 * TMW * WMw, BNc = 32 * TNW * WNw;
+    const int TW = 1 << a.tw_log2;
+    const int LH = ((64 >> a.tw_log2) - 1) * S + KH, LW = (TW - 1) * S + KH;
+    const size_t lds = (size_t)(BMc * 65 + BNc * ((LH * LW) | 1)) * sizeof(float);
+    dim3 grid(N * p.spi, tdr_cdiv(a.Cout, BMc), tdr_cdiv(a.Cin, BNc));
+    auto kern = wgrad_mfma_kernel<KH, S, WMw, WNw, WKw, TMW, TNW, GATE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    TDR_LAUNCH_CHECK("wgrad_mfma_kernel");
+    return TDR_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t tdr_wgrad_ws_floats(const TdrWgradDesc* d) {
+    const WgPlan p = make_plan(d);
+    return (int64_t)d->N * p.spi * p.WKw * d->Cout * d->Cin * d->KH * d->KH;
+}
+
+extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
+    TDR_REQUIRE(d && d->in && d->dout && d->g && d->ws, "tdr_conv_wgrad: null pointer");
+    const WgPlan p = make_plan(d);
+    const int64_t need = tdr_wgrad_ws_floats(d);
+    TDR_REQUIRE(d->ws_floats >= need, "tdr_conv_wgrad: workspace too small (%lld < %lld)", (long long)d->ws_floats,
+                (long long)need);
+    WgArgs a;
+    a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
+    a.gate_off = (long)d->Cin * d->H * d->W;
+    a.dout = d->dout; a.dout_ns = d->dout_ns; a.Cout = d->Cout; a.OH = d->OH; a.OW = d->OW;
+    a.pad = d->pad; a.tw_log2 = p.tw_log2; a.tiles_x = p.tiles_x; a.tpi = p.tpi; a.tps = p.tps; a.spi = p.spi;
+    a.part = d->ws;
+    hipStream_t st = (hipStream_t)stream;
+    const bool g = d->gate != 0;
+    int rc = TDR_ERR_UNSUPPORTED;
+    const int key = d->KH * 10 + d->stride;
+    if (key == 11) {
+        switch (p.cfg) {
+            case 0: rc = g ? launch_wg<1, 1, 2, 2, 1, 2, 2, true>(a, p, d->N, st) : launch_wg<1, 1, 2, 2, 1, 2, 2, false>(a, p, d->N, st); break;
+            case 1: rc = g ? launch_wg<1, 1, 1, 1, 4, 2, 1, true>(a, p, d->N, st) : launch_wg<1, 1, 1, 1, 4, 2, 1, false>(a, p, d->N, st); break;
+            case 2: rc = g ? launch_wg<1, 1, 2, 2, 1, 1, 1, true>(a, p, d->N, st) : launch_wg<1, 1, 2, 2, 1, 1, 1, false>(a, p, d->N, st); break;
+            default: rc = g ? launch_wg<1, 1, 1, 1, 4, 1, 1, true>(a, p, d->N, st) : launch_wg<1, 1, 1, 1, 4, 1, 1, false>(a, p, d->N, st); break;
+        }
+    } else if (key == 31 && !g) {
+        rc = p.cfg == 3 ? launch_wg<3, 1, 1, 1, 4, 1, 1, false>(a, p, d->N, st) : launch_wg<3, 1, 2, 2, 1, 1, 1, false>(a, p, d->N, st);
+    } else if (key == 32 && !g) {
+        rc = launch_wg<3, 2, 2, 2, 1, 1, 1, false>(a, p, d->N, st);
+    } else if (key == 22 && !g) {
+        rc = launch_wg<2, 2, 2, 2, 1, 1, 1, false>(a, p, d->N, st);
+    } else {
+        tdr_set_error("tdr_conv_wgrad: unsupported (KH=%d stride=%d gate=%d)", d->KH, d->stride, d->gate);
+        return TDR_ERR_UNSUPPORTED;
+    }
+    if (rc != TDR_OK) return rc;
+    const long elems = (long)d->Cout * d->Cin * d->KH * d->KH;
+    const int groups = d->per_image ? d->N : 1;
+    const int per_group = (d->per_image ? p.spi : d->N * p.spi) * p.WKw;
+    const long total = elems * groups;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, d->ws, elems, per_group, groups, d->g);
+    TDR_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return TDR_OK;
+}

@@ -1,0 +1,403 @@
+"""Hand-written forward/backward of the NAFNet-ref hot path on the HIP kernels.
+
+Functional pieces (`*_fwd` returns (out, saved), `*_bwd` returns (dx, grads))
+mirror the reference modules they replace and cite them; parameters are passed
+as dicts keyed by the reference's state-dict names, gradients come back keyed
+the same way.  No ATen arithmetic runs on the device here: every tensor op is a
+call into libtdr_hip.so (torch only allocates and views memory).
+"""
+import torch
+
+from . import kernels as K
+from .kernels import (EPI_GATEBWD, EPI_PSHUF, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2, PACK_DGRAD_S1, PACK_FWD)
+
+LN_EPS = 1e-6
+
+
+def _sub(P, pre):
+    """view of the params under a prefix (without the prefix)."""
+    n = len(pre)
+    return {k[n:]: v for k, v in P.items() if k.startswith(pre)}
+
+
+def _put(G, pre, g):
+    for k, v in g.items():
+        G[pre + k] = v
+
+
+# ---------------------------------------------------------------------------
+# NAFBlock / NAFResFuseBlock   models/archs/network_nafnet_guided_arch.py:178-302
+# ---------------------------------------------------------------------------
+def naf_fwd(x, P, c_out=None):
+    """x [N,c,H,W] -> [N,c_out,H,W] (c_out<c: only the first c_out output channels are
+    produced, the `[:, :chan]` slice of :719/:727 folded into conv5)."""
+    N, c, H, W = x.shape
+    c_out = c if c_out is None else c_out
+    xn, mu1, rs1 = K.layernorm2d_fwd(x, P['norm1.weight'], P['norm1.bias'], LN_EPS)
+    wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_FWD)
+    t1 = K.conv_forward(xn, wp, mp, 2 * c, 1, bias=P['conv1.bias'])
+    g, pooled = K.dwsg_fwd(t1, P['conv2.weight'], P['conv2.bias'])
+    s = K.sca_fwd(pooled, P['sca.1.weight'], P['sca.1.bias'])
+    wp, mp, *_ = K.pack_weights(P['conv3.weight'], PACK_FWD)
+    y = K.conv_forward(g, wp, mp, c, 1, kscale=s, bias=P['conv3.bias'], scale=P['beta'].view(-1), res=x)
+    yn, mu2, rs2 = K.layernorm2d_fwd(y, P['norm2.weight'], P['norm2.bias'], LN_EPS)
+    wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_FWD)
+    t4 = K.conv_forward(yn, wp, mp, 2 * c, 1, bias=P['conv4.bias'])
+    wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_FWD)
+    out = K.conv_forward(t4, wp, mp, c_out, 1, gate=True, bias=P['conv5.bias'], scale=P['gamma'].view(-1), res=y)
+    saved = (x, xn, mu1, rs1, t1, g, pooled, s, y, yn, mu2, rs2, t4, c_out)
+    return out, saved
+
+
+def naf_bwd(dout, P, saved):
+    x, xn, mu1, rs1, t1, g, pooled, s, y, yn, mu2, rs2, t4, c_out = saved
+    N, c, H, W = x.shape
+    dev = x.device
+    G = {}
+    beta, gamma = P['beta'].view(-1), P['gamma'].view(-1)
+    # ---- conv5 / gamma chain
+    G5 = K.conv_wgrad(t4, dout, c_out, c, 1, gate=True)
+    S5 = K.channel_sum(dout)
+    dw5, db5, dgam = K.scaled_conv_param_grads(G5.view(c_out, c), S5, P['conv5.weight'], P['conv5.bias'], gamma)
+    if c_out == c:
+        G['conv5.weight'], G['conv5.bias'], G['gamma'] = dw5.view(c, c, 1, 1), db5, dgam.view(1, c, 1, 1)
+    else:
+        fw = torch.zeros(c, c, 1, 1, dtype=torch.float32, device=dev)
+        fb = torch.zeros(c, dtype=torch.float32, device=dev)
+        fg = torch.zeros(1, c, 1, 1, dtype=torch.float32, device=dev)
+        K.copy_rows(dw5, 0, fw, 0, 1, c_out * c)
+        K.copy_rows(db5, 0, fb, 0, 1, c_out)
+        K.copy_rows(dgam, 0, fg, 0, 1, c_out)
+        G['conv5.weight'], G['conv5.bias'], G['gamma'] = fw, fb, fg
+    wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
+    dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
+    # ---- conv4
+    G['conv4.weight'] = K.conv_wgrad(yn, dt4, 2 * c, c, 1).view(2 * c, c, 1, 1)
+    G['conv4.bias'] = K.channel_sum(dt4)
+    wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)
+    dyn = K.conv_forward(dt4, wp, mp, c, 1)
+    # ---- norm2 (+ residual branch of `y + x*gamma`)
+    dy, G['norm2.weight'], G['norm2.bias'] = K.layernorm2d_bwd(dyn, y, mu2, rs2, P['norm2.weight'], add=dout)
+    # ---- conv3 / SCA / beta chain
+    G3 = K.conv_wgrad(g, dy, c, c, 1, per_image=True)
+    S3 = K.channel_sum(dy)
+    dw3, db3, dbeta, dwsca, dbsca, dpooled = K.sca_bwd(G3, S3, P['conv3.weight'], P['conv3.bias'], beta, s, pooled,
+                                                       P['sca.1.weight'])
+    G['conv3.weight'], G['conv3.bias'], G['beta'] = dw3, db3, dbeta
+    G['sca.1.weight'], G['sca.1.bias'] = dwsca, dbsca
+    wp, mp, *_ = K.pack_weights(P['conv3.weight'], PACK_DGRAD_S1)
+    dg = K.conv_forward(dy, wp, mp, c, 1, kscale=beta, scale=s, bias2=dpooled, bias2_mul=1.0 / (H * W))
+    # ---- depthwise + SimpleGate
+    dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'])
+    # ---- conv1
+    G['conv1.weight'] = K.conv_wgrad(xn, dt1, 2 * c, c, 1).view(2 * c, c, 1, 1)
+    G['conv1.bias'] = K.channel_sum(dt1)
+    wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)
+    dxn = K.conv_forward(dt1, wp, mp, c, 1)
+    dx, G['norm1.weight'], G['norm1.bias'] = K.layernorm2d_bwd(dxn, x, mu1, rs1, P['norm1.weight'], add=dy)
+    return dx, G
+
+
+def naf_seq_fwd(x, P, pre, n, c_out_last=None):
+    saved = []
+    for i in range(n):
+        x, sv = naf_fwd(x, _sub(P, f'{pre}{i}.'), c_out_last if i == n - 1 else None)
+        saved.append(sv)
+    return x, saved
+
+
+def naf_seq_bwd(dout, P, pre, n, saved, G):
+    for i in reversed(range(n)):
+        dout, g = naf_bwd(dout, _sub(P, f'{pre}{i}.'), saved[i])
+        _put(G, f'{pre}{i}.', g)
+    return dout
+
+
+# ---------------------------------------------------------------------------
+# dense convs: intro / ending / downs / ups (:429-434, :449-451, :468-473)
+# ---------------------------------------------------------------------------
+def conv_fwd(x, w, b, stride, pad, res=None, relu=False):
+    Cout, Cin, KH, _ = w.shape
+    wp, mp, *_ = K.pack_weights(w, PACK_FWD)
+    out = K.conv_forward(x, wp, mp, Cout, KH, stride=stride, pad=pad, bias=b, res=res, relu=relu)
+    return out
+
+
+def conv_bwd(dout, x, w, stride, pad, need_dx=True, add_to_dx=None):
+    """returns (dx or None, dw, db)."""
+    Cout, Cin, KH, _ = w.shape
+    dw = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad).view(Cout, Cin, KH, KH)
+    db = K.channel_sum(dout)
+    dx = None
+    if need_dx:
+        N, _, OH, OW = dout.shape
+        if stride == 1:
+            wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_S1)
+            dx = K.conv_forward(dout, wp, mp, Cin, KH, pad=KH - 1 - pad, res=add_to_dx)
+        elif KH == 2 and stride == 2 and pad == 0:
+            wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_2X2S2)
+            dx = K.conv_forward(dout, wp, mp, 4 * Cin, 1, epi=EPI_PSHUF, res=add_to_dx)
+        elif KH == 3 and stride == 2 and pad == 1:
+            wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_3X3S2)
+            dx = K.conv_forward(dout, wp, mp, 4 * Cin, 2, pad=0, OH=OH, OW=OW, epi=EPI_PSHUF, res=add_to_dx)
+        else:
+            raise NotImplementedError(f'conv dgrad KH={KH} stride={stride} pad={pad}')
+    return dx, dw, db
+
+
+def up_fwd(x, w, skip):
+    """ups: 1x1 (C->2C, no bias) + PixelShuffle(2), then `+ enc_skip` (:733-734)."""
+    C2 = w.shape[0]
+    wp, mp, *_ = K.pack_weights(w, PACK_FWD)
+    return K.conv_forward(x, wp, mp, C2, 1, epi=EPI_PSHUF, res=skip)
+
+
+def up_bwd(dout, x, w):
+    C2, Cc = w.shape[0], w.shape[1]
+    dT = K.pixel_unshuffle2(dout)
+    dw = K.conv_wgrad(x, dT, C2, Cc, 1).view(C2, Cc, 1, 1)
+    wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_S1)
+    dx = K.conv_forward(dT, wp, mp, Cc, 1)
+    return dx, dw
+
+
+# ---------------------------------------------------------------------------
+# MASA feature encoder (Encoder + ResidualBlock, :44-59, :110-143)
+# ---------------------------------------------------------------------------
+def _enc_counts(ext):
+    return [ext[0], ext[1], ext[2], ext[2], ext[2]]
+
+
+def encoder_fwd(x, P, pre, ext_n_blocks):
+    """returns ([f1..f5], saved)."""
+    feats, saved = [], []
+    cnt = _enc_counts(ext_n_blocks)
+    for lvl in range(5):
+        k = lvl + 1
+        xin = x
+        a = conv_fwd(xin, P[f'{pre}conv_L{k}.weight'], P[f'{pre}conv_L{k}.bias'], 1 if lvl == 0 else 2, 1, relu=True)
+        blocks = []
+        x = a
+        for i in range(cnt[lvl]):
+            bp = f'{pre}blk_L{k}.{i}.'
+            h = conv_fwd(x, P[bp + 'conv1.weight'], P[bp + 'conv1.bias'], 1, 1, relu=True)
+            o = conv_fwd(h, P[bp + 'conv2.weight'], P[bp + 'conv2.bias'], 1, 1, res=x)
+            blocks.append((x, h))
+            x = o
+        feats.append(x)
+        saved.append((xin, a, blocks))
+    return feats, saved
+
+
+def encoder_bwd(dfeats, P, pre, ext_n_blocks, saved, G):
+    """dfeats: list of 5 grads (or None).  Input-image gradient is not needed."""
+    cnt = _enc_counts(ext_n_blocks)
+    dnext = None                      # gradient flowing from level lvl+1 into feats[lvl]
+    for lvl in reversed(range(5)):
+        k = lvl + 1
+        xin, a, blocks = saved[lvl]
+        d = dfeats[lvl]
+        if d is None:
+            d = dnext
+        elif dnext is not None:
+            d = K.add_(dnext, d)      # dnext is a fresh tensor we own
+        if d is None:
+            continue
+        for i in reversed(range(cnt[lvl])):
+            bp = f'{pre}blk_L{k}.{i}.'
+            x_in, h = blocks[i]
+            w1, w2 = P[bp + 'conv1.weight'], P[bp + 'conv2.weight']
+            Cc = w1.shape[0]
+            G[bp + 'conv2.weight'] = K.conv_wgrad(h, d, Cc, Cc, 3, pad=1).view(Cc, Cc, 3, 3)
+            G[bp + 'conv2.bias'] = K.channel_sum(d)
+            wp, mp, *_ = K.pack_weights(w2, PACK_DGRAD_S1)
+            dh = K.conv_forward(d, wp, mp, Cc, 3, pad=1, mask=h)
+            G[bp + 'conv1.weight'] = K.conv_wgrad(x_in, dh, Cc, Cc, 3, pad=1).view(Cc, Cc, 3, 3)
+            G[bp + 'conv1.bias'] = K.channel_sum(dh)
+            wp, mp, *_ = K.pack_weights(w1, PACK_DGRAD_S1)
+            d = K.conv_forward(dh, wp, mp, Cc, 3, pad=1, res=d)
+        dpre = K.relu_bwd(d, a)
+        w = P[f'{pre}conv_L{k}.weight']
+        dnext, G[f'{pre}conv_L{k}.weight'], G[f'{pre}conv_L{k}.bias'] = conv_bwd(
+            dpre, xin, w, 1 if lvl == 0 else 2, 1, need_dx=(lvl > 0))
+    return None
+
+
+# ---------------------------------------------------------------------------
+# MASA match + transfer (:597-707)
+# ---------------------------------------------------------------------------
+class MasaGeom:
+    def __init__(self, h, w, hr, wr, n_enc, lr_block_size, ref_down_block_size, dilations):
+        padder = 2 ** n_enc
+        self.px = w // padder // lr_block_size
+        self.py = h // padder // lr_block_size
+        self.kx = w // padder // self.px
+        self.ky = h // padder // self.py
+        self.dia_x = 2 * int(wr // padder // (2 * self.px) * ref_down_block_size) + 1
+        self.dia_y = 2 * int(hr // padder // (2 * self.py) * ref_down_block_size) + 1
+        if self.dia_x != self.dia_y or self.kx != self.ky:
+            raise ValueError('MASA geometry must be square (the reference only runs for square geometry, :668-669)')
+        self.dilations = list(dilations)
+        self.P = self.py * self.px
+        self.K = self.kx
+        self.side = self.dia_x + 2
+
+
+def masa_fwd(feats, N, geo):
+    """feats: 5 pyramid levels for the stacked batch [lq(0..N-1), ref(N..2N-1)].
+    Returns (warp list finest->coarsest like the reference's warp_ref_l, saved)."""
+    P, Kk, side = geo.P, geo.K, geo.side
+    deep = feats[4]
+    _, Cc, H, W = deep.shape
+    lq4, ref4 = deep[:N], deep[N:]
+    Hr, Wr = H, W
+    lrb = K.lr_blocks_fwd(lq4, geo.py, geo.px, Kk, Kk)                    # [N*P, C, K+2, K+2]
+    # ---- coarse search (:515-536) on the MFMA conv with the LR centre taps as filters
+    ND = len(geo.dilations)
+    R = Hr * Wr
+    dots = torch.empty(ND, N, P, Hr, Wr, dtype=torch.float32, device=deep.device)
+    invq = torch.empty(ND, N * P, dtype=torch.float32, device=deep.device)
+    invk = torch.empty(ND, N, R, dtype=torch.float32, device=deep.device)
+    cc = (Kk + 2) // 2
+    for di, d in enumerate(geo.dilations):
+        wp, mp, per_b = K.pack_patches(lrb, P, 1, 1, 1, d, cc - d)
+        K.conv_forward(ref4, wp, mp, P, 3, dil=d, pad=d, wp_ns=per_b, out=dots[di])
+        K.patch_inv_norm(lrb, 1, 1, dil=d, off=cc - d, out=invq[di])
+        K.patch_inv_norm(ref4, Hr, Wr, dil=d, pad=d, out=invk[di])
+    index, y1, x1 = K.coarse_argmax_box(dots, invq, invk, N, P, Hr, Wr, geo.dia_x)
+    # ---- fine search (:495-513) inside the matched ref block
+    refb = K.gather_ref_block(ref4, y1, x1, P, side, 1)                   # [N*P, C, side, side]
+    wp, mp, per_b = K.pack_patches(lrb, 1, Kk, Kk, 1, 1, 0)
+    R1 = side - 2
+    fdots = K.conv_forward(refb, wp, mp, Kk * Kk, 3, pad=0, wp_ns=per_b)  # [N*P, K*K, R1, R1]
+    finvq = K.patch_inv_norm(lrb, Kk, Kk)                                 # [N*P, K, K]
+    finvk = K.patch_inv_norm(refb, R1, R1)
+    index_all, soft_att = K.fine_argmax(fdots, finvq, finvk, N * P, Kk * Kk, R1 * R1)
+    # ---- transfer at 5 scales, reading the ref features directly
+    warp = []
+    for lvl in range(5):
+        s = 2 ** (4 - lvl)
+        warp.append(K.transfer_fwd(feats[lvl][N:], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s))
+    saved = (lrb, refb, finvq, finvk, index, y1, x1, index_all, soft_att)
+    return warp, saved
+
+
+def masa_bwd(dwarp, feats, N, geo, saved):
+    """returns list of 5 gradients w.r.t. the stacked feats (zeros where unused)."""
+    lrb, refb, finvq, finvk, index, y1, x1, index_all, soft_att = saved
+    P, Kk, side = geo.P, geo.K, geo.side
+    dev = feats[4].device
+    dfeats = [torch.zeros_like(f) for f in feats]
+    datt = torch.zeros(N * P, Kk * Kk, dtype=torch.float32, device=dev)
+    for lvl in range(5):
+        s = 2 ** (4 - lvl)
+        K.transfer_bwd(dwarp[lvl], feats[lvl][N:], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s,
+                       dfeats[lvl][N:], datt)
+    dlrb, drefb = K.fine_search_bwd(datt, soft_att, index_all, lrb, refb, finvq, finvk, Kk, side)
+    K.scatter_ref_block(drefb, dfeats[4][N:], y1, x1, P, side)
+    _, Cc, H, W = feats[4].shape
+    dlq4 = K.lr_blocks_bwd(dlrb, N, Cc, H, W, geo.py, geo.px, Kk, Kk)
+    K.copy_rows(dlq4, Cc * H * W, dfeats[4], Cc * H * W, N, Cc * H * W)
+    return dfeats
+
+
+# ---------------------------------------------------------------------------
+# whole network  NAFNetRefFusion.forward (:587-740)
+# ---------------------------------------------------------------------------
+def net_fwd(P, cfg, inp, ref):
+    """inp, ref [N,3,H,W] -> (out [N,3,H,W], saved).  cfg: constructor kwargs."""
+    n_enc = len(cfg['enc_blk_nums'])
+    N, Ci, H0, W0 = inp.shape
+    mult = (2 ** n_enc) * cfg['lr_block_size']
+    Hp, Wp = -(-H0 // mult) * mult, -(-W0 // mult) * mult
+    Hr0, Wr0 = ref.shape[-2:]
+    Hrp, Wrp = -(-Hr0 // mult) * mult, -(-Wr0 // mult) * mult
+    if (Hrp, Wrp) != (Hp, Wp):
+        raise NotImplementedError('ref and lq must pad to the same size on the fused path '
+                                  '(the DINO window match makes them equal, image_restoration_ref_model.py:219-243)')
+    both = torch.empty(2 * N, Ci, Hp, Wp, dtype=torch.float32, device=inp.device)
+    # zero-pad (:576-585) and stack [lq; ref] so masa_enc runs once over 2N images
+    _pad_into(inp.contiguous(), both[:N])
+    _pad_into(ref.contiguous(), both[N:])
+    inp_p = both[:N]
+    geo = MasaGeom(Hp, Wp, Hrp, Wrp, n_enc, cfg['lr_block_size'], cfg['ref_down_block_size'], cfg['dilations'])
+    feats, sv_enc = encoder_fwd(both, P, 'masa_enc.', cfg['ext_n_blocks'])
+    warp, sv_masa = masa_fwd(feats, N, geo)
+
+    x = conv_fwd(inp_p, P['intro.weight'], P['intro.bias'], 1, 1)
+    chan = x.shape[1]
+    sv_levels, skips = [], []
+    for lvl in range(n_enc):
+        cat = K.concat2(x, warp[lvl])
+        x, sv_f = naf_seq_fwd(cat, P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], c_out_last=chan)
+        x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl])
+        skips.append(x)
+        xd = conv_fwd(x, P[f'downs.{lvl}.weight'], P[f'downs.{lvl}.bias'], 2, 0)
+        sv_levels.append((sv_f, sv_e, x))
+        x = xd
+        chan *= 2
+    cat = K.concat2(x, warp[n_enc])
+    x, sv_fm = naf_seq_fwd(cat, P, 'masa_blk_middle.0.', cfg['reffusion_n_blocks'][n_enc], c_out_last=chan)
+    x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'])
+    sv_dec = []
+    for lvl in range(len(cfg['dec_blk_nums'])):
+        xin = x
+        x = up_fwd(xin, P[f'ups.{lvl}.0.weight'], skips[-1 - lvl])
+        x, sv_d = naf_seq_fwd(x, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl])
+        sv_dec.append((xin, sv_d))
+    xe = x
+    out_p = conv_fwd(xe, P['ending.weight'], P['ending.bias'], 1, 1, res=inp_p)
+    out = out_p if (Hp, Wp) == (H0, W0) else K.pad_crop(out_p, H0, W0)
+    saved = (N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe)
+    return out, saved
+
+
+def _pad_into(src, dst_view):
+    """dst_view: dense [N,C,Hd,Wd] slice (contiguous along the batch)."""
+    N, Cc, Hs, Ws = src.shape
+    _, _, Hd, Wd = dst_view.shape
+    if (Hs, Ws) == (Hd, Wd):
+        K.copy_rows(src, Cc * Hs * Ws, dst_view, Cc * Hd * Wd, N, Cc * Hs * Ws)
+    else:
+        tmp = K.pad_crop(src, Hd, Wd)
+        K.copy_rows(tmp, Cc * Hd * Wd, dst_view, Cc * Hd * Wd, N, Cc * Hd * Wd)
+
+
+def net_bwd(dout, P, cfg, saved):
+    """dout [N,3,H0,W0] -> dict of parameter gradients keyed like P."""
+    N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe = saved
+    n_enc = len(cfg['enc_blk_nums'])
+    G = {}
+    inp_p = both[:N]
+    dout = dout.contiguous()
+    if (Hp, Wp) != (H0, W0):
+        dout = K.pad_crop(dout, Hp, Wp)
+    # ending conv (+inp residual has no parameter gradient)
+    d, G['ending.weight'], G['ending.bias'] = conv_bwd(dout, xe, P['ending.weight'], 1, 1)
+    dskips = [None] * n_enc
+    for lvl in reversed(range(len(cfg['dec_blk_nums']))):
+        xin, sv_d = sv_dec[lvl]
+        d = naf_seq_bwd(d, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl], sv_d, G)
+        dskips[n_enc - 1 - lvl] = d                    # gradient of `x + enc_skip` w.r.t. the skip
+        d, G[f'ups.{lvl}.0.weight'] = up_bwd(d, xin, P[f'ups.{lvl}.0.weight'])
+    d = naf_seq_bwd(d, P, 'middle_blks.', cfg['middle_blk_num'], sv_m, G)
+    dcat = naf_seq_bwd(d, P, 'masa_blk_middle.0.', cfg['reffusion_n_blocks'][n_enc], sv_fm, G)
+    dwarp = [None] * 5
+    chan = dcat.shape[1] // 2
+    dwarp[n_enc] = dcat[:, chan:]
+    d = K.slice_channels(dcat, 0, chan)
+    for lvl in reversed(range(n_enc)):
+        sv_f, sv_e, x_skip = sv_levels[lvl]
+        # downs: gradient into the skip tensor, accumulated with the decoder-side skip gradient
+        d, G[f'downs.{lvl}.weight'], G[f'downs.{lvl}.bias'] = conv_bwd(d, x_skip, P[f'downs.{lvl}.weight'], 2, 0,
+                                                                      add_to_dx=dskips[lvl])
+        d = naf_seq_bwd(d, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl], sv_e, G)
+        dcat = naf_seq_bwd(d, P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], sv_f, G)
+        chan = dcat.shape[1] // 2
+        dwarp[lvl] = dcat[:, chan:]
+        d = K.slice_channels(dcat, 0, chan)
+    # intro conv: input image needs no gradient
+    _, G['intro.weight'], G['intro.bias'] = conv_bwd(d, inp_p, P['intro.weight'], 1, 1, need_dx=False)
+    dfeats = masa_bwd(dwarp, feats, N, geo, sv_masa)
+    encoder_bwd(dfeats, P, 'masa_enc.', cfg['ext_n_blocks'], sv_enc, G)
+    return G

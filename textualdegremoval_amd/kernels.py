@@ -1,0 +1,412 @@
+"""Tensor-level wrappers over the C ABI (include/tdr.h).  PyTorch is plumbing
+here: it owns device memory and the HIP stream; all arithmetic happens in
+libtdr_hip.so.  Every wrapper enqueues on torch's current stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import TdrConvDesc, TdrWgradDesc, check
+
+EPI_STD, EPI_GATEBWD, EPI_PSHUF = 0, 1, 2
+PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2 = 0, 1, 2, 3
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _dense_nchw(t):
+    """tensor must be dense in its last 3 dims; returns the image stride."""
+    if t.dim() == 4:
+        n, c, h, w = t.shape
+        assert t.stride(3) == 1 and t.stride(2) == w and t.stride(1) == h * w, 'need NCHW dense per image'
+        return t.stride(0) if n > 1 else c * h * w
+    raise ValueError('expected 4-D tensor')
+
+
+def _vec_ns(v):
+    """per-channel vector [C] (shared, stride 0) or [N,C] (per image)."""
+    if v is None:
+        return 0
+    return v.shape[-1] if v.dim() == 2 else 0
+
+
+_ws_cache = {}
+
+
+def workspace(nfloats, device, tag='main'):
+    """grow-only scratch buffer (stream-ordered reuse)."""
+    key = (tag, device.index if hasattr(device, 'index') else device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_ck(kh_eff):
+    return _lib.load().tdr_conv_ck(kh_eff)
+
+
+def packed_floats(M, Kch, kh_eff):
+    return _lib.load().tdr_packed_weight_floats(M, Kch, kh_eff)
+
+
+def pack_weights(w, mode, out=None):
+    """w: (Cout,Cin,KH,KH) contiguous.  Returns (wp, Mpad, M, Kch, KH_eff)."""
+    lib = _lib.load()
+    Cout, Cin, KH, _ = w.shape
+    if mode == PACK_FWD:
+        M, Kch, KHe = Cout, Cin, KH
+    elif mode == PACK_DGRAD_S1:
+        M, Kch, KHe = Cin, Cout, KH
+    elif mode == PACK_DGRAD_2X2S2:
+        M, Kch, KHe = 4 * Cin, Cout, 1
+    else:
+        M, Kch, KHe = 4 * Cin, Cout, 2
+    n = lib.tdr_packed_weight_floats(M, Kch, KHe)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w.device)
+    assert out.numel() >= n and w.is_contiguous()
+    check(lib.tdr_pack_weights(w.data_ptr(), Cout, Cin, KH, mode, out.data_ptr(), _stream()), 'tdr_pack_weights')
+    return out, (M + 31) // 32 * 32, M, Kch, KHe
+
+
+def pack_patches(blk, G, PH, PW, pstep, dil, off):
+    """blk [B*G, C, BH, BW] -> per-image packed 3x3 patch filters, M = G*PH*PW."""
+    lib = _lib.load()
+    BG, Cc, BH, BW = blk.shape
+    B = BG // G
+    M = G * PH * PW
+    per_b = lib.tdr_packed_weight_floats(M, Cc, 3)
+    wp = torch.empty(B * per_b, dtype=torch.float32, device=blk.device)
+    check(lib.tdr_pack_patches(blk.data_ptr(), B, G, Cc, BH, BW, PH, PW, pstep, dil, off, wp.data_ptr(), _stream()),
+          'tdr_pack_patches')
+    return wp, (M + 31) // 32 * 32, per_b
+
+
+def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None, out=None, Cin=None, epi=EPI_STD,
+                 gate=False, kscale=None, wp_ns=0, bias=None, scale=None, bias2=None, bias2_mul=1.0, res=None,
+                 mask=None, aux=None, relu=False):
+    lib = _lib.load()
+    N, Cx, H, W = x.shape
+    if Cin is None:
+        Cin = Cx // 2 if gate else Cx
+    if OH is None:
+        OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+        OW = (W + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    if out is None:
+        if epi == EPI_PSHUF:
+            out = torch.empty(N, Cout // 4, 2 * OH, 2 * OW, dtype=torch.float32, device=x.device)
+        elif epi == EPI_GATEBWD:
+            out = torch.empty(N, 2 * Cout, OH, OW, dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x.device)
+    d = TdrConvDesc()
+    d.N, d.Cin, d.H, d.W = N, Cin, H, W
+    d.Cout, d.OH, d.OW = Cout, OH, OW
+    d.KH, d.stride, d.dil, d.pad = KH, stride, dil, pad
+    d.inp, d.in_ns = x.data_ptr(), _dense_nchw(x)
+    d.gate = 1 if gate else 0
+    d.kscale, d.kscale_ns = _p(kscale), _vec_ns(kscale)
+    d.wp, d.wp_ns, d.Mpad = wp.data_ptr(), wp_ns, Mpad
+    d.out, d.out_ns = out.data_ptr(), _dense_nchw(out)
+    d.epi = epi
+    d.bias, d.bias_ns = _p(bias), _vec_ns(bias)
+    d.scale, d.scale_ns = _p(scale), _vec_ns(scale)
+    d.bias2, d.bias2_ns, d.bias2_mul = _p(bias2), _vec_ns(bias2), float(bias2_mul)
+    d.res, d.res_ns = _p(res), (_dense_nchw(res) if res is not None else 0)
+    d.mask, d.mask_ns = _p(mask), (_dense_nchw(mask) if mask is not None else 0)
+    d.aux, d.aux_ns = _p(aux), (_dense_nchw(aux) if aux is not None else 0)
+    d.relu = 1 if relu else 0
+    check(lib.tdr_conv_forward(C.byref(d), _stream()), 'tdr_conv_forward')
+    return out
+
+
+def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=False):
+    """returns G [groups, Cout, Cin, KH, KH] (groups = N if per_image else 1)."""
+    lib = _lib.load()
+    N, _, H, W = x.shape
+    _, _, OH, OW = dout.shape
+    d = TdrWgradDesc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.OH, d.OW = N, Cin, H, W, Cout, OH, OW
+    d.KH, d.stride, d.pad = KH, stride, pad
+    d.inp, d.in_ns, d.gate = x.data_ptr(), _dense_nchw(x), 1 if gate else 0
+    d.dout, d.dout_ns = dout.data_ptr(), _dense_nchw(dout)
+    groups = N if per_image else 1
+    g = torch.empty(groups, Cout, Cin, KH, KH, dtype=torch.float32, device=x.device)
+    d.g = g.data_ptr()
+    d.per_image = 1 if per_image else 0
+    need = lib.tdr_wgrad_ws_floats(C.byref(d))
+    ws = workspace(need, x.device, 'wgrad')
+    d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+    check(lib.tdr_conv_wgrad(C.byref(d), _stream()), 'tdr_conv_wgrad')
+    return g
+
+
+def layernorm2d_fwd(x, w, b, eps):
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x.device)
+    mu = torch.empty(N, H * W, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mu)
+    check(lib.tdr_layernorm2d_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), b.data_ptr(), float(eps), N, Cc, H * W,
+                                  y.data_ptr(), mu.data_ptr(), rstd.data_ptr(), _stream()), 'tdr_layernorm2d_fwd')
+    return y, mu, rstd
+
+
+def layernorm2d_bwd(go, x, mu, rstd, w, add=None):
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    assert go.is_contiguous()
+    gx = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x.device)
+    gw = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    gb = torch.empty_like(gw)
+    ws = workspace(lib.tdr_ln_ws_floats(N, Cc, H * W), x.device)
+    add_ns = _dense_nchw(add) if add is not None else 0
+    add_C = add.shape[1] if add is not None else 0
+    check(lib.tdr_layernorm2d_bwd(go.data_ptr(), x.data_ptr(), _dense_nchw(x), mu.data_ptr(), rstd.data_ptr(),
+                                  w.data_ptr(), _p(add), add_ns, add_C, N, Cc, H * W, gx.data_ptr(), gw.data_ptr(),
+                                  gb.data_ptr(), ws.data_ptr(), _stream()), 'tdr_layernorm2d_bwd')
+    return gx, gw, gb
+
+
+def dwsg_fwd(t, w, b):
+    lib = _lib.load()
+    N, C2, H, W = t.shape
+    Cc = C2 // 2
+    assert t.is_contiguous()
+    g = torch.empty(N, Cc, H, W, dtype=torch.float32, device=t.device)
+    pooled = torch.empty(N, Cc, dtype=torch.float32, device=t.device)
+    ws = workspace(lib.tdr_dwsg_ws_floats(N, Cc, H, W), t.device)
+    check(lib.tdr_dwsg_fwd(t.data_ptr(), w.data_ptr(), b.data_ptr(), N, Cc, H, W, g.data_ptr(), pooled.data_ptr(),
+                           ws.data_ptr(), _stream()), 'tdr_dwsg_fwd')
+    return g, pooled
+
+
+def dwsg_bwd(dg, t, w, b):
+    lib = _lib.load()
+    N, C2, H, W = t.shape
+    Cc = C2 // 2
+    assert dg.is_contiguous() and t.is_contiguous()
+    dt = torch.empty_like(t)
+    dw = torch.empty(C2, 1, 3, 3, dtype=torch.float32, device=t.device)
+    db = torch.empty(C2, dtype=torch.float32, device=t.device)
+    ws = workspace(lib.tdr_dwsg_ws_floats(N, Cc, H, W), t.device)
+    check(lib.tdr_dwsg_bwd(dg.data_ptr(), t.data_ptr(), w.data_ptr(), b.data_ptr(), N, Cc, H, W, dt.data_ptr(),
+                           dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream()), 'tdr_dwsg_bwd')
+    return dt, dw, db
+
+
+def sca_fwd(pooled, wsca, bsca):
+    lib = _lib.load()
+    N, Cc = pooled.shape
+    s = torch.empty(N, Cc, dtype=torch.float32, device=pooled.device)
+    check(lib.tdr_sca_fwd(pooled.data_ptr(), wsca.data_ptr(), bsca.data_ptr(), N, Cc, s.data_ptr(), _stream()), 'tdr_sca_fwd')
+    return s
+
+
+def sca_bwd(G3, S3, w3, b3, beta, s, pooled, wsca):
+    lib = _lib.load()
+    N, Cc = s.shape
+    dev = s.device
+    dw3 = torch.empty(Cc, Cc, 1, 1, dtype=torch.float32, device=dev)
+    db3 = torch.empty(Cc, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(1, Cc, 1, 1, dtype=torch.float32, device=dev)
+    dwsca = torch.empty(Cc, Cc, 1, 1, dtype=torch.float32, device=dev)
+    dbsca = torch.empty(Cc, dtype=torch.float32, device=dev)
+    dpooled = torch.empty(N, Cc, dtype=torch.float32, device=dev)
+    ws = torch.empty(N * Cc, dtype=torch.float32, device=dev)
+    check(lib.tdr_sca_bwd(G3.data_ptr(), S3.data_ptr(), w3.data_ptr(), b3.data_ptr(), beta.data_ptr(), s.data_ptr(),
+                          pooled.data_ptr(), wsca.data_ptr(), N, Cc, dw3.data_ptr(), db3.data_ptr(), dbeta.data_ptr(),
+                          dwsca.data_ptr(), dbsca.data_ptr(), dpooled.data_ptr(), ws.data_ptr(), _stream()), 'tdr_sca_bwd')
+    return dw3, db3, dbeta, dwsca, dbsca, dpooled
+
+
+def scaled_conv_param_grads(G, S, w, b, gamma):
+    """G [Cout,Cin], S [Cout]; w/b/gamma may have more rows than Cout (first rows are used)."""
+    lib = _lib.load()
+    Cout, Cin = G.shape[-2], G.shape[-1]
+    dev = G.device
+    dw = torch.empty(Cout, Cin, dtype=torch.float32, device=dev)
+    db = torch.empty(Cout, dtype=torch.float32, device=dev)
+    dg = torch.empty(Cout, dtype=torch.float32, device=dev)
+    check(lib.tdr_scaled_conv_param_grads(G.data_ptr(), S.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), Cout,
+                                          Cin, dw.data_ptr(), db.data_ptr(), dg.data_ptr(), _stream()),
+          'tdr_scaled_conv_param_grads')
+    return dw, db, dg
+
+
+def channel_sum(x):
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.tdr_chansum_ws_floats(N, Cc, H * W), x.device)
+    check(lib.tdr_channel_sum(x.data_ptr(), _dense_nchw(x), N, Cc, H * W, out.data_ptr(), ws.data_ptr(), _stream()),
+          'tdr_channel_sum')
+    return out
+
+
+def copy_rows(src, src_ns, dst, dst_ns, N, length):
+    check(_lib.load().tdr_copy_rows(src.data_ptr(), src_ns, dst.data_ptr(), dst_ns, N, length, _stream()), 'tdr_copy_rows')
+
+
+def add_rows(src, src_ns, dst, dst_ns, N, length):
+    check(_lib.load().tdr_add_rows(src.data_ptr(), src_ns, dst.data_ptr(), dst_ns, N, length, _stream()), 'tdr_add_rows')
+
+
+def concat2(a, b):
+    """cat([a,b], dim=1) with the library's copy kernel (:719,727)."""
+    N, Ca, H, W = a.shape
+    Cb = b.shape[1]
+    out = torch.empty(N, Ca + Cb, H, W, dtype=torch.float32, device=a.device)
+    tot = (Ca + Cb) * H * W
+    copy_rows(a, _dense_nchw(a), out, tot, N, Ca * H * W)
+    copy_rows(b, _dense_nchw(b), out[:, Ca:], tot, N, Cb * H * W)
+    return out
+
+
+def slice_channels(x, c0, c1):
+    """contiguous copy of x[:, c0:c1]."""
+    N, Cc, H, W = x.shape
+    out = torch.empty(N, c1 - c0, H, W, dtype=torch.float32, device=x.device)
+    copy_rows(x[:, c0:c1], _dense_nchw(x), out, (c1 - c0) * H * W, N, (c1 - c0) * H * W)
+    return out
+
+
+def add_(dst, src):
+    """dst += src (same shape, dense per image)."""
+    N = dst.shape[0]
+    per = dst[0].numel()
+    add_rows(src, _dense_nchw(src) if src.dim() == 4 else per, dst, _dense_nchw(dst) if dst.dim() == 4 else per, N, per)
+    return dst
+
+
+def pixel_unshuffle2(x):
+    N, Cc, H2, W2 = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(N, 4 * Cc, H2 // 2, W2 // 2, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_pixel_unshuffle2(x.data_ptr(), N, Cc, H2 // 2, W2 // 2, out.data_ptr(), _stream()),
+          'tdr_pixel_unshuffle2')
+    return out
+
+
+def pad_crop(x, Hd, Wd):
+    N, Cc, Hs, Ws = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(N, Cc, Hd, Wd, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_pad_crop(x.data_ptr(), N, Cc, Hs, Ws, out.data_ptr(), Hd, Wd, _stream()), 'tdr_pad_crop')
+    return out
+
+
+def relu_bwd(go, act):
+    assert go.is_contiguous() and act.is_contiguous()
+    out = torch.empty_like(go)
+    check(_lib.load().tdr_relu_bwd(go.data_ptr(), act.data_ptr(), go.numel(), out.data_ptr(), _stream()), 'tdr_relu_bwd')
+    return out
+
+
+def l1_loss(pred, target, loss_weight=1.0):
+    assert pred.is_contiguous() and target.is_contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred)
+    ws = workspace(4096, pred.device, 'l1')
+    check(_lib.load().tdr_l1_loss(pred.data_ptr(), target.data_ptr(), pred.numel(), float(loss_weight), loss.data_ptr(),
+                                  dpred.data_ptr(), ws.data_ptr(), _stream()), 'tdr_l1_loss')
+    return loss, dpred
+
+
+# ------------------------------------------------------------------ MASA
+def lr_blocks_fwd(feat, py, px, ky, kx):
+    N, Cc, H, W = feat.shape
+    assert feat.is_contiguous()
+    blk = torch.empty(N * py * px, Cc, ky + 2, kx + 2, dtype=torch.float32, device=feat.device)
+    check(_lib.load().tdr_lr_blocks_fwd(feat.data_ptr(), N, Cc, H, W, py, px, ky, kx, blk.data_ptr(), _stream()),
+          'tdr_lr_blocks_fwd')
+    return blk
+
+
+def lr_blocks_bwd(dblk, N, Cc, H, W, py, px, ky, kx):
+    dfeat = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dblk.device)
+    check(_lib.load().tdr_lr_blocks_bwd(dblk.data_ptr(), N, Cc, H, W, py, px, ky, kx, dfeat.data_ptr(), _stream()),
+          'tdr_lr_blocks_bwd')
+    return dfeat
+
+
+def patch_inv_norm(x, OH, OW, dil=1, pad=0, step=1, off=0, out=None):
+    B, Cc, H, W = x.shape
+    assert x.is_contiguous()
+    inv = out if out is not None else torch.empty(B, OH, OW, dtype=torch.float32, device=x.device)
+    assert inv.is_contiguous() and inv.numel() == B * OH * OW
+    check(_lib.load().tdr_patch_inv_norm(x.data_ptr(), B, Cc, H, W, OH, OW, dil, pad, step, off, inv.data_ptr(), _stream()),
+          'tdr_patch_inv_norm')
+    return inv
+
+
+def coarse_argmax_box(dots, invq, invk, N, P, Hr, Wr, diameter):
+    ND = dots.shape[0]
+    dev = dots.device
+    index = torch.empty(N * P, dtype=torch.int32, device=dev)
+    y1 = torch.empty_like(index)
+    x1 = torch.empty_like(index)
+    check(_lib.load().tdr_coarse_argmax_box(dots.data_ptr(), invq.data_ptr(), invk.data_ptr(), ND, N, P, Hr, Wr, diameter,
+                                            index.data_ptr(), y1.data_ptr(), x1.data_ptr(), _stream()),
+          'tdr_coarse_argmax_box')
+    return index, y1, x1
+
+
+def gather_ref_block(feat, y1, x1, P, side, s):
+    N, Cc, H, W = feat.shape
+    out = torch.empty(N * P, Cc, side * s, side * s, dtype=torch.float32, device=feat.device)
+    check(_lib.load().tdr_gather_ref_block(feat.data_ptr(), N, Cc, H, W, y1.data_ptr(), x1.data_ptr(), P, side, s,
+                                           out.data_ptr(), _stream()), 'tdr_gather_ref_block')
+    return out
+
+
+def scatter_ref_block(dblk, dfeat, y1, x1, P, side):
+    N, Cc, H, W = dfeat.shape
+    check(_lib.load().tdr_scatter_ref_block(dblk.data_ptr(), N, Cc, H, W, y1.data_ptr(), x1.data_ptr(), P, side,
+                                            dfeat.data_ptr(), _stream()), 'tdr_scatter_ref_block')
+
+
+def fine_argmax(dots, invq, invk, B, P, R):
+    dev = dots.device
+    index_all = torch.empty(B, P, dtype=torch.int32, device=dev)
+    soft_att = torch.empty(B, P, dtype=torch.float32, device=dev)
+    check(_lib.load().tdr_fine_argmax(dots.data_ptr(), invq.data_ptr(), invk.data_ptr(), B, P, R, index_all.data_ptr(),
+                                      soft_att.data_ptr(), _stream()), 'tdr_fine_argmax')
+    return index_all, soft_att
+
+
+def fine_search_bwd(datt, soft_att, index_all, lrb, refb, invq, invk, K, D):
+    B, Cc = lrb.shape[0], lrb.shape[1]
+    dlrb = torch.empty_like(lrb)
+    drefb = torch.empty_like(refb)
+    check(_lib.load().tdr_fine_search_bwd(datt.data_ptr(), soft_att.data_ptr(), index_all.data_ptr(), lrb.data_ptr(),
+                                          refb.data_ptr(), invq.data_ptr(), invk.data_ptr(), B, Cc, K, D, dlrb.data_ptr(),
+                                          drefb.data_ptr(), _stream()), 'tdr_fine_search_bwd')
+    return dlrb, drefb
+
+
+def transfer_fwd(feat, y1, x1, index_all, soft_att, py, px, K, side, s, out=None):
+    N, Cc, H, W = feat.shape
+    assert feat.is_contiguous()
+    if out is None:
+        out = torch.empty(N, Cc, py * K * s, px * K * s, dtype=torch.float32, device=feat.device)
+    check(_lib.load().tdr_transfer_fwd(feat.data_ptr(), N, Cc, H, W, y1.data_ptr(), x1.data_ptr(), index_all.data_ptr(),
+                                       soft_att.data_ptr(), py, px, K, side, s, out.data_ptr(), _dense_nchw(out),
+                                       _stream()), 'tdr_transfer_fwd')
+    return out
+
+
+def transfer_bwd(dout, feat, y1, x1, index_all, soft_att, py, px, K, side, s, dfeat, datt):
+    N, Cc, H, W = feat.shape
+    ws = workspace(N * py * K * s * px * K * s, feat.device, 'transfer')
+    check(_lib.load().tdr_transfer_bwd(dout.data_ptr(), _dense_nchw(dout), feat.data_ptr(), N, Cc, H, W, y1.data_ptr(),
+                                       x1.data_ptr(), index_all.data_ptr(), soft_att.data_ptr(), py, px, K, side, s,
+                                       dfeat.data_ptr(), datt.data_ptr(), ws.data_ptr(), _stream()), 'tdr_transfer_bwd')
