@@ -83,8 +83,9 @@ def test_masa_encoder_vs_reference_golden(E):
     P = {str(k): T(g['enc_p_' + str(k)]) for k in g['enc_names']}
     Pc = cuda_params(P)
     feats, saved = E.encoder_fwd(T(g['enc_x']).cuda(), Pc, '', [1, 1, 1, 1])
-    for i, f in enumerate(feats):
-        assert maxdiff(f, T(g[f'enc_f{i}'])) < 3e-5
+    for i, f in enumerate(feats):            # activations here are O(100): relative tolerance
+        ref = T(g[f'enc_f{i}'])
+        assert maxdiff(f, ref) < 3e-6 * max(1.0, ref.abs().max().item())
     # loss = sum_i (i+1) * mean(f_i^2)  ->  df_i = 2 (i+1) f_i / numel
     dfe = [(2.0 * (i + 1) / f.numel()) * f for i, f in enumerate(feats)]
     G = {}
@@ -94,7 +95,8 @@ def test_masa_encoder_vs_reference_golden(E):
         assert maxdiff(G[k].view_as(ref), ref) < 3e-5 * max(1.0, ref.abs().max().item()), k
 
 
-CASES = [('net_w8_128_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+CASES = [('net_w8_256_b2_clear', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+         ('net_w8_128_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_w8_256_b2', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_w8_120x100_pad', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_cfg1_w16_128', dict(width=16, nf=16, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2]))]
@@ -114,9 +116,27 @@ def test_whole_net_vs_reference_golden(E, name, kw):
     index, index_all, soft_att = sv_masa[4], sv_masa[7], sv_masa[8]
     gi = g['index'][..., 0] if g['index'].ndim == 3 else g['index']
     assert np.array_equal(index.cpu().numpy().reshape(gi.shape), gi)
+    # hard-attention protocol (SURVEY hard part 2): the arg-max may only differ from the reference
+    # where the reference's own top-1/top-2 gap is below 1e-5 (summation-order noise); such cases are
+    # then compared teacher-forced (reference indices fed to the transfer kernels).
     ia = index_all.cpu().numpy().reshape(g['index_all'].shape)
-    agree = (ia == g['index_all']).mean()
-    assert agree == 1.0, f'fine-search index agreement {agree}'
+    mism = ia != g['index_all']
+    assert mism.mean() <= 0.005, f'fine-search index agreement {1 - mism.mean()}'
+    assert (g['fine_gap'].reshape(mism.shape)[mism] < 1e-5).all(), 'index flip at a non-tie'
+    if mism.any():
+        forced = torch.from_numpy(g['index_all'].reshape(index_all.shape)).int().cuda()
+        orig = K.fine_argmax
+
+        def teacher(dots, invq, invk, B, Pn, R):
+            _, _ = orig(dots, invq, invk, B, Pn, R)
+            val = (dots.view(B, Pn, R) * invq.view(B, Pn, 1) * invk.view(B, 1, R)).gather(2, forced.long().view(B, Pn, 1))
+            return forced, val.view(B, Pn).contiguous()
+        K.fine_argmax = teacher
+        try:
+            out, saved = E.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
+        finally:
+            K.fine_argmax = orig
+        soft_att = saved[6][8]
     assert maxdiff(soft_att.view(-1), T(g['soft_att']).reshape(-1)) < 1e-5
     assert maxdiff(out, T(g['out'])) < 1e-4
     loss, dpred = K.l1_loss(out.contiguous(), gt.cuda().contiguous())

@@ -7,6 +7,11 @@ or `make -C textualdegremoval_amd/csrc`.
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64; it must be the HIP runtime already resident
+# when libtdr_hip.so is dlopen'ed so both share one runtime (one device context,
+# one set of streams).  Loading in the other order gives two runtimes.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtdr_hip.so')
 
