@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: train images/sec of the NAFNet-ref guided-restoration step
+(BASELINE.json configs[1]: NAFNet-width32 + ref fusion, 512x512, sigma=15, bs=4/GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+(N>1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI.)
+
+A step = feed_train_data + optimize_parameters of RefGuidedImageCleanModel:
+forward, L1, hand-written backward, gradient all-reduce (N>1), global-norm clip,
+AdamW -- all HIP kernels, fp32, synthetic inputs resident in HBM.
+Prints ONE JSON line (rank 0)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work per image, SURVEY.md 8(d) (module-granular fp32 traffic; dense conv+matmul FLOPs, bwd = 2x fwd)
+CFG2 = dict(B_alg=52.2e9, F_alg=2.00e12)
+PEAK_HBM, PEAK_F32 = 8.0e12, 157.3e12
+
+
+def make_opt(width, enc, batch_hw, dist_on):
+    return {
+        'model_type': 'RefGuidedImageCleanModel', 'num_gpu': 1, 'dist': dist_on, 'is_train': True,
+        'network_g': dict(type='NAFNetRefFusion', width=width, nf=width, enc_blk_nums=enc, dec_blk_nums=[1, 1, 1, 1],
+                          middle_blk_num=1, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2]),
+        'path': {},
+        'train': {'optim_g': {'type': 'AdamW', 'lr': 2e-4, 'ref_lr': 1e-4, 'weight_decay': 1e-4, 'betas': [0.9, 0.999]},
+                  'scheduler': {'type': 'CosineAnnealingRestartCyclicLR', 'periods': [306000, 694000],
+                                'restart_weights': [1, 1], 'eta_mins': [3e-4, 1e-6]},
+                  'pixel_opt': {'type': 'L1Loss', 'loss_weight': 1, 'reduction': 'mean'},
+                  'use_grad_clip': True, 'total_iter': 1000000, 'warmup_iter': -1},
+        'logger': {'check_freq': 10 ** 9}, 'val': {}, 'scale': 1,
+    }
+
+
+def cpu_baseline(width, enc, H, seconds_budget=30.0):
+    """Reported baseline only: the CPU oracle (a port of the reference's path, pinned to the
+    reference by tests/golden) timed on this host's cores on a bounded sample (B=1)."""
+    from oracle import nafnet_ref_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.default_cfg(width=width, nf=width, enc_blk_nums=enc, ext_n_blocks=[4, 4, 4, 4],
+                        reffusion_n_blocks=[2, 2, 2, 2, 2])
+    tr = O.OracleTrainer(O.synth_params(cfg, seed=0), cfg)
+    lq, gt, ref = O.synth_pair(1, 128, 128, seed=1)
+    tr.step(lq, gt, ref)                                  # thread-pool / allocator warm-up
+    lq, gt, ref = O.synth_pair(1, H, H, seed=2)
+    t0 = time.time()
+    n = 0
+    while True:
+        tr.step(lq, gt, ref)
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
+            break
+    dt = time.time() - t0
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} train step(s), batch 1 x {H}x{H}, same network, torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=4)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--width', type=int, default=32)
+    ap.add_argument('--enc', type=str, default='1,1,1,28')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+    enc = [int(v) for v in a.enc.split(',')]
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+    from textualdegremoval_amd.models import create_model
+    from textualdegremoval_amd.utils.synthetic import randomize_gates, synthetic_pair
+    from textualdegremoval_amd import kernels as K
+
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    model = create_model(make_opt(a.width, enc, a.size, world > 1))
+    randomize_gates(model.net_g)
+    data = synthetic_pair(a.batch, a.size, a.size, seed=1234 + rank)
+    data = {k: v.cuda() for k, v in data.items()}          # inputs resident in HBM before the timed region
+
+    def step(it):
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.feed_train_data(data)
+        model.optimize_parameters(it)
+
+    it = 0
+    for _ in range(a.warmup):
+        it += 1
+        step(it)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        it += 1
+        step(it)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = model.get_current_log()['l_pix']
+
+    # ---- roofline of the dominant kernel family (3x3 stride-1 implicit GEMM on the fp32 matrix
+    # cores: masa_enc forward + data-gradient launches), measured with HIP events on the launch stream
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        recs = []
+        orig = K.conv_forward
+
+        def timed(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, **kw):
+            if KH == 3 and stride == 1 and dil == 1 and kw.get('wp_ns', 0) == 0:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
+                e1.record()
+                recs.append((2.0 * x.shape[0] * Cout * x.shape[1] * 9 * out.shape[2] * out.shape[3], e0, e1))
+                return out
+            return orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
+        K.conv_forward = timed
+        try:
+            it += 1
+            step(it)
+            torch.cuda.synchronize()
+        finally:
+            K.conv_forward = orig
+        fl = sum(r[0] for r in recs)
+        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel<KH=3,S=1> (fp32 v_mfma_f32_32x32x2_f32)',
+                'achieved': ach, 'peak': PEAK_F32 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_F32 / 1e12),
+                'launches': len(recs), 'avg_launch_ms': ms / max(len(recs), 1),
+                'alg_flop_per_launch': fl / max(len(recs), 1), 'traffic': None}
+
+    if rank == 0:
+        ips = world * a.batch * a.steps / dt
+        per_gpu = ips / world
+        is_cfg2 = (a.width, enc, a.size, a.batch) == (32, [1, 1, 1, 28], 512, 4)
+        line = {
+            'metric': 'train images/sec (512x512, bs=4/GPU)', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
+                                   f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW',
+                       'width': a.width, 'enc_blk_nums': enc, 'global_batch': world * a.batch,
+                       'parallelism': f'dp{world}', 'dino_match': 'skipped bit-identically (ref size == lq size, N=1 window)'},
+            'final_loss': loss,
+        }
+        if is_cfg2:
+            line['roofline_step'] = {'achieved_hbm_frac': CFG2['B_alg'] * per_gpu / PEAK_HBM,
+                                     'achieved_f32_flop_frac': CFG2['F_alg'] * per_gpu / PEAK_F32,
+                                     'alg_bytes_per_image': CFG2['B_alg'], 'alg_flop_per_image': CFG2['F_alg']}
+        if roof is not None:
+            line['roofline'] = roof
+        if not a.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(a.width, enc, a.size)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -536,6 +536,15 @@ __global__ void rows_kernel(const float* __restrict__ src, long src_ns, float* _
     }
 }
 
+template <bool ADD>
+__global__ void rows_scalar_kernel(const float* __restrict__ src, long src_ns, float* __restrict__ dst, long dst_ns, long len) {
+    const int n = blockIdx.y;
+    const float* s = src + (long)n * src_ns;
+    float* d = dst + (long)n * dst_ns;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < len; i += (long)gridDim.x * blockDim.x)
+        d[i] = ADD ? d[i] + s[i] : s[i];
+}
+
 __global__ void pixel_unshuffle2_kernel(const float* __restrict__ in, int C, int H, int W, long total,
                                         float* __restrict__ out) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -745,7 +754,12 @@ extern "C" int tdr_channel_sum(const float* x, int64_t x_ns, int N, int C, int H
 extern "C" int tdr_copy_rows(const float* src, int64_t src_ns, float* dst, int64_t dst_ns, int N, int64_t len,
                              void* stream) {
     TDR_REQUIRE(src && dst, "tdr_copy_rows: null pointer");
-    TDR_REQUIRE(len % 4 == 0 && src_ns % 4 == 0 && dst_ns % 4 == 0, "tdr_copy_rows: lengths/strides must be multiples of 4");
+    if (len % 4 || src_ns % 4 || dst_ns % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {
+        hipLaunchKernelGGL(rows_scalar_kernel<false>, dim3(grid1d(len, 2048), N), dim3(256), 0, (hipStream_t)stream, src,
+                           (long)src_ns, dst, (long)dst_ns, (long)len);
+        TDR_LAUNCH_CHECK("copy_rows");
+        return TDR_OK;
+    }
     hipLaunchKernelGGL(rows_kernel<false>, dim3(grid1d(len / 4, 2048), N), dim3(256), 0, (hipStream_t)stream, src,
                        (long)src_ns, dst, (long)dst_ns, (long)(len / 4));
     TDR_LAUNCH_CHECK("copy_rows");
@@ -755,7 +769,12 @@ extern "C" int tdr_copy_rows(const float* src, int64_t src_ns, float* dst, int64
 extern "C" int tdr_add_rows(const float* src, int64_t src_ns, float* dst, int64_t dst_ns, int N, int64_t len,
                             void* stream) {
     TDR_REQUIRE(src && dst, "tdr_add_rows: null pointer");
-    TDR_REQUIRE(len % 4 == 0 && src_ns % 4 == 0 && dst_ns % 4 == 0, "tdr_add_rows: lengths/strides must be multiples of 4");
+    if (len % 4 || src_ns % 4 || dst_ns % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {
+        hipLaunchKernelGGL(rows_scalar_kernel<true>, dim3(grid1d(len, 2048), N), dim3(256), 0, (hipStream_t)stream, src,
+                           (long)src_ns, dst, (long)dst_ns, (long)len);
+        TDR_LAUNCH_CHECK("add_rows");
+        return TDR_OK;
+    }
     hipLaunchKernelGGL(rows_kernel<true>, dim3(grid1d(len / 4, 2048), N), dim3(256), 0, (hipStream_t)stream, src,
                        (long)src_ns, dst, (long)dst_ns, (long)(len / 4));
     TDR_LAUNCH_CHECK("add_rows");

@@ -363,11 +363,13 @@ def _pad_into(src, dst_view):
         K.copy_rows(tmp, Cc * Hd * Wd, dst_view, Cc * Hd * Wd, N, Cc * Hd * Wd)
 
 
-def net_bwd(dout, P, cfg, saved):
-    """dout [N,3,H0,W0] -> dict of parameter gradients keyed like P."""
+def net_bwd(dout, P, cfg, saved, G=None):
+    """dout [N,3,H0,W0] -> dict of parameter gradients keyed like P.  `G` may be a caller's
+    dict-like collector (e.g. parallel.GradSink, which starts the RCCL all-reduce of a
+    gradient bucket as soon as its last tensor is stored)."""
     N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe = saved
     n_enc = len(cfg['enc_blk_nums'])
-    G = {}
+    G = {} if G is None else G
     inp_p = both[:N]
     dout = dout.contiguous()
     if (Hp, Wp) != (H0, W0):

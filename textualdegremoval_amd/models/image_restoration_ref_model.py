@@ -1,0 +1,206 @@
+"""RefGuidedImageCleanModel on the HIP engine -- the train/step API of the
+reference's models/image_restoration_ref_model.py (:56-438) with the same
+method names, config keys and error behaviour, so
+scripts/train/main_train_restoration_with_ref_input.py drives it unchanged.
+
+optimize_parameters = DINO window match (bit-identically skipped when ref and lq
+have equal size: N==1 window, top-1 of one) -> forward -> L1 -> hand-written
+backward -> RCCL gradient average (dist) -> global-norm clip(0.01) + AdamW,
+all on libtdr_hip.so kernels."""
+import importlib
+import os
+from collections import OrderedDict
+from copy import deepcopy
+from functools import partial
+
+import torch
+
+from .. import engine as E
+from .. import kernels as K
+from .. import losses as loss_module
+from .. import metrics as metric_module
+from ..metrics import tensor2img
+from ..optim import FusedClipAdamW
+from .archs import define_network
+from .base_model import BaseModel, logger
+
+
+class RefGuidedImageCleanModel(BaseModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.net_g = define_network(deepcopy(opt['network_g']))
+        self.net_g = self.model_to_device(self.net_g)
+        self.print_network(self.net_g)
+        # DINOv2 window matcher (reference :74-90).  Only needed when ref is larger than lq.
+        self.net_ext = None
+        self.pretrain_dino = self.opt['path'].get('pretrain_dino')
+        load_path = self.opt['path'].get('pretrain_network_g', None)
+        if load_path is not None:
+            self.load_network(self.net_g, load_path, self.opt['path'].get('strict_load_g', False),
+                              param_key=self.opt['path'].get('param_key', 'params'))
+        if self.is_train:
+            self.init_training_settings()
+
+    def init_training_settings(self):
+        self.net_g.train()
+        train_opt = self.opt['train']
+        self.ema_decay = train_opt.get('ema_decay', 0)
+        if self.ema_decay > 0:
+            self.net_g_ema = define_network(deepcopy(self.opt['network_g'])).to(self.device)
+            load_path = self.opt['path'].get('pretrain_network_g', None)
+            if load_path is not None:
+                self.load_network(self.net_g_ema, load_path, self.opt['path'].get('strict_load_g', True), 'params_ema')
+            else:
+                self.model_ema(0)
+            self.net_g_ema.eval()
+        if train_opt.get('pixel_opt'):
+            pixel_type = train_opt['pixel_opt'].pop('type')
+            self.cri_pix = getattr(loss_module, pixel_type)(**train_opt['pixel_opt']).to(self.device)
+        else:
+            raise ValueError('pixel loss are None.')
+        self.setup_optimizers()
+        self.setup_schedulers()
+
+    def setup_optimizers(self):
+        train_opt = self.opt['train']
+        # reference quirk R3: the key read is 'fix_iterations' (YAMLs set 'param_fix_iterations')
+        self.param_fix_iters = train_opt['fix_iterations'] if 'fix_iterations' in train_opt else None
+        optim_params, optim_ref_params = [], []
+        for k, v in self.net_g.named_parameters():
+            (optim_ref_params if 'masa' in k else optim_params).append(v)
+        groups = [{'params': optim_params, 'lr': train_opt['optim_g']['lr']},
+                  {'params': optim_ref_params, 'lr': train_opt['optim_g']['ref_lr']}]
+        optim_type = train_opt['optim_g'].pop('type')
+        clip = bool(train_opt.get('use_grad_clip', False))
+        if optim_type == 'AdamW':
+            if self.device.type == 'cuda':
+                self.optimizer_g = FusedClipAdamW(groups, lr=train_opt['optim_g']['lr'],
+                                                  weight_decay=train_opt['optim_g']['weight_decay'],
+                                                  betas=train_opt['optim_g']['betas'], max_norm=0.01, use_grad_clip=clip)
+            else:
+                self.optimizer_g = torch.optim.AdamW(groups, lr=train_opt['optim_g']['lr'],
+                                                     weight_decay=train_opt['optim_g']['weight_decay'],
+                                                     betas=train_opt['optim_g']['betas'])
+        elif optim_type == 'Adam':
+            kw = {k: v for k, v in train_opt['optim_g'].items() if k != 'ref_lr'}
+            self.optimizer_g = torch.optim.Adam(groups, **kw)
+        else:
+            raise NotImplementedError(f'optimizer {optim_type} is not supperted yet.')
+        self.optimizers.append(self.optimizer_g)
+
+    def feed_train_data(self, data):
+        self.lq = data['lq'].to(self.device)
+        if 'gt' in data:
+            self.gt = data['gt'].to(self.device)
+        if 'ref' in data:
+            self.ref = data['ref'].to(self.device)
+
+    feed_data = feed_train_data
+
+    # ------------------------------------------------------------------ step
+    def _match_reference_window(self):
+        """reference :215-247.  With ref.shape == lq.shape the unfold yields one window and
+        top-1 of one candidate is that window: ref_in == ref bit-exactly, so the two frozen
+        ViT passes (whose only output is that arg-max) are skipped."""
+        if self.ref.shape[-2:] == self.lq.shape[-2:]:
+            return self.ref
+        raise NotImplementedError(
+            'ref larger than lq needs the DINOv2 ViT-B/14 window matcher (SURVEY 8a row a22), which is not on the '
+            'HIP path yet; feed a ref of the lq size (what the shipped data pipeline produces after matching).')
+
+    def optimize_parameters(self, current_iter):
+        if self.param_fix_iters is not None and current_iter < self.param_fix_iters:
+            raise NotImplementedError('fix_iterations (frozen masa params) is not supported on the HIP path')
+        self.ref_in = self._match_reference_window()
+        net = self.get_bare_model(self.net_g)
+        names = [k for k, _ in net.named_parameters()]
+        params = [p for _, p in net.named_parameters()]
+        fused = self.device.type == 'cuda' and isinstance(self.cri_pix, loss_module.L1Loss) and \
+            self.cri_pix.reduction == 'mean'
+        if not fused:
+            raise NotImplementedError('HIP step needs a GPU and pixel_opt.type == L1Loss (the YAML default)')
+        P = {k: p.data for k, p in zip(names, params)}
+        out, saved = E.net_fwd(P, net.cfg, self.lq, self.ref_in)
+        self.output = out
+        loss, dpred = K.l1_loss(out.contiguous(), self.gt.contiguous(), float(self.cri_pix.loss_weight))
+        loss_dict = OrderedDict(l_pix=loss[0])
+        if not hasattr(self, 'grad_reducer'):
+            from ..parallel import GradAllReducer
+            self.grad_reducer = GradAllReducer(list(zip(names, params)))
+        sink = self.grad_reducer.begin()
+        E.net_bwd(dpred, P, net.cfg, saved, G=sink)
+        grads = self.grad_reducer.finish()
+        for k, p in zip(names, params):
+            p.grad = grads[k]
+        self.optimizer_g.use_grad_clip = bool(self.opt['train']['use_grad_clip'])
+        self.optimizer_g.step()
+        self.log_dict = self.reduce_loss_dict(loss_dict)
+        if self.ema_decay > 0:
+            self.model_ema(decay=self.ema_decay)
+
+    # ------------------------------------------------------------------ validation (reference :286-409)
+    def pad_test(self, window_size):
+        import torch.nn.functional as F
+        scale = self.opt.get('scale', 1)
+        _, _, h, w = self.lq.size()
+        mod_pad_h = (window_size - h % window_size) % window_size
+        mod_pad_w = (window_size - w % window_size) % window_size
+        img = F.pad(self.lq, (0, mod_pad_w, 0, mod_pad_h), 'reflect')
+        self.nonpad_test(img)
+        _, _, h, w = self.output.size()
+        self.output = self.output[:, :, 0:h - mod_pad_h * scale, 0:w - mod_pad_w * scale]
+
+    def nonpad_test(self, img=None):
+        img = self.lq if img is None else img
+        net = self.net_g_ema if hasattr(self, 'net_g_ema') else self.net_g
+        net.eval()
+        with torch.no_grad():
+            pred = net(img, self.ref)
+        self.output = pred[-1] if isinstance(pred, list) else pred
+        if net is self.net_g:
+            self.net_g.train()
+
+    def dist_validation(self, dataloader, current_iter, tb_logger, save_img, rgb2bgr, use_image):
+        if os.environ.get('LOCAL_RANK', '0') == '0':
+            return self.nondist_validation(dataloader, current_iter, tb_logger, save_img, rgb2bgr, use_image)
+        return 0.
+
+    def nondist_validation(self, dataloader, current_iter, tb_logger, save_img, rgb2bgr, use_image):
+        with_metrics = self.opt['val'].get('metrics') is not None
+        if with_metrics:
+            self.metric_results = {m: 0 for m in self.opt['val']['metrics'].keys()}
+        window_size = self.opt['val'].get('window_size', 0)
+        test = partial(self.pad_test, window_size) if window_size else self.nonpad_test
+        cnt = 0
+        for val_data in dataloader:
+            self.feed_data(val_data)
+            test()
+            visuals = self.get_current_visuals()
+            sr_img = tensor2img(visuals['result'], rgb2bgr=rgb2bgr)
+            gt_img = tensor2img(visuals['gt'], rgb2bgr=rgb2bgr) if 'gt' in visuals else None
+            if with_metrics:
+                for name, opt_ in deepcopy(self.opt['val']['metrics']).items():
+                    fn = getattr(metric_module, opt_.pop('type'))
+                    a, b = (sr_img, gt_img) if use_image else (visuals['result'], visuals['gt'])
+                    self.metric_results[name] += fn(a, b, **opt_)
+            cnt += 1
+        current_metric = 0.
+        if with_metrics:
+            for m in self.metric_results:
+                self.metric_results[m] /= max(cnt, 1)
+                current_metric = self.metric_results[m]
+            logger.info('Validation ' + ', '.join(f'{m}: {v:.4f}' for m, v in self.metric_results.items()))
+        return current_metric
+
+    def get_current_visuals(self):
+        out = OrderedDict(lq=self.lq.detach().cpu(), result=self.output.detach().cpu())
+        if hasattr(self, 'gt'):
+            out['gt'] = self.gt.detach().cpu()
+        return out
+
+    def save(self, epoch, current_iter):
+        if self.ema_decay > 0:
+            self.save_network([self.net_g, self.net_g_ema], 'net_g', current_iter, param_key=['params', 'params_ema'])
+        else:
+            self.save_network(self.net_g, 'net_g', current_iter)
+        self.save_training_state(epoch, current_iter)
