@@ -166,4 +166,4 @@ class BaseModel:
                 losses = torch.stack([loss_dict[k].reshape(()) for k in keys], 0)
                 losses = reduce_loss_to_rank0(losses, world, rank)
                 loss_dict = {k: v for k, v in zip(keys, losses)}
-            return OrderedDict((k, v.mean()) for k, v in loss_dict.items())
+            return OrderedDict((k, v.reshape(())) for k, v in loss_dict.items())
