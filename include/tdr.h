@@ -89,6 +89,7 @@ typedef struct TdrWgradDesc {
     const float* in;   int64_t in_ns;  int gate;
     const float* dout; int64_t dout_ns;
     float* g;          /* [groups][Cout][Cin][KH*KH] */
+    float* db;         /* optional [Cout]: bias gradient sum_{n,oy,ox} dout (fused, saves a pass over dout) */
     int per_image;
     float* ws; int64_t ws_floats;      /* split-K workspace */
 } TdrWgradDesc;

@@ -47,6 +47,7 @@ class TdrWgradDesc(C.Structure):
         ('inp', c_fp), ('in_ns', i64), ('gate', i32),
         ('dout', c_fp), ('dout_ns', i64),
         ('g', c_fp),
+        ('db', c_fp),
         ('per_image', i32),
         ('ws', c_fp), ('ws_floats', i64),
     ]

@@ -76,67 +76,76 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const long HWin = (long)a.H * a.W;
 
     // ---- per-lane staging geometry (identical for every chunk) ----
-    int goff[MAXPIT], loff[MAXPIT];
+    // Loads are UNCONDITIONAL (addresses clamped into the tensor) and kept raw in registers;
+    // validity masks, kscale and the SimpleGate product are applied when the registers are
+    // written to LDS.  (Conditional loads make hipcc emit a branch + s_waitcnt vmcnt(0) per
+    // load, which serialises the whole staging phase.)
+    int gsafe[MAXPIT];
+    unsigned okmask = 0, inplane = 0;
 #pragma unroll
     for (int it = 0; it < MAXPIT; ++it) {
         const int p = lane + 64 * it;
         const int r = p / LW, x = p - r * LW;
         const int gy = iy0 + r, gx = ix0 + x;
-        const bool ok = (p < plane) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        goff[it] = ok ? gy * a.W + gx : -1;
-        loff[it] = (p < plane) ? p : -1;
+        const bool inp = p < plane;
+        const bool ok = inp && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        gsafe[it] = ok ? gy * a.W + gx : 0;
+        okmask |= (ok ? 1u : 0u) << it;
+        inplane |= (inp ? 1u : 0u) << it;
     }
     const float* in_n = a.in + (long)n * a.in_ns;
     const float* wp_n = a.wp + (long)n * a.wp_ns;
     const float* ks_n = a.kscale ? a.kscale + (long)n * a.kscale_ns : nullptr;
 
     float rin[CPW][MAXPIT];
+    float rin2[GATE ? CPW : 1][GATE ? MAXPIT : 1];
+    float rks[CPW];
     float4 rw[WIT];
     const int nchunks = (a.Cin + CK - 1) / CK;
+    const long wrow_max = (long)nchunks * KC - 1;
 
     auto load_chunk = [&](int ch) {
 #pragma unroll
         for (int ic = 0; ic < CPW; ++ic) {
-            const int ci = ch * CK + wave + 4 * ic;
-            const bool cok = ci < a.Cin;
+            const int ci = min(ch * CK + wave + 4 * ic, a.Cin - 1);
             const float* base = in_n + (long)ci * HWin;
-            float ks = 1.f;
-            if (ks_n && cok) ks = ks_n[ci];
+            rks[ic] = ks_n ? ks_n[ci] : 1.f;
 #pragma unroll
             for (int it = 0; it < MAXPIT; ++it) {
-                float v = 0.f;
-                if (cok && goff[it] >= 0) {
-                    v = base[goff[it]];
-                    if (GATE) v *= base[goff[it] + a.gate_off];
-                    v *= ks;
-                }
-                rin[ic][it] = v;
+                rin[ic][it] = base[gsafe[it]];
+                if (GATE) rin2[ic][it] = base[gsafe[it] + a.gate_off];
             }
         }
 #pragma unroll
         for (int i = 0; i < WIT; ++i) {
-            const int idx = tid + 256 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < W4) {
-                const int k = idx / (BM / 4), c4 = idx % (BM / 4);
-                const int m = m0 + c4 * 4;
-                if (m < a.Mpad) v = *reinterpret_cast<const float4*>(wp_n + ((long)ch * KC + k) * a.Mpad + m);
-            }
-            rw[i] = v;
+            const int idx = min(tid + 256 * i, W4 - 1);
+            const int k = idx / (BM / 4), c4 = idx % (BM / 4);
+            const int m = min(m0 + c4 * 4, a.Mpad - 4);
+            rw[i] = *reinterpret_cast<const float4*>(wp_n + min((long)ch * KC + k, wrow_max) * a.Mpad + m);
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int ch) {
 #pragma unroll
         for (int ic = 0; ic < CPW; ++ic) {
             const int c = wave + 4 * ic;
+            const bool cok = ch * CK + c < a.Cin;
 #pragma unroll
-            for (int it = 0; it < MAXPIT; ++it)
-                if (loff[it] >= 0) s_in[c * plane + loff[it]] = rin[ic][it];
+            for (int it = 0; it < MAXPIT; ++it) {
+                float v = rin[ic][it];
+                if (GATE) v *= rin2[ic][it];
+                v *= rks[ic];
+                v = (cok && ((okmask >> it) & 1u)) ? v : 0.f;
+                if ((inplane >> it) & 1u) s_in[c * plane + lane + 64 * it] = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < WIT; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < W4) *reinterpret_cast<float4*>(s_w + idx * 4) = rw[i];
+            if (idx < W4) {
+                const int c4 = idx % (BM / 4);
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(s_w + idx * 4) = (m0 + c4 * 4 < a.Mpad) ? rw[i] : z;
+            }
         }
     };
 
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     load_chunk(0);
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();
-        store_chunk();
+        store_chunk(ch);
         __syncthreads();
         if (ch + 1 < nchunks) load_chunk(ch + 1);
 #pragma unroll
@@ -184,56 +193,116 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: lane holds pixel j of sub-tile tn, rows (r&3)+8*(r>>2)+4*kk ----
+    // All optional operand loads are unconditional (clamped indices) and grouped per operand so
+    // they are issued back to back; only the final stores are predicated.
     const long HWo = (long)a.OH * a.OW;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int t = wn * TN + tn;
         const int oy = oy0 + t * SR + (j >> a.tw_log2), ox = ox0 + (j & (TW - 1));
-        if (oy >= a.OH || ox >= a.OW) continue;
+        const bool pvalid = oy < a.OH && ox < a.OW;
+        const long pix = pvalid ? (long)oy * a.OW + ox : 0;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int mb = m0 + (wm * TM + tm) * 32 + 4 * kk;
             if (EPI == EPI_PSHUF) {
                 // rows 4q..4q+3 (q = r>>2) of this lane are the 2x2 sub-pixels of channel (mb+8q)/4
                 const long OW2 = 2L * a.OW;
+                const long p2 = pvalid ? (2L * oy) * OW2 + 2L * ox : 0;
+                float2 r0[4], r1[4];
+                if (a.res) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = min(mb + 8 * q, a.Cout - 4) >> 2;
+                        const float* rp = a.res + (long)n * a.res_ns + (long)c * 4 * HWo + p2;
+                        r0[q] = *reinterpret_cast<const float2*>(rp);
+                        r1[q] = *reinterpret_cast<const float2*>(rp + OW2);
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = mb + 8 * q;
-                    if (m >= a.Cout) continue;
-                    const int c = m >> 2;
-                    const long o0 = (long)c * 4 * HWo + (2L * oy) * OW2 + 2L * ox;
                     float v0 = acc[tm][tn][4 * q + 0], v1 = acc[tm][tn][4 * q + 1];
                     float v2 = acc[tm][tn][4 * q + 2], v3 = acc[tm][tn][4 * q + 3];
-                    if (a.res) {
-                        const float* r = a.res + (long)n * a.res_ns + o0;
-                        v0 += r[0]; v1 += r[1]; v2 += r[OW2]; v3 += r[OW2 + 1];
+                    if (a.res) { v0 += r0[q].x; v1 += r0[q].y; v2 += r1[q].x; v3 += r1[q].y; }
+                    if (pvalid && m < a.Cout) {
+                        float* o = a.out + (long)n * a.out_ns + (long)(m >> 2) * 4 * HWo + p2;
+                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                        *reinterpret_cast<float2*>(o + OW2) = make_float2(v2, v3);
                     }
-                    float* o = a.out + (long)n * a.out_ns + o0;
-                    *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
-                    *reinterpret_cast<float2*>(o + OW2) = make_float2(v2, v3);
                 }
-            } else {
+            } else if (EPI == EPI_GATEBWD) {
+                const float* ax = a.aux + (long)n * a.aux_ns;
+                const long half = (long)a.Cout * HWo;
+                float a0[16], a1[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mc = min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1);
+                    const long o = (long)mc * HWo + pix;
+                    a0[r] = ax[o];
+                    a1[r] = ax[o + half];
+                }
+                float* op = a.out + (long)n * a.out_ns;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m >= a.Cout) continue;
-                    const long o = (long)m * HWo + (long)oy * a.OW + ox;
-                    float v = acc[tm][tn][r];
-                    if (EPI == EPI_GATEBWD) {
-                        const float* ax = a.aux + (long)n * a.aux_ns;
-                        const long half = (long)a.Cout * HWo;
-                        float* op = a.out + (long)n * a.out_ns;
-                        op[o] = v * ax[o + half];
-                        op[o + half] = v * ax[o];
-                    } else {
-                        if (a.bias) v += a.bias[(long)n * a.bias_ns + m];
-                        if (a.scale) v *= a.scale[(long)n * a.scale_ns + m];
-                        if (a.bias2) v += a.bias2_mul * a.bias2[(long)n * a.bias2_ns + m];
-                        if (a.res) v += a.res[(long)n * a.res_ns + o];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (a.mask) v = a.mask[(long)n * a.mask_ns + o] > 0.f ? v : 0.f;
-                        a.out[(long)n * a.out_ns + o] = v;
+                    if (pvalid && m < a.Cout) {
+                        const long o = (long)m * HWo + pix;
+                        const float v = acc[tm][tn][r];
+                        op[o] = v * a1[r];
+                        op[o + half] = v * a0[r];
                     }
+                }
+            } else {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r];
+                if (a.bias) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = a.bias[(long)n * a.bias_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += tv[r];
+                }
+                if (a.scale) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = a.scale[(long)n * a.scale_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] *= tv[r];
+                }
+                if (a.bias2) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = a.bias2[(long)n * a.bias2_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += a.bias2_mul * tv[r];
+                }
+                if (a.res) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tv[r] = a.res[(long)n * a.res_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HWo + pix];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += tv[r];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (a.mask) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tv[r] = a.mask[(long)n * a.mask_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HWo + pix];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = tv[r] > 0.f ? v[r] : 0.f;
+                }
+                float* op = a.out + (long)n * a.out_ns + pix;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (pvalid && m < a.Cout) op[(long)m * HWo] = v[r];
                 }
             }
         }

@@ -21,13 +21,14 @@ __global__ __launch_bounds__(64 * SLICES) void ln_fwd_kernel(const float* __rest
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
     const bool pok = px < HW;
-    const float* xn = x + (long)n * x_ns + px;
+    const float* xn = x + (long)n * x_ns + (pok ? px : HW - 1);
     float v[CPT];
     float s = 0.f;
 #pragma unroll
+    for (int i = 0; i < CPT; ++i) v[i] = xn[(long)min(slice + SLICES * i, C - 1) * HW];
+#pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        const int c = slice + SLICES * i;
-        v[i] = (pok && c < C) ? xn[(long)c * HW] : 0.f;
+        v[i] = (pok && slice + SLICES * i < C) ? v[i] : 0.f;
         s += v[i];
     }
     red[slice][lane] = s;
@@ -116,21 +117,27 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
     for (int t = blockIdx.x; t < N * tiles; t += gridDim.x) {
         const int n = t / tiles, px = (t % tiles) * 64 + lane;
         const bool pok = px < HW;
-        const float m = pok ? mu[(long)n * HW + px] : 0.f, rs = pok ? rstd[(long)n * HW + px] : 0.f;
+        const int pxc = pok ? px : HW - 1;                 // clamped: loads stay unconditional
+        const float m = mu[(long)n * HW + pxc], rs = pok ? rstd[(long)n * HW + pxc] : 0.f;
         float yh[CPT], g[CPT];
+        float xv[CPT], g0[CPT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = min(slice + SLICES * i, C - 1);
+            xv[i] = x[(long)n * x_ns + (long)c * HW + pxc];
+            g0[i] = go[((long)n * C + c) * HW + pxc];
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = slice + SLICES * i;
-            const bool ok = pok && c < C;
-            const float xv = ok ? x[(long)n * x_ns + (long)c * HW + px] : 0.f;
-            const float g0 = ok ? go[((long)n * C + c) * HW + px] : 0.f;
-            yh[i] = ok ? (xv - m) * rs : 0.f;
-            g[i] = g0 * wv[i];
+            const bool ok = pok && (slice + SLICES * i) < C;
+            const float gg = ok ? g0[i] : 0.f;
+            yh[i] = ok ? (xv[i] - m) * rs : 0.f;
+            g[i] = gg * wv[i];
             s1 += g[i];
             s2 += g[i] * yh[i];
-            aw[i] += g0 * yh[i];
-            ab[i] += g0;
+            aw[i] += gg * yh[i];
+            ab[i] += gg;
         }
         red[0][slice][lane] = s1;
         red[1][slice][lane] = s2;
@@ -140,16 +147,17 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
         for (int k = 0; k < SLICES; ++k) { S1 += red[0][k][lane]; S2 += red[1][k][lane]; }
         __syncthreads();
         const float mg = S1 / (float)C, mgy = S2 / (float)C;
-        if (pok) {
+        float av[CPT];
+        if (add) {
 #pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                const int c = slice + SLICES * i;
-                if (c < C) {
-                    float v = rs * (g[i] - yh[i] * mgy - mg);
-                    if (add && c < add_C) v += add[(long)n * add_ns + (long)c * HW + px];
-                    gx[((long)n * C + c) * HW + px] = v;
-                }
-            }
+            for (int i = 0; i < CPT; ++i) av[i] = add[(long)n * add_ns + (long)min(slice + SLICES * i, add_C - 1) * HW + pxc];
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = slice + SLICES * i;
+            float v = rs * (g[i] - yh[i] * mgy - mg);
+            if (add && c < add_C) v += av[i];
+            if (pok && c < C) gx[((long)n * C + c) * HW + px] = v;
         }
     }
 #pragma unroll
@@ -231,7 +239,30 @@ __global__ void pair_reduce_kernel(const float* __restrict__ part, int nparts, i
     o0[c] = a; o1[c] = b;
 }
 
-constexpr int LN_BWD_GRID = 1024;
+// out[g][e] = sum_{k<nparts} part[(g*nparts + k)*stride + e]; block = 64 elements x KL k-lanes
+template <int KL>
+__global__ __launch_bounds__(64 * KL) void sum_partials_kernel(const float* __restrict__ part, long stride, int nparts,
+                                                               long elems, float* __restrict__ out) {
+    __shared__ float red[KL][64];
+    const int lane = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const long e = blockIdx.x * 64L + lane;
+    const long ec = e < elems ? e : elems - 1;
+    const float* p = part + (long)blockIdx.y * nparts * stride + ec;
+    float s0 = 0.f, s1 = 0.f;
+    int k = kl;
+    for (; k + KL < nparts; k += 2 * KL) { s0 += p[(long)k * stride]; s1 += p[(long)(k + KL) * stride]; }
+    if (k < nparts) s0 += p[(long)k * stride];
+    red[kl][lane] = s0 + s1;
+    __syncthreads();
+    if (kl == 0 && e < elems) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < KL; ++q) t += red[q][lane];
+        out[(long)blockIdx.y * elems + e] = t;
+    }
+}
+
+constexpr int LN_BWD_GRID = 256;
 constexpr int LN_GEN_SPLITS = 16;
 
 // ===========================================================================
@@ -239,16 +270,14 @@ constexpr int LN_GEN_SPLITS = 16;
 //   network_nafnet_guided_arch.py:185-187, 170-175, 192-196
 // block = (band of BR rows, channel c, image n); thread = 4 consecutive x.
 // ===========================================================================
-__device__ __forceinline__ void load_row6(const float* __restrict__ row, int x0, int W, bool rok, float (&r)[6]) {
-    if (!rok) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) r[i] = 0.f;
-        return;
-    }
+__device__ __forceinline__ void load_row6(const float* __restrict__ plane, int yy, int H, int x0, int W, float (&r)[6]) {
+    const bool rok = yy >= 0 && yy < H;
+    const float* row = plane + (long)min(max(yy, 0), H - 1) * W;      // clamped: loads unconditional
     const float4 m = *reinterpret_cast<const float4*>(row + x0);
-    r[0] = x0 > 0 ? row[x0 - 1] : 0.f;
-    r[1] = m.x; r[2] = m.y; r[3] = m.z; r[4] = m.w;
-    r[5] = x0 + 4 < W ? row[x0 + 4] : 0.f;
+    const float l = row[max(x0 - 1, 0)], rr = row[min(x0 + 4, W - 1)];
+    r[0] = (rok && x0 > 0) ? l : 0.f;
+    r[1] = rok ? m.x : 0.f; r[2] = rok ? m.y : 0.f; r[3] = rok ? m.z : 0.f; r[4] = rok ? m.w : 0.f;
+    r[5] = (rok && x0 + 4 < W) ? rr : 0.f;
 }
 
 __global__ __launch_bounds__(256) void dwsg_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w,
@@ -272,10 +301,9 @@ __global__ __launch_bounds__(256) void dwsg_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y + ky - 1;
-            const bool rok = yy >= 0 && yy < H;
             float r1[6], r2[6];
-            load_row6(t1 + (long)yy * W, x0, W, rok, r1);
-            load_row6(t2 + (long)yy * W, x0, W, rok, r2);
+            load_row6(t1, yy, H, x0, W, r1);
+            load_row6(t2, yy, H, x0, W, r2);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -334,14 +362,17 @@ __global__ __launch_bounds__(256) void dwsg_bwd_kernel(const float* __restrict__
             const int r = i / TW2, q = i % TW2;
             const int y = ty0 + r - 2, x = tx0 + q - 2;
             const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-            st1[r][q] = ok ? t1[(long)y * W + x] : 0.f;
-            st2[r][q] = ok ? t2[(long)y * W + x] : 0.f;
+            const long off = (long)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+            const float v1 = t1[off], v2 = t2[off];
+            st1[r][q] = ok ? v1 : 0.f;
+            st2[r][q] = ok ? v2 : 0.f;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < TH1 * TW1; i += 256) {
             const int r = i / TW1, q = i % TW1;
             const int y = ty0 + r - 1, x = tx0 + q - 1;
             float d1 = 0.f, d2 = 0.f;
+            const float gvl = dgp[(long)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)];
             if (y >= 0 && y < H && x >= 0 && x < W) {
                 float u1 = b1, u2 = b2;
 #pragma unroll
@@ -349,7 +380,7 @@ __global__ __launch_bounds__(256) void dwsg_bwd_kernel(const float* __restrict__
                     u1 += w1[k] * st1[r + k / 3][q + k % 3];
                     u2 += w2[k] * st2[r + k / 3][q + k % 3];
                 }
-                const float gv = dgp[(long)y * W + x];
+                const float gv = gvl;
                 d1 = gv * u2; d2 = gv * u1;
                 const bool interior = r >= 1 && r <= TBY && q >= 1 && q <= TBX;
                 if (interior) {
@@ -442,35 +473,57 @@ __global__ __launch_bounds__(256) void sca_bwd_rows_kernel(const float* __restri
     }
 }
 
-// ds[n][ci] = sum_co beta[co] W3[co][ci] G3[n][co][ci]; thread per (n,ci)
-__global__ void sca_bwd_ds_kernel(const float* __restrict__ G3, const float* __restrict__ w3,
-                                  const float* __restrict__ beta, int N, int C, float* __restrict__ ds) {
-    const int ci = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-    if (ci >= C) return;
+// ds[n][ci] = sum_co beta[co] W3[co][ci] G3[n][co][ci]; block = 64 ci x 16 co-slices
+__global__ __launch_bounds__(1024) void sca_bwd_ds_kernel(const float* __restrict__ G3, const float* __restrict__ w3,
+                                                         const float* __restrict__ beta, int N, int C, float* __restrict__ ds) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int ci = blockIdx.x * 64 + lane, n = blockIdx.y;
+    const int cic = min(ci, C - 1);
     float a = 0.f;
-    for (int co = 0; co < C; ++co) a += beta[co] * w3[(long)co * C + ci] * G3[((long)n * C + co) * C + ci];
-    ds[(long)n * C + ci] = a;
+    for (int co = sl; co < C; co += 16) a += beta[co] * w3[(long)co * C + cic] * G3[((long)n * C + co) * C + cic];
+    red[sl][lane] = a;
+    __syncthreads();
+    if (sl == 0 && ci < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][lane];
+        ds[(long)n * C + ci] = t;
+    }
 }
 
-// dpooled[n][cj] = sum_ci Wsca[ci][cj] ds[n][ci];  dWsca[ci][cj] = sum_n ds[n][ci] pooled[n][cj]; dbsca[ci] = sum_n ds
-__global__ void sca_bwd_tail_kernel(const float* __restrict__ ds, const float* __restrict__ pooled,
-                                    const float* __restrict__ wsca, int N, int C, float* __restrict__ dwsca,
-                                    float* __restrict__ dbsca, float* __restrict__ dpooled) {
-    const int cj = blockIdx.x * blockDim.x + threadIdx.x;
+// dWsca[ci][cj] = sum_n ds[n][ci] pooled[n][cj]   (grid: (C/256, C))
+__global__ void sca_bwd_dw_kernel(const float* __restrict__ ds, const float* __restrict__ pooled, int N, int C,
+                                  float* __restrict__ dwsca) {
+    const int cj = blockIdx.x * blockDim.x + threadIdx.x, ci = blockIdx.y;
     if (cj >= C) return;
-    const int ci_row = blockIdx.y;                 // rows of dWsca handled by grid.y
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a += ds[(long)n * C + ci_row] * pooled[(long)n * C + cj];
-    dwsca[(long)ci_row * C + cj] = a;
-    if (ci_row == 0) {
-        for (int n = 0; n < N; ++n) {
-            float p = 0.f;
-            for (int ci = 0; ci < C; ++ci) p += wsca[(long)ci * C + cj] * ds[(long)n * C + ci];
-            dpooled[(long)n * C + cj] = p;
+    for (int n = 0; n < N; ++n) a += ds[(long)n * C + ci] * pooled[(long)n * C + cj];
+    dwsca[(long)ci * C + cj] = a;
+}
+
+// dpooled[n][cj] = sum_ci Wsca[ci][cj] ds[n][ci] (block = 64 cj x 16 ci-slices); dbsca[cj] = sum_n ds[n][cj]
+__global__ __launch_bounds__(1024) void sca_bwd_tail_kernel(const float* __restrict__ ds, const float* __restrict__ wsca,
+                                                           int N, int C, float* __restrict__ dbsca,
+                                                           float* __restrict__ dpooled) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int cj = blockIdx.x * 64 + lane, n = blockIdx.y;
+    const int cjc = min(cj, C - 1);
+    float a = 0.f;
+    for (int ci = sl; ci < C; ci += 16) a += wsca[(long)ci * C + cjc] * ds[(long)n * C + ci];
+    red[sl][lane] = a;
+    __syncthreads();
+    if (sl == 0 && cj < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][lane];
+        dpooled[(long)n * C + cj] = t;
+        if (n == 0) {
+            float sb = 0.f;
+            for (int m = 0; m < N; ++m) sb += ds[(long)m * C + cj];
+            dbsca[cj] = sb;
         }
-        float sb = 0.f;
-        for (int n = 0; n < N; ++n) sb += ds[(long)n * C + cj];
-        dbsca[cj] = sb;
     }
 }
 
@@ -654,7 +707,8 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
                            HW, ws);
         nparts = LN_GEN_SPLITS;
     }
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3(tdr_cdiv(C, 256)), dim3(256), 0, st, ws, nparts, C, gw, gb);
+    hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 1), dim3(1024), 0, st, ws, 2L * C, nparts, (long)C, gw);
+    hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 1), dim3(1024), 0, st, ws + C, 2L * C, nparts, (long)C, gb);
     TDR_LAUNCH_CHECK("ln_bwd");
     return TDR_OK;
 }
@@ -720,9 +774,9 @@ extern "C" int tdr_sca_bwd(const float* G3, const float* S3, const float* w3, co
     hipStream_t st = (hipStream_t)stream;
     float* ds = ws;          // [N][C]
     hipLaunchKernelGGL(sca_bwd_rows_kernel, dim3(C), dim3(256), 0, st, G3, S3, w3, b3, beta, s, N, C, dw3, db3, dbeta);
-    hipLaunchKernelGGL(sca_bwd_ds_kernel, dim3(tdr_cdiv(C, 256), N), dim3(256), 0, st, G3, w3, beta, N, C, ds);
-    hipLaunchKernelGGL(sca_bwd_tail_kernel, dim3(tdr_cdiv(C, 256), C), dim3(256), 0, st, ds, pooled, wsca, N, C, dwsca,
-                       dbsca, dpooled);
+    hipLaunchKernelGGL(sca_bwd_ds_kernel, dim3(tdr_cdiv(C, 64), N), dim3(1024), 0, st, G3, w3, beta, N, C, ds);
+    hipLaunchKernelGGL(sca_bwd_dw_kernel, dim3(tdr_cdiv(C, 256), C), dim3(256), 0, st, ds, pooled, N, C, dwsca);
+    hipLaunchKernelGGL(sca_bwd_tail_kernel, dim3(tdr_cdiv(C, 64), N), dim3(1024), 0, st, ds, wsca, N, C, dbsca, dpooled);
     TDR_LAUNCH_CHECK("sca_bwd");
     return TDR_OK;
 }

@@ -21,6 +21,7 @@ struct WgArgs {
     const float* dout; long dout_ns; int Cout, OH, OW;
     int pad, tw_log2, tiles_x, tpi /*tiles per image*/, tps /*tiles per split*/, spi /*splits per image*/;
     float* part;
+    float* dbpart;      // optional [nsplit][Cout]: per-split sums of dout rows (bias gradient), ci-tile 0 only
 };
 
 constexpr int wg_plane(int TW, int KH, int S) { return (((64 / TW) - 1) * S + KH) * ((TW - 1) * S + KH); }
@@ -68,45 +69,60 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
         pc[it] = p - (p / LW) * LW;
     }
 
+    // unconditional (clamped) loads kept raw in registers; masks and the gate product are applied
+    // at LDS-store time (conditional loads would be serialised by per-load vmcnt(0) waits).
     float rd[DPT];
+    float rdsum[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) rdsum[i] = 0.f;
     float ri[IPT][MAXPIT];
+    float ri2[GATE ? IPT : 1][GATE ? MAXPIT : 1];
+    bool dok_r = false;
+    unsigned iok_r = 0;
     auto load_tile = [&](int t) {
         const int ty = t / a.tiles_x, tx = t % a.tiles_x;
         const int oy0 = ty * (64 >> a.tw_log2), ox0 = tx * TW;
         const int oy = oy0 + dpy, ox = ox0 + dpx;
-        const bool dok = oy < a.OH && ox < a.OW;
-        const long doff = (long)oy * a.OW + ox;
+        dok_r = oy < a.OH && ox < a.OW;
+        const long doff = dok_r ? (long)oy * a.OW + ox : 0;
 #pragma unroll
         for (int i = 0; i < DPT; ++i) {
-            const int co = co0 + wave + 4 * i;
-            rd[i] = (dok && co < a.Cout) ? do_n[(long)co * HWo + doff] : 0.f;
+            const int co = min(co0 + wave + 4 * i, a.Cout - 1);
+            rd[i] = do_n[(long)co * HWo + doff];
         }
         const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+        iok_r = 0;
 #pragma unroll
         for (int it = 0; it < MAXPIT; ++it) {
             const int gy = iy0 + pr[it], gx = ix0 + pc[it];
             const bool ok = pr[it] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const long off = (long)gy * a.W + gx;
+            iok_r |= (ok ? 1u : 0u) << it;
+            const long off = ok ? (long)gy * a.W + gx : 0;
 #pragma unroll
             for (int i = 0; i < IPT; ++i) {
-                const int ci = ci0 + wave + 4 * i;
-                float v = 0.f;
-                if (ok && ci < a.Cin) {
-                    v = in_n[(long)ci * HWin + off];
-                    if (GATE) v *= in_n[(long)ci * HWin + off + a.gate_off];
-                }
-                ri[i][it] = v;
+                const int ci = min(ci0 + wave + 4 * i, a.Cin - 1);
+                ri[i][it] = in_n[(long)ci * HWin + off];
+                if (GATE) ri2[i][it] = in_n[(long)ci * HWin + off + a.gate_off];
             }
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < DPT; ++i) s_d[(wave + 4 * i) * 65 + lane] = rd[i];
+        for (int i = 0; i < DPT; ++i) {
+            const float dv = (dok_r && co0 + wave + 4 * i < a.Cout) ? rd[i] : 0.f;
+            s_d[(wave + 4 * i) * 65 + lane] = dv;
+            rdsum[i] += dv;
+        }
 #pragma unroll
         for (int it = 0; it < MAXPIT; ++it)
             if (pr[it] >= 0) {
 #pragma unroll
-                for (int i = 0; i < IPT; ++i) s_i[(wave + 4 * i) * planeP + lane + 64 * it] = ri[i][it];
+                for (int i = 0; i < IPT; ++i) {
+                    float v = ri[i][it];
+                    if (GATE) v *= ri2[i][it];
+                    s_i[(wave + 4 * i) * planeP + lane + 64 * it] =
+                        (((iok_r >> it) & 1u) && ci0 + wave + 4 * i < a.Cin) ? v : 0.f;
+                }
             }
     };
 
@@ -152,6 +168,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
         }
     }
 
+    if (a.dbpart && blockIdx.z == 0) {
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) {
+            const float sv = wave_sum(rdsum[i]);
+            const int co = co0 + wave + 4 * i;
+            if (lane == 0 && co < a.Cout) a.dbpart[(long)split * a.Cout + co] = sv;
+        }
+    }
     // partial[(split*WKw + wk)][co][ci][tap]
     float* part = a.part + ((long)split * WKw + wk) * a.Cout * a.Cin * TAPS;
 #pragma unroll
@@ -170,16 +194,26 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
         }
 }
 
-// out[g][e] = sum_{s < per_group} part[(g*per_group + s)][e]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, long elems, int per_group, int groups,
-                                    float* __restrict__ out) {
-    const long total = elems * groups;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long g = i / elems, e = i % elems;
-        const float* p = part + g * per_group * elems + e;
-        float s = 0.f;
-        for (int k = 0; k < per_group; ++k) s += p[(long)k * elems];
-        out[i] = s;
+// out[g][e] = sum_{s < per_group} part[(g*per_group + s)][e]; block = 64 elements x KL partial-lanes
+template <int KL>
+__global__ __launch_bounds__(64 * KL) void wgrad_reduce_kernel(const float* __restrict__ part, long elems, int per_group,
+                                                               float* __restrict__ out) {
+    __shared__ float red[KL][64];
+    const int lane = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const long e = blockIdx.x * 64L + lane;
+    const long ec = e < elems ? e : elems - 1;
+    const float* p = part + (long)blockIdx.y * per_group * elems + ec;
+    float s0 = 0.f, s1 = 0.f;
+    int k = kl;
+    for (; k + KL < per_group; k += 2 * KL) { s0 += p[(long)k * elems]; s1 += p[(long)(k + KL) * elems]; }
+    if (k < per_group) s0 += p[(long)k * elems];
+    red[kl][lane] = s0 + s1;
+    __syncthreads();
+    if (kl == 0 && e < elems) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < KL; ++q) t += red[q][lane];
+        out[(long)blockIdx.y * elems + e] = t;
     }
 }
 
@@ -206,10 +240,10 @@ WgPlan make_plan(const TdrWgradDesc* d) {
     static const int bm[4] = {128, 64, 64, 32}, bn[4] = {128, 32, 64, 32}, wk[4] = {1, 4, 1, 4};
     p.BMc = bm[p.cfg]; p.BNc = bn[p.cfg]; p.WKw = wk[p.cfg];
     const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
-    long want = 768 / out_tiles;                      // target ~3 blocks per CU in total
+    long want = (p.WKw > 1 ? 256 : 512) / out_tiles;  // ~1-2 blocks per CU in total; K-split waves write WKw partials each
     if (want < 1) want = 1;
     long spi = (want + d->N - 1) / d->N;              // splits per image
-    if (spi > p.tpi) spi = p.tpi;
+    if (spi > p.tpi / 4) spi = p.tpi / 4;             // at least 4 pixel tiles per block
     if (spi < 1) spi = 1;
     p.tps = tdr_cdiv(p.tpi, spi);
     p.spi = tdr_cdiv(p.tpi, p.tps);
@@ -238,7 +272,7 @@ int launch_wg(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
 
 extern "C" int64_t tdr_wgrad_ws_floats(const TdrWgradDesc* d) {
     const WgPlan p = make_plan(d);
-    return (int64_t)d->N * p.spi * p.WKw * d->Cout * d->Cin * d->KH * d->KH;
+    return (int64_t)d->N * p.spi * p.WKw * d->Cout * d->Cin * d->KH * d->KH + (int64_t)d->N * p.spi * d->Cout;
 }
 
 extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
@@ -253,6 +287,7 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     a.dout = d->dout; a.dout_ns = d->dout_ns; a.Cout = d->Cout; a.OH = d->OH; a.OW = d->OW;
     a.pad = d->pad; a.tw_log2 = p.tw_log2; a.tiles_x = p.tiles_x; a.tpi = p.tpi; a.tps = p.tps; a.spi = p.spi;
     a.part = d->ws;
+    a.dbpart = d->db ? d->ws + (int64_t)d->N * p.spi * p.WKw * d->Cout * d->Cin * d->KH * d->KH : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool g = d->gate != 0;
     int rc = TDR_ERR_UNSUPPORTED;
@@ -278,9 +313,15 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     const long elems = (long)d->Cout * d->Cin * d->KH * d->KH;
     const int groups = d->per_image ? d->N : 1;
     const int per_group = (d->per_image ? p.spi : d->N * p.spi) * p.WKw;
-    const long total = elems * groups;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, d->ws, elems, per_group, groups, d->g);
+    if (per_group <= 8)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(tdr_cdiv(elems, 64), groups), dim3(64), 0, st, d->ws, elems, per_group, d->g);
+    else if (per_group <= 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(tdr_cdiv(elems, 64), groups), dim3(256), 0, st, d->ws, elems, per_group, d->g);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(tdr_cdiv(elems, 64), groups), dim3(1024), 0, st, d->ws, elems, per_group, d->g);
+    if (d->db)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(tdr_cdiv(d->Cout, 64), 1), dim3(1024), 0, st, a.dbpart, (long)d->Cout,
+                           d->N * p.spi, d->db);
     TDR_LAUNCH_CHECK("wgrad_reduce_kernel");
     return TDR_OK;
 }

@@ -56,8 +56,7 @@ def naf_bwd(dout, P, saved):
     G = {}
     beta, gamma = P['beta'].view(-1), P['gamma'].view(-1)
     # ---- conv5 / gamma chain
-    G5 = K.conv_wgrad(t4, dout, c_out, c, 1, gate=True)
-    S5 = K.channel_sum(dout)
+    G5, S5 = K.conv_wgrad(t4, dout, c_out, c, 1, gate=True, want_db=True)
     dw5, db5, dgam = K.scaled_conv_param_grads(G5.view(c_out, c), S5, P['conv5.weight'], P['conv5.bias'], gamma)
     if c_out == c:
         G['conv5.weight'], G['conv5.bias'], G['gamma'] = dw5.view(c, c, 1, 1), db5, dgam.view(1, c, 1, 1)
@@ -72,15 +71,14 @@ def naf_bwd(dout, P, saved):
     wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
     dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
     # ---- conv4
-    G['conv4.weight'] = K.conv_wgrad(yn, dt4, 2 * c, c, 1).view(2 * c, c, 1, 1)
-    G['conv4.bias'] = K.channel_sum(dt4)
+    g4, G['conv4.bias'] = K.conv_wgrad(yn, dt4, 2 * c, c, 1, want_db=True)
+    G['conv4.weight'] = g4.view(2 * c, c, 1, 1)
     wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)
     dyn = K.conv_forward(dt4, wp, mp, c, 1)
     # ---- norm2 (+ residual branch of `y + x*gamma`)
     dy, G['norm2.weight'], G['norm2.bias'] = K.layernorm2d_bwd(dyn, y, mu2, rs2, P['norm2.weight'], add=dout)
     # ---- conv3 / SCA / beta chain
-    G3 = K.conv_wgrad(g, dy, c, c, 1, per_image=True)
-    S3 = K.channel_sum(dy)
+    G3, S3 = K.conv_wgrad(g, dy, c, c, 1, per_image=True, want_db=True)
     dw3, db3, dbeta, dwsca, dbsca, dpooled = K.sca_bwd(G3, S3, P['conv3.weight'], P['conv3.bias'], beta, s, pooled,
                                                        P['sca.1.weight'])
     G['conv3.weight'], G['conv3.bias'], G['beta'] = dw3, db3, dbeta
@@ -90,8 +88,8 @@ def naf_bwd(dout, P, saved):
     # ---- depthwise + SimpleGate
     dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'])
     # ---- conv1
-    G['conv1.weight'] = K.conv_wgrad(xn, dt1, 2 * c, c, 1).view(2 * c, c, 1, 1)
-    G['conv1.bias'] = K.channel_sum(dt1)
+    g1, G['conv1.bias'] = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)
+    G['conv1.weight'] = g1.view(2 * c, c, 1, 1)
     wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)
     dxn = K.conv_forward(dt1, wp, mp, c, 1)
     dx, G['norm1.weight'], G['norm1.bias'] = K.layernorm2d_bwd(dxn, x, mu1, rs1, P['norm1.weight'], add=dy)
@@ -126,8 +124,8 @@ def conv_fwd(x, w, b, stride, pad, res=None, relu=False):
 def conv_bwd(dout, x, w, stride, pad, need_dx=True, add_to_dx=None):
     """returns (dx or None, dw, db)."""
     Cout, Cin, KH, _ = w.shape
-    dw = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad).view(Cout, Cin, KH, KH)
-    db = K.channel_sum(dout)
+    dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad, want_db=True)
+    dw = dw.view(Cout, Cin, KH, KH)
     dx = None
     if need_dx:
         N, _, OH, OW = dout.shape
@@ -208,12 +206,12 @@ def encoder_bwd(dfeats, P, pre, ext_n_blocks, saved, G):
             x_in, h = blocks[i]
             w1, w2 = P[bp + 'conv1.weight'], P[bp + 'conv2.weight']
             Cc = w1.shape[0]
-            G[bp + 'conv2.weight'] = K.conv_wgrad(h, d, Cc, Cc, 3, pad=1).view(Cc, Cc, 3, 3)
-            G[bp + 'conv2.bias'] = K.channel_sum(d)
+            gw, G[bp + 'conv2.bias'] = K.conv_wgrad(h, d, Cc, Cc, 3, pad=1, want_db=True)
+            G[bp + 'conv2.weight'] = gw.view(Cc, Cc, 3, 3)
             wp, mp, *_ = K.pack_weights(w2, PACK_DGRAD_S1)
             dh = K.conv_forward(d, wp, mp, Cc, 3, pad=1, mask=h)
-            G[bp + 'conv1.weight'] = K.conv_wgrad(x_in, dh, Cc, Cc, 3, pad=1).view(Cc, Cc, 3, 3)
-            G[bp + 'conv1.bias'] = K.channel_sum(dh)
+            gw, G[bp + 'conv1.bias'] = K.conv_wgrad(x_in, dh, Cc, Cc, 3, pad=1, want_db=True)
+            G[bp + 'conv1.weight'] = gw.view(Cc, Cc, 3, 3)
             wp, mp, *_ = K.pack_weights(w1, PACK_DGRAD_S1)
             d = K.conv_forward(dh, wp, mp, Cc, 3, pad=1, res=d)
         dpre = K.relu_bwd(d, a)

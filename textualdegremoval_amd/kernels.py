@@ -128,8 +128,9 @@ def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None
     return out
 
 
-def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=False):
-    """returns G [groups, Cout, Cin, KH, KH] (groups = N if per_image else 1)."""
+def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=False, want_db=False):
+    """returns G [groups, Cout, Cin, KH, KH] (groups = N if per_image else 1); with want_db also the
+    bias gradient sum_{n,y,x} dout [Cout] computed in the same pass."""
     lib = _lib.load()
     N, _, H, W = x.shape
     _, _, OH, OW = dout.shape
@@ -141,12 +142,14 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
     groups = N if per_image else 1
     g = torch.empty(groups, Cout, Cin, KH, KH, dtype=torch.float32, device=x.device)
     d.g = g.data_ptr()
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
+    d.db = _p(db)
     d.per_image = 1 if per_image else 0
     need = lib.tdr_wgrad_ws_floats(C.byref(d))
     ws = workspace(need, x.device, 'wgrad')
     d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
     check(lib.tdr_conv_wgrad(C.byref(d), _stream()), 'tdr_conv_wgrad')
-    return g
+    return (g, db) if want_db else g
 
 
 def layernorm2d_fwd(x, w, b, eps):
