@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __rest
 
 // backward, register path.  grid.x blocks walk pixel tiles (n, 64 px); per-channel
 // sum(go*yhat), sum(go) are kept in registers and reduced across lanes once.
+// Register budget: 5 arrays of CPT floats (x->yhat, go, acc_w, acc_b, add).
 template <int SLICES, int CPT>
 __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
     const float* __restrict__ go, const float* __restrict__ x, long x_ns, const float* __restrict__ mu,
@@ -107,36 +108,39 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
     __shared__ float red[2][SLICES][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int tiles = (HW + 63) / 64;
-    float aw[CPT], ab[CPT], wv[CPT];
+    float aw[CPT], ab[CPT];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        aw[i] = 0.f; ab[i] = 0.f;
-        const int c = slice + SLICES * i;
-        wv[i] = c < C ? w[c] : 0.f;
-    }
+    for (int i = 0; i < CPT; ++i) { aw[i] = 0.f; ab[i] = 0.f; }
+    // 32-bit element offsets from uniform base pointers (saddr + voffset addressing): the
+    // 64-bit per-channel addresses of four tensors would otherwise eat 8*CPT registers.
+    const unsigned uHW = (unsigned)HW;
     for (int t = blockIdx.x; t < N * tiles; t += gridDim.x) {
         const int n = t / tiles, px = (t % tiles) * 64 + lane;
         const bool pok = px < HW;
-        const int pxc = pok ? px : HW - 1;                 // clamped: loads stay unconditional
+        const unsigned pxc = pok ? px : HW - 1;            // clamped: loads stay unconditional
         const float m = mu[(long)n * HW + pxc], rs = pok ? rstd[(long)n * HW + pxc] : 0.f;
-        float yh[CPT], g[CPT];
+        const float* xb = x + (long)n * x_ns;
+        const float* gb_ = go + (long)n * C * HW;
+        float* ob = gx + (long)n * C * HW;
         float xv[CPT], g0[CPT];
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = min(slice + SLICES * i, C - 1);
-            xv[i] = x[(long)n * x_ns + (long)c * HW + pxc];
-            g0[i] = go[((long)n * C + c) * HW + pxc];
+            const unsigned c = min(slice + SLICES * i, C - 1);
+            xv[i] = xb[c * uHW + pxc];
+            g0[i] = gb_[c * uHW + pxc];
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const bool ok = pok && (slice + SLICES * i) < C;
+            const int c = slice + SLICES * i;
+            const bool ok = pok && c < C;
             const float gg = ok ? g0[i] : 0.f;
-            yh[i] = ok ? (xv[i] - m) * rs : 0.f;
-            g[i] = gg * wv[i];
-            s1 += g[i];
-            s2 += g[i] * yh[i];
-            aw[i] += gg * yh[i];
+            const float yh = ok ? (xv[i] - m) * rs : 0.f;
+            const float gv = gg * w[min(c, C - 1)];
+            xv[i] = yh; g0[i] = gv;
+            s1 += gv;
+            s2 += gv * yh;
+            aw[i] += gg * yh;
             ab[i] += gg;
         }
         red[0][slice][lane] = s1;
@@ -149,15 +153,16 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
         const float mg = S1 / (float)C, mgy = S2 / (float)C;
         float av[CPT];
         if (add) {
+            const float* ab_ = add + (long)n * add_ns;
 #pragma unroll
-            for (int i = 0; i < CPT; ++i) av[i] = add[(long)n * add_ns + (long)min(slice + SLICES * i, add_C - 1) * HW + pxc];
+            for (int i = 0; i < CPT; ++i) av[i] = ab_[(unsigned)min(slice + SLICES * i, add_C - 1) * uHW + pxc];
         }
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = slice + SLICES * i;
-            float v = rs * (g[i] - yh[i] * mgy - mg);
+            float v = rs * (g0[i] - xv[i] * mgy - mg);
             if (add && c < add_C) v += av[i];
-            if (pok && c < C) gx[((long)n * C + c) * HW + px] = v;
+            if (pok && c < C) ob[(unsigned)c * uHW + pxc] = v;
         }
     }
 #pragma unroll
@@ -171,34 +176,43 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_generic_kernel(
+// any C: 64 pixels x 16 channel slices; two passes over the channels (the second re-reads the
+// 64-pixel x C tile from L2).  Loads are unconditional (clamped pixel index).
+__global__ __launch_bounds__(1024) void ln_bwd_generic_kernel(
     const float* __restrict__ go, const float* __restrict__ x, long x_ns, const float* __restrict__ mu,
     const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ add, long add_ns, int add_C,
     int C, int HW, float* __restrict__ gx) {
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
     const bool pok = px < HW;
-    const float m = pok ? mu[(long)n * HW + px] : 0.f, rs = pok ? rstd[(long)n * HW + px] : 0.f;
+    const unsigned pxc = pok ? px : HW - 1, uHW = (unsigned)HW;
+    const float m = mu[(long)n * HW + pxc], rs = rstd[(long)n * HW + pxc];
+    const float* xb = x + (long)n * x_ns;
+    const float* gb_ = go + (long)n * C * HW;
     float s1 = 0.f, s2 = 0.f;
-    for (int c = slice; c < C; c += 4) {
-        if (pok) {
-            const float g = go[((long)n * C + c) * HW + px] * w[c];
-            const float yh = (x[(long)n * x_ns + (long)c * HW + px] - m) * rs;
-            s1 += g; s2 += g * yh;
-        }
+#pragma unroll 4
+    for (int c = slice; c < C; c += 16) {
+        const float g = gb_[(unsigned)c * uHW + pxc] * w[c];
+        const float yh = (xb[(unsigned)c * uHW + pxc] - m) * rs;
+        s1 += g; s2 += g * yh;
     }
     red[0][slice][lane] = s1; red[1][slice][lane] = s2;
     __syncthreads();
-    const float mg = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
-    const float mgy = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
-    if (!pok) return;
-    for (int c = slice; c < C; c += 4) {
-        const float g = go[((long)n * C + c) * HW + px] * w[c];
-        const float yh = (x[(long)n * x_ns + (long)c * HW + px] - m) * rs;
+    float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { S1 += red[0][k][lane]; S2 += red[1][k][lane]; }
+    const float mg = S1 / (float)C, mgy = S2 / (float)C;
+    const float* ab_ = add ? add + (long)n * add_ns : xb;
+    float* ob = gx + (long)n * C * HW;
+#pragma unroll 4
+    for (int c = slice; c < C; c += 16) {
+        const float g = gb_[(unsigned)c * uHW + pxc] * w[c];
+        const float yh = (xb[(unsigned)c * uHW + pxc] - m) * rs;
+        const float av = ab_[(unsigned)min(c, add ? add_C - 1 : C - 1) * uHW + pxc];
         float v = rs * (g - yh * mgy - mg);
-        if (add && c < add_C) v += add[(long)n * add_ns + (long)c * HW + px];
-        gx[((long)n * C + c) * HW + px] = v;
+        if (add && c < add_C) v += av;
+        if (pok) ob[(unsigned)c * uHW + pxc] = v;
     }
 }
 
@@ -691,17 +705,16 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
     hipStream_t st = (hipStream_t)stream;
     const int tiles = tdr_cdiv(HW, 64) * N;
     int nparts;
-    if (C <= 256) {
+    if (C <= 128) {
         const int grid = tiles < LN_BWD_GRID ? tiles : LN_BWD_GRID;
         nparts = grid;
 #define LN_BWD(S, P) hipLaunchKernelGGL((ln_bwd_kernel<S, P>), dim3(grid), dim3(64 * S), 0, st, go, x, (long)x_ns, mu, rstd, w, add, (long)add_ns, add_C, N, C, HW, gx, ws)
         if (C <= 32) LN_BWD(4, 8);
         else if (C <= 64) LN_BWD(4, 16);
-        else if (C <= 128) LN_BWD(4, 32);
-        else LN_BWD(8, 32);
+        else LN_BWD(8, 16);
 #undef LN_BWD
     } else {
-        hipLaunchKernelGGL(ln_bwd_generic_kernel, dim3(tdr_cdiv(HW, 64), N), dim3(256), 0, st, go, x, (long)x_ns, mu, rstd,
+        hipLaunchKernelGGL(ln_bwd_generic_kernel, dim3(tdr_cdiv(HW, 64), N), dim3(1024), 0, st, go, x, (long)x_ns, mu, rstd,
                            w, add, (long)add_ns, add_C, C, HW, gx);
         hipLaunchKernelGGL(ln_param_grad_kernel, dim3(C, LN_GEN_SPLITS), dim3(256), 0, st, go, x, (long)x_ns, mu, rstd, N, C,
                            HW, ws);
