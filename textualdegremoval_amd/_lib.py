@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtdr_hip.so')
+LIB_PATH = os.environ.get('TDR_LIB_PATH', os.path.join(_HERE, 'libtdr_hip.so'))   # override: profiling probe builds
 
 c_fp = C.c_void_p      # device pointers travel as integers
 i32, i64, f32 = C.c_int, C.c_int64, C.c_float

@@ -17,6 +17,12 @@
 #include "tdr_common.h"
 #include "../../include/tdr.h"
 
+// TDR_PROBE (profiling builds only, see profiles/probes/): 1 = no global loads inside the K loop,
+// 2 = no LDS staging/barriers inside the K loop, 3 = no LDS fragment reads (MFMA + loop only).
+#ifndef TDR_PROBE
+#define TDR_PROBE 0
+#endif
+
 namespace {
 
 enum { EPI_STD = 0, EPI_GATEBWD = 1, EPI_PSHUF = 2 };
@@ -169,10 +175,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
     load_chunk(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();
-        store_chunk(ch);
-        __syncthreads();
-        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        if (TDR_PROBE < 2 || ch == 0) {
+            __syncthreads();
+            store_chunk(ch);
+            __syncthreads();
+        }
+        if (TDR_PROBE == 0 && ch + 1 < nchunks) load_chunk(ch + 1);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int tapoff = (tap / KH) * D * LW + (tap % KH) * D;
@@ -180,9 +188,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int c2 = 0; c2 < CK / 2; ++c2) {
                 float af[TM], bf[TN];
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) af[tm] = s_w[abase + (tap * CK + 2 * c2) * BM + tm * 32];
+                for (int tm = 0; tm < TM; ++tm)
+                    af[tm] = TDR_PROBE == 3 ? (float)(tap + c2 + tm) : s_w[abase + (tap * CK + 2 * c2) * BM + tm * 32];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bf[tn] = s_in[bbase[tn] + 2 * c2 * plane + tapoff];
+                for (int tn = 0; tn < TN; ++tn)
+                    bf[tn] = TDR_PROBE == 3 ? (float)(tap - c2 + tn + lane) : s_in[bbase[tn] + 2 * c2 * plane + tapoff];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
