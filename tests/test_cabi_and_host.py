@@ -1,0 +1,125 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/tdr.h
+declares; the module surface mirrors the reference's names/order/shapes; host logic
+(registry errors, schedulers, PSNR, MASA geometry) matches the oracle / golden vectors."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nafnet_ref_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'tdr.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(tdr_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from textualdegremoval_amd import _lib
+    lib = _lib.load()                       # raises if a declared symbol is missing
+    syms = header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in include/tdr.h but not exported'
+    assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
+    assert lib.tdr_version() >= 100
+    assert lib.tdr_conv_ck(1) == 32 and lib.tdr_conv_ck(3) == 8 and lib.tdr_conv_ck(2) == 16
+    assert lib.tdr_packed_weight_floats(40, 3, 3) == 1 * 9 * 8 * 64      # Mpad=64, one chunk of 8 channels
+
+
+def test_error_convention_no_throw_and_message():
+    from textualdegremoval_amd import _lib
+    lib = _lib.load()
+    rc = lib.tdr_pack_weights(None, 8, 8, 3, 0, None, None)          # null pointers -> error code, no crash
+    assert rc < 0 and b'null' in lib.tdr_last_error()
+    with pytest.raises(_lib.TdrError):
+        _lib.check(rc, 'tdr_pack_weights')
+
+
+def test_module_surface_matches_reference_registration_order():
+    from textualdegremoval_amd.models.archs import define_network
+    for kw in (dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1]),
+               dict(width=16, nf=16, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2])):
+        net = define_network(dict(type='NAFNetRefFusion', enc_blk_nums=[1, 1, 1, 1], dec_blk_nums=[1, 1, 1, 1], **kw))
+        sd = net.state_dict()
+        shapes = O.param_shapes(O.default_cfg(**kw))
+        assert list(sd.keys()) == list(shapes.keys())
+        assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+        # default init: beta/gamma zeros, LN weight ones / bias zeros (reference :213-214, nafnet_arch_utils.py:295-296)
+        assert sd['encoders.0.0.beta'].abs().sum() == 0 and sd['encoders.0.0.norm1.weight'].eq(1).all()
+    masa = [k for k in sd if 'masa' in k]
+    assert masa == list(sd.keys())[:len(masa)]          # the ref_lr group is a prefix of the registration order
+
+
+def test_registry_and_step_api_error_behaviour():
+    from textualdegremoval_amd.models import create_model
+    from textualdegremoval_amd.models.archs import define_network
+    with pytest.raises(ValueError):
+        define_network({'type': 'NoSuchNet'})
+    with pytest.raises(ValueError):
+        create_model({'model_type': 'NoSuchModel'})
+    with pytest.raises(ValueError):                      # nf != width (concat widths)
+        define_network(dict(type='NAFNetRefFusion', width=8, nf=16, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
+                            reffusion_n_blocks=[1] * 5))
+    with pytest.raises(IndexError):                      # reference quirk R2: needs len(enc)+1 fusion counts
+        define_network(dict(type='NAFNetRefFusion', width=8, nf=8, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
+                            reffusion_n_blocks=[1] * 4))
+    opt = {'model_type': 'RefGuidedImageCleanModel', 'num_gpu': 0, 'dist': False, 'is_train': True,
+           'network_g': dict(type='NAFNetRefFusion', width=8, nf=8, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
+                             ext_n_blocks=[1] * 4, reffusion_n_blocks=[1] * 5),
+           'path': {}, 'train': {}, 'logger': {}, 'val': {}}
+    with pytest.raises(ValueError, match='pixel loss are None'):
+        create_model(opt)
+    opt['train'] = {'pixel_opt': {'type': 'L1Loss'}, 'optim_g': {'type': 'SGD', 'lr': 1e-3, 'ref_lr': 1e-3}}
+    with pytest.raises(NotImplementedError):
+        create_model(opt)
+
+
+def test_no_cpu_fallback_on_the_product_path():
+    from textualdegremoval_amd.models.archs import define_network
+    net = define_network(dict(type='NAFNetRefFusion', width=8, nf=8, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
+                              ext_n_blocks=[1] * 4, reffusion_n_blocks=[1] * 5))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net(torch.zeros(1, 3, 128, 128), torch.zeros(1, 3, 128, 128))
+
+
+def test_scheduler_matches_reference_lr_table():
+    from textualdegremoval_amd.models.lr_scheduler import CosineAnnealingRestartCyclicLR
+    g = np.load(os.path.join(GOLDEN, 'trajectory.npz'))
+    p1, p2 = torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([{'params': [p1], 'lr': 2e-4}, {'params': [p2], 'lr': 1e-4}], lr=2e-4)
+    sch = CosineAnnealingRestartCyclicLR(opt, periods=[30, 70], restart_weights=[1, 1], eta_mins=[3e-4, 1e-6])
+    lrs = [[g_['lr'] for g_ in opt.param_groups]]
+    for it in range(2, 101):
+        opt.step(); sch.step()
+        lrs.append([g_['lr'] for g_ in opt.param_groups])
+    assert np.allclose(np.array(lrs[:3]), g['lrs'], rtol=0, atol=1e-15)
+    assert np.allclose(np.array(lrs[3:]), g['lr_table_from_iter4'], rtol=0, atol=1e-15)
+
+
+def test_psnr_and_l1_host_semantics():
+    from textualdegremoval_amd.losses import L1Loss
+    from textualdegremoval_amd.metrics import calculate_psnr, tensor2img
+    g = np.load(os.path.join(GOLDEN, 'psnr.npz'))
+    a, b = torch.from_numpy(g['a']), torch.from_numpy(g['b'])
+    assert abs(calculate_psnr(tensor2img(a, rgb2bgr=False), tensor2img(b, rgb2bgr=False), 0) - float(g['psnr_u8'])) < 1e-9
+    assert abs(calculate_psnr(a, b.clamp(0, 1), 2) - float(g['psnr_float_crop2'])) < 1e-9
+    with pytest.raises(ValueError):
+        L1Loss(reduction='bogus')
+    assert abs(L1Loss(0.5)(a, b).item() - 0.5 * (a - b).abs().mean().item()) < 1e-7
+
+
+def test_masa_geometry_matches_reference_formulas():
+    from textualdegremoval_amd.engine import MasaGeom
+    g = MasaGeom(512, 512, 512, 512, 4, 8, 1.5, [1, 2, 3])
+    assert (g.py, g.px, g.K, g.dia_x, g.side, g.P) == (4, 4, 8, 13, 15, 16)
+    g = MasaGeom(128, 128, 128, 128, 4, 8, 1.5, [1, 2, 3])
+    assert (g.py, g.px, g.K, g.dia_x, g.side) == (1, 1, 8, 13, 15)                    # cfg1 (wrap case)
+    with pytest.raises(ValueError):
+        MasaGeom(128, 256, 128, 128, 4, 8, 1.5, [1, 2, 3])                            # non-square: reference crashes too
