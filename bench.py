@@ -41,11 +41,11 @@ def make_opt(width, enc, batch_hw, dist_on):
     }
 
 
-def cpu_baseline(width, enc, H, seconds_budget=30.0):
-    """Reported baseline only: the CPU oracle (a port of the reference's path, pinned to the
-    reference by tests/golden) timed on this host's cores on a bounded sample (B=1)."""
+def _cpu_baseline_worker(width, enc, H, threads, budget):
+    """child process: the CPU oracle (a port of the reference's path, pinned to the reference by
+    tests/golden) timed on a bounded sample.  Prints one JSON object."""
     from oracle import nafnet_ref_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     cfg = O.default_cfg(width=width, nf=width, enc_blk_nums=enc, ext_n_blocks=[4, 4, 4, 4],
                         reffusion_n_blocks=[2, 2, 2, 2, 2])
     tr = O.OracleTrainer(O.synth_params(cfg, seed=0), cfg)
@@ -57,11 +57,30 @@ def cpu_baseline(width, enc, H, seconds_budget=30.0):
     while True:
         tr.step(lq, gt, ref)
         n += 1
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
+        if time.time() - t0 > budget or n >= 3:
             break
-    dt = time.time() - t0
-    return {'value': n / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} train step(s), batch 1 x {H}x{H}, same network, torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py)'}
+    print(json.dumps({'n': n, 'dt': time.time() - t0, 'threads': torch.get_num_threads()}))
+
+
+def cpu_baseline(width, enc, size, sample_size=256, threads=None, budget=20.0, hard_timeout=240.0):
+    """Reported baseline only (never the thing shipped): `oracle/` timed on this host's cores in a child
+    process with a hard timeout.  Sample = train steps of the same network on 1 x sample_size^2 pairs;
+    the rate is scaled by pixel count to the metric's 512x512 images/sec."""
+    import subprocess
+    threads = threads or min(os.cpu_count() or 1, 16)     # MKLDNN fp32 convs stop scaling (and can collapse) beyond this
+    code = (f'import sys; sys.path.insert(0, {ROOT!r}); import bench; '
+            f'bench._cpu_baseline_worker({width}, {enc!r}, {sample_size}, {threads}, {budget})')
+    try:
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=hard_timeout,
+                             env=dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES=''))
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001  (timeout / crash of the baseline must not lose the GPU measurement)
+        return {'value': None, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'sample': f'failed: {type(e).__name__}'}
+    scale = (sample_size * sample_size) / float(size * size)
+    return {'value': r['n'] / r['dt'] * scale, 'unit': 'images/sec', 'cores': r['threads'], 'kind': 'port',
+            'host_cpus': os.cpu_count(),
+            'sample': f"{r['n']} train step(s) of the same network on 1 x {sample_size}x{sample_size} pairs in {r['dt']:.1f} s, "
+                      f"torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py), rate scaled by pixel count to {size}x{size} images"}
 
 
 def main():
@@ -139,12 +158,15 @@ def main():
                 return out
             return orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
         K.conv_forward = timed
+        graph_was = getattr(model, 'use_hip_graph', False)
+        model.use_hip_graph = False                       # instrumented step runs eagerly (a replayed graph makes no Python calls)
         try:
             it += 1
             step(it)
             torch.cuda.synchronize()
         finally:
             K.conv_forward = orig
+            model.use_hip_graph = graph_was
         fl = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = fl / (ms * 1e-3) / 1e12

@@ -47,7 +47,9 @@ typedef struct TdrConvDesc {
     const float* in;  int64_t in_ns;
     int gate;
     const float* kscale; int64_t kscale_ns;
-    const float* wp;  int64_t wp_ns;  int Mpad;   /* packed weights, see tdr_pack_weights */
+    const void* wp;  int64_t wp_ns;  int Mpad;    /* packed weights, see tdr_pack_weights / tdr_pack_weights_bx3 */
+    int wp_fmt;                  /* 0: fp32 rows (tdr_pack_weights, exact fp32 MFMA)
+                                    1: 3-way bf16 split fragments (tdr_pack_weights_bx3, bf16 MFMA x6, fp32-equivalent) */
     float* out; int64_t out_ns;
     int epi;                     /* 0 STD, 1 GATEBWD, 2 PSHUF */
     const float* bias;  int64_t bias_ns;
@@ -71,6 +73,25 @@ int tdr_conv_forward(const TdrConvDesc* d, void* stream);
 int tdr_conv_ck(int KH_eff);
 int64_t tdr_packed_weight_floats(int M, int Kch, int KH_eff);
 int tdr_pack_weights(const float* w, int Cout, int Cin, int KH, int mode, float* wp, void* stream);
+/* Split-bf16 packing for the bf16 matrix-core path (wp_fmt = 1): every weight is split into three bf16
+ * terms h+m+l (24+ significant bits) and laid out in MFMA A-fragment order
+ *   Wp3[c/16][tap][m/32][split][lane][8]  (16-byte fragments; lane = (m%32) + 32*((c%16)/8), element = c%8)
+ * same `mode` semantics as tdr_pack_weights.  The convolution then evaluates each fp32 product as six
+ * bf16 cross products with fp32 accumulation (v_mfma_f32_32x32x16_bf16), see csrc/tdr_conv_bx3.hip. */
+int64_t tdr_packed_weight_bytes_bx3(int M, int Kch, int KH_eff);
+int tdr_pack_weights_bx3(const float* w, int Cout, int Cin, int KH, int mode, void* wp, void* stream);
+/* Multi-tensor packing: one launch packs every (weight, mode, format) job of a step.
+ * The caller fills jobs with tdr_pack_job_init (host), sets first_block = running sum of ceil(total/256),
+ * copies the array to the device and launches with total_blocks = the final sum. */
+typedef struct TdrPackJob {
+    const float* w; void* wp;
+    int Cout, Cin, KH, mode, fmt;      /* fmt 0: fp32 rows, 1: split-bf16 fragments */
+    int M, Kch, KHe, CK, Mx;           /* derived by tdr_pack_job_init (Mx = Mpad for fmt 0, m-tiles for fmt 1) */
+    int64_t total;                     /* work items (floats for fmt 0, 16-byte fragment triples for fmt 1) */
+    int64_t first_block;
+} TdrPackJob;
+int tdr_pack_job_init(TdrPackJob* job, const float* w, int Cout, int Cin, int KH, int mode, int fmt, void* wp);
+int tdr_pack_weights_multi(const TdrPackJob* jobs_dev, int n_jobs, int64_t total_blocks, void* stream);
 /* Per-image "filters" of search / search_org: 3x3 patches cut from LR blocks become GEMM rows.
  * blk [B][G][C][BH][BW]; M = G*PH*PW rows, m = g*PH*PW + py*PW + px;
  * Wp[b][c][tap] = blk[b,g,c, py*pstep+ky*dil+off, px*pstep+kx*dil+off]  (3x3 taps, CK=8 layout,
@@ -92,6 +113,8 @@ typedef struct TdrWgradDesc {
     float* db;         /* optional [Cout]: bias gradient sum_{n,oy,ox} dout (fused, saves a pass over dout) */
     int per_image;
     float* ws; int64_t ws_floats;      /* split-K workspace */
+    int math;          /* 0: exact fp32 MFMA; 1: 3-way bf16 split on the bf16 MFMA pipe where supported
+                          (stride 1, 1x1 / 3x3), exact fp32 otherwise */
 } TdrWgradDesc;
 int64_t tdr_wgrad_ws_floats(const TdrWgradDesc* d);
 int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream);
@@ -203,6 +226,9 @@ int tdr_scatter_ref_block(const float* dblk, int N, int C, int H, int W, const i
  * grads/params/...: device arrays of n_tensors device pointers; sizes: device int64[n_tensors].
  * sumsq[0] = sum g^2 over all tensors (double, deterministic two-stage; partial: n_chunks doubles). */
 int tdr_optim_chunk(void);
+/* dst[t][0..sizes[t]) = src[t][..] for all tensors of the chunk table, one launch (gradient arena gather) */
+int tdr_multi_copy(const float* const* src, float* const* dst, const int64_t* sizes, const int* chunk_tensor,
+                   const int* chunk_index, int n_chunks, void* stream);
 int tdr_grad_sumsq(const float* const* grads, const int64_t* sizes, const int* chunk_tensor, const int* chunk_index,
                    int n_chunks, double* partial, double* sumsq, void* stream);
 /* p,m,v updated in place.  coef = min(1, max_norm/(sqrt(sumsq)+1e-6)) computed on device when
@@ -212,6 +238,12 @@ int tdr_adamw_step(float* const* params, const float* const* grads, float* const
                    const int64_t* sizes, const int* group, const int* chunk_tensor, const int* chunk_index, int n_chunks,
                    const double* sumsq, const float* group_lr, int n_groups, float max_norm, int use_clip, float beta1,
                    float beta2, float eps, float weight_decay, int step, void* stream);
+/* Same update, per-step scalars in device memory: hp = {lr[0..3], 1-beta1^step, sqrt(1-beta2^step)} (6 floats).
+ * Launch arguments are step-invariant, so the optimiser can be replayed from a captured hipGraph. */
+int tdr_adamw_step_dev(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const int64_t* sizes, const int* group, const int* chunk_tensor, const int* chunk_index, int n_chunks,
+                       const double* sumsq, const float* hp, float max_norm, int use_clip, float beta1, float beta2,
+                       float eps, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@ from textualdegremoval_amd import kernels as K
 torch.manual_seed(0)
 FILT = sys.argv[1] if len(sys.argv) > 1 else ''
 ITERS = int(os.environ.get('ITERS', '10'))
+MATHS = os.environ.get('MATHS', 'f32,bx3').split(',')
 
 
 def timeit(name, fn, flops=None, nbytes=None):
@@ -37,15 +38,23 @@ def conv_case(tag, N, Cin, Cout, H, KH, stride=1, **kw):
     x = torch.randn(N, Cin, H, H, device='cuda')
     w = torch.randn(Cout, Cin, KH, KH, device='cuda') * 0.05
     b = torch.randn(Cout, device='cuda')
-    wp, mp, *_ = K.pack_weights(w, K.PACK_FWD)
     pad = 1 if KH == 3 else 0
     OH = (H + 2 * pad - KH) // stride + 1
     out = torch.empty(N, Cout, OH, OH, device='cuda')
     fl = 2.0 * N * Cout * Cin * KH * KH * OH * OH
     by = 4.0 * (x.numel() + out.numel())
-    timeit(f'conv{KH}x{KH} {tag} N{N} {Cin}->{Cout} @{H}', lambda: K.conv_forward(x, wp, mp, Cout, KH, stride=stride, pad=pad, bias=b, out=out), fl, by)
+    outs = {}
+    for math in MATHS:
+        K.set_math(math)
+        wp, mp, *_ = K.pack_weights(w, K.PACK_FWD)
+        timeit(f'[{math}] conv{KH}x{KH} {tag} N{N} {Cin}->{Cout} @{H}', lambda: K.conv_forward(x, wp, mp, Cout, KH, stride=stride, pad=pad, bias=b, out=out), fl, by)
+        outs[math] = out.clone()
+    if len(outs) == 2:
+        print(f'      max|bx3 - f32| = {(outs["bx3"] - outs["f32"]).abs().max().item():.3e}   (|out| max {outs["f32"].abs().max().item():.2f})')
     go = torch.randn_like(out)
-    timeit(f'wgrad{KH}x{KH} {tag} N{N} {Cin}->{Cout} @{H}', lambda: K.conv_wgrad(x, go, Cout, Cin, KH, stride=stride, pad=pad, want_db=True), fl, by)
+    for math in MATHS:
+        K.set_math(math)
+        timeit(f'[{math}] wgrad{KH}x{KH} {tag} N{N} {Cin}->{Cout} @{H}', lambda: K.conv_wgrad(x, go, Cout, Cin, KH, stride=stride, pad=pad, want_db=True), fl, by)
 
 
 if __name__ == '__main__':

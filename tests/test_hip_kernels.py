@@ -15,12 +15,17 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-@pytest.fixture(scope='module')
-def K():
+@pytest.fixture(scope='module', params=['bx3', 'f32'])
+def K(request):
+    """every kernel test runs under both matrix-core arithmetic modes of the dense convolutions
+    (split-bf16 'bx3' = product default, exact fp32 MFMA 'f32')."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from textualdegremoval_amd import kernels
-    return kernels
+    prev = kernels.MATH
+    kernels.set_math(request.param)
+    yield kernels
+    kernels.set_math(prev)
 
 
 def dev(t):
@@ -72,7 +77,7 @@ def test_conv_forward_plain(K, case):
     w = rnd(Cout, Cin, KH, KH, seed=2, scale=1.0 / (Cin * KH * KH) ** 0.5)
     b = rnd(Cout, seed=3, scale=0.3)
     ref = F.conv2d(x, w, b, stride=st, padding=pd, dilation=dl)
-    wp, mp, *_ = K.pack_weights(dev(w), K.PACK_FWD)
+    wp, mp, *_ = K.pack_weights(dev(w), K.PACK_FWD, math='f32' if dl != 1 else None)   # dilation: search path, exact only
     out = K.conv_forward(dev(x), wp, mp, Cout, KH, stride=st, dil=dl, pad=pd, bias=dev(b))
     assert out.shape == ref.shape
     assert maxdiff(out, ref) < 2e-5

@@ -13,12 +13,16 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-@pytest.fixture(scope='module')
-def E():
+@pytest.fixture(scope='module', params=['bx3', 'f32'])
+def E(request):
+    """whole-network parity under both matrix-core arithmetic modes (kernels.MATH)."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
-    from textualdegremoval_amd import engine
-    return engine
+    from textualdegremoval_amd import engine, kernels
+    prev = kernels.MATH
+    kernels.set_math(request.param)
+    yield engine
+    kernels.set_math(prev)
 
 
 def gold(name):

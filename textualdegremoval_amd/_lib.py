@@ -27,7 +27,7 @@ class TdrConvDesc(C.Structure):
         ('inp', c_fp), ('in_ns', i64),
         ('gate', i32),
         ('kscale', c_fp), ('kscale_ns', i64),
-        ('wp', c_fp), ('wp_ns', i64), ('Mpad', i32),
+        ('wp', c_fp), ('wp_ns', i64), ('Mpad', i32), ('wp_fmt', i32),
         ('out', c_fp), ('out_ns', i64),
         ('epi', i32),
         ('bias', c_fp), ('bias_ns', i64),
@@ -37,6 +37,15 @@ class TdrConvDesc(C.Structure):
         ('mask', c_fp), ('mask_ns', i64),
         ('aux', c_fp), ('aux_ns', i64),
         ('relu', i32),
+    ]
+
+
+class TdrPackJob(C.Structure):
+    _fields_ = [
+        ('w', c_fp), ('wp', c_fp),
+        ('Cout', i32), ('Cin', i32), ('KH', i32), ('mode', i32), ('fmt', i32),
+        ('M', i32), ('Kch', i32), ('KHe', i32), ('CK', i32), ('Mx', i32),
+        ('total', i64), ('first_block', i64),
     ]
 
 
@@ -50,6 +59,7 @@ class TdrWgradDesc(C.Structure):
         ('db', c_fp),
         ('per_image', i32),
         ('ws', c_fp), ('ws_floats', i64),
+        ('math', i32),
     ]
 
 
@@ -61,6 +71,10 @@ SIGNATURES = {
     'tdr_conv_ck': (i32, [i32]),
     'tdr_packed_weight_floats': (i64, [i32, i32, i32]),
     'tdr_pack_weights': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_packed_weight_bytes_bx3': (i64, [i32, i32, i32]),
+    'tdr_pack_weights_bx3': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_pack_job_init': (i32, [C.POINTER(TdrPackJob), c_fp, i32, i32, i32, i32, i32, c_fp]),
+    'tdr_pack_weights_multi': (i32, [c_fp, i32, i64, c_fp]),
     'tdr_pack_patches': (i32, [c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_wgrad_ws_floats': (i64, [C.POINTER(TdrWgradDesc)]),
     'tdr_conv_wgrad': (i32, [C.POINTER(TdrWgradDesc), c_fp]),
@@ -94,8 +108,10 @@ SIGNATURES = {
     'tdr_transfer_bwd': (i32, [c_fp, i64, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32,
                                c_fp, c_fp, c_fp, c_fp]),
     'tdr_optim_chunk': (i32, []),
+    'tdr_multi_copy': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp]),
     'tdr_grad_sumsq': (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp]),
     'tdr_adamw_step': (i32, [c_fp] * 8 + [i32, c_fp, C.POINTER(f32), i32, f32, i32, f32, f32, f32, f32, i32, c_fp]),
+    'tdr_adamw_step_dev': (i32, [c_fp] * 8 + [i32, c_fp, c_fp, f32, i32, f32, f32, f32, f32, c_fp]),
 }
 
 _lib = None

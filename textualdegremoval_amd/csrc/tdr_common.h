@@ -29,6 +29,9 @@ void tdr_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+struct TdrConvDesc;
+int tdr_conv_forward_bx3(const TdrConvDesc* d, void* stream);   // tdr_conv_bx3.hip
+
 static inline int tdr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;

@@ -1,0 +1,320 @@
+// Implicit-GEMM convolution on the gfx950 bf16 matrix cores with fp32-equivalent arithmetic.
+//
+// Every fp32 operand x is split on the fly into three bf16 terms x = h + m + l
+// (h = rn_bf16(x), m = rn_bf16(x - h), l = rn_bf16(x - h - m): 24+ significant bits), and each
+// fp32 product a*b is evaluated as the six cross products
+//     al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh          (dropped terms <= 2^-25 |a*b|)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Per product this is at least as accurate as
+// one fp32 multiply; the accumulation is fp32 like the exact kernel (tdr_conv_mfma.hip).  The bf16
+// pipe is 16x the fp32-MFMA rate, so six products cost 0.375x of v_mfma_f32_32x32x2_f32
+// (ceiling 2.5 PFLOP/s / 6 = 416 fp32-equivalent TFLOP/s vs 157).  profiles/probes/bf16x3_probe.hip
+// measures the error of this scheme against the exact chain and an fp64 reference.
+//
+//   out[n][m][pix] = epi( sum_k A[m][k] * B[k][pix] ),  k = (16-channel group, tap, channel)
+//
+// One workgroup = 4 waves, one per SIMD, two workgroups per CU.  The block owns BM = 32*TM*WM
+// output channels x 32*TN*WN pixels (32-pixel sub-tiles of 32/TW rows x TW cols).
+//   A (weights): pre-split and pre-packed in MFMA fragment order by tdr_pack_weights_bx3, read
+//                straight from L2/L1 into VGPRs (1 KiB coalesced wave loads, never through LDS);
+//   B (pixels) : the input halo tile of 16 channels is loaded NCHW-coalesced, split in registers
+//                and written to LDS as s_in[buf][split][kgroup][pixel] 16-byte slots (8 channels),
+//                so a B fragment is one conflict-free ds_read_b128 per lane for any tap shift.
+// LDS is double buffered: the global loads of group c+1 are in flight under the MFMAs of group c,
+// one barrier per group.
+#include "tdr_common.h"
+#include "tdr_conv_epi.h"
+#include "tdr_pack.h"
+#include "../../include/tdr.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int bx_cmax(int a, int b) { return a > b ? a : b; }
+constexpr int bx_plane(int NT, int TW, int KH, int S) {
+    return (((NT * 32 / TW) - 1) * S + KH) * ((TW - 1) * S + KH);
+}
+constexpr int bx_max_plane(int NT, int KH, int S) {
+    return bx_cmax(bx_plane(NT, 8, KH, S), bx_cmax(bx_plane(NT, 16, KH, S), bx_plane(NT, 32, KH, S)));
+}
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r = x - (float)h;
+    m = (__bf16)r;
+    l = (__bf16)(r - (float)m);
+}
+
+union Frag {
+    uint4 u;
+    bf16x8 v;
+};
+
+template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE>
+__global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
+    constexpr int WN = 4 / WM;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int NT = TN * WN;
+    constexpr int TAPS = KH * KH;
+    constexpr int NIT = (bx_max_plane(NT, KH, S) + 127) / 128;   // a wave pair stages 128 halo pixels per pass
+
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int j = lane & 31, kk = lane >> 5;
+    const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2, TH = NT * SR;
+    const int LH = (TH - 1) * S + KH, LW = (TW - 1) * S + KH;
+    const int plane = LH * LW;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int m0 = blockIdx.y * BM;
+    const int n = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+    const long HWin = (long)a.H * a.W;
+
+    // ---- staging geometry: waves {0,1} stage channels 0-7 of the group, waves {2,3} channels 8-15
+    const int sg = wave >> 1;
+    const int sp0 = (wave & 1) * 64 + lane;
+    int gsafe[NIT];
+    unsigned okmask = 0, inplane = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = sp0 + 128 * it;
+        const int r = p / LW, x = p - r * LW;
+        const int gy = iy0 + r, gx = ix0 + x;
+        const bool inp = p < plane;
+        const bool ok = inp && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        gsafe[it] = ok ? gy * a.W + gx : 0;
+        okmask |= (ok ? 1u : 0u) << it;
+        inplane |= (inp ? 1u : 0u) << it;
+    }
+    const float* in_n = a.in + (long)n * a.in_ns;
+    const float* ks_n = a.kscale ? a.kscale + (long)n * a.kscale_ns : nullptr;
+    const int ngroups = (a.Cin + 15) >> 4;
+
+    float rin[NIT][8];
+    float rin2[GATE ? NIT : 1][GATE ? 8 : 1];
+    float rks[8];
+    auto load_group = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ci = min(g * 16 + sg * 8 + i, a.Cin - 1);
+            const float* base = in_n + (long)ci * HWin;
+            rks[i] = ks_n ? ks_n[ci] : 1.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                rin[it][i] = base[gsafe[it]];
+                if (GATE) rin2[it][i] = base[gsafe[it] + a.gate_off];
+            }
+        }
+    };
+    auto store_group = [&](int g, int buf) {
+        uint4* sb = smem4 + (buf * 6 + sg) * plane;
+        const int cbase = g * 16 + sg * 8;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            Frag h, m, l;
+            const bool ok = (okmask >> it) & 1u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = rin[it][i];
+                if (GATE) v *= rin2[it][i];
+                v *= rks[i];
+                v = (ok && cbase + i < a.Cin) ? v : 0.f;
+                __bf16 hh, mm, ll;
+                split3(v, hh, mm, ll);
+                h.v[i] = hh; m.v[i] = mm; l.v[i] = ll;
+            }
+            if ((inplane >> it) & 1u) {
+                const int p = sp0 + 128 * it;
+                sb[p] = h.u;
+                sb[2 * plane + p] = m.u;
+                sb[4 * plane + p] = l.u;
+            }
+        }
+    };
+
+    // ---- fragment addresses
+    int bbase[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int t = wn * TN + tn;
+        const int py = t * SR + (j >> a.tw_log2), px = j & (TW - 1);
+        bbase[tn] = kk * plane + py * S * LW + px * S;
+    }
+    // packed weights: [group][tap][m-tile][split][lane] 16-byte fragments
+    const int MT = a.Mpad >> 5;
+    const uint4* wfrag[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int mt = min((m0 >> 5) + wm * TM + tm, MT - 1);
+        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)mt * 192 + lane;
+    }
+    const long wstep = (long)MT * 192;          // 16-byte units per (group, tap)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    Frag af[TM][3], afn[TM][3];
+    auto load_a = [&](Frag (&dst)[TM][3], long gt) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) dst[tm][s].u = wfrag[tm][gt * wstep + s * 64];
+    };
+
+    load_group(0);
+    load_a(af, 0);
+    store_group(0, 0);
+    __syncthreads();
+
+    for (int g = 0; g < ngroups; ++g) {
+        const int buf = g & 1;
+        if (g + 1 < ngroups) load_group(g + 1);
+        const uint4* sb = smem4 + buf * 6 * plane;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int tapoff = (tap / KH) * LW + (tap % KH);
+            // next (group, tap) weight fragments; the last prefetch of the last group re-reads a valid slot
+            const long gtn = min((long)g * TAPS + tap + 1, (long)ngroups * TAPS - 1);
+            load_a(afn, gtn);
+            Frag bf[TN][3];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) bf[tn][s].u = sb[s * 2 * plane + bbase[tn] + tapoff];
+            // small cross terms first, the dominant h*h last
+            constexpr int SA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int SB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) af[tm][s] = afn[tm][s];
+        }
+        if (g + 1 < ngroups) store_group(g + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    conv_epilogue<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
+}
+
+template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE>
+int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
+    constexpr int WN = 4 / WM;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int NT = TN * WN;
+    const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2, TH = NT * SR;
+    const int LH = (TH - 1) * S + KH, LW = (TW - 1) * S + KH;
+    const size_t lds = (size_t)12 * LH * LW * 16;
+    ConvArgs b = a;
+    b.tiles_x = tdr_cdiv(a.OW, TW);
+    const int tiles_y = tdr_cdiv(a.OH, TH);
+    dim3 grid(b.tiles_x * tiles_y, tdr_cdiv(a.Cout, BM), N);
+    auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, b);
+    TDR_LAUNCH_CHECK("conv_bx3_kernel");
+    return TDR_OK;
+}
+
+template <int KH, int S, int EPI, bool GATE>
+int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
+    const long pix = (long)a.OH * a.OW;
+    auto blocks = [&](int bm, int bn) { return (long)tdr_cdiv(a.Cout, bm) * tdr_cdiv(pix, bn) * N; };
+    if constexpr (S == 2) {   // the input halo of a stride-2 tile is 4x the output pixels: keep the pixel tile small
+        if (a.Cout <= 32) return launch_bx_cfg<KH, S, 1, 1, 1, EPI, GATE>(a, N, st);  // 32 x 128
+        if (a.Cout <= 64 || blocks(128, 64) < 512) return launch_bx_cfg<KH, S, 2, 1, 1, EPI, GATE>(a, N, st);  // 64 x 64
+        return launch_bx_cfg<KH, S, 2, 2, 1, EPI, GATE>(a, N, st);                     // 128 x 64
+    } else {
+        // largest tile that still gives every CU its two resident workgroups (512 blocks)
+        if (a.Cout <= 32) {
+            if (blocks(32, 256) >= 512) return launch_bx_cfg<KH, S, 1, 1, 2, EPI, GATE>(a, N, st);   // 32 x 256
+            return launch_bx_cfg<KH, S, 1, 1, 1, EPI, GATE>(a, N, st);                               // 32 x 128
+        }
+        if (a.Cout > 64 && blocks(128, 256) >= 512) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);  // 128 x 256
+        if (blocks(64, 256) >= 512) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);       // 64 x 256
+        return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);                                   // 64 x 128
+    }
+}
+
+// one thread per 16-byte fragment (all three splits)
+__global__ void pack_weights_bx3_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int mode, int M, int Kch,
+                                        int KHe, int MT, long total, uint4* __restrict__ wp) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        tdr_pack_bx3_frag(w, Cin, KH, mode, M, Kch, KHe, MT, i, wp);
+}
+
+}  // namespace
+
+extern "C" int64_t tdr_packed_weight_bytes_bx3(int M, int Kch, int KH_eff) {
+    const long MT = (M + 31) / 32;
+    return (long)((Kch + 15) / 16) * KH_eff * KH_eff * MT * 3 * 1024;
+}
+
+extern "C" int tdr_pack_weights_bx3(const float* w, int Cout, int Cin, int KH, int mode, void* wp, void* stream) {
+    TDR_REQUIRE(w && wp, "tdr_pack_weights_bx3: null pointer");
+    TDR_REQUIRE(mode >= 0 && mode <= 3, "tdr_pack_weights_bx3: bad mode %d", mode);
+    int M, Kch, KHe;
+    if (mode == 0) { M = Cout; Kch = Cin; KHe = KH; }
+    else if (mode == 1) { M = Cin; Kch = Cout; KHe = KH; }
+    else if (mode == 2) { TDR_REQUIRE(KH == 2, "mode 2 needs a 2x2 kernel"); M = 4 * Cin; Kch = Cout; KHe = 1; }
+    else { TDR_REQUIRE(KH == 3, "mode 3 needs a 3x3 kernel"); M = 4 * Cin; Kch = Cout; KHe = 2; }
+    const int MT = (M + 31) / 32;
+    const long total = (long)((Kch + 15) / 16) * KHe * KHe * MT * 64;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weights_bx3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KH, mode, M,
+                       Kch, KHe, MT, total, (uint4*)wp);
+    TDR_LAUNCH_CHECK("pack_weights_bx3_kernel");
+    return TDR_OK;
+}
+
+// called by tdr_conv_forward (tdr_conv_mfma.hip) when the descriptor carries bx3-packed weights
+int tdr_conv_forward_bx3(const TdrConvDesc* d, void* stream) {
+    TDR_REQUIRE(d->dil == 1 && d->wp_ns == 0, "tdr_conv_forward: split-bf16 path needs dil=1 and shared weights");
+    ConvArgs a;
+    a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
+    a.wp = (const float*)d->wp; a.wp_ns = 0; a.Mpad = d->Mpad; a.Cout = d->Cout;
+    a.out = d->out; a.out_ns = d->out_ns; a.OH = d->OH; a.OW = d->OW;
+    a.pad = d->pad;
+    a.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);
+    a.tiles_x = 0;
+    a.kscale = d->kscale; a.kscale_ns = d->kscale_ns;
+    a.gate_off = (long)d->Cin * d->H * d->W;
+    a.bias = d->bias; a.bias_ns = d->bias_ns; a.scale = d->scale; a.scale_ns = d->scale_ns;
+    a.bias2 = d->bias2; a.bias2_ns = d->bias2_ns; a.bias2_mul = d->bias2_mul;
+    a.res = d->res; a.res_ns = d->res_ns; a.mask = d->mask; a.mask_ns = d->mask_ns;
+    a.aux = d->aux; a.aux_ns = d->aux_ns; a.relu = d->relu;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = d->N;
+    const int key = d->KH * 100 + d->stride * 10 + d->epi;
+    const bool g = d->gate != 0;
+    switch (key) {
+        case 110: return g ? launch_bx_shape<1, 1, EPI_STD, true>(a, N, st) : launch_bx_shape<1, 1, EPI_STD, false>(a, N, st);
+        case 111: if (!g) return launch_bx_shape<1, 1, EPI_GATEBWD, false>(a, N, st); break;
+        case 112: if (!g) return launch_bx_shape<1, 1, EPI_PSHUF, false>(a, N, st); break;
+        case 310: if (!g) return launch_bx_shape<3, 1, EPI_STD, false>(a, N, st); break;
+        case 320: if (!g) return launch_bx_shape<3, 2, EPI_STD, false>(a, N, st); break;
+        case 220: if (!g) return launch_bx_shape<2, 2, EPI_STD, false>(a, N, st); break;
+        case 212: if (!g) return launch_bx_shape<2, 1, EPI_PSHUF, false>(a, N, st); break;
+        default: break;
+    }
+    tdr_set_error("tdr_conv_forward(bx3): unsupported (KH=%d stride=%d epi=%d gate=%d)", d->KH, d->stride, d->epi, d->gate);
+    return TDR_ERR_UNSUPPORTED;
+}

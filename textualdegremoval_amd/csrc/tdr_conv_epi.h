@@ -1,0 +1,147 @@
+// Shared argument block and output epilogues of the implicit-GEMM convolution kernels
+// (tdr_conv_mfma.hip: exact fp32 MFMA; tdr_conv_bx3.hip: 3-way bf16 split MFMA).  Both produce
+// 32x32 accumulator tiles in the gfx950 C/D layout: lane (j = lane&31, kk = lane>>5) holds pixel j
+// of sub-tile tn and rows (r&3) + 8*(r>>2) + 4*kk.
+#pragma once
+#include "tdr_common.h"
+
+namespace {
+
+enum { EPI_STD = 0, EPI_GATEBWD = 1, EPI_PSHUF = 2 };
+
+struct ConvArgs {
+    const float* in; long in_ns; int Cin, H, W;
+    const float* wp; long wp_ns; int Mpad, Cout;
+    float* out; long out_ns; int OH, OW;
+    int pad, tw_log2, tiles_x;
+    const float* kscale; long kscale_ns;
+    long gate_off;
+    const float* bias; long bias_ns;
+    const float* scale; long scale_ns;
+    const float* bias2; long bias2_ns; float bias2_mul;
+    const float* res; long res_ns;
+    const float* mask; long mask_ns;
+    const float* aux; long aux_ns;
+    int relu;
+};
+
+// acc[TM][TN]: wave (wm, wn) owns output-channel tiles wm*TM.. and pixel sub-tiles wn*TN..
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int n, int m0, int wm, int wn,
+                                              int oy0, int ox0, int j, int kk) {
+    const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2;
+    const long HWo = (long)a.OH * a.OW;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int t = wn * TN + tn;
+        const int oy = oy0 + t * SR + (j >> a.tw_log2), ox = ox0 + (j & (TW - 1));
+        const bool pvalid = oy < a.OH && ox < a.OW;
+        const long pix = pvalid ? (long)oy * a.OW + ox : 0;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int mb = m0 + (wm * TM + tm) * 32 + 4 * kk;
+            if (EPI == EPI_PSHUF) {
+                // rows 4q..4q+3 (q = r>>2) of this lane are the 2x2 sub-pixels of channel (mb+8q)/4
+                const long OW2 = 2L * a.OW;
+                const long p2 = pvalid ? (2L * oy) * OW2 + 2L * ox : 0;
+                float2 r0[4], r1[4];
+                if (a.res) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = min(mb + 8 * q, a.Cout - 4) >> 2;
+                        const float* rp = a.res + (long)n * a.res_ns + (long)c * 4 * HWo + p2;
+                        r0[q] = *reinterpret_cast<const float2*>(rp);
+                        r1[q] = *reinterpret_cast<const float2*>(rp + OW2);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mb + 8 * q;
+                    float v0 = acc[tm][tn][4 * q + 0], v1 = acc[tm][tn][4 * q + 1];
+                    float v2 = acc[tm][tn][4 * q + 2], v3 = acc[tm][tn][4 * q + 3];
+                    if (a.res) { v0 += r0[q].x; v1 += r0[q].y; v2 += r1[q].x; v3 += r1[q].y; }
+                    if (pvalid && m < a.Cout) {
+                        float* o = a.out + (long)n * a.out_ns + (long)(m >> 2) * 4 * HWo + p2;
+                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                        *reinterpret_cast<float2*>(o + OW2) = make_float2(v2, v3);
+                    }
+                }
+            } else if (EPI == EPI_GATEBWD) {
+                const float* ax = a.aux + (long)n * a.aux_ns;
+                const long half = (long)a.Cout * HWo;
+                float a0[16], a1[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mc = min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1);
+                    const long o = (long)mc * HWo + pix;
+                    a0[r] = ax[o];
+                    a1[r] = ax[o + half];
+                }
+                float* op = a.out + (long)n * a.out_ns;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (pvalid && m < a.Cout) {
+                        const long o = (long)m * HWo + pix;
+                        const float v = acc[tm][tn][r];
+                        op[o] = v * a1[r];
+                        op[o + half] = v * a0[r];
+                    }
+                }
+            } else {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r];
+                if (a.bias) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = a.bias[(long)n * a.bias_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += tv[r];
+                }
+                if (a.scale) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = a.scale[(long)n * a.scale_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] *= tv[r];
+                }
+                if (a.bias2) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = a.bias2[(long)n * a.bias2_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += a.bias2_mul * tv[r];
+                }
+                if (a.res) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tv[r] = a.res[(long)n * a.res_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HWo + pix];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += tv[r];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (a.mask) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tv[r] = a.mask[(long)n * a.mask_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HWo + pix];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = tv[r] > 0.f ? v[r] : 0.f;
+                }
+                float* op = a.out + (long)n * a.out_ns + pix;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (pvalid && m < a.Cout) op[(long)m * HWo] = v[r];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace

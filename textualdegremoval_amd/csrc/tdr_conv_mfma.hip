@@ -15,6 +15,8 @@
 // address VALU are free.  fp32 MFMA keeps the 1e-4 max-abs parity bar of the
 // reference's fp32 CPU path; see DESIGN.md for the roofline of this choice.
 #include "tdr_common.h"
+#include "tdr_conv_epi.h"
+#include "tdr_pack.h"
 #include "../../include/tdr.h"
 
 // TDR_PROBE (profiling builds only, see profiles/probes/): 1 = no global loads inside the K loop,
@@ -24,24 +26,6 @@
 #endif
 
 namespace {
-
-enum { EPI_STD = 0, EPI_GATEBWD = 1, EPI_PSHUF = 2 };
-
-struct ConvArgs {
-    const float* in; long in_ns; int Cin, H, W;
-    const float* wp; long wp_ns; int Mpad, Cout;
-    float* out; long out_ns; int OH, OW;
-    int pad, tw_log2, tiles_x;
-    const float* kscale; long kscale_ns;
-    long gate_off;
-    const float* bias; long bias_ns;
-    const float* scale; long scale_ns;
-    const float* bias2; long bias2_ns; float bias2_mul;
-    const float* res; long res_ns;
-    const float* mask; long mask_ns;
-    const float* aux; long aux_ns;
-    int relu;
-};
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int plane_elems(int NT, int TW, int KH, int S, int D) {
@@ -202,121 +186,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         }
     }
 
-    // ---- epilogue: lane holds pixel j of sub-tile tn, rows (r&3)+8*(r>>2)+4*kk ----
-    // All optional operand loads are unconditional (clamped indices) and grouped per operand so
-    // they are issued back to back; only the final stores are predicated.
-    const long HWo = (long)a.OH * a.OW;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int t = wn * TN + tn;
-        const int oy = oy0 + t * SR + (j >> a.tw_log2), ox = ox0 + (j & (TW - 1));
-        const bool pvalid = oy < a.OH && ox < a.OW;
-        const long pix = pvalid ? (long)oy * a.OW + ox : 0;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int mb = m0 + (wm * TM + tm) * 32 + 4 * kk;
-            if (EPI == EPI_PSHUF) {
-                // rows 4q..4q+3 (q = r>>2) of this lane are the 2x2 sub-pixels of channel (mb+8q)/4
-                const long OW2 = 2L * a.OW;
-                const long p2 = pvalid ? (2L * oy) * OW2 + 2L * ox : 0;
-                float2 r0[4], r1[4];
-                if (a.res) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = min(mb + 8 * q, a.Cout - 4) >> 2;
-                        const float* rp = a.res + (long)n * a.res_ns + (long)c * 4 * HWo + p2;
-                        r0[q] = *reinterpret_cast<const float2*>(rp);
-                        r1[q] = *reinterpret_cast<const float2*>(rp + OW2);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = mb + 8 * q;
-                    float v0 = acc[tm][tn][4 * q + 0], v1 = acc[tm][tn][4 * q + 1];
-                    float v2 = acc[tm][tn][4 * q + 2], v3 = acc[tm][tn][4 * q + 3];
-                    if (a.res) { v0 += r0[q].x; v1 += r0[q].y; v2 += r1[q].x; v3 += r1[q].y; }
-                    if (pvalid && m < a.Cout) {
-                        float* o = a.out + (long)n * a.out_ns + (long)(m >> 2) * 4 * HWo + p2;
-                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
-                        *reinterpret_cast<float2*>(o + OW2) = make_float2(v2, v3);
-                    }
-                }
-            } else if (EPI == EPI_GATEBWD) {
-                const float* ax = a.aux + (long)n * a.aux_ns;
-                const long half = (long)a.Cout * HWo;
-                float a0[16], a1[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mc = min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1);
-                    const long o = (long)mc * HWo + pix;
-                    a0[r] = ax[o];
-                    a1[r] = ax[o + half];
-                }
-                float* op = a.out + (long)n * a.out_ns;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (pvalid && m < a.Cout) {
-                        const long o = (long)m * HWo + pix;
-                        const float v = acc[tm][tn][r];
-                        op[o] = v * a1[r];
-                        op[o + half] = v * a0[r];
-                    }
-                }
-            } else {
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r];
-                if (a.bias) {
-                    float tv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) tv[r] = a.bias[(long)n * a.bias_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] += tv[r];
-                }
-                if (a.scale) {
-                    float tv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) tv[r] = a.scale[(long)n * a.scale_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] *= tv[r];
-                }
-                if (a.bias2) {
-                    float tv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) tv[r] = a.bias2[(long)n * a.bias2_ns + min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] += a.bias2_mul * tv[r];
-                }
-                if (a.res) {
-                    float tv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        tv[r] = a.res[(long)n * a.res_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HWo + pix];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] += tv[r];
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                if (a.mask) {
-                    float tv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        tv[r] = a.mask[(long)n * a.mask_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HWo + pix];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = tv[r] > 0.f ? v[r] : 0.f;
-                }
-                float* op = a.out + (long)n * a.out_ns + pix;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (pvalid && m < a.Cout) op[(long)m * HWo] = v[r];
-                }
-            }
-        }
-    }
+    conv_epilogue<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
 }
 
 template <int KH, int S, int D, int CK, int WM, int TM, int TN, int EPI, bool GATE>
@@ -359,32 +229,8 @@ int launch_shape(const ConvArgs& a, int N, hipStream_t st) {
 // ---------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int mode, int CK,
                                     int M, int Kch, int KHe, int Mpad, long total, float* __restrict__ wp) {
-    const int taps_e = KHe * KHe;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(i % Mpad);
-        long r = i / Mpad;
-        const int ck = (int)(r % CK); r /= CK;
-        const int tap = (int)(r % taps_e);
-        const int chunk = (int)(r / taps_e);
-        const int c = chunk * CK + ck;
-        float v = 0.f;
-        if (m < M && c < Kch) {
-            const int taps = KH * KH;
-            if (mode == 0) {
-                v = w[((long)m * Cin + c) * taps + tap];
-            } else if (mode == 1) {
-                v = w[((long)c * Cin + m) * taps + (taps - 1 - tap)];
-            } else if (mode == 2) {              // 2x2 s2 dgrad as 1x1: m = ci*4 + a*2 + b
-                v = w[((long)c * Cin + (m >> 2)) * 4 + (m & 3)];
-            } else {                             // 3x3 s2 p1 dgrad as 2x2 s1: tap = u*2+v
-                const int ci = m >> 2, aa = (m >> 1) & 1, bb = m & 1, u = tap >> 1, vv = tap & 1;
-                const int ky = aa == 0 ? (u == 0 ? 1 : -1) : (u == 0 ? 2 : 0);
-                const int kx = bb == 0 ? (vv == 0 ? 1 : -1) : (vv == 0 ? 2 : 0);
-                if (ky >= 0 && kx >= 0) v = w[((long)c * Cin + ci) * 9 + ky * 3 + kx];
-            }
-        }
-        wp[i] = v;
-    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        wp[i] = tdr_pack_f32_elem(w, Cin, KH, mode, CK, M, Kch, KHe, Mpad, i);
 }
 
 __global__ void pack_patches_kernel(const float* __restrict__ blk, int G, int C, int BH, int BW, int PH, int PW, int pstep,
@@ -455,9 +301,11 @@ extern "C" int tdr_conv_forward(const TdrConvDesc* d, void* stream) {
     TDR_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->OH > 0 && d->OW > 0, "tdr_conv_forward: bad shape");
     TDR_REQUIRE(d->Mpad % 32 == 0 && d->Mpad >= d->Cout, "tdr_conv_forward: Mpad %d invalid for Cout %d", d->Mpad, d->Cout);
     TDR_REQUIRE(d->epi != EPI_GATEBWD || d->aux, "tdr_conv_forward: GATEBWD needs aux");
+    if (d->wp_fmt == 1) return tdr_conv_forward_bx3(d, stream);
+    TDR_REQUIRE(d->wp_fmt == 0, "tdr_conv_forward: unknown wp_fmt %d", d->wp_fmt);
     ConvArgs a;
     a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
-    a.wp = d->wp; a.wp_ns = d->wp_ns; a.Mpad = d->Mpad; a.Cout = d->Cout;
+    a.wp = (const float*)d->wp; a.wp_ns = d->wp_ns; a.Mpad = d->Mpad; a.Cout = d->Cout;
     a.out = d->out; a.out_ns = d->out_ns; a.OH = d->OH; a.OW = d->OW;
     a.pad = d->pad;
     a.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);
@@ -488,4 +336,56 @@ extern "C" int tdr_conv_forward(const TdrConvDesc* d, void* stream) {
     tdr_set_error("tdr_conv_forward: unsupported (KH=%d stride=%d dil=%d epi=%d gate=%d)", d->KH, d->stride, d->dil,
                   d->epi, d->gate);
     return TDR_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------
+// multi-tensor packing: every weight of the network for every use (forward / data-gradient layout,
+// fp32 rows or split-bf16 fragments) in ONE launch per step instead of ~480 small ones.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void pack_multi_kernel(const TdrPackJob* __restrict__ jobs, int n_jobs) {
+    // binary search: last job whose first_block <= blockIdx.x
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const TdrPackJob jb = jobs[lo];
+    const long i = ((long)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (i >= jb.total) return;
+    if (jb.fmt == 0)
+        reinterpret_cast<float*>(jb.wp)[i] = tdr_pack_f32_elem(jb.w, jb.Cin, jb.KH, jb.mode, jb.CK, jb.M, jb.Kch, jb.KHe, jb.Mx, i);
+    else
+        tdr_pack_bx3_frag(jb.w, jb.Cin, jb.KH, jb.mode, jb.M, jb.Kch, jb.KHe, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
+}
+}  // namespace
+
+extern "C" int tdr_pack_job_init(TdrPackJob* job, const float* w, int Cout, int Cin, int KH, int mode, int fmt, void* wp) {
+    TDR_REQUIRE(job && w && wp, "tdr_pack_job_init: null pointer");
+    TDR_REQUIRE(mode >= 0 && mode <= 3 && (fmt == 0 || fmt == 1), "tdr_pack_job_init: bad mode/fmt");
+    int M, Kch, KHe;
+    if (mode == 0) { M = Cout; Kch = Cin; KHe = KH; }
+    else if (mode == 1) { M = Cin; Kch = Cout; KHe = KH; }
+    else if (mode == 2) { TDR_REQUIRE(KH == 2, "mode 2 needs a 2x2 kernel"); M = 4 * Cin; Kch = Cout; KHe = 1; }
+    else { TDR_REQUIRE(KH == 3, "mode 3 needs a 3x3 kernel"); M = 4 * Cin; Kch = Cout; KHe = 2; }
+    job->w = w; job->wp = wp; job->Cout = Cout; job->Cin = Cin; job->KH = KH; job->mode = mode; job->fmt = fmt;
+    job->M = M; job->Kch = Kch; job->KHe = KHe;
+    if (fmt == 0) {
+        job->CK = tdr_conv_ck(KHe);
+        job->Mx = (M + 31) / 32 * 32;
+        job->total = tdr_packed_weight_floats(M, Kch, KHe);
+    } else {
+        job->CK = 16;
+        job->Mx = (M + 31) / 32;
+        job->total = (long)((Kch + 15) / 16) * KHe * KHe * job->Mx * 64;
+    }
+    job->first_block = 0;
+    return TDR_OK;
+}
+
+extern "C" int tdr_pack_weights_multi(const TdrPackJob* jobs_dev, int n_jobs, int64_t total_blocks, void* stream) {
+    TDR_REQUIRE(jobs_dev && n_jobs > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "tdr_pack_weights_multi: bad argument");
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    TDR_LAUNCH_CHECK("pack_multi_kernel");
+    return TDR_OK;
 }

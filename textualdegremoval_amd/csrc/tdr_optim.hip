@@ -44,10 +44,24 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const double* __restr
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// dst[t][i] = src[t][i] for every tensor of a (tensor, chunk) table: gathers ~900 freshly produced gradient
+// tensors into the flat all-reduce / optimiser arena with ONE launch instead of one copy kernel per tensor.
+__global__ __launch_bounds__(256) void multi_copy_kernel(const float* const* __restrict__ src, float* const* __restrict__ dst,
+                                                        const int64_t* __restrict__ sizes, const int* __restrict__ chunk_tensor,
+                                                        const int* __restrict__ chunk_index) {
+    const int t = chunk_tensor[blockIdx.x];
+    const long base = (long)chunk_index[blockIdx.x] * CHUNK;
+    const long n = sizes[t];
+    const float* s = src[t];
+    float* d = dst[t];
+    for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) d[i] = s[i];
+}
+
 struct AdamArgs {
     float lr[4];
     float max_norm, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;
     int use_clip;
+    const float* hp;    // optional device-resident {lr[4], bc1, bc2_sqrt} (graph replay: values change, launch does not)
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ params, const float* const* __restrict__ grads,
@@ -62,19 +76,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ p
     const float* g = grads[t];
     float* m = exp_avg[t];
     float* v = exp_avg_sq[t];
-    const float lr = a.lr[group[t]];
+    const float lr = a.hp ? a.hp[group[t]] : a.lr[group[t]];
+    const float bc1 = a.hp ? a.hp[4] : a.bc1;
+    const float bc2_sqrt = a.hp ? a.hp[5] : a.bc2_sqrt;
     float coef = 1.f;
     if (a.use_clip) {
         const float total = (float)sqrt(sumsq[0]);
         coef = fminf(a.max_norm / (total + 1e-6f), 1.f);
     }
-    const float step = lr / a.bc1;
+    const float step = lr / bc1;
     for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) {
         const float gv = g[i] * coef;
         float pv = p[i] * (1.f - lr * a.weight_decay);
         const float mv = m[i] + (1.f - a.beta1) * (gv - m[i]);            // lerp, as torch.optim
         const float vv = a.beta2 * v[i] + (1.f - a.beta2) * gv * gv;
-        const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
+        const float denom = sqrtf(vv) / bc2_sqrt + a.eps;
         pv -= step * (mv / denom);
         p[i] = pv; m[i] = mv; v[i] = vv;
     }
@@ -106,8 +122,39 @@ extern "C" int tdr_adamw_step(float* const* params, const float* const* grads, f
     a.bc1 = (float)(1.0 - pow((double)beta1, step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
     a.use_clip = use_clip;
+    a.hp = nullptr;
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes,
                        group, chunk_tensor, chunk_index, sumsq, a);
     TDR_LAUNCH_CHECK("adamw_step");
+    return TDR_OK;
+}
+
+// Same update with the per-step scalars read from device memory: hp = {lr[0..3], 1-beta1^step, sqrt(1-beta2^step)}.
+// The launch arguments do not change from step to step, so the launch can be replayed from a hipGraph while the
+// host refreshes `hp` with a 24-byte copy.
+extern "C" int tdr_adamw_step_dev(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                  const int64_t* sizes, const int* group, const int* chunk_tensor, const int* chunk_index,
+                                  int n_chunks, const double* sumsq, const float* hp, float max_norm, int use_clip, float beta1,
+                                  float beta2, float eps, float weight_decay, void* stream) {
+    TDR_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes && group && chunk_tensor && chunk_index && sumsq && hp,
+                "tdr_adamw_step_dev: null pointer");
+    AdamArgs a;
+    for (int i = 0; i < 4; ++i) a.lr[i] = 0.f;
+    a.max_norm = max_norm; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = 1.f; a.bc2_sqrt = 1.f;
+    a.use_clip = use_clip;
+    a.hp = hp;
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes,
+                       group, chunk_tensor, chunk_index, sumsq, a);
+    TDR_LAUNCH_CHECK("adamw_step_dev");
+    return TDR_OK;
+}
+
+extern "C" int tdr_multi_copy(const float* const* src, float* const* dst, const int64_t* sizes, const int* chunk_tensor,
+                              const int* chunk_index, int n_chunks, void* stream) {
+    TDR_REQUIRE(src && dst && sizes && chunk_tensor && chunk_index && n_chunks > 0, "tdr_multi_copy: bad argument");
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, src, dst, sizes, chunk_tensor,
+                       chunk_index);
+    TDR_LAUNCH_CHECK("multi_copy");
     return TDR_OK;
 }

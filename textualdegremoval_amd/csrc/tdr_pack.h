@@ -1,0 +1,65 @@
+// Weight value lookup shared by the packing kernels (fp32 rows, split-bf16 fragments, multi-tensor).
+#pragma once
+#include "tdr_common.h"
+
+// GEMM-row m, contraction channel c, tap index of the *effective* kernel (see include/tdr.h, tdr_pack_weights):
+//   mode 0 FWD, 1 DGRAD_S1 (transposed + flipped), 2 DGRAD_2x2S2 (as 1x1, m = ci*4+a*2+b), 3 DGRAD_3x3S2 (as 2x2)
+__device__ __forceinline__ float tdr_pack_value(const float* __restrict__ w, int Cin, int KH, int mode, int m, int c, int tap) {
+    const int taps = KH * KH;
+    if (mode == 0) return w[((long)m * Cin + c) * taps + tap];
+    if (mode == 1) return w[((long)c * Cin + m) * taps + (taps - 1 - tap)];
+    if (mode == 2) return w[((long)c * Cin + (m >> 2)) * 4 + (m & 3)];
+    const int ci = m >> 2, aa = (m >> 1) & 1, bb = m & 1, u = tap >> 1, vv = tap & 1;
+    const int ky = aa == 0 ? (u == 0 ? 1 : -1) : (u == 0 ? 2 : 0);
+    const int kx = bb == 0 ? (vv == 0 ? 1 : -1) : (vv == 0 ? 2 : 0);
+    return (ky >= 0 && kx >= 0) ? w[((long)c * Cin + ci) * 9 + ky * 3 + kx] : 0.f;
+}
+
+__device__ __forceinline__ void tdr_split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r = x - (float)h;
+    m = (__bf16)r;
+    l = (__bf16)(r - (float)m);
+}
+
+typedef __bf16 tdr_bf16x8 __attribute__((ext_vector_type(8)));
+union TdrFrag {
+    uint4 u;
+    unsigned d[4];
+    tdr_bf16x8 v;
+};
+
+// element i of the fp32 row layout Wp[chunk][tap][ck][Mpad]
+__device__ __forceinline__ float tdr_pack_f32_elem(const float* __restrict__ w, int Cin, int KH, int mode, int CK, int M,
+                                                   int Kch, int KHe, int Mpad, long i) {
+    const int taps_e = KHe * KHe;
+    const int m = (int)(i % Mpad);
+    long r = i / Mpad;
+    const int ck = (int)(r % CK); r /= CK;
+    const int tap = (int)(r % taps_e);
+    const int c = (int)(r / taps_e) * CK + ck;
+    return (m < M && c < Kch) ? tdr_pack_value(w, Cin, KH, mode, m, c, tap) : 0.f;
+}
+
+// fragment i (= ((group*taps + tap)*MT + mt)*64 + lane) of the split layout Wp3[group][tap][mt][split][lane][8]
+__device__ __forceinline__ void tdr_pack_bx3_frag(const float* __restrict__ w, int Cin, int KH, int mode, int M, int Kch,
+                                                  int KHe, int MT, long i, uint4* __restrict__ wp) {
+    const int taps_e = KHe * KHe;
+    const int lane = (int)(i & 63);
+    long r = i >> 6;
+    const int mt = (int)(r % MT); r /= MT;
+    const int tap = (int)(r % taps_e);
+    const int grp = (int)(r / taps_e);
+    const int m = mt * 32 + (lane & 31);
+    TdrFrag h, mm, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = grp * 16 + 8 * (lane >> 5) + e;
+        const float v = (m < M && c < Kch) ? tdr_pack_value(w, Cin, KH, mode, m, c, tap) : 0.f;
+        __bf16 a0, a1, a2;
+        tdr_split3(v, a0, a1, a2);
+        h.v[e] = a0; mm.v[e] = a1; l.v[e] = a2;
+    }
+    uint4* o = wp + ((i >> 6) * 3) * 64 + lane;
+    o[0] = h.u; o[64] = mm.u; o[128] = l.u;
+}

@@ -1,0 +1,20 @@
+// Shared between the exact-fp32 (tdr_wgrad_mfma.hip) and split-bf16 (tdr_wgrad_bx3.hip) weight-gradient kernels.
+#pragma once
+#include "tdr_common.h"
+
+struct TdrWgradDesc;
+
+struct WgArgs {
+    const float* in; long in_ns; int Cin, H, W; long gate_off;
+    const float* dout; long dout_ns; int Cout, OH, OW;
+    int pad, tw_log2, tiles_x, tpi /*tiles per image*/, tps /*tiles per split*/, spi /*splits per image*/;
+    float* part;
+    float* dbpart;      // optional [nsplit][Cout]: per-split sums of dout rows (bias gradient), ci-tile 0 only
+};
+
+struct WgPlan { int tw_log2, tiles_x, tiles_y, tpi, tps, spi, cfg, WKw, BMc, BNc; };
+
+// tdr_wgrad_bx3.hip
+bool tdr_wgrad_bx3_supported(const TdrWgradDesc* d);
+WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d);
+int tdr_wgrad_bx3_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st);

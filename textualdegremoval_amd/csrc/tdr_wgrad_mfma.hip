@@ -12,17 +12,10 @@
 // waves split the K (pixel) range instead of the output tile.  Split-K partials
 // go to a workspace and are reduced in a fixed order (deterministic).
 #include "tdr_common.h"
+#include "tdr_wgrad_common.h"
 #include "../../include/tdr.h"
 
 namespace {
-
-struct WgArgs {
-    const float* in; long in_ns; int Cin, H, W; long gate_off;
-    const float* dout; long dout_ns; int Cout, OH, OW;
-    int pad, tw_log2, tiles_x, tpi /*tiles per image*/, tps /*tiles per split*/, spi /*splits per image*/;
-    float* part;
-    float* dbpart;      // optional [nsplit][Cout]: per-split sums of dout rows (bias gradient), ci-tile 0 only
-};
 
 constexpr int wg_plane(int TW, int KH, int S) { return (((64 / TW) - 1) * S + KH) * ((TW - 1) * S + KH); }
 constexpr int wg_cmax(int a, int b) { return a > b ? a : b; }
@@ -217,11 +210,11 @@ __global__ __launch_bounds__(64 * KL) void wgrad_reduce_kernel(const float* __re
     }
 }
 
-struct WgPlan { int tw_log2, tiles_x, tiles_y, tpi, tps, spi, cfg, WKw, BMc, BNc; };
 
 // cfg: 0 = waves 2x2x1 tile 2x2 (128x128) | 1 = waves 1x1x4 tile 2x1 (64x32) | 2 = 2x2x1 tile 1x1 (64x64)
 //      3 = waves 1x1x4 tile 1x1 (32x32)
 WgPlan make_plan(const TdrWgradDesc* d) {
+    if (d->math == 1 && tdr_wgrad_bx3_supported(d)) return tdr_wgrad_bx3_plan(d);
     WgPlan p;
     p.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);
     const int TW = 1 << p.tw_log2, TH = 64 >> p.tw_log2;
@@ -292,7 +285,9 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     const bool g = d->gate != 0;
     int rc = TDR_ERR_UNSUPPORTED;
     const int key = d->KH * 10 + d->stride;
-    if (key == 11) {
+    if (d->math == 1 && tdr_wgrad_bx3_supported(d)) {
+        rc = tdr_wgrad_bx3_launch(a, p, d, st);
+    } else if (key == 11) {
         switch (p.cfg) {
             case 0: rc = g ? launch_wg<1, 1, 2, 2, 1, 2, 2, true>(a, p, d->N, st) : launch_wg<1, 1, 2, 2, 1, 2, 2, false>(a, p, d->N, st); break;
             case 1: rc = g ? launch_wg<1, 1, 1, 1, 4, 2, 1, true>(a, p, d->N, st) : launch_wg<1, 1, 1, 1, 4, 2, 1, false>(a, p, d->N, st); break;

@@ -2,6 +2,7 @@
 here: it owns device memory and the HIP stream; all arithmetic happens in
 libtdr_hip.so.  Every wrapper enqueues on torch's current stream."""
 import ctypes as C
+import os
 
 import torch
 
@@ -10,6 +11,31 @@ from ._lib import TdrConvDesc, TdrWgradDesc, check
 
 EPI_STD, EPI_GATEBWD, EPI_PSHUF = 0, 1, 2
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2 = 0, 1, 2, 3
+
+# Matrix-core arithmetic of the dense convolutions (include/tdr.h, TdrConvDesc.wp_fmt):
+#   'bx3' : every fp32 operand split into 3 bf16 terms, 6 cross products on the bf16 MFMA pipe, fp32
+#           accumulate -- fp32-equivalent products at 2.7x the fp32-MFMA rate (csrc/tdr_conv_bx3.hip)
+#   'f32' : exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain)
+# The MASA arg-max searches always run on the exact path (near-tie indices must not move).
+MATH = os.environ.get('TDR_MATH', 'bx3')
+FMT_F32, FMT_BX3 = 0, 1
+
+
+def set_math(mode):
+    global MATH
+    assert mode in ('bx3', 'f32')
+    MATH = mode
+
+
+class PackedWeights:
+    """device buffer of packed weights + its format tag"""
+    __slots__ = ('buf', 'fmt')
+
+    def __init__(self, buf, fmt):
+        self.buf, self.fmt = buf, fmt
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
 
 
 def _stream():
@@ -57,24 +83,111 @@ def packed_floats(M, Kch, kh_eff):
     return _lib.load().tdr_packed_weight_floats(M, Kch, kh_eff)
 
 
-def pack_weights(w, mode, out=None):
-    """w: (Cout,Cin,KH,KH) contiguous.  Returns (wp, Mpad, M, Kch, KH_eff)."""
-    lib = _lib.load()
+def _pack_dims(w, mode):
     Cout, Cin, KH, _ = w.shape
     if mode == PACK_FWD:
-        M, Kch, KHe = Cout, Cin, KH
-    elif mode == PACK_DGRAD_S1:
-        M, Kch, KHe = Cin, Cout, KH
-    elif mode == PACK_DGRAD_2X2S2:
-        M, Kch, KHe = 4 * Cin, Cout, 1
+        return Cout, Cin, KH
+    if mode == PACK_DGRAD_S1:
+        return Cin, Cout, KH
+    if mode == PACK_DGRAD_2X2S2:
+        return 4 * Cin, Cout, 1
+    return 4 * Cin, Cout, 2
+
+
+def _packed_buffer(w, mode, math):
+    lib = _lib.load()
+    M, Kch, KHe = _pack_dims(w, mode)
+    if math == 'bx3':
+        n = lib.tdr_packed_weight_bytes_bx3(M, Kch, KHe) // 4
+        fmt = FMT_BX3
     else:
-        M, Kch, KHe = 4 * Cin, Cout, 2
-    n = lib.tdr_packed_weight_floats(M, Kch, KHe)
-    if out is None:
-        out = torch.empty(n, dtype=torch.float32, device=w.device)
-    assert out.numel() >= n and w.is_contiguous()
-    check(lib.tdr_pack_weights(w.data_ptr(), Cout, Cin, KH, mode, out.data_ptr(), _stream()), 'tdr_pack_weights')
-    return out, (M + 31) // 32 * 32, M, Kch, KHe
+        n = lib.tdr_packed_weight_floats(M, Kch, KHe)
+        fmt = FMT_F32
+    return PackedWeights(torch.empty(n, dtype=torch.float32, device=w.device), fmt)
+
+
+class PackPlan:
+    """Per-model cache of packed weights.  The first step records every (weight, mode) the engine asks for and
+    packs it on the spot into a persistent buffer; from then on `run()` re-packs ALL of them with one
+    multi-tensor launch at the start of a step (weights change once per step, in the optimiser) and
+    `pack_weights` returns the cached buffers without launching anything."""
+
+    def __init__(self):
+        self.entries = {}          # (ptr, shape, mode, math) -> (w, mode, math, PackedWeights)
+        self.table = None
+        self.dirty = True
+        self.valid = False
+
+    def lookup(self, w, mode, math):
+        key = (w.data_ptr(), tuple(w.shape), mode, math)
+        e = self.entries.get(key)
+        if e is None:
+            pw = _packed_buffer(w, mode, math)
+            self.entries[key] = (w, mode, math, pw)
+            self.dirty = True
+            _pack_into(w, mode, pw)
+            return pw
+        if not self.valid:
+            _pack_into(w, mode, e[3])
+        return e[3]
+
+    def run(self):
+        """one launch: re-pack every recorded weight (call after the weights changed, before the forward)."""
+        if not self.entries:
+            return
+        lib = _lib.load()
+        if self.dirty or self.table is None:
+            jobs = (_lib.TdrPackJob * len(self.entries))()
+            blocks = 0
+            for j, (w, mode, math, pw) in enumerate(self.entries.values()):
+                Cout, Cin, KH, _ = w.shape
+                check(lib.tdr_pack_job_init(C.byref(jobs[j]), w.data_ptr(), Cout, Cin, KH, mode, pw.fmt, pw.data_ptr()),
+                      'tdr_pack_job_init')
+                jobs[j].first_block = blocks
+                blocks += (jobs[j].total + 255) // 256
+            raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
+            dev = next(iter(self.entries.values()))[0].device
+            self.table = (raw.to(dev), len(self.entries), blocks)
+            self.dirty = False
+        tab, n, blocks = self.table
+        check(lib.tdr_pack_weights_multi(tab.data_ptr(), n, blocks, _stream()), 'tdr_pack_weights_multi')
+        self.valid = True
+
+    def invalidate(self):
+        self.valid = False
+
+
+_active_plan = None
+
+
+def set_pack_plan(plan):
+    """install (or clear, with None) the PackPlan consulted by pack_weights; returns the previous one."""
+    global _active_plan
+    prev = _active_plan
+    _active_plan = plan
+    return prev
+
+
+def _pack_into(w, mode, pw):
+    lib = _lib.load()
+    Cout, Cin, KH, _ = w.shape
+    assert w.is_contiguous()
+    if pw.fmt == FMT_BX3:
+        check(lib.tdr_pack_weights_bx3(w.data_ptr(), Cout, Cin, KH, mode, pw.data_ptr(), _stream()), 'tdr_pack_weights_bx3')
+    else:
+        check(lib.tdr_pack_weights(w.data_ptr(), Cout, Cin, KH, mode, pw.data_ptr(), _stream()), 'tdr_pack_weights')
+
+
+def pack_weights(w, mode, out=None, math=None):
+    """w: (Cout,Cin,KH,KH) contiguous.  Returns (wp, Mpad, M, Kch, KH_eff); wp is a PackedWeights."""
+    M, Kch, KHe = _pack_dims(w, mode)
+    math = math or MATH
+    if _active_plan is not None and out is None:
+        pw = _active_plan.lookup(w, mode, math)
+    else:
+        pw = PackedWeights(out, FMT_F32) if (out is not None and math != 'bx3') else _packed_buffer(w, mode, math)
+        _pack_into(w, mode, pw)
+    return pw, (M + 31) // 32 * 32, M, Kch, KHe
 
 
 def pack_patches(blk, G, PH, PW, pstep, dil, off):
@@ -115,6 +228,7 @@ def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None
     d.gate = 1 if gate else 0
     d.kscale, d.kscale_ns = _p(kscale), _vec_ns(kscale)
     d.wp, d.wp_ns, d.Mpad = wp.data_ptr(), wp_ns, Mpad
+    d.wp_fmt = getattr(wp, 'fmt', FMT_F32)
     d.out, d.out_ns = out.data_ptr(), _dense_nchw(out)
     d.epi = epi
     d.bias, d.bias_ns = _p(bias), _vec_ns(bias)
@@ -145,6 +259,7 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
     db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
     d.db = _p(db)
     d.per_image = 1 if per_image else 0
+    d.math = 1 if MATH == 'bx3' else 0
     need = lib.tdr_wgrad_ws_floats(C.byref(d))
     ws = workspace(need, x.device, 'wgrad')
     d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
@@ -253,6 +368,12 @@ def channel_sum(x):
     check(lib.tdr_channel_sum(x.data_ptr(), _dense_nchw(x), N, Cc, H * W, out.data_ptr(), ws.data_ptr(), _stream()),
           'tdr_channel_sum')
     return out
+
+
+def multi_copy(src_tab, dst_tab, sizes, chunk_tensor, chunk_index, n_chunks):
+    """device pointer tables (int64 tensors); one launch copies every listed tensor."""
+    check(_lib.load().tdr_multi_copy(src_tab.data_ptr(), dst_tab.data_ptr(), sizes.data_ptr(), chunk_tensor.data_ptr(),
+                                     chunk_index.data_ptr(), n_chunks, _stream()), 'tdr_multi_copy')
 
 
 def copy_rows(src, src_ns, dst, dst_ns, N, length):

@@ -112,31 +112,93 @@ class RefGuidedImageCleanModel(BaseModel):
         if self.param_fix_iters is not None and current_iter < self.param_fix_iters:
             raise NotImplementedError('fix_iterations (frozen masa params) is not supported on the HIP path')
         self.ref_in = self._match_reference_window()
-        net = self.get_bare_model(self.net_g)
-        names = [k for k, _ in net.named_parameters()]
-        params = [p for _, p in net.named_parameters()]
         fused = self.device.type == 'cuda' and isinstance(self.cri_pix, loss_module.L1Loss) and \
             self.cri_pix.reduction == 'mean'
         if not fused:
             raise NotImplementedError('HIP step needs a GPU and pixel_opt.type == L1Loss (the YAML default)')
-        P = {k: p.data for k, p in zip(names, params)}
-        out, saved = E.net_fwd(P, net.cfg, self.lq, self.ref_in)
-        self.output = out
-        loss, dpred = K.l1_loss(out.contiguous(), self.gt.contiguous(), float(self.cri_pix.loss_weight))
-        loss_dict = OrderedDict(l_pix=loss[0])
-        if not hasattr(self, 'grad_reducer'):
-            from ..parallel import GradAllReducer
-            self.grad_reducer = GradAllReducer(list(zip(names, params)))
-        sink = self.grad_reducer.begin()
-        E.net_bwd(dpred, P, net.cfg, saved, G=sink)
-        grads = self.grad_reducer.finish()
-        for k, p in zip(names, params):
-            p.grad = grads[k]
+        if not hasattr(self, '_step_names'):
+            net = self.get_bare_model(self.net_g)
+            self._step_names = [k for k, _ in net.named_parameters()]
+            self._step_params = [p for _, p in net.named_parameters()]
+            if not hasattr(self, 'grad_reducer'):
+                from ..parallel import GradAllReducer
+                self.grad_reducer = GradAllReducer(list(zip(self._step_names, self._step_params)))
+            self.use_hip_graph = os.environ.get('TDR_GRAPH', '1') == '1'
+            self._gstate = None
         self.optimizer_g.use_grad_clip = bool(self.opt['train']['use_grad_clip'])
-        self.optimizer_g.step()
-        self.log_dict = self.reduce_loss_dict(loss_dict)
+        if self.use_hip_graph:
+            loss = self._graph_step()
+        else:
+            loss = self._eager_step(self.lq, self.gt, self.ref_in)
+        self.log_dict = self.reduce_loss_dict(OrderedDict(l_pix=loss[0]))
         if self.ema_decay > 0:
             self.model_ema(decay=self.ema_decay)
+
+    def _fwd_bwd(self, lq, gt, ref_in, defer_collectives=False):
+        """forward, L1, hand-written backward; gradients land in the reducer's arena (RCCL-averaged when
+        distributed, unless `defer_collectives`).  Returns the loss tensor [1]."""
+        net = self.get_bare_model(self.net_g)
+        P = {k: p.data for k, p in zip(self._step_names, self._step_params)}
+        if not hasattr(self, '_pack_plan'):
+            self._pack_plan = K.PackPlan()
+        prev_plan = K.set_pack_plan(self._pack_plan)
+        try:
+            self._pack_plan.run()              # all weights, all layouts, one launch (no-op on the recording step)
+            out, saved = E.net_fwd(P, net.cfg, lq, ref_in)
+            self.output = out
+            loss, dpred = K.l1_loss(out.contiguous(), gt.contiguous(), float(self.cri_pix.loss_weight))
+            sink = self.grad_reducer.begin(defer_collectives=defer_collectives)
+            E.net_bwd(dpred, P, net.cfg, saved, G=sink)
+            grads = self.grad_reducer.finish()
+        finally:
+            K.set_pack_plan(prev_plan)
+            self._pack_plan.invalidate()       # the optimiser is about to change the weights
+        if not getattr(self, '_grads_bound', False) or self.grad_reducer.relaid:
+            for k, p in zip(self._step_names, self._step_params):
+                p.grad = grads[k]
+            self._grads_bound = True
+        return loss
+
+    def _eager_step(self, lq, gt, ref_in):
+        loss = self._fwd_bwd(lq, gt, ref_in)
+        self.optimizer_g.step()
+        return loss
+
+    def _graph_step(self):
+        """The step as two captured hipGraphs (forward+backward | clip+AdamW): ~4000 kernel launches are
+        replayed without host work; between them the flat gradient arena is all-reduced over RCCL when
+        distributed.  Shapes are static per graph; the first two steps of a shape run eagerly (allocator /
+        workspace / arena-layout warm-up)."""
+        key = (tuple(self.lq.shape), tuple(self.gt.shape), tuple(self.ref_in.shape), self.optimizer_g.use_grad_clip)
+        st = self._gstate
+        if st is None or st['key'] != key:
+            st = self._gstate = {'key': key, 'eager_left': 2, 'gA': None}
+        if st['gA'] is None:
+            if st['eager_left'] > 0:
+                st['eager_left'] -= 1
+                return self._eager_step(self.lq, self.gt, self.ref_in)
+            st['lq'], st['gt'], st['ref'] = self.lq.clone(), self.gt.clone(), self.ref_in.clone()
+            torch.cuda.synchronize()
+            gA = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gA):
+                st['loss'] = self._fwd_bwd(st['lq'], st['gt'], st['ref'], defer_collectives=True)
+            st['pinned'] = self.grad_reducer.pinned_tables      # host blocks the captured table uploads re-read on replay
+            self.optimizer_g.prepare()
+            gB = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gB, pool=gA.pool()):
+                self.optimizer_g.launch()
+            st['gA'], st['gB'] = gA, gB
+            st['output'] = self.output
+        else:
+            st['lq'].copy_(self.lq, non_blocking=True)
+            st['gt'].copy_(self.gt, non_blocking=True)
+            st['ref'].copy_(self.ref_in, non_blocking=True)
+            self.optimizer_g.prepare()
+        st['gA'].replay()
+        self.grad_reducer.allreduce_flat()
+        st['gB'].replay()
+        self.output = st['output']
+        return st['loss']
 
     # ------------------------------------------------------------------ validation (reference :286-409)
     def pad_test(self, window_size):

@@ -25,6 +25,9 @@ class FusedClipAdamW(torch.optim.Optimizer):
         self.use_grad_clip = bool(use_grad_clip)
         self._tables = None
         self.last_sumsq = None
+        self._step_count = None
+        self._hp_host = None
+        self._hp_dev = None
 
     # -- pointer / chunk tables (rebuilt when gradients or state tensors are re-allocated)
     def _build(self):
@@ -70,30 +73,61 @@ class FusedClipAdamW(torch.optim.Optimizer):
         self._tables = tab
         return tab
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        lib = _lib.load()
+    # -- the step is split so the kernel launches can live in a captured hipGraph:
+    #    prepare() refreshes the 24-byte device block {lr[0..3], 1-b1^t, sqrt(1-b2^t)} (host side, every step),
+    #    launch() enqueues the two multi-tensor kernels with step-invariant arguments.
+    def prepare(self):
         t = self._build()
-        stream = torch.cuda.current_stream().cuda_stream
-        check(lib.tdr_grad_sumsq(t['grads'].data_ptr(), t['sizes'].data_ptr(), t['chunk_tensor'].data_ptr(),
-                                 t['chunk_index'].data_ptr(), t['n_chunks'], t['partial'].data_ptr(),
-                                 t['sumsq'].data_ptr(), stream), 'tdr_grad_sumsq')
         g0 = self.param_groups[0]
         for g in self.param_groups:
             assert tuple(g['betas']) == tuple(g0['betas']) and g['eps'] == g0['eps'] and \
                 g['weight_decay'] == g0['weight_decay'], 'groups may differ in lr only'
-        step = int(self.state[t['ps'][0]]['step']) + 1
-        lrs = (C.c_float * 4)(*([float(g['lr']) for g in self.param_groups] + [0.0] * (4 - len(self.param_groups))))
-        check(lib.tdr_adamw_step(t['params'].data_ptr(), t['grads'].data_ptr(), t['m'].data_ptr(), t['v'].data_ptr(),
-                                 t['sizes'].data_ptr(), t['group'].data_ptr(), t['chunk_tensor'].data_ptr(),
-                                 t['chunk_index'].data_ptr(), t['n_chunks'], t['sumsq'].data_ptr(), lrs,
-                                 len(self.param_groups), self.max_norm, 1 if self.use_grad_clip else 0,
-                                 float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']),
-                                 float(g0['weight_decay']), step, stream), 'tdr_adamw_step')
-        for p in t['ps']:
-            self.state[p]['step'] = torch.tensor(float(step))
+        if self._step_count is None:
+            self._step_count = int(self.state[t['ps'][0]]['step'])
+        self._step_count += 1
+        step = self._step_count
+        b1, b2 = float(g0['betas'][0]), float(g0['betas'][1])
+        lrs = [float(g['lr']) for g in self.param_groups] + [0.0] * (4 - len(self.param_groups))
+        if self._hp_dev is None:
+            self._hp_dev = torch.empty(6, dtype=torch.float32, device=t['ps'][0].device)
+        # a fresh pinned block per step: torch's host allocator will not recycle it before the async copy ran
+        hp = torch.tensor(lrs + [1.0 - b1 ** step, (1.0 - b2 ** step) ** 0.5], dtype=torch.float32).pin_memory()
+        self._hp_dev.copy_(hp, non_blocking=True)
+
+    def launch(self):
+        lib = _lib.load()
+        t = self._build()
+        g0 = self.param_groups[0]
+        stream = torch.cuda.current_stream().cuda_stream
+        check(lib.tdr_grad_sumsq(t['grads'].data_ptr(), t['sizes'].data_ptr(), t['chunk_tensor'].data_ptr(),
+                                 t['chunk_index'].data_ptr(), t['n_chunks'], t['partial'].data_ptr(),
+                                 t['sumsq'].data_ptr(), stream), 'tdr_grad_sumsq')
+        check(lib.tdr_adamw_step_dev(t['params'].data_ptr(), t['grads'].data_ptr(), t['m'].data_ptr(), t['v'].data_ptr(),
+                                     t['sizes'].data_ptr(), t['group'].data_ptr(), t['chunk_tensor'].data_ptr(),
+                                     t['chunk_index'].data_ptr(), t['n_chunks'], t['sumsq'].data_ptr(),
+                                     self._hp_dev.data_ptr(), self.max_norm, 1 if self.use_grad_clip else 0,
+                                     float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']),
+                                     float(g0['weight_decay']), stream), 'tdr_adamw_step_dev')
         self.last_sumsq = t['sumsq']
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.prepare()
+        self.launch()
         return None
+
+    def state_dict(self):
+        """AdamW-compatible: the shared step counter is materialised into every per-parameter state."""
+        if self._step_count is not None:
+            for st in self.state.values():
+                if 'step' in st:
+                    st['step'] = torch.tensor(float(self._step_count))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._step_count = None
+        self._tables = None
 
     def grad_norm(self):
         """total gradient L2 norm of the last step (device sync)."""

@@ -69,11 +69,35 @@ class GradAllReducer:
         shapes = {k: p.shape for k, p in self.named}
         self.views = {k: self.flat[self.offsets[k]: self.offsets[k] + sizes[k]].view(shapes[k]) for k in order}
         self.order = list(order)
+        self._btab = None
+        if self.flat.is_cuda:
+            # per-bucket (tensor, chunk) tables of the one-launch gather kernel (tdr_multi_copy)
+            from . import _lib
+            chunk = _lib.load().tdr_optim_chunk()
+            self._btab = []
+            for _, _, ns in self.buckets:
+                ct, ci = [], []
+                for t, k in enumerate(ns):
+                    n = (sizes[k] + chunk - 1) // chunk
+                    ct += [t] * n
+                    ci += list(range(n))
+                self._btab.append(dict(
+                    names=ns, n_chunks=len(ct),
+                    dst=torch.tensor([self.views[k].data_ptr() for k in ns], dtype=torch.int64).to(device),
+                    sizes=torch.tensor([sizes[k] for k in ns], dtype=torch.int64).to(device),
+                    ct=torch.tensor(ct, dtype=torch.int32).to(device), ci=torch.tensor(ci, dtype=torch.int32).to(device),
+                    src=torch.empty(len(ns), dtype=torch.int64, device=device)))
 
     # ---- per step -----------------------------------------------------------
-    def begin(self):
+    def begin(self, defer_collectives=False):
+        """defer_collectives: do not launch per-bucket all-reduces while gradients arrive (hipGraph
+        capture of the backward pass); the caller runs allreduce_flat() afterwards."""
+        self._defer = defer_collectives
+        self.relaid = False
         self._arrived = []
         self._works = []
+        self._pending = {}
+        self.pinned_tables = []          # host blocks the async table uploads read from (kept alive by graph owners)
         if self.order is not None:
             self._bucket_left = [len(ns) for _, _, ns in self.buckets]
         return GradSink(self)
@@ -85,8 +109,32 @@ class GradAllReducer:
         else:
             dst.copy_(g)                                  # CPU (gloo unit tests only)
 
+    def allreduce_flat(self):
+        """one all-reduce (mean) of the whole gradient arena on the current stream (few, large collectives
+        suit the point-to-point xGMI links); no-op on one rank."""
+        if self.world == 1 or self.flat is None:
+            return
+        if self.flat.is_cuda:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
+            self.flat.div_(self.world)
+
+    def _gather(self, bi):
+        """copy every pending gradient of bucket `bi` into the arena with one kernel launch."""
+        if self._btab is None:
+            return
+        tb = self._btab[bi]
+        if not all(k in self._pending for k in tb['names']):
+            return
+        host = torch.tensor([self._pending[k].data_ptr() for k in tb['names']], dtype=torch.int64).pin_memory()
+        self.pinned_tables.append(host)
+        tb['src'].copy_(host, non_blocking=True)
+        K.multi_copy(tb['src'], tb['dst'], tb['sizes'], tb['ct'], tb['ci'], tb['n_chunks'])
+        self._keep = [self._pending.pop(k) for k in tb['names']]   # sources stay referenced until the next gather is enqueued
+
     def _launch(self, bi):
-        if self.world == 1:
+        if self.world == 1 or getattr(self, '_defer', False):
             return
         s, e, _ = self.buckets[bi]
         buf = self.flat[s:e]
@@ -103,10 +151,14 @@ class GradAllReducer:
         self._arrived.append((key, g))
         if self.order is None:
             return                                        # first step: layout not known yet
-        self._copy_in(key, g)
         bi = self.bucket_of[key]
+        if g.is_cuda and self._btab is not None:
+            self._pending[key] = g.contiguous()
+        else:
+            self._copy_in(key, g)
         self._bucket_left[bi] -= 1
         if self._bucket_left[bi] == 0:
+            self._gather(bi)
             self._launch(bi)
 
     def finish(self):
@@ -114,15 +166,21 @@ class GradAllReducer:
         if self.order is None:
             dev = self._arrived[0][1].device
             self._layout([k for k, _ in self._arrived], dev)
+            self.relaid = True
             for k, g in self._arrived:
-                self._copy_in(k, g)
+                if g.is_cuda and self._btab is not None:
+                    self._pending[k] = g.contiguous()
+                else:
+                    self._copy_in(k, g)
             for bi in range(len(self.buckets)):
+                self._gather(bi)
                 self._launch(bi)
         for w in self._works:
             w.wait()
-        if self.world > 1:
+        if self.world > 1 and not getattr(self, '_defer', False):
             if self.flat.is_cuda:
-                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                if self._comm_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self._comm_stream)
             else:
                 self.flat.div_(self.world)
         self._arrived = []
