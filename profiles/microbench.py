@@ -8,6 +8,7 @@ import torch
 from textualdegremoval_amd import kernels as K
 
 torch.manual_seed(0)
+K.WGRAD_1X1_BX3 = True
 FILT = sys.argv[1] if len(sys.argv) > 1 else ''
 ITERS = int(os.environ.get('ITERS', '10'))
 MATHS = os.environ.get('MATHS', 'f32,bx3').split(',')

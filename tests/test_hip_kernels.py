@@ -22,10 +22,12 @@ def K(request):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from textualdegremoval_amd import kernels
-    prev = kernels.MATH
+    prev, prev1 = kernels.MATH, kernels.WGRAD_1X1_BX3
     kernels.set_math(request.param)
+    kernels.WGRAD_1X1_BX3 = True          # exercise the split 1x1 weight-gradient kernel as well
     yield kernels
     kernels.set_math(prev)
+    kernels.WGRAD_1X1_BX3 = prev1
 
 
 def dev(t):

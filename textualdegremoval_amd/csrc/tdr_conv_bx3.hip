@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     constexpr int NT = TN * WN;
     constexpr int TAPS = KH * KH;
     constexpr int NIT = (bx_max_plane(NT, KH, S) + 127) / 128;   // a wave pair stages 128 halo pixels per pass
+    // prefetch depth in 16-channel groups: a 1x1 group is only TM*TN*6 MFMAs (0.2-0.6 us), far less than the
+    // HBM latency, so its operand loads are issued two groups ahead; 9-tap groups are long enough for one.
+    constexpr int PF = (KH == 1) ? 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
@@ -93,23 +96,23 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     const float* ks_n = a.kscale ? a.kscale + (long)n * a.kscale_ns : nullptr;
     const int ngroups = (a.Cin + 15) >> 4;
 
-    float rin[NIT][8];
-    float rin2[GATE ? NIT : 1][GATE ? 8 : 1];
-    float rks[8];
-    auto load_group = [&](int g) {
+    float rin[PF][NIT][8];
+    float rin2[GATE ? PF : 1][GATE ? NIT : 1][GATE ? 8 : 1];
+    float rks[PF][8];
+    auto load_group = [&](int g, int set) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ci = min(g * 16 + sg * 8 + i, a.Cin - 1);
             const float* base = in_n + (long)ci * HWin;
-            rks[i] = ks_n ? ks_n[ci] : 1.f;
+            rks[set][i] = ks_n ? ks_n[ci] : 1.f;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                rin[it][i] = base[gsafe[it]];
-                if (GATE) rin2[it][i] = base[gsafe[it] + a.gate_off];
+                rin[set][it][i] = base[gsafe[it]];
+                if (GATE) rin2[set][it][i] = base[gsafe[it] + a.gate_off];
             }
         }
     };
-    auto store_group = [&](int g, int buf) {
+    auto store_group = [&](int g, int set, int buf) {
         uint4* sb = smem4 + (buf * 6 + sg) * plane;
         const int cbase = g * 16 + sg * 8;
 #pragma unroll
@@ -118,9 +121,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             const bool ok = (okmask >> it) & 1u;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float v = rin[it][i];
-                if (GATE) v *= rin2[it][i];
-                v *= rks[i];
+                float v = rin[set][it][i];
+                if (GATE) v *= rin2[set][it][i];
+                v *= rks[set][i];
                 v = (ok && cbase + i < a.Cin) ? v : 0.f;
                 __bf16 hh, mm, ll;
                 split3(v, hh, mm, ll);
@@ -169,43 +172,54 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             for (int s = 0; s < 3; ++s) dst[tm][s].u = wfrag[tm][gt * wstep + s * 64];
     };
 
-    load_group(0);
     load_a(af, 0);
-    store_group(0, 0);
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (p < ngroups) load_group(p, p);
+    store_group(0, 0, 0);
     __syncthreads();
 
-    for (int g = 0; g < ngroups; ++g) {
-        const int buf = g & 1;
-        if (g + 1 < ngroups) load_group(g + 1);
-        const uint4* sb = smem4 + buf * 6 * plane;
+    for (int g0 = 0; g0 < ngroups; g0 += PF) {
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int tapoff = (tap / KH) * LW + (tap % KH);
-            // next (group, tap) weight fragments; the last prefetch of the last group re-reads a valid slot
-            const long gtn = min((long)g * TAPS + tap + 1, (long)ngroups * TAPS - 1);
-            load_a(afn, gtn);
-            Frag bf[TN][3];
+        for (int u = 0; u < PF; ++u) {
+            const int g = g0 + u;
+            if (g < ngroups) {
+                const int buf = g & 1;
+                const uint4* sb = smem4 + buf * 6 * plane;
+                if (PF == 1 && g + 1 < ngroups) load_group(g + 1, 0);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int s = 0; s < 3; ++s) bf[tn][s].u = sb[s * 2 * plane + bbase[tn] + tapoff];
-            // small cross terms first, the dominant h*h last
-            constexpr int SA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int SB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int tapoff = (tap / KH) * LW + (tap % KH);
+                    // next (group, tap) weight fragments first, THEN the far-ahead operand loads: the wait for
+                    // the fragments (in-order vmcnt) then leaves the operand loads in flight.
+                    // (the last prefetch of the last group re-reads a valid slot)
+                    const long gtn = min((long)g * TAPS + tap + 1, (long)ngroups * TAPS - 1);
+                    load_a(afn, gtn);
+                    if (PF > 1 && tap == 0 && g + PF < ngroups) load_group(g + PF, u);   // set u is free: group g already sits in LDS
+                    Frag bf[TN][3];
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                        for (int s = 0; s < 3; ++s) bf[tn][s].u = sb[s * 2 * plane + bbase[tn] + tapoff];
+                    // small cross terms first, the dominant h*h last
+                    constexpr int SA[6] = {2, 0, 1, 1, 0, 0};
+                    constexpr int SB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int s = 0; s < 3; ++s) af[tm][s] = afn[tm][s];
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) af[tm][s] = afn[tm][s];
+                }
+                if (g + 1 < ngroups) store_group(g + 1, (u + 1) % PF, buf ^ 1);
+                __syncthreads();
+            }
         }
-        if (g + 1 < ngroups) store_group(g + 1, buf ^ 1);
-        __syncthreads();
     }
 
     conv_epilogue<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
@@ -248,7 +262,11 @@ int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
             if (blocks(32, 256) >= 512) return launch_bx_cfg<KH, S, 1, 1, 2, EPI, GATE>(a, N, st);   // 32 x 256
             return launch_bx_cfg<KH, S, 1, 1, 1, EPI, GATE>(a, N, st);                               // 32 x 128
         }
-        if (a.Cout > 64 && blocks(128, 256) >= 512) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);  // 128 x 256
+        if constexpr (KH == 1) {   // two register sets of prefetched operands: 128 x 128 keeps the kernel under 256 VGPRs
+            if (a.Cout > 64 && blocks(128, 128) >= 512) return launch_bx_cfg<KH, S, 2, 2, 2, EPI, GATE>(a, N, st);
+        } else {
+            if (a.Cout > 64 && blocks(128, 256) >= 512) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);  // 128 x 256
+        }
         if (blocks(64, 256) >= 512) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);       // 64 x 256
         return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);                                   // 64 x 128
     }

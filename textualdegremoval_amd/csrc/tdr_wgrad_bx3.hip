@@ -23,11 +23,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-union WFrag {
-    uint4 u;
-    unsigned d[4];
-    bf16x8 v;
-};
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte fragment (8 bf16) as dwords
 
 __device__ __forceinline__ void wsplit3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -36,16 +32,31 @@ __device__ __forceinline__ void wsplit3(float x, __bf16& h, __bf16& m, __bf16& l
     l = (__bf16)(r - (float)m);
 }
 
-__device__ __forceinline__ void split8(const float (&v)[8], WFrag& h, WFrag& m, WFrag& l) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        __bf16 a0, a1, a2;
-        wsplit3(v[i], a0, a1, a2);
-        h.v[i] = a0; m.v[i] = a1; l.v[i] = a2;
+#define WSPLIT_ONE(x, i)                      \
+    {                                         \
+        __bf16 a0, a1, a2;                    \
+        wsplit3(x, a0, a1, a2);               \
+        hv[i] = a0; mv[i] = a1; lv[i] = a2;   \
     }
+
+constexpr int wb_max_nch(int KH, int P) {
+    // 8-element chunks per input channel, maximum over the tile widths C = 32, 16, 8
+    return KH == 3 ? ((P / 32 + 2) * 5 > (P / 8 + 2) * 2 ? ((P / 32 + 2) * 5 > (P / 16 + 2) * 3 ? (P / 32 + 2) * 5 : (P / 16 + 2) * 3)
+                                                         : ((P / 8 + 2) * 2 > (P / 16 + 2) * 3 ? (P / 8 + 2) * 2 : (P / 16 + 2) * 3))
+                   : P / 8;
 }
 
-template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE>
+__device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h, u32x4& m, u32x4& l) {
+    bf16x8 hv, mv, lv;
+    WSPLIT_ONE(a[0], 0) WSPLIT_ONE(a[1], 1) WSPLIT_ONE(a[2], 2) WSPLIT_ONE(a[3], 3)
+    WSPLIT_ONE(b[0], 4) WSPLIT_ONE(b[1], 5) WSPLIT_ONE(b[2], 6) WSPLIT_ONE(b[3], 7)
+    h = __builtin_bit_cast(u32x4, hv);
+    m = __builtin_bit_cast(u32x4, mv);
+    l = __builtin_bit_cast(u32x4, lv);
+}
+
+// PRE: the global loads of tile t+1 are issued before the MFMAs of tile t (register double buffering)
+template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE>
 __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     static_assert(WMw * WNw * WKw == 4, "4 waves");
     static_assert(KH == 1 || (TMW == 1 && TNW == 1), "3x3: one 32x32 tile pair (9 accumulators) per wave");
@@ -54,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     constexpr int HALO = KH == 3 ? 1 : 0;
     constexpr int DCH = P / 8;                       // 8-pixel chunks per dout row
     constexpr int NITD = (BMc * DCH + 255) / 256;
+    constexpr int NITI = (BNc * wb_max_nch(KH, P) + 255) / 256;
     constexpr int KSTEPS = P / 16;
     constexpr int KPW = KSTEPS / WKw;
     static_assert(KPW >= 1, "tile too small for the K split");
@@ -79,68 +91,115 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     const long HWin = (long)a.H * a.W, HWo = (long)a.OH * a.OW;
     const float* in_n = a.in + (long)n * a.in_ns;
     const float* do_n = a.dout + (long)n * a.dout_ns;
+    const int n_iitems = BNc * NCH;
 
     float dsum[NITD];
 #pragma unroll
     for (int i = 0; i < NITD; ++i) dsum[i] = 0.f;
 
-    const int n_iitems = BNc * NCH;
-
-    auto stage = [&](int t) {
+    // ---- staging.  dout item: (co row, 8-pixel chunk); input item: (ci row, 8-column chunk of the halo tile).
+    // LDS column c of the halo tile holds input x = ox0 + c - 4 (3x3, pad 1), so every 8-column chunk is two
+    // 16-byte-aligned float4 loads that are either fully inside the image row or fully outside
+    // (W % 4 == 0 is required by tdr_wgrad_bx3_supported).  All loads are unconditional (clamped address),
+    // validity is applied when the registers are converted.
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto d_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live) {
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
         const int oy0 = ty * R, ox0 = tx * C;
-        // ---- dout rows
+        const int id = tid + 256 * it;
+        live = (BMc * DCH % 256 == 0) || id < BMc * DCH;
+        const int idc = min(id, BMc * DCH - 1);
+        const int col = idc / DCH, ch = idc - col * DCH;
+        const int row = (ch * 8) >> cl, xo = (ch * 8) & (C - 1);
+        const int oy = oy0 + row, ox = ox0 + xo;
+        const int co = min(co0 + col, a.Cout - 1);
+        const bool rok = oy < a.OH && co0 + col < a.Cout;
+        const float* src = do_n + (long)co * HWo + (long)min(oy, a.OH - 1) * a.OW;
+        const bool ok0 = rok && ox < a.OW, ok1 = rok && ox + 4 < a.OW;
+        v0 = *reinterpret_cast<const f32x4*>(src + (ok0 ? ox : 0));
+        v1 = *reinterpret_cast<const f32x4*>(src + (ok1 ? ox + 4 : 0));
+        v0 = ok0 ? v0 : z4;
+        v1 = ok1 ? v1 : z4;
+        ldsoff = col * DPITCH + ch * 8;
+    };
+    auto d_store = [&](int it, const f32x4& v0, const f32x4& v1, int ldsoff, bool live) {
+        if (!live) return;
+        dsum[it] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+        u32x4 h, m, l;
+        split8v(v0, v1, h, m, l);
+        u32x4* dst = reinterpret_cast<u32x4*>(s_d + ldsoff);
+        dst[0] = h;
+        dst[(BMc * DPITCH) >> 3] = m;
+        dst[(2 * BMc * DPITCH) >> 3] = l;
+    };
+    auto i_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live) {
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int oy0 = ty * R, ox0 = tx * C;
+        const int id = tid + 256 * it;
+        live = id < n_iitems;
+        const int idc = min(id, n_iitems - 1);
+        const int cil = idc / NCH, ch = idc - cil * NCH;
+        const int lrow = (ch * 8) / CP, c0 = ch * 8 - lrow * CP;
+        const int gy = oy0 - a.pad + lrow;
+        const int gx0 = KH == 3 ? ox0 + c0 - 4 : ox0 + c0;
+        const int ci = min(ci0 + cil, a.Cin - 1);
+        const bool rok = gy >= 0 && gy < a.H && ci0 + cil < a.Cin;
+        const float* src = in_n + (long)ci * HWin + (long)min(max(gy, 0), a.H - 1) * a.W;
+        const bool ok0 = rok && gx0 >= 0 && gx0 < a.W, ok1 = rok && gx0 + 4 >= 0 && gx0 + 4 < a.W;
+        const int o0 = ok0 ? gx0 : 0, o1 = ok1 ? gx0 + 4 : 0;
+        v0 = *reinterpret_cast<const f32x4*>(src + o0);
+        v1 = *reinterpret_cast<const f32x4*>(src + o1);
+        if (GATE) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(src + o0 + a.gate_off);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(src + o1 + a.gate_off);
+            v0 *= g0;
+            v1 *= g1;
+        }
+        v0 = ok0 ? v0 : z4;
+        v1 = ok1 ? v1 : z4;
+        ldsoff = cil * IPITCH + ch * 8;
+    };
+    auto i_store = [&](const f32x4& v0, const f32x4& v1, int ldsoff, bool live) {
+        if (!live) return;
+        u32x4 h, m, l;
+        split8v(v0, v1, h, m, l);
+        u32x4* dst = reinterpret_cast<u32x4*>(s_i + ldsoff);
+        dst[0] = h;
+        dst[(BNc * IPITCH) >> 3] = m;
+        dst[(2 * BNc * IPITCH) >> 3] = l;
+    };
+    // prefetch registers (PRE only): every index below is a compile-time constant after unrolling
+    f32x4 pd0[PRE ? NITD : 1], pd1[PRE ? NITD : 1], pi0[PRE ? NITI : 1], pi1[PRE ? NITI : 1];
+    int pdo[PRE ? NITD : 1], pio[PRE ? NITI : 1];
+    bool pdl[PRE ? NITD : 1], pil[PRE ? NITI : 1];
+    auto prefetch = [&](int t) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int it = 0; it < NITD; ++it) d_load(t, it, pd0[it], pd1[it], pdo[it], pdl[it]);
+#pragma unroll
+            for (int it = 0; it < NITI; ++it) i_load(t, it, pi0[it], pi1[it], pio[it], pil[it]);
+        }
+    };
+    auto commit = [&]() {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int it = 0; it < NITD; ++it) d_store(it, pd0[it], pd1[it], pdo[it], pdl[it]);
+#pragma unroll
+            for (int it = 0; it < NITI; ++it) i_store(pi0[it], pi1[it], pio[it], pil[it]);
+        }
+    };
+    auto stage_sync = [&](int t) {      // load + convert + store, item by item (no registers live across the MFMAs)
 #pragma unroll
         for (int it = 0; it < NITD; ++it) {
-            const int id = tid + 256 * it;
-            const int col = id / DCH, ch = id - col * DCH;
-            if (BMc * DCH % 256 != 0 && id >= BMc * DCH) break;
-            const int row = (ch * 8) >> cl, xo = (ch * 8) & (C - 1);
-            const int oy = oy0 + row, ox = ox0 + xo;
-            const int co = min(co0 + col, a.Cout - 1);
-            const bool rok = oy < a.OH && co0 + col < a.Cout;
-            const float* src = do_n + (long)co * HWo + (long)min(oy, a.OH - 1) * a.OW;
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = src[min(ox + i, a.OW - 1)];
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                v[i] = (rok && ox + i < a.OW) ? v[i] : 0.f;
-                s += v[i];
-            }
-            dsum[it] += s;
-            WFrag h, m, l;
-            split8(v, h, m, l);
-            uint4* dst = reinterpret_cast<uint4*>(s_d + (long)col * DPITCH + ch * 8);
-            dst[0] = h.u;
-            dst[(BMc * DPITCH) >> 3] = m.u;
-            dst[(2 * BMc * DPITCH) >> 3] = l.u;
+            f32x4 v0, v1; int o; bool live;
+            d_load(t, it, v0, v1, o, live);
+            d_store(it, v0, v1, o, live);
         }
-        // ---- input halo tile
-        for (int id = tid; id < n_iitems; id += 256) {
-            const int cil = id / NCH, ch = id - cil * NCH;
-            const int lrow = (ch * 8) / CP, c0 = ch * 8 - lrow * CP;
-            const int gy = oy0 - a.pad + lrow;
-            const int gx0 = KH == 3 ? ox0 + c0 - 1 - a.pad : ox0 + c0;
-            const int ci = min(ci0 + cil, a.Cin - 1);
-            const bool rok = gy >= 0 && gy < a.H && ci0 + cil < a.Cin;
-            const float* src = in_n + (long)ci * HWin + (long)min(max(gy, 0), a.H - 1) * a.W;
-            float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int gx = min(max(gx0 + i, 0), a.W - 1);
-                v[i] = src[gx];
-                if (GATE) v[i] *= src[gx + a.gate_off];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (rok && gx0 + i >= 0 && gx0 + i < a.W) ? v[i] : 0.f;
-            WFrag h, m, l;
-            split8(v, h, m, l);
-            uint4* dst = reinterpret_cast<uint4*>(s_i + (long)cil * IPITCH + ch * 8);
-            dst[0] = h.u;
-            dst[(BNc * IPITCH) >> 3] = m.u;
-            dst[(2 * BNc * IPITCH) >> 3] = l.u;
+        for (int it = 0; it < NITI; ++it) {
+            f32x4 v0, v1; int o; bool live;
+            i_load(t, it, v0, v1, o, live);
+            i_store(v0, v1, o, live);
         }
     };
 
@@ -157,58 +216,60 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     constexpr int SA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int SB[6] = {0, 2, 1, 0, 1, 0};
 
+    if (PRE && t_begin < t_end) prefetch(t_begin);
     for (int t = t_begin; t < t_end; ++t) {
         __syncthreads();
-        stage(t);
+        if constexpr (PRE) commit(); else stage_sync(t);
         __syncthreads();
-#pragma unroll
+        if (PRE && t + 1 < t_end) prefetch(t + 1);
+#pragma unroll(KH == 3 ? 1 : KPW)
         for (int q = 0; q < KPW; ++q) {
             const int u = 2 * (wk * KPW + q) + kg;                       // this lane half's 8-pixel chunk
             const int row = (u * 8) >> cl, xo = (u * 8) & (C - 1);
-            WFrag af[TMW][3];
+            u32x4 af[TMW][3];
 #pragma unroll
             for (int x = 0; x < TMW; ++x)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
-                    af[x][s].u = *reinterpret_cast<const uint4*>(s_d + (long)(s * BMc + (wm * TMW + x) * 32 + j) * DPITCH + u * 8);
+                    af[x][s] = *reinterpret_cast<const u32x4*>(s_d + (long)(s * BMc + (wm * TMW + x) * 32 + j) * DPITCH + u * 8);
             if constexpr (KH == 1) {
-                WFrag bf[TNW][3];
+                u32x4 bf[TNW][3];
 #pragma unroll
                 for (int y = 0; y < TNW; ++y)
 #pragma unroll
                     for (int s = 0; s < 3; ++s)
-                        bf[y][s].u = *reinterpret_cast<const uint4*>(s_i + (long)(s * BNc + (wn * TNW + y) * 32 + j) * IPITCH + u * 8);
+                        bf[y][s] = *reinterpret_cast<const u32x4*>(s_i + (long)(s * BNc + (wn * TNW + y) * 32 + j) * IPITCH + u * 8);
 #pragma unroll
                 for (int p = 0; p < 6; ++p)
 #pragma unroll
                     for (int x = 0; x < TMW; ++x)
 #pragma unroll
                         for (int y = 0; y < TNW; ++y)
-                            acc[x][y][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[x][SA[p]].v, bf[y][SB[p]].v, acc[x][y][0], 0, 0, 0);
+                            acc[x][y][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[x][SA[p]]),
+                                                                                  __builtin_bit_cast(bf16x8, bf[y][SB[p]]), acc[x][y][0], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    WFrag bf[3][3];                                      // [kx][split]
+                    u32x4 bf[3][3];                                      // [kx][split]
 #pragma unroll
                     for (int s = 0; s < 3; ++s) {
-                        const uint4* src = reinterpret_cast<const uint4*>(s_i + (long)(s * BNc + wn * 32 + j) * IPITCH + (row + ky) * CP + xo);
-                        WFrag lo, hi;
-                        lo.u = src[0];
-                        hi.u = src[1];
-                        // LDS col c holds input x = ox0 + c - 1 - pad; tap kx reads cols xo + kx + 1 ... + 8
-                        const unsigned D[6] = {lo.d[0], lo.d[1], lo.d[2], lo.d[3], hi.d[0], hi.d[1]};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            bf[0][s].d[i] = __builtin_amdgcn_alignbit(D[i + 1], D[i], 16);
-                            bf[1][s].d[i] = D[i + 1];
-                            bf[2][s].d[i] = __builtin_amdgcn_alignbit(D[i + 2], D[i + 1], 16);
-                        }
+                        const u32x4* src = reinterpret_cast<const u32x4*>(s_i + (long)(s * BNc + wn * 32 + j) * IPITCH + (row + ky) * CP + xo);
+                        const u32x4 lo = src[0], hi = src[1];
+                        // LDS col c holds input x = ox0 + c - 4; tap kx reads cols xo + kx + 3 ... + 10 (pad = 1):
+                        // dwords D0..D6 = lo[0..3], hi[0..2]
+                        bf[1][s] = (u32x4){lo[2], lo[3], hi[0], hi[1]};
+                        bf[0][s] = (u32x4){__builtin_amdgcn_alignbit(lo[2], lo[1], 16), __builtin_amdgcn_alignbit(lo[3], lo[2], 16),
+                                           __builtin_amdgcn_alignbit(hi[0], lo[3], 16), __builtin_amdgcn_alignbit(hi[1], hi[0], 16)};
+                        bf[2][s] = (u32x4){__builtin_amdgcn_alignbit(lo[3], lo[2], 16), __builtin_amdgcn_alignbit(hi[0], lo[3], 16),
+                                           __builtin_amdgcn_alignbit(hi[1], hi[0], 16), __builtin_amdgcn_alignbit(hi[2], hi[1], 16)};
                     }
 #pragma unroll
                     for (int p = 0; p < 6; ++p)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx)
-                            acc[0][0][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][SA[p]].v, bf[kx][SB[p]].v, acc[0][0][ky * 3 + kx], 0, 0, 0);
+                            acc[0][0][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[0][SA[p]]),
+                                                                                            __builtin_bit_cast(bf16x8, bf[kx][SB[p]]),
+                                                                                            acc[0][0][ky * 3 + kx], 0, 0, 0);
                 }
             }
         }
@@ -279,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         }
 }
 
-template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE>
+template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE>
 int launch_wgb(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
     constexpr int BMc = 32 * TMW * WMw, BNc = 32 * TNW * WNw;
     const int C = 1 << a.tw_log2, R = P / C;
@@ -287,7 +348,7 @@ int launch_wgb(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
     const int ipitch = (((LR * CP) >> 3) | 1) << 3;
     const size_t lds = (size_t)(3 * BMc * (P + 8) + 3 * BNc * ipitch) * 2;
     dim3 grid(N * p.spi, tdr_cdiv(a.Cout, BMc), tdr_cdiv(a.Cin, BNc));
-    auto kern = wgrad_bx3_kernel<KH, P, WMw, WNw, WKw, TMW, TNW, GATE>;
+    auto kern = wgrad_bx3_kernel<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -307,7 +368,11 @@ int launch_wgb(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
 //            4 = 3x3, waves 1x1x4 (32 x 32, K split), P = 128
 //            5 = 1x1, waves 2x1x2 (64 co x 32 ci, K split 2), P = 64
 bool tdr_wgrad_bx3_supported(const TdrWgradDesc* d) {
-    return d->stride == 1 && (d->KH == 1 || (d->KH == 3 && !d->gate)) && d->OW >= 8 && d->Cin >= 8;
+    // float4 staging: rows must be 16-byte aligned pieces (W % 4 == 0), 3x3 only with pad 1
+    if (d->stride != 1 || d->OW < 8 || d->Cin < 8 || d->W % 4 != 0 || d->OW % 4 != 0) return false;
+    if (d->in_ns % 4 != 0 || d->dout_ns % 4 != 0) return false;
+    if (d->KH == 1) return d->pad == 0;
+    return d->KH == 3 && d->pad == 1 && !d->gate;
 }
 
 WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d) {
@@ -344,11 +409,11 @@ WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d) {
 int tdr_wgrad_bx3_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st) {
     const bool g = d->gate != 0;
     switch (p.cfg) {
-        case 0: return g ? launch_wgb<1, 32, 2, 2, 1, 2, 2, true>(a, p, d->N, st) : launch_wgb<1, 32, 2, 2, 1, 2, 2, false>(a, p, d->N, st);
-        case 1: return g ? launch_wgb<1, 64, 2, 2, 1, 1, 1, true>(a, p, d->N, st) : launch_wgb<1, 64, 2, 2, 1, 1, 1, false>(a, p, d->N, st);
-        case 2: return g ? launch_wgb<1, 128, 1, 1, 4, 1, 1, true>(a, p, d->N, st) : launch_wgb<1, 128, 1, 1, 4, 1, 1, false>(a, p, d->N, st);
-        case 3: return launch_wgb<3, 32, 2, 2, 1, 1, 1, false>(a, p, d->N, st);
-        case 4: return launch_wgb<3, 128, 1, 1, 4, 1, 1, false>(a, p, d->N, st);
-        default: return g ? launch_wgb<1, 64, 2, 1, 2, 1, 1, true>(a, p, d->N, st) : launch_wgb<1, 64, 2, 1, 2, 1, 1, false>(a, p, d->N, st);
+        case 0: return g ? launch_wgb<1, 32, 2, 2, 1, 2, 2, true, true>(a, p, d->N, st) : launch_wgb<1, 32, 2, 2, 1, 2, 2, false, true>(a, p, d->N, st);
+        case 1: return g ? launch_wgb<1, 64, 2, 2, 1, 1, 1, true, true>(a, p, d->N, st) : launch_wgb<1, 64, 2, 2, 1, 1, 1, false, true>(a, p, d->N, st);
+        case 2: return g ? launch_wgb<1, 128, 1, 1, 4, 1, 1, true, true>(a, p, d->N, st) : launch_wgb<1, 128, 1, 1, 4, 1, 1, false, true>(a, p, d->N, st);
+        case 3: return launch_wgb<3, 32, 2, 2, 1, 1, 1, false, false>(a, p, d->N, st);
+        case 4: return launch_wgb<3, 128, 1, 1, 4, 1, 1, false, false>(a, p, d->N, st);
+        default: return g ? launch_wgb<1, 64, 2, 1, 2, 1, 1, true, true>(a, p, d->N, st) : launch_wgb<1, 64, 2, 1, 2, 1, 1, false, true>(a, p, d->N, st);
     }
 }

@@ -18,6 +18,8 @@ PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2 = 0, 1, 2, 3
 #   'f32' : exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain)
 # The MASA arg-max searches always run on the exact path (near-tie indices must not move).
 MATH = os.environ.get('TDR_MATH', 'bx3')
+# weight gradients of 1x1 convs on the split-bf16 kernel as well (0: exact fp32 kernel)
+WGRAD_1X1_BX3 = os.environ.get('TDR_WGRAD_1X1_BX3', '1') == '1'
 FMT_F32, FMT_BX3 = 0, 1
 
 
@@ -259,7 +261,7 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
     db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
     d.db = _p(db)
     d.per_image = 1 if per_image else 0
-    d.math = 1 if MATH == 'bx3' else 0
+    d.math = 1 if (MATH == 'bx3' and (KH == 3 or WGRAD_1X1_BX3)) else 0
     need = lib.tdr_wgrad_ws_floats(C.byref(d))
     ws = workspace(need, x.device, 'wgrad')
     d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
