@@ -209,10 +209,12 @@ int tdr_fine_search_bwd(const float* datt, const float* soft_att, const int* ind
 int tdr_transfer_fwd(const float* feat, int N, int C, int H, int W, const int* y1, const int* x1,
                      const int* index_all, const float* soft_att, int py, int px, int K, int side, int s,
                      float* out, int64_t out_ns, void* stream);
-/* backward: dfeat (accumulated with atomics, caller zeroes) and datt[B,K,K] partial for this scale (+=) */
+/* backward: dfeat (accumulated with atomics, caller zeroes) and datt[B,K,K] partial for this scale (+=);
+ * ws >= tdr_transfer_ws_floats(...) floats */
+int64_t tdr_transfer_ws_floats(int N, int C, int py, int px, int K, int s);
 int tdr_transfer_bwd(const float* dout, int64_t dout_ns, const float* feat, int N, int C, int H, int W,
                      const int* y1, const int* x1, const int* index_all, const float* soft_att, int py, int px,
-                     int K, int side, int s, float* dfeat, float* datt, float* ws /* N*OH*OW floats */, void* stream);
+                     int K, int side, int s, float* dfeat, float* datt, float* ws, void* stream);
 /* scatter-add of the ref-block gradient back into the deepest ref feature (wrap-aware) */
 int tdr_scatter_ref_block(const float* dblk, int N, int C, int H, int W, const int* y1, const int* x1, int P,
                           int side, float* dfeat, void* stream);

@@ -28,6 +28,13 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// TDR_PROBE (profiling builds only, profiles/probes/): ablations of the main loop --
+// 1: no operand (pixel) global loads after the prologue   2: no MFMAs (operands kept live)
+// 3: no weight-fragment loads after the prologue          4: no LDS stores / barriers after the prologue
+#ifndef TDR_PROBE
+#define TDR_PROBE 0
+#endif
+
 namespace {
 
 constexpr int bx_cmax(int a, int b) { return a > b ? a : b; }
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             if (g < ngroups) {
                 const int buf = g & 1;
                 const uint4* sb = smem4 + buf * 6 * plane;
-                if (PF == 1 && g + 1 < ngroups) load_group(g + 1, 0);
+                if (TDR_PROBE != 1 && PF == 1 && g + 1 < ngroups) load_group(g + 1, 0);
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
                     const int tapoff = (tap / KH) * LW + (tap % KH);
@@ -194,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                     // the fragments (in-order vmcnt) then leaves the operand loads in flight.
                     // (the last prefetch of the last group re-reads a valid slot)
                     const long gtn = min((long)g * TAPS + tap + 1, (long)ngroups * TAPS - 1);
-                    load_a(afn, gtn);
-                    if (PF > 1 && tap == 0 && g + PF < ngroups) load_group(g + PF, u);   // set u is free: group g already sits in LDS
+                    if (TDR_PROBE != 3) load_a(afn, gtn);
+                    if (TDR_PROBE != 1 && PF > 1 && tap == 0 && g + PF < ngroups) load_group(g + PF, u);   // set u is free: group g already sits in LDS
                     Frag bf[TN][3];
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
@@ -210,18 +217,32 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn)
-                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
+                                if (TDR_PROBE != 2) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
+                                else if (q == 0) {
+                                    asm volatile("" ::"v"(__builtin_bit_cast(f32x4, af[tm][0].v)), "v"(__builtin_bit_cast(f32x4, af[tm][1].v)),
+                                                 "v"(__builtin_bit_cast(f32x4, af[tm][2].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][0].v)),
+                                                 "v"(__builtin_bit_cast(f32x4, bf[tn][1].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][2].v)));
+                                }
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int s = 0; s < 3; ++s) af[tm][s] = afn[tm][s];
                 }
-                if (g + 1 < ngroups) store_group(g + 1, (u + 1) % PF, buf ^ 1);
-                __syncthreads();
+                if (TDR_PROBE != 4) {
+                    if (g + 1 < ngroups) store_group(g + 1, (u + 1) % PF, buf ^ 1);
+                    __syncthreads();
+                }
             }
         }
     }
 
+    if constexpr (EPI != EPI_PSHUF) {
+        if (a.vec_epi) {
+            __syncthreads();                              // every wave is done with the operand tiles
+            conv_epilogue_vec<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, lane, reinterpret_cast<float*>(smem4) + wave * (32 * 36));
+            return;
+        }
+    }
     conv_epilogue<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
 }
 
@@ -267,7 +288,10 @@ int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
         } else {
             if (a.Cout > 64 && blocks(128, 256) >= 512) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);  // 128 x 256
         }
-        if (blocks(64, 256) >= 512) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);       // 64 x 256
+        // weight fragments are re-read per 32-pixel column of the wave tile: wide pixel tiles (TN = 4) halve that L2->VGPR
+        // stream; with a long K loop one resident block per CU (256 blocks) already hides the latencies
+        const long ksteps = (long)((a.Cin + 15) / 16) * KH * KH;
+        if (blocks(64, 256) >= (ksteps >= 64 ? 256 : 512)) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);       // 64 x 256
         return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);                                   // 64 x 128
     }
 }
@@ -319,6 +343,9 @@ int tdr_conv_forward_bx3(const TdrConvDesc* d, void* stream) {
     a.bias2 = d->bias2; a.bias2_ns = d->bias2_ns; a.bias2_mul = d->bias2_mul;
     a.res = d->res; a.res_ns = d->res_ns; a.mask = d->mask; a.mask_ns = d->mask_ns;
     a.aux = d->aux; a.aux_ns = d->aux_ns; a.relu = d->relu;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    a.vec_epi = (d->OW % 4 == 0 && d->out_ns % 4 == 0 && al16(d->out) && (!d->res || (d->res_ns % 4 == 0 && al16(d->res))) &&
+                 (!d->mask || (d->mask_ns % 4 == 0 && al16(d->mask))) && (!d->aux || (d->aux_ns % 4 == 0 && al16(d->aux)))) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const int N = d->N;
     const int key = d->KH * 100 + d->stride * 10 + d->epi;

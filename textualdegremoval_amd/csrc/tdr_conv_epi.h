@@ -23,6 +23,7 @@ struct ConvArgs {
     const float* mask; long mask_ns;
     const float* aux; long aux_ns;
     int relu;
+    int vec_epi;      // 1: rows are 16-byte aligned (OW % 4 == 0, aligned bases): LDS-transposed float4 epilogue
 };
 
 // acc[TM][TN]: wave (wm, wn) owns output-channel tiles wm*TM.. and pixel sub-tiles wn*TN..
@@ -142,6 +143,94 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             }
         }
     }
+}
+
+
+// Vector epilogue: each 32x32 accumulator tile goes through a wave-private LDS patch (32 rows x 36 floats) so
+// that a lane ends up with 4 consecutive pixels of one output channel: the tile leaves as 4 global_store_dwordx4
+// per lane (8 x 128-byte row segments per wave instruction) instead of 16 dword stores (2 segments per
+// instruction), and residual / mask / gate operands arrive as float4 loads.  DS operations of one wave execute
+// in order, so the patch needs no barrier.  Requires a.vec_epi (all rows 16-byte aligned); STD and GATEBWD only.
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& a, f32x16 (&acc)[TM][TN], int n, int m0, int wm, int wn,
+                                                  int oy0, int ox0, int lane, float* sw) {
+    static_assert(EPI == EPI_STD || EPI == EPI_GATEBWD, "vector epilogue: STD / GATEBWD");
+    const int j = lane & 31, kk = lane >> 5;
+    const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2;
+    const long HWo = (long)a.OH * a.OW;
+    const int c4 = (lane & 7) * 4;            // first of this lane's 4 pixels inside the 32-pixel sub-tile
+    const int r0 = lane >> 3;                 // rows r0 + 8 i
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int t = wn * TN + tn;
+        const int oy = oy0 + t * SR + (c4 >> a.tw_log2), ox = ox0 + (c4 & (TW - 1));
+        const bool pvalid = oy < a.OH && ox < a.OW;
+        const long pix = pvalid ? (long)oy * a.OW + ox : 0;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * kk) * 36 + j] = acc[tm][tn][r];
+            f32x4 v[4];
+            int mrow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = *reinterpret_cast<const f32x4*>(sw + (r0 + 8 * i) * 36 + c4);
+                mrow[i] = m0 + (wm * TM + tm) * 32 + r0 + 8 * i;
+            }
+            if (EPI == EPI_GATEBWD) {
+                const float* ax = a.aux + (long)n * a.aux_ns;
+                const long half = (long)a.Cout * HWo;
+                f32x4 a0[4], a1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long o = (long)min(mrow[i], a.Cout - 1) * HWo + pix;
+                    a0[i] = *reinterpret_cast<const f32x4*>(ax + o);
+                    a1[i] = *reinterpret_cast<const f32x4*>(ax + o + half);
+                }
+                float* op = a.out + (long)n * a.out_ns;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (pvalid && mrow[i] < a.Cout) {
+                        const long o = (long)mrow[i] * HWo + pix;
+                        *reinterpret_cast<f32x4*>(op + o) = v[i] * a1[i];
+                        *reinterpret_cast<f32x4*>(op + o + half) = v[i] * a0[i];
+                    }
+            } else {
+                f32x4 rv[4], mv[4];
+                if (a.res) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        rv[i] = *reinterpret_cast<const f32x4*>(a.res + (long)n * a.res_ns + (long)min(mrow[i], a.Cout - 1) * HWo + pix);
+                }
+                if (a.mask) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        mv[i] = *reinterpret_cast<const f32x4*>(a.mask + (long)n * a.mask_ns + (long)min(mrow[i], a.Cout - 1) * HWo + pix);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mc = min(mrow[i], a.Cout - 1);
+                    f32x4 x = v[i];
+                    if (a.bias) x += a.bias[(long)n * a.bias_ns + mc];
+                    if (a.scale) x *= a.scale[(long)n * a.scale_ns + mc];
+                    if (a.bias2) x += a.bias2_mul * a.bias2[(long)n * a.bias2_ns + mc];
+                    if (a.res) x += rv[i];
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+                    }
+                    if (a.mask) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = mv[i][e] > 0.f ? x[e] : 0.f;
+                    }
+                    if (pvalid && mrow[i] < a.Cout)
+                        *reinterpret_cast<f32x4*>(a.out + (long)n * a.out_ns + (long)mrow[i] * HWo + pix) = x;
+                }
+            }
+        }
+    }
+    (void)z4;
 }
 
 }  // namespace

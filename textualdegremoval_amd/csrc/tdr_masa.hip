@@ -311,14 +311,19 @@ __global__ __launch_bounds__(256) void transfer_fwd_kernel(const float* __restri
     }
 }
 
-// backward pass 1: dfeat scatter (atomics) + per-pixel dA = sum_c dout * acc/cnt
+// backward pass 1: dfeat scatter (atomics) + per-pixel dA = sum_c dout * acc/cnt.
+// grid = (pixel blocks, channel chunks, N): the coarse levels have few pixels and many channels, so channels are
+// split across blocks (dA partial per chunk, summed by pass 2).  The <= 9 patches covering an output pixel usually
+// point at the SAME source pixel (coherent matches): duplicates are merged once per pixel, so a channel costs one
+// gather + one atomic per distinct source instead of nine.
 __global__ __launch_bounds__(256) void transfer_bwd_kernel(const float* __restrict__ dout, long dout_ns,
                                                           const float* __restrict__ feat, int C, int H, int W,
                                                           const int* __restrict__ y1, const int* __restrict__ x1,
                                                           const int* __restrict__ index_all,
                                                           const float* __restrict__ soft_att, int py, int px, int K,
-                                                          int side, int s, float* __restrict__ dfeat,
-                                                          float* __restrict__ dA /*[N][OH*OW]*/) {
+                                                          int side, int s, int cpb /*channels per block*/, int N,
+                                                          float* __restrict__ dfeat,
+                                                          float* __restrict__ dA /*[chunks][N][OH*OW]*/) {
     const int OW = px * K * s, OH = py * K * s;
     const int pix = blockIdx.x * 256 + threadIdx.x, n = blockIdx.z;
     if (pix >= OH * OW) return;
@@ -329,8 +334,22 @@ __global__ __launch_bounds__(256) void transfer_bwd_kernel(const float* __restri
     tr_geometry(Y - by * K * s, X - bx * K * s, b, y1, x1, index_all, soft_att, K, side, s, H, W, g);
     const long HWf = (long)H * W, HWo = (long)OH * OW;
     const float coef = g.inv_cnt * g.wgt;
+    float mult[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        int m = 0;
+        bool first = g.src[k] >= 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const bool same = g.src[q] == g.src[k];
+            m += same ? 1 : 0;
+            if (q < k && same) first = false;
+        }
+        mult[k] = first ? (float)m : 0.f;
+    }
     float da = 0.f;
-    for (int c = 0; c < C; ++c) {
+    const int c0 = blockIdx.y * cpb, c1 = min(c0 + cpb, C);
+    for (int c = c0; c < c1; ++c) {
         const float* f = feat + ((long)n * C + c) * HWf;
         float* df = dfeat + ((long)n * C + c) * HWf;
         const float go = dout[(long)n * dout_ns + (long)c * HWo + pix];
@@ -338,16 +357,16 @@ __global__ __launch_bounds__(256) void transfer_bwd_kernel(const float* __restri
         const float gv = go * coef;
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            if (g.src[k] >= 0) { acc += f[g.src[k]]; atomicAdd(&df[g.src[k]], gv); }
+            if (mult[k] > 0.f) { acc += mult[k] * f[g.src[k]]; atomicAdd(&df[g.src[k]], gv * mult[k]); }
         da += go * acc * g.inv_cnt;
     }
-    dA[(long)n * HWo + pix] = da;
+    dA[((long)blockIdx.y * N + n) * HWo + pix] = da;
 }
 
 // backward pass 2 (deterministic gather): datt[b][i][j] += sum over local pixels whose bilinear
 // footprint touches (i,j)
 __global__ __launch_bounds__(64) void transfer_datt_kernel(const float* __restrict__ dA, int py, int px, int K, int s,
-                                                          float* __restrict__ datt) {
+                                                          int chunks, long chunk_stride, float* __restrict__ datt) {
     const int b = blockIdx.x, e = blockIdx.y;           // e = i*K + j
     const int P = py * px, n = b / P, by = (b % P) / px, bx = b % px;
     const int i = e / K, j = e % K;
@@ -367,7 +386,12 @@ __global__ __launch_bounds__(64) void transfer_datt_kernel(const float* __restri
         if (yy0 == i && xx1 == j) wgt += (1.f - ly) * lx;
         if (yy1 == i && xx0 == j) wgt += ly * (1.f - lx);
         if (yy1 == i && xx1 == j) wgt += ly * lx;
-        if (wgt != 0.f) acc += wgt * dA[(long)n * OH * OW + (long)(by * KS + Yl) * OW + bx * KS + Xl];
+        if (wgt != 0.f) {
+            const long o = (long)n * OH * OW + (long)(by * KS + Yl) * OW + bx * KS + Xl;
+            float v = 0.f;
+            for (int q = 0; q < chunks; ++q) v += dA[q * chunk_stride + o];
+            acc += wgt * v;
+        }
     }
     acc = wave_sum(acc);
     if (threadIdx.x == 0) datt[(long)b * K * K + e] += acc;
@@ -471,15 +495,32 @@ extern "C" int tdr_transfer_fwd(const float* feat, int N, int C, int H, int W, c
     return TDR_OK;
 }
 
+// channel chunks of transfer_bwd: enough blocks to fill the chip (>= ~1024), at least 8 channels per block
+static int tdr_transfer_chunks(int N, int C, int py, int px, int K, int s) {
+    const long opix = (long)py * K * s * px * K * s;
+    const long pix_blocks = ((opix + 255) / 256) * N;
+    long chunks = (1024 + pix_blocks - 1) / pix_blocks;
+    if (chunks > C / 8) chunks = C / 8;
+    if (chunks < 1) chunks = 1;
+    return (int)chunks;
+}
+
+extern "C" int64_t tdr_transfer_ws_floats(int N, int C, int py, int px, int K, int s) {
+    return (int64_t)tdr_transfer_chunks(N, C, py, px, K, s) * N * py * K * s * px * K * s;
+}
+
 extern "C" int tdr_transfer_bwd(const float* dout, int64_t dout_ns, const float* feat, int N, int C, int H, int W,
                                 const int* y1, const int* x1, const int* index_all, const float* soft_att, int py, int px,
                                 int K, int side, int s, float* dfeat, float* datt, float* ws, void* stream) {
     TDR_REQUIRE(dout && feat && y1 && x1 && index_all && soft_att && dfeat && datt && ws, "tdr_transfer_bwd: null pointer");
     const long opix = (long)py * K * s * px * K * s;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(transfer_bwd_kernel, dim3((unsigned)((opix + 255) / 256), 1, N), dim3(256), 0, st, dout, (long)dout_ns,
-                       feat, C, H, W, y1, x1, index_all, soft_att, py, px, K, side, s, dfeat, ws);
-    hipLaunchKernelGGL(transfer_datt_kernel, dim3(N * py * px, K * K), dim3(64), 0, st, ws, py, px, K, s, datt);
+    const int chunks = tdr_transfer_chunks(N, C, py, px, K, s);
+    const int cpb = tdr_cdiv(C, chunks);
+    hipLaunchKernelGGL(transfer_bwd_kernel, dim3((unsigned)((opix + 255) / 256), tdr_cdiv(C, cpb), N), dim3(256), 0, st, dout,
+                       (long)dout_ns, feat, C, H, W, y1, x1, index_all, soft_att, py, px, K, side, s, cpb, N, dfeat, ws);
+    hipLaunchKernelGGL(transfer_datt_kernel, dim3(N * py * px, K * K), dim3(64), 0, st, ws, py, px, K, s, tdr_cdiv(C, cpb),
+                       (long)N * opix, datt);
     TDR_LAUNCH_CHECK("transfer_bwd");
     return TDR_OK;
 }

@@ -187,29 +187,37 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
         }
 }
 
-// out[g][e] = sum_{s < per_group} part[(g*per_group + s)][e]; block = 64 elements x KL partial-lanes
+// out[g][e] = sum_{s < per_group} part[(g*per_group + s)][e]; block = 64 elements x KL partial-lanes.
+// Blocks with blockIdx.x >= nb_main run the second (bias-gradient) job in the same launch.
 template <int KL>
 __global__ __launch_bounds__(64 * KL) void wgrad_reduce_kernel(const float* __restrict__ part, long elems, int per_group,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, int nb_main,
+                                                               const float* __restrict__ part2, long elems2, int per_group2,
+                                                               float* __restrict__ out2) {
     __shared__ float red[KL][64];
     const int lane = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    const long e = blockIdx.x * 64L + lane;
-    const long ec = e < elems ? e : elems - 1;
-    const float* p = part + (long)blockIdx.y * per_group * elems + ec;
+    const bool second = (int)blockIdx.x >= nb_main;
+    if (second && blockIdx.y != 0) return;
+    const float* pbase = second ? part2 : part;
+    const long ne = second ? elems2 : elems;
+    const int pg = second ? per_group2 : per_group;
+    float* o = second ? out2 : out;
+    const long e = ((int)blockIdx.x - (second ? nb_main : 0)) * 64L + lane;
+    const long ec = e < ne ? e : ne - 1;
+    const float* p = pbase + (second ? 0L : (long)blockIdx.y * pg * ne) + ec;
     float s0 = 0.f, s1 = 0.f;
     int k = kl;
-    for (; k + KL < per_group; k += 2 * KL) { s0 += p[(long)k * elems]; s1 += p[(long)(k + KL) * elems]; }
-    if (k < per_group) s0 += p[(long)k * elems];
+    for (; k + KL < pg; k += 2 * KL) { s0 += p[(long)k * ne]; s1 += p[(long)(k + KL) * ne]; }
+    if (k < pg) s0 += p[(long)k * ne];
     red[kl][lane] = s0 + s1;
     __syncthreads();
-    if (kl == 0 && e < elems) {
+    if (kl == 0 && e < ne) {
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < KL; ++q) t += red[q][lane];
-        out[(long)blockIdx.y * elems + e] = t;
+        o[(second ? 0L : (long)blockIdx.y * ne) + e] = t;
     }
 }
-
 
 // cfg: 0 = waves 2x2x1 tile 2x2 (128x128) | 1 = waves 1x1x4 tile 2x1 (64x32) | 2 = 2x2x1 tile 1x1 (64x64)
 //      3 = waves 1x1x4 tile 1x1 (32x32)
@@ -308,15 +316,19 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     const long elems = (long)d->Cout * d->Cin * d->KH * d->KH;
     const int groups = d->per_image ? d->N : 1;
     const int per_group = (d->per_image ? p.spi : d->N * p.spi) * p.WKw;
-    if (per_group <= 8)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(tdr_cdiv(elems, 64), groups), dim3(64), 0, st, d->ws, elems, per_group, d->g);
-    else if (per_group <= 64)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(tdr_cdiv(elems, 64), groups), dim3(256), 0, st, d->ws, elems, per_group, d->g);
+    const int nb_main = tdr_cdiv(elems, 64);
+    const int nb2 = d->db ? tdr_cdiv(d->Cout, 64) : 0;
+    const int pg2 = d->N * p.spi;
+    const dim3 rgrid(nb_main + nb2, groups);
+    if (per_group <= 8 && pg2 <= 8)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, rgrid, dim3(64), 0, st, d->ws, elems, per_group, d->g, nb_main, a.dbpart,
+                           (long)d->Cout, pg2, d->db);
+    else if (per_group <= 64 && pg2 <= 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, rgrid, dim3(256), 0, st, d->ws, elems, per_group, d->g, nb_main, a.dbpart,
+                           (long)d->Cout, pg2, d->db);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(tdr_cdiv(elems, 64), groups), dim3(1024), 0, st, d->ws, elems, per_group, d->g);
-    if (d->db)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(tdr_cdiv(d->Cout, 64), 1), dim3(1024), 0, st, a.dbpart, (long)d->Cout,
-                           d->N * p.spi, d->db);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, rgrid, dim3(1024), 0, st, d->ws, elems, per_group, d->g, nb_main, a.dbpart,
+                           (long)d->Cout, pg2, d->db);
     TDR_LAUNCH_CHECK("wgrad_reduce_kernel");
     return TDR_OK;
 }

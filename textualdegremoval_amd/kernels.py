@@ -532,7 +532,7 @@ def transfer_fwd(feat, y1, x1, index_all, soft_att, py, px, K, side, s, out=None
 
 def transfer_bwd(dout, feat, y1, x1, index_all, soft_att, py, px, K, side, s, dfeat, datt):
     N, Cc, H, W = feat.shape
-    ws = workspace(N * py * K * s * px * K * s, feat.device, 'transfer')
+    ws = workspace(_lib.load().tdr_transfer_ws_floats(N, Cc, py, px, K, s), feat.device, 'transfer')
     check(_lib.load().tdr_transfer_bwd(dout.data_ptr(), _dense_nchw(dout), feat.data_ptr(), N, Cc, H, W, y1.data_ptr(),
                                        x1.data_ptr(), index_all.data_ptr(), soft_att.data_ptr(), py, px, K, side, s,
                                        dfeat.data_ptr(), datt.data_ptr(), ws.data_ptr(), _stream()), 'tdr_transfer_bwd')
