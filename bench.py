@@ -24,6 +24,8 @@ import torch.distributed as dist  # noqa: E402
 # algorithmic work per image, SURVEY.md 8(d) (module-granular fp32 traffic; dense conv+matmul FLOPs, bwd = 2x fwd)
 CFG2 = dict(B_alg=52.2e9, F_alg=2.00e12)
 PEAK_HBM, PEAK_F32 = 8.0e12, 157.3e12
+PEAK_BF16 = 2.5e15                    # dense bf16 MFMA (MI355X_MICROARCH.md); the split-bf16 kernels spend 6 products per fp32 product
+PEAK_BX3 = PEAK_BF16 / 6.0
 
 
 def make_opt(width, enc, batch_hw, dist_on):
@@ -119,6 +121,11 @@ def main():
         model.optimize_parameters(it)
 
     it = 0
+    # one-time set-up, like building the model: the first steps of a shape run eagerly (workspaces, gradient-arena
+    # layout, weight-pack plan) and then the step is captured into hipGraphs; none of that is steady-state work.
+    for _ in range(3 if getattr(model, 'use_hip_graph', True) and os.environ.get('TDR_GRAPH', '1') == '1' else 1):
+        it += 1
+        step(it)
     for _ in range(a.warmup):
         it += 1
         step(it)
@@ -154,7 +161,8 @@ def main():
                 e0.record()
                 out = orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
                 e1.record()
-                recs.append((2.0 * x.shape[0] * Cout * x.shape[1] * 9 * out.shape[2] * out.shape[3], e0, e1))
+                recs.append((2.0 * x.shape[0] * Cout * x.shape[1] * 9 * out.shape[2] * out.shape[3], e0, e1,
+                             4.0 * (x.numel() + out.numel())))
                 return out
             return orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
         K.conv_forward = timed
@@ -170,10 +178,32 @@ def main():
         fl = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel<KH=3,S=1> (fp32 v_mfma_f32_32x32x2_f32)',
-                'achieved': ach, 'peak': PEAK_F32 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_F32 / 1e12),
+        bx3 = K.MATH == 'bx3'
+        peak = (PEAK_BX3 if bx3 else PEAK_F32) / 1e12
+        roof = {'bound': 'mfma',
+                'kernel': ('conv_bx3_kernel<KH=3,S=1> (3-way bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)'
+                           if bx3 else 'conv_mfma_kernel<KH=3,S=1> (exact fp32 v_mfma_f32_32x32x2_f32)'),
+                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                'peak_note': ('2.5 PFLOP/s dense bf16 MFMA / 6 cross products = fp32-equivalent peak of the split scheme'
+                              if bx3 else 'dense fp32 MFMA peak'),
+                'frac_of_f32_mfma_peak': ach / (PEAK_F32 / 1e12),
                 'launches': len(recs), 'avg_launch_ms': ms / max(len(recs), 1),
                 'alg_flop_per_launch': fl / max(len(recs), 1), 'traffic': None}
+        # HBM bytes per launch of the same kernel family from the committed PMC passes (profiles/pmc_workload.py)
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r1', 'pmc_traffic.json')) as fh:
+                pmc = json.load(fh)
+            tot, n = 0.0, 0
+            for name, v in pmc['kernels'].items():
+                if name.startswith('conv_bx3_kernel<3, 1,' if bx3 else 'conv_mfma_kernel<3, 1, 1,'):
+                    tot += (v['read_bytes_per_launch'] + v['write_bytes_per_launch']) * v['launches']
+                    n += v['launches']
+            if n:
+                roof['traffic'] = tot / n
+                roof['traffic_unit'] = 'bytes/launch (FETCH_SIZE + WRITE_SIZE, calibrated, profiles/r1/pmc_traffic.json)'
+                roof['alg_bytes_per_launch'] = sum(r[3] for r in recs) / max(len(recs), 1)
+        except (OSError, KeyError, ValueError):
+            pass
 
     if rank == 0:
         ips = world * a.batch * a.steps / dt
@@ -183,6 +213,9 @@ def main():
             'metric': 'train images/sec (512x512, bs=4/GPU)', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'math': ('fp32 tensors; dense contractions as 3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate): '
+                     'per-product error <= one fp32 rounding, see profiles/r1/bf16x3_probe_mi355x.log; TDR_MATH=f32 selects exact fp32 MFMA'
+                     if K.MATH == 'bx3' else 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)'),
             'config': {'workload': 'BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
                                    f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW',
                        'width': a.width, 'enc_blk_nums': enc, 'global_batch': world * a.batch,
@@ -192,6 +225,7 @@ def main():
         if is_cfg2:
             line['roofline_step'] = {'achieved_hbm_frac': CFG2['B_alg'] * per_gpu / PEAK_HBM,
                                      'achieved_f32_flop_frac': CFG2['F_alg'] * per_gpu / PEAK_F32,
+                                     'achieved_bx3_flop_frac': CFG2['F_alg'] * per_gpu / PEAK_BX3,
                                      'alg_bytes_per_image': CFG2['B_alg'], 'alg_flop_per_image': CFG2['F_alg']}
         if roof is not None:
             line['roofline'] = roof

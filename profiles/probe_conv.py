@@ -25,3 +25,7 @@ t('3x3 L5 512->512 @32 N8', 8, 512, 512, 32, 3)
 t('1x1 256->512 @64 N4', 4, 256, 512, 64, 1)
 t('1x1 256->256 @64 N4', 4, 256, 256, 64, 1)
 t('1x1 64->128 @512 N4', 4, 64, 128, 512, 1)
+t('1x1 128->256 @256 N4', 4, 128, 256, 256, 1)
+t('1x1 128->128 @256 N4', 4, 128, 128, 256, 1)
+t('1x1 32->64 @512 N4', 4, 32, 64, 512, 1)
+t('1x1 512->1024 @64 N4', 4, 512, 1024, 64, 1)

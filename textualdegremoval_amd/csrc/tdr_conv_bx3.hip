@@ -21,6 +21,7 @@
 //                so a B fragment is one conflict-free ds_read_b128 per lane for any tap shift.
 // LDS is double buffered: the global loads of group c+1 are in flight under the MFMAs of group c,
 // one barrier per group.
+#include <stdlib.h>
 #include "tdr_common.h"
 #include "tdr_conv_epi.h"
 #include "tdr_pack.h"
@@ -76,8 +77,19 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2, TH = NT * SR;
     const int LH = (TH - 1) * S + KH, LW = (TW - 1) * S + KH;
     const int plane = LH * LW;
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    const int m0 = blockIdx.y * BM;
+    // XCD-aware block order (workgroup b runs on XCD b % 8, each XCD has its own L2): XCD k walks a contiguous
+    // range of the logical (pixel tile, m-tile) sequence with the m-tiles of one pixel tile back to back, so an
+    // input tile is fetched from HBM once per XCD and re-used from its L2 by the other m-tiles, and halo lines
+    // are shared between neighbouring pixel tiles on the same XCD.  Bijective for any grid size; speed only.
+    int logical;
+    {
+        const int T = gridDim.x, b = blockIdx.x;
+        const int q = T >> 3, r = T & 7, xcd = b & 7, slot = b >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int mtile = logical % a.mtiles, ptile = logical / a.mtiles;
+    const int tx = ptile % a.tiles_x, ty = ptile / a.tiles_x;
+    const int m0 = mtile * BM;
     const int n = blockIdx.z;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
@@ -257,7 +269,8 @@ int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
     ConvArgs b = a;
     b.tiles_x = tdr_cdiv(a.OW, TW);
     const int tiles_y = tdr_cdiv(a.OH, TH);
-    dim3 grid(b.tiles_x * tiles_y, tdr_cdiv(a.Cout, BM), N);
+    b.mtiles = tdr_cdiv(a.Cout, BM);
+    dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
     auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -284,6 +297,11 @@ int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
             return launch_bx_cfg<KH, S, 1, 1, 1, EPI, GATE>(a, N, st);                               // 32 x 128
         }
         if constexpr (KH == 1) {   // two register sets of prefetched operands: 128 x 128 keeps the kernel under 256 VGPRs
+            static const int force = getenv("TDR_BX_CFG1") ? atoi(getenv("TDR_BX_CFG1")) : 0;   // tuning aid
+            if (force == 1) return launch_bx_cfg<KH, S, 2, 2, 2, EPI, GATE>(a, N, st);
+            if (force == 2) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);
+            if (force == 3) return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);
+            if (force == 4) return launch_bx_cfg<KH, S, 1, 1, 2, EPI, GATE>(a, N, st);
             if (a.Cout > 64 && blocks(128, 128) >= 512) return launch_bx_cfg<KH, S, 2, 2, 2, EPI, GATE>(a, N, st);
         } else {
             if (a.Cout > 64 && blocks(128, 256) >= 512) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);  // 128 x 256

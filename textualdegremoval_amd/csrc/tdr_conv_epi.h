@@ -13,7 +13,7 @@ struct ConvArgs {
     const float* in; long in_ns; int Cin, H, W;
     const float* wp; long wp_ns; int Mpad, Cout;
     float* out; long out_ns; int OH, OW;
-    int pad, tw_log2, tiles_x;
+    int pad, tw_log2, tiles_x, mtiles;
     const float* kscale; long kscale_ns;
     long gate_off;
     const float* bias; long bias_ns;
