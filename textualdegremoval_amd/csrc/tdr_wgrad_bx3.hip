@@ -56,8 +56,14 @@ __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h
 }
 
 // PRE: the global loads of tile t+1 are issued before the MFMAs of tile t (register double buffering)
-template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE>
+// DMA (3x3 only): the raw fp32 rows of tile t+1 are fetched by global_load_lds (LDS-DMA, no VGPRs) into a staging
+// patch while tile t is on the matrix pipe, and split from there after the barrier -- HBM latency hidden without
+// the register budget a prefetch would need.  Tiles that start a column are staged synchronously.
+// CL = log2 of the tile width C (a template constant: the staging index arithmetic divides by C-derived sizes for
+// every item of every tile; with run-time divisors that integer math out-weighed the MFMAs)
+template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL>
 __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
+    static_assert(!DMA || (KH == 3 && !PRE && !GATE), "DMA staging: 3x3 only");
     static_assert(WMw * WNw * WKw == 4, "4 waves");
     static_assert(KH == 1 || (TMW == 1 && TNW == 1), "3x3: one 32x32 tile pair (9 accumulators) per wave");
     constexpr int TAPS = KH * KH;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     constexpr int HALO = KH == 3 ? 1 : 0;
     constexpr int DCH = P / 8;                       // 8-pixel chunks per dout row
     constexpr int NITD = (BMc * DCH + 255) / 256;
-    constexpr int NITI = (BNc * wb_max_nch(KH, P) + 255) / 256;
+    constexpr int NITI = (BNc * (((P >> CL) + (KH == 3 ? 2 : 0)) * ((KH == 3 ? (1 << CL) + 8 : (1 << CL)) >> 3)) + 255) / 256;
     constexpr int KSTEPS = P / 16;
     constexpr int KPW = KSTEPS / WKw;
     static_assert(KPW >= 1, "tile too small for the K split");
@@ -75,13 +81,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WKw, wn = (wave / WKw) % WNw, wm = wave / (WKw * WNw);
     const int j = lane & 31, kg = lane >> 5;
-    const int cl = a.tw_log2, C = 1 << cl, R = P >> cl;
-    const int CP = KH == 3 ? C + 8 : C;              // LDS row pitch of the input tile (elements)
-    const int LR = R + 2 * HALO;
-    const int NCH = (LR * CP) >> 3;                  // 8-element chunks per input channel
-    const int IPITCH = (NCH | 1) << 3;               // channel pitch (elements): 16 B x odd
+    constexpr int cl = CL, C = 1 << cl, R = P >> cl;
+    static_assert(R >= 1, "tile narrower than its width");
+    constexpr int CP = KH == 3 ? C + 8 : C;          // LDS row pitch of the input tile (elements)
+    constexpr int LR = R + 2 * HALO;
+    constexpr int NCH = (LR * CP) >> 3;              // 8-element chunks per input channel
+    constexpr int IPITCH = (NCH | 1) << 3;           // channel pitch (elements): 16 B x odd
     __bf16* s_d = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* s_i = s_d + 3 * BMc * DPITCH;
+    float* raw_d = reinterpret_cast<float*>(s_i + 3 * BNc * IPITCH);     // [BMc][P] fp32 (DMA only)
+    float* raw_i = raw_d + BMc * P;                                       // [BNc][R][CP] fp32: the R new halo rows
 
     const int split = blockIdx.x;
     const int n = split / a.spi;
@@ -91,7 +100,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     const long HWin = (long)a.H * a.W, HWo = (long)a.OH * a.OW;
     const float* in_n = a.in + (long)n * a.in_ns;
     const float* do_n = a.dout + (long)n * a.dout_ns;
-    const int n_iitems = BNc * NCH;
 
     float dsum[NITD];
 #pragma unroll
@@ -103,9 +111,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     // (W % 4 == 0 is required by tdr_wgrad_bx3_supported).  All loads are unconditional (clamped address),
     // validity is applied when the registers are converted.
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    auto d_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live) {
-        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-        const int oy0 = ty * R, ox0 = tx * C;
+    // tile order: row-major for 1x1; column-major (walk down a 32-column strip) for 3x3, so consecutive tiles of a
+    // block share input rows and only the R new halo rows are staged per tile (the LDS tile is a ring of rows)
+    auto tile_origin = [&](int t, int& oy0, int& ox0, int& ty) {
+        int tx;
+        if (KH == 3) { tx = t / a.tiles_y; ty = t - tx * a.tiles_y; }
+        else { ty = t / a.tiles_x; tx = t - ty * a.tiles_x; }
+        oy0 = ty * R;
+        ox0 = tx * C;
+    };
+    auto d_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live, bool from_raw = false) {
+        int oy0, ox0, ty;
+        tile_origin(t, oy0, ox0, ty);
         const int id = tid + 256 * it;
         live = (BMc * DCH % 256 == 0) || id < BMc * DCH;
         const int idc = min(id, BMc * DCH - 1);
@@ -116,8 +133,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         const bool rok = oy < a.OH && co0 + col < a.Cout;
         const float* src = do_n + (long)co * HWo + (long)min(oy, a.OH - 1) * a.OW;
         const bool ok0 = rok && ox < a.OW, ok1 = rok && ox + 4 < a.OW;
-        v0 = *reinterpret_cast<const f32x4*>(src + (ok0 ? ox : 0));
-        v1 = *reinterpret_cast<const f32x4*>(src + (ok1 ? ox + 4 : 0));
+        if (DMA && from_raw) {
+            v0 = *reinterpret_cast<const f32x4*>(raw_d + idc * 8);
+            v1 = *reinterpret_cast<const f32x4*>(raw_d + idc * 8 + 4);
+        } else {
+            v0 = *reinterpret_cast<const f32x4*>(src + (ok0 ? ox : 0));
+            v1 = *reinterpret_cast<const f32x4*>(src + (ok1 ? ox + 4 : 0));
+        }
         v0 = ok0 ? v0 : z4;
         v1 = ok1 ? v1 : z4;
         ldsoff = col * DPITCH + ch * 8;
@@ -132,14 +154,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         dst[(BMc * DPITCH) >> 3] = m;
         dst[(2 * BMc * DPITCH) >> 3] = l;
     };
-    auto i_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live) {
-        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-        const int oy0 = ty * R, ox0 = tx * C;
+    auto i_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live, bool from_raw = false) {
+        int oy0, ox0, ty;
+        tile_origin(t, oy0, ox0, ty);
+        // 3x3: rows 0,1 of the halo tile are the previous tile's rows R, R+1 unless this is the first tile of the
+        // block or of a column
+        const int lr0 = (KH == 3 && t != t_begin && ty != 0) ? 2 : 0;
+        constexpr int CPR = CP >> 3;
+        const int nchr = (LR - lr0) * CPR;
         const int id = tid + 256 * it;
-        live = id < n_iitems;
-        const int idc = min(id, n_iitems - 1);
-        const int cil = idc / NCH, ch = idc - cil * NCH;
-        const int lrow = (ch * 8) / CP, c0 = ch * 8 - lrow * CP;
+        live = id < BNc * nchr;
+        const int idc = min(id, BNc * nchr - 1);
+        const int cil = idc / nchr, rem = idc - cil * nchr;
+        const int lrow = lr0 + rem / CPR, c0 = (rem % CPR) * 8;
+        const int slot = KH == 3 ? (oy0 + lrow) % LR : lrow;
         const int gy = oy0 - a.pad + lrow;
         const int gx0 = KH == 3 ? ox0 + c0 - 4 : ox0 + c0;
         const int ci = min(ci0 + cil, a.Cin - 1);
@@ -147,8 +175,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         const float* src = in_n + (long)ci * HWin + (long)min(max(gy, 0), a.H - 1) * a.W;
         const bool ok0 = rok && gx0 >= 0 && gx0 < a.W, ok1 = rok && gx0 + 4 >= 0 && gx0 + 4 < a.W;
         const int o0 = ok0 ? gx0 : 0, o1 = ok1 ? gx0 + 4 : 0;
-        v0 = *reinterpret_cast<const f32x4*>(src + o0);
-        v1 = *reinterpret_cast<const f32x4*>(src + o1);
+        if (DMA && from_raw) {                       // steady-state tile: items enumerate exactly the raw patch
+            v0 = *reinterpret_cast<const f32x4*>(raw_i + idc * 8);
+            v1 = *reinterpret_cast<const f32x4*>(raw_i + idc * 8 + 4);
+        } else {
+            v0 = *reinterpret_cast<const f32x4*>(src + o0);
+            v1 = *reinterpret_cast<const f32x4*>(src + o1);
+        }
         if (GATE) {
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(src + o0 + a.gate_off);
             const f32x4 g1 = *reinterpret_cast<const f32x4*>(src + o1 + a.gate_off);
@@ -157,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         }
         v0 = ok0 ? v0 : z4;
         v1 = ok1 ? v1 : z4;
-        ldsoff = cil * IPITCH + ch * 8;
+        ldsoff = cil * IPITCH + slot * CP + c0;
     };
     auto i_store = [&](const f32x4& v0, const f32x4& v1, int ldsoff, bool live) {
         if (!live) return;
@@ -188,18 +221,58 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
             for (int it = 0; it < NITI; ++it) i_store(pi0[it], pi1[it], pio[it], pil[it]);
         }
     };
-    auto stage_sync = [&](int t) {      // load + convert + store, item by item (no registers live across the MFMAs)
+    auto stage_sync = [&](int t, bool from_raw = false) {   // load + convert + store, item by item
 #pragma unroll
         for (int it = 0; it < NITD; ++it) {
             f32x4 v0, v1; int o; bool live;
-            d_load(t, it, v0, v1, o, live);
+            d_load(t, it, v0, v1, o, live, from_raw);
             d_store(it, v0, v1, o, live);
         }
 #pragma unroll
         for (int it = 0; it < NITI; ++it) {
             f32x4 v0, v1; int o; bool live;
-            i_load(t, it, v0, v1, o, live);
+            i_load(t, it, v0, v1, o, live, from_raw);
             i_store(v0, v1, o, live);
+        }
+    };
+    // a tile whose rows 0,1 are already in the LDS ring (not the first of the block / of a column)
+    auto steady = [&](int t) {
+        int oy0, ox0, ty;
+        tile_origin(t, oy0, ox0, ty);
+        return KH == 3 && t != t_begin && ty != 0;
+    };
+    // LDS-DMA of the raw fp32 operands of a steady tile: 16-byte pieces, lane-linear destination
+    auto dma_issue = [&](int t) {
+        if constexpr (DMA) {
+            int oy0, ox0, ty;
+            tile_origin(t, oy0, ox0, ty);
+            constexpr int DP = BMc * P / 4;                       // dout pieces
+#pragma unroll
+            for (int k = 0; k < (DP + 255) / 256; ++k) {
+                const int id = tid + 256 * k;
+                if (DP % 256 == 0 || id < DP) {
+                    const int col = id / (P / 4), c4 = id - col * (P / 4);
+                    const int row = (c4 * 4) >> cl, xo = (c4 * 4) & (C - 1);
+                    const int oy = min(oy0 + row, a.OH - 1), ox = ox0 + xo;
+                    const float* g = do_n + (long)min(co0 + col, a.Cout - 1) * HWo + (long)oy * a.OW + (ox < a.OW ? ox : 0);
+                    float* l = raw_d + __builtin_amdgcn_readfirstlane((wave * 64 + 256 * k) * 4);
+                    __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)g,
+                                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+                }
+            }
+            constexpr int CPQ = CP >> 2, per_c = R * CPQ, IP = BNc * per_c;   // input pieces: [ci][R new rows][CP/4]
+            for (int k = 0; k * 256 < IP; ++k) {
+                const int id = tid + 256 * k;
+                if (id < IP) {
+                    const int cil = id / per_c, rem = id - cil * per_c;
+                    const int lrow = 2 + rem / CPQ, q = rem % CPQ;
+                    const int gy = min(max(oy0 - a.pad + lrow, 0), a.H - 1), gx = ox0 - 4 + 4 * q;
+                    const float* g = in_n + (long)min(ci0 + cil, a.Cin - 1) * HWin + (long)gy * a.W + ((gx >= 0 && gx < a.W) ? gx : 0);
+                    float* l = raw_i + __builtin_amdgcn_readfirstlane((wave * 64 + 256 * k) * 4);
+                    __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)g,
+                                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+                }
+            }
         }
     };
 
@@ -218,10 +291,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
 
     if (PRE && t_begin < t_end) prefetch(t_begin);
     for (int t = t_begin; t < t_end; ++t) {
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA pieces have landed
         __syncthreads();
-        if constexpr (PRE) commit(); else stage_sync(t);
+        if constexpr (PRE) commit();
+        else if constexpr (DMA) stage_sync(t, steady(t));
+        else stage_sync(t);
         __syncthreads();
         if (PRE && t + 1 < t_end) prefetch(t + 1);
+        if (DMA && t + 1 < t_end && steady(t + 1)) dma_issue(t + 1);
+        int ring0 = 0;
+        if (KH == 3) { int ox0_, ty_; tile_origin(t, ring0, ox0_, ty_); }
 #pragma unroll(KH == 3 ? 1 : KPW)
         for (int q = 0; q < KPW; ++q) {
             const int u = 2 * (wk * KPW + q) + kg;                       // this lane half's 8-pixel chunk
@@ -253,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
                     u32x4 bf[3][3];                                      // [kx][split]
 #pragma unroll
                     for (int s = 0; s < 3; ++s) {
-                        const u32x4* src = reinterpret_cast<const u32x4*>(s_i + (long)(s * BNc + wn * 32 + j) * IPITCH + (row + ky) * CP + xo);
+                        const u32x4* src = reinterpret_cast<const u32x4*>(s_i + (long)(s * BNc + wn * 32 + j) * IPITCH + ((ring0 + row + ky) % LR) * CP + xo);
                         const u32x4 lo = src[0], hi = src[1];
                         // LDS col c holds input x = ox0 + c - 4; tap kx reads cols xo + kx + 3 ... + 10 (pad = 1):
                         // dwords D0..D6 = lo[0..3], hi[0..2]
@@ -340,15 +419,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         }
 }
 
-template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE>
-int launch_wgb(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
+template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL>
+int launch_wgb_cl(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
     constexpr int BMc = 32 * TMW * WMw, BNc = 32 * TNW * WNw;
-    const int C = 1 << a.tw_log2, R = P / C;
-    const int CP = KH == 3 ? C + 8 : C, LR = KH == 3 ? R + 2 : R;
-    const int ipitch = (((LR * CP) >> 3) | 1) << 3;
-    const size_t lds = (size_t)(3 * BMc * (P + 8) + 3 * BNc * ipitch) * 2;
+    constexpr int C = 1 << CL, R = P / C;
+    constexpr int CP = KH == 3 ? C + 8 : C, LR = KH == 3 ? R + 2 : R;
+    constexpr int ipitch = (((LR * CP) >> 3) | 1) << 3;
+    const size_t lds = (size_t)(3 * BMc * (P + 8) + 3 * BNc * ipitch) * 2 + (DMA ? (size_t)(BMc * P + BNc * R * CP) * 4 : 0);
     dim3 grid(N * p.spi, tdr_cdiv(a.Cout, BMc), tdr_cdiv(a.Cin, BNc));
-    auto kern = wgrad_bx3_kernel<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE>;
+    auto kern = wgrad_bx3_kernel<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, CL>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -357,6 +436,13 @@ int launch_wgb(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     TDR_LAUNCH_CHECK("wgrad_bx3_kernel");
     return TDR_OK;
+}
+
+template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA = false>
+int launch_wgb(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
+    if (a.tw_log2 == 5) return launch_wgb_cl<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, 5>(a, p, N, st);
+    if (a.tw_log2 == 4) return launch_wgb_cl<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, 4>(a, p, N, st);
+    return launch_wgb_cl<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, 3>(a, p, N, st);
 }
 
 }  // namespace
@@ -412,7 +498,7 @@ int tdr_wgrad_bx3_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d
         case 0: return g ? launch_wgb<1, 32, 2, 2, 1, 2, 2, true, true>(a, p, d->N, st) : launch_wgb<1, 32, 2, 2, 1, 2, 2, false, true>(a, p, d->N, st);
         case 1: return g ? launch_wgb<1, 64, 2, 2, 1, 1, 1, true, true>(a, p, d->N, st) : launch_wgb<1, 64, 2, 2, 1, 1, 1, false, true>(a, p, d->N, st);
         case 2: return g ? launch_wgb<1, 128, 1, 1, 4, 1, 1, true, true>(a, p, d->N, st) : launch_wgb<1, 128, 1, 1, 4, 1, 1, false, true>(a, p, d->N, st);
-        case 3: return launch_wgb<3, 32, 2, 2, 1, 1, 1, false, false>(a, p, d->N, st);
+        case 3: return launch_wgb<3, 32, 2, 2, 1, 1, 1, false, false, true>(a, p, d->N, st);
         case 4: return launch_wgb<3, 128, 1, 1, 4, 1, 1, false, false>(a, p, d->N, st);
         default: return g ? launch_wgb<1, 64, 2, 1, 2, 1, 1, true, true>(a, p, d->N, st) : launch_wgb<1, 64, 2, 1, 2, 1, 1, false, true>(a, p, d->N, st);
     }

@@ -7,7 +7,7 @@ struct TdrWgradDesc;
 struct WgArgs {
     const float* in; long in_ns; int Cin, H, W; long gate_off;
     const float* dout; long dout_ns; int Cout, OH, OW;
-    int pad, tw_log2, tiles_x, tpi /*tiles per image*/, tps /*tiles per split*/, spi /*splits per image*/;
+    int pad, tw_log2, tiles_x, tiles_y, tpi /*tiles per image*/, tps /*tiles per split*/, spi /*splits per image*/;
     float* part;
     float* dbpart;      // optional [nsplit][Cout]: per-split sums of dout rows (bias gradient), ci-tile 0 only
 };

@@ -286,7 +286,7 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
     a.gate_off = (long)d->Cin * d->H * d->W;
     a.dout = d->dout; a.dout_ns = d->dout_ns; a.Cout = d->Cout; a.OH = d->OH; a.OW = d->OW;
-    a.pad = d->pad; a.tw_log2 = p.tw_log2; a.tiles_x = p.tiles_x; a.tpi = p.tpi; a.tps = p.tps; a.spi = p.spi;
+    a.pad = d->pad; a.tw_log2 = p.tw_log2; a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.tpi = p.tpi; a.tps = p.tps; a.spi = p.spi;
     a.part = d->ws;
     a.dbpart = d->db ? d->ws + (int64_t)d->N * p.spi * p.WKw * d->Cout * d->Cin * d->KH * d->KH : nullptr;
     hipStream_t st = (hipStream_t)stream;

@@ -180,12 +180,13 @@ class RefGuidedImageCleanModel(BaseModel):
             st['lq'], st['gt'], st['ref'] = self.lq.clone(), self.gt.clone(), self.ref_in.clone()
             torch.cuda.synchronize()
             gA = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gA):
+            # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
+            with torch.cuda.graph(gA, capture_error_mode='thread_local'):
                 st['loss'] = self._fwd_bwd(st['lq'], st['gt'], st['ref'], defer_collectives=True)
             st['pinned'] = self.grad_reducer.pinned_tables      # host blocks the captured table uploads re-read on replay
             self.optimizer_g.prepare()
             gB = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gB, pool=gA.pool()):
+            with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode='thread_local'):
                 self.optimizer_g.launch()
             st['gA'], st['gB'] = gA, gB
             st['output'] = self.output
