@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave index through readfirstlane: everything derived from it (channel rows, LDS bases) is then provably
+    // wave-uniform and its address arithmetic runs on the scalar unit
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int j = lane & 31, kk = lane >> 5;
     const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2, TH = NT * SR;

@@ -1,0 +1,226 @@
+// depthwise 3x3 (+bias) + SimpleGate (+ SCA pool partials), forward and backward
+//   network_nafnet_guided_arch.py:185-187 (conv2, groups = 2c), :170-175 (SimpleGate), :192-196 (pool)
+//
+// HBM-bound stencils.  A thread owns a 4-column strip and walks RPT rows with a 3-row register window: each input
+// row is fetched once as one float4 per plane (consecutive lanes -> consecutive 16-byte pieces of the row), the
+// x-1 / x+4 neighbours come from the adjacent lanes by DPP shuffles (an extra dword load only at wave / row-block
+// edges), the rows above/below are re-used from registers.  No LDS tiles, no barriers in the main loop.
+//   MODE_FWD : g = (dw1(t1)+b1) * (dw2(t2)+b2), pool partial sums
+//   MODE_DU  : u1,u2 recomputed; du1 = dg*u2, du2 = dg*u1 written to scratch; dW / db partial sums (20 per block)
+//   MODE_DT  : dt1 = dw1^T(du1), dt2 = dw2^T(du2)   (the same stencil with flipped taps)
+// The backward is two passes over a 2c-plane scratch tensor (du) instead of one LDS-tiled kernel with halo
+// recomputation: 9c instead of 5c plane passes, but both run at streaming speed and du stays in L2/MALL.
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+namespace {
+
+enum { MODE_FWD = 0, MODE_DU = 1, MODE_DT = 2 };
+
+struct DwArgs {
+    const float* a;      // FWD/DU: t [N][2C][H][W]; DT: du [N][2C][H][W]
+    const float* dg;     // DU: [N][C][H][W]
+    const float* w;      // [2C][9]
+    const float* b;      // [2C]
+    float* out;          // FWD: g [N][C]; DU: du [N][2C]; DT: dt [N][2C]
+    float* part;         // FWD: [N*C][nb]; DU: [N*C][nb][20]
+    int C, H, W, tprw_log2, rpt, ncb;
+};
+
+struct Row6 { float v[6]; };
+
+// one row of the 4-column strip with its two horizontal neighbours; zero outside the image
+__device__ __forceinline__ Row6 fetch_row(const float* __restrict__ plane, int y, int x0, int H, int W, bool active,
+                                          bool left_lane, bool right_lane) {
+    const bool rok = active && y >= 0 && y < H;
+    const float* row = plane + (long)min(max(y, 0), H - 1) * W;
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+    if (rok) m = *reinterpret_cast<const f32x4*>(row + x0);
+    float l = __shfl_up(m[3], 1, 64), r = __shfl_down(m[0], 1, 64);
+    if (!left_lane) l = (rok && x0 > 0) ? row[x0 - 1] : 0.f;
+    if (!right_lane) r = (rok && x0 + 4 < W) ? row[x0 + 4] : 0.f;
+    Row6 o;
+    o.v[0] = l; o.v[1] = m[0]; o.v[2] = m[1]; o.v[3] = m[2]; o.v[4] = m[3]; o.v[5] = r;
+    return o;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
+    __shared__ float red[4][20];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int c = blockIdx.y, n = blockIdx.z, C = a.C, H = a.H, W = a.W;
+    const int TPRW = 1 << a.tprw_log2;
+    const int cg = tid & (TPRW - 1), strip = tid >> a.tprw_log2;
+    const int bx = blockIdx.x % a.ncb, by = blockIdx.x / a.ncb;
+    const int x0 = (bx * TPRW + cg) * 4;
+    const int ybeg = (by * (256 >> a.tprw_log2) + strip) * a.rpt;
+    const bool active = x0 < W && ybeg < H;
+    // the neighbour lane holds the adjacent strip unless this is the first/last lane of the wave or of the row block
+    const bool left_lane = lane != 0 && cg != 0;
+    const bool right_lane = lane != 63 && cg != TPRW - 1;
+    const long HW = (long)H * W;
+    const float* p1 = a.a + ((long)n * 2 * C + c) * HW;
+    const float* p2 = p1 + (long)C * HW;
+    float w1[9], w2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int k = MODE == MODE_DT ? 8 - i : i;           // transposed conv = correlation with flipped taps
+        w1[i] = a.w[c * 9 + k];
+        w2[i] = a.w[(c + C) * 9 + k];
+    }
+    const float b1 = MODE == MODE_DT ? 0.f : a.b[c], b2 = MODE == MODE_DT ? 0.f : a.b[c + C];
+    float acc[MODE == MODE_DU ? 20 : 1];
+#pragma unroll
+    for (int i = 0; i < (MODE == MODE_DU ? 20 : 1); ++i) acc[i] = 0.f;
+
+    Row6 r1[3], r2[3];
+    r1[0] = fetch_row(p1, ybeg - 1, x0, H, W, active, left_lane, right_lane);
+    r2[0] = fetch_row(p2, ybeg - 1, x0, H, W, active, left_lane, right_lane);
+    r1[1] = fetch_row(p1, ybeg, x0, H, W, active, left_lane, right_lane);
+    r2[1] = fetch_row(p2, ybeg, x0, H, W, active, left_lane, right_lane);
+    for (int i = 0; i < a.rpt; ++i) {
+        const int y = ybeg + i;
+        r1[2] = fetch_row(p1, y + 1, x0, H, W, active, left_lane, right_lane);     // uniform trip count: shuffles stay converged
+        r2[2] = fetch_row(p2, y + 1, x0, H, W, active, left_lane, right_lane);
+        const bool live = active && y < H;
+        float o1[4] = {b1, b1, b1, b1}, o2[4] = {b2, b2, b2, b2};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o1[e] += w1[ky * 3 + kx] * r1[ky].v[e + kx];
+                    o2[e] += w2[ky * 3 + kx] * r2[ky].v[e + kx];
+                }
+        if (MODE == MODE_FWD) {
+            const f32x4 o = {o1[0] * o2[0], o1[1] * o2[1], o1[2] * o2[2], o1[3] * o2[3]};
+            if (live) {
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * C + c) * HW + (long)y * W + x0) = o;
+                acc[0] += (o[0] + o[1]) + (o[2] + o[3]);
+            }
+        } else if (MODE == MODE_DU) {
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+            if (live) gv = *reinterpret_cast<const f32x4*>(a.dg + ((long)n * C + c) * HW + (long)y * W + x0);
+            f32x4 d1, d2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d1[e] = gv[e] * o2[e]; d2[e] = gv[e] * o1[e]; }
+            if (live) {
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)y * W + x0) = d1;
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)y * W + x0) = d2;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[ky * 3 + kx] += d1[e] * r1[ky].v[e + kx];
+                        acc[10 + ky * 3 + kx] += d2[e] * r2[ky].v[e + kx];
+                    }
+            acc[9] += (d1[0] + d1[1]) + (d1[2] + d1[3]);
+            acc[19] += (d2[0] + d2[1]) + (d2[2] + d2[3]);
+        } else {
+            if (live) {
+                const f32x4 q1 = {o1[0], o1[1], o1[2], o1[3]}, q2 = {o2[0], o2[1], o2[2], o2[3]};
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)y * W + x0) = q1;
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)y * W + x0) = q2;
+            }
+        }
+        r1[0] = r1[1]; r1[1] = r1[2];
+        r2[0] = r2[1]; r2[1] = r2[2];
+    }
+    if (MODE == MODE_FWD) {
+        const float s = wave_sum(acc[0]);
+        if (lane == 0) red[tid >> 6][0] = s;
+        __syncthreads();
+        if (tid == 0) a.part[((long)n * C + c) * gridDim.x + blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    } else if (MODE == MODE_DU) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            const float s = wave_sum(acc[i]);
+            if (lane == 0) red[tid >> 6][i] = s;
+        }
+        __syncthreads();
+        if (tid < 20)
+            a.part[(((long)n * C + c) * gridDim.x + blockIdx.x) * 20 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+__global__ void dw_pool_finish_kernel(const float* __restrict__ part, int NC, int nb, float inv_hw, float* __restrict__ pooled) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    float s = 0.f;
+    for (int k = 0; k < nb; ++k) s += part[(long)i * nb + k];
+    pooled[i] = s * inv_hw;
+}
+
+// dw[ch][9], db[ch] from part[N][C][nb][20]  (ch < C: first half, ch >= C: second half)
+__global__ void dw_param_finish_kernel(const float* __restrict__ part, int N, int C, int nb, float* __restrict__ dw,
+                                       float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over C*20
+    if (i >= C * 20) return;
+    const int c = i / 20, k = i % 20;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n)
+        for (int g = 0; g < nb; ++g) s += part[(((long)n * C + c) * nb + g) * 20 + k];
+    const int ch = k < 10 ? c : c + C, kk = k % 10;
+    if (kk < 9) dw[ch * 9 + kk] = s; else db[ch] = s;
+}
+
+struct DwGeom { int tprw_log2, rpt, ncb, nby, nb; };
+
+DwGeom dw_geom(int H, int W) {
+    DwGeom g;
+    int groups = W / 4, lg = 0;
+    while ((1 << lg) < groups && lg < 8) ++lg;          // threads per row block: next power of two, at most 256
+    g.tprw_log2 = lg;
+    const int spb = 256 >> lg;                           // strips per block
+    g.ncb = tdr_cdiv(groups, 1 << lg);
+    int rpt = tdr_cdiv(H, spb);                          // rows per thread: up to 8, fewer on small maps (more blocks)
+    if (rpt > 8) rpt = 8;
+    if (rpt < 1) rpt = 1;
+    g.rpt = rpt;
+    g.nby = tdr_cdiv(H, spb * rpt);
+    g.nb = g.ncb * g.nby;
+    return g;
+}
+
+}  // namespace
+
+extern "C" int64_t tdr_dwsg_ws_floats(int N, int C, int H, int W) {
+    const DwGeom g = dw_geom(H, W);
+    return (int64_t)N * C * g.nb * 20 + 4 + (int64_t)N * 2 * C * H * W;  // partial sums + (aligned) du scratch of the backward
+}
+
+extern "C" int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, float* g, float* pooled,
+                            float* ws, void* stream) {
+    TDR_REQUIRE(t && w && b && g && pooled && ws, "tdr_dwsg_fwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0, "tdr_dwsg_fwd: W must be a multiple of 4 (got %d)", W);
+    hipStream_t st = (hipStream_t)stream;
+    const DwGeom q = dw_geom(H, W);
+    DwArgs a{t, nullptr, w, b, g, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL(dwsg_stencil_kernel<MODE_FWD>, dim3(q.nb, C, N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(dw_pool_finish_kernel, dim3(tdr_cdiv(N * C, 256)), dim3(256), 0, st, ws, N * C, q.nb,
+                       1.0f / (float)((long)H * W), pooled);
+    TDR_LAUNCH_CHECK("dwsg_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
+                            float* dt, float* dw, float* db, float* ws, void* stream) {
+    TDR_REQUIRE(dg && t && w && b && dt && dw && db && ws, "tdr_dwsg_bwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0, "tdr_dwsg_bwd: W must be a multiple of 4 (got %d)", W);
+    hipStream_t st = (hipStream_t)stream;
+    const DwGeom q = dw_geom(H, W);
+    float* part = ws;
+    float* du = ws + (int64_t)N * C * q.nb * 20;
+    du += (4 - (reinterpret_cast<uintptr_t>(du) / 4) % 4) % 4;   // 16-byte aligned scratch planes (ws holds one spare vector)
+    DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL(dwsg_stencil_kernel<MODE_DU>, dim3(q.nb, C, N), dim3(256), 0, st, a1);
+    DwArgs a2{du, nullptr, w, b, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL(dwsg_stencil_kernel<MODE_DT>, dim3(q.nb, C, N), dim3(256), 0, st, a2);
+    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, part, N, C, q.nb, dw, db);
+    TDR_LAUNCH_CHECK("dwsg_bwd");
+    return TDR_OK;
+}

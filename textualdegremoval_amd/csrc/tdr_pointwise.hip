@@ -280,175 +280,6 @@ constexpr int LN_BWD_GRID = 256;
 constexpr int LN_GEN_SPLITS = 16;
 
 // ===========================================================================
-// depthwise 3x3 + bias + SimpleGate (+ pool partials)
-//   network_nafnet_guided_arch.py:185-187, 170-175, 192-196
-// block = (band of BR rows, channel c, image n); thread = 4 consecutive x.
-// ===========================================================================
-__device__ __forceinline__ void load_row6(const float* __restrict__ plane, int yy, int H, int x0, int W, float (&r)[6]) {
-    const bool rok = yy >= 0 && yy < H;
-    const float* row = plane + (long)min(max(yy, 0), H - 1) * W;      // clamped: loads unconditional
-    const float4 m = *reinterpret_cast<const float4*>(row + x0);
-    const float l = row[max(x0 - 1, 0)], rr = row[min(x0 + 4, W - 1)];
-    r[0] = (rok && x0 > 0) ? l : 0.f;
-    r[1] = rok ? m.x : 0.f; r[2] = rok ? m.y : 0.f; r[3] = rok ? m.z : 0.f; r[4] = rok ? m.w : 0.f;
-    r[5] = (rok && x0 + 4 < W) ? rr : 0.f;
-}
-
-__global__ __launch_bounds__(256) void dwsg_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w,
-                                                      const float* __restrict__ b, int C, int H, int W, int BR,
-                                                      float* __restrict__ g, float* __restrict__ part) {
-    __shared__ float red[4];
-    const int band = blockIdx.x, c = blockIdx.y, n = blockIdx.z, nb = gridDim.x;
-    const long HW = (long)H * W;
-    const float* t1 = t + ((long)n * 2 * C + c) * HW;
-    const float* t2 = t1 + (long)C * HW;
-    float w1[9], w2[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { w1[i] = w[c * 9 + i]; w2[i] = w[(c + C) * 9 + i]; }
-    const float b1 = b[c], b2 = b[c + C];
-    const int W4 = W >> 2;
-    const int y0 = band * BR, y1 = min(y0 + BR, H);
-    float psum = 0.f;
-    for (int idx = threadIdx.x; idx < (y1 - y0) * W4; idx += 256) {
-        const int y = y0 + idx / W4, x0 = (idx % W4) * 4;
-        float o1[4] = {b1, b1, b1, b1}, o2[4] = {b2, b2, b2, b2};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yy = y + ky - 1;
-            float r1[6], r2[6];
-            load_row6(t1, yy, H, x0, W, r1);
-            load_row6(t2, yy, H, x0, W, r2);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    o1[i] += w1[ky * 3 + kx] * r1[i + kx];
-                    o2[i] += w2[ky * 3 + kx] * r2[i + kx];
-                }
-        }
-        const float4 o = make_float4(o1[0] * o2[0], o1[1] * o2[1], o1[2] * o2[2], o1[3] * o2[3]);
-        *reinterpret_cast<float4*>(g + ((long)n * C + c) * HW + (long)y * W + x0) = o;
-        psum += (o.x + o.y) + (o.z + o.w);
-    }
-    psum = wave_sum(psum);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = psum;
-    __syncthreads();
-    if (threadIdx.x == 0) part[((long)n * C + c) * nb + band] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-__global__ void pool_finish_kernel(const float* __restrict__ part, int NC, int nb, float inv_hw,
-                                   float* __restrict__ pooled) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NC) return;
-    float s = 0.f;
-    for (int k = 0; k < nb; ++k) s += part[(long)i * nb + k];
-    pooled[i] = s * inv_hw;
-}
-
-// backward: LDS tile.  Output tile TBY x 32; du needs a 1-halo, t a 2-halo.
-constexpr int TBX = 32, TBY = 16;
-__global__ __launch_bounds__(256) void dwsg_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ t,
-                                                      const float* __restrict__ w, const float* __restrict__ b, int C,
-                                                      int H, int W, int tiles_x, int tiles_per_group, int ntiles,
-                                                      float* __restrict__ dt, float* __restrict__ part /*[N][C][groups][20]*/) {
-    constexpr int TW2 = TBX + 4, TH2 = TBY + 4;     // t tile (2-halo)
-    constexpr int TW1 = TBX + 2, TH1 = TBY + 2;     // du tile (1-halo)
-    __shared__ float st1[TH2][TW2 + 1], st2[TH2][TW2 + 1];
-    __shared__ float sd1[TH1][TW1 + 1], sd2[TH1][TW1 + 1];
-    __shared__ float red[4][20];
-    const int grp = blockIdx.x, c = blockIdx.y, n = blockIdx.z, ngrp = gridDim.x;
-    const long HW = (long)H * W;
-    const float* t1 = t + ((long)n * 2 * C + c) * HW;
-    const float* t2 = t1 + (long)C * HW;
-    const float* dgp = dg + ((long)n * C + c) * HW;
-    float w1[9], w2[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { w1[i] = w[c * 9 + i]; w2[i] = w[(c + C) * 9 + i]; }
-    const float b1 = b[c], b2 = b[c + C];
-    float acc[20];
-#pragma unroll
-    for (int i = 0; i < 20; ++i) acc[i] = 0.f;
-    const int tl0 = grp * tiles_per_group, tl1 = min(tl0 + tiles_per_group, ntiles);
-    for (int tl = tl0; tl < tl1; ++tl) {
-        const int ty0 = (tl / tiles_x) * TBY, tx0 = (tl % tiles_x) * TBX;
-        __syncthreads();
-        for (int i = threadIdx.x; i < TH2 * TW2; i += 256) {
-            const int r = i / TW2, q = i % TW2;
-            const int y = ty0 + r - 2, x = tx0 + q - 2;
-            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-            const long off = (long)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-            const float v1 = t1[off], v2 = t2[off];
-            st1[r][q] = ok ? v1 : 0.f;
-            st2[r][q] = ok ? v2 : 0.f;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < TH1 * TW1; i += 256) {
-            const int r = i / TW1, q = i % TW1;
-            const int y = ty0 + r - 1, x = tx0 + q - 1;
-            float d1 = 0.f, d2 = 0.f;
-            const float gvl = dgp[(long)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)];
-            if (y >= 0 && y < H && x >= 0 && x < W) {
-                float u1 = b1, u2 = b2;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    u1 += w1[k] * st1[r + k / 3][q + k % 3];
-                    u2 += w2[k] * st2[r + k / 3][q + k % 3];
-                }
-                const float gv = gvl;
-                d1 = gv * u2; d2 = gv * u1;
-                const bool interior = r >= 1 && r <= TBY && q >= 1 && q <= TBX;
-                if (interior) {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        acc[k] += d1 * st1[r + k / 3][q + k % 3];
-                        acc[10 + k] += d2 * st2[r + k / 3][q + k % 3];
-                    }
-                    acc[9] += d1; acc[19] += d2;
-                }
-            }
-            sd1[r][q] = d1; sd2[r][q] = d2;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < TBY * TBX; i += 256) {
-            const int r = i / TBX, q = i % TBX;
-            const int y = ty0 + r, x = tx0 + q;
-            if (y < H && x < W) {
-                float o1 = 0.f, o2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {       // dt[y][x] = sum_k w[k] * du[y - ky + 1][x - kx + 1]
-                    o1 += w1[k] * sd1[r + 2 - k / 3][q + 2 - k % 3];
-                    o2 += w2[k] * sd2[r + 2 - k / 3][q + 2 - k % 3];
-                }
-                dt[((long)n * 2 * C + c) * HW + (long)y * W + x] = o1;
-                dt[((long)n * 2 * C + c + C) * HW + (long)y * W + x] = o2;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 20; ++i) {
-        const float s = wave_sum(acc[i]);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 20)
-        part[(((long)n * C + c) * ngrp + grp) * 20 + threadIdx.x] =
-            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
-// dw[ch][9], db[ch] from part[N][C][groups][20]  (ch<C -> first half, ch>=C -> second)
-__global__ void dwsg_param_finish_kernel(const float* __restrict__ part, int N, int C, int ngrp,
-                                         float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over C*20
-    if (i >= C * 20) return;
-    const int c = i / 20, k = i % 20;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n)
-        for (int g = 0; g < ngrp; ++g) s += part[(((long)n * C + c) * ngrp + g) * 20 + k];
-    const int ch = k < 10 ? c : c + C, kk = k % 10;
-    if (kk < 9) dw[ch * 9 + kk] = s; else db[ch] = s;
-}
-
-// ===========================================================================
 // SCA 1x1 on pooled vectors and the tiny parameter-gradient chains
 // ===========================================================================
 __global__ __launch_bounds__(256) void sca_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ wsca,
@@ -723,51 +554,6 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
     hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 1), dim3(1024), 0, st, ws, 2L * C, nparts, (long)C, gw);
     hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 1), dim3(1024), 0, st, ws + C, 2L * C, nparts, (long)C, gb);
     TDR_LAUNCH_CHECK("ln_bwd");
-    return TDR_OK;
-}
-
-static int dwsg_band_rows(int H, int W) {
-    int br = 4096 / W;           // ~1024 float4 per block
-    if (br < 1) br = 1;
-    if (br > H) br = H;
-    return br;
-}
-static int dwsg_bwd_groups(int H, int W, int* tiles_x, int* ntiles, int* tpg) {
-    *tiles_x = tdr_cdiv(W, 32);
-    *ntiles = *tiles_x * tdr_cdiv(H, 16);
-    *tpg = *ntiles >= 64 ? 8 : (*ntiles >= 8 ? 2 : 1);
-    return tdr_cdiv(*ntiles, *tpg);
-}
-
-extern "C" int64_t tdr_dwsg_ws_floats(int N, int C, int H, int W) {
-    const long fwd = (long)N * C * tdr_cdiv(H, dwsg_band_rows(H, W));
-    int tx, nt, tpg;
-    const long bwd = (long)N * C * dwsg_bwd_groups(H, W, &tx, &nt, &tpg) * 20;
-    return fwd > bwd ? fwd : bwd;
-}
-
-extern "C" int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, float* g,
-                            float* pooled, float* ws, void* stream) {
-    TDR_REQUIRE(t && w && b && g && pooled && ws, "tdr_dwsg_fwd: null pointer");
-    TDR_REQUIRE(W % 4 == 0, "tdr_dwsg_fwd: W must be a multiple of 4 (got %d)", W);
-    hipStream_t st = (hipStream_t)stream;
-    const int BR = dwsg_band_rows(H, W), nb = tdr_cdiv(H, BR);
-    hipLaunchKernelGGL(dwsg_fwd_kernel, dim3(nb, C, N), dim3(256), 0, st, t, w, b, C, H, W, BR, g, ws);
-    hipLaunchKernelGGL(pool_finish_kernel, dim3(tdr_cdiv(N * C, 256)), dim3(256), 0, st, ws, N * C, nb,
-                       1.0f / (float)((long)H * W), pooled);
-    TDR_LAUNCH_CHECK("dwsg_fwd");
-    return TDR_OK;
-}
-
-extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
-                            float* dt, float* dw, float* db, float* ws, void* stream) {
-    TDR_REQUIRE(dg && t && w && b && dt && dw && db && ws, "tdr_dwsg_bwd: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    int tx, nt, tpg;
-    const int ngrp = dwsg_bwd_groups(H, W, &tx, &nt, &tpg);
-    hipLaunchKernelGGL(dwsg_bwd_kernel, dim3(ngrp, C, N), dim3(256), 0, st, dg, t, w, b, C, H, W, tx, tpg, nt, dt, ws);
-    hipLaunchKernelGGL(dwsg_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, ws, N, C, ngrp, dw, db);
-    TDR_LAUNCH_CHECK("dwsg_bwd");
     return TDR_OK;
 }
 

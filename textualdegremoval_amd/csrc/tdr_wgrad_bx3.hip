@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     constexpr int DPITCH = P + 8;                    // bf16 elements; (2P+16)/16 is odd for P = 32, 64, 128
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int wk = wave % WKw, wn = (wave / WKw) % WNw, wm = wave / (WKw * WNw);
     const int j = lane & 31, kg = lane >> 5;
     constexpr int cl = CL, C = 1 << cl, R = P >> cl;
