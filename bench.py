@@ -96,15 +96,16 @@ def main():
     ap.add_argument('--enc', type=str, default='1,1,1,28')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (multi-process smoke test on one GPU)')
     a = ap.parse_args()
     enc = [int(v) for v in a.enc.split(',')]
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        dist.init_process_group(a.backend)
     from textualdegremoval_amd.models import create_model
     from textualdegremoval_amd.utils.synthetic import randomize_gates, synthetic_pair
     from textualdegremoval_amd import kernels as K

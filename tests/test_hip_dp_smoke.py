@@ -1,0 +1,34 @@
+"""GPU smoke test of the multi-process step: two ranks (sharing the one GPU of the test box, gloo transport) run the
+captured-graph train step of bench.py -- exercises what the 8-GPU RCCL run uses except the transport itself:
+process-group + hipGraph capture, deferred flat all-reduce between the two graphs, loss reduce to rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(nproc, port):
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ['-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+                '--master-port', str(port)]
+    cmd += [os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc), '--steps', '2', '--warmup', '1', '--width', '8', '--enc', '1,1,1,1',
+            '--size', '128', '--batch', '1', '--backend', 'gloo', '--no-roofline', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    return json.loads(line)
+
+
+def test_two_rank_graph_step_runs():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    r2 = _bench(2, 29541)
+    assert r2['n_gpus'] == 2 and r2['value'] > 0 and r2['final_loss'] == r2['final_loss']      # finite
+    assert r2['config']['global_batch'] == 2

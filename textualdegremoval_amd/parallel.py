@@ -86,7 +86,10 @@ class GradAllReducer:
                     dst=torch.tensor([self.views[k].data_ptr() for k in ns], dtype=torch.int64).to(device),
                     sizes=torch.tensor([sizes[k] for k in ns], dtype=torch.int64).to(device),
                     ct=torch.tensor(ct, dtype=torch.int32).to(device), ci=torch.tensor(ci, dtype=torch.int32).to(device),
-                    src=torch.empty(len(ns), dtype=torch.int64, device=device)))
+                    src=torch.empty(len(ns), dtype=torch.int64, device=device),
+                    # pinned source-pointer tables, allocated here (never inside a stream capture), used alternately
+                    host=[torch.empty(len(ns), dtype=torch.int64).pin_memory() for _ in range(2)],
+                    done=[None, None], flip=0))
 
     # ---- per step -----------------------------------------------------------
     def begin(self, defer_collectives=False):
@@ -114,9 +117,9 @@ class GradAllReducer:
         suit the point-to-point xGMI links); no-op on one rank."""
         if self.world == 1 or self.flat is None:
             return
-        if self.flat.is_cuda:
+        if self.flat.is_cuda and dist.get_backend(self.pg) == 'nccl':
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg)
-        else:
+        else:                                             # gloo (CPU unit tests, single-GPU multi-process smoke runs)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
             self.flat.div_(self.world)
 
@@ -127,9 +130,18 @@ class GradAllReducer:
         tb = self._btab[bi]
         if not all(k in self._pending for k in tb['names']):
             return
-        host = torch.tensor([self._pending[k].data_ptr() for k in tb['names']], dtype=torch.int64).pin_memory()
+        capturing = torch.cuda.is_current_stream_capturing()
+        slot = tb['flip']
+        tb['flip'] ^= 1
+        if tb['done'][slot] is not None and not capturing:
+            tb['done'][slot].synchronize()                # the upload that last read this table (two steps ago) has run
+        host = tb['host'][slot]
+        host.copy_(torch.tensor([self._pending[k].data_ptr() for k in tb['names']], dtype=torch.int64))
         self.pinned_tables.append(host)
         tb['src'].copy_(host, non_blocking=True)
+        if not capturing:
+            tb['done'][slot] = torch.cuda.Event()
+            tb['done'][slot].record()
         K.multi_copy(tb['src'], tb['dst'], tb['sizes'], tb['ct'], tb['ci'], tb['n_chunks'])
         self._keep = [self._pending.pop(k) for k in tb['names']]   # sources stay referenced until the next gather is enqueued
 
@@ -142,8 +154,12 @@ class GradAllReducer:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            avg = dist.ReduceOp.AVG if dist.get_backend(self.pg) == 'nccl' else dist.ReduceOp.SUM
             with torch.cuda.stream(self._comm_stream):
-                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+                self._works.append(dist.all_reduce(buf, op=avg, group=self.pg, async_op=True))
+                if avg != dist.ReduceOp.AVG:
+                    self._works[-1].wait()
+                    buf.div_(self.world)
         else:
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
