@@ -36,6 +36,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define TDR_PROBE 0
 #endif
 
+#if TDR_PROBE == 5
+// timeline probe: wave 0 of a few blocks stamps s_memtime at the phase boundaries of the main loop
+__device__ unsigned long long tdr_probe_ts[8][64];
+#define TDR_STAMP(slot) do { const int s__ = (slot); if (probe_on && s__ < 64) tdr_probe_ts[probe_blk][s__] = __builtin_readcyclecounter(); } while (0)
+extern "C" int tdr_probe_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tdr_probe_ts), sizeof(tdr_probe_ts));
+}
+#else
+#define TDR_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int bx_cmax(int a, int b) { return a > b ? a : b; }
@@ -193,12 +204,21 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             for (int s = 0; s < 3; ++s) dst[tm][s].u = wfrag[tm][gt * wstep + s * 64];
     };
 
+#if TDR_PROBE == 5
+    const int probe_blk = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : 7));
+    const bool probe_on = tid == 0 && blockIdx.z == 0 && probe_blk < 7;
+    int probe_slot = 0;
+#endif
+    TDR_STAMP(probe_slot++);                      // 0: kernel start (after geometry)
     load_a(af, 0);
 #pragma unroll
     for (int p = 0; p < PF; ++p)
         if (p < ngroups) load_group(p, p);
+    TDR_STAMP(probe_slot++);                      // 1: prologue loads issued
     store_group(0, 0, 0);
+    TDR_STAMP(probe_slot++);                      // 2: group 0 converted + stored (includes the load wait)
     __syncthreads();
+    TDR_STAMP(probe_slot++);                      // 3: first barrier passed
 
     for (int g0 = 0; g0 < ngroups; g0 += PF) {
 #pragma unroll
@@ -242,18 +262,23 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
                         for (int s = 0; s < 3; ++s) af[tm][s] = afn[tm][s];
                 }
+                TDR_STAMP(probe_slot++);                  // 4+3g: MFMA phase of group g issued
                 if (TDR_PROBE != 4) {
                     if (g + 1 < ngroups) store_group(g + 1, (u + 1) % PF, buf ^ 1);
+                    TDR_STAMP(probe_slot++);              // 5+3g: next group converted + stored
                     __syncthreads();
+                    TDR_STAMP(probe_slot++);              // 6+3g: barrier passed
                 }
             }
         }
     }
 
+    TDR_STAMP(probe_slot++);                      // main loop done
     if constexpr (EPI != EPI_PSHUF) {
         if (a.vec_epi) {
             __syncthreads();                              // every wave is done with the operand tiles
             conv_epilogue_vec<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, lane, reinterpret_cast<float*>(smem4) + wave * (32 * 36));
+            TDR_STAMP(probe_slot++);              // epilogue stores issued
             return;
         }
     }
