@@ -58,7 +58,7 @@ typedef struct TdrConvDesc {
     const float* res;   int64_t res_ns;
     const float* mask;  int64_t mask_ns;
     const float* aux;   int64_t aux_ns;
-    int relu;
+    int relu;                    /* 0 none, 1 ReLU, 2 exact (erf) GELU */
 } TdrConvDesc;
 
 int tdr_conv_forward(const TdrConvDesc* d, void* stream);
@@ -218,6 +218,29 @@ int tdr_transfer_bwd(const float* dout, int64_t dout_ns, const float* feat, int 
 /* scatter-add of the ref-block gradient back into the deepest ref feature (wrap-aware) */
 int tdr_scatter_ref_block(const float* dblk, int N, int C, int H, int W, const int* y1, const int* x1, int P,
                           int side, float* dfeat, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Frozen ViT window matcher (DINOv2 ViT-B/14, forward only): models/image_restoration_ref_model.py:215-247,
+ * models/dino/.  Activations are channel-major [B][D][T]: every Linear is tdr_conv_forward (1x1), the token
+ * LayerNorm is tdr_layernorm2d_fwd (eps 1e-6), the MLP GELU is the relu=2 epilogue.
+ * ------------------------------------------------------------------------- */
+/* F.interpolate(bilinear, align_corners=False) of `planes` = B*C planes */
+int tdr_resize_bilinear(const float* src, int planes, int Hs, int Ws, float* dst, int Hd, int Wd, void* stream);
+/* F.unfold(ref,(h,h),stride) -> [B*N][C][h][h], window n = wy*nx + wx (:220-224) */
+int tdr_unfold_windows(const float* ref, int B, int C, int Hr, int Wr, int h, int stride, float* out, void* stream);
+/* Token tensors use a padded row length LD (multiple of 32, >= 1+T): column 0 class token, 1..T patches, rest padding,
+ * so the 1x1-conv kernels see [B][D][LD] as an [LD/32] x 32 image.
+ * p x p stride-p patch gather: x [B][Ci][H][W] -> [B][Ci*p*p][LD], patch t at column 1+t (patch_embed.py:26-80) */
+int tdr_patchify(const float* x, int B, int Ci, int H, int W, int p, int LD, float* out, void* stream);
+/* in place: column 0 = cls + pos[:,0], columns 1..T += pos, padding = 0 (pos channel-major [D][1+T]; vision_transformers.py:209-221) */
+int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int D, int T, int LD, void* stream);
+/* multi-head softmax(q k^T scale) v over the first T columns; qkv [B][3C][LD] -> out [B][C][LD] (padding columns zeroed);
+ * head dim C/heads in {16,32,64} (attention.py:56-71) */
+int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream);
+/* cosine similarity of flattened patch-token maps (columns 1..T1-1), first arg-max, window gather:
+ * fl [B][D][LD], fr [B*N][D][LD], windows [B*N][per] -> corr [B][N], index [B] (int32), ref_in [B][per] (:230-243) */
+int tdr_token_match(const float* fl, const float* fr, const float* windows, int B, int N, int D, int T1, int LD, int64_t per,
+                    float* corr, int* index, float* ref_in, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Optimiser: global-norm clip (max_norm 0.01) + AdamW, multi-tensor

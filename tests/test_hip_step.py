@@ -78,3 +78,31 @@ def test_checkpoint_round_trip(tmp_path):
     model2.net_g.load_state_dict(ck['params']); model2.optimize_parameters(2)
     a = model.get_current_log()['l_pix']; b = model2.get_current_log()['l_pix']
     assert abs(a - b) < 1e-7
+
+
+def test_step_with_dino_window_match(tmp_path):
+    """ref larger than lq: the frozen ViT matcher (path.pretrain_dino) picks the window; ref_in must equal the oracle's."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.nn.functional as F
+    from oracle import dino_oracle as D
+    from textualdegremoval_amd.models import create_model
+    sd = D.synth_vit_params(192, 1, 12, seed=21)                      # 12 heads like ViT-B (head dim 16), one block
+    ck = os.path.join(str(tmp_path), 'dino.pth')
+    torch.save(sd, ck)
+    opt = make_opt()
+    opt['path'] = {'pretrain_dino': ck}
+    model = create_model(opt)
+    g = torch.Generator().manual_seed(5)
+    clean = F.interpolate(torch.rand(1, 3, 16, 16, generator=g), size=(256, 256), mode='bicubic').clamp(0, 1)
+    gt = clean[:, :, 64:192, 32:160].contiguous()                      # window (row 2, col 1) of the stride-32 grid
+    lq = gt + torch.randn(1, 3, 128, 128, generator=g) * (15 / 255)
+    o_ref_in, o_idx, o_corr = D.match_reference_window(sd, lq, clean, heads=12)
+    for it in (1, 2, 3, 4):                                            # eager, eager, capture, replay
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.feed_train_data({'lq': lq, 'gt': gt, 'ref': clean})
+        model.optimize_parameters(it)
+        assert int(model.match_index[0]) == int(o_idx[0]) == 2 * 5 + 1
+        assert torch.equal(model.ref_in.cpu(), o_ref_in)
+        assert (model.match_corr.cpu() - o_corr).abs().max().item() < 1e-5
+    assert np.isfinite(model.get_current_log()['l_pix'])

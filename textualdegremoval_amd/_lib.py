@@ -108,6 +108,12 @@ SIGNATURES = {
     'tdr_transfer_ws_floats': (i64, [i32, i32, i32, i32, i32, i32]),
     'tdr_transfer_bwd': (i32, [c_fp, i64, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32,
                                c_fp, c_fp, c_fp, c_fp]),
+    'tdr_resize_bilinear': (i32, [c_fp, i32, i32, i32, c_fp, i32, i32, c_fp]),
+    'tdr_unfold_windows': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_patchify': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_vit_assemble': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
+    'tdr_attention_fwd': (i32, [c_fp, i32, i32, i32, i32, i32, f32, c_fp, c_fp]),
+    'tdr_token_match': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i64, c_fp, c_fp, c_fp, c_fp]),
     'tdr_optim_chunk': (i32, []),
     'tdr_multi_copy': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp]),
     'tdr_grad_sumsq': (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp]),

@@ -122,9 +122,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] += tv[r];
                 }
-                if (a.relu) {
+                if (a.relu == 1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (a.relu == 2) {               // exact (erf) GELU: ViT MLP
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));
                 }
                 if (a.mask) {
                     float tv[16];
@@ -216,9 +219,12 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& a, f32x16 (&ac
                     if (a.scale) x *= a.scale[(long)n * a.scale_ns + mc];
                     if (a.bias2) x += a.bias2_mul * a.bias2[(long)n * a.bias2_ns + mc];
                     if (a.res) x += rv[i];
-                    if (a.relu) {
+                    if (a.relu == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+                    } else if (a.relu == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = 0.5f * x[e] * (1.f + erff(x[e] * 0.70710678118654752f));
                     }
                     if (a.mask) {
 #pragma unroll

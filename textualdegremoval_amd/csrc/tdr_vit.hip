@@ -1,0 +1,273 @@
+// Frozen ViT window matcher (DINOv2 ViT-B/14) -- forward-only pieces that are not convolutions.
+//   models/image_restoration_ref_model.py:215-247   window unfold, bilinear resize, token cosine, top-1 gather
+//   models/dino/patch_embed.py:26-80                14x14 stride-14 projection  (patch gather here + 1x1 conv kernel)
+//   models/dino/vision_transformers.py:209-236      cls token + position embedding
+//   models/dino/attention.py:36-71                  softmax(q k^T * d^-1/2) v, all heads
+// Activations are channel-major [B][D][T] so every Linear of the ViT is a 1x1 convolution on the matrix-core
+// kernels and the token LayerNorm is the channel LayerNorm kernel (eps 1e-6 in both networks).
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+namespace {
+
+// F.interpolate(mode='bilinear', align_corners=False): src = (dst + 0.5) * (in/out) - 0.5, clamped at 0
+__global__ void resize_bilinear_kernel(const float* __restrict__ src, int Hs, int Ws, float* __restrict__ dst, int Hd, int Wd,
+                                       long planes) {
+    const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+    const long total = planes * Hd * Wd;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wd);
+        const int y = (int)((i / Wd) % Hd);
+        const long pl = i / ((long)Wd * Hd);
+        const float fy = fmaxf(((float)y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)x + 0.5f) * sx - 0.5f, 0.f);
+        const int y0 = min((int)fy, Hs - 1), x0 = min((int)fx, Ws - 1);
+        const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p = src + pl * Hs * Ws;
+        const float top = p[y0 * Ws + x0] * (1.f - lx) + p[y0 * Ws + x1] * lx;
+        const float bot = p[y1 * Ws + x0] * (1.f - lx) + p[y1 * Ws + x1] * lx;
+        dst[i] = top * (1.f - ly) + bot * ly;
+    }
+}
+
+// F.unfold(ref, (h,h), stride) -> windows [B*N][C][h][h], n = wy*nx + wx
+__global__ void unfold_windows_kernel(const float* __restrict__ ref, int C, int Hr, int Wr, int h, int stride, int nx, int N,
+                                      long total, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % h);
+        long r = i / h;
+        const int y = (int)(r % h); r /= h;
+        const int c = (int)(r % C); r /= C;
+        const int n = (int)(r % N);
+        const long b = r / N;
+        const int wy = n / nx, wx = n % nx;
+        out[i] = ref[((b * C + c) * Hr + wy * stride + y) * Wr + wx * stride + x];
+    }
+}
+
+// Token tensors are stored with a padded row length LD (a multiple of 32, >= 1+T) so that the 1x1-conv kernels can
+// treat [B][D][LD] as a [LD/32] x 32 image; column 0 is the class token, columns 1..T the patches, the rest padding.
+// x [B][Ci][H][W] -> out [B][Ci*p*p][LD]: row k = c*p*p + ky*p + kx, patch t = ty*cols + tx at column 1+t, zeros elsewhere
+__global__ void patchify_kernel(const float* __restrict__ x, int Ci, int H, int W, int p, int cols, int T, int LD, long total,
+                                float* __restrict__ out) {
+    const int K = Ci * p * p;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % LD);
+        long r = i / LD;
+        const int k = (int)(r % K);
+        const long b = r / K;
+        float v = 0.f;
+        if (col >= 1 && col <= T) {
+            const int t = col - 1;
+            const int c = k / (p * p), ky = (k / p) % p, kx = k % p;
+            const int ty = t / cols, tx = t % cols;
+            v = x[((b * Ci + c) * H + ty * p + ky) * W + tx * p + kx];
+        }
+        out[i] = v;
+    }
+}
+
+// in place on tok [B][D][LD]: column 0 = cls + pos[:,0]; columns 1..T += pos; padding columns = 0   (pos is [D][1+T])
+__global__ void vit_assemble_kernel(float* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ pos,
+                                    int D, int T, int LD, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % LD);
+        const int d = (int)((i / LD) % D);
+        float v = 0.f;
+        if (col == 0) v = cls[d] + pos[(long)d * (T + 1)];
+        else if (col <= T) v = tok[i] + pos[(long)d * (T + 1) + col];
+        tok[i] = v;
+    }
+}
+
+// softmax(q k^T * scale) v for one (image, head, 32-query tile) per wave, exact fp32 MFMA (32x32x2), online softmax.
+// qkv [B][3C][T] channel-major: q rows h*HD.., k rows C + h*HD.., v rows 2C + h*HD..;  out [B][C][T].
+template <int HD>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ qkv, int C, int T, int LD, float scale,
+                                                     float* __restrict__ out) {
+    constexpr int NDT = (HD + 31) / 32;
+    __shared__ float sK[HD][33], sV[HD][33], sP[32][33];
+    const int lane = threadIdx.x, j = lane & 31, kk = lane >> 5;
+    const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const float* Q = qkv + ((long)b * 3 * C + h * HD) * LD;
+    const float* Kp = Q + (long)C * LD;
+    const float* Vp = Kp + (long)C * LD;
+    float qa[HD / 2];
+#pragma unroll
+    for (int s = 0; s < HD / 2; ++s) qa[s] = (q0 + j < T) ? Q[(long)(2 * s + kk) * LD + q0 + j] * scale : 0.f;
+    f32x16 o[NDT];
+    float mrow[16], lrow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mrow[r] = -1e30f; lrow[r] = 0.f; }
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+    for (int key0 = 0; key0 < T; key0 += 32) {
+        const bool kok = key0 + j < T;
+        const int kc = kok ? key0 + j : T - 1;
+#pragma unroll
+        for (int r = 0; r < HD / 2; ++r) {
+            const int d = 2 * r + kk;
+            const float kv = Kp[(long)d * LD + kc], vv = Vp[(long)d * LD + kc];
+            sK[d][j] = kok ? kv : 0.f;
+            sV[d][j] = kok ? vv : 0.f;
+        }
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < HD / 2; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], sK[2 * s + kk][j], sc, 0, 0, 0);
+        float alpha[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = kok ? sc[r] : -1e30f;
+            float mx = v;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            const float mnew = fmaxf(mrow[r], mx);
+            const float p = kok ? expf(v - mnew) : 0.f;
+            float sum = p;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            alpha[r] = expf(mrow[r] - mnew);
+            lrow[r] = lrow[r] * alpha[r] + sum;
+            mrow[r] = mnew;
+            sP[(r & 3) + 8 * (r >> 2) + 4 * kk][j] = p;
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha[r];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int d = dt * 32 + j;
+                const float bv = d < HD ? sV[d < HD ? d : 0][2 * s + kk] : 0.f;
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[j][2 * s + kk], bv, o[dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+        const int d = dt * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (d < HD && q < LD) out[((long)b * C + h * HD + d) * LD + q] = q < T ? o[dt][r] / lrow[r] : 0.f;
+        }
+    }
+}
+
+// corr[b][n] = <L_b, R_{b,n}> / (max(|L_b|,1e-12) max(|R_{b,n}|,1e-12)) over the patch tokens (columns 1..T of [D][1+T])
+__global__ __launch_bounds__(256) void token_corr_kernel(const float* __restrict__ fl, const float* __restrict__ fr, int D, int T1,
+                                                        int LD, int N, float* __restrict__ corr) {
+    __shared__ float red[3][4];
+    const int n = blockIdx.x, b = blockIdx.y;
+    const float* L = fl + (long)b * D * LD;
+    const float* R = fr + ((long)b * N + n) * D * LD;
+    float dot = 0.f, nl = 0.f, nr = 0.f;
+    const long tot = (long)D * LD;
+    for (long i = threadIdx.x; i < tot; i += 256) {
+        const int col = (int)(i % LD);
+        if (col == 0 || col >= T1) continue;         // class token column, padding
+        const float a = L[i], c = R[i];
+        dot += a * c; nl += a * a; nr += c * c;
+    }
+    dot = wave_sum(dot); nl = wave_sum(nl); nr = wave_sum(nr);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dot; red[1][threadIdx.x >> 6] = nl; red[2][threadIdx.x >> 6] = nr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float d = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float a = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const float c = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        corr[(long)b * N + n] = d / (fmaxf(sqrtf(a), 1e-12f) * fmaxf(sqrtf(c), 1e-12f));
+    }
+}
+
+// index[b] = argmax_n corr[b][n] (first maximum, like torch.topk); out[b] = windows[b][index[b]]
+__global__ __launch_bounds__(256) void select_window_kernel(const float* __restrict__ corr, const float* __restrict__ win, int N,
+                                                           long per, int* __restrict__ index, float* __restrict__ out) {
+    __shared__ int sbest;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        int best = 0;
+        float bv = corr[(long)b * N];
+        for (int n = 1; n < N; ++n) {
+            const float v = corr[(long)b * N + n];
+            if (v > bv) { bv = v; best = n; }
+        }
+        sbest = best;
+        if (blockIdx.x == 0) index[b] = best;
+    }
+    __syncthreads();
+    const float* src = win + ((long)b * N + sbest) * per;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += (long)gridDim.x * 256) out[(long)b * per + i] = src[i];
+}
+
+inline int vgrid(long total, int cap = 16384) {
+    long b = (total + 255) / 256;
+    return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+}  // namespace
+
+extern "C" int tdr_resize_bilinear(const float* src, int planes, int Hs, int Ws, float* dst, int Hd, int Wd, void* stream) {
+    TDR_REQUIRE(src && dst && planes > 0, "tdr_resize_bilinear: bad argument");
+    const long total = (long)planes * Hd * Wd;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(vgrid(total)), dim3(256), 0, (hipStream_t)stream, src, Hs, Ws, dst, Hd, Wd,
+                       (long)planes);
+    TDR_LAUNCH_CHECK("resize_bilinear");
+    return TDR_OK;
+}
+
+extern "C" int tdr_unfold_windows(const float* ref, int B, int C, int Hr, int Wr, int h, int stride, float* out, void* stream) {
+    TDR_REQUIRE(ref && out && h <= Hr && h <= Wr && stride > 0, "tdr_unfold_windows: bad argument");
+    const int ny = (Hr - h) / stride + 1, nx = (Wr - h) / stride + 1;
+    const long total = (long)B * ny * nx * C * h * h;
+    hipLaunchKernelGGL(unfold_windows_kernel, dim3(vgrid(total)), dim3(256), 0, (hipStream_t)stream, ref, C, Hr, Wr, h, stride, nx,
+                       ny * nx, total, out);
+    TDR_LAUNCH_CHECK("unfold_windows");
+    return TDR_OK;
+}
+
+extern "C" int tdr_patchify(const float* x, int B, int Ci, int H, int W, int p, int LD, float* out, void* stream) {
+    TDR_REQUIRE(x && out && H % p == 0 && W % p == 0, "tdr_patchify: H, W must be multiples of the patch size");
+    const int cols = W / p, T = (H / p) * cols;
+    TDR_REQUIRE(LD >= T + 1, "tdr_patchify: LD %d < 1 + T", LD);
+    const long total = (long)B * Ci * p * p * LD;
+    hipLaunchKernelGGL(patchify_kernel, dim3(vgrid(total)), dim3(256), 0, (hipStream_t)stream, x, Ci, H, W, p, cols, T, LD, total, out);
+    TDR_LAUNCH_CHECK("patchify");
+    return TDR_OK;
+}
+
+extern "C" int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int D, int T, int LD, void* stream) {
+    TDR_REQUIRE(tok && cls && pos && LD >= T + 1, "tdr_vit_assemble: bad argument");
+    const long total = (long)B * D * LD;
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(vgrid(total)), dim3(256), 0, (hipStream_t)stream, tok, cls, pos, D, T, LD, total);
+    TDR_LAUNCH_CHECK("vit_assemble");
+    return TDR_OK;
+}
+
+extern "C" int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream) {
+    TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T, "tdr_attention_fwd: bad argument");
+    const int hd = C / heads;
+    dim3 grid(tdr_cdiv(LD, 32), heads, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(64), 0, st, qkv, C, T, LD, scale, out);
+    else if (hd == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(64), 0, st, qkv, C, T, LD, scale, out);
+    else if (hd == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(64), 0, st, qkv, C, T, LD, scale, out);
+    else { tdr_set_error("tdr_attention_fwd: head dim %d not supported (16, 32, 64)", hd); return TDR_ERR_UNSUPPORTED; }
+    TDR_LAUNCH_CHECK("attention_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_token_match(const float* fl, const float* fr, const float* windows, int B, int N, int D, int T1, int LD, int64_t per,
+                               float* corr, int* index, float* ref_in, void* stream) {
+    TDR_REQUIRE(fl && fr && windows && corr && index && ref_in && N > 0, "tdr_token_match: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(token_corr_kernel, dim3(N, B), dim3(256), 0, st, fl, fr, D, T1, LD, N, corr);
+    hipLaunchKernelGGL(select_window_kernel, dim3(vgrid(per, 256), B), dim3(256), 0, st, corr, windows, N, (long)per, index, ref_in);
+    TDR_LAUNCH_CHECK("token_match");
+    return TDR_OK;
+}

@@ -1,0 +1,108 @@
+"""Frozen DINOv2 ViT window matcher on the HIP kernels (forward only, no-grad).
+
+Replaces `self.net_ext` of the reference step (models/image_restoration_ref_model.py:74-90, 215-247; network:
+models/dino/vision_transformers.py `vit_base(img_size=518, patch_size=14, init_values=1.0, ffn_layer='mlp')`).
+Takes the reference's state dict (same key names, strict) and keeps every Linear as a packed 1x1 convolution over
+channel-major activations [B, D, 1, T]; LayerNorm is the channel LayerNorm kernel (both use eps 1e-6).
+Only the parameter pre-processing (bicubic interpolation of the position embedding to the patch grid of a given
+input size, once per size, as vision_transformers.py:179-207 does it) runs in torch on the host.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import kernels as K
+from .kernels import PACK_FWD
+
+LN_EPS = 1e-6
+
+
+class DinoMatcher:
+    def __init__(self, state_dict, device, patch=14, heads=12, interpolate_offset=0.1):
+        sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
+        need = ['cls_token', 'pos_embed', 'patch_embed.proj.weight', 'patch_embed.proj.bias', 'norm.weight', 'norm.bias']
+        miss = [k for k in need if k not in sd]
+        if miss:
+            raise KeyError(f'DINOv2 state dict is missing {miss}')
+        self.device, self.patch, self.heads, self.offset = device, patch, heads, interpolate_offset
+        self.D = sd['cls_token'].shape[-1]
+        self.depth = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('blocks.'))
+        self.pos_embed = sd['pos_embed']                                 # host copy, interpolated per input size
+        self._pos_cache = {}
+        dev = lambda t: t.to(device).contiguous()
+        self.cls = dev(sd['cls_token'].reshape(-1))
+        self.P = {k: dev(v) for k, v in sd.items() if k not in ('pos_embed', 'mask_token')}
+        # frozen weights: packed once (the split-bf16 / fp32 layout follows kernels.MATH at construction time)
+        self.W = {}
+        pw = sd['patch_embed.proj.weight']
+        self._pack('patch', pw.reshape(pw.shape[0], -1, 1, 1))
+        for i in range(self.depth):
+            p = f'blocks.{i}.'
+            for name in ('attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2'):
+                w = sd[p + name + '.weight']
+                self._pack(p + name, w.reshape(w.shape[0], w.shape[1], 1, 1))
+
+    def _pack(self, key, w4):
+        prev = K.set_pack_plan(None)                      # persistent buffers, not a per-step plan
+        try:
+            wp, mp, *_ = K.pack_weights(w4.to(self.device).contiguous(), PACK_FWD)
+        finally:
+            K.set_pack_plan(prev)
+        self.W[key] = (wp, mp, w4.shape[0])
+
+    def _pos(self, rows, cols):
+        """channel-major [D, 1+T] position embedding for a rows x cols patch grid (vision_transformers.py:179-207)."""
+        key = (rows, cols)
+        if key not in self._pos_cache:
+            pe = self.pos_embed
+            n = pe.shape[1] - 1
+            if not (rows * cols == n and rows == cols):
+                side = int(math.sqrt(n))
+                grid = pe[:, 1:].reshape(1, side, side, self.D).permute(0, 3, 1, 2)
+                sr, sc = float(rows + self.offset) / math.sqrt(n), float(cols + self.offset) / math.sqrt(n)
+                grid = F.interpolate(grid, scale_factor=(sr, sc), mode='bicubic')
+                assert grid.shape[-2] == rows and grid.shape[-1] == cols
+                pe = torch.cat((pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, self.D)), dim=1)
+            self._pos_cache[key] = pe[0].t().contiguous().to(self.device)
+        return self._pos_cache[key]
+
+    def _linear(self, x, key, bias, **kw):
+        wp, mp, cout = self.W[key]
+        return K.conv_forward(x, wp, mp, cout, 1, bias=bias, **kw)
+
+    def tokens(self, x):
+        """x [B,3,H,W] (multiples of the patch size) -> (final-norm tokens [B, D, LD/32, 32], T): flat column 0 is the
+        class token, columns 1..T the patch tokens, the rest padding (kernels.token_ld)."""
+        B, _, H, W = x.shape
+        P, D = self.P, self.D
+        rows, cols = H // self.patch, W // self.patch
+        xp, T = K.patchify(x.contiguous(), self.patch)
+        t = K.vit_assemble_(self._linear(xp, 'patch', P['patch_embed.proj.bias']), self.cls, self._pos(rows, cols), T)
+        scale = (D // self.heads) ** -0.5
+        for i in range(self.depth):
+            p = f'blocks.{i}.'
+            h, _, _ = K.layernorm2d_fwd(t, P[p + 'norm1.weight'], P[p + 'norm1.bias'], LN_EPS)
+            qkv = self._linear(h, p + 'attn.qkv', P[p + 'attn.qkv.bias'])
+            a = K.attention_fwd(qkv, self.heads, scale, T + 1)
+            t = self._linear(a, p + 'attn.proj', P[p + 'attn.proj.bias'], scale=P[p + 'ls1.gamma'], res=t)
+            h, _, _ = K.layernorm2d_fwd(t, P[p + 'norm2.weight'], P[p + 'norm2.bias'], LN_EPS)
+            h = self._linear(h, p + 'mlp.fc1', P[p + 'mlp.fc1.bias'], relu=2)
+            t = self._linear(h, p + 'mlp.fc2', P[p + 'mlp.fc2.bias'], scale=P[p + 'ls2.gamma'], res=t)
+        t, _, _ = K.layernorm2d_fwd(t, P['norm.weight'], P['norm.bias'], LN_EPS)
+        return t, T
+
+    @torch.no_grad()
+    def match(self, lq, ref):
+        """the lq-sized window of `ref` whose token map is most similar to lq's (:215-247).
+        Returns (ref_in [B,C,h,w], index [B] int32, corr [B,N])."""
+        B, Cc, h, w = lq.shape
+        if h != w:
+            raise NotImplementedError('the reference unfolds square (h, h) windows; lq must be square')
+        stride = int(h // 4)
+        windows, N = K.unfold_windows(ref.contiguous(), h, stride)
+        Hd, Wd = int(math.ceil(h / self.patch) * self.patch), int(math.ceil(w / self.patch) * self.patch)
+        fl, T = self.tokens(K.resize_bilinear(lq.contiguous(), Hd, Wd))
+        fr, _ = self.tokens(K.resize_bilinear(windows, Hd, Wd))
+        corr, index, ref_in = K.token_match(fl, fr, windows, N, T + 1)
+        return ref_in, index, corr

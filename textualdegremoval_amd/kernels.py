@@ -239,7 +239,7 @@ def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None
     d.res, d.res_ns = _p(res), (_dense_nchw(res) if res is not None else 0)
     d.mask, d.mask_ns = _p(mask), (_dense_nchw(mask) if mask is not None else 0)
     d.aux, d.aux_ns = _p(aux), (_dense_nchw(aux) if aux is not None else 0)
-    d.relu = 1 if relu else 0
+    d.relu = int(relu) if not isinstance(relu, bool) else (1 if relu else 0)      # 2 = exact GELU
     check(lib.tdr_conv_forward(C.byref(d), _stream()), 'tdr_conv_forward')
     return out
 
@@ -536,3 +536,68 @@ def transfer_bwd(dout, feat, y1, x1, index_all, soft_att, py, px, K, side, s, df
     check(_lib.load().tdr_transfer_bwd(dout.data_ptr(), _dense_nchw(dout), feat.data_ptr(), N, Cc, H, W, y1.data_ptr(),
                                        x1.data_ptr(), index_all.data_ptr(), soft_att.data_ptr(), py, px, K, side, s,
                                        dfeat.data_ptr(), datt.data_ptr(), ws.data_ptr(), _stream()), 'tdr_transfer_bwd')
+
+
+# ------------------------------------------------------------------ frozen ViT window matcher (DINOv2)
+def resize_bilinear(x, Hd, Wd):
+    B, Cc, Hs, Ws = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(B, Cc, Hd, Wd, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_resize_bilinear(x.data_ptr(), B * Cc, Hs, Ws, out.data_ptr(), Hd, Wd, _stream()), 'tdr_resize_bilinear')
+    return out
+
+
+def unfold_windows(ref, h, stride):
+    B, Cc, Hr, Wr = ref.shape
+    assert ref.is_contiguous()
+    N = ((Hr - h) // stride + 1) * ((Wr - h) // stride + 1)
+    out = torch.empty(B * N, Cc, h, h, dtype=torch.float32, device=ref.device)
+    check(_lib.load().tdr_unfold_windows(ref.data_ptr(), B, Cc, Hr, Wr, h, stride, out.data_ptr(), _stream()), 'tdr_unfold_windows')
+    return out, N
+
+
+def token_ld(T):
+    """padded token-row length: class token + T patches, rounded up to a multiple of 32"""
+    return (T + 1 + 31) // 32 * 32
+
+
+def patchify(x, p):
+    """-> [B, Ci*p*p, LD/32, 32] with patch t at flat column 1+t (zeros at column 0 and in the padding)"""
+    B, Ci, H, W = x.shape
+    assert x.is_contiguous()
+    T = (H // p) * (W // p)
+    LD = token_ld(T)
+    out = torch.empty(B, Ci * p * p, LD // 32, 32, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_patchify(x.data_ptr(), B, Ci, H, W, p, LD, out.data_ptr(), _stream()), 'tdr_patchify')
+    return out, T
+
+
+def vit_assemble_(tok, cls, pos_cm, T):
+    B, D = tok.shape[0], tok.shape[1]
+    LD = tok.shape[2] * tok.shape[3]
+    check(_lib.load().tdr_vit_assemble(tok.data_ptr(), cls.data_ptr(), pos_cm.data_ptr(), B, D, T, LD, _stream()), 'tdr_vit_assemble')
+    return tok
+
+
+def attention_fwd(qkv, heads, scale, T1):
+    """qkv [B, 3C, LD/32, 32]; attends over the first T1 columns"""
+    B, C3 = qkv.shape[0], qkv.shape[1]
+    Cc, LD = C3 // 3, qkv.shape[2] * qkv.shape[3]
+    assert qkv.is_contiguous()
+    out = torch.empty(B, Cc, qkv.shape[2], qkv.shape[3], dtype=torch.float32, device=qkv.device)
+    check(_lib.load().tdr_attention_fwd(qkv.data_ptr(), B, Cc, heads, T1, LD, float(scale), out.data_ptr(), _stream()),
+          'tdr_attention_fwd')
+    return out
+
+
+def token_match(fl, fr, windows, N, T1):
+    """fl [B,D,LD/32,32], fr [B*N,D,LD/32,32], windows [B*N,C,h,w] -> (corr [B,N], index [B] int32, ref_in [B,C,h,w])"""
+    B, D = fl.shape[0], fl.shape[1]
+    LD = fl.shape[2] * fl.shape[3]
+    per = windows[0].numel()
+    corr = torch.empty(B, N, dtype=torch.float32, device=fl.device)
+    index = torch.empty(B, dtype=torch.int32, device=fl.device)
+    ref_in = torch.empty((B,) + tuple(windows.shape[1:]), dtype=torch.float32, device=fl.device)
+    check(_lib.load().tdr_token_match(fl.data_ptr(), fr.data_ptr(), windows.data_ptr(), B, N, D, T1, LD, per, corr.data_ptr(),
+                                      index.data_ptr(), ref_in.data_ptr(), _stream()), 'tdr_token_match')
+    return corr, index, ref_in

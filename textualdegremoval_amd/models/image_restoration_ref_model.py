@@ -31,9 +31,13 @@ class RefGuidedImageCleanModel(BaseModel):
         self.net_g = define_network(deepcopy(opt['network_g']))
         self.net_g = self.model_to_device(self.net_g)
         self.print_network(self.net_g)
-        # DINOv2 window matcher (reference :74-90).  Only needed when ref is larger than lq.
+        # DINOv2 ViT-B/14 window matcher (reference :74-90: vit_base(518, 14, init_values=1.0, 'mlp'), strict-loaded
+        # from path.pretrain_dino, frozen).  Only exercised when ref is larger than lq.
         self.net_ext = None
         self.pretrain_dino = self.opt['path'].get('pretrain_dino')
+        if self.pretrain_dino is not None and self.device.type == 'cuda':
+            from ..dino import DinoMatcher
+            self.net_ext = DinoMatcher(torch.load(self.pretrain_dino, map_location='cpu'), self.device, patch=14, heads=12)
         load_path = self.opt['path'].get('pretrain_network_g', None)
         if load_path is not None:
             self.load_network(self.net_g, load_path, self.opt['path'].get('strict_load_g', False),
@@ -99,14 +103,16 @@ class RefGuidedImageCleanModel(BaseModel):
 
     # ------------------------------------------------------------------ step
     def _match_reference_window(self):
-        """reference :215-247.  With ref.shape == lq.shape the unfold yields one window and
-        top-1 of one candidate is that window: ref_in == ref bit-exactly, so the two frozen
-        ViT passes (whose only output is that arg-max) are skipped."""
+        """reference :215-247.  With ref.shape == lq.shape the unfold yields one window and top-1 of one candidate is
+        that window: ref_in == ref bit-exactly, so the two frozen ViT passes (whose only output is that arg-max) are
+        skipped.  Otherwise the DINOv2 matcher picks the most similar lq-sized window of ref (HIP kernels, no-grad)."""
         if self.ref.shape[-2:] == self.lq.shape[-2:]:
             return self.ref
-        raise NotImplementedError(
-            'ref larger than lq needs the DINOv2 ViT-B/14 window matcher (SURVEY 8a row a22), which is not on the '
-            'HIP path yet; feed a ref of the lq size (what the shipped data pipeline produces after matching).')
+        if self.net_ext is None:
+            raise ValueError('ref is larger than lq: the DINOv2 window matcher needs path.pretrain_dino '
+                             '(the reference loads it unconditionally, image_restoration_ref_model.py:83-86)')
+        ref_in, self.match_index, self.match_corr = self.net_ext.match(self.lq, self.ref)
+        return ref_in
 
     def optimize_parameters(self, current_iter):
         if self.param_fix_iters is not None and current_iter < self.param_fix_iters:
