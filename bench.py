@@ -96,6 +96,9 @@ def main():
     ap.add_argument('--enc', type=str, default='1,1,1,28')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dino-ref-size', type=int, default=0,
+                    help='feed a reference image of this size (> --size): the frozen DINOv2 ViT-B/14 window matcher runs every step '
+                         '(random-init weights); 0 = ref of the lq size, where the match is the identity')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (multi-process smoke test on one GPU)')
     a = ap.parse_args()
     enc = [int(v) for v in a.enc.split(',')]
@@ -111,9 +114,21 @@ def main():
     from textualdegremoval_amd import kernels as K
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = create_model(make_opt(a.width, enc, a.size, world > 1))
+    opt = make_opt(a.width, enc, a.size, world > 1)
+    if a.dino_ref_size > a.size:
+        from textualdegremoval_amd.dino import random_vit_b14_state_dict
+        ck = f'/tmp/tdr_dino_vitb14_rank{rank}.pth'
+        torch.save(random_vit_b14_state_dict(seed=0), ck)
+        opt['path']['pretrain_dino'] = ck
+    model = create_model(opt)
     randomize_gates(model.net_g)
     data = synthetic_pair(a.batch, a.size, a.size, seed=1234 + rank)
+    if a.dino_ref_size > a.size:                           # clean image of the larger size; lq/gt = a crop of it (+ noise)
+        big = synthetic_pair(a.batch, a.dino_ref_size, a.dino_ref_size, seed=1234 + rank)
+        o = (a.dino_ref_size - a.size) // 2 // max(a.size // 4, 1) * max(a.size // 4, 1)
+        data['ref'] = big['gt']
+        data['gt'] = big['gt'][:, :, o:o + a.size, o:o + a.size].contiguous()
+        data['lq'] = (data['gt'] + (big['lq'] - big['gt'])[:, :, o:o + a.size, o:o + a.size]).contiguous()
     data = {k: v.cuda() for k, v in data.items()}          # inputs resident in HBM before the timed region
 
     def step(it):
@@ -220,7 +235,10 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
                                    f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW',
                        'width': a.width, 'enc_blk_nums': enc, 'global_batch': world * a.batch,
-                       'parallelism': f'dp{world}', 'dino_match': 'skipped bit-identically (ref size == lq size, N=1 window)'},
+                       'parallelism': f'dp{world}',
+                       'dino_match': ('skipped bit-identically (ref size == lq size, N=1 window)' if a.dino_ref_size <= a.size else
+                                      f'DINOv2 ViT-B/14 window match every step, ref {a.dino_ref_size}x{a.dino_ref_size} '
+                                      f'({((a.dino_ref_size - a.size) // max(a.size // 4, 1) + 1) ** 2} windows/image, random-init ViT)')},
             'final_loss': loss,
         }
         if is_cfg2:

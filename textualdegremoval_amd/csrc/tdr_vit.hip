@@ -80,82 +80,92 @@ __global__ void vit_assemble_kernel(float* __restrict__ tok, const float* __rest
     }
 }
 
-// softmax(q k^T * scale) v for one (image, head, 32-query tile) per wave, exact fp32 MFMA (32x32x2), online softmax.
-// qkv [B][3C][T] channel-major: q rows h*HD.., k rows C + h*HD.., v rows 2C + h*HD..;  out [B][C][T].
+// softmax(q k^T * scale) v.  Workgroup = 4 waves = 4 x 32 queries of one (image, head); K/V tiles of 32 keys are
+// staged once per workgroup.  The score tile is computed TRANSPOSED on the exact fp32 MFMA (S^T = K Q^T): a lane then
+// owns one query column with 16 of the 32 keys in its registers, so the online-softmax max / sum are register
+// reductions plus ONE cross-half exchange, and P^T is already in B-operand layout for O^T += V^T P^T when the
+// contraction walks the keys in the accumulator's own row order (key(s, half) = (s&3) + 8(s>>2) + 4 half) -- no LDS
+// round trip, no transposes.  Output columns (queries) are contiguous across lanes: coalesced stores.
+// qkv [B][3C][LD] channel-major: q rows h*HD.., k rows C + h*HD.., v rows 2C + h*HD..;  out [B][C][LD].
 template <int HD>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ qkv, int C, int T, int LD, float scale,
-                                                     float* __restrict__ out) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int C, int T, int LD, float scale,
+                                                      float* __restrict__ out) {
     constexpr int NDT = (HD + 31) / 32;
-    __shared__ float sK[HD][33], sV[HD][33], sP[32][33];
-    const int lane = threadIdx.x, j = lane & 31, kk = lane >> 5;
-    const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    __shared__ float sK[HD][33], sV[HD][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
     const float* Q = qkv + ((long)b * 3 * C + h * HD) * LD;
     const float* Kp = Q + (long)C * LD;
     const float* Vp = Kp + (long)C * LD;
-    float qa[HD / 2];
+    const bool qok = q0 + j < T;
+    float qb[HD / 2];                                      // B operand of S^T: Q[q = j][d = 2s + kk] * scale
 #pragma unroll
-    for (int s = 0; s < HD / 2; ++s) qa[s] = (q0 + j < T) ? Q[(long)(2 * s + kk) * LD + q0 + j] * scale : 0.f;
+    for (int s = 0; s < HD / 2; ++s) qb[s] = qok ? Q[(long)(2 * s + kk) * LD + q0 + j] * scale : 0.f;
     f32x16 o[NDT];
-    float mrow[16], lrow[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { mrow[r] = -1e30f; lrow[r] = 0.f; }
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = -1e30f, l = 0.f;
 
     for (int key0 = 0; key0 < T; key0 += 32) {
-        const bool kok = key0 + j < T;
-        const int kc = kok ? key0 + j : T - 1;
-#pragma unroll
-        for (int r = 0; r < HD / 2; ++r) {
-            const int d = 2 * r + kk;
+        __syncthreads();                                   // everyone is done with the previous K/V tile
+        for (int e = tid; e < HD * 32; e += 256) {
+            const int d = e >> 5, kx = e & 31;
+            const bool kok = key0 + kx < T;
+            const int kc = kok ? key0 + kx : T - 1;
             const float kv = Kp[(long)d * LD + kc], vv = Vp[(long)d * LD + kc];
-            sK[d][j] = kok ? kv : 0.f;
-            sV[d][j] = kok ? vv : 0.f;
+            sK[d][kx] = kok ? kv : 0.f;
+            sV[d][kx] = kok ? vv : 0.f;
         }
-        f32x16 sc;
+        __syncthreads();
+        f32x16 st;                                         // S^T tile: rows = keys, column j = this lane's query
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < HD / 2; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], sK[2 * s + kk][j], sc, 0, 0, 0);
-        float alpha[16];
+        for (int s = 0; s < HD / 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[2 * s + kk][j], qb[s], st, 0, 0, 0);
+        float mx = -1e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v = kok ? sc[r] : -1e30f;
-            float mx = v;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-            const float mnew = fmaxf(mrow[r], mx);
-            const float p = kok ? expf(v - mnew) : 0.f;
-            float sum = p;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-            alpha[r] = expf(mrow[r] - mnew);
-            lrow[r] = lrow[r] * alpha[r] + sum;
-            mrow[r] = mnew;
-            sP[(r & 3) + 8 * (r >> 2) + 4 * kk][j] = p;
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            st[r] = key < T ? st[r] : -1e30f;
+            mx = fmaxf(mx, st[r]);
         }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the other half of the wave holds the other 16 keys
+        const float mnew = fmaxf(m, mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            st[r] = key < T ? __expf(st[r] - mnew) : 0.f;
+            sum += st[r];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float alpha = __expf(m - mnew);
+        l = l * alpha + sum;
+        m = mnew;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha[r];
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            const int d = dt * 32 + j;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int d = dt * 32 + j;
-                const float bv = d < HD ? sV[d < HD ? d : 0][2 * s + kk] : 0.f;
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[j][2 * s + kk], bv, o[dt], 0, 0, 0);
+            for (int s = 0; s < 16; ++s) {                 // O^T[d][q] += V^T[d][key] P^T[key][q], key = row order of st
+                const int kx = (s & 3) + 8 * (s >> 2) + 4 * kk;
+                const float av = d < HD ? sV[d < HD ? d : 0][kx] : 0.f;
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, st[s], o[dt], 0, 0, 0);
             }
         }
     }
+    const float inv = 1.f / l;
+    if (q0 + j < LD) {
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-        const int d = dt * 32 + j;
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            if (d < HD && q < LD) out[((long)b * C + h * HD + d) * LD + q] = q < T ? o[dt][r] / lrow[r] : 0.f;
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (d < HD) out[((long)b * C + h * HD + d) * LD + q0 + j] = qok ? o[dt][r] * inv : 0.f;
+            }
     }
 }
 
@@ -252,11 +262,11 @@ extern "C" int tdr_vit_assemble(float* tok, const float* cls, const float* pos, 
 extern "C" int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream) {
     TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T, "tdr_attention_fwd: bad argument");
     const int hd = C / heads;
-    dim3 grid(tdr_cdiv(LD, 32), heads, B);
+    dim3 grid(tdr_cdiv(LD, 128), heads, B);
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(64), 0, st, qkv, C, T, LD, scale, out);
-    else if (hd == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(64), 0, st, qkv, C, T, LD, scale, out);
-    else if (hd == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(64), 0, st, qkv, C, T, LD, scale, out);
+    if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
+    else if (hd == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
+    else if (hd == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
     else { tdr_set_error("tdr_attention_fwd: head dim %d not supported (16, 32, 64)", hd); return TDR_ERR_UNSUPPORTED; }
     TDR_LAUNCH_CHECK("attention_fwd");
     return TDR_OK;

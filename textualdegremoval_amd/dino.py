@@ -106,3 +106,25 @@ class DinoMatcher:
         fr, _ = self.tokens(K.resize_bilinear(windows, Hd, Wd))
         corr, index, ref_in = K.token_match(fl, fr, windows, N, T + 1)
         return ref_in, index, corr
+
+
+def random_vit_b14_state_dict(seed=0, embed=768, depth=12, grid=37, patch=14):
+    """random-init ViT-B/14 state dict with the reference's key names (benchmarks only: no checkpoint is reachable
+    offline; the arithmetic does not depend on the weight values)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=0.02: torch.randn(*s, generator=g) * sc
+    sd = {'cls_token': r(1, 1, embed), 'pos_embed': r(1, 1 + grid * grid, embed), 'mask_token': torch.zeros(1, embed),
+          'patch_embed.proj.weight': r(embed, 3, patch, patch), 'patch_embed.proj.bias': torch.zeros(embed)}
+    for i in range(depth):
+        p = f'blocks.{i}.'
+        sd[p + 'norm1.weight'] = torch.ones(embed); sd[p + 'norm1.bias'] = torch.zeros(embed)
+        sd[p + 'attn.qkv.weight'] = r(3 * embed, embed); sd[p + 'attn.qkv.bias'] = torch.zeros(3 * embed)
+        sd[p + 'attn.proj.weight'] = r(embed, embed); sd[p + 'attn.proj.bias'] = torch.zeros(embed)
+        sd[p + 'ls1.gamma'] = torch.ones(embed)
+        sd[p + 'norm2.weight'] = torch.ones(embed); sd[p + 'norm2.bias'] = torch.zeros(embed)
+        sd[p + 'mlp.fc1.weight'] = r(4 * embed, embed); sd[p + 'mlp.fc1.bias'] = torch.zeros(4 * embed)
+        sd[p + 'mlp.fc2.weight'] = r(embed, 4 * embed); sd[p + 'mlp.fc2.bias'] = torch.zeros(embed)
+        sd[p + 'ls2.gamma'] = torch.ones(embed)
+    sd['norm.weight'] = torch.ones(embed)
+    sd['norm.bias'] = torch.zeros(embed)
+    return sd
