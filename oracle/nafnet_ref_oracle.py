@@ -80,11 +80,12 @@ def residual_block(x, P, pre):
     return F.conv2d(h, P[pre + 'conv2.weight'], P[pre + 'conv2.bias'], padding=1) + x
 
 
-def masa_encoder(x, P, pre, ext_n_blocks):
-    """Encoder.forward (:136-143).  Levels 3,4,5 all use n_blks[2] (:123-129)."""
+def masa_encoder(x, P, pre, ext_n_blocks, levels=5):
+    """Encoder.forward (:136-143).  Levels 3,4,5 all use n_blks[2] (:123-129).  `levels` < 5 stops
+    early (Restormer-ref only consumes L1..L4, oracle/restormer_ref_oracle.py)."""
     counts = [ext_n_blocks[0], ext_n_blocks[1], ext_n_blocks[2], ext_n_blocks[2], ext_n_blocks[2]]
     feats = []
-    for lvl in range(5):
+    for lvl in range(levels):
         k = lvl + 1
         stride = 1 if lvl == 0 else 2
         x = F.relu(F.conv2d(x, P[f'{pre}conv_L{k}.weight'], P[f'{pre}conv_L{k}.bias'],
@@ -269,11 +270,12 @@ def default_cfg(**kw):
     return cfg
 
 
-def masa_match_and_transfer(feat_lq, feat_ref, cfg, h, w, hr, wr, return_aux=False):
-    """:597-707.  feat_* are the 5-level pyramids; returns warp_ref_l
-    (finest first, like the reference list)."""
-    n_enc = len(cfg['enc_blk_nums'])
-    padder = 2 ** n_enc
+def masa_match_and_transfer(feat_lq, feat_ref, cfg, h, w, hr, wr, return_aux=False, padder=None):
+    """:597-707.  feat_* are the pyramids (finest first; 5 levels for NAFNet-ref, 4 for
+    Restormer-ref whose padder_size is 8); returns warp_ref_l (finest first, like the reference list)."""
+    L = len(feat_lq)
+    if padder is None:
+        padder = 2 ** len(cfg['enc_blk_nums'])
     lbs = cfg['lr_block_size']
     px = w // padder // lbs
     py = h // padder // lbs
@@ -281,7 +283,7 @@ def masa_match_and_transfer(feat_lq, feat_ref, cfg, h, w, hr, wr, return_aux=Fal
     ky = h // padder // py
     dia_x = 2 * int(wr // padder // (2 * px) * cfg['ref_down_block_size']) + 1
     dia_y = 2 * int(hr // padder // (2 * py) * cfg['ref_down_block_size']) + 1
-    deep_lq, deep_ref = feat_lq[4], feat_ref[4]
+    deep_lq, deep_ref = feat_lq[L - 1], feat_ref[L - 1]
     N, C, H, W = deep_lq.shape
     Hr, Wr = deep_ref.shape[-2:]
     lrb = lr_blocks(deep_lq, py, px, ky, kx)
@@ -295,8 +297,8 @@ def masa_match_and_transfer(feat_lq, feat_ref, cfg, h, w, hr, wr, return_aux=Fal
     lrb_flat = lrb.reshape(N * py * px, C, ky + 2, kx + 2)
     soft_att, index_all, corr_fine = fine_search(lrb_flat, refb)
     warp = []
-    for lvl in range(5):                       # lvl 0 = finest (scale 16)
-        s = 2 ** (4 - lvl)
+    for lvl in range(L):                       # lvl 0 = finest (scale 2^(L-1))
+        s = 2 ** (L - 1 - lvl)
         blk = gather_ref_block(feat_ref[lvl], y1, x1, side_x, s)
         t = transfer(blk, index_all, soft_att, s, side_x - 2)
         Cs = t.shape[1]
