@@ -122,15 +122,18 @@ int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream);
 /* ---------------------------------------------------------------------------
  * Streaming (HBM-bound) kernels.
  * ------------------------------------------------------------------------- */
-/* LayerNorm2d fwd/bwd -- models/archs/nafnet_arch_utils.py:264-300.
- * y = w*(x-mu)*rstd+b ; mu,rstd [N,H*W] saved for backward.
- * bwd: gx = rstd*(g - yhat*mean_c(g*yhat) - mean_c(g)) (+add), g=go*w;
- *      gw = sum go*yhat, gb = sum go  (deterministic two-stage; ws >= tdr_ln_ws_floats) */
-int tdr_layernorm2d_fwd(const float* x, int64_t x_ns, const float* w, const float* b, float eps,
+/* LayerNorm2d fwd/bwd -- models/archs/nafnet_arch_utils.py:264-300 (eps 1e-6) and
+ * network_restormer_guided_arch.py:172-218 (eps 1e-5; WithBias = center 1, BiasFree = center 0, b NULL).
+ * center 1: y = w*(x-mu)*rstd+b ; center 0: y = w*x*rstd (variance still about the mean).
+ * mu,rstd [N,H*W] saved for backward.
+ * bwd (center 1): gx = rstd*(g - yhat*mean_c(g*yhat) - mean_c(g)) (+add), g=go*w;
+ *      gw = sum go*yhat, gb = sum go  (deterministic two-stage; ws >= tdr_ln_ws_floats)
+ * bwd (center 0): gx = rstd*(g - yhat*mean_c(g*x*rstd)) (+add); gw = sum go*x*rstd; gb is scratch. */
+int tdr_layernorm2d_fwd(const float* x, int64_t x_ns, const float* w, const float* b, float eps, int center,
                         int N, int C, int HW, float* y, float* mu, float* rstd, void* stream);
 int64_t tdr_ln_ws_floats(int N, int C, int HW);
 int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns, const float* mu, const float* rstd,
-                        const float* w, const float* add, int64_t add_ns, int add_C,
+                        const float* w, const float* add, int64_t add_ns, int add_C, int center,
                         int N, int C, int HW, float* gx, float* gw, float* gb, float* ws, void* stream);
 
 /* depthwise 3x3 (+bias) + SimpleGate + global-average-pool partials
@@ -142,6 +145,42 @@ int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int N, int C, i
 /* backward: dg [N,C,H,W] -> dt [N,2C,H,W], dw [2C,9], db [2C] */
 int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
                  float* dt, float* dw, float* db, float* ws, void* stream);
+
+/* ---- Restormer-ref depthwise stencils (models/archs/network_restormer_guided_arch.py); b / db may be NULL (bias=False).
+ * GDFN gate (:236-239): t [N,2C,H,W] -> g [N,C,H,W] = gelu(dw(t)[:C]) * dw(t)[C:]  (erf GELU) */
+int tdr_dwgelu_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, float* g, void* stream);
+/* dg [N,C,H,W] -> dt [N,2C,H,W], dw [2C,9], db [2C]; ws >= tdr_dwsg_ws_floats(N,C,H,W) */
+int tdr_dwgelu_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
+                   float* dt, float* dw, float* db, float* ws, void* stream);
+/* plain depthwise 3x3, pad 1 (MDTA qkv_dwconv :254,260): t [N,planes,H,W] -> out same shape; planes even, W % 4 == 0 */
+int tdr_dwconv_fwd(const float* t, const float* w, const float* b, int N, int planes, int H, int W, float* out,
+                   void* stream);
+/* dout -> dt = dw^T(dout), dw [planes,9], db [planes]; ws >= tdr_dwsg_ws_floats(N,planes/2,H,W) */
+int tdr_dwconv_bwd(const float* dout, const float* t, const float* w, int N, int planes, int H, int W, float* dt,
+                   float* dw, float* db, float* ws, void* stream);
+
+/* ---- Restormer-ref MDTA core (:246-277), per image and head over CHANNEL tokens (c = C/heads <= 120).
+ * The pixel contractions run on tdr_conv_wgrad (per_image Gram q k^T) and tdr_conv_forward (1x1, per-image weights);
+ * these entry points do the c x c part.  Cp = tdr_mdta_pad(C) = C rounded up to 32.
+ * out[n][r] = sum_p x[n][r][p]^2  (F.normalize denominators of q and k, :266-267) */
+int tdr_row_sumsq(const float* x, int64_t x_ns, int N, int rows, int HW, float* out, void* stream);
+int tdr_mdta_pad(int C);
+/* G [N,C,C] (G[i][j] = q_i . k_j), ss [N,2C] (|q|^2 then |k|^2), temp [heads] ->
+ * A [N,Cp,Cp]: A[i][j] = softmax_j(temp_h * G_ij / (max(|q_i|,1e-12) max(|k_j|,1e-12))) inside a head, 0 elsewhere;
+ * AT = A^T.  Both are directly the fp32 packed 1x1 weights ([cin][Mpad]) of tdr_conv_forward:
+ * wp = AT computes attn v, wp = A computes attn^T dout. */
+int tdr_mdta_softmax(const float* G, const float* ss, const float* temp, int N, int C, int heads, float* A, float* AT,
+                     void* stream);
+/* dA [N,C,C] (dA[i][j] = dout_i . v_j) -> W [N,Wp,Wp] (Wp = tdr_mdta_pad(2C)), the symmetric packed 1x1 weights with
+ * d[q;k] = W [q;k], and dtemp [heads].  ws >= N*heads floats. */
+int tdr_mdta_bwd(const float* G, const float* ss, const float* temp, const float* A, const float* dA, int N, int C,
+                 int heads, float* W, float* dtemp, float* ws, void* stream);
+/* out = a * alpha[0] + b  (b may be NULL): TransformerResFusionBlock `x * alpha + shortcut` (:353) and its backward */
+int tdr_axpby_dev(const float* a, const float* alpha, const float* b, int64_t numel, float* out, void* stream);
+/* out[0] = sum a*b (fixed-order two-stage, double accumulation of the partials); ws >= 512 floats */
+int tdr_dot(const float* a, const float* b, int64_t numel, float* out, float* ws, void* stream);
+/* nn.PixelShuffle(2): in [N,4C,H,W] -> out [N,C,2H,2W] (:391; backward of Downsample's PixelUnshuffle :378) */
+int tdr_pixel_shuffle2(const float* in, int N, int C, int H, int W, float* out, void* stream);
 
 /* SCA 1x1 on the pooled vector: s[n,co] = sum_ci Wsca[co,ci]*pooled[n,ci] + bsca[co] (:192-196) */
 int tdr_sca_fwd(const float* pooled, const float* wsca, const float* bsca, int N, int C, float* s, void* stream);

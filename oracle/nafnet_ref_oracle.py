@@ -506,9 +506,10 @@ class OracleTrainer:
     'masa' substring LR split.  AdamW restated explicitly (no torch.optim)."""
 
     def __init__(self, P, cfg, lr=2e-4, ref_lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999),
-                 eps=1e-8, max_norm=0.01, use_grad_clip=True):
+                 eps=1e-8, max_norm=0.01, use_grad_clip=True, forward_fn=None):
         self.P = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in P.items())
         self.cfg = cfg
+        self.forward_fn = forward_fn or nafnet_ref_forward      # e.g. restormer_ref_oracle.restormer_ref_forward
         self.lr = {k: (ref_lr if 'masa' in k else lr) for k in self.P}
         self.base_lr, self.base_ref_lr = lr, ref_lr
         self.wd, self.betas, self.eps = weight_decay, betas, eps
@@ -523,7 +524,7 @@ class OracleTrainer:
     def step(self, lq, gt, ref):
         for p in self.P.values():
             p.grad = None
-        out = nafnet_ref_forward(self.P, self.cfg, lq, ref)
+        out = self.forward_fn(self.P, self.cfg, lq, ref)
         loss = l1_loss(out, gt)
         loss.backward()
         grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in self.P.items()}

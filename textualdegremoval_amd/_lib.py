@@ -78,13 +78,24 @@ SIGNATURES = {
     'tdr_pack_patches': (i32, [c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_wgrad_ws_floats': (i64, [C.POINTER(TdrWgradDesc)]),
     'tdr_conv_wgrad': (i32, [C.POINTER(TdrWgradDesc), c_fp]),
-    'tdr_layernorm2d_fwd': (i32, [c_fp, i64, c_fp, c_fp, f32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_layernorm2d_fwd': (i32, [c_fp, i64, c_fp, c_fp, f32, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_ln_ws_floats': (i64, [i32, i32, i32]),
-    'tdr_layernorm2d_bwd': (i32, [c_fp, c_fp, i64, c_fp, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp,
+    'tdr_layernorm2d_bwd': (i32, [c_fp, c_fp, i64, c_fp, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp,
                                   c_fp, c_fp]),
     'tdr_dwsg_ws_floats': (i64, [i32, i32, i32, i32]),
     'tdr_dwsg_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwsg_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_dwgelu_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_dwgelu_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_dwconv_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_dwconv_bwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_row_sumsq': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp]),
+    'tdr_mdta_pad': (i32, [i32]),
+    'tdr_mdta_softmax': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_mdta_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_axpby_dev': (i32, [c_fp, c_fp, c_fp, i64, c_fp, c_fp]),
+    'tdr_dot': (i32, [c_fp, c_fp, i64, c_fp, c_fp, c_fp]),
+    'tdr_pixel_shuffle2': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_sca_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, c_fp, c_fp]),
     'tdr_sca_bwd': (i32, [c_fp] * 8 + [i32, i32] + [c_fp] * 7 + [c_fp]),
     'tdr_scaled_conv_param_grads': (i32, [c_fp] * 5 + [i32, i32] + [c_fp] * 3 + [c_fp]),

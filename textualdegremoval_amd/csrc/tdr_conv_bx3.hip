@@ -400,6 +400,7 @@ int tdr_conv_forward_bx3(const TdrConvDesc* d, void* stream) {
         case 111: if (!g) return launch_bx_shape<1, 1, EPI_GATEBWD, false>(a, N, st); break;
         case 112: if (!g) return launch_bx_shape<1, 1, EPI_PSHUF, false>(a, N, st); break;
         case 310: if (!g) return launch_bx_shape<3, 1, EPI_STD, false>(a, N, st); break;
+        case 312: if (!g) return launch_bx_shape<3, 1, EPI_PSHUF, false>(a, N, st); break;
         case 320: if (!g) return launch_bx_shape<3, 2, EPI_STD, false>(a, N, st); break;
         case 220: if (!g) return launch_bx_shape<2, 2, EPI_STD, false>(a, N, st); break;
         case 212: if (!g) return launch_bx_shape<2, 1, EPI_PSHUF, false>(a, N, st); break;

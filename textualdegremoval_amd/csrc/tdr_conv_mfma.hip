@@ -327,6 +327,7 @@ extern "C" int tdr_conv_forward(const TdrConvDesc* d, void* stream) {
         case 1111: if (!g) return launch_shape<1, 1, 1, 32, EPI_GATEBWD, false>(a, N, st); break;
         case 1112: if (!g) return launch_shape<1, 1, 1, 32, EPI_PSHUF, false>(a, N, st); break;
         case 3110: if (!g) return launch_shape<3, 1, 1, 8, EPI_STD, false>(a, N, st); break;
+        case 3112: if (!g) return launch_shape<3, 1, 1, 8, EPI_PSHUF, false>(a, N, st); break;
         case 3120: if (!g) return launch_shape<3, 1, 2, 8, EPI_STD, false>(a, N, st); break;
         case 3130: if (!g) return launch_shape<3, 1, 3, 8, EPI_STD, false>(a, N, st); break;
         case 3210: if (!g) return launch_shape<3, 2, 1, 8, EPI_STD, false>(a, N, st); break;

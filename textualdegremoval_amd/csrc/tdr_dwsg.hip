@@ -10,12 +10,23 @@
 //   MODE_DT  : dt1 = dw1^T(du1), dt2 = dw2^T(du2)   (the same stencil with flipped taps)
 // The backward is two passes over a 2c-plane scratch tensor (du) instead of one LDS-tiled kernel with halo
 // recomputation: 9c instead of 5c plane passes, but both run at streaming speed and du stays in L2/MALL.
+//
+// The same stencil serves Restormer-ref (network_restormer_guided_arch.py):
+//   GATE_GELU : GDFN gate  g = gelu(dw1(t1)) * dw2(t2)  (:236-239, erf GELU), no pooling
+//   GATE_NONE : the plain depthwise conv of MDTA's qkv_dwconv (:254,260): planes handled in pairs (c, c+C),
+//               FWD writes both filtered planes, DU only accumulates dW/db from dout (nothing to recompute)
 #include "tdr_common.h"
 #include "../../include/tdr.h"
 
 namespace {
 
 enum { MODE_FWD = 0, MODE_DU = 1, MODE_DT = 2 };
+enum { GATE_MUL = 0, GATE_GELU = 1, GATE_NONE = 2 };
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 
 struct DwArgs {
     const float* a;      // FWD/DU: t [N][2C][H][W]; DT: du [N][2C][H][W]
@@ -44,7 +55,7 @@ __device__ __forceinline__ Row6 fetch_row(const float* __restrict__ plane, int y
     return o;
 }
 
-template <int MODE>
+template <int MODE, int GATE>
 __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
     __shared__ float red[4][20];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,7 +79,7 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
         w1[i] = a.w[c * 9 + k];
         w2[i] = a.w[(c + C) * 9 + k];
     }
-    const float b1 = MODE == MODE_DT ? 0.f : a.b[c], b2 = MODE == MODE_DT ? 0.f : a.b[c + C];
+    const float b1 = (MODE == MODE_DT || !a.b) ? 0.f : a.b[c], b2 = (MODE == MODE_DT || !a.b) ? 0.f : a.b[c + C];
     float acc[MODE == MODE_DU ? 20 : 1];
 #pragma unroll
     for (int i = 0; i < (MODE == MODE_DU ? 20 : 1); ++i) acc[i] = 0.f;
@@ -93,21 +104,44 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
                     o1[e] += w1[ky * 3 + kx] * r1[ky].v[e + kx];
                     o2[e] += w2[ky * 3 + kx] * r2[ky].v[e + kx];
                 }
-        if (MODE == MODE_FWD) {
-            const f32x4 o = {o1[0] * o2[0], o1[1] * o2[1], o1[2] * o2[2], o1[3] * o2[3]};
+        if (MODE == MODE_FWD && GATE == GATE_NONE) {
+            if (live) {
+                const f32x4 q1 = {o1[0], o1[1], o1[2], o1[3]}, q2 = {o2[0], o2[1], o2[2], o2[3]};
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)y * W + x0) = q1;
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)y * W + x0) = q2;
+            }
+        } else if (MODE == MODE_FWD) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (GATE == GATE_GELU ? gelu_erf(o1[e]) : o1[e]) * o2[e];
             if (live) {
                 *reinterpret_cast<f32x4*>(a.out + ((long)n * C + c) * HW + (long)y * W + x0) = o;
                 acc[0] += (o[0] + o[1]) + (o[2] + o[3]);
             }
         } else if (MODE == MODE_DU) {
-            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-            if (live) gv = *reinterpret_cast<const f32x4*>(a.dg + ((long)n * C + c) * HW + (long)y * W + x0);
-            f32x4 d1, d2;
+            f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
+            if (GATE == GATE_NONE) {
+                if (live) {
+                    d1 = *reinterpret_cast<const f32x4*>(a.dg + ((long)n * 2 * C + c) * HW + (long)y * W + x0);
+                    d2 = *reinterpret_cast<const f32x4*>(a.dg + ((long)n * 2 * C + c + C) * HW + (long)y * W + x0);
+                }
+            } else {
+                f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+                if (live) gv = *reinterpret_cast<const f32x4*>(a.dg + ((long)n * C + c) * HW + (long)y * W + x0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { d1[e] = gv[e] * o2[e]; d2[e] = gv[e] * o1[e]; }
-            if (live) {
-                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)y * W + x0) = d1;
-                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)y * W + x0) = d2;
+                for (int e = 0; e < 4; ++e) {
+                    if (GATE == GATE_GELU) {
+                        d1[e] = gv[e] * o2[e] * gelu_erf_grad(o1[e]);
+                        d2[e] = gv[e] * gelu_erf(o1[e]);
+                    } else {
+                        d1[e] = gv[e] * o2[e];
+                        d2[e] = gv[e] * o1[e];
+                    }
+                }
+                if (live) {
+                    *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)y * W + x0) = d1;
+                    *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)y * W + x0) = d2;
+                }
             }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -130,7 +164,7 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
         r1[0] = r1[1]; r1[1] = r1[2];
         r2[0] = r2[1]; r2[1] = r2[2];
     }
-    if (MODE == MODE_FWD) {
+    if (MODE == MODE_FWD && GATE == GATE_MUL) {
         const float s = wave_sum(acc[0]);
         if (lane == 0) red[tid >> 6][0] = s;
         __syncthreads();
@@ -165,7 +199,7 @@ __global__ void dw_param_finish_kernel(const float* __restrict__ part, int N, in
     for (int n = 0; n < N; ++n)
         for (int g = 0; g < nb; ++g) s += part[(((long)n * C + c) * nb + g) * 20 + k];
     const int ch = k < 10 ? c : c + C, kk = k % 10;
-    if (kk < 9) dw[ch * 9 + kk] = s; else db[ch] = s;
+    if (kk < 9) dw[ch * 9 + kk] = s; else if (db) db[ch] = s;
 }
 
 struct DwGeom { int tprw_log2, rpt, ncb, nby, nb; };
@@ -200,7 +234,7 @@ extern "C" int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int 
     hipStream_t st = (hipStream_t)stream;
     const DwGeom q = dw_geom(H, W);
     DwArgs a{t, nullptr, w, b, g, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb};
-    hipLaunchKernelGGL(dwsg_stencil_kernel<MODE_FWD>, dim3(q.nb, C, N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a);
     hipLaunchKernelGGL(dw_pool_finish_kernel, dim3(tdr_cdiv(N * C, 256)), dim3(256), 0, st, ws, N * C, q.nb,
                        1.0f / (float)((long)H * W), pooled);
     TDR_LAUNCH_CHECK("dwsg_fwd");
@@ -217,10 +251,69 @@ extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, con
     float* du = ws + (int64_t)N * C * q.nb * 20;
     du += (4 - (reinterpret_cast<uintptr_t>(du) / 4) % 4) % 4;   // 16-byte aligned scratch planes (ws holds one spare vector)
     DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb};
-    hipLaunchKernelGGL(dwsg_stencil_kernel<MODE_DU>, dim3(q.nb, C, N), dim3(256), 0, st, a1);
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
     DwArgs a2{du, nullptr, w, b, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
-    hipLaunchKernelGGL(dwsg_stencil_kernel<MODE_DT>, dim3(q.nb, C, N), dim3(256), 0, st, a2);
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
     hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, part, N, C, q.nb, dw, db);
     TDR_LAUNCH_CHECK("dwsg_bwd");
+    return TDR_OK;
+}
+
+// ---- Restormer-ref: GDFN gate (gelu(dw1 t1) * dw2 t2) and the plain depthwise conv of MDTA; b / db may be NULL (bias=False)
+extern "C" int tdr_dwgelu_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, float* g,
+                              void* stream) {
+    TDR_REQUIRE(t && w && g, "tdr_dwgelu_fwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0, "tdr_dwgelu_fwd: W must be a multiple of 4 (got %d)", W);
+    const DwGeom q = dw_geom(H, W);
+    DwArgs a{t, nullptr, w, b, g, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_GELU>), dim3(q.nb, C, N), dim3(256), 0, (hipStream_t)stream, a);
+    TDR_LAUNCH_CHECK("dwgelu_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_dwgelu_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
+                              float* dt, float* dw, float* db, float* ws, void* stream) {
+    TDR_REQUIRE(dg && t && w && dt && dw && ws, "tdr_dwgelu_bwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0, "tdr_dwgelu_bwd: W must be a multiple of 4 (got %d)", W);
+    hipStream_t st = (hipStream_t)stream;
+    const DwGeom q = dw_geom(H, W);
+    float* part = ws;
+    float* du = ws + (int64_t)N * C * q.nb * 20;
+    du += (4 - (reinterpret_cast<uintptr_t>(du) / 4) % 4) % 4;
+    DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_GELU>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
+    DwArgs a2{du, nullptr, w, nullptr, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
+    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, part, N, C, q.nb, dw, db);
+    TDR_LAUNCH_CHECK("dwgelu_bwd");
+    return TDR_OK;
+}
+
+// planes = 2*C (even); out[n][p] = dw_p * t[n][p] (+ b[p])
+extern "C" int tdr_dwconv_fwd(const float* t, const float* w, const float* b, int N, int planes, int H, int W, float* out,
+                              void* stream) {
+    TDR_REQUIRE(t && w && out, "tdr_dwconv_fwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0 && planes % 2 == 0, "tdr_dwconv_fwd: W %% 4 and planes %% 2 must be 0 (got %d, %d)", W, planes);
+    const DwGeom q = dw_geom(H, W);
+    DwArgs a{t, nullptr, w, b, out, nullptr, planes / 2, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_NONE>), dim3(q.nb, planes / 2, N), dim3(256), 0, (hipStream_t)stream, a);
+    TDR_LAUNCH_CHECK("dwconv_fwd");
+    return TDR_OK;
+}
+
+// dt = dw^T(dout); dw[p][9] = sum dout[p] * shifted t[p]; db[p] = sum dout[p] (db may be NULL).  ws >= tdr_dwsg_ws_floats(N, planes/2, H, W)
+extern "C" int tdr_dwconv_bwd(const float* dout, const float* t, const float* w, int N, int planes, int H, int W, float* dt,
+                              float* dw, float* db, float* ws, void* stream) {
+    TDR_REQUIRE(dout && t && w && dt && dw && ws, "tdr_dwconv_bwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0 && planes % 2 == 0, "tdr_dwconv_bwd: W %% 4 and planes %% 2 must be 0 (got %d, %d)", W, planes);
+    hipStream_t st = (hipStream_t)stream;
+    const int C = planes / 2;
+    const DwGeom q = dw_geom(H, W);
+    DwArgs a1{t, dout, w, nullptr, nullptr, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_NONE>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
+    DwArgs a2{dout, nullptr, w, nullptr, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
+    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, ws, N, C, q.nb, dw, db);
+    TDR_LAUNCH_CHECK("dwconv_bwd");
     return TDR_OK;
 }

@@ -15,8 +15,9 @@ namespace {
 template <int SLICES, int CPT>
 __global__ __launch_bounds__(64 * SLICES) void ln_fwd_kernel(const float* __restrict__ x, long x_ns,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            float eps, int C, int HW, float* __restrict__ y,
-                                                            float* __restrict__ mu, float* __restrict__ rstd) {
+                                                            float eps, int center, int C, int HW,
+                                                            float* __restrict__ y, float* __restrict__ mu,
+                                                            float* __restrict__ rstd) {
     __shared__ float red[SLICES][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
@@ -53,10 +54,11 @@ __global__ __launch_bounds__(64 * SLICES) void ln_fwd_kernel(const float* __rest
     const float rs = 1.0f / sqrtf(vt / (float)C + eps);
     if (!pok) return;
     float* yn = y + ((long)n * C) * HW + px;
+    const float mo = center ? mean : 0.f;          // BiasFree_LayerNorm scales the uncentred x
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int c = slice + SLICES * i;
-        if (c < C) yn[(long)c * HW] = (v[i] - mean) * rs * w[c] + b[c];
+        if (c < C) yn[(long)c * HW] = (v[i] - mo) * rs * w[c] + (b ? b[c] : 0.f);
     }
     if (slice == 0) {
         mu[(long)n * HW + px] = mean;
@@ -67,8 +69,9 @@ __global__ __launch_bounds__(64 * SLICES) void ln_fwd_kernel(const float* __rest
 // any C: re-reads x (L2-resident for the small deep maps this serves)
 __global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __restrict__ x, long x_ns,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            float eps, int C, int HW, float* __restrict__ y,
-                                                            float* __restrict__ mu, float* __restrict__ rstd) {
+                                                            float eps, int center, int C, int HW,
+                                                            float* __restrict__ y, float* __restrict__ mu,
+                                                            float* __restrict__ rstd) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __rest
     const float rs = 1.0f / sqrtf((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C + eps);
     if (!pok) return;
     float* yn = y + ((long)n * C) * HW + px;
-    for (int c = slice; c < C; c += 4) yn[(long)c * HW] = (xn[(long)c * HW] - mean) * rs * w[c] + b[c];
+    const float mo = center ? mean : 0.f;
+    for (int c = slice; c < C; c += 4) yn[(long)c * HW] = (xn[(long)c * HW] - mo) * rs * w[c] + (b ? b[c] : 0.f);
     if (slice == 0) {
         mu[(long)n * HW + px] = mean;
         rstd[(long)n * HW + px] = rs;
@@ -104,7 +108,7 @@ template <int SLICES, int CPT>
 __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
     const float* __restrict__ go, const float* __restrict__ x, long x_ns, const float* __restrict__ mu,
     const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ add, long add_ns, int add_C,
-    int N, int C, int HW, float* __restrict__ gx, float* __restrict__ part /*[grid][2][C]*/) {
+    int center, int N, int C, int HW, float* __restrict__ gx, float* __restrict__ part /*[grid][2][C]*/) {
     __shared__ float red[2][SLICES][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int tiles = (HW + 63) / 64;
@@ -129,6 +133,9 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
             xv[i] = xb[c * uHW + pxc];
             g0[i] = gb_[c * uHW + pxc];
         }
+        // BiasFree (center == 0): y = x*rs*w, so the sums run over the uncentred yu = yh + mu*rs and the
+        // mean(g) term vanishes; the (x-mu)*rs factor of d rs/dx stays centred.
+        const float off = center ? 0.f : m * rs;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
@@ -136,11 +143,12 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
             const bool ok = pok && c < C;
             const float gg = ok ? g0[i] : 0.f;
             const float yh = ok ? (xv[i] - m) * rs : 0.f;
+            const float yu = ok ? yh + off : 0.f;
             const float gv = gg * w[min(c, C - 1)];
             xv[i] = yh; g0[i] = gv;
             s1 += gv;
-            s2 += gv * yh;
-            aw[i] += gg * yh;
+            s2 += gv * yu;
+            aw[i] += gg * yu;
             ab[i] += gg;
         }
         red[0][slice][lane] = s1;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < SLICES; ++k) { S1 += red[0][k][lane]; S2 += red[1][k][lane]; }
         __syncthreads();
-        const float mg = S1 / (float)C, mgy = S2 / (float)C;
+        const float mg = center ? S1 / (float)C : 0.f, mgy = S2 / (float)C;
         float av[CPT];
         if (add) {
             const float* ab_ = add + (long)n * add_ns;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
 __global__ __launch_bounds__(1024) void ln_bwd_generic_kernel(
     const float* __restrict__ go, const float* __restrict__ x, long x_ns, const float* __restrict__ mu,
     const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ add, long add_ns, int add_C,
-    int C, int HW, float* __restrict__ gx) {
+    int center, int C, int HW, float* __restrict__ gx) {
     __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
@@ -190,19 +198,20 @@ __global__ __launch_bounds__(1024) void ln_bwd_generic_kernel(
     const float m = mu[(long)n * HW + pxc], rs = rstd[(long)n * HW + pxc];
     const float* xb = x + (long)n * x_ns;
     const float* gb_ = go + (long)n * C * HW;
+    const float off = center ? 0.f : m * rs;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
     for (int c = slice; c < C; c += 16) {
         const float g = gb_[(unsigned)c * uHW + pxc] * w[c];
         const float yh = (xb[(unsigned)c * uHW + pxc] - m) * rs;
-        s1 += g; s2 += g * yh;
+        s1 += g; s2 += g * (yh + off);
     }
     red[0][slice][lane] = s1; red[1][slice][lane] = s2;
     __syncthreads();
     float S1 = 0.f, S2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { S1 += red[0][k][lane]; S2 += red[1][k][lane]; }
-    const float mg = S1 / (float)C, mgy = S2 / (float)C;
+    const float mg = center ? S1 / (float)C : 0.f, mgy = S2 / (float)C;
     const float* ab_ = add ? add + (long)n * add_ns : xb;
     float* ob = gx + (long)n * C * HW;
 #pragma unroll 4
@@ -219,8 +228,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_generic_kernel(
 // generic path parameter grads: block (c, split) walks channel c's pixels; part[split][2][C]
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ go, const float* __restrict__ x,
                                                            long x_ns, const float* __restrict__ mu,
-                                                           const float* __restrict__ rstd, int N, int C, int HW,
-                                                           float* __restrict__ part) {
+                                                           const float* __restrict__ rstd, int center, int N, int C,
+                                                           int HW, float* __restrict__ part) {
     __shared__ float red[2][4];
     const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const long total = (long)N * HW;
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
     for (long i = (long)split * 256 + threadIdx.x; i < total; i += (long)nsplit * 256) {
         const int n = (int)(i / HW), px = (int)(i % HW);
         const float g0 = go[((long)n * C + c) * HW + px];
-        const float yh = (x[(long)n * x_ns + (long)c * HW + px] - mu[i]) * rstd[i];
+        const float yh = (x[(long)n * x_ns + (long)c * HW + px] - (center ? mu[i] : 0.f)) * rstd[i];
         sw += g0 * yh; sb += g0;
     }
     sw = wave_sum(sw); sb = wave_sum(sb);
@@ -506,19 +515,19 @@ inline int grid1d(long total, int cap = 8192) {
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-extern "C" int tdr_layernorm2d_fwd(const float* x, int64_t x_ns, const float* w, const float* b, float eps, int N, int C,
-                                   int HW, float* y, float* mu, float* rstd, void* stream) {
-    TDR_REQUIRE(x && w && b && y && mu && rstd, "tdr_layernorm2d_fwd: null pointer");
+extern "C" int tdr_layernorm2d_fwd(const float* x, int64_t x_ns, const float* w, const float* b, float eps, int center,
+                                   int N, int C, int HW, float* y, float* mu, float* rstd, void* stream) {
+    TDR_REQUIRE(x && w && y && mu && rstd, "tdr_layernorm2d_fwd: null pointer");
     TDR_REQUIRE(N > 0 && C > 0 && HW > 0, "tdr_layernorm2d_fwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(tdr_cdiv(HW, 64), N);
-#define LN_FWD(S, P) hipLaunchKernelGGL((ln_fwd_kernel<S, P>), grid, dim3(64 * S), 0, st, x, (long)x_ns, w, b, eps, C, HW, y, mu, rstd)
+#define LN_FWD(S, P) hipLaunchKernelGGL((ln_fwd_kernel<S, P>), grid, dim3(64 * S), 0, st, x, (long)x_ns, w, b, eps, center, C, HW, y, mu, rstd)
     if (C <= 32) LN_FWD(4, 8);
     else if (C <= 64) LN_FWD(4, 16);
     else if (C <= 128) LN_FWD(4, 32);
     else if (C <= 256) LN_FWD(8, 32);
     else if (C <= 512) LN_FWD(16, 32);
-    else hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, dim3(256), 0, st, x, (long)x_ns, w, b, eps, C, HW, y, mu, rstd);
+    else hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, dim3(256), 0, st, x, (long)x_ns, w, b, eps, center, C, HW, y, mu, rstd);
 #undef LN_FWD
     TDR_LAUNCH_CHECK("ln_fwd");
     return TDR_OK;
@@ -530,8 +539,8 @@ extern "C" int64_t tdr_ln_ws_floats(int N, int C, int HW) {
 }
 
 extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns, const float* mu, const float* rstd,
-                                   const float* w, const float* add, int64_t add_ns, int add_C, int N, int C, int HW,
-                                   float* gx, float* gw, float* gb, float* ws, void* stream) {
+                                   const float* w, const float* add, int64_t add_ns, int add_C, int center, int N, int C,
+                                   int HW, float* gx, float* gw, float* gb, float* ws, void* stream) {
     TDR_REQUIRE(go && x && mu && rstd && w && gx && gw && gb && ws, "tdr_layernorm2d_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int tiles = tdr_cdiv(HW, 64) * N;
@@ -539,16 +548,16 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
     if (C <= 128) {
         const int grid = tiles < LN_BWD_GRID ? tiles : LN_BWD_GRID;
         nparts = grid;
-#define LN_BWD(S, P) hipLaunchKernelGGL((ln_bwd_kernel<S, P>), dim3(grid), dim3(64 * S), 0, st, go, x, (long)x_ns, mu, rstd, w, add, (long)add_ns, add_C, N, C, HW, gx, ws)
+#define LN_BWD(S, P) hipLaunchKernelGGL((ln_bwd_kernel<S, P>), dim3(grid), dim3(64 * S), 0, st, go, x, (long)x_ns, mu, rstd, w, add, (long)add_ns, add_C, center, N, C, HW, gx, ws)
         if (C <= 32) LN_BWD(4, 8);
         else if (C <= 64) LN_BWD(4, 16);
         else LN_BWD(8, 16);
 #undef LN_BWD
     } else {
         hipLaunchKernelGGL(ln_bwd_generic_kernel, dim3(tdr_cdiv(HW, 64), N), dim3(1024), 0, st, go, x, (long)x_ns, mu, rstd,
-                           w, add, (long)add_ns, add_C, C, HW, gx);
-        hipLaunchKernelGGL(ln_param_grad_kernel, dim3(C, LN_GEN_SPLITS), dim3(256), 0, st, go, x, (long)x_ns, mu, rstd, N, C,
-                           HW, ws);
+                           w, add, (long)add_ns, add_C, center, C, HW, gx);
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3(C, LN_GEN_SPLITS), dim3(256), 0, st, go, x, (long)x_ns, mu, rstd, center, N,
+                           C, HW, ws);
         nparts = LN_GEN_SPLITS;
     }
     hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 1), dim3(1024), 0, st, ws, 2L * C, nparts, (long)C, gw);

@@ -121,10 +121,13 @@ def conv_fwd(x, w, b, stride, pad, res=None, relu=False):
     return out
 
 
-def conv_bwd(dout, x, w, stride, pad, need_dx=True, add_to_dx=None):
-    """returns (dx or None, dw, db)."""
+def conv_bwd(dout, x, w, stride, pad, need_dx=True, add_to_dx=None, bias=True):
+    """returns (dx or None, dw, db); db is None for a bias-free conv (bias=False)."""
     Cout, Cin, KH, _ = w.shape
-    dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad, want_db=True)
+    if bias:
+        dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad, want_db=True)
+    else:
+        dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad), None
     dw = dw.view(Cout, Cin, KH, KH)
     dx = None
     if need_dx:
@@ -166,11 +169,12 @@ def _enc_counts(ext):
     return [ext[0], ext[1], ext[2], ext[2], ext[2]]
 
 
-def encoder_fwd(x, P, pre, ext_n_blocks):
-    """returns ([f1..f5], saved)."""
+def encoder_fwd(x, P, pre, ext_n_blocks, levels=5):
+    """returns ([f1..f_levels], saved).  levels=4: the Restormer-ref file's own 4-level Encoder
+    (network_restormer_guided_arch.py:99-133)."""
     feats, saved = [], []
     cnt = _enc_counts(ext_n_blocks)
-    for lvl in range(5):
+    for lvl in range(levels):
         k = lvl + 1
         xin = x
         a = conv_fwd(xin, P[f'{pre}conv_L{k}.weight'], P[f'{pre}conv_L{k}.bias'], 1 if lvl == 0 else 2, 1, relu=True)
@@ -188,10 +192,10 @@ def encoder_fwd(x, P, pre, ext_n_blocks):
 
 
 def encoder_bwd(dfeats, P, pre, ext_n_blocks, saved, G):
-    """dfeats: list of 5 grads (or None).  Input-image gradient is not needed."""
+    """dfeats: list of per-level grads (or None).  Input-image gradient is not needed."""
     cnt = _enc_counts(ext_n_blocks)
     dnext = None                      # gradient flowing from level lvl+1 into feats[lvl]
-    for lvl in reversed(range(5)):
+    for lvl in reversed(range(len(dfeats))):
         k = lvl + 1
         xin, a, blocks = saved[lvl]
         d = dfeats[lvl]
@@ -226,7 +230,7 @@ def encoder_bwd(dfeats, P, pre, ext_n_blocks, saved, G):
 # ---------------------------------------------------------------------------
 class MasaGeom:
     def __init__(self, h, w, hr, wr, n_enc, lr_block_size, ref_down_block_size, dilations):
-        padder = 2 ** n_enc
+        padder = 2 ** n_enc           # padder_size (:419; Restormer-ref: 2**3, network_restormer_guided_arch.py:546)
         self.px = w // padder // lr_block_size
         self.py = h // padder // lr_block_size
         self.kx = w // padder // self.px
@@ -242,10 +246,11 @@ class MasaGeom:
 
 
 def masa_fwd(feats, N, geo):
-    """feats: 5 pyramid levels for the stacked batch [lq(0..N-1), ref(N..2N-1)].
-    Returns (warp list finest->coarsest like the reference's warp_ref_l, saved)."""
+    """feats: pyramid levels (finest first; 5 for NAFNet-ref, 4 for Restormer-ref) for the stacked batch
+    [lq(0..N-1), ref(N..2N-1)].  Returns (warp list finest->coarsest like the reference's warp_ref_l, saved)."""
     P, Kk, side = geo.P, geo.K, geo.side
-    deep = feats[4]
+    L = len(feats)
+    deep = feats[L - 1]
     _, Cc, H, W = deep.shape
     lq4, ref4 = deep[:N], deep[N:]
     Hr, Wr = H, W
@@ -271,31 +276,32 @@ def masa_fwd(feats, N, geo):
     finvq = K.patch_inv_norm(lrb, Kk, Kk)                                 # [N*P, K, K]
     finvk = K.patch_inv_norm(refb, R1, R1)
     index_all, soft_att = K.fine_argmax(fdots, finvq, finvk, N * P, Kk * Kk, R1 * R1)
-    # ---- transfer at 5 scales, reading the ref features directly
+    # ---- transfer at every scale, reading the ref features directly
     warp = []
-    for lvl in range(5):
-        s = 2 ** (4 - lvl)
+    for lvl in range(L):
+        s = 2 ** (L - 1 - lvl)
         warp.append(K.transfer_fwd(feats[lvl][N:], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s))
     saved = (lrb, refb, finvq, finvk, index, y1, x1, index_all, soft_att)
     return warp, saved
 
 
 def masa_bwd(dwarp, feats, N, geo, saved):
-    """returns list of 5 gradients w.r.t. the stacked feats (zeros where unused)."""
+    """returns the gradients w.r.t. the stacked feats (zeros where unused)."""
     lrb, refb, finvq, finvk, index, y1, x1, index_all, soft_att = saved
     P, Kk, side = geo.P, geo.K, geo.side
-    dev = feats[4].device
+    L = len(feats)
+    dev = feats[L - 1].device
     dfeats = [torch.zeros_like(f) for f in feats]
     datt = torch.zeros(N * P, Kk * Kk, dtype=torch.float32, device=dev)
-    for lvl in range(5):
-        s = 2 ** (4 - lvl)
+    for lvl in range(L):
+        s = 2 ** (L - 1 - lvl)
         K.transfer_bwd(dwarp[lvl], feats[lvl][N:], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s,
                        dfeats[lvl][N:], datt)
     dlrb, drefb = K.fine_search_bwd(datt, soft_att, index_all, lrb, refb, finvq, finvk, Kk, side)
-    K.scatter_ref_block(drefb, dfeats[4][N:], y1, x1, P, side)
-    _, Cc, H, W = feats[4].shape
+    K.scatter_ref_block(drefb, dfeats[L - 1][N:], y1, x1, P, side)
+    _, Cc, H, W = feats[L - 1].shape
     dlq4 = K.lr_blocks_bwd(dlrb, N, Cc, H, W, geo.py, geo.px, Kk, Kk)
-    K.copy_rows(dlq4, Cc * H * W, dfeats[4], Cc * H * W, N, Cc * H * W)
+    K.copy_rows(dlq4, Cc * H * W, dfeats[L - 1], Cc * H * W, N, Cc * H * W)
     return dfeats
 
 

@@ -269,18 +269,19 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
     return (g, db) if want_db else g
 
 
-def layernorm2d_fwd(x, w, b, eps):
+def layernorm2d_fwd(x, w, b, eps, center=True):
+    """center=False (b None): BiasFree_LayerNorm, y = x * rstd * w."""
     lib = _lib.load()
     N, Cc, H, W = x.shape
     y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x.device)
     mu = torch.empty(N, H * W, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mu)
-    check(lib.tdr_layernorm2d_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), b.data_ptr(), float(eps), N, Cc, H * W,
-                                  y.data_ptr(), mu.data_ptr(), rstd.data_ptr(), _stream()), 'tdr_layernorm2d_fwd')
+    check(lib.tdr_layernorm2d_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), _p(b), float(eps), 1 if center else 0, N, Cc,
+                                  H * W, y.data_ptr(), mu.data_ptr(), rstd.data_ptr(), _stream()), 'tdr_layernorm2d_fwd')
     return y, mu, rstd
 
 
-def layernorm2d_bwd(go, x, mu, rstd, w, add=None):
+def layernorm2d_bwd(go, x, mu, rstd, w, add=None, center=True):
     lib = _lib.load()
     N, Cc, H, W = x.shape
     assert go.is_contiguous()
@@ -291,8 +292,8 @@ def layernorm2d_bwd(go, x, mu, rstd, w, add=None):
     add_ns = _dense_nchw(add) if add is not None else 0
     add_C = add.shape[1] if add is not None else 0
     check(lib.tdr_layernorm2d_bwd(go.data_ptr(), x.data_ptr(), _dense_nchw(x), mu.data_ptr(), rstd.data_ptr(),
-                                  w.data_ptr(), _p(add), add_ns, add_C, N, Cc, H * W, gx.data_ptr(), gw.data_ptr(),
-                                  gb.data_ptr(), ws.data_ptr(), _stream()), 'tdr_layernorm2d_bwd')
+                                  w.data_ptr(), _p(add), add_ns, add_C, 1 if center else 0, N, Cc, H * W, gx.data_ptr(),
+                                  gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), _stream()), 'tdr_layernorm2d_bwd')
     return gx, gw, gb
 
 
@@ -601,3 +602,108 @@ def token_match(fl, fr, windows, N, T1):
     check(_lib.load().tdr_token_match(fl.data_ptr(), fr.data_ptr(), windows.data_ptr(), B, N, D, T1, LD, per, corr.data_ptr(),
                                       index.data_ptr(), ref_in.data_ptr(), _stream()), 'tdr_token_match')
     return corr, index, ref_in
+
+
+# ------------------------------------------------------------------ Restormer-ref (network_restormer_guided_arch.py)
+def dwgelu_fwd(t, w, b=None):
+    """GDFN gate: gelu(dw(t)[:, :h]) * dw(t)[:, h:]"""
+    N, C2, H, W = t.shape
+    assert t.is_contiguous()
+    g = torch.empty(N, C2 // 2, H, W, dtype=torch.float32, device=t.device)
+    check(_lib.load().tdr_dwgelu_fwd(t.data_ptr(), w.data_ptr(), _p(b), N, C2 // 2, H, W, g.data_ptr(), _stream()), 'tdr_dwgelu_fwd')
+    return g
+
+
+def dwgelu_bwd(dg, t, w, b=None):
+    lib = _lib.load()
+    N, C2, H, W = t.shape
+    Cc = C2 // 2
+    assert dg.is_contiguous() and t.is_contiguous()
+    dt = torch.empty_like(t)
+    dw = torch.empty(C2, 1, 3, 3, dtype=torch.float32, device=t.device)
+    db = torch.empty(C2, dtype=torch.float32, device=t.device) if b is not None else None
+    ws = workspace(lib.tdr_dwsg_ws_floats(N, Cc, H, W), t.device)
+    check(lib.tdr_dwgelu_bwd(dg.data_ptr(), t.data_ptr(), w.data_ptr(), _p(b), N, Cc, H, W, dt.data_ptr(), dw.data_ptr(),
+                             _p(db), ws.data_ptr(), _stream()), 'tdr_dwgelu_bwd')
+    return dt, dw, db
+
+
+def dwconv_fwd(t, w, b=None):
+    """plain depthwise 3x3, pad 1"""
+    N, Pn, H, W = t.shape
+    assert t.is_contiguous()
+    out = torch.empty_like(t)
+    check(_lib.load().tdr_dwconv_fwd(t.data_ptr(), w.data_ptr(), _p(b), N, Pn, H, W, out.data_ptr(), _stream()), 'tdr_dwconv_fwd')
+    return out
+
+
+def dwconv_bwd(dout, t, w, want_db=False):
+    lib = _lib.load()
+    N, Pn, H, W = t.shape
+    assert dout.is_contiguous() and t.is_contiguous()
+    dt = torch.empty_like(t)
+    dw = torch.empty(Pn, 1, 3, 3, dtype=torch.float32, device=t.device)
+    db = torch.empty(Pn, dtype=torch.float32, device=t.device) if want_db else None
+    ws = workspace(lib.tdr_dwsg_ws_floats(N, Pn // 2, H, W), t.device)
+    check(lib.tdr_dwconv_bwd(dout.data_ptr(), t.data_ptr(), w.data_ptr(), N, Pn, H, W, dt.data_ptr(), dw.data_ptr(), _p(db),
+                             ws.data_ptr(), _stream()), 'tdr_dwconv_bwd')
+    return dt, dw, db
+
+
+def row_sumsq(x, rows):
+    """x [N, >=rows, H, W] (dense per image) -> [N, rows] sums of squares over H*W of the first `rows` channels"""
+    N, _, H, W = x.shape
+    out = torch.empty(N, rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_row_sumsq(x.data_ptr(), _dense_nchw(x), N, rows, H * W, out.data_ptr(), _stream()), 'tdr_row_sumsq')
+    return out
+
+
+def mdta_pad(Cc):
+    return (Cc + 31) // 32 * 32
+
+
+def mdta_softmax(G, ss, temp, heads):
+    """G [N,C,C], ss [N,2C], temp [heads,1,1] -> (A, AT) [N,Cp,Cp] packed 1x1 weights (see include/tdr.h)"""
+    N, Cc = G.shape[0], G.shape[-1]
+    Cp = mdta_pad(Cc)
+    A = torch.empty(N, Cp, Cp, dtype=torch.float32, device=G.device)
+    AT = torch.empty_like(A)
+    check(_lib.load().tdr_mdta_softmax(G.data_ptr(), ss.data_ptr(), temp.data_ptr(), N, Cc, heads, A.data_ptr(), AT.data_ptr(),
+                                       _stream()), 'tdr_mdta_softmax')
+    return A, AT
+
+
+def mdta_bwd(G, ss, temp, A, dA, heads):
+    """-> (W [N,Wp,Wp] packed weights of d[q;k] = W [q;k], dtemp [heads,1,1])"""
+    N, Cc = G.shape[0], G.shape[-1]
+    Wp = mdta_pad(2 * Cc)
+    W = torch.empty(N, Wp, Wp, dtype=torch.float32, device=G.device)
+    dtemp = torch.empty(heads, 1, 1, dtype=torch.float32, device=G.device)
+    ws = torch.empty(N * heads, dtype=torch.float32, device=G.device)
+    check(_lib.load().tdr_mdta_bwd(G.data_ptr(), ss.data_ptr(), temp.data_ptr(), A.data_ptr(), dA.data_ptr(), N, Cc, heads,
+                                   W.data_ptr(), dtemp.data_ptr(), ws.data_ptr(), _stream()), 'tdr_mdta_bwd')
+    return W, dtemp
+
+
+def axpby_dev(a, alpha, b=None):
+    """a * alpha[0] + b with alpha a device scalar"""
+    assert a.is_contiguous() and (b is None or b.is_contiguous())
+    out = torch.empty_like(a)
+    check(_lib.load().tdr_axpby_dev(a.data_ptr(), alpha.data_ptr(), _p(b), a.numel(), out.data_ptr(), _stream()), 'tdr_axpby_dev')
+    return out
+
+
+def dot(a, b):
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = workspace(512, a.device, 'dot')
+    check(_lib.load().tdr_dot(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), ws.data_ptr(), _stream()), 'tdr_dot')
+    return out
+
+
+def pixel_shuffle2(x):
+    N, C4, H, W = x.shape
+    assert x.is_contiguous() and C4 % 4 == 0
+    out = torch.empty(N, C4 // 4, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_pixel_shuffle2(x.data_ptr(), N, C4 // 4, H, W, out.data_ptr(), _stream()), 'tdr_pixel_shuffle2')
+    return out

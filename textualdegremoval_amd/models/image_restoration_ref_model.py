@@ -150,11 +150,12 @@ class RefGuidedImageCleanModel(BaseModel):
         prev_plan = K.set_pack_plan(self._pack_plan)
         try:
             self._pack_plan.run()              # all weights, all layouts, one launch (no-op on the recording step)
-            out, saved = E.net_fwd(P, net.cfg, lq, ref_in)
+            eng = getattr(net, 'engine', E)    # RestormerRefFusion carries restormer_engine
+            out, saved = eng.net_fwd(P, net.cfg, lq, ref_in)
             self.output = out
             loss, dpred = K.l1_loss(out.contiguous(), gt.contiguous(), float(self.cri_pix.loss_weight))
             sink = self.grad_reducer.begin(defer_collectives=defer_collectives)
-            E.net_bwd(dpred, P, net.cfg, saved, G=sink)
+            eng.net_bwd(dpred, P, net.cfg, saved, G=sink)
             grads = self.grad_reducer.finish()
         finally:
             K.set_pack_plan(prev_plan)
