@@ -28,11 +28,18 @@ PEAK_BF16 = 2.5e15                    # dense bf16 MFMA (MI355X_MICROARCH.md); t
 PEAK_BX3 = PEAK_BF16 / 6.0
 
 
-def make_opt(width, enc, batch_hw, dist_on):
+def make_opt(width, enc, batch_hw, dist_on, arch='nafnet'):
+    if arch == 'restormer':      # BASELINE configs[2] / SURVEY 8d cfg3: Restormer-ref dim=nf=48
+        net = dict(type='RestormerRefFusion', inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8],
+                   num_refinement_blocks=4, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
+                   LayerNorm_type='WithBias', dual_pixel_task=False, nf=48, ext_n_blocks=[4, 4, 4, 4],
+                   reffusion_n_blocks=[2, 2, 2, 2])
+    else:
+        net = dict(type='NAFNetRefFusion', width=width, nf=width, enc_blk_nums=enc, dec_blk_nums=[1, 1, 1, 1],
+                   middle_blk_num=1, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2])
     return {
         'model_type': 'RefGuidedImageCleanModel', 'num_gpu': 1, 'dist': dist_on, 'is_train': True,
-        'network_g': dict(type='NAFNetRefFusion', width=width, nf=width, enc_blk_nums=enc, dec_blk_nums=[1, 1, 1, 1],
-                          middle_blk_num=1, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2]),
+        'network_g': net,
         'path': {},
         'train': {'optim_g': {'type': 'AdamW', 'lr': 2e-4, 'ref_lr': 1e-4, 'weight_decay': 1e-4, 'betas': [0.9, 0.999]},
                   'scheduler': {'type': 'CosineAnnealingRestartCyclicLR', 'periods': [306000, 694000],
@@ -90,8 +97,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=4)
-    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer'],
+                    help="nafnet: the headline workload (BASELINE configs[1]); restormer: configs[2]'s per-GPU workload "
+                         '(Restormer-ref dim 48, 256x256, bs 8) -- a secondary measurement, not the metric line')
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--size', type=int, default=None)
     ap.add_argument('--width', type=int, default=32)
     ap.add_argument('--enc', type=str, default='1,1,1,28')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -101,6 +111,10 @@ def main():
                          '(random-init weights); 0 = ref of the lq size, where the match is the identity')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (multi-process smoke test on one GPU)')
     a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 8 if a.arch == 'restormer' else 4
+    if a.size is None:
+        a.size = 256 if a.arch == 'restormer' else 512
     enc = [int(v) for v in a.enc.split(',')]
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -114,7 +128,7 @@ def main():
     from textualdegremoval_amd import kernels as K
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    opt = make_opt(a.width, enc, a.size, world > 1)
+    opt = make_opt(a.width, enc, a.size, world > 1, a.arch)
     if a.dino_ref_size > a.size:
         from textualdegremoval_amd.dino import random_vit_b14_state_dict
         ck = f'/tmp/tdr_dino_vitb14_rank{rank}.pth'
@@ -224,17 +238,21 @@ def main():
     if rank == 0:
         ips = world * a.batch * a.steps / dt
         per_gpu = ips / world
-        is_cfg2 = (a.width, enc, a.size, a.batch) == (32, [1, 1, 1, 28], 512, 4)
+        is_cfg2 = (a.arch, a.width, enc, a.size, a.batch) == ('nafnet', 32, [1, 1, 1, 28], 512, 4)
         line = {
-            'metric': 'train images/sec (512x512, bs=4/GPU)', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
+            'metric': f'train images/sec ({a.size}x{a.size}, bs={a.batch}/GPU)', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'math': ('fp32 tensors; dense contractions as 3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate): '
                      'per-product error <= one fp32 rounding, see profiles/r1/bf16x3_probe_mi355x.log; TDR_MATH=f32 selects exact fp32 MFMA'
                      if K.MATH == 'bx3' else 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)'),
-            'config': {'workload': 'BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
-                                   f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW',
-                       'width': a.width, 'enc_blk_nums': enc, 'global_batch': world * a.batch,
+            'config': {'workload': ('BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
+                                    f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
+                                    if a.arch == 'nafnet' else
+                                    'BASELINE configs[2] per-GPU workload: Restormer-ref dim48 blocks[4,6,6,8] refine4 heads[1,2,4,8] '
+                                    f'fusion[2,2,2,2], {a.size}x{a.size} synthetic pairs, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'),
+                       'width': a.width if a.arch == 'nafnet' else 48, 'enc_blk_nums': enc if a.arch == 'nafnet' else [4, 6, 6, 8],
+                       'global_batch': world * a.batch,
                        'parallelism': f'dp{world}',
                        'dino_match': ('skipped bit-identically (ref size == lq size, N=1 window)' if a.dino_ref_size <= a.size else
                                       f'DINOv2 ViT-B/14 window match every step, ref {a.dino_ref_size}x{a.dino_ref_size} '
@@ -248,7 +266,12 @@ def main():
                                      'alg_bytes_per_image': CFG2['B_alg'], 'alg_flop_per_image': CFG2['F_alg']}
         if roof is not None:
             line['roofline'] = roof
-        if not a.no_cpu_baseline and world == 1:
+        if a.arch == 'restormer':
+            CFG3 = dict(B_alg=69.4e9, F_alg=1.86e12)       # SURVEY 8(d), per 256x256 image
+            line['roofline_step'] = {'achieved_hbm_frac': CFG3['B_alg'] * per_gpu / PEAK_HBM,
+                                     'achieved_f32_flop_frac': CFG3['F_alg'] * per_gpu / PEAK_F32,
+                                     'alg_bytes_per_image': CFG3['B_alg'], 'alg_flop_per_image': CFG3['F_alg']}
+        if not a.no_cpu_baseline and world == 1 and a.arch == 'nafnet':
             line['cpu_baseline'] = cpu_baseline(a.width, enc, a.size)
         print(json.dumps(line))
     if world > 1:

@@ -14,10 +14,10 @@ def synthetic_pair(B, H, W, seed=1234, sigma=15.0):
 
 
 def randomize_gates(net, std=0.1, seed=0):
-    """beta/gamma are zero-initialised (blocks start as identities); give them N(0,std) so the
-    benchmark exercises every kernel with non-trivial data."""
+    """beta/gamma (NAFNet) and alpha (Restormer fusion blocks) are zero-initialised (blocks start as
+    identities); give them N(0,std) so the benchmark exercises every kernel with non-trivial data."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for k, p in net.named_parameters():
-            if k.endswith('beta') or k.endswith('gamma'):
+            if k.endswith('beta') or k.endswith('gamma') or k.endswith('alpha'):
                 p.copy_(torch.randn(p.shape, generator=g) * std)
