@@ -1,0 +1,141 @@
+"""Generate golden vectors for the stage-A (image-to-text mapping) pieces, SURVEY.md 8a rows a28-a30.
+
+Run in the build container only:
+    python tests/golden/make_golden_i2t.py
+Writes tests/golden/i2t_*.npz (data only; weights are regenerated from seeds by oracle.i2t_oracle.synth_*).
+
+  a28  CLIP ViT image encoder: THIRD-PARTY (`transformers`, pinned 4.31.0 by the reference, not vendored).  The vectors
+       come from `transformers.CLIPVisionModel` as installed here (version recorded in the file) with random weights,
+       called the way the reference calls it (scripts/train/main_train_i2t_mapping.py:726-731).
+  a29/a30  `Mapper`, `inj_forward_crossattention` and the head reshapes: the reference defines them inside
+       scripts/train/main_train_i2t_mapping.py, whose module-level imports need `diffusers` (absent).  Their
+       definitions are therefore located with `ast` and executed from the reference file in a namespace holding
+       torch only -- the reference's code runs, nothing of it is copied; only numeric outputs are saved.
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF_SCRIPT = '/root/reference/scripts/train/main_train_i2t_mapping.py'
+
+from oracle import i2t_oracle as IO  # noqa: E402
+
+
+def sample(t, n=16):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy()
+
+
+def load_reference_defs(names):
+    src = open(REF_SCRIPT).read()
+    tree = ast.parse(src)
+    ns = {'torch': torch, 'nn': nn, 'F': F}
+    for node in tree.body:
+        if isinstance(node, (ast.ClassDef, ast.FunctionDef)) and node.name in names:
+            node.decorator_list = []
+            exec(compile(ast.Module([node], []), REF_SCRIPT, 'exec'), ns)
+    return ns
+
+
+def clip_cases():
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    d = {'transformers_version': np.array(transformers.__version__)}
+    for tag, (hidden, inter, layers, heads, image, act) in {
+            'a': (64, 128, 2, 4, 56, 'quick_gelu'),          # head dim 16, 16 patch tokens
+            'b': (160, 320, 1, 2, 42, 'gelu')}.items():      # head dim 80 (ViT-H geometry), 9 patch tokens
+        cfg = CLIPVisionConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                               num_attention_heads=heads, image_size=image, patch_size=14, hidden_act=act)
+        m = CLIPVisionModel(cfg).eval()
+        sd = IO.synth_clip_params(hidden, inter, layers, 14, image, seed=ord(tag))
+        keys = list(m.state_dict().keys())
+        pref = 'vision_model.' if keys[0].startswith('vision_model.') else ''
+        missing = m.load_state_dict({pref + k: v for k, v in sd.items()}, strict=False)
+        assert not [k for k in missing.missing_keys if 'position_ids' not in k], missing
+        g = torch.Generator().manual_seed(100 + ord(tag))
+        big = torch.rand(2, 3, 70, 70, generator=g)
+        x = F.interpolate(big, (image, image), mode='bilinear')          # :726
+        with torch.no_grad():
+            feats = m(x, output_hidden_states=True)
+        d[f'{tag}_x'] = x.numpy()
+        d[f'{tag}_out'] = feats[0].numpy()                               # image_features[0] (:730)
+        d[f'{tag}_cfg'] = np.array([hidden, inter, layers, heads, image])
+        d[f'{tag}_act'] = np.array(act)
+        print('clip', tag, feats[0].shape, float(feats[0].abs().mean()))
+    np.savez_compressed(os.path.join(HERE, 'i2t_clip.npz'), **d)
+
+
+def mapper_case():
+    ns = load_reference_defs({'Mapper'})
+    din, dout, words, B, T = 48, 40, 2, 2, 16
+    mp = ns['Mapper'](input_dim=din, output_dim=dout, num_words=words)
+    P = IO.synth_mapper_params(din, 1280, dout, words, seed=5)
+    assert sorted(P.keys()) == sorted(mp.state_dict().keys())
+    mp.load_state_dict(P)
+    g = torch.Generator().manual_seed(9)
+    emb = torch.randn(B, 1 + T, din, generator=g)
+    out = mp([emb])
+    go = torch.randn(out.shape, generator=g)
+    (out * go).sum().backward()
+    d = dict(emb=emb.numpy(), out=out.detach().numpy(), go=go.numpy(), cfg=np.array([din, dout, words, B, T]))
+    names = sorted(P.keys())
+    d['names'] = np.array(names)
+    sdp = dict(mp.named_parameters())
+    d['grad_norm'] = np.array([sdp[k].grad.double().norm().item() for k in names])
+    d['grad_sample'] = np.stack([np.pad(sample(sdp[k].grad, 8), (0, 8 - min(8, sdp[k].grad.numel()))) for k in names])
+    np.savez_compressed(os.path.join(HERE, 'i2t_mapper.npz'), **d)
+    print('mapper', out.shape, float(out.abs().mean()))
+
+
+def cross_attention_case():
+    ns = load_reference_defs({'inj_forward_crossattention', 'reshape_heads_to_batch_dim', 'reshape_batch_dim_to_heads'})
+
+    class Attn(nn.Module):          # the attributes diffusers' CrossAttention carries (:197-233 reads exactly these)
+        def __init__(self, dq, dc, inner, heads):
+            super().__init__()
+            self.heads, self.scale = heads, (inner // heads) ** -0.5
+            self.to_q = nn.Linear(dq, inner, bias=False)
+            self.to_k = nn.Linear(dq, inner, bias=False)
+            self.to_v = nn.Linear(dq, inner, bias=False)
+            self.to_k_global = nn.Linear(dc, inner, bias=False)
+            self.to_v_global = nn.Linear(dc, inner, bias=False)
+            self.to_out = nn.ModuleList([nn.Linear(inner, dq), nn.Dropout(0.0)])
+    Attn.reshape_heads_to_batch_dim = ns['reshape_heads_to_batch_dim']
+    Attn.reshape_batch_dim_to_heads = ns['reshape_batch_dim_to_heads']
+    Attn.forward = ns['inj_forward_crossattention']
+    d = {}
+    for tag, (dq, dc, inner, heads, B, Tq, Tk) in {'x': (48, 40, 64, 2, 2, 96, 77), 's': (64, 40, 128, 2, 1, 80, 0)}.items():
+        torch.manual_seed(3 + ord(tag))
+        at = Attn(dq, dc, inner, heads)
+        g = torch.Generator().manual_seed(ord(tag))
+        hid = torch.randn(B, Tq, dq, generator=g, requires_grad=True)
+        ctx = torch.randn(B, Tk, dc, generator=g, requires_grad=True) if Tk else None
+        out = at(hid, {'CONTEXT_TENSOR': ctx} if Tk else None)
+        go = torch.randn(out.shape, generator=g)
+        (out * go).sum().backward()
+        d.update({f'{tag}_hid': hid.detach().numpy(), f'{tag}_out': out.detach().numpy(), f'{tag}_go': go.numpy(),
+                  f'{tag}_ghid': hid.grad.numpy(), f'{tag}_cfg': np.array([dq, dc, inner, heads, B, Tq, Tk])})
+        if Tk:
+            d[f'{tag}_ctx'] = ctx.detach().numpy(); d[f'{tag}_gctx'] = ctx.grad.numpy()
+        for k, p in at.named_parameters():
+            d[f'{tag}_p_{k}'] = p.detach().numpy()
+            if p.grad is not None:
+                d[f'{tag}_g_{k}'] = p.grad.numpy()
+        print('xattn', tag, out.shape)
+    np.savez_compressed(os.path.join(HERE, 'i2t_xattn.npz'), **d)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    clip_cases()
+    mapper_case()
+    cross_attention_case()

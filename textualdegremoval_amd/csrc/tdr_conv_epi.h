@@ -128,6 +128,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 } else if (a.relu == 2) {               // exact (erf) GELU: ViT MLP
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));
+                } else if (a.relu == 3) {               // quick_gelu x*sigmoid(1.702x): OpenAI CLIP MLP
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] / (1.f + expf(-1.702f * v[r]));
                 }
                 if (a.mask) {
                     float tv[16];
@@ -225,6 +228,9 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& a, f32x16 (&ac
                     } else if (a.relu == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[e] = 0.5f * x[e] * (1.f + erff(x[e] * 0.70710678118654752f));
+                    } else if (a.relu == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = x[e] / (1.f + expf(-1.702f * x[e]));
                     }
                     if (a.mask) {
 #pragma unroll

@@ -264,7 +264,8 @@ extern "C" int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int 
     const int hd = C / heads;
     dim3 grid(tdr_cdiv(LD, 128), heads, B);
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
+    if (hd == 80) hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
+    else if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
     else if (hd == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
     else if (hd == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
     else { tdr_set_error("tdr_attention_fwd: head dim %d not supported (16, 32, 64)", hd); return TDR_ERR_UNSUPPORTED; }
