@@ -58,7 +58,7 @@ typedef struct TdrConvDesc {
     const float* res;   int64_t res_ns;
     const float* mask;  int64_t mask_ns;
     const float* aux;   int64_t aux_ns;
-    int relu;                    /* 0 none, 1 ReLU, 2 exact (erf) GELU */
+    int relu;                    /* 0 none, 1 ReLU, 2 exact (erf) GELU, 3 quick_gelu x*sigmoid(1.702x) */
 } TdrConvDesc;
 
 int tdr_conv_forward(const TdrConvDesc* d, void* stream);
@@ -280,6 +280,26 @@ int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, 
  * fl [B][D][LD], fr [B*N][D][LD], windows [B*N][per] -> corr [B][N], index [B] (int32), ref_in [B][per] (:230-243) */
 int tdr_token_match(const float* fl, const float* fr, const float* windows, int B, int N, int D, int T1, int LD, int64_t per,
                     float* corr, int* index, float* ref_in, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Stage-A (image-to-text mapping) glue: scripts/train/main_train_i2t_mapping.py:40-81 (Mapper), :85-98,197-233 (injected
+ * cross-attention).  The frozen CLIP ViT image encoder (:564,726-731) reuses the ViT kernels above (patchify, assemble,
+ * tdr_attention_fwd incl. head dim 80, quick_gelu = relu code 3 of tdr_conv_forward).  Linears are 1x1 convs over
+ * channel-major tokens [B][D][LD]; nn.LayerNorm is tdr_layernorm2d_* (eps 1e-5).
+ * ------------------------------------------------------------------------- */
+/* nn.LeakyReLU (slope > 0); the backward takes the activation OUTPUT y (same sign as the input) */
+int tdr_leaky_relu_fwd(const float* x, int64_t numel, float slope, float* y, void* stream);
+int tdr_leaky_relu_bwd(const float* go, const float* y, int64_t numel, float slope, float* gx, void* stream);
+/* dst [D][32]: dst[d][b] = src[b][d][col] (b < B <= 32), zero-padded: the class tokens `embs[:, :1]` as one 32-pixel row (:77) */
+int tdr_gather_col(const float* src, int B, int D, int LD, int col, float* dst, void* stream);
+/* out[b][word][d] = cls[d][b] + mean_{t=1..T} patch[b][d][t]   (:77-79; out [B][words][D]) */
+int tdr_mapper_combine(const float* cls, const float* patch, int B, int D, int LD, int T, int words, int word, float* out,
+                       void* stream);
+/* gradient of the above w.r.t. cls [D][32] and patch [B][D][LD] (go [B][words][D]) */
+int tdr_mapper_combine_bwd(const float* go, int B, int D, int LD, int T, int words, int word, float* dcls, float* dpatch,
+                           void* stream);
+/* dst[b][c][r] = src[b][r][c] (r < R), 0 for R <= r < LDd: token-major [B][T][D] <-> channel-major [B][D][LD] */
+int tdr_transpose_pad(const float* src, int B, int R, int C, int LDd, float* dst, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Optimiser: global-norm clip (max_norm 0.01) + AdamW, multi-tensor

@@ -1,0 +1,114 @@
+"""GPU parity of the stage-A (image-to-text mapping) pieces, SURVEY 8a rows a28-a30, through the C ABI against the
+golden fixtures (tests/golden/i2t_*.npz: transformers' CLIPVisionModel; the reference's Mapper /
+inj_forward_crossattention definitions) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import i2t_oracle as IO
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module', params=['bx3', 'f32'])
+def K(request):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels
+    prev = kernels.MATH
+    kernels.set_math(request.param)
+    yield kernels
+    kernels.set_math(prev)
+
+
+def gold(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def token_major(tok, Tn):
+    """[B, D, LD/32, 32] channel-major -> [B, 1+T, D] (host-side view change for comparison only)"""
+    B, D = tok.shape[0], tok.shape[1]
+    return tok.reshape(B, D, -1)[:, :, :Tn + 1].permute(0, 2, 1).contiguous()
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_clip_vision_encoder_vs_transformers_golden(K, tag):
+    from textualdegremoval_amd.clip_vision import ClipVisionEncoder
+    g = gold('i2t_clip')
+    hidden, inter, layers, heads, image = [int(v) for v in g[tag + '_cfg']]
+    sd = IO.synth_clip_params(hidden, inter, layers, 14, image, seed=ord(tag))
+    enc = ClipVisionEncoder({'vision_model.' + k: v for k, v in sd.items()}, 'cuda', heads, act=str(g[tag + '_act']))
+    tok, Tn = enc.tokens(T(g[tag + '_x']).cuda())
+    assert Tn == (image // 14) ** 2
+    assert maxdiff(token_major(tok, Tn), T(g[tag + '_out'])) < 1e-4
+
+
+def test_clip_encode_resizes_like_the_reference_call(K):
+    """F.interpolate(image, (S, S), 'bilinear') then the encoder (main_train_i2t_mapping.py:726-730)."""
+    import torch.nn.functional as F
+    from textualdegremoval_amd.clip_vision import ClipVisionEncoder
+    sd = IO.synth_clip_params(64, 128, 1, 14, 56, seed=11)
+    enc = ClipVisionEncoder(sd, 'cuda', 4)
+    img = torch.rand(2, 3, 90, 90, generator=torch.Generator().manual_seed(2))
+    tok, Tn = enc.encode(img.cuda(), size=56)
+    ref = IO.clip_vision_tokens(sd, F.interpolate(img, (56, 56), mode='bilinear'), 4)
+    assert maxdiff(token_major(tok, Tn), ref) < 1e-4
+
+
+def test_glue_kernels(K):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 50, 7, generator=gen)
+    assert torch.equal(K.leaky_relu_fwd(x.cuda()).cpu(), F.leaky_relu(x, 0.01))
+    go = torch.randn(3, 50, 7, generator=gen)
+    y = F.leaky_relu(x, 0.01)
+    assert torch.equal(K.leaky_relu_bwd(go.cuda(), y.cuda()).cpu(), torch.where(x > 0, go, go * 0.01))
+    t = torch.randn(2, 17, 40, generator=gen)
+    tp = K.transpose_pad(t.cuda(), 32).cpu()
+    assert torch.equal(tp[:, :, :17], t.transpose(1, 2)) and tp[:, :, 17:].abs().max() == 0
+
+
+def test_mapper_vs_reference_golden(K):
+    from textualdegremoval_amd.i2t import Mapper
+    g = gold('i2t_mapper')
+    din, dout, words, B, Tn = [int(v) for v in g['cfg']]
+    P = IO.synth_mapper_params(din, 1280, dout, words, seed=5)
+    mp = Mapper(input_dim=din, output_dim=dout, num_words=words).cuda()
+    assert sorted(mp.state_dict().keys()) == sorted(P.keys())
+    mp.load_state_dict(P, strict=True)
+    out = mp([T(g['emb']).cuda()])
+    assert maxdiff(out, T(g['out'])) < 1e-4
+    (out * T(g['go']).cuda()).sum().backward()
+    sdp = dict(mp.named_parameters())
+    for i, k in enumerate(str(n) for n in g['names']):
+        gr = sdp[k].grad
+        assert abs(gr.double().norm().item() - g['grad_norm'][i]) < 3e-3 * g['grad_norm'][i] + 1e-6, k
+        s = gr.reshape(-1)
+        smp = s[::max(1, s.numel() // 8)][:8].cpu().numpy()
+        assert np.abs(smp - g['grad_sample'][i][:len(smp)]).max() < 3e-4 * max(1e-3, g['grad_norm'][i]) + 1e-6, k
+
+
+def test_mapper_on_channel_major_clip_tokens_matches_oracle(K):
+    """encoder -> mapper without leaving the channel-major layout (the (tokens, T) hand-over)."""
+    from textualdegremoval_amd.clip_vision import ClipVisionEncoder
+    from textualdegremoval_amd.i2t import Mapper
+    sd = IO.synth_clip_params(64, 128, 1, 14, 56, seed=4)
+    enc = ClipVisionEncoder(sd, 'cuda', 4)
+    x = torch.rand(3, 3, 56, 56, generator=torch.Generator().manual_seed(8))
+    P = IO.synth_mapper_params(64, 1280, 24, 2, seed=6)
+    mp = Mapper(64, 24, 2).cuda()
+    mp.load_state_dict(P)
+    out = mp([enc.tokens(x.cuda())])
+    ref = IO.mapper_forward(P, IO.clip_vision_tokens(sd, x, 4), 2)
+    assert maxdiff(out, ref) < 1e-4

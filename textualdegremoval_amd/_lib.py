@@ -96,6 +96,12 @@ SIGNATURES = {
     'tdr_axpby_dev': (i32, [c_fp, c_fp, c_fp, i64, c_fp, c_fp]),
     'tdr_dot': (i32, [c_fp, c_fp, i64, c_fp, c_fp, c_fp]),
     'tdr_pixel_shuffle2': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_leaky_relu_fwd': (i32, [c_fp, i64, f32, c_fp, c_fp]),
+    'tdr_leaky_relu_bwd': (i32, [c_fp, c_fp, i64, f32, c_fp, c_fp]),
+    'tdr_gather_col': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_mapper_combine': (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_mapper_combine_bwd': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_transpose_pad': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_sca_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, c_fp, c_fp]),
     'tdr_sca_bwd': (i32, [c_fp] * 8 + [i32, i32] + [c_fp] * 7 + [c_fp]),
     'tdr_scaled_conv_param_grads': (i32, [c_fp] * 5 + [i32, i32] + [c_fp] * 3 + [c_fp]),

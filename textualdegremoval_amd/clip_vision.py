@@ -1,0 +1,118 @@
+"""Frozen CLIP ViT image encoder on the HIP kernels (forward only, no-grad) -- SURVEY.md 8a row a28.
+
+Replaces the `CLIPVisionModel` the stage-A trainers call (scripts/train/main_train_i2t_mapping.py:564,726-731;
+main_train_tr_mapping.py:609,780; models/image_restoration_text_embed_diffir_model.py:137,264-268): bilinear
+resize to the encoder's input size, then `image_features[0]` = the encoder's last hidden state (class token +
+patch tokens, no post-layernorm), detached.  The model is third-party (`transformers`); this class takes its state
+dict (key names of CLIPVisionModel, with or without the `vision_model.` prefix).
+
+Same layout as dino.py: activations channel-major [B, D, LD/32, 32] (column 0 class token, 1..T patches, rest
+padding), every Linear a packed 1x1 convolution (q/k/v projections concatenated into one), LayerNorm the channel
+LayerNorm kernel, GELU / quick_gelu a conv epilogue, attention the fused MFMA kernel of csrc/tdr_vit.hip.
+"""
+import torch
+
+from . import kernels as K
+from .kernels import PACK_FWD
+
+
+def _strip(sd):
+    return {(k[len('vision_model.'):] if k.startswith('vision_model.') else k): v.detach().to(torch.float32) for k, v in sd.items()}
+
+
+class ClipVisionEncoder:
+    def __init__(self, state_dict, device, heads, act='quick_gelu', eps=1e-5):
+        """heads / act / eps: CLIPVisionConfig.num_attention_heads / hidden_act / layer_norm_eps
+        (ViT-L/14 openai: 16, quick_gelu; ViT-H/14 laion: 16, gelu)."""
+        if act not in ('quick_gelu', 'gelu'):
+            raise NotImplementedError(f'CLIP hidden_act {act!r}')
+        sd = _strip(state_dict)
+        need = ['embeddings.class_embedding', 'embeddings.patch_embedding.weight', 'embeddings.position_embedding.weight',
+                'pre_layrnorm.weight', 'pre_layrnorm.bias']
+        miss = [k for k in need if k not in sd]
+        if miss:
+            raise KeyError(f'CLIP vision state dict is missing {miss}')
+        self.device, self.heads, self.eps = device, heads, eps
+        self.act = 3 if act == 'quick_gelu' else 2                  # conv epilogue code (include/tdr.h)
+        pw = sd['embeddings.patch_embedding.weight']
+        self.D, self.patch = pw.shape[0], pw.shape[-1]
+        self.depth = 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('encoder.layers.'))
+        dev = lambda t: t.to(device).contiguous()
+        self.cls = dev(sd['embeddings.class_embedding'].reshape(-1))
+        self.pos = dev(sd['embeddings.position_embedding.weight'].t())        # channel-major [D, 1+T]
+        self.P = {k: dev(v) for k, v in sd.items() if 'self_attn' not in k and 'embeddings' not in k}
+        self.W = {}
+        self._pack('patch', pw.reshape(self.D, -1, 1, 1))
+        for i in range(self.depth):
+            p = f'encoder.layers.{i}.'
+            qkv = torch.cat([sd[p + f'self_attn.{n}_proj.weight'] for n in 'qkv'], dim=0)
+            self.P[p + 'qkv.bias'] = dev(torch.cat([sd[p + f'self_attn.{n}_proj.bias'] for n in 'qkv'], dim=0))
+            self.P[p + 'out.bias'] = dev(sd[p + 'self_attn.out_proj.bias'])
+            self._pack(p + 'qkv', qkv.reshape(3 * self.D, self.D, 1, 1))
+            w = sd[p + 'self_attn.out_proj.weight']
+            self._pack(p + 'out', w.reshape(self.D, self.D, 1, 1))
+            for name in ('mlp.fc1', 'mlp.fc2'):
+                w = sd[p + name + '.weight']
+                self._pack(p + name, w.reshape(w.shape[0], w.shape[1], 1, 1))
+
+    def _pack(self, key, w4):
+        prev = K.set_pack_plan(None)                      # persistent buffers, not a per-step plan
+        try:
+            wp, mp, *_ = K.pack_weights(w4.to(self.device).contiguous(), PACK_FWD)
+        finally:
+            K.set_pack_plan(prev)
+        self.W[key] = (wp, mp, w4.shape[0])
+
+    def _linear(self, x, key, bias, **kw):
+        wp, mp, cout = self.W[key]
+        return K.conv_forward(x, wp, mp, cout, 1, bias=bias, **kw)
+
+    @torch.no_grad()
+    def tokens(self, x):
+        """x [B,3,H,W] at the encoder's input size -> (last hidden state, channel-major [B, D, LD/32, 32], T)."""
+        B, _, H, W = x.shape
+        P = self.P
+        xp, T = K.patchify(x.contiguous(), self.patch)
+        if T + 1 != self.pos.shape[1]:
+            raise ValueError(f'CLIP encoder built for {self.pos.shape[1] - 1} patches, input gives {T} '
+                             '(position embeddings are not interpolated, transformers CLIPVisionEmbeddings)')
+        t = K.vit_assemble_(self._linear(xp, 'patch', None), self.cls, self.pos, T)
+        t, _, _ = K.layernorm2d_fwd(t, P['pre_layrnorm.weight'], P['pre_layrnorm.bias'], self.eps)
+        scale = (self.D // self.heads) ** -0.5
+        for i in range(self.depth):
+            p = f'encoder.layers.{i}.'
+            h, _, _ = K.layernorm2d_fwd(t, P[p + 'layer_norm1.weight'], P[p + 'layer_norm1.bias'], self.eps)
+            qkv = self._linear(h, p + 'qkv', P[p + 'qkv.bias'])
+            a = K.attention_fwd(qkv, self.heads, scale, T + 1)
+            t = self._linear(a, p + 'out', P[p + 'out.bias'], res=t)
+            h, _, _ = K.layernorm2d_fwd(t, P[p + 'layer_norm2.weight'], P[p + 'layer_norm2.bias'], self.eps)
+            h = self._linear(h, p + 'mlp.fc1', P[p + 'mlp.fc1.bias'], relu=self.act)
+            t = self._linear(h, p + 'mlp.fc2', P[p + 'mlp.fc2.bias'], res=t)
+        return t, T
+
+    @torch.no_grad()
+    def encode(self, image, size=224):
+        """the reference call: F.interpolate(image, (224, 224), mode='bilinear') then image_features[0]."""
+        x = image.contiguous()
+        if tuple(x.shape[-2:]) != (size, size):
+            x = K.resize_bilinear(x, size, size)
+        return self.tokens(x)
+
+
+def random_clip_state_dict(hidden=1024, inter=4096, layers=24, patch=14, image=224, seed=0):
+    """random-init CLIP ViT state dict with transformers' key names (benchmarks only; ViT-L/14 defaults)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=0.02: torch.randn(*s, generator=g) * sc
+    T = (image // patch) ** 2
+    sd = {'embeddings.class_embedding': r(hidden), 'embeddings.patch_embedding.weight': r(hidden, 3, patch, patch),
+          'embeddings.position_embedding.weight': r(1 + T, hidden),
+          'pre_layrnorm.weight': torch.ones(hidden), 'pre_layrnorm.bias': torch.zeros(hidden)}
+    for i in range(layers):
+        pr = f'encoder.layers.{i}.'
+        for nm in ('k_proj', 'v_proj', 'q_proj', 'out_proj'):
+            sd[pr + f'self_attn.{nm}.weight'] = r(hidden, hidden); sd[pr + f'self_attn.{nm}.bias'] = torch.zeros(hidden)
+        sd[pr + 'layer_norm1.weight'] = torch.ones(hidden); sd[pr + 'layer_norm1.bias'] = torch.zeros(hidden)
+        sd[pr + 'mlp.fc1.weight'] = r(inter, hidden); sd[pr + 'mlp.fc1.bias'] = torch.zeros(inter)
+        sd[pr + 'mlp.fc2.weight'] = r(hidden, inter); sd[pr + 'mlp.fc2.bias'] = torch.zeros(hidden)
+        sd[pr + 'layer_norm2.weight'] = torch.ones(hidden); sd[pr + 'layer_norm2.bias'] = torch.zeros(hidden)
+    return sd

@@ -1,0 +1,142 @@
+// Stage-A (image-to-text mapping) glue kernels, SURVEY.md 8a rows a29/a30
+// (scripts/train/main_train_i2t_mapping.py:40-81 Mapper, :85-98,197-233 injected cross-attention).
+// The Linears run on the 1x1 conv kernels over channel-major tokens [B][D][LD] (LD = padded token count, a
+// multiple of 32: column 0 class token, 1..T patch tokens, rest padding), nn.LayerNorm on the channel LayerNorm
+// kernel; what is left is HBM-bound elementwise / gather work:
+//   leaky_relu fwd / bwd            nn.LeakyReLU() (slope 0.01), :55,58,61
+//   gather_col                      emb[:, :1]  -> [D][32] "image" holding the B class tokens as pixels (:77)
+//   mapper_combine fwd / bwd        mapping_i(cls) + mapping_patch_i(patches).mean(dim=1)  (:77) and its gradient
+//   transpose                       token-major [B][T][D] <-> channel-major [B][D][LD] at the attention boundary
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+namespace {
+
+inline int grid_for(long total, int cap = 8192) {
+    long b = (total + 255) / 256;
+    return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+__global__ void leaky_fwd_kernel(const float* __restrict__ x, long n, float slope, float* __restrict__ y) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = v > 0.f ? v : v * slope;
+    }
+}
+
+// sign(y) == sign(x) for slope > 0, so the activation output is enough
+__global__ void leaky_bwd_kernel(const float* __restrict__ go, const float* __restrict__ y, long n, float slope,
+                                 float* __restrict__ gx) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        gx[i] = y[i] > 0.f ? go[i] : go[i] * slope;
+}
+
+// dst[d][b] = src[b][d][col] for b < B, 0 for B <= b < 32
+__global__ void gather_col_kernel(const float* __restrict__ src, int B, int D, int LD, int col, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * 32) return;
+    const int d = i >> 5, b = i & 31;
+    dst[i] = b < B ? src[((long)b * D + d) * LD + col] : 0.f;
+}
+
+// out[b][word][d] = cls[d][b] + mean_{t=1..T} patch[b][d][t];  one wave per (b, d)
+__global__ __launch_bounds__(256) void mapper_combine_kernel(const float* __restrict__ cls, const float* __restrict__ patch,
+                                                            int B, int D, int LD, int T, int words, int word,
+                                                            float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= (long)B * D) return;
+    const int b = (int)(row / D), d = (int)(row % D);
+    const float* p = patch + row * LD;
+    float s = 0.f;
+    for (int t = 1 + lane; t <= T; t += 64) s += p[t];
+    s = wave_sum(s);
+    if (lane == 0) out[((long)b * words + word) * D + d] = cls[d * 32 + b] + s / (float)T;
+}
+
+// dcls[d][b] = go[b][word][d] (0 for b >= B);  dpatch[b][d][t] = go[b][word][d] / T for 1 <= t <= T, else 0
+__global__ void mapper_combine_bwd_kernel(const float* __restrict__ go, int B, int D, int LD, int T, int words, int word,
+                                          float* __restrict__ dcls, float* __restrict__ dpatch) {
+    const long total = (long)B * D * LD;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % LD);
+        const long row = i / LD;
+        const int b = (int)(row / D), d = (int)(row % D);
+        const float g = go[((long)b * words + word) * D + d];
+        dpatch[i] = (t >= 1 && t <= T) ? g / (float)T : 0.f;
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)D * 32; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i >> 5), b = (int)(i & 31);
+        dcls[i] = b < B ? go[((long)b * words + word) * D + d] : 0.f;
+    }
+}
+
+// dst[b][c][r] = src[b][r][c] for r < R, 0 for R <= r < LDd   (src [B][R][C] dense, dst [B][C][LDd]); 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int R, int C, int LDd,
+                                                       float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const float* s = src + (long)b * R * C;
+    float* d = dst + (long)b * C * LDd;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < R && c < C) ? s[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < C && r < LDd) d[(long)c * LDd + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+}  // namespace
+
+extern "C" int tdr_leaky_relu_fwd(const float* x, int64_t numel, float slope, float* y, void* stream) {
+    TDR_REQUIRE(x && y && slope > 0.f, "tdr_leaky_relu_fwd: bad argument (slope must be > 0)");
+    hipLaunchKernelGGL(leaky_fwd_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, x, (long)numel, slope, y);
+    TDR_LAUNCH_CHECK("leaky_relu_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_leaky_relu_bwd(const float* go, const float* y, int64_t numel, float slope, float* gx, void* stream) {
+    TDR_REQUIRE(go && y && gx && slope > 0.f, "tdr_leaky_relu_bwd: bad argument (slope must be > 0)");
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, go, y, (long)numel, slope, gx);
+    TDR_LAUNCH_CHECK("leaky_relu_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_gather_col(const float* src, int B, int D, int LD, int col, float* dst, void* stream) {
+    TDR_REQUIRE(src && dst && B > 0 && B <= 32 && col >= 0 && col < LD, "tdr_gather_col: need 1 <= B <= 32 and 0 <= col < LD");
+    hipLaunchKernelGGL(gather_col_kernel, dim3(tdr_cdiv((long)D * 32, 256)), dim3(256), 0, (hipStream_t)stream, src, B, D, LD, col, dst);
+    TDR_LAUNCH_CHECK("gather_col");
+    return TDR_OK;
+}
+
+extern "C" int tdr_mapper_combine(const float* cls, const float* patch, int B, int D, int LD, int T, int words, int word,
+                                  float* out, void* stream) {
+    TDR_REQUIRE(cls && patch && out && B > 0 && B <= 32 && T >= 1 && T < LD && word >= 0 && word < words, "tdr_mapper_combine: bad argument");
+    hipLaunchKernelGGL(mapper_combine_kernel, dim3(tdr_cdiv((long)B * D, 4)), dim3(256), 0, (hipStream_t)stream, cls, patch, B, D,
+                       LD, T, words, word, out);
+    TDR_LAUNCH_CHECK("mapper_combine");
+    return TDR_OK;
+}
+
+extern "C" int tdr_mapper_combine_bwd(const float* go, int B, int D, int LD, int T, int words, int word, float* dcls,
+                                      float* dpatch, void* stream) {
+    TDR_REQUIRE(go && dcls && dpatch && B > 0 && B <= 32 && T >= 1 && T < LD && word >= 0 && word < words, "tdr_mapper_combine_bwd: bad argument");
+    hipLaunchKernelGGL(mapper_combine_bwd_kernel, dim3(grid_for((long)B * D * LD)), dim3(256), 0, (hipStream_t)stream, go, B, D, LD,
+                       T, words, word, dcls, dpatch);
+    TDR_LAUNCH_CHECK("mapper_combine_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_transpose_pad(const float* src, int B, int R, int C, int LDd, float* dst, void* stream) {
+    TDR_REQUIRE(src && dst && LDd >= R, "tdr_transpose_pad: bad argument");
+    hipLaunchKernelGGL(transpose_kernel, dim3(tdr_cdiv(C, 32), tdr_cdiv(LDd, 32), B), dim3(256), 0, (hipStream_t)stream, src, R, C,
+                       LDd, dst);
+    TDR_LAUNCH_CHECK("transpose_pad");
+    return TDR_OK;
+}

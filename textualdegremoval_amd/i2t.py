@@ -1,0 +1,140 @@
+"""Stage-A image-to-text mapping pieces on the HIP kernels -- SURVEY.md 8a rows a29 / a30.
+
+`Mapper` mirrors the class the reference defines in scripts/train/main_train_i2t_mapping.py:40-81 (also
+main_train_tr_mapping.py): same constructor, same parameter names (`mapping_{i}.{0,1,3,4,6,7,9}.*`,
+`mapping_patch_{i}.*`), same default init (the nn.Linear / nn.LayerNorm members are parameter containers; their ATen
+forward is never called).  Forward and backward run in libtdr_hip.so: every Linear is a 1x1 convolution over
+channel-major tokens, nn.LayerNorm the channel LayerNorm kernel (eps 1e-5), LeakyReLU / class-token gather /
+token-mean combine the kernels of csrc/tdr_i2t.hip.
+
+`CrossAttentionFn` / `cross_attention` restate `inj_forward_crossattention` (:197-233).
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .kernels import PACK_DGRAD_S1, PACK_FWD
+
+LN_EPS = 1e-5          # nn.LayerNorm default
+SLOPE = 0.01           # nn.LeakyReLU default
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f'{what}: the HIP path needs tensors on the MI355X; there is no CPU fallback')
+
+
+def _lin_fwd(x, w, b):
+    wp, mp, *_ = K.pack_weights(w.view(w.shape[0], w.shape[1], 1, 1), PACK_FWD)
+    return K.conv_forward(x, wp, mp, w.shape[0], 1, bias=b)
+
+
+def _lin_bwd(dout, x, w, need_dx):
+    """returns (dx or None, dw [out,in], db [out])."""
+    Cout, Cin = w.shape
+    gw, gb = K.conv_wgrad(x, dout, Cout, Cin, 1, want_db=True)
+    dx = None
+    if need_dx:
+        wp, mp, *_ = K.pack_weights(w.view(Cout, Cin, 1, 1), PACK_DGRAD_S1)
+        dx = K.conv_forward(dout, wp, mp, Cin, 1)
+    return dx, gw.view(Cout, Cin), gb
+
+
+def mlp_fwd(x, P, pre):
+    """Linear-LayerNorm-LeakyReLU x3 + Linear (:53-62) on channel-major tokens x [n, Din, h, 32]."""
+    saved = []
+    for j in (0, 3, 6):
+        z = _lin_fwd(x, P[f'{pre}{j}.weight'], P[f'{pre}{j}.bias'])
+        zn, mu, rs = K.layernorm2d_fwd(z, P[f'{pre}{j + 1}.weight'], P[f'{pre}{j + 1}.bias'], LN_EPS)
+        y = K.leaky_relu_fwd(zn, SLOPE)
+        saved.append((x, z, mu, rs, y))
+        x = y
+    return _lin_fwd(x, P[f'{pre}9.weight'], P[f'{pre}9.bias']), (saved, x)
+
+
+def mlp_bwd(dout, P, pre, saved, G):
+    """parameter gradients into G (the input embedding is detached in the reference, :731)."""
+    layers, x_last = saved
+    d, G[f'{pre}9.weight'], G[f'{pre}9.bias'] = _lin_bwd(dout, x_last, P[f'{pre}9.weight'], True)
+    for j, (x, z, mu, rs, y) in zip((6, 3, 0), reversed(layers)):
+        dzn = K.leaky_relu_bwd(d, y, SLOPE)
+        dz, G[f'{pre}{j + 1}.weight'], G[f'{pre}{j + 1}.bias'] = K.layernorm2d_bwd(dzn, z, mu, rs, P[f'{pre}{j + 1}.weight'])
+        d, G[f'{pre}{j}.weight'], G[f'{pre}{j}.bias'] = _lin_bwd(dz, x, P[f'{pre}{j}.weight'], j > 0)
+
+
+def mapper_fwd(tok, T, P, num_words):
+    """tok [B, Din, LD/32, 32] channel-major (column 0 class token, 1..T patches) -> ([B, words, Dout], saved)."""
+    B = tok.shape[0]
+    if B > 32:
+        raise NotImplementedError('HIP Mapper: batch <= 32 per call (class tokens travel as one 32-pixel row)')
+    cls_in = K.gather_col(tok, 0)                                     # embs[:, :1]
+    dout_dim = P['mapping_0.9.weight'].shape[0]
+    out = torch.empty(B, num_words, dout_dim, dtype=torch.float32, device=tok.device)
+    saved = []
+    for i in range(num_words):
+        c, sv_c = mlp_fwd(cls_in, P, f'mapping_{i}.')
+        p, sv_p = mlp_fwd(tok, P, f'mapping_patch_{i}.')
+        K.mapper_combine(c, p, T, out, i)
+        saved.append((sv_c, sv_p))
+    return out, (saved, tok.shape[2] * tok.shape[3], T)
+
+
+def mapper_bwd(dout, P, num_words, saved):
+    sv, LD, T = saved
+    G = {}
+    dout = dout.contiguous()
+    for i in range(num_words):
+        dc, dp = K.mapper_combine_bwd(dout, LD, T, i)
+        mlp_bwd(dc, P, f'mapping_{i}.', sv[i][0], G)
+        mlp_bwd(dp, P, f'mapping_patch_{i}.', sv[i][1], G)
+    return G
+
+
+class _MapperFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, T, names, num_words, *params):
+        _require_gpu(tok, 'Mapper')
+        P = dict(zip(names, [p.detach() for p in params]))
+        out, saved = mapper_fwd(tok.contiguous(), T, P, num_words)
+        ctx.names, ctx.P, ctx.saved, ctx.num_words = names, P, saved, num_words
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        G = mapper_bwd(dout, ctx.P, ctx.num_words, ctx.saved)
+        ctx.saved = None
+        return (None, None, None, None) + tuple(G[k] for k in ctx.names)
+
+
+class Mapper(nn.Module):
+    def __init__(self, input_dim: int, output_dim: int, num_words: int):
+        super().__init__()
+        self.num_words = num_words
+
+        def mlp():
+            return nn.Sequential(nn.Linear(input_dim, 1280), nn.LayerNorm(1280), nn.LeakyReLU(),
+                                 nn.Linear(1280, 1280), nn.LayerNorm(1280), nn.LeakyReLU(),
+                                 nn.Linear(1280, 1280), nn.LayerNorm(1280), nn.LeakyReLU(),
+                                 nn.Linear(1280, output_dim))
+        for i in range(self.num_words):
+            setattr(self, f'mapping_{i}', mlp())
+            setattr(self, f'mapping_patch_{i}', mlp())
+
+    def forward(self, embs):
+        """embs: list whose first entry is the image embedding -- either the reference's token-major tensor
+        [B, 1+T, D] (transposed on the device here), or the `(tokens, T)` pair ClipVisionEncoder returns
+        (already channel-major, no transpose)."""
+        e = embs[0]
+        if isinstance(e, tuple):
+            tok, T = e
+        else:
+            _require_gpu(e, 'Mapper')
+            B, T1, D = e.shape
+            T = T1 - 1
+            LD = K.token_ld(T)
+            tok = K.transpose_pad(e.detach().contiguous(), LD).view(B, D, LD // 32, 32)
+        names, params = [], []
+        for k, p in self.named_parameters():
+            names.append(k)
+            params.append(p)
+        return _MapperFn.apply(tok, T, names, self.num_words, *params)

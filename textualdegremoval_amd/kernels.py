@@ -707,3 +707,57 @@ def pixel_shuffle2(x):
     out = torch.empty(N, C4 // 4, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
     check(_lib.load().tdr_pixel_shuffle2(x.data_ptr(), N, C4 // 4, H, W, out.data_ptr(), _stream()), 'tdr_pixel_shuffle2')
     return out
+
+
+# ------------------------------------------------------------------ stage-A mapper glue (main_train_i2t_mapping.py:40-81)
+def leaky_relu_fwd(x, slope=0.01):
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    check(_lib.load().tdr_leaky_relu_fwd(x.data_ptr(), x.numel(), float(slope), y.data_ptr(), _stream()), 'tdr_leaky_relu_fwd')
+    return y
+
+
+def leaky_relu_bwd(go, y, slope=0.01):
+    assert go.is_contiguous() and y.is_contiguous()
+    gx = torch.empty_like(go)
+    check(_lib.load().tdr_leaky_relu_bwd(go.data_ptr(), y.data_ptr(), go.numel(), float(slope), gx.data_ptr(), _stream()),
+          'tdr_leaky_relu_bwd')
+    return gx
+
+
+def gather_col(tok, col=0):
+    """tok [B, D, LD/32, 32] -> [1, D, 1, 32]: column `col` of every image as pixel b (zero-padded to 32)"""
+    B, D = tok.shape[0], tok.shape[1]
+    LD = tok.shape[2] * tok.shape[3]
+    assert tok.is_contiguous()
+    out = torch.empty(1, D, 1, 32, dtype=torch.float32, device=tok.device)
+    check(_lib.load().tdr_gather_col(tok.data_ptr(), B, D, LD, col, out.data_ptr(), _stream()), 'tdr_gather_col')
+    return out
+
+
+def mapper_combine(cls_out, patch_out, T, out, word):
+    """out[:, word] = cls_out[d][b] + mean over the T patch columns of patch_out"""
+    B, D = patch_out.shape[0], patch_out.shape[1]
+    LD = patch_out.shape[2] * patch_out.shape[3]
+    check(_lib.load().tdr_mapper_combine(cls_out.data_ptr(), patch_out.data_ptr(), B, D, LD, T, out.shape[1], word, out.data_ptr(),
+                                         _stream()), 'tdr_mapper_combine')
+
+
+def mapper_combine_bwd(go, LD, T, word):
+    B, words, D = go.shape
+    assert go.is_contiguous()
+    dcls = torch.empty(1, D, 1, 32, dtype=torch.float32, device=go.device)
+    dpatch = torch.empty(B, D, LD // 32, 32, dtype=torch.float32, device=go.device)
+    check(_lib.load().tdr_mapper_combine_bwd(go.data_ptr(), B, D, LD, T, words, word, dcls.data_ptr(), dpatch.data_ptr(),
+                                             _stream()), 'tdr_mapper_combine_bwd')
+    return dcls, dpatch
+
+
+def transpose_pad(src, LDd=None):
+    """src [B, R, C] -> [B, C, LDd] with dst[b][c][r] = src[b][r][c], zero for r >= R"""
+    B, R, Cc = src.shape
+    assert src.is_contiguous()
+    LDd = R if LDd is None else LDd
+    out = torch.empty(B, Cc, LDd, dtype=torch.float32, device=src.device)
+    check(_lib.load().tdr_transpose_pad(src.data_ptr(), B, R, Cc, LDd, out.data_ptr(), _stream()), 'tdr_transpose_pad')
+    return out
