@@ -298,6 +298,16 @@ int tdr_mapper_combine(const float* cls, const float* patch, int B, int D, int L
 /* gradient of the above w.r.t. cls [D][32] and patch [B][D][LD] (go [B][words][D]) */
 int tdr_mapper_combine_bwd(const float* go, int B, int D, int LD, int T, int words, int word, float* dcls, float* dpatch,
                            void* stream);
+/* softmax(Q K^T * scale) V with separate tensors (inj_forward_crossattention :216-225): q [B][C][LDq] (Tq valid columns),
+ * k, v [B][C][LDk] (Tk valid), channel-major, heads split along C (head dim C/heads in {16,32,64,80}) -> out [B][C][LDq]
+ * (padding columns zeroed); lse [B][heads][LDq] (may be NULL) = log-sum-exp of the scaled scores, kept for the backward */
+int tdr_cross_attention_fwd(const float* q, const float* k, const float* v, int B, int C, int heads, int Tq, int LDq,
+                            int Tk, int LDk, float scale, float* out, float* lse, void* stream);
+/* gradient of the above: dout [B][C][LDq] -> dq [B][C][LDq], dk, dv [B][C][LDk] (padding columns zeroed).
+ * Two deterministic passes (per-query-tile dq, per-key-tile dk/dv), no atomics.  ws >= B*heads*LDq floats. */
+int tdr_cross_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                            const float* lse, int B, int C, int heads, int Tq, int LDq, int Tk, int LDk, float scale,
+                            float* dq, float* dk, float* dv, float* ws, void* stream);
 /* dst[b][c][r] = src[b][r][c] (r < R), 0 for R <= r < LDd: token-major [B][T][D] <-> channel-major [B][D][LD] */
 int tdr_transpose_pad(const float* src, int B, int R, int C, int LDd, float* dst, void* stream);
 

@@ -112,3 +112,56 @@ def test_mapper_on_channel_major_clip_tokens_matches_oracle(K):
     out = mp([enc.tokens(x.cuda())])
     ref = IO.mapper_forward(P, IO.clip_vision_tokens(sd, x, 4), 2)
     assert maxdiff(out, ref) < 1e-4
+
+
+@pytest.mark.parametrize('tag', ['x', 's'])
+def test_injected_cross_attention_vs_reference_golden(K, tag):
+    """inj_forward_crossattention forward + all gradients (hidden, context, the five weight tensors)."""
+    from textualdegremoval_amd.i2t import cross_attention
+    g = gold('i2t_xattn')
+    dq, dc, inner, heads, B, Tq, Tk = [int(v) for v in g[tag + '_cfg']]
+    P = {k[len(tag) + 3:]: T(g[k]).cuda().requires_grad_(True) for k in g.files if k.startswith(tag + '_p_')}
+    hid = T(g[tag + '_hid']).cuda().requires_grad_(True)
+    ctx = T(g[tag + '_ctx']).cuda().requires_grad_(True) if Tk else None
+    out = cross_attention(P, hid, ctx, heads, (inner // heads) ** -0.5)
+    assert maxdiff(out, T(g[tag + '_out'])) < 1e-4
+    (out * T(g[tag + '_go']).cuda()).sum().backward()
+    assert maxdiff(hid.grad, T(g[tag + '_ghid'])) < 1e-4
+    if Tk:
+        assert maxdiff(ctx.grad, T(g[tag + '_gctx'])) < 1e-4
+    for k, p in P.items():
+        key = f'{tag}_g_{k}'
+        if key in g.files:
+            assert maxdiff(p.grad, T(g[key])) < 2e-4 * max(1.0, np.abs(g[key]).max()), k
+
+
+@pytest.mark.parametrize('hd,Tq,Tk', [(16, 70, 33), (64, 200, 77), (80, 130, 140)])
+def test_cross_attention_kernels_vs_torch(K, hd, Tq, Tk):
+    """the attention core alone (forward, lse, dq / dk / dv) at ragged lengths and every supported head dim."""
+    gen = torch.Generator().manual_seed(hd + Tq)
+    B, heads = 2, 2
+    C = heads * hd
+    LDq, LDk = (Tq + 31) // 32 * 32, (Tk + 31) // 32 * 32
+    q = torch.randn(B, C, Tq, generator=gen, requires_grad=True)
+    k = torch.randn(B, C, Tk, generator=gen, requires_grad=True)
+    v = torch.randn(B, C, Tk, generator=gen, requires_grad=True)
+    scale = hd ** -0.5
+    sh = lambda z: z.reshape(B, heads, hd, -1)
+    att = torch.softmax(torch.einsum('bhdq,bhdk->bhqk', sh(q), sh(k)) * scale, dim=-1)
+    out = torch.einsum('bhqk,bhdk->bhdq', att, sh(v)).reshape(B, C, Tq)
+    go = torch.randn(B, C, Tq, generator=gen)
+    out.backward(go)
+
+    def pad(z, LD):
+        o = torch.zeros(B, C, LD)
+        o[:, :, :z.shape[2]] = z.detach()
+        return o.cuda().view(B, C, LD // 32, 32)
+    qd, kd, vd = pad(q, LDq), pad(k, LDk), pad(v, LDk)
+    o, lse = K.cross_attention_fwd(qd, kd, vd, heads, scale, Tq, Tk)
+    assert maxdiff(o.reshape(B, C, LDq)[:, :, :Tq], out) < 2e-5
+    assert o.reshape(B, C, LDq)[:, :, Tq:].abs().max().item() == 0
+    dq, dk, dv = K.cross_attention_bwd(qd, kd, vd, o, pad(go, LDq), lse, heads, scale, Tq, Tk)
+    assert maxdiff(dq.reshape(B, C, LDq)[:, :, :Tq], q.grad) < 5e-5
+    assert maxdiff(dk.reshape(B, C, LDk)[:, :, :Tk], k.grad) < 5e-5
+    assert maxdiff(dv.reshape(B, C, LDk)[:, :, :Tk], v.grad) < 5e-5
+    assert dq.reshape(B, C, LDq)[:, :, Tq:].abs().max().item() == 0 and dk.reshape(B, C, LDk)[:, :, Tk:].abs().max().item() == 0

@@ -101,6 +101,9 @@ SIGNATURES = {
     'tdr_gather_col': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_mapper_combine': (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_mapper_combine_bwd': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_cross_attention_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, f32, c_fp, c_fp, c_fp]),
+    'tdr_cross_attention_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, f32, c_fp, c_fp,
+                                      c_fp, c_fp, c_fp]),
     'tdr_transpose_pad': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_sca_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, c_fp, c_fp]),
     'tdr_sca_bwd': (i32, [c_fp] * 8 + [i32, i32] + [c_fp] * 7 + [c_fp]),

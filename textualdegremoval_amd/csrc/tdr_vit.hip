@@ -87,20 +87,31 @@ __global__ void vit_assemble_kernel(float* __restrict__ tok, const float* __rest
 // contraction walks the keys in the accumulator's own row order (key(s, half) = (s&3) + 8(s>>2) + 4 half) -- no LDS
 // round trip, no transposes.  Output columns (queries) are contiguous across lanes: coalesced stores.
 // qkv [B][3C][LD] channel-major: q rows h*HD.., k rows C + h*HD.., v rows 2C + h*HD..;  out [B][C][LD].
+// Separate q / k / v tensors (cross-attention: Tq queries, Tk keys; lse optional = m + log(l) per query, for the backward).
+struct AttnArgs {
+    const float* q; long q_bs; int LDq, Tq;           // [B][C][LDq]
+    const float* k; const float* v; long kv_bs; int LDk, Tk;
+    int C; float scale;
+    float* out;                                        // [B][C][LDq]
+    float* lse;                                        // [B][heads][LDq] or null
+};
+
 template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int C, int T, int LD, float scale,
-                                                      float* __restrict__ out) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     constexpr int NDT = (HD + 31) / 32;
     __shared__ float sK[HD][33], sV[HD][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
     const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
-    const float* Q = qkv + ((long)b * 3 * C + h * HD) * LD;
-    const float* Kp = Q + (long)C * LD;
-    const float* Vp = Kp + (long)C * LD;
-    const bool qok = q0 + j < T;
+    const int C = a.C, T = a.Tk, LD = a.LDk, LDq = a.LDq;
+    const float scale = a.scale;
+    float* out = a.out;
+    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * LDq;
+    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * LD;
+    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * LD;
+    const bool qok = q0 + j < a.Tq;
     float qb[HD / 2];                                      // B operand of S^T: Q[q = j][d = 2s + kk] * scale
 #pragma unroll
-    for (int s = 0; s < HD / 2; ++s) qb[s] = qok ? Q[(long)(2 * s + kk) * LD + q0 + j] * scale : 0.f;
+    for (int s = 0; s < HD / 2; ++s) qb[s] = qok ? Q[(long)(2 * s + kk) * LDq + q0 + j] * scale : 0.f;
     f32x16 o[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
@@ -158,13 +169,200 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
     }
     const float inv = 1.f / l;
-    if (q0 + j < LD) {
+    if (q0 + j < LDq) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (d < HD) out[((long)b * C + h * HD + d) * LD + q0 + j] = qok ? o[dt][r] * inv : 0.f;
+                if (d < HD) out[((long)b * C + h * HD + d) * LDq + q0 + j] = qok ? o[dt][r] * inv : 0.f;
+            }
+        if (a.lse && kk == 0) a.lse[((long)b * gridDim.y + h) * LDq + q0 + j] = qok ? m + __logf(l) : 0.f;
+    }
+}
+
+// ---- backward (injected cross-attention of the stage-A trainers, main_train_i2t_mapping.py:197-233) ----------------
+// Two deterministic passes instead of one with atomics:
+//   attn_bwd_dq : one wave per 32 queries, walks the key tiles (same skeleton as the forward: S^T, then dP^T = V dO^T
+//                 with the same operand roles, dS^T = P^T (dP^T - D), dQ^T += K^T dS^T in the accumulator's row order)
+//   attn_bwd_dkv: one wave per 32 keys, walks the query tiles with the roles of q and k swapped
+//                 (S = Q K^T rows = queries; dV^T += dO^T P, dK^T += Q^T dS)
+// D[q] = sum_d dO[d][q] O[d][q] comes from attn_rowdot_kernel.
+struct AttnBwdArgs {
+    const float* q; long q_bs; int LDq, Tq;
+    const float* k; const float* v; long kv_bs; int LDk, Tk;
+    const float* dout;                                 // [B][C][LDq]
+    const float* lse; const float* D;                  // [B][heads][LDq]
+    int C; float scale;
+    float* dq;                                         // [B][C][LDq]
+    float* dk; float* dv; long dkv_bs;                 // [B][C][LDk]
+};
+
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(const float* __restrict__ dout, const float* __restrict__ o, int C,
+                                                         int hd, int LD, int T, float* __restrict__ D) {
+    const int t = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (t >= LD) return;
+    float s = 0.f;
+    if (t < T) {
+        const long base = ((long)b * C + (long)h * hd) * LD + t;
+        for (int d = 0; d < hd; ++d) s += dout[base + (long)d * LD] * o[base + (long)d * LD];
+    }
+    D[((long)b * gridDim.y + h) * LD + t] = s;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+    constexpr int NDT = (HD + 31) / 32;
+    __shared__ float sK[HD][33], sV[HD][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
+    const int C = a.C, T = a.Tk, LD = a.LDk, LDq = a.LDq;
+    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * LDq;
+    const float* dO = a.dout + ((long)b * C + (long)h * HD) * LDq;
+    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * LD;
+    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * LD;
+    const bool qok = q0 + j < a.Tq;
+    const int qc = qok ? q0 + j : 0;
+    float qb[HD / 2], dob[HD / 2];
+#pragma unroll
+    for (int s = 0; s < HD / 2; ++s) {
+        qb[s] = qok ? Q[(long)(2 * s + kk) * LDq + qc] * a.scale : 0.f;
+        dob[s] = qok ? dO[(long)(2 * s + kk) * LDq + qc] : 0.f;
+    }
+    const float lse = a.lse[((long)b * gridDim.y + h) * LDq + qc], Dq = a.D[((long)b * gridDim.y + h) * LDq + qc];
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    for (int key0 = 0; key0 < T; key0 += 32) {
+        __syncthreads();
+        for (int e = tid; e < HD * 32; e += 256) {
+            const int d = e >> 5, kx = e & 31;
+            const bool kok = key0 + kx < T;
+            const int kc = kok ? key0 + kx : T - 1;
+            const float kv = Kp[(long)d * LD + kc], vv = Vp[(long)d * LD + kc];
+            sK[d][kx] = kok ? kv : 0.f;
+            sV[d][kx] = kok ? vv : 0.f;
+        }
+        __syncthreads();
+        f32x16 st, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < HD / 2; ++s) {
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[2 * s + kk][j], qb[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[2 * s + kk][j], dob[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const float p = (key < T && qok) ? __expf(st[r] - lse) : 0.f;
+            st[r] = p * (dp[r] - Dq) * a.scale;                               // dS^T * scale
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const int d = dt * 32 + j;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int kx = (s & 3) + 8 * (s >> 2) + 4 * kk;
+                const float av = d < HD ? sK[d < HD ? d : 0][kx] : 0.f;
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, st[s], acc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (q0 + j < LDq) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (d < HD) a.dq[((long)b * C + h * HD + d) * LDq + q0 + j] = qok ? acc[dt][r] : 0.f;
+            }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
+    constexpr int NDT = (HD + 31) / 32;
+    __shared__ float sQ[HD][33], sO[HD][33], sL[32], sD[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
+    const int k0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
+    const int C = a.C, Tk = a.Tk, LDk = a.LDk, LDq = a.LDq, Tq = a.Tq;
+    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * LDq;
+    const float* dO = a.dout + ((long)b * C + (long)h * HD) * LDq;
+    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * LDk;
+    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * LDk;
+    const float* lsep = a.lse + ((long)b * gridDim.y + h) * LDq;
+    const float* Dp = a.D + ((long)b * gridDim.y + h) * LDq;
+    const bool kok = k0 + j < Tk;
+    const int kc = kok ? k0 + j : 0;
+    float kb[HD / 2], vb[HD / 2];
+#pragma unroll
+    for (int s = 0; s < HD / 2; ++s) {
+        kb[s] = kok ? Kp[(long)(2 * s + kk) * LDk + kc] * a.scale : 0.f;
+        vb[s] = kok ? Vp[(long)(2 * s + kk) * LDk + kc] : 0.f;
+    }
+    f32x16 ak[NDT], av_[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ak[dt][r] = 0.f; av_[dt][r] = 0.f; }
+    for (int qt = 0; qt < Tq; qt += 32) {
+        __syncthreads();
+        for (int e = tid; e < HD * 32; e += 256) {
+            const int d = e >> 5, qx = e & 31;
+            const bool ok = qt + qx < Tq;
+            const int qc = ok ? qt + qx : Tq - 1;
+            const float qv = Q[(long)d * LDq + qc], ov = dO[(long)d * LDq + qc];
+            sQ[d][qx] = ok ? qv : 0.f;
+            sO[d][qx] = ok ? ov : 0.f;
+        }
+        if (tid < 32) {
+            const bool ok = qt + tid < Tq;
+            sL[tid] = ok ? lsep[qt + tid] : 0.f;
+            sD[tid] = ok ? Dp[qt + tid] : 0.f;
+        }
+        __syncthreads();
+        f32x16 st, dp;                                     // S tile: rows = queries, column j = this lane's key
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < HD / 2; ++s) {
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[2 * s + kk][j], kb[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sO[2 * s + kk][j], vb[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qx = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const float p = (qt + qx < Tq && kok) ? __expf(st[r] - sL[qx]) : 0.f;
+            st[r] = p;                                     // P
+            dp[r] = p * (dp[r] - sD[qx]) * a.scale;        // dS * scale
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const int d = dt * 32 + j;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int qx = (s & 3) + 8 * (s >> 2) + 4 * kk;
+                const float ao = d < HD ? sO[d < HD ? d : 0][qx] : 0.f;
+                const float aq = d < HD ? sQ[d < HD ? d : 0][qx] : 0.f;
+                av_[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, st[s], av_[dt], 0, 0, 0);     // dV^T += dO^T P
+                ak[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, dp[s], ak[dt], 0, 0, 0);       // dK^T += Q^T dS
+            }
+        }
+    }
+    if (k0 + j < LDk) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (d < HD) {
+                    const long o = (long)b * a.dkv_bs + ((long)h * HD + d) * LDk + k0 + j;
+                    a.dk[o] = kok ? ak[dt][r] : 0.f;
+                    a.dv[o] = kok ? av_[dt][r] : 0.f;
+                }
             }
     }
 }
@@ -259,17 +457,54 @@ extern "C" int tdr_vit_assemble(float* tok, const float* cls, const float* pos, 
     return TDR_OK;
 }
 
+static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st) {
+    const int hd = a.C / heads;
+    dim3 grid(tdr_cdiv(a.LDq, 128), heads, B);
+    if (hd == 80) hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, dim3(256), 0, st, a);
+    else if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, a);
+    else if (hd == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, a);
+    else if (hd == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, a);
+    else { tdr_set_error("attention: head dim %d not supported (16, 32, 64, 80)", hd); return TDR_ERR_UNSUPPORTED; }
+    TDR_LAUNCH_CHECK("attention_fwd");
+    return TDR_OK;
+}
+
 extern "C" int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream) {
     TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T, "tdr_attention_fwd: bad argument");
-    const int hd = C / heads;
-    dim3 grid(tdr_cdiv(LD, 128), heads, B);
+    AttnArgs a{qkv, 3L * C * LD, LD, T, qkv + (long)C * LD, qkv + 2L * C * LD, 3L * C * LD, LD, T, C, scale, out, nullptr};
+    return attn_fwd_launch(a, B, heads, (hipStream_t)stream);
+}
+
+extern "C" int tdr_cross_attention_fwd(const float* q, const float* k, const float* v, int B, int C, int heads, int Tq, int LDq,
+                                       int Tk, int LDk, float scale, float* out, float* lse, void* stream) {
+    TDR_REQUIRE(q && k && v && out && heads > 0 && C % heads == 0 && LDq >= Tq && LDk >= Tk && Tq > 0 && Tk > 0,
+                "tdr_cross_attention_fwd: bad argument");
+    AttnArgs a{q, (long)C * LDq, LDq, Tq, k, v, (long)C * LDk, LDk, Tk, C, scale, out, lse};
+    return attn_fwd_launch(a, B, heads, (hipStream_t)stream);
+}
+
+extern "C" int tdr_cross_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                       const float* lse, int B, int C, int heads, int Tq, int LDq, int Tk, int LDk, float scale,
+                                       float* dq, float* dk, float* dv, float* ws, void* stream) {
+    TDR_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && ws, "tdr_cross_attention_bwd: null pointer (ws: B*heads*LDq floats)");
+    TDR_REQUIRE(heads > 0 && C % heads == 0 && LDq >= Tq && LDk >= Tk && Tq > 0 && Tk > 0, "tdr_cross_attention_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 80) hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
-    else if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
-    else if (hd == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
-    else if (hd == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, qkv, C, T, LD, scale, out);
-    else { tdr_set_error("tdr_attention_fwd: head dim %d not supported (16, 32, 64)", hd); return TDR_ERR_UNSUPPORTED; }
-    TDR_LAUNCH_CHECK("attention_fwd");
+    const int hd = C / heads;
+    hipLaunchKernelGGL(attn_rowdot_kernel, dim3(tdr_cdiv(LDq, 256), heads, B), dim3(256), 0, st, dout, out, C, hd, LDq, Tq, ws);
+    AttnBwdArgs a{q, (long)C * LDq, LDq, Tq, k, v, (long)C * LDk, LDk, Tk, dout, lse, ws, C, scale, dq, dk, dv, (long)C * LDk};
+    dim3 gq(tdr_cdiv(LDq, 128), heads, B), gk(tdr_cdiv(LDk, 128), heads, B);
+#define ATTN_BWD(H)                                                                            \
+    do {                                                                                       \
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<H>, gq, dim3(256), 0, st, a);                    \
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<H>, gk, dim3(256), 0, st, a);                   \
+    } while (0)
+    if (hd == 80) ATTN_BWD(80);
+    else if (hd == 64) ATTN_BWD(64);
+    else if (hd == 32) ATTN_BWD(32);
+    else if (hd == 16) ATTN_BWD(16);
+    else { tdr_set_error("tdr_cross_attention_bwd: head dim %d not supported (16, 32, 64, 80)", hd); return TDR_ERR_UNSUPPORTED; }
+#undef ATTN_BWD
+    TDR_LAUNCH_CHECK("cross_attention_bwd");
     return TDR_OK;
 }
 

@@ -138,3 +138,83 @@ class Mapper(nn.Module):
             names.append(k)
             params.append(p)
         return _MapperFn.apply(tok, T, names, self.num_words, *params)
+
+
+# ---------------------------------------------------------------------------- a30 injected cross-attention
+def _ld(T):
+    return (T + 31) // 32 * 32
+
+
+def _to_cm(x, LD):
+    """token-major [B, T, D] -> channel-major [B, D, LD/32, 32] (zero-padded columns)"""
+    B, T, D = x.shape
+    return K.transpose_pad(x.contiguous(), LD).view(B, D, LD // 32, 32)
+
+
+def _to_tm(x, T):
+    """channel-major [B, D, LD/32, 32] -> token-major [B, T, D]"""
+    B, D = x.shape[0], x.shape[1]
+    LD = x.shape[2] * x.shape[3]
+    return K.transpose_pad(x.reshape(B, D, LD), D)[:, :T]
+
+
+def _lin_nobias_bwd(dout, x, w, need_dx=True):
+    Cout, Cin = w.shape
+    gw = K.conv_wgrad(x, dout, Cout, Cin, 1).view(Cout, Cin)
+    dx = None
+    if need_dx:
+        wp, mp, *_ = K.pack_weights(w.view(Cout, Cin, 1, 1), PACK_DGRAD_S1)
+        dx = K.conv_forward(dout, wp, mp, Cin, 1)
+    return dx, gw
+
+
+class CrossAttentionFn(torch.autograd.Function):
+    """`inj_forward_crossattention` (main_train_i2t_mapping.py:197-233): q = to_q(hidden); k, v = to_k_global /
+    to_v_global (context) when a context is given, to_k / to_v (hidden) otherwise; heads split (:85-98);
+    softmax(q k^T * scale) v; to_out[0] (Linear with bias; to_out[1] is Dropout(0))."""
+
+    @staticmethod
+    def forward(ctx, hidden, context, wq, wk, wv, wo, bo, heads, scale):
+        _require_gpu(hidden, 'cross_attention')
+        B, Tq, _ = hidden.shape
+        LDq = _ld(Tq)
+        hcm = _to_cm(hidden.detach(), LDq)
+        if context is None:
+            ccm, Tk = hcm, Tq
+        else:
+            Tk = context.shape[1]
+            ccm = _to_cm(context.detach(), _ld(Tk))
+        q = _lin_fwd(hcm, wq.detach(), None)
+        k = _lin_fwd(ccm, wk.detach(), None)
+        v = _lin_fwd(ccm, wv.detach(), None)
+        a, lse = K.cross_attention_fwd(q, k, v, heads, scale, Tq, Tk)
+        o = _lin_fwd(a, wo.detach(), bo.detach())
+        ctx.save_for_backward(hcm, ccm, q, k, v, a, lse, wq, wk, wv, wo)
+        ctx.meta = (heads, scale, Tq, Tk, context is None)
+        return _to_tm(o, Tq).contiguous()
+
+    @staticmethod
+    def backward(ctx, dout):
+        hcm, ccm, q, k, v, a, lse, wq, wk, wv, wo = ctx.saved_tensors
+        heads, scale, Tq, Tk, self_attn = ctx.meta
+        do = _to_cm(dout.contiguous(), hcm.shape[2] * hcm.shape[3])
+        da, gwo, gbo = _lin_bwd(do, a, wo.detach(), True)
+        dq, dk, dv = K.cross_attention_bwd(q, k, v, a, da, lse, heads, scale, Tq, Tk)
+        dh, gwq = _lin_nobias_bwd(dq, hcm, wq.detach())
+        dc1, gwk = _lin_nobias_bwd(dk, ccm, wk.detach())
+        dc2, gwv = _lin_nobias_bwd(dv, ccm, wv.detach())
+        dc = K.add_(dc1, dc2)
+        if self_attn:
+            dh = K.add_(dh, dc)
+            dctx = None
+        else:
+            dctx = _to_tm(dc, Tk).contiguous()
+        return _to_tm(dh, Tq).contiguous(), dctx, gwq, gwk, gwv, gwo, gbo, None, None
+
+
+def cross_attention(P, hidden, context, heads, scale):
+    """P: dict with the attention module's parameters (to_q / to_k / to_v / to_k_global / to_v_global `.weight`,
+    to_out.0.weight / .bias); hidden [B,Tq,Dq], context [B,Tk,Dc] or None -- the tensors the reference function sees."""
+    kn, vn = ('to_k', 'to_v') if context is None else ('to_k_global', 'to_v_global')
+    return CrossAttentionFn.apply(hidden, context, P['to_q.weight'], P[kn + '.weight'], P[vn + '.weight'],
+                                  P['to_out.0.weight'], P['to_out.0.bias'], heads, scale)

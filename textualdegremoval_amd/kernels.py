@@ -761,3 +761,27 @@ def transpose_pad(src, LDd=None):
     out = torch.empty(B, Cc, LDd, dtype=torch.float32, device=src.device)
     check(_lib.load().tdr_transpose_pad(src.data_ptr(), B, R, Cc, LDd, out.data_ptr(), _stream()), 'tdr_transpose_pad')
     return out
+
+
+def cross_attention_fwd(q, k, v, heads, scale, Tq, Tk):
+    """q [B,C,LDq/32,32] (Tq valid columns), k/v [B,C,LDk/32,32] (Tk valid) -> (out like q, lse [B,heads,LDq])"""
+    B, Cc = q.shape[0], q.shape[1]
+    LDq, LDk = q.shape[2] * q.shape[3], k.shape[2] * k.shape[3]
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    out = torch.empty_like(q)
+    lse = torch.empty(B, heads, LDq, dtype=torch.float32, device=q.device)
+    check(_lib.load().tdr_cross_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), B, Cc, heads, Tq, LDq, Tk, LDk,
+                                              float(scale), out.data_ptr(), lse.data_ptr(), _stream()), 'tdr_cross_attention_fwd')
+    return out, lse
+
+
+def cross_attention_bwd(q, k, v, out, dout, lse, heads, scale, Tq, Tk):
+    B, Cc = q.shape[0], q.shape[1]
+    LDq, LDk = q.shape[2] * q.shape[3], k.shape[2] * k.shape[3]
+    assert dout.is_contiguous() and out.is_contiguous()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ws = workspace(B * heads * LDq, q.device, 'xattn')
+    check(_lib.load().tdr_cross_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                              lse.data_ptr(), B, Cc, heads, Tq, LDq, Tk, LDk, float(scale), dq.data_ptr(),
+                                              dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), _stream()), 'tdr_cross_attention_bwd')
+    return dq, dk, dv
