@@ -25,6 +25,31 @@ def _put(G, pre, g):
         G[pre + k] = v
 
 
+# Weight gradients run on the side stream (kernels.on_side).  A backward helper called on its own joins the side
+# branch before it returns (its results are then ordinary current-stream tensors); inside a whole-network backward
+# the joins are deferred to the end so the weight-gradient branch overlaps the data-gradient chain of later layers.
+_defer_join = 0
+
+
+class deferred_join:
+    def __enter__(self):
+        global _defer_join
+        _defer_join += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _defer_join
+        _defer_join -= 1
+        if _defer_join == 0:
+            K.side_join()
+        return False
+
+
+def maybe_join():
+    if _defer_join == 0:
+        K.side_join()
+
+
 # ---------------------------------------------------------------------------
 # NAFBlock / NAFResFuseBlock   models/archs/network_nafnet_guided_arch.py:178-302
 # ---------------------------------------------------------------------------
@@ -55,24 +80,27 @@ def naf_bwd(dout, P, saved):
     dev = x.device
     G = {}
     beta, gamma = P['beta'].view(-1), P['gamma'].view(-1)
-    # ---- conv5 / gamma chain
-    G5, S5 = K.conv_wgrad(t4, dout, c_out, c, 1, gate=True, want_db=True)
-    dw5, db5, dgam = K.scaled_conv_param_grads(G5.view(c_out, c), S5, P['conv5.weight'], P['conv5.bias'], gamma)
-    if c_out == c:
-        G['conv5.weight'], G['conv5.bias'], G['gamma'] = dw5.view(c, c, 1, 1), db5, dgam.view(1, c, 1, 1)
-    else:
+    # ---- conv5 / gamma chain (parameter gradients only: side stream, off the data-gradient chain)
+    if c_out != c:
         fw = torch.zeros(c, c, 1, 1, dtype=torch.float32, device=dev)
         fb = torch.zeros(c, dtype=torch.float32, device=dev)
         fg = torch.zeros(1, c, 1, 1, dtype=torch.float32, device=dev)
-        K.copy_rows(dw5, 0, fw, 0, 1, c_out * c)
-        K.copy_rows(db5, 0, fb, 0, 1, c_out)
-        K.copy_rows(dgam, 0, fg, 0, 1, c_out)
-        G['conv5.weight'], G['conv5.bias'], G['gamma'] = fw, fb, fg
+    with K.on_side(t4, dout):
+        G5, S5 = K.side_keep(*K.conv_wgrad(t4, dout, c_out, c, 1, gate=True, want_db=True))
+        dw5, db5, dgam = K.side_keep(*K.scaled_conv_param_grads(G5.view(c_out, c), S5, P['conv5.weight'], P['conv5.bias'], gamma))
+        if c_out == c:
+            G['conv5.weight'], G['conv5.bias'], G['gamma'] = dw5.view(c, c, 1, 1), db5, dgam.view(1, c, 1, 1)
+        else:
+            K.copy_rows(dw5, 0, fw, 0, 1, c_out * c)
+            K.copy_rows(db5, 0, fb, 0, 1, c_out)
+            K.copy_rows(dgam, 0, fg, 0, 1, c_out)
+            G['conv5.weight'], G['conv5.bias'], G['gamma'] = fw, fb, fg
     wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
     dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
     # ---- conv4
-    g4, G['conv4.bias'] = K.conv_wgrad(yn, dt4, 2 * c, c, 1, want_db=True)
-    G['conv4.weight'] = g4.view(2 * c, c, 1, 1)
+    with K.on_side(yn, dt4):
+        g4, G['conv4.bias'] = K.conv_wgrad(yn, dt4, 2 * c, c, 1, want_db=True)
+        G['conv4.weight'] = g4.view(2 * c, c, 1, 1)
     wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)
     dyn = K.conv_forward(dt4, wp, mp, c, 1)
     # ---- norm2 (+ residual branch of `y + x*gamma`)
@@ -88,11 +116,13 @@ def naf_bwd(dout, P, saved):
     # ---- depthwise + SimpleGate
     dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'])
     # ---- conv1
-    g1, G['conv1.bias'] = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)
-    G['conv1.weight'] = g1.view(2 * c, c, 1, 1)
+    with K.on_side(xn, dt1):
+        g1, G['conv1.bias'] = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)
+        G['conv1.weight'] = g1.view(2 * c, c, 1, 1)
     wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)
     dxn = K.conv_forward(dt1, wp, mp, c, 1)
     dx, G['norm1.weight'], G['norm1.bias'] = K.layernorm2d_bwd(dxn, x, mu1, rs1, P['norm1.weight'], add=dy)
+    maybe_join()
     return dx, G
 
 
@@ -124,10 +154,11 @@ def conv_fwd(x, w, b, stride, pad, res=None, relu=False):
 def conv_bwd(dout, x, w, stride, pad, need_dx=True, add_to_dx=None, bias=True):
     """returns (dx or None, dw, db); db is None for a bias-free conv (bias=False)."""
     Cout, Cin, KH, _ = w.shape
-    if bias:
-        dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad, want_db=True)
-    else:
-        dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad), None
+    with K.on_side(x, dout):
+        if bias:
+            dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad, want_db=True)
+        else:
+            dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad), None
     dw = dw.view(Cout, Cin, KH, KH)
     dx = None
     if need_dx:
@@ -143,6 +174,7 @@ def conv_bwd(dout, x, w, stride, pad, need_dx=True, add_to_dx=None, bias=True):
             dx = K.conv_forward(dout, wp, mp, 4 * Cin, 2, pad=0, OH=OH, OW=OW, epi=EPI_PSHUF, res=add_to_dx)
         else:
             raise NotImplementedError(f'conv dgrad KH={KH} stride={stride} pad={pad}')
+    maybe_join()
     return dx, dw, db
 
 
@@ -156,9 +188,11 @@ def up_fwd(x, w, skip):
 def up_bwd(dout, x, w):
     C2, Cc = w.shape[0], w.shape[1]
     dT = K.pixel_unshuffle2(dout)
-    dw = K.conv_wgrad(x, dT, C2, Cc, 1).view(C2, Cc, 1, 1)
+    with K.on_side(x, dT):
+        dw = K.conv_wgrad(x, dT, C2, Cc, 1).view(C2, Cc, 1, 1)
     wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_S1)
     dx = K.conv_forward(dT, wp, mp, Cc, 1)
+    maybe_join()
     return dx, dw
 
 
@@ -195,6 +229,13 @@ def encoder_bwd(dfeats, P, pre, ext_n_blocks, saved, G):
     """dfeats: list of per-level grads (or None).  Input-image gradient is not needed."""
     cnt = _enc_counts(ext_n_blocks)
     dnext = None                      # gradient flowing from level lvl+1 into feats[lvl]
+    with deferred_join():
+        _encoder_bwd_levels(dfeats, P, pre, cnt, saved, G, dnext)
+    maybe_join()
+    return None
+
+
+def _encoder_bwd_levels(dfeats, P, pre, cnt, saved, G, dnext):
     for lvl in reversed(range(len(dfeats))):
         k = lvl + 1
         xin, a, blocks = saved[lvl]
@@ -210,18 +251,21 @@ def encoder_bwd(dfeats, P, pre, ext_n_blocks, saved, G):
             x_in, h = blocks[i]
             w1, w2 = P[bp + 'conv1.weight'], P[bp + 'conv2.weight']
             Cc = w1.shape[0]
-            gw, G[bp + 'conv2.bias'] = K.conv_wgrad(h, d, Cc, Cc, 3, pad=1, want_db=True)
-            G[bp + 'conv2.weight'] = gw.view(Cc, Cc, 3, 3)
+            with K.on_side(h, d):
+                gw, G[bp + 'conv2.bias'] = K.conv_wgrad(h, d, Cc, Cc, 3, pad=1, want_db=True)
+                G[bp + 'conv2.weight'] = gw.view(Cc, Cc, 3, 3)
             wp, mp, *_ = K.pack_weights(w2, PACK_DGRAD_S1)
             dh = K.conv_forward(d, wp, mp, Cc, 3, pad=1, mask=h)
-            gw, G[bp + 'conv1.bias'] = K.conv_wgrad(x_in, dh, Cc, Cc, 3, pad=1, want_db=True)
-            G[bp + 'conv1.weight'] = gw.view(Cc, Cc, 3, 3)
+            with K.on_side(x_in, dh):
+                gw, G[bp + 'conv1.bias'] = K.conv_wgrad(x_in, dh, Cc, Cc, 3, pad=1, want_db=True)
+                G[bp + 'conv1.weight'] = gw.view(Cc, Cc, 3, 3)
             wp, mp, *_ = K.pack_weights(w1, PACK_DGRAD_S1)
             d = K.conv_forward(dh, wp, mp, Cc, 3, pad=1, res=d)
         dpre = K.relu_bwd(d, a)
         w = P[f'{pre}conv_L{k}.weight']
         dnext, G[f'{pre}conv_L{k}.weight'], G[f'{pre}conv_L{k}.bias'] = conv_bwd(
             dpre, xin, w, 1 if lvl == 0 else 2, 1, need_dx=(lvl > 0))
+    maybe_join()
     return None
 
 
@@ -371,6 +415,11 @@ def net_bwd(dout, P, cfg, saved, G=None):
     """dout [N,3,H0,W0] -> dict of parameter gradients keyed like P.  `G` may be a caller's
     dict-like collector (e.g. parallel.GradSink, which starts the RCCL all-reduce of a
     gradient bucket as soon as its last tensor is stored)."""
+    with deferred_join():
+        return _net_bwd(dout, P, cfg, saved, G)
+
+
+def _net_bwd(dout, P, cfg, saved, G):
     N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe = saved
     n_enc = len(cfg['enc_blk_nums'])
     G = {} if G is None else G

@@ -40,7 +40,79 @@ class PackedWeights:
         return self.buf.data_ptr()
 
 
+# ---- side stream for work off the critical chain (weight gradients: nothing downstream in the backward needs them).
+# Inside `with on_side(...)` every libtdr call is enqueued on the side stream, which first waits for everything
+# issued so far on the current stream; allocations still come from the current stream's pool, and every tensor the
+# side kernels touch is kept referenced until side_join() (the current stream waits for the side stream), so memory
+# is never recycled under a running side kernel.  Under hipGraph capture this becomes a parallel branch of the graph.
+SIDE_WGRAD = os.environ.get('TDR_SIDE_WGRAD', '1') == '1'
+_side_stream = None
+_side_active = False
+_side_dirty = False
+_side_keep = []
+
+
+class on_side:
+    def __init__(self, *keep):
+        self.keep = keep
+        self.on = False
+
+    def __enter__(self):
+        global _side_stream, _side_active, _side_dirty
+        if SIDE_WGRAD and not _side_active:
+            if _side_stream is None:
+                _side_stream = torch.cuda.Stream()
+            _side_stream.wait_stream(torch.cuda.current_stream())
+            _side_active = _side_dirty = self.on = True
+            _side_keep.extend(self.keep)
+        return self
+
+    def __exit__(self, *exc):
+        global _side_active
+        if self.on:
+            _side_active = False
+        return False
+
+
+def side_keep(*tensors):
+    """keep intermediates of the side branch alive until side_join()"""
+    if _side_active:
+        _side_keep.extend(tensors)
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
+def side_join():
+    """make the current stream wait for the side branch (before anything reads its results)"""
+    global _side_dirty
+    if _side_dirty:
+        torch.cuda.current_stream().wait_stream(_side_stream)
+        _side_dirty = False
+        _side_keep.clear()
+
+
+class side_suspended:
+    """for code that must run on the current stream and read side-branch results even when called from inside an
+    on_side block (the gradient sink's bucket gather): joins the side branch, runs the body on the current stream,
+    then lets the enclosing on_side block continue on the side stream (after it has re-synchronised)."""
+
+    def __enter__(self):
+        global _side_active
+        self.was = _side_active
+        _side_active = False
+        side_join()
+        return self
+
+    def __exit__(self, *exc):
+        global _side_active, _side_dirty
+        if self.was:
+            _side_stream.wait_stream(torch.cuda.current_stream())
+            _side_active = _side_dirty = True
+        return False
+
+
 def _stream():
+    if _side_active:
+        return _side_stream.cuda_stream
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -69,7 +141,7 @@ _ws_cache = {}
 
 def workspace(nfloats, device, tag='main'):
     """grow-only scratch buffer (stream-ordered reuse)."""
-    key = (tag, device.index if hasattr(device, 'index') else device)
+    key = (tag + ('@side' if _side_active else ''), device.index if hasattr(device, 'index') else device)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)

@@ -174,8 +174,9 @@ class GradAllReducer:
             self._copy_in(key, g)
         self._bucket_left[bi] -= 1
         if self._bucket_left[bi] == 0:
-            self._gather(bi)
-            self._launch(bi)
+            with K.side_suspended():                      # weight gradients are produced on the side stream
+                self._gather(bi)
+                self._launch(bi)
 
     def finish(self):
         """wait for the collectives; returns {name: averaged gradient view}."""
@@ -188,6 +189,7 @@ class GradAllReducer:
                     self._pending[k] = g.contiguous()
                 else:
                     self._copy_in(k, g)
+            K.side_join()
             for bi in range(len(self.buckets)):
                 self._gather(bi)
                 self._launch(bi)

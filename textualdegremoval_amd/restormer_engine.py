@@ -54,11 +54,12 @@ def _pw_bwd(dout, x, P, name, G):
     w = P[name + '.weight']
     Cout, Cin = w.shape[0], w.shape[1]
     has_b = (name + '.bias') in P
-    r = K.conv_wgrad(x, dout, Cout, Cin, 1, want_db=has_b)
-    if has_b:
-        G[name + '.weight'], G[name + '.bias'] = r[0].view(Cout, Cin, 1, 1), r[1]
-    else:
-        G[name + '.weight'] = r.view(Cout, Cin, 1, 1)
+    with K.on_side(x, dout):          # parameter gradient: side stream, off the data-gradient chain
+        r = K.conv_wgrad(x, dout, Cout, Cin, 1, want_db=has_b)
+        if has_b:
+            G[name + '.weight'], G[name + '.bias'] = r[0].view(Cout, Cin, 1, 1), r[1]
+        else:
+            G[name + '.weight'] = r.view(Cout, Cin, 1, 1)
     wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_S1)
     return K.conv_forward(dout, wp, mp, Cin, 1)
 
@@ -112,6 +113,7 @@ def tblock_bwd(dout, P, heads, ln_type, saved):
         G['attn.qkv_dwconv.bias'] = db
     dxn = _pw_bwd(dt, xn, P, 'attn.qkv', G)
     dx = _ln_bwd(dxn, x, mu1, rs1, P, 'norm1.', ln_type, G, add=dy)
+    E.maybe_join()
     return dx, G
 
 
@@ -125,9 +127,12 @@ def fblock_bwd(dout, P, heads, ln_type, saved):
     sv, z = saved
     dalpha = K.dot(dout, z)
     dz = K.axpby_dev(dout, P['alpha'])
-    dx, G = tblock_bwd(dz, P, heads, ln_type, sv)
+    with E.deferred_join():
+        dx, G = tblock_bwd(dz, P, heads, ln_type, sv)
     G['alpha'] = dalpha
-    return K.add_(dx, dout), G
+    dx = K.add_(dx, dout)
+    E.maybe_join()
+    return dx, G
 
 
 def seq_fwd(x, P, pre, n, heads, ln_type, fusion=False):
@@ -222,6 +227,11 @@ def net_fwd(P, cfg, inp, ref):
 
 
 def net_bwd(dout, P, cfg, saved, G=None):
+    with E.deferred_join():
+        return _net_bwd(dout, P, cfg, saved, G)
+
+
+def _net_bwd(dout, P, cfg, saved, G):
     (N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, rf,
      sv_rf) = saved
     G = {} if G is None else G
