@@ -175,3 +175,29 @@ def test_module_surface_forward_backward_and_state_dict(E):
     (out - gt.cuda()).abs().mean().backward()
     gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
     assert np.allclose(gn, g['grad_norm'], rtol=5e-3, atol=5e-6)
+
+
+def test_side_stream_weight_gradients_match(E):
+    """TDR_SIDE_WGRAD: weight gradients on a parallel stream give the same results (bit-identical except where the
+    MASA transfer backward accumulates with float atomics, whose order varies from run to run anyway)."""
+    from textualdegremoval_amd import kernels as K
+    cfg = O.default_cfg(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
+    P = cuda_params(O.synth_params(cfg, seed=2))
+    lq, gt, ref = O.synth_pair(2, 128, 128, seed=12)
+    res = []
+    for side in (False, True):
+        prev, K.SIDE_WGRAD = K.SIDE_WGRAD, side
+        try:
+            out, saved = E.net_fwd(P, cfg, lq.cuda(), ref.cuda())
+            loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0)
+            G = E.net_bwd(dpred, P, cfg, saved)
+            torch.cuda.synchronize()
+            res.append({k: v.clone() for k, v in G.items()})
+        finally:
+            K.SIDE_WGRAD = prev
+    assert set(res[0]) == set(res[1])
+    for k in res[0]:
+        if k.startswith('masa_enc.'):
+            assert maxdiff(res[0][k], res[1][k]) <= 1e-5 * max(1e-6, res[0][k].abs().max().item()), k
+        else:
+            assert torch.equal(res[0][k], res[1][k]), k

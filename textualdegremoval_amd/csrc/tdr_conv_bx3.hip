@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
         const int q = T >> 3, r = T & 7, xcd = b & 7, slot = b >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int mtile = logical % a.mtiles, ptile = logical / a.mtiles;
+    int mtile = logical % a.mtiles, ptile = logical / a.mtiles;
+    if (a.order == 1) { mtile = (int)blockIdx.x % a.mtiles; ptile = (int)blockIdx.x / a.mtiles; }
+    else if (a.order == 2) { const int np = (int)gridDim.x / a.mtiles; ptile = (int)blockIdx.x % np; mtile = (int)blockIdx.x / np; }
     const int tx = ptile % a.tiles_x, ty = ptile / a.tiles_x;
     const int m0 = mtile * BM;
     const int n = blockIdx.z;
@@ -297,6 +299,8 @@ int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
     b.tiles_x = tdr_cdiv(a.OW, TW);
     const int tiles_y = tdr_cdiv(a.OH, TH);
     b.mtiles = tdr_cdiv(a.Cout, BM);
+    static const int order_env = getenv("TDR_BX_ORDER") ? atoi(getenv("TDR_BX_ORDER")) : 0;   // tuning aid
+    b.order = order_env;
     dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
     auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE>;
     static bool attr_set = false;
@@ -308,6 +312,9 @@ int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
     TDR_LAUNCH_CHECK("conv_bx3_kernel");
     return TDR_OK;
 }
+
+// tile-configuration override for profiles/autotune_conv.py: [0] 1x1 kernels, [1] 3x3 / 2x2 kernels; 0 = heuristic
+int g_force_cfg[2] = {getenv("TDR_BX_CFG1") ? atoi(getenv("TDR_BX_CFG1")) : 0, getenv("TDR_BX_CFG3") ? atoi(getenv("TDR_BX_CFG3")) : 0};
 
 template <int KH, int S, int EPI, bool GATE>
 int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
@@ -323,20 +330,30 @@ int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
             if (blocks(32, 256) >= 512) return launch_bx_cfg<KH, S, 1, 1, 2, EPI, GATE>(a, N, st);   // 32 x 256
             return launch_bx_cfg<KH, S, 1, 1, 1, EPI, GATE>(a, N, st);                               // 32 x 128
         }
+        // short K loops over many pixels (the high-resolution levels) are staging-bound: the small 64 x 128 tile keeps
+        // four workgroups per CU in flight (profiles/autotune_conv.py: 5-15 % on Cin <= 128 1x1 layers at >= 256^2)
+        if (g_force_cfg[KH == 1 ? 0 : 1] == 0 && a.Cin <= (KH == 1 ? 128 : 64) && blocks(64, 128) >= 2048)
+            return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);
         if constexpr (KH == 1) {   // two register sets of prefetched operands: 128 x 128 keeps the kernel under 256 VGPRs
-            static const int force = getenv("TDR_BX_CFG1") ? atoi(getenv("TDR_BX_CFG1")) : 0;   // tuning aid
+            const int force = g_force_cfg[0];   // tuning aid (tdr_conv_force_cfg / TDR_BX_CFG1)
             if (force == 1) return launch_bx_cfg<KH, S, 2, 2, 2, EPI, GATE>(a, N, st);
             if (force == 2) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);
             if (force == 3) return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);
             if (force == 4) return launch_bx_cfg<KH, S, 1, 1, 2, EPI, GATE>(a, N, st);
+            if (force == 5) return launch_bx_cfg<KH, S, 4, 2, 2, EPI, GATE>(a, N, st);    // 256 x 64
             if (a.Cout > 64 && blocks(128, 128) >= 512) return launch_bx_cfg<KH, S, 2, 2, 2, EPI, GATE>(a, N, st);
         } else {
+            const int force3 = g_force_cfg[1];   // tuning aid (tdr_conv_force_cfg / TDR_BX_CFG3)
+            if (force3 == 1) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);
+            if (force3 == 2) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);
+            if (force3 == 3) return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);
+            if (force3 == 4) return launch_bx_cfg<KH, S, 2, 2, 2, EPI, GATE>(a, N, st);
             if (a.Cout > 64 && blocks(128, 256) >= 512) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);  // 128 x 256
         }
         // weight fragments are re-read per 32-pixel column of the wave tile: wide pixel tiles (TN = 4) halve that L2->VGPR
-        // stream; with a long K loop one resident block per CU (256 blocks) already hides the latencies
-        const long ksteps = (long)((a.Cin + 15) / 16) * KH * KH;
-        if (blocks(64, 256) >= (ksteps >= 64 ? 256 : 512)) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);       // 64 x 256
+        // stream -- but only with two resident workgroups per CU: one wave per SIMD cannot overlap its own LDS reads and
+        // operand conversion with its MFMAs (512 -> 512 @ 32x32, N = 8: 321 us at 256 blocks of 64 x 256, 232 us at 512 of 64 x 128)
+        if (blocks(64, 256) >= 512) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);       // 64 x 256
         return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);                                   // 64 x 128
     }
 }
@@ -349,6 +366,11 @@ __global__ void pack_weights_bx3_kernel(const float* __restrict__ w, int Cout, i
 }
 
 }  // namespace
+
+extern "C" int tdr_conv_force_cfg(int kh, int cfg) {
+    g_force_cfg[kh == 1 ? 0 : 1] = cfg;
+    return TDR_OK;
+}
 
 extern "C" int64_t tdr_packed_weight_bytes_bx3(int M, int Kch, int KH_eff) {
     const long MT = (M + 31) / 32;

@@ -45,7 +45,10 @@ class PackedWeights:
 # issued so far on the current stream; allocations still come from the current stream's pool, and every tensor the
 # side kernels touch is kept referenced until side_join() (the current stream waits for the side stream), so memory
 # is never recycled under a running side kernel.  Under hipGraph capture this becomes a parallel branch of the graph.
-SIDE_WGRAD = os.environ.get('TDR_SIDE_WGRAD', '1') == '1'
+# Opt-in (TDR_SIDE_WGRAD=1): measured +1.2 % (NAFNet-ref cfg2) / +2 % (Restormer-ref cfg3) -- the MFMA kernels hold
+# their LDS / wave slots while resident, so two of them barely co-run -- and per-kernel profiles of overlapped launches
+# are no longer comparable with the serial ones, so the default keeps the backward on one stream.
+SIDE_WGRAD = os.environ.get('TDR_SIDE_WGRAD', '0') == '1'
 _side_stream = None
 _side_active = False
 _side_dirty = False
