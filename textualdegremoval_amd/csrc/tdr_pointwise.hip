@@ -249,39 +249,28 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
     }
 }
 
-// out0[c] = sum_k part[k][0][c], out1[c] = sum_k part[k][1][c]
-__global__ void pair_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ o0,
-                                   float* __restrict__ o1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nparts; ++k) {
-        a += part[((long)k * 2 + 0) * C + c];
-        b += part[((long)k * 2 + 1) * C + c];
-    }
-    o0[c] = a; o1[c] = b;
-}
-
-// out[g][e] = sum_{k<nparts} part[(g*nparts + k)*stride + e]; block = 64 elements x KL k-lanes
+// LayerNorm parameter gradients: part [nparts][2][C] -> o0[c] = sum_k part[k][0][c], o1[c] = sum_k part[k][1][c]
+// (blockIdx.y picks the half; one launch for both)
 template <int KL>
-__global__ __launch_bounds__(64 * KL) void sum_partials_kernel(const float* __restrict__ part, long stride, int nparts,
-                                                               long elems, float* __restrict__ out) {
+__global__ __launch_bounds__(64 * KL) void pair_sum_partials_kernel(const float* __restrict__ part, int nparts, int C,
+                                                                    float* __restrict__ o0, float* __restrict__ o1) {
     __shared__ float red[KL][64];
     const int lane = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    const long e = blockIdx.x * 64L + lane;
-    const long ec = e < elems ? e : elems - 1;
-    const float* p = part + (long)blockIdx.y * nparts * stride + ec;
+    const int e = blockIdx.x * 64 + lane;
+    const int ec = e < C ? e : C - 1;
+    const float* p = part + (long)blockIdx.y * C + ec;
+    const long stride = 2L * C;
     float s0 = 0.f, s1 = 0.f;
     int k = kl;
     for (; k + KL < nparts; k += 2 * KL) { s0 += p[(long)k * stride]; s1 += p[(long)(k + KL) * stride]; }
     if (k < nparts) s0 += p[(long)k * stride];
     red[kl][lane] = s0 + s1;
     __syncthreads();
-    if (kl == 0 && e < elems) {
+    if (kl == 0 && e < C) {
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < KL; ++q) t += red[q][lane];
-        out[(long)blockIdx.y * elems + e] = t;
+        (blockIdx.y ? o1 : o0)[e] = t;
     }
 }
 
@@ -560,8 +549,7 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
                            C, HW, ws);
         nparts = LN_GEN_SPLITS;
     }
-    hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 1), dim3(1024), 0, st, ws, 2L * C, nparts, (long)C, gw);
-    hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 1), dim3(1024), 0, st, ws + C, 2L * C, nparts, (long)C, gb);
+    hipLaunchKernelGGL(pair_sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 2), dim3(1024), 0, st, ws, nparts, C, gw, gb);
     TDR_LAUNCH_CHECK("ln_bwd");
     return TDR_OK;
 }
