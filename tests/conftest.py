@@ -2,6 +2,12 @@ import os
 import sys
 
 import pytest
+import torch
+
+# The CPU oracle (torch fp32 on the host) runs inside both test tiers.  On the 256-CPU GPU hosts an unbounded intra-op
+# pool makes the MKLDNN convolutions collapse and starves the HIP runtime's own threads (a D2H copy then waits for
+# minutes), so the pool is capped for the whole session -- test modules must not raise it again.
+torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -10,7 +10,6 @@ import torch
 from oracle import nafnet_ref_oracle as NO
 from oracle import restormer_ref_oracle as RO
 
-torch.set_num_threads(max(1, os.cpu_count() or 1))
 
 
 def load(golden_dir, name):
