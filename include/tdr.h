@@ -80,6 +80,10 @@ int tdr_pack_weights(const float* w, int Cout, int Cin, int KH, int mode, float*
  * bf16 cross products with fp32 accumulation (v_mfma_f32_32x32x16_bf16), see csrc/tdr_conv_bx3.hip. */
 int64_t tdr_packed_weight_bytes_bx3(int M, int Kch, int KH_eff);
 int tdr_pack_weights_bx3(const float* w, int Cout, int Cin, int KH, int mode, void* wp, void* stream);
+/* the same for B matrices in one launch (per-image weights, TdrConvDesc.wp_ns = packed bytes / 4): matrix b is read at
+ * w + b*w_stride floats and packed to wp + b*tdr_packed_weight_bytes_bx3(M, Kch, KH) bytes; mode 0 or 1 */
+int tdr_pack_weights_bx3_batch(const float* w, int64_t w_stride, int B, int Cout, int Cin, int KH, int mode, void* wp,
+                               void* stream);
 /* tuning aid (profiles/autotune_conv.py): force tile configuration `cfg` (0 = built-in heuristic) of the split-bf16
  * forward kernels with kernel size kh == 1, or of the 3x3 / 2x2 ones (any other kh) */
 int tdr_conv_force_cfg(int kh, int cfg);

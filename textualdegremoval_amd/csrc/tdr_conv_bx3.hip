@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int mt = min((m0 >> 5) + wm * TM + tm, MT - 1);
-        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)mt * 192 + lane;
+        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)n * (a.wp_ns >> 2) + (long)mt * 192 + lane;   // wp_ns: floats per image (0 = shared)
     }
     const long wstep = (long)MT * 192;          // 16-byte units per (group, tap)
 
@@ -359,10 +359,12 @@ int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
 }
 
 // one thread per 16-byte fragment (all three splits)
-__global__ void pack_weights_bx3_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int mode, int M, int Kch,
-                                        int KHe, int MT, long total, uint4* __restrict__ wp) {
+__global__ void pack_weights_bx3_kernel(const float* __restrict__ w, long w_bs, int Cout, int Cin, int KH, int mode, int M,
+                                        int Kch, int KHe, int MT, long total, uint4* __restrict__ wp, long wp_bs16) {
+    const float* wb = w + (long)blockIdx.y * w_bs;              // blockIdx.y: matrix of a batch (per-image weights)
+    uint4* ob = wp + (long)blockIdx.y * wp_bs16;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-        tdr_pack_bx3_frag(w, Cin, KH, mode, M, Kch, KHe, MT, i, wp);
+        tdr_pack_bx3_frag(wb, Cin, KH, mode, M, Kch, KHe, MT, i, ob);
 }
 
 }  // namespace
@@ -388,18 +390,35 @@ extern "C" int tdr_pack_weights_bx3(const float* w, int Cout, int Cin, int KH, i
     const int MT = (M + 31) / 32;
     const long total = (long)((Kch + 15) / 16) * KHe * KHe * MT * 64;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_weights_bx3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KH, mode, M,
-                       Kch, KHe, MT, total, (uint4*)wp);
+    hipLaunchKernelGGL(pack_weights_bx3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, 0L, Cout, Cin, KH, mode, M,
+                       Kch, KHe, MT, total, (uint4*)wp, 0L);
     TDR_LAUNCH_CHECK("pack_weights_bx3_kernel");
+    return TDR_OK;
+}
+
+// B matrices at once (per-image weights of the MDTA core): matrix b is w + b*w_stride (floats), packed to wp + b*per_b bytes,
+// per_b = tdr_packed_weight_bytes_bx3(M, Kch, KH_eff)
+extern "C" int tdr_pack_weights_bx3_batch(const float* w, int64_t w_stride, int B, int Cout, int Cin, int KH, int mode, void* wp,
+                                          void* stream) {
+    TDR_REQUIRE(w && wp && B > 0, "tdr_pack_weights_bx3_batch: bad argument");
+    TDR_REQUIRE(mode == 0 || mode == 1, "tdr_pack_weights_bx3_batch: mode 0 or 1 only (got %d)", mode);
+    const int M = mode == 0 ? Cout : Cin, Kch = mode == 0 ? Cin : Cout;
+    const int MT = (M + 31) / 32;
+    const long total = (long)((Kch + 15) / 16) * KH * KH * MT * 64;
+    const long per_b16 = tdr_packed_weight_bytes_bx3(M, Kch, KH) / 16;
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(pack_weights_bx3_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, w, (long)w_stride, Cout, Cin,
+                       KH, mode, M, Kch, KH, MT, total, (uint4*)wp, per_b16);
+    TDR_LAUNCH_CHECK("pack_weights_bx3_kernel(batch)");
     return TDR_OK;
 }
 
 // called by tdr_conv_forward (tdr_conv_mfma.hip) when the descriptor carries bx3-packed weights
 int tdr_conv_forward_bx3(const TdrConvDesc* d, void* stream) {
-    TDR_REQUIRE(d->dil == 1 && d->wp_ns == 0, "tdr_conv_forward: split-bf16 path needs dil=1 and shared weights");
+    TDR_REQUIRE(d->dil == 1 && d->wp_ns % 4 == 0, "tdr_conv_forward: split-bf16 path needs dil=1 (and wp_ns a multiple of 4 floats)");
     ConvArgs a;
     a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
-    a.wp = (const float*)d->wp; a.wp_ns = 0; a.Mpad = d->Mpad; a.Cout = d->Cout;
+    a.wp = (const float*)d->wp; a.wp_ns = d->wp_ns; a.Mpad = d->Mpad; a.Cout = d->Cout;
     a.out = d->out; a.out_ns = d->out_ns; a.OH = d->OH; a.OW = d->OW;
     a.pad = d->pad;
     a.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);

@@ -733,6 +733,20 @@ def row_sumsq(x, rows):
     return out
 
 
+def pack_f32packed_to_bx3(Wt):
+    """Wt [B, Kp, Mp]: per-image 1x1 weights in the fp32 packed layout (Wt[b][cin][m] = W_b[m][cin], what tdr_mdta_* emit)
+    -> (PackedWeights in the split-bf16 fragment layout, floats per image) for conv_forward(..., wp_ns=...)"""
+    lib = _lib.load()
+    B, Kp, Mp = Wt.shape
+    assert Wt.is_contiguous()
+    per_b = lib.tdr_packed_weight_bytes_bx3(Mp, Kp, 1) // 4
+    buf = torch.empty(B * per_b, dtype=torch.float32, device=Wt.device)
+    # mode 1 reads w[c * Cin + m]: with "Cin" = Mp (row length) and "Cout" = Kp this is exactly Wt[c][m]
+    check(lib.tdr_pack_weights_bx3_batch(Wt.data_ptr(), Kp * Mp, B, Kp, Mp, 1, 1, buf.data_ptr(), _stream()),
+          'tdr_pack_weights_bx3_batch')
+    return PackedWeights(buf, FMT_BX3), per_b
+
+
 def mdta_pad(Cc):
     return (Cc + 31) // 32 * 32
 

@@ -64,6 +64,16 @@ def _pw_bwd(dout, x, P, name, G):
     return K.conv_forward(dout, wp, mp, Cin, 1)
 
 
+def _img_conv(x, Wt, Cout, out=None):
+    """1x1 conv with per-image weights Wt [N, Kp, Mp] (fp32 packed layout emitted by tdr_mdta_*): on the split-bf16
+    kernel after one batched re-pack, or directly on the exact fp32 kernel (kernels.MATH)."""
+    Kp, Mp = Wt.shape[-2], Wt.shape[-1]
+    if K.MATH == 'bx3':
+        pw, per_b = K.pack_f32packed_to_bx3(Wt)
+        return K.conv_forward(x, pw, Mp, Cout, 1, wp_ns=per_b, out=out)
+    return K.conv_forward(x, Wt, Mp, Cout, 1, wp_ns=Kp * Mp, out=out)
+
+
 # ---------------------------------------------------------------------------
 # TransformerBlock (:318-331) = x + MDTA(LN(x)); + GDFN(LN(.))
 # ---------------------------------------------------------------------------
@@ -76,8 +86,7 @@ def tblock_fwd(x, P, heads, ln_type):
     ss = K.row_sumsq(qkv, 2 * Cc)                                                # |q_i|^2, |k_j|^2
     Gm = K.conv_wgrad(qkv[:, Cc:2 * Cc], qkv[:, :Cc], Cc, Cc, 1, per_image=True).view(N, Cc, Cc)   # q k^T
     A, AT = K.mdta_softmax(Gm, ss, P['attn.temperature'], heads)
-    Cp = A.shape[-1]
-    o = K.conv_forward(qkv[:, 2 * Cc:], AT, Cp, Cc, 1, wp_ns=Cp * Cp)            # attn v
+    o = _img_conv(qkv[:, 2 * Cc:], AT, Cc)                                       # attn v
     y = _pw_fwd(o, P, 'attn.project_out', res=x)
     # ---- GDFN (:223-241)
     yn, mu2, rs2 = _ln_fwd(y, P, 'norm2.', ln_type)
@@ -104,9 +113,8 @@ def tblock_bwd(dout, P, heads, ln_type, saved):
     dA = K.conv_wgrad(qkv[:, 2 * Cc:], do, Cc, Cc, 1, per_image=True).view(N, Cc, Cc)      # dA_ij = do_i . v_j
     Wm, G['attn.temperature'] = K.mdta_bwd(Gm, ss, P['attn.temperature'], A, dA, heads)
     dqkv = torch.empty_like(qkv)
-    Cp, Wp = A.shape[-1], Wm.shape[-1]
-    K.conv_forward(do, A, Cp, Cc, 1, wp_ns=Cp * Cp, out=dqkv[:, 2 * Cc:])                  # dv = attn^T do
-    K.conv_forward(qkv[:, :2 * Cc], Wm, Wp, 2 * Cc, 1, wp_ns=Wp * Wp, out=dqkv[:, :2 * Cc])  # d[q;k] = W [q;k]
+    _img_conv(do, A, Cc, out=dqkv[:, 2 * Cc:])                                             # dv = attn^T do
+    _img_conv(qkv[:, :2 * Cc], Wm, 2 * Cc, out=dqkv[:, :2 * Cc])                           # d[q;k] = W [q;k]
     has_b = 'attn.qkv_dwconv.bias' in P
     dt, G['attn.qkv_dwconv.weight'], db = K.dwconv_bwd(dqkv, t, P['attn.qkv_dwconv.weight'], want_db=has_b)
     if has_b:
