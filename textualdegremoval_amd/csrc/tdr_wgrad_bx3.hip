@@ -482,7 +482,10 @@ WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d) {
     p.tiles_y = tdr_cdiv(d->OH, R);
     p.tpi = p.tiles_x * p.tiles_y;
     const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
-    long want = 768 / out_tiles;                      // 2 blocks per CU resident, ~1.5 rounds of blocks
+    // split-K so that ONE round of blocks fills the chip (2 resident workgroups x 256 CUs): 768 (1.5 rounds) leaves a
+    // half-empty tail round on every launch -- 94.7 vs 90.4 ms per cfg2 step; TDR_WG_WANT overrides (tuning aid)
+    static const long want_total = getenv("TDR_WG_WANT") ? atol(getenv("TDR_WG_WANT")) : 512;
+    long want = want_total / out_tiles;
     if (want < 1) want = 1;
     long spi = (want + d->N - 1) / d->N;              // splits per image
     if (spi > p.tpi / 4) spi = p.tpi / 4;             // at least 4 pixel tiles per block
