@@ -100,9 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
         const int q = T >> 3, r = T & 7, xcd = b & 7, slot = b >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    int mtile = logical % a.mtiles, ptile = logical / a.mtiles;
-    if (a.order == 1) { mtile = (int)blockIdx.x % a.mtiles; ptile = (int)blockIdx.x / a.mtiles; }
-    else if (a.order == 2) { const int np = (int)gridDim.x / a.mtiles; ptile = (int)blockIdx.x % np; mtile = (int)blockIdx.x / np; }
+    const int mtile = logical % a.mtiles, ptile = logical / a.mtiles;
     const int tx = ptile % a.tiles_x, ty = ptile / a.tiles_x;
     const int m0 = mtile * BM;
     const int n = blockIdx.z;
@@ -299,8 +297,6 @@ int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
     b.tiles_x = tdr_cdiv(a.OW, TW);
     const int tiles_y = tdr_cdiv(a.OH, TH);
     b.mtiles = tdr_cdiv(a.Cout, BM);
-    static const int order_env = getenv("TDR_BX_ORDER") ? atoi(getenv("TDR_BX_ORDER")) : 0;   // tuning aid
-    b.order = order_env;
     dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
     auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE>;
     static bool attr_set = false;

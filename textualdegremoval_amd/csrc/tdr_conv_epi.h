@@ -24,7 +24,6 @@ struct ConvArgs {
     const float* aux; long aux_ns;
     int relu;
     int vec_epi;      // 1: rows are 16-byte aligned (OW % 4 == 0, aligned bases): LDS-transposed float4 epilogue
-    int order;        // block order of the split-bf16 kernel: 0 XCD-aware, 1 linear m-tile fastest, 2 linear pixel-tile fastest
 };
 
 // acc[TM][TN]: wave (wm, wn) owns output-channel tiles wm*TM.. and pixel sub-tiles wn*TN..
