@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
         for (int u = 0; u < PF; ++u) {
             const int g = g0 + u;
             if (g < ngroups) {
-                const int buf = g & 1;
+                const int buf = a.single_buf ? 0 : (g & 1);
                 const uint4* sb = smem4 + buf * 6 * plane;
                 if (TDR_PROBE != 1 && PF == 1 && g + 1 < ngroups) load_group(g + 1, 0);
 #pragma unroll
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                 }
                 TDR_STAMP(probe_slot++);                  // 4+3g: MFMA phase of group g issued
                 if (TDR_PROBE != 4) {
-                    if (g + 1 < ngroups) store_group(g + 1, (u + 1) % PF, buf ^ 1);
+                    if (a.single_buf) __syncthreads();        // one LDS buffer: every wave is done reading group g
+                    if (g + 1 < ngroups) store_group(g + 1, (u + 1) % PF, a.single_buf ? 0 : (buf ^ 1));
                     TDR_STAMP(probe_slot++);              // 5+3g: next group converted + stored
                     __syncthreads();
                     TDR_STAMP(probe_slot++);              // 6+3g: barrier passed
@@ -292,8 +293,12 @@ int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
     constexpr int NT = TN * WN;
     const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2, TH = NT * SR;
     const int LH = (TH - 1) * S + KH, LW = (TW - 1) * S + KH;
-    const size_t lds = (size_t)12 * LH * LW * 16;
     ConvArgs b = a;
+    // short K loops (<= 2 channel groups) of the 3x3 kernels: one LDS buffer instead of two halves the 65 KB footprint, so
+    // four workgroups instead of two share a CU and hide each other's load / store latencies (tuning aid: TDR_BX_SINGLE)
+    static const int single_env = getenv("TDR_BX_SINGLE") ? atoi(getenv("TDR_BX_SINGLE")) : 2;
+    b.single_buf = (KH == 3 && (a.Cin + 15) / 16 <= single_env) ? 1 : 0;
+    const size_t lds = (size_t)(b.single_buf ? 6 : 12) * LH * LW * 16;
     b.tiles_x = tdr_cdiv(a.OW, TW);
     const int tiles_y = tdr_cdiv(a.OH, TH);
     b.mtiles = tdr_cdiv(a.Cout, BM);

@@ -24,6 +24,7 @@ struct ConvArgs {
     const float* aux; long aux_ns;
     int relu;
     int vec_epi;      // 1: rows are 16-byte aligned (OW % 4 == 0, aligned bases): LDS-transposed float4 epilogue
+    int single_buf;   // split-bf16 kernel: one LDS operand buffer (short K loops; more workgroups per CU)
 };
 
 // acc[TM][TN]: wave (wm, wn) owns output-channel tiles wm*TM.. and pixel sub-tiles wn*TN..

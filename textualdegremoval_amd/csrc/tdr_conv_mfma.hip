@@ -316,7 +316,7 @@ extern "C" int tdr_conv_forward(const TdrConvDesc* d, void* stream) {
     a.bias2 = d->bias2; a.bias2_ns = d->bias2_ns; a.bias2_mul = d->bias2_mul;
     a.res = d->res; a.res_ns = d->res_ns; a.mask = d->mask; a.mask_ns = d->mask_ns;
     a.aux = d->aux; a.aux_ns = d->aux_ns; a.relu = d->relu;
-    a.vec_epi = 0;
+    a.vec_epi = 0; a.single_buf = 0;
     hipStream_t st = (hipStream_t)stream;
     const int N = d->N;
     const int key = d->KH * 1000 + d->stride * 100 + d->dil * 10 + d->epi;
