@@ -298,7 +298,8 @@ int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
     // four workgroups instead of two share a CU and hide each other's load / store latencies (tuning aid: TDR_BX_SINGLE)
     static const int single_env = getenv("TDR_BX_SINGLE") ? atoi(getenv("TDR_BX_SINGLE")) : 2;
     b.single_buf = (KH == 3 && (a.Cin + 15) / 16 <= single_env) ? 1 : 0;
-    const size_t lds = (size_t)(b.single_buf ? 6 : 12) * LH * LW * 16;
+    size_t lds = (size_t)(b.single_buf ? 6 : 12) * LH * LW * 16;
+    if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);   // the vector epilogue's four wave-private 32 x 36 patches
     b.tiles_x = tdr_cdiv(a.OW, TW);
     const int tiles_y = tdr_cdiv(a.OH, TH);
     b.mtiles = tdr_cdiv(a.Cout, BM);

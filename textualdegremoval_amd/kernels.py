@@ -147,6 +147,8 @@ def workspace(nfloats, device, tag='main'):
     key = (tag + ('@side' if _side_active else ''), device.index if hasattr(device, 'index') else device)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
+        if buf is not None and _side_active:
+            _side_keep.append(buf)          # a side-stream kernel may still be using the smaller buffer
         buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
         _ws_cache[key] = buf
     return buf
