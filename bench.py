@@ -199,6 +199,16 @@ def main():
         graph_was = getattr(model, 'use_hip_graph', False)
         model.use_hip_graph = False                       # instrumented step runs eagerly (a replayed graph makes no Python calls)
         try:
+            # The eager host loop issues launches more slowly than the GPU retires them; an event pair around a launch
+            # would then also time the idle gap before it.  Park the GPU on a calibrated spin kernel so that the whole
+            # step is queued before it starts executing: the event pairs then bracket back-to-back device work.
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            torch.cuda._sleep(20_000_000)
+            c1.record()
+            torch.cuda.synchronize()
+            per_cycle_ms = max(c0.elapsed_time(c1), 1e-3) / 20_000_000
+            torch.cuda._sleep(int(min(1500.0, 12 * (dt / a.steps * 1e3)) / per_cycle_ms))
             it += 1
             step(it)
             torch.cuda.synchronize()
