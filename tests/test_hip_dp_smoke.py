@@ -32,3 +32,17 @@ def test_two_rank_graph_step_runs():
     r2 = _bench(2, 29541)
     assert r2['n_gpus'] == 2 and r2['value'] > 0 and r2['final_loss'] == r2['final_loss']      # finite
     assert r2['config']['global_batch'] == 2
+
+
+def test_single_rank_rccl_collectives_under_graph_capture():
+    """One rank, backend nccl (= RCCL), TDR_FORCE_COLLECTIVES=1: the bucketed all-reduces of the eager steps (comm
+    stream, ReduceOp.AVG), the flat all-reduce between the two captured graphs and the loss reduce all go through
+    RCCL on the real GPU -- everything of the N-GPU path except a second peer."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(ROOT, 'tests', '_rccl_single_rank.py')]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(os.environ, TDR_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    assert 'RCCL_SINGLE_RANK_OK' in out.stdout

@@ -11,6 +11,8 @@ traffic hides under the rest of the backward pass.  xGMI is point-to-point
 one step moves ~254 MB of fp32 gradients for NAFNet-ref w32.
 On one rank the same arena is used without any collective (stable gradient
 addresses for the fused optimiser)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -38,6 +40,9 @@ class GradAllReducer:
         self.named = list(named_params)                  # [(name, param)] in registration order
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # single-rank process groups normally skip the collectives; TDR_FORCE_COLLECTIVES=1 issues them anyway (a 1-GPU box
+        # then exercises the RCCL calls, the comm stream and their interplay with hipGraph capture -- tests/test_hip_dp_smoke.py)
+        self.collective = self.world > 1 or (os.environ.get('TDR_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized())
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.order = None                                # arrival order (fixed after the first step)
         self.flat = None
@@ -115,7 +120,7 @@ class GradAllReducer:
     def allreduce_flat(self):
         """one all-reduce (mean) of the whole gradient arena on the current stream (few, large collectives
         suit the point-to-point xGMI links); no-op on one rank."""
-        if self.world == 1 or self.flat is None:
+        if not self.collective or self.flat is None:
             return
         if self.flat.is_cuda and dist.get_backend(self.pg) == 'nccl':
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg)
@@ -146,7 +151,7 @@ class GradAllReducer:
         self._keep = [self._pending.pop(k) for k in tb['names']]   # sources stay referenced until the next gather is enqueued
 
     def _launch(self, bi):
-        if self.world == 1 or getattr(self, '_defer', False):
+        if not self.collective or getattr(self, '_defer', False):
             return
         s, e, _ = self.buckets[bi]
         buf = self.flat[s:e]
@@ -195,7 +200,7 @@ class GradAllReducer:
                 self._launch(bi)
         for w in self._works:
             w.wait()
-        if self.world > 1 and not getattr(self, '_defer', False):
+        if self.collective and not getattr(self, '_defer', False):
             if self.flat.is_cuda:
                 if self._comm_stream is not None:
                     torch.cuda.current_stream().wait_stream(self._comm_stream)
