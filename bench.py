@@ -180,7 +180,7 @@ def main():
 
     # ---- roofline of the dominant kernel family (3x3 stride-1 implicit GEMM on the fp32 matrix
     # cores: masa_enc forward + data-gradient launches), measured with HIP events on the launch stream
-    roof = None
+    roof, roof_other = None, []
     if rank == 0 and not a.no_roofline:
         recs = []
         orig = K.conv_forward
@@ -192,7 +192,7 @@ def main():
                 out = orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
                 e1.record()
                 recs.append((2.0 * x.shape[0] * Cout * x.shape[1] * 9 * out.shape[2] * out.shape[3], e0, e1,
-                             4.0 * (x.numel() + out.numel())))
+                             4.0 * (x.numel() + out.numel()), getattr(wp, 'fmt', 0)))
                 return out
             return orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
         K.conv_forward = timed
@@ -215,20 +215,28 @@ def main():
         finally:
             K.conv_forward = orig
             model.use_hip_graph = graph_was
-        fl = sum(r[0] for r in recs)
-        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
-        ach = fl / (ms * 1e-3) / 1e12
-        bx3 = K.MATH == 'bx3'
-        peak = (PEAK_BX3 if bx3 else PEAK_F32) / 1e12
-        roof = {'bound': 'mfma',
-                'kernel': ('conv_bx3_kernel<KH=3,S=1> (3-way bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)'
-                           if bx3 else 'conv_mfma_kernel<KH=3,S=1> (exact fp32 v_mfma_f32_32x32x2_f32)'),
-                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                'peak_note': ('2.5 PFLOP/s dense bf16 MFMA / 6 cross products = fp32-equivalent peak of the split scheme'
-                              if bx3 else 'dense fp32 MFMA peak'),
-                'frac_of_f32_mfma_peak': ach / (PEAK_F32 / 1e12),
-                'launches': len(recs), 'avg_launch_ms': ms / max(len(recs), 1),
-                'alg_flop_per_launch': fl / max(len(recs), 1), 'traffic': None}
+        # the family splits by operand scheme (kernels.MATH = 'hx2': forward launches on the 2-way fp16 split, data-gradient
+        # launches on the 3-way bf16 split); `roofline` is the scheme with the larger total time, the other goes to roofline_other
+        FAM = {0: ('conv_mfma_kernel<KH=3,S=1> (exact fp32 v_mfma_f32_32x32x2_f32)', PEAK_F32, 'dense fp32 MFMA peak'),
+               1: ('conv_bx3_kernel<KH=3,S=1,SCH_BX3> (3-way bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)',
+                   PEAK_BX3, '2.5 PFLOP/s dense bf16 MFMA / 6 cross products = fp32-equivalent peak of the split scheme'),
+               2: ('conv_bx3_kernel<KH=3,S=1,SCH_HX2> (2-way fp16 split, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)',
+                   PEAK_BF16 / 3.0, '2.5 PFLOP/s dense f16 MFMA / 3 cross products = fp32-equivalent peak of the split scheme')}
+        fams = {}
+        for fmt in sorted({r[4] for r in recs}):
+            rr = [r for r in recs if r[4] == fmt]
+            fl = sum(r[0] for r in rr)
+            ms = sum(r[1].elapsed_time(r[2]) for r in rr)
+            ach = fl / (ms * 1e-3) / 1e12
+            name, pk, note = FAM[fmt]
+            fams[fmt] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': pk / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (pk / 1e12),
+                         'peak_note': note, 'frac_of_f32_mfma_peak': ach / (PEAK_F32 / 1e12), 'launches': len(rr),
+                         'avg_launch_ms': ms / max(len(rr), 1), 'alg_flop_per_launch': fl / max(len(rr), 1), 'traffic': None,
+                         'alg_bytes_per_launch': sum(r[3] for r in rr) / max(len(rr), 1), '_total_ms': ms}
+        order = sorted(fams, key=lambda f: -fams[f]['_total_ms'])
+        roof = fams[order[0]]
+        roof_other = [fams[f] for f in order[1:]]
+        bx3 = order[0] != 0
         # HBM bytes per launch of the same kernel family from the committed PMC passes (profiles/pmc_workload.py)
         try:
             with open(os.path.join(ROOT, 'profiles', 'r1', 'pmc_traffic.json')) as fh:
@@ -240,10 +248,12 @@ def main():
                     n += v['launches']
             if n:
                 roof['traffic'] = tot / n
-                roof['traffic_unit'] = 'bytes/launch (FETCH_SIZE + WRITE_SIZE, calibrated, profiles/r1/pmc_traffic.json)'
-                roof['alg_bytes_per_launch'] = sum(r[3] for r in recs) / max(len(recs), 1)
+                roof['traffic_unit'] = ('bytes/launch of the KH=3,S=1 family (FETCH_SIZE + WRITE_SIZE, calibrated, '
+                                        'profiles/r1/pmc_traffic.json)')
         except (OSError, KeyError, ValueError):
             pass
+        for f in fams.values():
+            f.pop('_total_ms', None)
 
     if rank == 0:
         ips = world * a.batch * a.steps / dt
@@ -253,9 +263,13 @@ def main():
             'metric': f'train images/sec ({a.size}x{a.size}, bs={a.batch}/GPU)', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'math': ('fp32 tensors; dense contractions as 3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate): '
-                     'per-product error <= one fp32 rounding, see profiles/r1/bf16x3_probe_mi355x.log; TDR_MATH=f32 selects exact fp32 MFMA'
-                     if K.MATH == 'bx3' else 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)'),
+            'math': {'bx3': 'fp32 tensors; dense contractions as 3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate): '
+                            'per-product error <= one fp32 rounding, see profiles/r1/bf16x3_probe_mi355x.log; TDR_MATH=f32 selects exact fp32 MFMA',
+                     'hx2': 'fp32 tensors; forward convolutions as 2-way fp16 split (3 f16 MFMA products per fp32 product), data- and '
+                            'weight-gradient contractions as 3-way bf16 split (6 products), fp32 accumulate everywhere: measured error of both '
+                            'schemes = that of the exact fp32 MFMA chain (profiles/r1/fp16x2_probe_mi355x.log, bf16x3_probe_mi355x.log); '
+                            'TDR_MATH=bx3 / f32 select the all-bf16-split / exact fp32 MFMA paths',
+                     'f32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)'}[K.MATH],
             'config': {'workload': ('BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
                                     f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
                                     if a.arch == 'nafnet' else
@@ -276,6 +290,8 @@ def main():
                                      'alg_bytes_per_image': CFG2['B_alg'], 'alg_flop_per_image': CFG2['F_alg']}
         if roof is not None:
             line['roofline'] = roof
+            if roof_other:
+                line['roofline_other'] = roof_other
         if a.arch == 'restormer':
             CFG3 = dict(B_alg=69.4e9, F_alg=1.86e12)       # SURVEY 8(d), per 256x256 image
             line['roofline_step'] = {'achieved_hbm_frac': CFG3['B_alg'] * per_gpu / PEAK_HBM,

@@ -49,7 +49,8 @@ typedef struct TdrConvDesc {
     const float* kscale; int64_t kscale_ns;
     const void* wp;  int64_t wp_ns;  int Mpad;    /* packed weights, see tdr_pack_weights / tdr_pack_weights_bx3 */
     int wp_fmt;                  /* 0: fp32 rows (tdr_pack_weights, exact fp32 MFMA)
-                                    1: 3-way bf16 split fragments (tdr_pack_weights_bx3, bf16 MFMA x6, fp32-equivalent) */
+                                    1: 3-way bf16 split fragments (tdr_pack_weights_bx3, bf16 MFMA x6, fp32-equivalent)
+                                    2: 2-way fp16 split fragments (tdr_pack_weights_hx2, f16 MFMA x3, operands in fp16 range) */
     float* out; int64_t out_ns;
     int epi;                     /* 0 STD, 1 GATEBWD, 2 PSHUF */
     const float* bias;  int64_t bias_ns;
@@ -84,6 +85,11 @@ int tdr_pack_weights_bx3(const float* w, int Cout, int Cin, int KH, int mode, vo
  * w + b*w_stride floats and packed to wp + b*tdr_packed_weight_bytes_bx3(M, Kch, KH) bytes; mode 0 or 1 */
 int tdr_pack_weights_bx3_batch(const float* w, int64_t w_stride, int B, int Cout, int Cin, int KH, int mode, void* wp,
                                void* stream);
+/* 2-way fp16 split (wp_fmt 2): [group][tap][m-tile][split h,m][lane] 16-byte fragments of 8 x f16; three f16 MFMA products
+ * (hh, hm, mh) per fp32 product.  fp32-class accuracy for operands inside the fp16 range -- forward activations and
+ * weights; gradient-sized operands need an exact power-of-two pre-scale (profiles/r1/fp16x2_probe_mi355x.log). */
+int64_t tdr_packed_weight_bytes_hx2(int M, int Kch, int KH_eff);
+int tdr_pack_weights_hx2(const float* w, int Cout, int Cin, int KH, int mode, void* wp, void* stream);
 /* tuning aid (profiles/autotune_conv.py): force tile configuration `cfg` (0 = built-in heuristic) of the split-bf16
  * forward kernels with kernel size kh == 1, or of the 3x3 / 2x2 ones (any other kh) */
 int tdr_conv_force_cfg(int kh, int cfg);

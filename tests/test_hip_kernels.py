@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-@pytest.fixture(scope='module', params=['bx3', 'f32'])
+@pytest.fixture(scope='module', params=['bx3', 'f32', 'hx2'])
 def K(request):
     """every kernel test runs under both matrix-core arithmetic modes of the dense convolutions
     (split-bf16 'bx3' = product default, exact fp32 MFMA 'f32')."""

@@ -106,6 +106,8 @@ SIGNATURES = {
                                       c_fp, c_fp, c_fp]),
     'tdr_transpose_pad': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_conv_force_cfg': (i32, [i32, i32]),
+    'tdr_packed_weight_bytes_hx2': (i64, [i32, i32, i32]),
+    'tdr_pack_weights_hx2': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_pack_weights_bx3_batch': (i32, [c_fp, i64, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_sca_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, c_fp, c_fp]),
     'tdr_sca_bwd': (i32, [c_fp] * 8 + [i32, i32] + [c_fp] * 7 + [c_fp]),

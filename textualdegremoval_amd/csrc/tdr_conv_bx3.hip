@@ -64,13 +64,25 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r - (float)m);
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 union Frag {
     uint4 u;
     bf16x8 v;
+    f16x8 hv;
 };
 
-template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE>
+// Operand split schemes (fp32 tensors in, fp32 accumulation, fp32-class products):
+//   SCH_BX3  x = h + m + l, bf16 each: 6 cross products (lh, hl, mm, mh, hm, hh) -- any fp32 range
+//   SCH_HX2  x = h + m, fp16 each (11 + 11 mantissa bits): 3 cross products (mh, hm, hh; m*m is 2^-22 relative and
+//            measurably irrelevant, profiles/r1/fp16x2_probe_mi355x.log) -- half the matrix work and two operand planes
+//            instead of three, for operands inside the fp16 range (|x| < 65504, magnitudes of interest above ~2^-14):
+//            forward activations and weights; NOT raw gradients (3e-7-sized values lose everything without a pre-scale).
+enum { SCH_BX3 = 0, SCH_HX2 = 1 };
+
+template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH>
 __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
+    constexpr int NS = SCH == SCH_HX2 ? 2 : 3;                  // operand planes
+    constexpr int NP = SCH == SCH_HX2 ? 3 : 6;                  // matrix products per fp32 product
     constexpr int WN = 4 / WM;
     constexpr int BM = 32 * TM * WM;
     constexpr int NT = TN * WN;
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
         }
     };
     auto store_group = [&](int g, int set, int buf) {
-        uint4* sb = smem4 + (buf * 6 + sg) * plane;
+        uint4* sb = smem4 + (buf * (2 * NS) + sg) * plane;
         const int cbase = g * 16 + sg * 8;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -157,15 +169,21 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                 if (GATE) v *= rin2[set][it][i];
                 v *= rks[set][i];
                 v = (ok && cbase + i < a.Cin) ? v : 0.f;
-                __bf16 hh, mm, ll;
-                split3(v, hh, mm, ll);
-                h.v[i] = hh; m.v[i] = mm; l.v[i] = ll;
+                if constexpr (SCH == SCH_HX2) {
+                    const _Float16 hh = (_Float16)v;
+                    h.hv[i] = hh;
+                    m.hv[i] = (_Float16)(v - (float)hh);
+                } else {
+                    __bf16 hh, mm, ll;
+                    split3(v, hh, mm, ll);
+                    h.v[i] = hh; m.v[i] = mm; l.v[i] = ll;
+                }
             }
             if ((inplane >> it) & 1u) {
                 const int p = sp0 + 128 * it;
                 sb[p] = h.u;
                 sb[2 * plane + p] = m.u;
-                sb[4 * plane + p] = l.u;
+                if constexpr (NS == 3) sb[4 * plane + p] = l.u;
             }
         }
     };
@@ -184,9 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int mt = min((m0 >> 5) + wm * TM + tm, MT - 1);
-        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)n * (a.wp_ns >> 2) + (long)mt * 192 + lane;   // wp_ns: floats per image (0 = shared)
+        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)n * (a.wp_ns >> 2) + (long)mt * (NS * 64) + lane;   // wp_ns: floats per image (0 = shared)
     }
-    const long wstep = (long)MT * 192;          // 16-byte units per (group, tap)
+    const long wstep = (long)MT * (NS * 64);    // 16-byte units per (group, tap)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -196,12 +214,12 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    Frag af[TM][3], afn[TM][3];
-    auto load_a = [&](Frag (&dst)[TM][3], long gt) {
+    Frag af[TM][NS], afn[TM][NS];
+    auto load_a = [&](Frag (&dst)[TM][NS], long gt) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) dst[tm][s].u = wfrag[tm][gt * wstep + s * 64];
+            for (int s = 0; s < NS; ++s) dst[tm][s].u = wfrag[tm][gt * wstep + s * 64];
     };
 
 #if TDR_PROBE == 5
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             const int g = g0 + u;
             if (g < ngroups) {
                 const int buf = a.single_buf ? 0 : (g & 1);
-                const uint4* sb = smem4 + buf * 6 * plane;
+                const uint4* sb = smem4 + buf * (2 * NS) * plane;
                 if (TDR_PROBE != 1 && PF == 1 && g + 1 < ngroups) load_group(g + 1, 0);
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
@@ -237,30 +255,36 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                     const long gtn = min((long)g * TAPS + tap + 1, (long)ngroups * TAPS - 1);
                     if (TDR_PROBE != 3) load_a(afn, gtn);
                     if (TDR_PROBE != 1 && PF > 1 && tap == 0 && g + PF < ngroups) load_group(g + PF, u);   // set u is free: group g already sits in LDS
-                    Frag bf[TN][3];
+                    Frag bf[TN][NS];
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                        for (int s = 0; s < 3; ++s) bf[tn][s].u = sb[s * 2 * plane + bbase[tn] + tapoff];
+                        for (int s = 0; s < NS; ++s) bf[tn][s].u = sb[s * 2 * plane + bbase[tn] + tapoff];
                     // small cross terms first, the dominant h*h last
-                    constexpr int SA[6] = {2, 0, 1, 1, 0, 0};
-                    constexpr int SB[6] = {0, 2, 1, 0, 1, 0};
+                    constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};          // bx3: lh hl mm mh hm hh
+                    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};                            // hx2: mh hm hh
 #pragma unroll
-                    for (int q = 0; q < 6; ++q)
+                    for (int q = 0; q < NP; ++q)
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                            for (int tn = 0; tn < TN; ++tn)
-                                if (TDR_PROBE != 2) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
-                                else if (q == 0) {
+                            for (int tn = 0; tn < TN; ++tn) {
+#if TDR_PROBE == 2
+                                if (q == 0)
                                     asm volatile("" ::"v"(__builtin_bit_cast(f32x4, af[tm][0].v)), "v"(__builtin_bit_cast(f32x4, af[tm][1].v)),
                                                  "v"(__builtin_bit_cast(f32x4, af[tm][2].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][0].v)),
                                                  "v"(__builtin_bit_cast(f32x4, bf[tn][1].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][2].v)));
-                                }
+#else
+                                if constexpr (SCH == SCH_HX2)
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
+                                else
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
+#endif
+                            }
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                        for (int s = 0; s < 3; ++s) af[tm][s] = afn[tm][s];
+                        for (int s = 0; s < NS; ++s) af[tm][s] = afn[tm][s];
                 }
                 TDR_STAMP(probe_slot++);                  // 4+3g: MFMA phase of group g issued
                 if (TDR_PROBE != 4) {
@@ -286,8 +310,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     conv_epilogue<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
 }
 
-template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE>
-int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
+template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH>
+int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
+    constexpr int NS = SCH == SCH_HX2 ? 2 : 3;
     constexpr int WN = 4 / WM;
     constexpr int BM = 32 * TM * WM;
     constexpr int NT = TN * WN;
@@ -298,13 +323,13 @@ int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
     // four workgroups instead of two share a CU and hide each other's load / store latencies (tuning aid: TDR_BX_SINGLE)
     static const int single_env = getenv("TDR_BX_SINGLE") ? atoi(getenv("TDR_BX_SINGLE")) : 2;
     b.single_buf = (KH == 3 && (a.Cin + 15) / 16 <= single_env) ? 1 : 0;
-    size_t lds = (size_t)(b.single_buf ? 6 : 12) * LH * LW * 16;
+    size_t lds = (size_t)(b.single_buf ? 1 : 2) * (2 * NS) * LH * LW * 16;
     if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);   // the vector epilogue's four wave-private 32 x 36 patches
     b.tiles_x = tdr_cdiv(a.OW, TW);
     const int tiles_y = tdr_cdiv(a.OH, TH);
     b.mtiles = tdr_cdiv(a.Cout, BM);
     dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
-    auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE>;
+    auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE, SCH>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -317,6 +342,12 @@ int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
 
 // tile-configuration override for profiles/autotune_conv.py: [0] 1x1 kernels, [1] 3x3 / 2x2 kernels; 0 = heuristic
 int g_force_cfg[2] = {getenv("TDR_BX_CFG1") ? atoi(getenv("TDR_BX_CFG1")) : 0, getenv("TDR_BX_CFG3") ? atoi(getenv("TDR_BX_CFG3")) : 0};
+
+template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE>
+int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
+    if (a.scheme == SCH_HX2) return launch_bx_cfg_s<KH, S, WM, TM, TN, EPI, GATE, SCH_HX2>(a, N, st);
+    return launch_bx_cfg_s<KH, S, WM, TM, TN, EPI, GATE, SCH_BX3>(a, N, st);
+}
 
 template <int KH, int S, int EPI, bool GATE>
 int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
@@ -369,6 +400,12 @@ __global__ void pack_weights_bx3_kernel(const float* __restrict__ w, long w_bs, 
         tdr_pack_bx3_frag(wb, Cin, KH, mode, M, Kch, KHe, MT, i, ob);
 }
 
+__global__ void pack_weights_hx2_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int mode, int M, int Kch, int KHe,
+                                        int MT, long total, uint4* __restrict__ wp) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        tdr_pack_hx2_frag(w, Cin, KH, mode, M, Kch, KHe, MT, i, wp);
+}
+
 }  // namespace
 
 extern "C" int tdr_conv_force_cfg(int kh, int cfg) {
@@ -398,6 +435,28 @@ extern "C" int tdr_pack_weights_bx3(const float* w, int Cout, int Cin, int KH, i
     return TDR_OK;
 }
 
+extern "C" int64_t tdr_packed_weight_bytes_hx2(int M, int Kch, int KH_eff) {
+    const long MT = (M + 31) / 32;
+    return (long)((Kch + 15) / 16) * KH_eff * KH_eff * MT * 2 * 1024;
+}
+
+extern "C" int tdr_pack_weights_hx2(const float* w, int Cout, int Cin, int KH, int mode, void* wp, void* stream) {
+    TDR_REQUIRE(w && wp, "tdr_pack_weights_hx2: null pointer");
+    TDR_REQUIRE(mode >= 0 && mode <= 3, "tdr_pack_weights_hx2: bad mode %d", mode);
+    int M, Kch, KHe;
+    if (mode == 0) { M = Cout; Kch = Cin; KHe = KH; }
+    else if (mode == 1) { M = Cin; Kch = Cout; KHe = KH; }
+    else if (mode == 2) { TDR_REQUIRE(KH == 2, "mode 2 needs a 2x2 kernel"); M = 4 * Cin; Kch = Cout; KHe = 1; }
+    else { TDR_REQUIRE(KH == 3, "mode 3 needs a 3x3 kernel"); M = 4 * Cin; Kch = Cout; KHe = 2; }
+    const int MT = (M + 31) / 32;
+    const long total = (long)((Kch + 15) / 16) * KHe * KHe * MT * 64;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weights_hx2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KH, mode, M, Kch,
+                       KHe, MT, total, (uint4*)wp);
+    TDR_LAUNCH_CHECK("pack_weights_hx2_kernel");
+    return TDR_OK;
+}
+
 // B matrices at once (per-image weights of the MDTA core): matrix b is w + b*w_stride (floats), packed to wp + b*per_b bytes,
 // per_b = tdr_packed_weight_bytes_bx3(M, Kch, KH_eff)
 extern "C" int tdr_pack_weights_bx3_batch(const float* w, int64_t w_stride, int B, int Cout, int Cin, int KH, int mode, void* wp,
@@ -421,6 +480,7 @@ int tdr_conv_forward_bx3(const TdrConvDesc* d, void* stream) {
     ConvArgs a;
     a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
     a.wp = (const float*)d->wp; a.wp_ns = d->wp_ns; a.Mpad = d->Mpad; a.Cout = d->Cout;
+    a.scheme = d->wp_fmt == 2 ? SCH_HX2 : SCH_BX3;
     a.out = d->out; a.out_ns = d->out_ns; a.OH = d->OH; a.OW = d->OW;
     a.pad = d->pad;
     a.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);

@@ -25,6 +25,7 @@ struct ConvArgs {
     int relu;
     int vec_epi;      // 1: rows are 16-byte aligned (OW % 4 == 0, aligned bases): LDS-transposed float4 epilogue
     int single_buf;   // split-bf16 kernel: one LDS operand buffer (short K loops; more workgroups per CU)
+    int scheme;       // 0: 3-way bf16 split (6 products), 1: 2-way fp16 split (3 products; operands in fp16 range)
 };
 
 // acc[TM][TN]: wave (wm, wn) owns output-channel tiles wm*TM.. and pixel sub-tiles wn*TN..

@@ -301,7 +301,7 @@ extern "C" int tdr_conv_forward(const TdrConvDesc* d, void* stream) {
     TDR_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->OH > 0 && d->OW > 0, "tdr_conv_forward: bad shape");
     TDR_REQUIRE(d->Mpad % 32 == 0 && d->Mpad >= d->Cout, "tdr_conv_forward: Mpad %d invalid for Cout %d", d->Mpad, d->Cout);
     TDR_REQUIRE(d->epi != EPI_GATEBWD || d->aux, "tdr_conv_forward: GATEBWD needs aux");
-    if (d->wp_fmt == 1) return tdr_conv_forward_bx3(d, stream);
+    if (d->wp_fmt == 1 || d->wp_fmt == 2) return tdr_conv_forward_bx3(d, stream);
     TDR_REQUIRE(d->wp_fmt == 0, "tdr_conv_forward: unknown wp_fmt %d", d->wp_fmt);
     ConvArgs a;
     a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
@@ -316,7 +316,7 @@ extern "C" int tdr_conv_forward(const TdrConvDesc* d, void* stream) {
     a.bias2 = d->bias2; a.bias2_ns = d->bias2_ns; a.bias2_mul = d->bias2_mul;
     a.res = d->res; a.res_ns = d->res_ns; a.mask = d->mask; a.mask_ns = d->mask_ns;
     a.aux = d->aux; a.aux_ns = d->aux_ns; a.relu = d->relu;
-    a.vec_epi = 0; a.single_buf = 0;
+    a.vec_epi = 0; a.single_buf = 0; a.scheme = 0;
     hipStream_t st = (hipStream_t)stream;
     const int N = d->N;
     const int key = d->KH * 1000 + d->stride * 100 + d->dil * 10 + d->epi;
@@ -357,14 +357,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const TdrPackJob* __res
     if (i >= jb.total) return;
     if (jb.fmt == 0)
         reinterpret_cast<float*>(jb.wp)[i] = tdr_pack_f32_elem(jb.w, jb.Cin, jb.KH, jb.mode, jb.CK, jb.M, jb.Kch, jb.KHe, jb.Mx, i);
-    else
+    else if (jb.fmt == 1)
         tdr_pack_bx3_frag(jb.w, jb.Cin, jb.KH, jb.mode, jb.M, jb.Kch, jb.KHe, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
+    else
+        tdr_pack_hx2_frag(jb.w, jb.Cin, jb.KH, jb.mode, jb.M, jb.Kch, jb.KHe, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
 }
 }  // namespace
 
 extern "C" int tdr_pack_job_init(TdrPackJob* job, const float* w, int Cout, int Cin, int KH, int mode, int fmt, void* wp) {
     TDR_REQUIRE(job && w && wp, "tdr_pack_job_init: null pointer");
-    TDR_REQUIRE(mode >= 0 && mode <= 3 && (fmt == 0 || fmt == 1), "tdr_pack_job_init: bad mode/fmt");
+    TDR_REQUIRE(mode >= 0 && mode <= 3 && fmt >= 0 && fmt <= 2, "tdr_pack_job_init: bad mode/fmt");
     int M, Kch, KHe;
     if (mode == 0) { M = Cout; Kch = Cin; KHe = KH; }
     else if (mode == 1) { M = Cin; Kch = Cout; KHe = KH; }

@@ -63,3 +63,28 @@ __device__ __forceinline__ void tdr_pack_bx3_frag(const float* __restrict__ w, i
     uint4* o = wp + ((i >> 6) * 3) * 64 + lane;
     o[0] = h.u; o[64] = mm.u; o[128] = l.u;
 }
+
+// the same fragment in the 2-way fp16 split layout Wp2[group][tap][mt][split(h, m)][lane][8 x f16]
+typedef _Float16 tdr_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void tdr_pack_hx2_frag(const float* __restrict__ w, int Cin, int KH, int mode, int M, int Kch,
+                                                  int KHe, int MT, long i, uint4* __restrict__ wp) {
+    const int taps_e = KHe * KHe;
+    const int lane = (int)(i & 63);
+    long r = i >> 6;
+    const int mt = (int)(r % MT); r /= MT;
+    const int tap = (int)(r % taps_e);
+    const int grp = (int)(r / taps_e);
+    const int m = mt * 32 + (lane & 31);
+    tdr_f16x8 h, mm;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = grp * 16 + 8 * (lane >> 5) + e;
+        const float v = (m < M && c < Kch) ? tdr_pack_value(w, Cin, KH, mode, m, c, tap) : 0.f;
+        const _Float16 a0 = (_Float16)v;
+        h[e] = a0;
+        mm[e] = (_Float16)(v - (float)a0);
+    }
+    uint4* o = wp + ((i >> 6) * 2) * 64 + lane;
+    o[0] = __builtin_bit_cast(uint4, h);
+    o[64] = __builtin_bit_cast(uint4, mm);
+}

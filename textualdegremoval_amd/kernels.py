@@ -16,16 +16,20 @@ PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2 = 0, 1, 2, 3
 #   'bx3' : every fp32 operand split into 3 bf16 terms, 6 cross products on the bf16 MFMA pipe, fp32
 #           accumulate -- fp32-equivalent products at 2.7x the fp32-MFMA rate (csrc/tdr_conv_bx3.hip)
 #   'f32' : exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain)
+#   'hx2' : forward convolutions (PACK_FWD weights: every conv of the forward pass, the frozen ViTs) with a 2-way fp16
+#           split, 3 f16 MFMA products per fp32 product -- half the matrix work of 'bx3' at the same measured accuracy
+#           (profiles/r1/fp16x2_probe_mi355x.log) for operands inside the fp16 range, which forward activations and weights
+#           are; data-gradient and weight-gradient kernels see 1e-7-sized operands and stay on the 3-way bf16 split.
 # The MASA arg-max searches always run on the exact path (near-tie indices must not move).
-MATH = os.environ.get('TDR_MATH', 'bx3')
+MATH = os.environ.get('TDR_MATH', 'hx2')
 # weight gradients of 1x1 convs on the split-bf16 kernel as well (0: exact fp32 kernel)
 WGRAD_1X1_BX3 = os.environ.get('TDR_WGRAD_1X1_BX3', '1') == '1'
-FMT_F32, FMT_BX3 = 0, 1
+FMT_F32, FMT_BX3, FMT_HX2 = 0, 1, 2
 
 
 def set_math(mode):
     global MATH
-    assert mode in ('bx3', 'f32')
+    assert mode in ('bx3', 'f32', 'hx2')
     MATH = mode
 
 
@@ -176,7 +180,10 @@ def _pack_dims(w, mode):
 def _packed_buffer(w, mode, math):
     lib = _lib.load()
     M, Kch, KHe = _pack_dims(w, mode)
-    if math == 'bx3':
+    if math == 'hx2' and mode == PACK_FWD:
+        n = lib.tdr_packed_weight_bytes_hx2(M, Kch, KHe) // 4
+        fmt = FMT_HX2
+    elif math in ('bx3', 'hx2'):
         n = lib.tdr_packed_weight_bytes_bx3(M, Kch, KHe) // 4
         fmt = FMT_BX3
     else:
@@ -251,7 +258,9 @@ def _pack_into(w, mode, pw):
     lib = _lib.load()
     Cout, Cin, KH, _ = w.shape
     assert w.is_contiguous()
-    if pw.fmt == FMT_BX3:
+    if pw.fmt == FMT_HX2:
+        check(lib.tdr_pack_weights_hx2(w.data_ptr(), Cout, Cin, KH, mode, pw.data_ptr(), _stream()), 'tdr_pack_weights_hx2')
+    elif pw.fmt == FMT_BX3:
         check(lib.tdr_pack_weights_bx3(w.data_ptr(), Cout, Cin, KH, mode, pw.data_ptr(), _stream()), 'tdr_pack_weights_bx3')
     else:
         check(lib.tdr_pack_weights(w.data_ptr(), Cout, Cin, KH, mode, pw.data_ptr(), _stream()), 'tdr_pack_weights')
@@ -264,7 +273,7 @@ def pack_weights(w, mode, out=None, math=None):
     if _active_plan is not None and out is None:
         pw = _active_plan.lookup(w, mode, math)
     else:
-        pw = PackedWeights(out, FMT_F32) if (out is not None and math != 'bx3') else _packed_buffer(w, mode, math)
+        pw = PackedWeights(out, FMT_F32) if (out is not None and math == 'f32') else _packed_buffer(w, mode, math)
         _pack_into(w, mode, pw)
     return pw, (M + 31) // 32 * 32, M, Kch, KHe
 
@@ -338,7 +347,7 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
     db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
     d.db = _p(db)
     d.per_image = 1 if per_image else 0
-    d.math = 1 if (MATH == 'bx3' and (KH == 3 or WGRAD_1X1_BX3)) else 0
+    d.math = 1 if (MATH != 'f32' and (KH == 3 or WGRAD_1X1_BX3)) else 0
     need = lib.tdr_wgrad_ws_floats(C.byref(d))
     ws = workspace(need, x.device, 'wgrad')
     d.ws, d.ws_floats = ws.data_ptr(), ws.numel()

@@ -68,7 +68,7 @@ def _img_conv(x, Wt, Cout, out=None):
     """1x1 conv with per-image weights Wt [N, Kp, Mp] (fp32 packed layout emitted by tdr_mdta_*): on the split-bf16
     kernel after one batched re-pack, or directly on the exact fp32 kernel (kernels.MATH)."""
     Kp, Mp = Wt.shape[-2], Wt.shape[-1]
-    if K.MATH == 'bx3':
+    if K.MATH != 'f32':
         pw, per_b = K.pack_f32packed_to_bx3(Wt)
         return K.conv_forward(x, pw, Mp, Cout, 1, wp_ns=per_b, out=out)
     return K.conv_forward(x, Wt, Mp, Cout, 1, wp_ns=Kp * Mp, out=out)
