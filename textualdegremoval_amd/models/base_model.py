@@ -50,7 +50,13 @@ class BaseModel:
     def get_current_log(self):
         """floats, like the reference; the device->host read happens here (at print_freq), not in
         every optimize_parameters call."""
-        return OrderedDict((k, float(v)) for k, v in self.log_dict.items())
+        out = OrderedDict((k, float(v)) for k, v in self.log_dict.items())
+        if any(v != v or v in (float('inf'), float('-inf')) for v in out.values()):
+            from .. import kernels as K
+            hint = (' -- under TDR_MATH=hx2 the forward convolutions need activations inside the fp16 range (|x| < 65504); '
+                    'TDR_MATH=bx3 has the full fp32 range') if K.MATH == 'hx2' else ''
+            raise FloatingPointError(f'non-finite loss {dict(out)}{hint}')
+        return out
 
     def model_to_device(self, net):
         """to(device); in distributed mode a GradAllReducer (RCCL over xGMI) takes DDP's place."""
