@@ -37,9 +37,9 @@ orig = K.conv_forward
 
 def rec(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, **kw):
     out = orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
-    if getattr(wp, 'fmt', 0) == K.FMT_BX3 and stride == 1 and Cout > 32:
+    if getattr(wp, 'fmt', 0) in (K.FMT_BX3, K.FMT_HX2) and stride == 1 and Cout > 32:
         key = (KH, x.shape[0], kw.get('Cin') or (x.shape[1] // 2 if kw.get('gate') else x.shape[1]), Cout, x.shape[2], x.shape[3],
-               kw.get('epi', 0), bool(kw.get('gate')))
+               kw.get('epi', 0), bool(kw.get('gate')), 'hx2' if wp.fmt == K.FMT_HX2 else 'bx3')
         if key not in calls:
             kw2 = dict(kw); kw2['out'] = out
             calls[key] = [0, (x, wp, Mpad, Cout, KH, stride, dil, pad, kw2)]
@@ -86,6 +86,6 @@ for key, (cnt, args) in sorted(calls.items(), key=lambda kv: -kv[1][0]):
     lib.tdr_conv_force_cfg(KH, 0)
     tot_def += cnt * base
     tot_best += cnt * best
-    tag = f'{key[0]}x{key[0]} N{key[1]} {key[2]}->{key[3]} @{key[4]}x{key[5]} e{key[6]} g{int(key[7])}'
-    print(f'{tag:40s} {cnt:6d} {base:9.1f}  {"  ".join(row)}   best {bestc}')
+    tag = f'{key[0]}x{key[0]} N{key[1]} {key[2]}->{key[3]} @{key[4]}x{key[5]} e{key[6]} g{int(key[7])} {key[8]}'
+    print(f'{tag:44s} {cnt:6d} {base:9.1f}  {"  ".join(row)}   best {bestc}')
 print(f'sum over the step: heuristic {tot_def / 1e3:.2f} ms, per-shape best {tot_best / 1e3:.2f} ms')

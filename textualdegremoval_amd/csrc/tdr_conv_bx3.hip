@@ -365,7 +365,8 @@ int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
         }
         // short K loops over many pixels (the high-resolution levels) are staging-bound: the small 64 x 128 tile keeps
         // four workgroups per CU in flight (profiles/autotune_conv.py: 5-15 % on Cin <= 128 1x1 layers at >= 256^2)
-        if (g_force_cfg[KH == 1 ? 0 : 1] == 0 && a.Cin <= (KH == 1 ? 128 : 64) && blocks(64, 128) >= 2048)
+        // (3-way split only: with the cheaper 2-plane fp16 staging the larger tiles win again, autotune_nafnet_hx2.log)
+        if (g_force_cfg[KH == 1 ? 0 : 1] == 0 && a.scheme == SCH_BX3 && a.Cin <= (KH == 1 ? 128 : 64) && blocks(64, 128) >= 2048)
             return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);
         if constexpr (KH == 1) {   // two register sets of prefetched operands: 128 x 128 keeps the kernel under 256 VGPRs
             const int force = g_force_cfg[0];   // tuning aid (tdr_conv_force_cfg / TDR_BX_CFG1)
