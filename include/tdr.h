@@ -226,8 +226,10 @@ int tdr_pad_crop(const float* src, int N, int C, int Hs, int Ws, float* dst, int
 /* ReLU backward: out = act > 0 ? go : 0 (Encoder/ResidualBlock nn.ReLU, :52,132) */
 int tdr_relu_bwd(const float* go, const float* act, int64_t numel, float* out, void* stream);
 
-/* L1 loss fwd+bwd -- losses/losses.py:11-13,52-53.  loss (1 float) = w*mean|p-t|, dpred = w*sign/numel */
-int tdr_l1_loss(const float* pred, const float* target, int64_t numel, float loss_weight,
+/* L1 loss fwd+bwd -- losses/losses.py:11-13,52-53.  loss (1 float) = w*mean|p-t|, dpred = grad_scale*w*sign/numel.
+ * grad_scale is the (power-of-two, hence exact) loss scale of the backward pass: 1 unless the fp16-split kernels carry the
+ * gradient chain; the parameter gradients are divided by it again in tdr_multi_copy. */
+int tdr_l1_loss(const float* pred, const float* target, int64_t numel, float loss_weight, float grad_scale,
                 float* loss, float* dpred, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------
@@ -333,9 +335,10 @@ int tdr_transpose_pad(const float* src, int B, int R, int C, int LDd, float* dst
  * grads/params/...: device arrays of n_tensors device pointers; sizes: device int64[n_tensors].
  * sumsq[0] = sum g^2 over all tensors (double, deterministic two-stage; partial: n_chunks doubles). */
 int tdr_optim_chunk(void);
-/* dst[t][0..sizes[t]) = src[t][..] for all tensors of the chunk table, one launch (gradient arena gather) */
+/* dst[t][0..sizes[t]) = scale * src[t][..] for all tensors of the chunk table, one launch (gradient arena gather;
+ * scale = 1 / loss scale) */
 int tdr_multi_copy(const float* const* src, float* const* dst, const int64_t* sizes, const int* chunk_tensor,
-                   const int* chunk_index, int n_chunks, void* stream);
+                   const int* chunk_index, int n_chunks, float scale, void* stream);
 int tdr_grad_sumsq(const float* const* grads, const int64_t* sizes, const int* chunk_tensor, const int* chunk_index,
                    int n_chunks, double* partial, double* sumsq, void* stream);
 /* p,m,v updated in place.  coef = min(1, max_norm/(sqrt(sumsq)+1e-6)) computed on device when

@@ -119,7 +119,7 @@ SIGNATURES = {
     'tdr_pixel_unshuffle2': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_pad_crop': (i32, [c_fp, i32, i32, i32, i32, c_fp, i32, i32, c_fp]),
     'tdr_relu_bwd': (i32, [c_fp, c_fp, i64, c_fp, c_fp]),
-    'tdr_l1_loss': (i32, [c_fp, c_fp, i64, f32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_l1_loss': (i32, [c_fp, c_fp, i64, f32, f32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_lr_blocks_fwd': (i32, [c_fp] + [i32] * 8 + [c_fp, c_fp]),
     'tdr_lr_blocks_bwd': (i32, [c_fp] + [i32] * 8 + [c_fp, c_fp]),
     'tdr_patch_inv_norm': (i32, [c_fp] + [i32] * 10 + [c_fp, c_fp]),
@@ -139,7 +139,7 @@ SIGNATURES = {
     'tdr_attention_fwd': (i32, [c_fp, i32, i32, i32, i32, i32, f32, c_fp, c_fp]),
     'tdr_token_match': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i64, c_fp, c_fp, c_fp, c_fp]),
     'tdr_optim_chunk': (i32, []),
-    'tdr_multi_copy': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp]),
+    'tdr_multi_copy': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
     'tdr_grad_sumsq': (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp]),
     'tdr_adamw_step': (i32, [c_fp] * 8 + [i32, c_fp, C.POINTER(f32), i32, f32, i32, f32, f32, f32, f32, i32, c_fp]),
     'tdr_adamw_step_dev': (i32, [c_fp] * 8 + [i32, c_fp, c_fp, f32, i32, f32, f32, f32, f32, c_fp]),

@@ -48,13 +48,13 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const double* __restr
 // tensors into the flat all-reduce / optimiser arena with ONE launch instead of one copy kernel per tensor.
 __global__ __launch_bounds__(256) void multi_copy_kernel(const float* const* __restrict__ src, float* const* __restrict__ dst,
                                                         const int64_t* __restrict__ sizes, const int* __restrict__ chunk_tensor,
-                                                        const int* __restrict__ chunk_index) {
+                                                        const int* __restrict__ chunk_index, float scale) {
     const int t = chunk_tensor[blockIdx.x];
     const long base = (long)chunk_index[blockIdx.x] * CHUNK;
     const long n = sizes[t];
     const float* s = src[t];
     float* d = dst[t];
-    for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) d[i] = s[i];
+    for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) d[i] = s[i] * scale;   // scale: 1 / (power-of-two loss scale)
 }
 
 struct AdamArgs {
@@ -151,10 +151,10 @@ extern "C" int tdr_adamw_step_dev(float* const* params, const float* const* grad
 }
 
 extern "C" int tdr_multi_copy(const float* const* src, float* const* dst, const int64_t* sizes, const int* chunk_tensor,
-                              const int* chunk_index, int n_chunks, void* stream) {
+                              const int* chunk_index, int n_chunks, float scale, void* stream) {
     TDR_REQUIRE(src && dst && sizes && chunk_tensor && chunk_index && n_chunks > 0, "tdr_multi_copy: bad argument");
     hipLaunchKernelGGL(multi_copy_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, src, dst, sizes, chunk_tensor,
-                       chunk_index);
+                       chunk_index, scale);
     TDR_LAUNCH_CHECK("multi_copy");
     return TDR_OK;
 }

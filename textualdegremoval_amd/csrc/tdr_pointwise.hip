@@ -655,14 +655,14 @@ extern "C" int tdr_relu_bwd(const float* go, const float* act, int64_t numel, fl
     return TDR_OK;
 }
 
-extern "C" int tdr_l1_loss(const float* pred, const float* target, int64_t numel, float loss_weight, float* loss,
-                           float* dpred, float* ws, void* stream) {
+extern "C" int tdr_l1_loss(const float* pred, const float* target, int64_t numel, float loss_weight, float grad_scale,
+                           float* loss, float* dpred, float* ws, void* stream) {
     TDR_REQUIRE(pred && target && loss && dpred && ws, "tdr_l1_loss: null pointer (ws needs 2*1024 floats)");
     hipStream_t st = (hipStream_t)stream;
     const int blocks = grid1d(numel, L1_BLOCKS);
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(l1_kernel, dim3(blocks), dim3(256), 0, st, pred, target, (long)numel,
-                       loss_weight / (float)numel, dpred, part);
+                       loss_weight / (float)numel * grad_scale, dpred, part);
     hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, st, part, blocks, (double)loss_weight / (double)numel, loss);
     TDR_LAUNCH_CHECK("l1_loss");
     return TDR_OK;

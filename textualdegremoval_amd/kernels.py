@@ -27,6 +27,18 @@ WGRAD_1X1_BX3 = os.environ.get('TDR_WGRAD_1X1_BX3', '1') == '1'
 FMT_F32, FMT_BX3, FMT_HX2 = 0, 1, 2
 
 
+# True while a backward pass runs on loss-scaled gradients (models/image_restoration_ref_model.py picks the power of two
+# that brings dpred to ~2^9): the data-gradient convolutions of TDR_MATH=hx2 then use the fp16 split as well -- every
+# gradient operand of a cfg2 step has max|g| within 2^-0.4 .. 2^10 of that scale (profiles/grad_range_survey.py).
+GRAD_SCALED = False
+
+
+def set_grad_scaled(on):
+    global GRAD_SCALED
+    prev, GRAD_SCALED = GRAD_SCALED, bool(on)
+    return prev
+
+
 def set_math(mode):
     global MATH
     assert mode in ('bx3', 'f32', 'hx2')
@@ -180,7 +192,7 @@ def _pack_dims(w, mode):
 def _packed_buffer(w, mode, math):
     lib = _lib.load()
     M, Kch, KHe = _pack_dims(w, mode)
-    if math == 'hx2' and mode == PACK_FWD:
+    if math == 'hx2' and (mode == PACK_FWD or GRAD_SCALED):
         n = lib.tdr_packed_weight_bytes_hx2(M, Kch, KHe) // 4
         fmt = FMT_HX2
     elif math in ('bx3', 'hx2'):
@@ -205,7 +217,7 @@ class PackPlan:
         self.valid = False
 
     def lookup(self, w, mode, math):
-        key = (w.data_ptr(), tuple(w.shape), mode, math)
+        key = (w.data_ptr(), tuple(w.shape), mode, math, GRAD_SCALED)
         e = self.entries.get(key)
         if e is None:
             pw = _packed_buffer(w, mode, math)
@@ -459,10 +471,10 @@ def channel_sum(x):
     return out
 
 
-def multi_copy(src_tab, dst_tab, sizes, chunk_tensor, chunk_index, n_chunks):
-    """device pointer tables (int64 tensors); one launch copies every listed tensor."""
+def multi_copy(src_tab, dst_tab, sizes, chunk_tensor, chunk_index, n_chunks, scale=1.0):
+    """device pointer tables (int64 tensors); one launch copies (and scales) every listed tensor."""
     check(_lib.load().tdr_multi_copy(src_tab.data_ptr(), dst_tab.data_ptr(), sizes.data_ptr(), chunk_tensor.data_ptr(),
-                                     chunk_index.data_ptr(), n_chunks, _stream()), 'tdr_multi_copy')
+                                     chunk_index.data_ptr(), n_chunks, float(scale), _stream()), 'tdr_multi_copy')
 
 
 def copy_rows(src, src_ns, dst, dst_ns, N, length):
@@ -524,12 +536,12 @@ def relu_bwd(go, act):
     return out
 
 
-def l1_loss(pred, target, loss_weight=1.0):
+def l1_loss(pred, target, loss_weight=1.0, grad_scale=1.0):
     assert pred.is_contiguous() and target.is_contiguous()
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred)
     ws = workspace(4096, pred.device, 'l1')
-    check(_lib.load().tdr_l1_loss(pred.data_ptr(), target.data_ptr(), pred.numel(), float(loss_weight), loss.data_ptr(),
+    check(_lib.load().tdr_l1_loss(pred.data_ptr(), target.data_ptr(), pred.numel(), float(loss_weight), float(grad_scale), loss.data_ptr(),
                                   dpred.data_ptr(), ws.data_ptr(), _stream()), 'tdr_l1_loss')
     return loss, dpred
 

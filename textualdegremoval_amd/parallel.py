@@ -97,6 +97,8 @@ class GradAllReducer:
                     done=[None, None], flip=0))
 
     # ---- per step -----------------------------------------------------------
+    grad_unscale = 1.0          # 1 / (power-of-two loss scale of the backward pass); applied while gathering
+
     def begin(self, defer_collectives=False):
         """defer_collectives: do not launch per-bucket all-reduces while gradients arrive (hipGraph
         capture of the backward pass); the caller runs allreduce_flat() afterwards."""
@@ -113,9 +115,12 @@ class GradAllReducer:
     def _copy_in(self, key, g):
         dst = self.views[key]
         if g.is_cuda:
+            assert self.grad_unscale == 1.0, 'loss-scaled gradients go through the bucket gather'
             K.copy_rows(g.contiguous(), 0, dst, 0, 1, g.numel())
         else:
             dst.copy_(g)                                  # CPU (gloo unit tests only)
+            if self.grad_unscale != 1.0:
+                dst.mul_(self.grad_unscale)
 
     def allreduce_flat(self):
         """one all-reduce (mean) of the whole gradient arena on the current stream (few, large collectives
@@ -147,7 +152,7 @@ class GradAllReducer:
         if not capturing:
             tb['done'][slot] = torch.cuda.Event()
             tb['done'][slot].record()
-        K.multi_copy(tb['src'], tb['dst'], tb['sizes'], tb['ct'], tb['ci'], tb['n_chunks'])
+        K.multi_copy(tb['src'], tb['dst'], tb['sizes'], tb['ct'], tb['ci'], tb['n_chunks'], scale=self.grad_unscale)
         self._keep = [self._pending.pop(k) for k in tb['names']]   # sources stay referenced until the next gather is enqueued
 
     def _launch(self, bi):
