@@ -127,7 +127,9 @@ typedef struct TdrWgradDesc {
     int per_image;
     float* ws; int64_t ws_floats;      /* split-K workspace */
     int math;          /* 0: exact fp32 MFMA; 1: 3-way bf16 split on the bf16 MFMA pipe where supported
-                          (stride 1, 1x1 / 3x3), exact fp32 otherwise */
+                          (stride 1, 1x1 / 3x3), exact fp32 otherwise; 2: 2-way fp16 split (3 products) on the same
+                          kernels -- both operands must lie in the fp16 range (activations; gradients of a loss-scaled
+                          backward pass, see tdr_l1_loss) */
 } TdrWgradDesc;
 int64_t tdr_wgrad_ws_floats(const TdrWgradDesc* d);
 int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream);

@@ -20,8 +20,13 @@
 #include "../../include/tdr.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
+
+// operand schemes, as in tdr_conv_bx3.hip: 0 = 3-way bf16 split (6 products), 1 = 2-way fp16 split (3 products; both
+// operands inside the fp16 range: activations, and gradients of a loss-scaled backward pass)
+enum { WSCH_BX3 = 0, WSCH_HX2 = 1 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte fragment (8 bf16) as dwords
 
@@ -46,13 +51,28 @@ constexpr int wb_max_nch(int KH, int P) {
                    : P / 8;
 }
 
+template <int SCH>
 __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h, u32x4& m, u32x4& l) {
-    bf16x8 hv, mv, lv;
-    WSPLIT_ONE(a[0], 0) WSPLIT_ONE(a[1], 1) WSPLIT_ONE(a[2], 2) WSPLIT_ONE(a[3], 3)
-    WSPLIT_ONE(b[0], 4) WSPLIT_ONE(b[1], 5) WSPLIT_ONE(b[2], 6) WSPLIT_ONE(b[3], 7)
-    h = __builtin_bit_cast(u32x4, hv);
-    m = __builtin_bit_cast(u32x4, mv);
-    l = __builtin_bit_cast(u32x4, lv);
+    if constexpr (SCH == WSCH_HX2) {
+        wf16x8 hv, mv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = i < 4 ? a[i & 3] : b[i & 3];
+            const _Float16 hh = (_Float16)x;
+            hv[i] = hh;
+            mv[i] = (_Float16)(x - (float)hh);
+        }
+        h = __builtin_bit_cast(u32x4, hv);
+        m = __builtin_bit_cast(u32x4, mv);
+        l = m;
+    } else {
+        bf16x8 hv, mv, lv;
+        WSPLIT_ONE(a[0], 0) WSPLIT_ONE(a[1], 1) WSPLIT_ONE(a[2], 2) WSPLIT_ONE(a[3], 3)
+        WSPLIT_ONE(b[0], 4) WSPLIT_ONE(b[1], 5) WSPLIT_ONE(b[2], 6) WSPLIT_ONE(b[3], 7)
+        h = __builtin_bit_cast(u32x4, hv);
+        m = __builtin_bit_cast(u32x4, mv);
+        l = __builtin_bit_cast(u32x4, lv);
+    }
 }
 
 // PRE: the global loads of tile t+1 are issued before the MFMAs of tile t (register double buffering)
@@ -61,8 +81,10 @@ __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h
 // the register budget a prefetch would need.  Tiles that start a column are staged synchronously.
 // CL = log2 of the tile width C (a template constant: the staging index arithmetic divides by C-derived sizes for
 // every item of every tile; with run-time divisors that integer math out-weighed the MFMAs)
-template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL>
+template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL, int SCH>
 __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
+    constexpr int NS = SCH == WSCH_HX2 ? 2 : 3;      // operand planes
+    constexpr int NP = SCH == WSCH_HX2 ? 3 : 6;      // matrix products per fp32 product
     static_assert(!DMA || (KH == 3 && !PRE && !GATE), "DMA staging: 3x3 only");
     static_assert(WMw * WNw * WKw == 4, "4 waves");
     static_assert(KH == 1 || (TMW == 1 && TNW == 1), "3x3: one 32x32 tile pair (9 accumulators) per wave");
@@ -88,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     constexpr int NCH = (LR * CP) >> 3;              // 8-element chunks per input channel
     constexpr int IPITCH = (NCH | 1) << 3;           // channel pitch (elements): 16 B x odd
     __bf16* s_d = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* s_i = s_d + 3 * BMc * DPITCH;
-    float* raw_d = reinterpret_cast<float*>(s_i + 3 * BNc * IPITCH);     // [BMc][P] fp32 (DMA only)
+    __bf16* s_i = s_d + NS * BMc * DPITCH;           // (2-byte elements: bf16 or f16 planes)
+    float* raw_d = reinterpret_cast<float*>(s_i + NS * BNc * IPITCH);    // [BMc][P] fp32 (DMA only)
     float* raw_i = raw_d + BMc * P;                                       // [BNc][R][CP] fp32: the R new halo rows
 
     const int split = blockIdx.x;
@@ -148,11 +170,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         if (!live) return;
         dsum[it] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
         u32x4 h, m, l;
-        split8v(v0, v1, h, m, l);
+        split8v<SCH>(v0, v1, h, m, l);
         u32x4* dst = reinterpret_cast<u32x4*>(s_d + ldsoff);
         dst[0] = h;
         dst[(BMc * DPITCH) >> 3] = m;
-        dst[(2 * BMc * DPITCH) >> 3] = l;
+        if constexpr (NS == 3) dst[(2 * BMc * DPITCH) >> 3] = l;
     };
     auto i_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live, bool from_raw = false) {
         int oy0, ox0, ty;
@@ -195,11 +217,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     auto i_store = [&](const f32x4& v0, const f32x4& v1, int ldsoff, bool live) {
         if (!live) return;
         u32x4 h, m, l;
-        split8v(v0, v1, h, m, l);
+        split8v<SCH>(v0, v1, h, m, l);
         u32x4* dst = reinterpret_cast<u32x4*>(s_i + ldsoff);
         dst[0] = h;
         dst[(BNc * IPITCH) >> 3] = m;
-        dst[(2 * BNc * IPITCH) >> 3] = l;
+        if constexpr (NS == 3) dst[(2 * BNc * IPITCH) >> 3] = l;
     };
     // prefetch registers (PRE only): every index below is a compile-time constant after unrolling
     f32x4 pd0[PRE ? NITD : 1], pd1[PRE ? NITD : 1], pi0[PRE ? NITI : 1], pi1[PRE ? NITI : 1];
@@ -286,8 +308,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][y][t][r] = 0.f;
 
-    constexpr int SA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int SB[6] = {0, 2, 1, 0, 1, 0};
+    // bx3: lh hl mm mh hm hh; hx2: mh hm hh (small cross terms first)
+    constexpr int SA[6] = {SCH == WSCH_HX2 ? 1 : 2, 0, SCH == WSCH_HX2 ? 0 : 1, 1, 0, 0};
+    constexpr int SB[6] = {0, SCH == WSCH_HX2 ? 1 : 2, SCH == WSCH_HX2 ? 0 : 1, 0, 1, 0};
+    auto mma = [](const u32x4& x, const u32x4& y, const f32x16& c) {
+        if constexpr (SCH == WSCH_HX2)
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, x), __builtin_bit_cast(wf16x8, y), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+    };
 
     if (PRE && t_begin < t_end) prefetch(t_begin);
     for (int t = t_begin; t < t_end; ++t) {
@@ -305,33 +334,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         for (int q = 0; q < KPW; ++q) {
             const int u = 2 * (wk * KPW + q) + kg;                       // this lane half's 8-pixel chunk
             const int row = (u * 8) >> cl, xo = (u * 8) & (C - 1);
-            u32x4 af[TMW][3];
+            u32x4 af[TMW][NS];
 #pragma unroll
             for (int x = 0; x < TMW; ++x)
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < NS; ++s)
                     af[x][s] = *reinterpret_cast<const u32x4*>(s_d + (long)(s * BMc + (wm * TMW + x) * 32 + j) * DPITCH + u * 8);
             if constexpr (KH == 1) {
-                u32x4 bf[TNW][3];
+                u32x4 bf[TNW][NS];
 #pragma unroll
                 for (int y = 0; y < TNW; ++y)
 #pragma unroll
-                    for (int s = 0; s < 3; ++s)
+                    for (int s = 0; s < NS; ++s)
                         bf[y][s] = *reinterpret_cast<const u32x4*>(s_i + (long)(s * BNc + (wn * TNW + y) * 32 + j) * IPITCH + u * 8);
 #pragma unroll
-                for (int p = 0; p < 6; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int x = 0; x < TMW; ++x)
 #pragma unroll
-                        for (int y = 0; y < TNW; ++y)
-                            acc[x][y][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[x][SA[p]]),
-                                                                                  __builtin_bit_cast(bf16x8, bf[y][SB[p]]), acc[x][y][0], 0, 0, 0);
+                        for (int y = 0; y < TNW; ++y) acc[x][y][0] = mma(af[x][SA[p]], bf[y][SB[p]], acc[x][y][0]);
             } else {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    u32x4 bf[3][3];                                      // [kx][split]
+                    u32x4 bf[3][NS];                                     // [kx][split]
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) {
+                    for (int s = 0; s < NS; ++s) {
                         const u32x4* src = reinterpret_cast<const u32x4*>(s_i + (long)(s * BNc + wn * 32 + j) * IPITCH + ((ring0 + row + ky) % LR) * CP + xo);
                         const u32x4 lo = src[0], hi = src[1];
                         // LDS col c holds input x = ox0 + c - 4; tap kx reads cols xo + kx + 3 ... + 10 (pad = 1):
@@ -343,12 +370,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
                                            __builtin_amdgcn_alignbit(hi[1], hi[0], 16), __builtin_amdgcn_alignbit(hi[2], hi[1], 16)};
                     }
 #pragma unroll
-                    for (int p = 0; p < 6; ++p)
+                    for (int p = 0; p < NP; ++p)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx)
-                            acc[0][0][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[0][SA[p]]),
-                                                                                            __builtin_bit_cast(bf16x8, bf[kx][SB[p]]),
-                                                                                            acc[0][0][ky * 3 + kx], 0, 0, 0);
+                        for (int kx = 0; kx < 3; ++kx) acc[0][0][ky * 3 + kx] = mma(af[0][SA[p]], bf[kx][SB[p]], acc[0][0][ky * 3 + kx]);
                 }
             }
         }
@@ -419,15 +443,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         }
 }
 
-template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL>
-int launch_wgb_cl(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
+template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL, int SCH>
+int launch_wgb_cl_s(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
+    constexpr int NS = SCH == WSCH_HX2 ? 2 : 3;
     constexpr int BMc = 32 * TMW * WMw, BNc = 32 * TNW * WNw;
     constexpr int C = 1 << CL, R = P / C;
     constexpr int CP = KH == 3 ? C + 8 : C, LR = KH == 3 ? R + 2 : R;
     constexpr int ipitch = (((LR * CP) >> 3) | 1) << 3;
-    const size_t lds = (size_t)(3 * BMc * (P + 8) + 3 * BNc * ipitch) * 2 + (DMA ? (size_t)(BMc * P + BNc * R * CP) * 4 : 0);
+    size_t lds = (size_t)(NS * BMc * (P + 8) + NS * BNc * ipitch) * 2 + (DMA ? (size_t)(BMc * P + BNc * R * CP) * 4 : 0);
+    const size_t red = (size_t)(WKw > 1 ? (4 / WKw) * TMW * TNW * KH * KH * 16 * 64 : BMc * (P / 8)) * 4;   // in-block reductions reuse the tile memory
+    if (lds < red) lds = red;
     dim3 grid(N * p.spi, tdr_cdiv(a.Cout, BMc), tdr_cdiv(a.Cin, BNc));
-    auto kern = wgrad_bx3_kernel<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, CL>;
+    auto kern = wgrad_bx3_kernel<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, CL, SCH>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -436,6 +463,12 @@ int launch_wgb_cl(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     TDR_LAUNCH_CHECK("wgrad_bx3_kernel");
     return TDR_OK;
+}
+
+template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL>
+int launch_wgb_cl(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
+    if (a.scheme == WSCH_HX2) return launch_wgb_cl_s<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, CL, WSCH_HX2>(a, p, N, st);
+    return launch_wgb_cl_s<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, CL, WSCH_BX3>(a, p, N, st);
 }
 
 template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA = false>

@@ -10,6 +10,7 @@ struct WgArgs {
     int pad, tw_log2, tiles_x, tiles_y, tpi /*tiles per image*/, tps /*tiles per split*/, spi /*splits per image*/;
     float* part;
     float* dbpart;      // optional [nsplit][Cout]: per-split sums of dout rows (bias gradient), ci-tile 0 only
+    int scheme;         // split-kernel operand scheme: 0 = 3-way bf16, 1 = 2-way fp16 (TdrWgradDesc.math == 2)
 };
 
 struct WgPlan { int tw_log2, tiles_x, tiles_y, tpi, tps, spi, cfg, WKw, BMc, BNc; };

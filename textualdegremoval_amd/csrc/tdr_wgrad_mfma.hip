@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * KL) void wgrad_reduce_kernel(const float* __re
 // cfg: 0 = waves 2x2x1 tile 2x2 (128x128) | 1 = waves 1x1x4 tile 2x1 (64x32) | 2 = 2x2x1 tile 1x1 (64x64)
 //      3 = waves 1x1x4 tile 1x1 (32x32)
 WgPlan make_plan(const TdrWgradDesc* d) {
-    if (d->math == 1 && tdr_wgrad_bx3_supported(d)) return tdr_wgrad_bx3_plan(d);
+    if (d->math >= 1 && tdr_wgrad_bx3_supported(d)) return tdr_wgrad_bx3_plan(d);
     WgPlan p;
     p.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);
     const int TW = 1 << p.tw_log2, TH = 64 >> p.tw_log2;
@@ -293,7 +293,8 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     const bool g = d->gate != 0;
     int rc = TDR_ERR_UNSUPPORTED;
     const int key = d->KH * 10 + d->stride;
-    if (d->math == 1 && tdr_wgrad_bx3_supported(d)) {
+    a.scheme = d->math == 2 ? 1 : 0;
+    if (d->math >= 1 && tdr_wgrad_bx3_supported(d)) {
         rc = tdr_wgrad_bx3_launch(a, p, d, st);
     } else if (key == 11) {
         switch (p.cfg) {

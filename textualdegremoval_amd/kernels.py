@@ -342,7 +342,7 @@ def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None
     return out
 
 
-def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=False, want_db=False):
+def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=False, want_db=False, fp16_range=False):
     """returns G [groups, Cout, Cin, KH, KH] (groups = N if per_image else 1); with want_db also the
     bias gradient sum_{n,y,x} dout [Cout] computed in the same pass."""
     lib = _lib.load()
@@ -359,7 +359,12 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
     db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
     d.db = _p(db)
     d.per_image = 1 if per_image else 0
-    d.math = 1 if (MATH != 'f32' and (KH == 3 or WGRAD_1X1_BX3)) else 0
+    # fp16_range: both operands are forward activations (Restormer's q k^T Gram); otherwise `dout` is a gradient and the
+    # fp16 split needs the loss-scaled backward pass (GRAD_SCALED)
+    if MATH == 'hx2' and (fp16_range or GRAD_SCALED) and (KH == 3 or WGRAD_1X1_BX3):
+        d.math = 2
+    else:
+        d.math = 1 if (MATH != 'f32' and (KH == 3 or WGRAD_1X1_BX3)) else 0
     need = lib.tdr_wgrad_ws_floats(C.byref(d))
     ws = workspace(need, x.device, 'wgrad')
     d.ws, d.ws_floats = ws.data_ptr(), ws.numel()

@@ -84,7 +84,7 @@ def tblock_fwd(x, P, heads, ln_type):
     t = _pw_fwd(xn, P, 'attn.qkv')                                               # [N,3C,H,W]
     qkv = K.dwconv_fwd(t, P['attn.qkv_dwconv.weight'], P.get('attn.qkv_dwconv.bias'))
     ss = K.row_sumsq(qkv, 2 * Cc)                                                # |q_i|^2, |k_j|^2
-    Gm = K.conv_wgrad(qkv[:, Cc:2 * Cc], qkv[:, :Cc], Cc, Cc, 1, per_image=True).view(N, Cc, Cc)   # q k^T
+    Gm = K.conv_wgrad(qkv[:, Cc:2 * Cc], qkv[:, :Cc], Cc, Cc, 1, per_image=True, fp16_range=True).view(N, Cc, Cc)   # q k^T
     A, AT = K.mdta_softmax(Gm, ss, P['attn.temperature'], heads)
     o = _img_conv(qkv[:, 2 * Cc:], AT, Cc)                                       # attn v
     y = _pw_fwd(o, P, 'attn.project_out', res=x)
