@@ -265,10 +265,11 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'math': {'bx3': 'fp32 tensors; dense contractions as 3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate): '
                             'per-product error <= one fp32 rounding, see profiles/r1/bf16x3_probe_mi355x.log; TDR_MATH=f32 selects exact fp32 MFMA',
-                     'hx2': 'fp32 tensors; forward convolutions as 2-way fp16 split (3 f16 MFMA products per fp32 product), data- and '
-                            'weight-gradient contractions as 3-way bf16 split (6 products), fp32 accumulate everywhere: measured error of both '
-                            'schemes = that of the exact fp32 MFMA chain (profiles/r1/fp16x2_probe_mi355x.log, bf16x3_probe_mi355x.log); '
-                            'TDR_MATH=bx3 / f32 select the all-bf16-split / exact fp32 MFMA paths',
+                     'hx2': 'fp32 tensors; dense contractions as 2-way fp16 split (3 f16 MFMA products per fp32 product, fp32 accumulate), '
+                            'the backward pass on gradients scaled by an exact power of two (dpred ~ 2^9, removed when the parameter '
+                            'gradients are gathered); per-image correlations as 3-way bf16 split / exact fp32: measured error of the split '
+                            'schemes = that of the exact fp32 MFMA chain (profiles/r1/fp16x2_probe_mi355x.log, bf16x3_probe_mi355x.log, '
+                            'grad_range_survey_cfg2.log); TDR_MATH=bx3 / f32 select the all-bf16-split / exact fp32 MFMA paths',
                      'f32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)'}[K.MATH],
             'config': {'workload': ('BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
                                     f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
