@@ -488,7 +488,7 @@ int launch_wgb(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
 //            5 = 1x1, waves 2x1x2 (64 co x 32 ci, K split 2), P = 64
 bool tdr_wgrad_bx3_supported(const TdrWgradDesc* d) {
     // float4 staging: rows must be 16-byte aligned pieces (W % 4 == 0), 3x3 only with pad 1
-    if (d->stride != 1 || d->OW < 8 || d->Cin < 8 || d->W % 4 != 0 || d->OW % 4 != 0) return false;
+    if (d->stride != 1 || d->OW < 8 || d->W % 4 != 0 || d->OW % 4 != 0) return false;
     if (d->in_ns % 4 != 0 || d->dout_ns % 4 != 0) return false;
     if (d->KH == 1) return d->pad == 0;
     return d->KH == 3 && d->pad == 1 && !d->gate;
