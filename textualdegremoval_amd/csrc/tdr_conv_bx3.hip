@@ -32,6 +32,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // TDR_PROBE (profiling builds only, profiles/probes/): ablations of the main loop --
 // 1: no operand (pixel) global loads after the prologue   2: no MFMAs (operands kept live)
 // 3: no weight-fragment loads after the prologue          4: no LDS stores / barriers after the prologue
+// conv1x1_hx2_kernel: 11: no operand loads after the prologue   12: no MFMAs   13: no epilogue   14: return after the
+// prologue (launch + first stage)   15: no conversion / LDS stores after the prologue
 #ifndef TDR_PROBE
 #define TDR_PROBE 0
 #endif
@@ -310,8 +312,262 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     conv_epilogue<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 / stride 1 / 2-way fp16 split with 16-byte operand staging.
+//
+// The generic kernel above stages pixels with one dword load per (lane, channel): on the K <= 256 layers the texture-
+// address path, not the matrix pipe, is the limit (profiles/README.md, timeline probe).  A 1x1 tile has no halo, so here a
+// lane owns 4 adjacent pixels x 8 channels = eight float4 loads (128-byte row segments per 8 lanes), converts them to the
+// same [split][octet][pixel] 16-byte LDS slots, and one pass of the 256 threads stages KS = 8192 / NPX channels (64 for
+// a 128-pixel tile) instead of 16: a quarter of the vector-memory instructions and a quarter of the barriers.  LDS slots
+// are XOR-swizzled (slot ^ ((slot >> 4) & 3)) so that both the 4-slot-strided writes and the 32-contiguous fragment reads
+// are conflict-free.  Same weight fragments, accumulator layout and epilogues as conv_bx3_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz1(int slot) { return slot ^ ((slot >> 4) & 3); }
+
+template <int WM, int TM, int TN, int EPI, bool GATE>
+__global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
+    constexpr int NS = 2, NP = 3;
+    constexpr int WN = 4 / WM;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int NT = TN * WN;
+    constexpr int NPX = 32 * NT;          // pixels per tile
+    constexpr int QUADS = NPX / 4;        // float4 pixel quads per tile
+    constexpr int OCT = 256 / QUADS;      // 8-channel octets staged per pass: one (octet, quad) task per thread
+    constexpr int KS = 8 * OCT;           // channels per stage
+    constexpr int GPS = KS / 16;          // 16-channel MFMA groups per stage
+    constexpr int PFD = GATE ? 1 : 2;     // stages of operand loads in flight (register sets)
+
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int j = lane & 31, kk = lane >> 5;
+    const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2, TH = NT * SR;
+    int logical;
+    {   // XCD-aware block order, as in conv_bx3_kernel
+        const int T = gridDim.x, b = blockIdx.x;
+        const int q = T >> 3, r = T & 7, xcd = b & 7, slot = b >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int mtile = logical % a.mtiles, ptile = logical / a.mtiles;
+    const int tx = ptile % a.tiles_x, ty = ptile / a.tiles_x;
+    const int m0 = mtile * BM;
+    const int n = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const long HWin = (long)a.H * a.W;
+
+    // ---- staging task of this thread: octet so, pixel quad sq
+    const int so = tid / QUADS, sq = tid % QUADS;
+    const int p0 = 4 * sq;
+    const int gy = oy0 + (p0 >> a.tw_log2), gx = ox0 + (p0 & (TW - 1));
+    const bool pok = gy < a.H && gx < a.W;            // W % 4 == 0: a quad is inside or outside as a whole
+    const long goff = pok ? (long)gy * a.W + gx : 0;
+    const float* in_n = a.in + (long)n * a.in_ns;
+    const float* ks_n = a.kscale ? a.kscale + (long)n * a.kscale_ns : nullptr;
+    const int ngroups = (a.Cin + 15) >> 4;
+    const int nstages = (a.Cin + KS - 1) / KS;
+
+    float4 rin[PFD][8];
+    float4 rin2[GATE ? PFD : 1][GATE ? 8 : 1];
+    float rks[PFD][8];
+    auto load_stage = [&](int st, int set) {
+        const int cbase = st * KS + so * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ci = cbase + i;
+            rin[set][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rks[set][i] = 1.f;
+            if (GATE) rin2[set][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pok && ci < a.Cin) {
+                const float* src = in_n + (long)ci * HWin + goff;
+                rin[set][i] = *reinterpret_cast<const float4*>(src);
+                if (GATE) rin2[set][i] = *reinterpret_cast<const float4*>(src + a.gate_off);
+                if (ks_n) rks[set][i] = ks_n[ci];
+            }
+        }
+    };
+    int wslot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wslot[i] = so * NPX + swz1(p0 + i);
+    auto store_stage = [&](int set, int buf) {
+        uint4* sb = smem4 + buf * (NS * OCT * NPX);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            Frag h, m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 q4 = rin[set][i];
+                float v = px == 0 ? q4.x : (px == 1 ? q4.y : (px == 2 ? q4.z : q4.w));
+                if (GATE) {
+                    const float4 g4 = rin2[set][i];
+                    v *= px == 0 ? g4.x : (px == 1 ? g4.y : (px == 2 ? g4.z : g4.w));
+                }
+                v *= rks[set][i];
+                const _Float16 hh = (_Float16)v;
+                h.hv[i] = hh;
+                m.hv[i] = (_Float16)(v - (float)hh);
+            }
+            sb[wslot[px]] = h.u;
+            sb[OCT * NPX + wslot[px]] = m.u;
+        }
+    };
+
+    // ---- fragment addresses
+    int bslot[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bslot[tn] = kk * NPX + swz1(32 * (wn * TN + tn) + j);
+    const int MT = a.Mpad >> 5;
+    const uint4* wfrag[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int mt = min((m0 >> 5) + wm * TM + tm, MT - 1);
+        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)n * (a.wp_ns >> 2) + (long)mt * (NS * 64) + lane;
+    }
+    const long wstep = (long)MT * (NS * 64);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    Frag af[TM][NS], afn[TM][NS];
+    auto load_a = [&](Frag (&dst)[TM][NS], long g) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) dst[tm][s].u = wfrag[tm][g * wstep + s * 64];
+    };
+
+    load_a(af, 0);
+#pragma unroll
+    for (int p = 0; p < PFD; ++p)
+        if (p < nstages) load_stage(p, p);
+    store_stage(0, 0);
+    __syncthreads();
+#if TDR_PROBE == 14
+    if (a.Cin > 0) return;
+#endif
+
+    for (int s0 = 0; s0 < nstages; s0 += PFD) {
+#pragma unroll
+        for (int u = 0; u < PFD; ++u) {
+            const int st = s0 + u;
+            if (st < nstages) {
+                const int buf = a.single_buf ? 0 : (st & 1);
+                const uint4* sb = smem4 + buf * (NS * OCT * NPX);
+#pragma unroll
+                for (int gg = 0; gg < GPS; ++gg) {
+                    const int g = st * GPS + gg;
+                    if (g < ngroups) {
+                        load_a(afn, min(g + 1, ngroups - 1));
+                        // set u is free (stage st already sits in LDS): the loads of stage st + PFD go out behind the
+                        // first weight-fragment prefetch, so the in-order wait for the fragments leaves them in flight
+                        if (TDR_PROBE != 11 && gg == 0 && st + PFD < nstages) load_stage(st + PFD, u);
+                        Frag bf[TN][NS];
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) bf[tn][s].u = sb[s * (OCT * NPX) + 2 * gg * NPX + bslot[tn]];
+                        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};   // mh hm hh
+#pragma unroll
+                        for (int q = 0; q < NP; ++q)
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) {
+#if TDR_PROBE == 12
+                                    if (q == 0)
+                                        asm volatile("" ::"v"(__builtin_bit_cast(f32x4, af[tm][0].u)), "v"(__builtin_bit_cast(f32x4, af[tm][1].u)),
+                                                     "v"(__builtin_bit_cast(f32x4, bf[tn][0].u)), "v"(__builtin_bit_cast(f32x4, bf[tn][1].u)));
+#else
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
+#endif
+                                }
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) af[tm][s] = afn[tm][s];
+                    }
+                }
+#if TDR_PROBE == 15
+                __syncthreads();
+                continue;
+#endif
+                if (a.single_buf) __syncthreads();            // one LDS stage: every wave is done reading stage st
+                if (st + 1 < nstages) store_stage((u + 1) % PFD, a.single_buf ? 0 : (buf ^ 1));
+                __syncthreads();
+            }
+        }
+    }
+
+#if TDR_PROBE == 13
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[tm][tn][r];
+        if (sacc == 1.2345e33f) a.out[0] = sacc;
+        return;
+    }
+#endif
+    if constexpr (EPI != EPI_PSHUF) {
+        if (a.vec_epi) {
+            conv_epilogue_vec<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, lane, reinterpret_cast<float*>(smem4) + wave * (32 * 36));
+            return;
+        }
+    }
+    conv_epilogue<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
+}
+
+template <int WM, int TM, int TN, int EPI, bool GATE>
+int launch_c1_hx2(const ConvArgs& a, int N, hipStream_t st) {
+    constexpr int WN = 4 / WM;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int NT = TN * WN;
+    const int TW = 1 << a.tw_log2, SR = 32 >> a.tw_log2, TH = NT * SR;
+    ConvArgs b = a;
+    b.tiles_x = tdr_cdiv(a.OW, TW);
+    const int tiles_y = tdr_cdiv(a.OH, TH);
+    b.mtiles = tdr_cdiv(a.Cout, BM);
+    dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
+    // a stage is 2 splits x OCT octets x NPX pixels x 16 B = 32 KiB.  Launches of several rounds of workgroups run with
+    // one stage buffer (four workgroups per CU overlap each other's phases); a single round double-buffers instead.
+    static const long single_from = getenv("TDR_C1_SINGLE") ? atol(getenv("TDR_C1_SINGLE")) : 1025;
+    b.single_buf = (long)grid.x * N >= single_from ? 1 : 0;
+    const size_t lds = b.single_buf ? 32768 : 2 * 32768;
+    auto kern = conv1x1_hx2_kernel<WM, TM, TN, EPI, GATE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, b);
+    TDR_LAUNCH_CHECK("conv1x1_hx2_kernel");
+    return TDR_OK;
+}
+
+// 16-byte staging needs whole, aligned pixel quads; it pays from four stages of K on (probe_conv1x1.py on MI355X:
+// 256->512 @64x64 N=4 30.1 -> 27.0 us, 512->256 37.9 -> 32.2 us; 128->256 @256x256 with two stages 123 -> 134 us,
+// 64->128 @512x512 with one stage 189 -> 226 us: those stay on the 16-channel pipeline of conv_bx3_kernel)
+inline bool c1_hx2_ok(const ConvArgs& a, int npx) {
+    static const bool off = getenv("TDR_C1_OLD") != nullptr;
+    static const int min_stages = getenv("TDR_C1_STAGES") ? atoi(getenv("TDR_C1_STAGES")) : 4;
+    const int ks = 8192 / npx;
+    return !off && (a.Cin + ks - 1) / ks >= min_stages && a.pad == 0 && a.W % 4 == 0 && a.in_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+           a.H == a.OH && a.W == a.OW;
+}
+
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH>
 int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
+    if constexpr (KH == 1 && S == 1 && SCH == SCH_HX2 && EPI != EPI_PSHUF)
+        if (c1_hx2_ok(a, 32 * TN * (4 / WM))) return launch_c1_hx2<WM, TM, TN, EPI, GATE>(a, N, st);
     constexpr int NS = SCH == SCH_HX2 ? 2 : 3;
     constexpr int WN = 4 / WM;
     constexpr int BM = 32 * TM * WM;
