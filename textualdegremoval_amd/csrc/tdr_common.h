@@ -42,6 +42,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// wave sum on the VALU only (DPP lane permutes inside each row of 16, then one v_readlane per row): no LDS traffic
+// and short dependency chains, for kernels that reduce many values per wave.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_perm<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_perm<0x141>(v);    // row_half_mirror
+    v += dpp_perm<0x140>(v);    // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

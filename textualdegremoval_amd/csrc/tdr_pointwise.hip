@@ -66,35 +66,44 @@ __global__ __launch_bounds__(64 * SLICES) void ln_fwd_kernel(const float* __rest
     }
 }
 
-// any C: re-reads x (L2-resident for the small deep maps this serves)
-__global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __restrict__ x, long x_ns,
-                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                            float eps, int center, int C, int HW,
-                                                            float* __restrict__ y, float* __restrict__ mu,
-                                                            float* __restrict__ rstd) {
-    __shared__ float red[4][64];
+// any C: re-reads x (L2-resident for the small deep maps this serves); 16 channel slices of 64 pixels
+__global__ __launch_bounds__(1024) void ln_fwd_generic_kernel(const float* __restrict__ x, long x_ns,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             float eps, int center, int C, int HW,
+                                                             float* __restrict__ y, float* __restrict__ mu,
+                                                             float* __restrict__ rstd) {
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
     const bool pok = px < HW;
-    const float* xn = x + (long)n * x_ns + px;
+    const float* xn = x + (long)n * x_ns + (pok ? px : HW - 1);
+    auto total = [&]() {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        return t;
+    };
     float s = 0.f;
-    for (int c = slice; c < C; c += 4) s += pok ? xn[(long)c * HW] : 0.f;
+#pragma unroll 8
+    for (int c = slice; c < C; c += 16) s += xn[(long)c * HW];
     red[slice][lane] = s;
     __syncthreads();
-    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    const float mean = total() / (float)C;
     __syncthreads();
     float q = 0.f;
-    for (int c = slice; c < C; c += 4) {
-        const float d = (pok ? xn[(long)c * HW] : 0.f) - mean;
+#pragma unroll 8
+    for (int c = slice; c < C; c += 16) {
+        const float d = xn[(long)c * HW] - mean;
         q += d * d;
     }
     red[slice][lane] = q;
     __syncthreads();
-    const float rs = 1.0f / sqrtf((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C + eps);
+    const float rs = 1.0f / sqrtf(total() / (float)C + eps);
     if (!pok) return;
     float* yn = y + ((long)n * C) * HW + px;
     const float mo = center ? mean : 0.f;
-    for (int c = slice; c < C; c += 4) yn[(long)c * HW] = (xn[(long)c * HW] - mo) * rs * w[c] + (b ? b[c] : 0.f);
+#pragma unroll 8
+    for (int c = slice; c < C; c += 16) yn[(long)c * HW] = (xn[(long)c * HW] - mo) * rs * w[c] + (b ? b[c] : 0.f);
     if (slice == 0) {
         mu[(long)n * HW + px] = mean;
         rstd[(long)n * HW + px] = rs;
@@ -186,10 +195,13 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
 
 // any C: 64 pixels x 16 channel slices; two passes over the channels (the second re-reads the
 // 64-pixel x C tile from L2).  Loads are unconditional (clamped pixel index).
+// PART: the second pass also reduces this block's 64 pixels of sum(go*yhat), sum(go) per channel into
+// part[block][2][C] (instead of a separate ln_param_grad_kernel pass over go and x).
+template <bool PART>
 __global__ __launch_bounds__(1024) void ln_bwd_generic_kernel(
     const float* __restrict__ go, const float* __restrict__ x, long x_ns, const float* __restrict__ mu,
     const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ add, long add_ns, int add_C,
-    int center, int C, int HW, float* __restrict__ gx) {
+    int center, int C, int HW, float* __restrict__ gx, float* __restrict__ part) {
     __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
@@ -214,14 +226,93 @@ __global__ __launch_bounds__(1024) void ln_bwd_generic_kernel(
     const float mg = center ? S1 / (float)C : 0.f, mgy = S2 / (float)C;
     const float* ab_ = add ? add + (long)n * add_ns : xb;
     float* ob = gx + (long)n * C * HW;
-#pragma unroll 4
-    for (int c = slice; c < C; c += 16) {
-        const float g = gb_[(unsigned)c * uHW + pxc] * w[c];
-        const float yh = (xb[(unsigned)c * uHW + pxc] - m) * rs;
-        const float av = ab_[(unsigned)min(c, add ? add_C - 1 : C - 1) * uHW + pxc];
-        float v = rs * (g - yh * mgy - mg);
+    for (int c0 = slice; c0 < C; c0 += 64) {        // four channels per trip: 12 loads in flight, then the reductions
+        float g0[4], xv[4], av[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = min(c0 + 16 * k, C - 1);
+            g0[k] = gb_[(unsigned)c * uHW + pxc];
+            xv[k] = xb[(unsigned)c * uHW + pxc];
+            av[k] = ab_[(unsigned)min(c, add ? add_C - 1 : C - 1) * uHW + pxc];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + 16 * k;
+            if (c < C) {                              // wave-uniform
+                const float g = g0[k] * w[c];
+                const float yh = (xv[k] - m) * rs;
+                float v = rs * (g - yh * mgy - mg);
+                if (add && c < add_C) v += av[k];
+                if (pok) ob[(unsigned)c * uHW + pxc] = v;
+                if (PART) {
+                    const float sw = wave_sum(pok ? g0[k] * (yh + off) : 0.f), sb = wave_sum(pok ? g0[k] : 0.f);
+                    if (lane == 0) {
+                        float* pb = part + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 2) * C;
+                        pb[c] = sw;
+                        pb[C + c] = sb;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// single pass for C <= 16*CPT: the 64-pixel x C tile of go and x lives in registers (CPT channels per thread, all
+// 2*CPT loads in flight at once), with the per-block parameter-gradient partials of the PART variant above.
+template <int CPT>
+__global__ __launch_bounds__(1024) void ln_bwd_cached_kernel(
+    const float* __restrict__ go, const float* __restrict__ x, long x_ns, const float* __restrict__ mu,
+    const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ add, long add_ns, int add_C,
+    int center, int C, int HW, float* __restrict__ gx, float* __restrict__ part) {
+    __shared__ float red[2][16][64];
+    // the channel slice through readfirstlane: channel row offsets are then scalar, every access is
+    // (scalar row base) + (one 32-bit pixel offset register) instead of a 64-bit address per channel
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int px = blockIdx.x * 64 + lane, n = blockIdx.y;
+    const bool pok = px < HW;
+    const unsigned pxc = pok ? px : HW - 1;
+    const float* xb = x + (long)n * x_ns;
+    const float* gb_ = go + (long)n * C * HW;
+    float g0[CPT], xv[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const long row = (long)min(slice + 16 * i, C - 1) * HW;
+        g0[i] = (gb_ + row)[pxc];
+        xv[i] = (xb + row)[pxc];
+    }
+    const float m = mu[(long)n * HW + pxc], rs = rstd[(long)n * HW + pxc];
+    const float off = center ? 0.f : m * rs;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {            // branch-free: channels past C carry clamped loads and a zero weight
+        const int c = slice + 16 * i;
+        const float wc = c < C ? w[min(c, C - 1)] : 0.f;
+        g0[i] = c < C ? g0[i] : 0.f;
+        xv[i] = (xv[i] - m) * rs;                // yhat
+        const float g = g0[i] * wc;
+        s1 += g; s2 += g * (xv[i] + off);
+    }
+    red[0][slice][lane] = s1; red[1][slice][lane] = s2;
+    __syncthreads();
+    float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { S1 += red[0][k][lane]; S2 += red[1][k][lane]; }
+    const float mg = center ? S1 / (float)C : 0.f, mgy = S2 / (float)C;
+    const float* ab_ = add ? add + (long)n * add_ns : xb;
+    float* ob = gx + (long)n * C * HW;
+    float* pb = part + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 2) * C;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + 16 * i, cc = min(c, C - 1);
+        const long row = (long)cc * HW;
+        float v = rs * (g0[i] * w[cc] - xv[i] * mgy - mg);
+        const float av = (ab_ + (long)min(cc, add ? add_C - 1 : C - 1) * HW)[pxc];
         if (add && c < add_C) v += av;
-        if (pok) ob[(unsigned)c * uHW + pxc] = v;
+        const float sw = wave_sum_dpp(pok ? g0[i] * (xv[i] + off) : 0.f), sb = wave_sum_dpp(pok ? g0[i] : 0.f);
+        if (c < C) {                              // wave-uniform
+            if (pok) (ob + row)[pxc] = v;
+            if (lane == 0) { pb[c] = sw; pb[C + c] = sb; }
+        }
     }
 }
 
@@ -516,7 +607,7 @@ extern "C" int tdr_layernorm2d_fwd(const float* x, int64_t x_ns, const float* w,
     else if (C <= 128) LN_FWD(4, 32);
     else if (C <= 256) LN_FWD(8, 32);
     else if (C <= 512) LN_FWD(16, 32);
-    else hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, dim3(256), 0, st, x, (long)x_ns, w, b, eps, center, C, HW, y, mu, rstd);
+    else hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, dim3(1024), 0, st, x, (long)x_ns, w, b, eps, center, C, HW, y, mu, rstd);
 #undef LN_FWD
     TDR_LAUNCH_CHECK("ln_fwd");
     return TDR_OK;
@@ -543,11 +634,24 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
         else LN_BWD(8, 16);
 #undef LN_BWD
     } else {
-        hipLaunchKernelGGL(ln_bwd_generic_kernel, dim3(tdr_cdiv(HW, 64), N), dim3(1024), 0, st, go, x, (long)x_ns, mu, rstd,
-                           w, add, (long)add_ns, add_C, center, C, HW, gx);
-        hipLaunchKernelGGL(ln_param_grad_kernel, dim3(C, LN_GEN_SPLITS), dim3(256), 0, st, go, x, (long)x_ns, mu, rstd, center, N,
-                           C, HW, ws);
-        nparts = LN_GEN_SPLITS;
+        static const bool fuse = getenv("TDR_LN_NOFUSE") == nullptr;
+        if (tiles <= LN_BWD_GRID && fuse) {   // the workspace holds LN_BWD_GRID partial rows: one per 64-pixel block
+            static const bool cached = getenv("TDR_LN_NOCACHE") == nullptr;
+#define LN_BWDC(P) hipLaunchKernelGGL(ln_bwd_cached_kernel<P>, dim3(tdr_cdiv(HW, 64), N), dim3(1024), 0, st, go, x, (long)x_ns, mu, rstd, w, add, (long)add_ns, add_C, center, C, HW, gx, ws)
+            if (cached && C <= 256) LN_BWDC(16);
+            else if (cached && C <= 512) LN_BWDC(32);
+            else
+                hipLaunchKernelGGL(ln_bwd_generic_kernel<true>, dim3(tdr_cdiv(HW, 64), N), dim3(1024), 0, st, go, x, (long)x_ns,
+                                   mu, rstd, w, add, (long)add_ns, add_C, center, C, HW, gx, ws);
+#undef LN_BWDC
+            nparts = tiles;
+        } else {
+            hipLaunchKernelGGL(ln_bwd_generic_kernel<false>, dim3(tdr_cdiv(HW, 64), N), dim3(1024), 0, st, go, x, (long)x_ns, mu,
+                               rstd, w, add, (long)add_ns, add_C, center, C, HW, gx, (float*)nullptr);
+            hipLaunchKernelGGL(ln_param_grad_kernel, dim3(C, LN_GEN_SPLITS), dim3(256), 0, st, go, x, (long)x_ns, mu, rstd, center,
+                               N, C, HW, ws);
+            nparts = LN_GEN_SPLITS;
+        }
     }
     hipLaunchKernelGGL(pair_sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 2), dim3(1024), 0, st, ws, nparts, C, gw, gb);
     TDR_LAUNCH_CHECK("ln_bwd");
