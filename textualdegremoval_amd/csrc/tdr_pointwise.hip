@@ -119,7 +119,8 @@ __global__ __launch_bounds__(64 * SLICES) void ln_bwd_kernel(
     const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ add, long add_ns, int add_C,
     int center, int N, int C, int HW, float* __restrict__ gx, float* __restrict__ part /*[grid][2][C]*/) {
     __shared__ float red[2][SLICES][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    // wave-uniform channel slice (readfirstlane): channel row offsets become scalar address arithmetic
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles = (HW + 63) / 64;
     float aw[CPT], ab[CPT];
 #pragma unroll
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(64 * KL) void pair_sum_partials_kernel(const float*
     }
 }
 
-constexpr int LN_BWD_GRID = 256;
+constexpr int LN_BWD_GRID = 1024;     // workspace rows (upper bound of the persistent grid)
+static const int ln_bwd_grid = getenv("TDR_LN_BWD_GRID") ? atoi(getenv("TDR_LN_BWD_GRID")) : 256;
 constexpr int LN_GEN_SPLITS = 16;
 
 // ===========================================================================
@@ -626,7 +628,8 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
     const int tiles = tdr_cdiv(HW, 64) * N;
     int nparts;
     if (C <= 128) {
-        const int grid = tiles < LN_BWD_GRID ? tiles : LN_BWD_GRID;
+        const int cap = ln_bwd_grid < 1 ? 1 : (ln_bwd_grid > LN_BWD_GRID ? LN_BWD_GRID : ln_bwd_grid);
+        const int grid = tiles < cap ? tiles : cap;
         nparts = grid;
 #define LN_BWD(S, P) hipLaunchKernelGGL((ln_bwd_kernel<S, P>), dim3(grid), dim3(64 * S), 0, st, go, x, (long)x_ns, mu, rstd, w, add, (long)add_ns, add_C, center, N, C, HW, gx, ws)
         if (C <= 32) LN_BWD(4, 8);
