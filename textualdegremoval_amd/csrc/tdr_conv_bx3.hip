@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
         for (int u = 0; u < PFD; ++u) {
             const int st = s0 + u;
             if (st < nstages) {
-                const int buf = a.single_buf ? 0 : (st & 1);
+                const int buf = st & 1;
                 const uint4* sb = smem4 + buf * (NS * OCT * NPX);
 #pragma unroll
                 for (int gg = 0; gg < GPS; ++gg) {
@@ -497,8 +497,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
                 __syncthreads();
                 continue;
 #endif
-                if (a.single_buf) __syncthreads();            // one LDS stage: every wave is done reading stage st
-                if (st + 1 < nstages) store_stage((u + 1) % PFD, a.single_buf ? 0 : (buf ^ 1));
+                if (st + 1 < nstages) store_stage((u + 1) % PFD, buf ^ 1);
                 __syncthreads();
             }
         }
@@ -537,11 +536,8 @@ int launch_c1_hx2(const ConvArgs& a, int N, hipStream_t st) {
     const int tiles_y = tdr_cdiv(a.OH, TH);
     b.mtiles = tdr_cdiv(a.Cout, BM);
     dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
-    // a stage is 2 splits x OCT octets x NPX pixels x 16 B = 32 KiB.  Launches of several rounds of workgroups run with
-    // one stage buffer (four workgroups per CU overlap each other's phases); a single round double-buffers instead.
-    static const long single_from = getenv("TDR_C1_SINGLE") ? atol(getenv("TDR_C1_SINGLE")) : 1025;
-    b.single_buf = (long)grid.x * N >= single_from ? 1 : 0;
-    const size_t lds = b.single_buf ? 32768 : 2 * 32768;
+    b.single_buf = 0;
+    const size_t lds = 2 * 32768;        // two stages of 2 splits x OCT octets x NPX pixels x 16 B = 32 KiB
     auto kern = conv1x1_hx2_kernel<WM, TM, TN, EPI, GATE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -553,21 +549,25 @@ int launch_c1_hx2(const ConvArgs& a, int N, hipStream_t st) {
     return TDR_OK;
 }
 
-// 16-byte staging needs whole, aligned pixel quads; it pays from four stages of K on (probe_conv1x1.py on MI355X:
-// 256->512 @64x64 N=4 30.1 -> 27.0 us, 512->256 37.9 -> 32.2 us; 128->256 @256x256 with two stages 123 -> 134 us,
-// 64->128 @512x512 with one stage 189 -> 226 us: those stay on the 16-channel pipeline of conv_bx3_kernel)
-inline bool c1_hx2_ok(const ConvArgs& a, int npx) {
+// 16-byte staging needs whole, aligned pixel quads; it pays from four stages of K on and for launches of a single
+// round of workgroups (probe_conv1x1.py / kernel traces on MI355X: 256->512 @64x64 N=4 30.1 -> 27.0 us, 512->256 37.9
+// -> 32.2 us; 128->256 @256x256 with two stages 123 -> 134 us, 64->128 @512x512 with one stage 189 -> 226 us; 2048
+// workgroups of 256->256 @128x128 87 -> 96 us: with 64 KiB of LDS only two workgroups share a CU, and the many-round
+// launches want the four or five of the 16-channel pipeline of conv_bx3_kernel)
+inline bool c1_hx2_ok(const ConvArgs& a, int npx, int bm, int N) {
     static const bool off = getenv("TDR_C1_OLD") != nullptr;
     static const int min_stages = getenv("TDR_C1_STAGES") ? atoi(getenv("TDR_C1_STAGES")) : 4;
+    static const long max_blocks = getenv("TDR_C1_BLOCKS") ? atol(getenv("TDR_C1_BLOCKS")) : 512;
     const int ks = 8192 / npx;
-    return !off && (a.Cin + ks - 1) / ks >= min_stages && a.pad == 0 && a.W % 4 == 0 && a.in_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+    const long blocks = (long)tdr_cdiv((long)a.OH * a.OW, npx) * tdr_cdiv(a.Cout, bm) * N;
+    return !off && blocks <= max_blocks && (a.Cin + ks - 1) / ks >= min_stages && a.pad == 0 && a.W % 4 == 0 && a.in_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
            a.H == a.OH && a.W == a.OW;
 }
 
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH>
 int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
     if constexpr (KH == 1 && S == 1 && SCH == SCH_HX2 && EPI != EPI_PSHUF)
-        if (c1_hx2_ok(a, 32 * TN * (4 / WM))) return launch_c1_hx2<WM, TM, TN, EPI, GATE>(a, N, st);
+        if (c1_hx2_ok(a, 32 * TN * (4 / WM), 32 * TM * WM, N)) return launch_c1_hx2<WM, TM, TN, EPI, GATE>(a, N, st);
     constexpr int NS = SCH == SCH_HX2 ? 2 : 3;
     constexpr int WN = 4 / WM;
     constexpr int BM = 32 * TM * WM;

@@ -11,6 +11,8 @@
 // Waves are arranged WMw x WNw x WKw: for narrow layers (32 channels) the four
 // waves split the K (pixel) range instead of the output tile.  Split-K partials
 // go to a workspace and are reduced in a fixed order (deterministic).
+#include <stdio.h>
+#include <stdlib.h>
 #include "tdr_common.h"
 #include "tdr_wgrad_common.h"
 #include "../../include/tdr.h"
@@ -294,6 +296,10 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     int rc = TDR_ERR_UNSUPPORTED;
     const int key = d->KH * 10 + d->stride;
     a.scheme = d->math == 2 ? 1 : 0;
+    static const bool dbg = getenv("TDR_WG_DEBUG") != nullptr;   // which shapes miss the split kernel
+    if (dbg && !(d->math >= 1 && tdr_wgrad_bx3_supported(d)))
+        fprintf(stderr, "[tdr] exact wgrad: math %d N %d %d->%d @%dx%d k%d s%d pad %d gate %d per_image %d in_ns %ld dout_ns %ld\n", d->math,
+                d->N, d->Cin, d->Cout, d->H, d->W, d->KH, d->stride, d->pad, d->gate, d->per_image, (long)d->in_ns, (long)d->dout_ns);
     if (d->math >= 1 && tdr_wgrad_bx3_supported(d)) {
         rc = tdr_wgrad_bx3_launch(a, p, d, st);
     } else if (key == 11) {
