@@ -180,8 +180,9 @@ def main():
 
     # ---- roofline of the dominant kernel family (3x3 stride-1 implicit GEMM on the fp32 matrix
     # cores: masa_enc forward + data-gradient launches), measured with HIP events on the launch stream
+    # (every rank runs the instrumented step -- it contains the gradient all-reduce -- but only rank 0 reports)
     roof, roof_other = None, []
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
         recs = []
         orig = K.conv_forward
 
@@ -215,8 +216,9 @@ def main():
         finally:
             K.conv_forward = orig
             model.use_hip_graph = graph_was
-        # the family splits by operand scheme (kernels.MATH = 'hx2': forward launches on the 2-way fp16 split, data-gradient
-        # launches on the 3-way bf16 split); `roofline` is the scheme with the larger total time, the other goes to roofline_other
+        # the family splits by operand scheme if a step mixes them (TDR_GRAD_SCALE=0 under hx2: forward launches on the 2-way
+        # fp16 split, data-gradient launches on the 3-way bf16 split); `roofline` is the scheme with the larger total time,
+        # the other goes to roofline_other
         FAM = {0: ('conv_mfma_kernel<KH=3,S=1> (exact fp32 v_mfma_f32_32x32x2_f32)', PEAK_F32, 'dense fp32 MFMA peak'),
                1: ('conv_bx3_kernel<KH=3,S=1,SCH_BX3> (3-way bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)',
                    PEAK_BX3, '2.5 PFLOP/s dense bf16 MFMA / 6 cross products = fp32-equivalent peak of the split scheme'),
@@ -300,8 +302,9 @@ def main():
                                      'alg_bytes_per_image': CFG3['B_alg'], 'alg_flop_per_image': CFG3['F_alg']}
         if not a.no_cpu_baseline and world == 1 and a.arch == 'nafnet':
             line['cpu_baseline'] = cpu_baseline(a.width, enc, a.size)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        barrier()
         dist.destroy_process_group()
 
 

@@ -19,7 +19,7 @@ def _bench(nproc, port):
         cmd += ['-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
                 '--master-port', str(port)]
     cmd += [os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc), '--steps', '2', '--warmup', '1', '--width', '8', '--enc', '1,1,1,1',
-            '--size', '128', '--batch', '1', '--backend', 'gloo', '--no-roofline', '--no-cpu-baseline']
+            '--size', '128', '--batch', '1', '--backend', 'gloo', '--no-cpu-baseline']     # roofline leg on: every rank must run its instrumented step
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
