@@ -38,6 +38,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define TDR_PROBE 0
 #endif
 
+
 #if TDR_PROBE == 5
 // timeline probe: wave 0 of a few blocks stamps s_memtime at the phase boundaries of the main loop
 __device__ unsigned long long tdr_probe_ts[8][64];
@@ -81,7 +82,7 @@ union Frag {
 //            forward activations and weights; NOT raw gradients (3e-7-sized values lose everything without a pre-scale).
 enum { SCH_BX3 = 0, SCH_HX2 = 1 };
 
-template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH>
+template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH, int AD = 0>
 __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     constexpr int NS = SCH == SCH_HX2 ? 2 : 3;                  // operand planes
     constexpr int NP = SCH == SCH_HX2 ? 3 : 6;                  // matrix products per fp32 product
@@ -93,6 +94,13 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     // prefetch depth in 16-channel groups: a 1x1 group is only TM*TN*6 MFMAs (0.2-0.6 us), far less than the
     // HBM latency, so its operand loads are issued two groups ahead; 9-tap groups are long enough for one.
     constexpr int PF = (KH == 1) ? 2 : 1;
+    // AD > 0: weight-fragment prefetch ring of the 9-tap kernels.  A (group, tap) step is only TM*TN*NP MFMAs (0.1 - 0.4 us),
+    // less than an L2 round trip, so the fragments of step i + AD are requested when step i has consumed its slot (slot =
+    // tap % AD is a compile-time index: AD divides 9).  AD = 0: the next step's fragments only (afn double buffer).
+    // MI355X, N = 8: 512 -> 512 @32x32 175 -> 122 us and 256 -> 256 @64x64 125 -> 114 us with AD = 9; the 72 extra VGPRs
+    // cost the many-round high-resolution launches their occupancy (32 -> 32 @512x512 230 -> 241 us), and with two m-tiles
+    // per wave the ring spills: launch_bx_cfg_s picks it for single-round launches of the TM = 1 kernels only.
+    static_assert(AD == 0 || (KH == 3 && 9 % AD == 0), "ring depth must divide the 9 taps");
 
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
@@ -217,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     Frag af[TM][NS], afn[TM][NS];
+    Frag aq[AD > 0 ? AD : 1][TM][NS];
     auto load_a = [&](Frag (&dst)[TM][NS], long gt) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -230,7 +239,12 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
     int probe_slot = 0;
 #endif
     TDR_STAMP(probe_slot++);                      // 0: kernel start (after geometry)
-    load_a(af, 0);
+    if constexpr (AD > 0) {
+#pragma unroll
+        for (int d = 0; d < AD; ++d) load_a(aq[d], min((long)d, (long)ngroups * TAPS - 1));
+    } else {
+        load_a(af, 0);
+    }
 #pragma unroll
     for (int p = 0; p < PF; ++p)
         if (p < ngroups) load_group(p, p);
@@ -255,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                     // the fragments (in-order vmcnt) then leaves the operand loads in flight.
                     // (the last prefetch of the last group re-reads a valid slot)
                     const long gtn = min((long)g * TAPS + tap + 1, (long)ngroups * TAPS - 1);
-                    if (TDR_PROBE != 3) load_a(afn, gtn);
+                    if (TDR_PROBE != 3 && AD == 0) load_a(afn, gtn);
+                    Frag (&afc)[TM][NS] = AD > 0 ? aq[AD > 0 ? tap % (AD > 0 ? AD : 1) : 0] : af;
                     if (TDR_PROBE != 1 && PF > 1 && tap == 0 && g + PF < ngroups) load_group(g + PF, u);   // set u is free: group g already sits in LDS
                     Frag bf[TN][NS];
 #pragma unroll
@@ -273,20 +288,24 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                             for (int tn = 0; tn < TN; ++tn) {
 #if TDR_PROBE == 2
                                 if (q == 0)
-                                    asm volatile("" ::"v"(__builtin_bit_cast(f32x4, af[tm][0].v)), "v"(__builtin_bit_cast(f32x4, af[tm][1].v)),
-                                                 "v"(__builtin_bit_cast(f32x4, af[tm][2].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][0].v)),
-                                                 "v"(__builtin_bit_cast(f32x4, bf[tn][1].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][2].v)));
+                                    asm volatile("" ::"v"(__builtin_bit_cast(f32x4, afc[tm][0].v)), "v"(__builtin_bit_cast(f32x4, afc[tm][1].v)),
+                                                 "v"(__builtin_bit_cast(f32x4, afc[tm][NS - 1].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][0].v)),
+                                                 "v"(__builtin_bit_cast(f32x4, bf[tn][1].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][NS - 1].v)));
 #else
                                 if constexpr (SCH == SCH_HX2)
-                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
                                 else
-                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
 #endif
                             }
+                    if constexpr (AD > 0) {      // the slot is consumed: request the fragments AD steps ahead into it
+                        if (TDR_PROBE != 3) load_a(aq[tap % (AD > 0 ? AD : 1)], min((long)g * TAPS + tap + AD, (long)ngroups * TAPS - 1));
+                    } else {
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
+                        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) af[tm][s] = afn[tm][s];
+                            for (int s = 0; s < NS; ++s) af[tm][s] = afn[tm][s];
+                    }
                 }
                 TDR_STAMP(probe_slot++);                  // 4+3g: MFMA phase of group g issued
                 if (TDR_PROBE != 4) {
@@ -585,6 +604,20 @@ int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
     const int tiles_y = tdr_cdiv(a.OH, TH);
     b.mtiles = tdr_cdiv(a.Cout, BM);
     dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
+    if constexpr (KH == 3 && S == 1 && TM == 1 && SCH == SCH_HX2 && EPI == EPI_STD) {   // weight-fragment ring: single-round launches
+        static const long ring_blocks = getenv("TDR_RING_BLOCKS") ? atol(getenv("TDR_RING_BLOCKS")) : 512;
+        if ((long)grid.x * N <= ring_blocks) {
+            auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE, SCH, 9>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, b);
+            TDR_LAUNCH_CHECK("conv_bx3_kernel(ring)");
+            return TDR_OK;
+        }
+    }
     auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE, SCH>;
     static bool attr_set = false;
     if (!attr_set) {
