@@ -218,7 +218,11 @@ template <int KH, int S, int D, int CK, int EPI, bool GATE>
 int launch_shape(const ConvArgs& a, int N, hipStream_t st) {
     const long pix = (long)a.OH * a.OW;
     auto blocks = [&](int bm, int bn) { return (long)tdr_cdiv(a.Cout, bm) * tdr_cdiv(pix, bn) * N; };
-    if (a.Cout <= 32) return launch_cfg<KH, S, D, CK, 1, 1, 2, EPI, GATE>(a, N, st);        // 32 x 256
+    if (a.Cout <= 32) {
+        // few pixels (the MASA coarse search: 16 filters over a 32 x 32 map, K = 4608): 128-pixel tiles double the workgroups
+        if (blocks(32, 256) < 256) return launch_cfg<KH, S, D, CK, 1, 1, 1, EPI, GATE>(a, N, st);   // 32 x 128
+        return launch_cfg<KH, S, D, CK, 1, 1, 2, EPI, GATE>(a, N, st);                               // 32 x 256
+    }
     if (a.Cout > 64 && blocks(128, 128) >= 512) return launch_cfg<KH, S, D, CK, 2, 2, 2, EPI, GATE>(a, N, st);
     if (blocks(64, 128) >= 512) return launch_cfg<KH, S, D, CK, 2, 1, 2, EPI, GATE>(a, N, st);  // 64 x 128
     return launch_cfg<KH, S, D, CK, 2, 1, 1, EPI, GATE>(a, N, st);                              // 64 x 64
