@@ -10,6 +10,8 @@
 
 namespace {
 constexpr int CHUNK = 4096;   // elements per chunk (must match tdr_optim_chunk())
+static_assert(CHUNK % 1024 == 0, "float4 path: 256 threads x 4 elements per pass");
+__device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* const* __restrict__ grads, const int64_t* __restrict__ sizes,
                                                    const int* __restrict__ chunk_tensor, const int* __restrict__ chunk_index,
@@ -20,9 +22,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* const* __restri
     const long n = sizes[t];
     const float* g = grads[t];
     double s = 0.0;
-    for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) {
-        const float v = g[i];
-        s += (double)v * (double)v;
+    const long end = min(base + CHUNK, n);
+    if (al16(g) && end - base == CHUNK) {              // full chunk of a 16-byte aligned tensor: float4 loads
+#pragma unroll
+        for (int k = 0; k < CHUNK / 1024; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(g + base + 4 * (threadIdx.x + 256 * k));
+            s += ((double)v.x * (double)v.x + (double)v.y * (double)v.y) + ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
+        }
+    } else {
+        for (long i = base + threadIdx.x; i < end; i += 256) {
+            const float v = g[i];
+            s += (double)v * (double)v;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -54,7 +65,18 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const float* const* __r
     const long n = sizes[t];
     const float* s = src[t];
     float* d = dst[t];
-    for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) d[i] = s[i] * scale;   // scale: 1 / (power-of-two loss scale)
+    const long end = min(base + CHUNK, n);
+    if (al16(s) && al16(d) && end - base == CHUNK) {
+#pragma unroll
+        for (int k = 0; k < CHUNK / 1024; ++k) {
+            const long i = base + 4 * (threadIdx.x + 256 * k);
+            float4 v = *reinterpret_cast<const float4*>(s + i);
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            *reinterpret_cast<float4*>(d + i) = v;
+        }
+        return;
+    }
+    for (long i = base + threadIdx.x; i < end; i += 256) d[i] = s[i] * scale;   // scale: 1 / (power-of-two loss scale)
 }
 
 struct AdamArgs {
@@ -85,13 +107,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ p
         coef = fminf(a.max_norm / (total + 1e-6f), 1.f);
     }
     const float step = lr / bc1;
-    for (long i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) {
-        const float gv = g[i] * coef;
-        float pv = p[i] * (1.f - lr * a.weight_decay);
-        const float mv = m[i] + (1.f - a.beta1) * (gv - m[i]);            // lerp, as torch.optim
-        const float vv = a.beta2 * v[i] + (1.f - a.beta2) * gv * gv;
+    auto upd = [&](float g0, float& pv, float& mv, float& vv) {
+        const float gv = g0 * coef;
+        pv *= (1.f - lr * a.weight_decay);
+        mv = mv + (1.f - a.beta1) * (gv - mv);                            // lerp, as torch.optim
+        vv = a.beta2 * vv + (1.f - a.beta2) * gv * gv;
         const float denom = sqrtf(vv) / bc2_sqrt + a.eps;
         pv -= step * (mv / denom);
+    };
+    const long end = min(base + CHUNK, n);
+    if (al16(p) && al16(g) && al16(m) && al16(v) && end - base == CHUNK) {   // full chunk, aligned tensors: float4 streams
+#pragma unroll
+        for (int k = 0; k < CHUNK / 1024; ++k) {
+            const long i = base + 4 * (threadIdx.x + 256 * k);
+            const float4 g4 = *reinterpret_cast<const float4*>(g + i);
+            float4 p4 = *reinterpret_cast<const float4*>(p + i), m4 = *reinterpret_cast<const float4*>(m + i),
+                   v4 = *reinterpret_cast<const float4*>(v + i);
+            upd(g4.x, p4.x, m4.x, v4.x); upd(g4.y, p4.y, m4.y, v4.y); upd(g4.z, p4.z, m4.z, v4.z); upd(g4.w, p4.w, m4.w, v4.w);
+            *reinterpret_cast<float4*>(p + i) = p4;
+            *reinterpret_cast<float4*>(m + i) = m4;
+            *reinterpret_cast<float4*>(v + i) = v4;
+        }
+        return;
+    }
+    for (long i = base + threadIdx.x; i < end; i += 256) {
+        float pv = p[i], mv = m[i], vv = v[i];
+        upd(g[i], pv, mv, vv);
         p[i] = pv; m[i] = mv; v[i] = vv;
     }
 }
