@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256) void fine_search_bwd_kernel(const float* __res
     int* s_ix = reinterpret_cast<int*>(s_ik + P);   // [P]
     float* s_q = reinterpret_cast<float*>(s_ix + P);  // [BS*BS]
     float* s_k = s_q + BS * BS;                        // [D*D]
+    int* s_ry = reinterpret_cast<int*>(s_k + D * D);   // [P] row / col of the selected ref patch, q offset of patch p:
+    int* s_rx = s_ry + P;                              //     the integer divisions leave the P x D*D inner loop
+    int* s_qo = s_rx + P;
     for (int p = threadIdx.x; p < P; p += 256) {
         const int ix = index_all[(long)b * P + p];
         s_da[p] = datt[(long)b * P + p];
@@ -205,6 +208,9 @@ __global__ __launch_bounds__(256) void fine_search_bwd_kernel(const float* __res
         s_iq[p] = invq[(long)b * P + p];
         s_ik[p] = invk[(long)b * R1 * R1 + ix];
         s_ix[p] = ix;
+        s_ry[p] = ix / R1;
+        s_rx[p] = ix % R1;
+        s_qo[p] = (p / K) * BS + (p % K);
     }
     for (int i = threadIdx.x; i < BS * BS; i += 256) s_q[i] = lrb[((long)b * C + c) * BS * BS + i];
     for (int i = threadIdx.x; i < D * D; i += 256) s_k[i] = refb[((long)b * C + c) * D * D + i];
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void fine_search_bwd_kernel(const float* __res
             const int pyy = y - k / 3, pxx = x - k % 3;
             if (pyy < 0 || pyy >= K || pxx < 0 || pxx >= K) continue;
             const int p = pyy * K + pxx;
-            const int ry = s_ix[p] / R1, rx = s_ix[p] % R1;
+            const int ry = s_ry[p], rx = s_rx[p];
             const float kv = s_k[(ry + k / 3) * D + rx + k % 3];
             s += s_da[p] * s_iq[p] * (kv * s_ik[p] - s_at[p] * s_q[i] * s_iq[p]);
         }
@@ -229,10 +235,9 @@ __global__ __launch_bounds__(256) void fine_search_bwd_kernel(const float* __res
         const int v = i / D, u = i % D;
         float s = 0.f;
         for (int p = 0; p < P; ++p) {
-            const int ry = s_ix[p] / R1, rx = s_ix[p] % R1;
-            const int kyy = v - ry, kxx = u - rx;
+            const int kyy = v - s_ry[p], kxx = u - s_rx[p];
             if (kyy < 0 || kyy > 2 || kxx < 0 || kxx > 2) continue;
-            const float qv = s_q[(p / K + kyy) * BS + (p % K) + kxx];
+            const float qv = s_q[s_qo[p] + kyy * BS + kxx];
             s += s_da[p] * s_ik[p] * (qv * s_iq[p] - s_at[p] * s_k[i] * s_ik[p]);
         }
         drefb[((long)b * C + c) * D * D + i] = s;
@@ -477,7 +482,7 @@ extern "C" int tdr_fine_search_bwd(const float* datt, const float* soft_att, con
                                    const float* refb, const float* invq, const float* invk, int B, int C, int K, int D,
                                    float* dlrb, float* drefb, void* stream) {
     TDR_REQUIRE(datt && soft_att && index_all && lrb && refb && invq && invk && dlrb && drefb, "tdr_fine_search_bwd: null pointer");
-    const size_t lds = (size_t)(5 * K * K + (K + 2) * (K + 2) + D * D) * sizeof(float);
+    const size_t lds = (size_t)(8 * K * K + (K + 2) * (K + 2) + D * D) * sizeof(float);
     hipLaunchKernelGGL(fine_search_bwd_kernel, dim3(C, B), dim3(256), lds, (hipStream_t)stream, datt, soft_att, index_all, lrb,
                        refb, invq, invk, C, K, D, dlrb, drefb);
     TDR_LAUNCH_CHECK("fine_search_bwd");

@@ -580,11 +580,12 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ p, co
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ void l1_finish_kernel(const double* __restrict__ part, int nparts, double scale, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int k = 0; k < nparts; ++k) s += part[k];
-        loss[0] = (float)(s * scale);
-    }
+    // one wave, fixed order: lane-strided partial sums, then the xor butterfly (deterministic)
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 64) s += part[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) loss[0] = (float)(s * scale);
 }
 
 inline int grid1d(long total, int cap = 8192) {
