@@ -260,8 +260,9 @@ def _encoder_bwd_levels(dfeats, P, pre, cnt, saved, G, dnext):
                 gw, G[bp + 'conv1.bias'] = K.conv_wgrad(x_in, dh, Cc, Cc, 3, pad=1, want_db=True)
                 G[bp + 'conv1.weight'] = gw.view(Cc, Cc, 3, 3)
             wp, mp, *_ = K.pack_weights(w1, PACK_DGRAD_S1)
-            d = K.conv_forward(dh, wp, mp, Cc, 3, pad=1, res=d)
-        dpre = K.relu_bwd(d, a)
+            # the first block's input is the level's ReLU output `a`: its mask rides on this epilogue (conv + res, then mask)
+            d = K.conv_forward(dh, wp, mp, Cc, 3, pad=1, res=d, mask=a if i == 0 else None)
+        dpre = d if cnt[lvl] > 0 else K.relu_bwd(d, a)
         w = P[f'{pre}conv_L{k}.weight']
         dnext, G[f'{pre}conv_L{k}.weight'], G[f'{pre}conv_L{k}.bias'] = conv_bwd(
             dpre, xin, w, 1 if lvl == 0 else 2, 1, need_dx=(lvl > 0))
