@@ -239,11 +239,7 @@ def _encoder_bwd_levels(dfeats, P, pre, cnt, saved, G, dnext):
     for lvl in reversed(range(len(dfeats))):
         k = lvl + 1
         xin, a, blocks = saved[lvl]
-        d = dfeats[lvl]
-        if d is None:
-            d = dnext
-        elif dnext is not None:
-            d = K.add_(dnext, d)      # dnext is a fresh tensor we own
+        d = dnext if dnext is not None else dfeats[lvl]      # dnext already contains dfeats[lvl] (add_to_dx below)
         if d is None:
             continue
         for i in reversed(range(cnt[lvl])):
@@ -264,8 +260,9 @@ def _encoder_bwd_levels(dfeats, P, pre, cnt, saved, G, dnext):
             d = K.conv_forward(dh, wp, mp, Cc, 3, pad=1, res=d, mask=a if i == 0 else None)
         dpre = d if cnt[lvl] > 0 else K.relu_bwd(d, a)
         w = P[f'{pre}conv_L{k}.weight']
+        # the feature gradient of the level below joins in the data-gradient epilogue instead of a separate add
         dnext, G[f'{pre}conv_L{k}.weight'], G[f'{pre}conv_L{k}.bias'] = conv_bwd(
-            dpre, xin, w, 1 if lvl == 0 else 2, 1, need_dx=(lvl > 0))
+            dpre, xin, w, 1 if lvl == 0 else 2, 1, need_dx=(lvl > 0), add_to_dx=dfeats[lvl - 1] if lvl > 0 else None)
     maybe_join()
     return None
 
