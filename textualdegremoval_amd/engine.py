@@ -144,10 +144,10 @@ def naf_seq_bwd(dout, P, pre, n, saved, G):
 # ---------------------------------------------------------------------------
 # dense convs: intro / ending / downs / ups (:429-434, :449-451, :468-473)
 # ---------------------------------------------------------------------------
-def conv_fwd(x, w, b, stride, pad, res=None, relu=False):
+def conv_fwd(x, w, b, stride, pad, res=None, relu=False, out=None):
     Cout, Cin, KH, _ = w.shape
     wp, mp, *_ = K.pack_weights(w, PACK_FWD)
-    out = K.conv_forward(x, wp, mp, Cout, KH, stride=stride, pad=pad, bias=b, res=res, relu=relu)
+    out = K.conv_forward(x, wp, mp, Cout, KH, stride=stride, pad=pad, bias=b, res=res, relu=relu, out=out)
     return out
 
 
@@ -287,9 +287,10 @@ class MasaGeom:
         self.side = self.dia_x + 2
 
 
-def masa_fwd(feats, N, geo):
+def masa_fwd(feats, N, geo, outs=None):
     """feats: pyramid levels (finest first; 5 for NAFNet-ref, 4 for Restormer-ref) for the stacked batch
-    [lq(0..N-1), ref(N..2N-1)].  Returns (warp list finest->coarsest like the reference's warp_ref_l, saved)."""
+    [lq(0..N-1), ref(N..2N-1)].  Returns (warp list finest->coarsest like the reference's warp_ref_l, saved).
+    outs: optional per-level destination views (the second half of the fusion blocks' concat buffers)."""
     P, Kk, side = geo.P, geo.K, geo.side
     L = len(feats)
     deep = feats[L - 1]
@@ -322,7 +323,8 @@ def masa_fwd(feats, N, geo):
     warp = []
     for lvl in range(L):
         s = 2 ** (L - 1 - lvl)
-        warp.append(K.transfer_fwd(feats[lvl][N:], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s))
+        warp.append(K.transfer_fwd(feats[lvl][N:], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s,
+                                   out=None if outs is None else outs[lvl]))
     saved = (lrb, refb, finvq, finvk, index, y1, x1, index_all, soft_att)
     return warp, saved
 
@@ -368,21 +370,27 @@ def net_fwd(P, cfg, inp, ref):
     inp_p = both[:N]
     geo = MasaGeom(Hp, Wp, Hrp, Wrp, n_enc, cfg['lr_block_size'], cfg['ref_down_block_size'], cfg['dilations'])
     feats, sv_enc = encoder_fwd(both, P, 'masa_enc.', cfg['ext_n_blocks'])
-    warp, sv_masa = masa_fwd(feats, N, geo)
+    # cat([x, warp], 1) of every fusion level (:719,727) without copies: the transfer kernel writes the warped reference
+    # features into the second half of the level's concat buffer, the conv that produces x writes the first half
+    chan = P['intro.weight'].shape[0]
+    cats = []
+    for lvl in range(n_enc + 1):
+        Cl, Hl, Wl = feats[lvl].shape[1:]
+        if Cl != chan << lvl or (Hl, Wl) != (Hp >> lvl, Wp >> lvl):
+            raise ValueError('MASA feature pyramid does not match the fusion levels')
+        cats.append(torch.empty(N, 2 * Cl, Hl, Wl, dtype=torch.float32, device=inp.device))
+    warp, sv_masa = masa_fwd(feats, N, geo, outs=[c[:, c.shape[1] // 2:] for c in cats])
 
-    x = conv_fwd(inp_p, P['intro.weight'], P['intro.bias'], 1, 1)
-    chan = x.shape[1]
+    conv_fwd(inp_p, P['intro.weight'], P['intro.bias'], 1, 1, out=cats[0][:, :chan])
     sv_levels, skips = [], []
     for lvl in range(n_enc):
-        cat = K.concat2(x, warp[lvl])
-        x, sv_f = naf_seq_fwd(cat, P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], c_out_last=chan)
+        x, sv_f = naf_seq_fwd(cats[lvl], P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], c_out_last=chan)
         x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl])
         skips.append(x)
-        xd = conv_fwd(x, P[f'downs.{lvl}.weight'], P[f'downs.{lvl}.bias'], 2, 0)
+        conv_fwd(x, P[f'downs.{lvl}.weight'], P[f'downs.{lvl}.bias'], 2, 0, out=cats[lvl + 1][:, :2 * chan])
         sv_levels.append((sv_f, sv_e, x))
-        x = xd
         chan *= 2
-    cat = K.concat2(x, warp[n_enc])
+    cat = cats[n_enc]
     x, sv_fm = naf_seq_fwd(cat, P, 'masa_blk_middle.0.', cfg['reffusion_n_blocks'][n_enc], c_out_last=chan)
     x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'])
     sv_dec = []
