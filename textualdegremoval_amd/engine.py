@@ -446,7 +446,7 @@ def _net_bwd(dout, P, cfg, saved, G):
     dwarp = [None] * 5
     chan = dcat.shape[1] // 2
     dwarp[n_enc] = dcat[:, chan:]
-    d = K.slice_channels(dcat, 0, chan)
+    d = dcat[:, :chan]                                 # batch-strided view: every consumer takes an image stride
     for lvl in reversed(range(n_enc)):
         sv_f, sv_e, x_skip = sv_levels[lvl]
         # downs: gradient into the skip tensor, accumulated with the decoder-side skip gradient
@@ -456,7 +456,7 @@ def _net_bwd(dout, P, cfg, saved, G):
         dcat = naf_seq_bwd(d, P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], sv_f, G)
         chan = dcat.shape[1] // 2
         dwarp[lvl] = dcat[:, chan:]
-        d = K.slice_channels(dcat, 0, chan)
+        d = dcat[:, :chan]                             # batch-strided view: every consumer takes an image stride
     # intro conv: input image needs no gradient
     _, G['intro.weight'], G['intro.bias'] = conv_bwd(d, inp_p, P['intro.weight'], 1, 1, need_dx=False)
     dfeats = masa_bwd(dwarp, feats, N, geo, sv_masa)
