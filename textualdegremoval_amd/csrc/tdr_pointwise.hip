@@ -463,6 +463,92 @@ __global__ __launch_bounds__(1024) void sca_bwd_tail_kernel(const float* __restr
     }
 }
 
+// sca_bwd_rows_kernel and sca_bwd_ds_kernel are independent readers of G3: one launch, role by block index
+// (blocks [0, nds): ds role over (64-channel tile, image); then ceil(C/4) blocks with four co rows each)
+__global__ __launch_bounds__(1024) void sca_bwd_a_kernel(const float* __restrict__ G3, const float* __restrict__ S3,
+                                                        const float* __restrict__ w3, const float* __restrict__ b3,
+                                                        const float* __restrict__ beta, const float* __restrict__ s, int N,
+                                                        int C, int nds, float* __restrict__ dw3, float* __restrict__ db3,
+                                                        float* __restrict__ dbeta, float* __restrict__ ds) {
+    __shared__ float red[16][64];
+    if ((int)blockIdx.x < nds) {
+        const int tiles = (C + 63) / 64;
+        const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int ci = (blockIdx.x % tiles) * 64 + lane, n = blockIdx.x / tiles;
+        const int cic = min(ci, C - 1);
+        float a = 0.f;
+        for (int co = sl; co < C; co += 16) a += beta[co] * w3[(long)co * C + cic] * G3[((long)n * C + co) * C + cic];
+        red[sl][lane] = a;
+        __syncthreads();
+        if (sl == 0 && ci < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[q][lane];
+            ds[(long)n * C + ci] = t;
+        }
+        return;
+    }
+    const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int co = ((int)blockIdx.x - nds) * 4 + sub;
+    const bool live = co < C;
+    const int coc = live ? co : C - 1;
+    const float bt = beta[coc];
+    float acc = 0.f;
+    if (live)
+        for (int ci = tid; ci < C; ci += 256) {
+            float sg = 0.f;
+            for (int n = 0; n < N; ++n) sg += s[(long)n * C + ci] * G3[((long)n * C + co) * C + ci];
+            dw3[(long)co * C + ci] = bt * sg;
+            acc += w3[(long)co * C + ci] * sg;
+        }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[sub][tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0 && live) {
+        const float tot = (red[sub][0] + red[sub][1]) + (red[sub][2] + red[sub][3]);
+        db3[co] = bt * S3[co];
+        dbeta[co] = tot + b3[co] * S3[co];
+    }
+}
+
+// sca_bwd_dw_kernel and sca_bwd_tail_kernel both consume ds only: one launch (blocks [0, ntail): tail role over
+// (64-channel tile, image); then ceil(C/4) * ceil(C/256) blocks of four dWsca rows x 256 columns)
+__global__ __launch_bounds__(1024) void sca_bwd_b_kernel(const float* __restrict__ ds, const float* __restrict__ pooled,
+                                                        const float* __restrict__ wsca, int N, int C, int ntail,
+                                                        float* __restrict__ dwsca, float* __restrict__ dbsca,
+                                                        float* __restrict__ dpooled) {
+    __shared__ float red[16][64];
+    if ((int)blockIdx.x < ntail) {
+        const int tiles = (C + 63) / 64;
+        const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int cj = (blockIdx.x % tiles) * 64 + lane, n = blockIdx.x / tiles;
+        const int cjc = min(cj, C - 1);
+        float a = 0.f;
+        for (int ci = sl; ci < C; ci += 16) a += wsca[(long)ci * C + cjc] * ds[(long)n * C + ci];
+        red[sl][lane] = a;
+        __syncthreads();
+        if (sl == 0 && cj < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[q][lane];
+            dpooled[(long)n * C + cj] = t;
+            if (n == 0) {
+                float sb = 0.f;
+                for (int m = 0; m < N; ++m) sb += ds[(long)m * C + cj];
+                dbsca[cj] = sb;
+            }
+        }
+        return;
+    }
+    const int colb = (C + 255) / 256;
+    const int r = (int)blockIdx.x - ntail;
+    const int ci = (r / colb) * 4 + (threadIdx.x >> 8), cj = (r % colb) * 256 + (threadIdx.x & 255);
+    if (ci >= C || cj >= C) return;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += ds[(long)n * C + ci] * pooled[(long)n * C + cj];
+    dwsca[(long)ci * C + cj] = a;
+}
+
 __global__ __launch_bounds__(256) void scaled_conv_param_kernel(const float* __restrict__ G, const float* __restrict__ S,
                                                                const float* __restrict__ w, const float* __restrict__ b,
                                                                const float* __restrict__ gamma, int Cin,
@@ -677,10 +763,19 @@ extern "C" int tdr_sca_bwd(const float* G3, const float* S3, const float* w3, co
                 "tdr_sca_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     float* ds = ws;          // [N][C]
-    hipLaunchKernelGGL(sca_bwd_rows_kernel, dim3(C), dim3(256), 0, st, G3, S3, w3, b3, beta, s, N, C, dw3, db3, dbeta);
-    hipLaunchKernelGGL(sca_bwd_ds_kernel, dim3(tdr_cdiv(C, 64), N), dim3(1024), 0, st, G3, w3, beta, N, C, ds);
-    hipLaunchKernelGGL(sca_bwd_dw_kernel, dim3(tdr_cdiv(C, 256), C), dim3(256), 0, st, ds, pooled, N, C, dwsca);
-    hipLaunchKernelGGL(sca_bwd_tail_kernel, dim3(tdr_cdiv(C, 64), N), dim3(1024), 0, st, ds, wsca, N, C, dbsca, dpooled);
+    static const bool split4 = getenv("TDR_SCA_SPLIT") != nullptr;     // the four separate launches (reference for the merged pair)
+    if (split4) {
+        hipLaunchKernelGGL(sca_bwd_rows_kernel, dim3(C), dim3(256), 0, st, G3, S3, w3, b3, beta, s, N, C, dw3, db3, dbeta);
+        hipLaunchKernelGGL(sca_bwd_ds_kernel, dim3(tdr_cdiv(C, 64), N), dim3(1024), 0, st, G3, w3, beta, N, C, ds);
+        hipLaunchKernelGGL(sca_bwd_dw_kernel, dim3(tdr_cdiv(C, 256), C), dim3(256), 0, st, ds, pooled, N, C, dwsca);
+        hipLaunchKernelGGL(sca_bwd_tail_kernel, dim3(tdr_cdiv(C, 64), N), dim3(1024), 0, st, ds, wsca, N, C, dbsca, dpooled);
+    } else {
+        const int nt = tdr_cdiv(C, 64) * N;
+        hipLaunchKernelGGL(sca_bwd_a_kernel, dim3(nt + tdr_cdiv(C, 4)), dim3(1024), 0, st, G3, S3, w3, b3, beta, s, N, C, nt, dw3,
+                           db3, dbeta, ds);
+        hipLaunchKernelGGL(sca_bwd_b_kernel, dim3(nt + tdr_cdiv(C, 4) * tdr_cdiv(C, 256)), dim3(1024), 0, st, ds, pooled, wsca, N, C,
+                           nt, dwsca, dbsca, dpooled);
+    }
     TDR_LAUNCH_CHECK("sca_bwd");
     return TDR_OK;
 }
