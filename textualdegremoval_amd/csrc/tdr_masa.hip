@@ -56,11 +56,49 @@ __global__ void lr_blocks_bwd_kernel(const float* __restrict__ dblk, int C, int 
 // ---------------------------------------------------------------------------
 // inverse L2 norm of 3x3 (dilated) patches over all channels; zero outside the map
 // inv[b][oy][ox] = 1 / max(sqrt(sum_{c,ky,kx} x[b,c,oy*step+off+ky*dil, ox*step+off+kx*dil]^2), 1e-12)
-// one wave per output position, lanes over channels.
+// a block = 64 consecutive output positions (lanes: coalesced rows) x 16 channel slices (waves), summed through LDS in a
+// fixed order.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void patch_inv_norm_kernel(const float* __restrict__ x, int C, int H, int W, int OH,
-                                                            int OW, int dil, int step, int off, long npos,
-                                                            float* __restrict__ inv) {
+__global__ __launch_bounds__(1024) void patch_inv_norm_kernel(const float* __restrict__ x, int C, int H, int W, int OH,
+                                                             int OW, int dil, int step, int off, long npos,
+                                                             float* __restrict__ inv) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long pos = blockIdx.x * 64L + lane;
+    const bool live = pos < npos;
+    const long pc = live ? pos : npos - 1;
+    const int ox = (int)(pc % OW); const long r = pc / OW;
+    const int oy = (int)(r % OH); const long b = r / OH;
+    int offs[9];                      // tap offsets inside a channel plane, -1 outside the map
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = oy * step + off + (k / 3) * dil, xx = ox * step + off + (k % 3) * dil;
+        offs[k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
+    }
+    float s = 0.f;
+    const long HW = (long)H * W;
+    for (int c = sl; c < C; c += 16) {
+        const float* xc = x + (b * C + c) * HW;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float v = offs[k] >= 0 ? xc[offs[k]] : 0.f;
+            s += v * v;
+        }
+    }
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][lane];
+        inv[pos] = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+    }
+}
+
+// few positions (the LR centre patches: N*P of them): one wave per position, lanes over channels
+__global__ __launch_bounds__(256) void patch_inv_norm_wave_kernel(const float* __restrict__ x, int C, int H, int W, int OH,
+                                                                 int OW, int dil, int step, int off, long npos,
+                                                                 float* __restrict__ inv) {
     const long pos = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (pos >= npos) return;
     const int lane = threadIdx.x & 63;
@@ -433,8 +471,12 @@ extern "C" int tdr_patch_inv_norm(const float* x, int B, int C, int H, int W, in
                                   int off, float* inv, void* stream) {
     TDR_REQUIRE(x && inv, "tdr_patch_inv_norm: null pointer");
     const long npos = (long)B * OH * OW;
-    hipLaunchKernelGGL(patch_inv_norm_kernel, dim3((unsigned)((npos + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, C, H, W,
-                       OH, OW, dil, step, off - pad, npos, inv);
+    if (npos >= 1024)
+        hipLaunchKernelGGL(patch_inv_norm_kernel, dim3((unsigned)((npos + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, x, C, H,
+                           W, OH, OW, dil, step, off - pad, npos, inv);
+    else
+        hipLaunchKernelGGL(patch_inv_norm_wave_kernel, dim3((unsigned)((npos + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, C,
+                           H, W, OH, OW, dil, step, off - pad, npos, inv);
     TDR_LAUNCH_CHECK("patch_inv_norm");
     return TDR_OK;
 }
