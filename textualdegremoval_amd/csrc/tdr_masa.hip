@@ -343,15 +343,35 @@ __global__ __launch_bounds__(256) void transfer_fwd_kernel(const float* __restri
     TrGeom g;
     tr_geometry(Y - by * K * s, X - bx * K * s, b, y1, x1, index_all, soft_att, K, side, s, H, W, g);
     const long HWf = (long)H * W, HWo = (long)OH * OW;
+    // the <= 9 covering patches usually point at the same source pixel (coherent matches): one gather per distinct
+    // source, weighted by its multiplicity (as in transfer_bwd_kernel)
+    float mult[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        int m = 0;
+        bool first = g.src[k] >= 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const bool same = g.src[q] == g.src[k];
+            m += same ? 1 : 0;
+            if (q < k && same) first = false;
+        }
+        mult[k] = first ? (float)m : 0.f;
+    }
     const int c0 = blockIdx.y * TR_CG;
-    for (int c = c0; c < min(c0 + TR_CG, C); ++c) {
-        const float* f = feat + ((long)n * C + c) * HWf;
+    float accs[TR_CG];
+#pragma unroll
+    for (int i = 0; i < TR_CG; ++i) {              // all channels' gathers in flight before the first store
+        const float* f = feat + ((long)n * C + min(c0 + i, C - 1)) * HWf;
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            if (g.src[k] >= 0) acc += f[g.src[k]];
-        out[(long)n * out_ns + (long)c * HWo + pix] = acc * g.inv_cnt * g.wgt;
+            if (mult[k] != 0.f) acc += mult[k] * f[g.src[k]];
+        accs[i] = acc;
     }
+#pragma unroll
+    for (int i = 0; i < TR_CG; ++i)
+        if (c0 + i < C) out[(long)n * out_ns + (long)(c0 + i) * HWo + pix] = accs[i] * g.inv_cnt * g.wgt;
 }
 
 // backward pass 1: dfeat scatter (atomics) + per-pixel dA = sum_c dout * acc/cnt.
