@@ -65,6 +65,7 @@ CONV_CASES = [
     (2, 64, 64, 16, 16, 3, 1, 1, 1),
     (1, 256, 256, 8, 8, 3, 1, 1, 1),
     (4, 128, 128, 64, 64, 3, 1, 1, 1),
+    (8, 32, 32, 256, 256, 3, 1, 1, 1),     # 2048 workgroups: the many-round variant without the weight-fragment ring
     (1, 20, 12, 13, 21, 3, 1, 1, 1),
     (2, 16, 32, 32, 32, 3, 2, 1, 1),
     (1, 32, 64, 64, 96, 3, 2, 1, 1),
@@ -354,6 +355,20 @@ def test_coarse_search_and_box_vs_reference_golden(K):
     df = torch.zeros_like(r4)
     K.scatter_ref_block(dev(go), df, y1, x1, P, 15)
     assert maxdiff(df, rr.grad) < 1e-5
+
+
+@pytest.mark.parametrize('B,C,H,W,dil,pad', [(2, 70, 10, 12, 1, 0),      # 160 positions: wave-per-position kernel
+                                               (3, 70, 20, 24, 1, 0),      # 1188 positions: position-major kernel
+                                               (2, 96, 24, 24, 2, 2), (2, 40, 24, 24, 3, 3)])
+def test_patch_inv_norm_both_kernels(K, B, C, H, W, dil, pad):
+    """1 / ||3x3 (dilated) patch over all channels||, zero outside the map (network_nafnet_guided_arch.py:515-536)."""
+    x = rnd(B, C, H, W, seed=11)
+    OH, OW = H + 2 * pad - 2 * dil, W + 2 * pad - 2 * dil
+    ss = F.conv2d((x * x).sum(1, keepdim=True), torch.ones(1, 1, 3, 3), dilation=dil, padding=pad)[:, 0]
+    ref = 1.0 / ss.sqrt().clamp_min(1e-12)
+    out = K.patch_inv_norm(dev(x), OH, OW, dil=dil, pad=pad)
+    assert out.shape == ref.shape
+    assert rel(out, ref) < 2e-6
 
 
 # ------------------------------------------------------------------ optimiser
