@@ -665,6 +665,10 @@ int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
             if (force == 4) return launch_bx_cfg<KH, S, 1, 1, 2, EPI, GATE>(a, N, st);
             if (force == 5) return launch_bx_cfg<KH, S, 4, 2, 2, EPI, GATE>(a, N, st);    // 256 x 64
             if (a.Cout > 64 && blocks(128, 128) >= 512) return launch_bx_cfg<KH, S, 2, 2, 2, EPI, GATE>(a, N, st);
+            // long K over few pixels (Restormer's 32 x 32 level: 2042 -> 768 @32x32, N = 8: 160 us at 768 workgroups of 64 x 128,
+            // 94 us at 384 of 256 x 64): one round of tall tiles reads each pixel column once per 256 output channels
+            if (a.Cin >= 768 && a.Cout >= 256 && blocks(256, 64) >= 256 && blocks(256, 64) <= 512)
+                return launch_bx_cfg<KH, S, 4, 2, 2, EPI, GATE>(a, N, st);
         } else {
             const int force3 = g_force_cfg[1];   // tuning aid (tdr_conv_force_cfg / TDR_BX_CFG3)
             if (force3 == 1) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);
