@@ -375,11 +375,11 @@ def net_fwd(P, cfg, inp, ref):
     chan = P['intro.weight'].shape[0]
     cats = []
     for lvl in range(n_enc + 1):
-        Cl, Hl, Wl = feats[lvl].shape[1:]
-        if Cl != chan << lvl or (Hl, Wl) != (Hp >> lvl, Wp >> lvl):
+        Cl, Hl, Wl = feats[lvl].shape[1:]            # warped-feature channels (nf * 2^lvl) next to the chan * 2^lvl of x
+        if (Hl, Wl) != (Hp >> lvl, Wp >> lvl):
             raise ValueError('MASA feature pyramid does not match the fusion levels')
-        cats.append(torch.empty(N, 2 * Cl, Hl, Wl, dtype=torch.float32, device=inp.device))
-    warp, sv_masa = masa_fwd(feats, N, geo, outs=[c[:, c.shape[1] // 2:] for c in cats])
+        cats.append(torch.empty(N, (chan << lvl) + Cl, Hl, Wl, dtype=torch.float32, device=inp.device))
+    warp, sv_masa = masa_fwd(feats, N, geo, outs=[c[:, chan << lvl:] for lvl, c in enumerate(cats)])
 
     conv_fwd(inp_p, P['intro.weight'], P['intro.bias'], 1, 1, out=cats[0][:, :chan])
     sv_levels, skips = [], []
