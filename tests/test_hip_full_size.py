@@ -151,3 +151,75 @@ def test_full_size_loss_scaled_backward(world):
     for k, g1 in G1.items():
         tol = (1e-5 if k.startswith('masa_enc.') else 1e-6) * 2.0 * max(g1.abs().max().item(), 1e-30)
         assert (G2[k] - 2.0 * g1).abs().max().item() <= tol, k
+
+
+# ------------------------------------------------------------------ Restormer-ref at configs[2]'s per-GPU shapes (dim 48, 256x256)
+@pytest.fixture(scope='module')
+def rworld():
+    _need_gpu()
+    from oracle import restormer_ref_oracle as RO
+    from textualdegremoval_amd import kernels as K, restormer_engine as R
+    cfg = RO.default_cfg(dim=48, nf=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4, ext_n_blocks=[4, 4, 4, 4],
+                         reffusion_n_blocks=[2, 2, 2, 2])
+    P = RO.synth_params(cfg, seed=5)
+    Pc = {k: v.cuda() for k, v in P.items()}
+    prev = K.MATH
+    K.set_math('hx2')
+    yield R, RO, K, cfg, P, Pc
+    K.set_math(prev)
+
+
+def test_restormer_full_size_forward_against_oracle(rworld, monkeypatch):
+    """same two-step protocol as test_full_size_forward_against_oracle (the MASA restatement is shared)."""
+    R, RO, K, cfg, P, Pc = rworld
+    lq, gt, ref = O.synth_pair(1, 256, 256, seed=91)
+    out, saved = R.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
+    sv_masa = saved[6]
+    hip_index, hip_index_all = sv_masa[4].cpu().long(), sv_masa[7].cpu().long()
+    seen = {}
+    orig_cs, orig_fs = O.coarse_search, O.fine_search
+
+    def cs(lrb, r4, dil):
+        total, index = orig_cs(lrb, r4, dil)
+        hi = hip_index.view_as(index)
+        gap = (total.gather(2, index.unsqueeze(2)) - total.gather(2, hi.unsqueeze(2))).squeeze(2)
+        seen['coarse'] = ((index != hi).sum().item(), index.numel(), gap.abs().max().item())
+        return total, hi
+
+    def fs(lrb_flat, refb):
+        val, idx, corr = orig_fs(lrb_flat, refb)
+        B = corr.shape[0]
+        hi = hip_index_all.view(B, -1)
+        v2 = corr.gather(2, hi.unsqueeze(2)).squeeze(2)
+        seen['fine'] = ((idx.reshape(B, -1) != hi).sum().item(), hi.numel(), (val.reshape(B, -1) - v2).abs().max().item())
+        return v2.view_as(val), hi.view_as(idx), corr
+
+    monkeypatch.setattr(O, 'coarse_search', cs)
+    monkeypatch.setattr(O, 'fine_search', fs)
+    with torch.no_grad():
+        ro = RO.restormer_ref_forward(P, cfg, lq, ref)
+    print('restormer match decisions (mismatches, total, largest oracle score gap at a mismatch):', seen)
+    assert seen['coarse'][0] <= 2 and seen['coarse'][2] < 1e-5, seen
+    assert seen['fine'][0] <= 8 and seen['fine'][2] < 1e-5, seen
+    o = out.cpu()
+    diff = (o - ro).abs()
+    print(f'restormer full size vs oracle: max {diff.max().item():.3e} mean {diff.mean().item():.3e}')
+    assert diff.max().item() < 1e-4
+    assert abs(psnr(o.clamp(0, 1), gt) - psnr(ro.clamp(0, 1), gt)) < 1e-3
+
+
+def test_restormer_full_size_properties(rworld):
+    R, RO, K, cfg, P, Pc = rworld
+    lq, gt, ref = O.synth_pair(8, 256, 256, seed=92)
+    lq, ref, gtc = lq.cuda(), ref.cuda(), gt.cuda()
+    out, _ = R.net_fwd(Pc, cfg, lq, ref)
+    perm = [5, 2, 7, 0, 3, 6, 1, 4]
+    outp, _ = R.net_fwd(Pc, cfg, lq[perm].contiguous(), ref[perm].contiguous())
+    assert torch.equal(outp, out[perm])
+    K.set_math('f32')
+    try:
+        exact, _ = R.net_fwd(Pc, cfg, lq, ref)
+    finally:
+        K.set_math('hx2')
+    assert (out - exact).abs().max().item() < 1e-4
+    assert abs(psnr(out.clamp(0, 1), gtc) - psnr(exact.clamp(0, 1), gtc)) < 1e-3
