@@ -266,3 +266,44 @@ def test_restormer_full_size_properties(rworld):
         K.set_math('hx2')
     assert (out - exact).abs().max().item() < 1e-4
     assert abs(psnr(out.clamp(0, 1), gtc) - psnr(exact.clamp(0, 1), gtc)) < 1e-3
+
+
+def test_restormer_full_size_gradients_against_oracle(rworld, monkeypatch):
+    R, RO, K, cfg, P, Pc = rworld
+    lq, gt, ref = O.synth_pair(1, 256, 256, seed=93)
+    S = 2.0 ** math.floor(math.log2(512.0 * 3 * 256 * 256))
+    prev = K.set_grad_scaled(True)
+    try:
+        out, saved = R.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
+        loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0, grad_scale=S)
+        G = {k: v.cpu() / S for k, v in R.net_bwd(dpred, Pc, cfg, saved).items()}
+    finally:
+        K.set_grad_scaled(prev)
+    sv_masa = saved[6]
+    hip_index, hip_index_all = sv_masa[4].cpu().long(), sv_masa[7].cpu().long()
+    orig_cs, orig_fs = O.coarse_search, O.fine_search
+
+    def cs(lrb, r4, dil):
+        total, index = orig_cs(lrb, r4, dil)
+        return total, hip_index.view_as(index)
+
+    def fs(lrb_flat, refb):
+        val, idx, corr = orig_fs(lrb_flat, refb)
+        hi = hip_index_all.view(corr.shape[0], -1)
+        return corr.gather(2, hi.unsqueeze(2)).squeeze(2).view_as(val), hi.view_as(idx), corr
+
+    monkeypatch.setattr(O, 'coarse_search', cs)
+    monkeypatch.setattr(O, 'fine_search', fs)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    rl = O.l1_loss(RO.restormer_ref_forward(Pr, cfg, lq, ref), gt)
+    rl.backward()
+    assert abs(loss.item() - rl.item()) < 1e-6
+    worst, worst_k = 0.0, None
+    for k, p in Pr.items():
+        if p.grad is None or k not in G:
+            continue
+        r = (G[k].reshape(p.grad.shape) - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
+        if r > worst:
+            worst, worst_k = r, k
+    print(f'restormer full-size gradients vs oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
+    assert worst < 5e-3, (worst, worst_k)
