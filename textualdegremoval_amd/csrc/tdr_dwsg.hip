@@ -36,6 +36,7 @@ struct DwArgs {
     float* out;          // FWD: g [N][C]; DU: du [N][2C]; DT: dt [N][2C]
     float* part;         // FWD: [N*C][nb]; DU: [N*C][nb][20]
     int C, H, W, tprw_log2, rpt, ncb;
+    float pscale;        // FWD: factor on the pool partial (1, or 1/(H*W) when one block covers the plane and writes `pooled` itself)
 };
 
 struct Row6 { float v[6]; };
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
         const float s = wave_sum(acc[0]);
         if (lane == 0) red[tid >> 6][0] = s;
         __syncthreads();
-        if (tid == 0) a.part[((long)n * C + c) * gridDim.x + blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        if (tid == 0) a.part[((long)n * C + c) * gridDim.x + blockIdx.x] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * a.pscale;
     } else if (MODE == MODE_DU) {
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
@@ -233,10 +234,16 @@ extern "C" int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int 
     TDR_REQUIRE(W % 4 == 0, "tdr_dwsg_fwd: W must be a multiple of 4 (got %d)", W);
     hipStream_t st = (hipStream_t)stream;
     const DwGeom q = dw_geom(H, W);
-    DwArgs a{t, nullptr, w, b, g, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    const float inv_hw = 1.0f / (float)((long)H * W);
+    if (q.nb == 1) {     // one block per plane (the 64 x 64 level and below): the partial IS the pool sum -- no finish launch
+        DwArgs a{t, nullptr, w, b, g, pooled, C, H, W, q.tprw_log2, q.rpt, q.ncb, inv_hw};
+        hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a);
+        TDR_LAUNCH_CHECK("dwsg_fwd");
+        return TDR_OK;
+    }
+    DwArgs a{t, nullptr, w, b, g, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(dw_pool_finish_kernel, dim3(tdr_cdiv(N * C, 256)), dim3(256), 0, st, ws, N * C, q.nb,
-                       1.0f / (float)((long)H * W), pooled);
+    hipLaunchKernelGGL(dw_pool_finish_kernel, dim3(tdr_cdiv(N * C, 256)), dim3(256), 0, st, ws, N * C, q.nb, inv_hw, pooled);
     TDR_LAUNCH_CHECK("dwsg_fwd");
     return TDR_OK;
 }
@@ -250,9 +257,9 @@ extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, con
     float* part = ws;
     float* du = ws + (int64_t)N * C * q.nb * 20;
     du += (4 - (reinterpret_cast<uintptr_t>(du) / 4) % 4) % 4;   // 16-byte aligned scratch planes (ws holds one spare vector)
-    DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
-    DwArgs a2{du, nullptr, w, b, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    DwArgs a2{du, nullptr, w, b, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
     hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, part, N, C, q.nb, dw, db);
     TDR_LAUNCH_CHECK("dwsg_bwd");
@@ -265,7 +272,7 @@ extern "C" int tdr_dwgelu_fwd(const float* t, const float* w, const float* b, in
     TDR_REQUIRE(t && w && g, "tdr_dwgelu_fwd: null pointer");
     TDR_REQUIRE(W % 4 == 0, "tdr_dwgelu_fwd: W must be a multiple of 4 (got %d)", W);
     const DwGeom q = dw_geom(H, W);
-    DwArgs a{t, nullptr, w, b, g, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    DwArgs a{t, nullptr, w, b, g, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_GELU>), dim3(q.nb, C, N), dim3(256), 0, (hipStream_t)stream, a);
     TDR_LAUNCH_CHECK("dwgelu_fwd");
     return TDR_OK;
@@ -280,9 +287,9 @@ extern "C" int tdr_dwgelu_bwd(const float* dg, const float* t, const float* w, c
     float* part = ws;
     float* du = ws + (int64_t)N * C * q.nb * 20;
     du += (4 - (reinterpret_cast<uintptr_t>(du) / 4) % 4) % 4;
-    DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_GELU>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
-    DwArgs a2{du, nullptr, w, nullptr, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    DwArgs a2{du, nullptr, w, nullptr, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
     hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, part, N, C, q.nb, dw, db);
     TDR_LAUNCH_CHECK("dwgelu_bwd");
@@ -295,7 +302,7 @@ extern "C" int tdr_dwconv_fwd(const float* t, const float* w, const float* b, in
     TDR_REQUIRE(t && w && out, "tdr_dwconv_fwd: null pointer");
     TDR_REQUIRE(W % 4 == 0 && planes % 2 == 0, "tdr_dwconv_fwd: W %% 4 and planes %% 2 must be 0 (got %d, %d)", W, planes);
     const DwGeom q = dw_geom(H, W);
-    DwArgs a{t, nullptr, w, b, out, nullptr, planes / 2, H, W, q.tprw_log2, q.rpt, q.ncb};
+    DwArgs a{t, nullptr, w, b, out, nullptr, planes / 2, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_NONE>), dim3(q.nb, planes / 2, N), dim3(256), 0, (hipStream_t)stream, a);
     TDR_LAUNCH_CHECK("dwconv_fwd");
     return TDR_OK;
@@ -309,9 +316,9 @@ extern "C" int tdr_dwconv_bwd(const float* dout, const float* t, const float* w,
     hipStream_t st = (hipStream_t)stream;
     const int C = planes / 2;
     const DwGeom q = dw_geom(H, W);
-    DwArgs a1{t, dout, w, nullptr, nullptr, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    DwArgs a1{t, dout, w, nullptr, nullptr, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_NONE>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
-    DwArgs a2{dout, nullptr, w, nullptr, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb};
+    DwArgs a2{dout, nullptr, w, nullptr, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
     hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, ws, N, C, q.nb, dw, db);
     TDR_LAUNCH_CHECK("dwconv_bwd");
