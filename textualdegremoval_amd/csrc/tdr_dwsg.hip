@@ -37,6 +37,8 @@ struct DwArgs {
     float* part;         // FWD: [N*C][nb]; DU: [N*C][nb][20]
     int C, H, W, tprw_log2, rpt, ncb;
     float pscale;        // FWD: factor on the pool partial (1, or 1/(H*W) when one block covers the plane and writes `pooled` itself)
+    float* pdw;          // DT: dw [2C][9] / db [2C] (db may be NULL) finished from the DU pass's `part` by block (0, c, 0) --
+    float* pdb;          //     the parameter-gradient finish rides on the second pass instead of its own launch
 };
 
 struct Row6 { float v[6]; };
@@ -179,6 +181,18 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
         __syncthreads();
         if (tid < 20)
             a.part[(((long)n * C + c) * gridDim.x + blockIdx.x) * 20 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    } else if (MODE == MODE_DT) {
+        // dw[ch][9], db[ch] from part[N][C][nb][20] of the previous (DU) launch (ch < C: first half, ch >= C: second half);
+        // same summation order as dw_param_finish_kernel
+        if (a.pdw && blockIdx.x == 0 && blockIdx.z == 0 && tid < 20) {
+            const int nb = gridDim.x, N = gridDim.z;
+            float sacc = 0.f;
+            for (int m = 0; m < N; ++m)
+                for (int g = 0; g < nb; ++g) sacc += a.part[(((long)m * C + c) * nb + g) * 20 + tid];
+            const int ch = tid < 10 ? c : c + C, kk = tid % 10;
+            if (kk < 9) a.pdw[ch * 9 + kk] = sacc;
+            else if (a.pdb) a.pdb[ch] = sacc;
+        }
     }
 }
 
@@ -188,19 +202,6 @@ __global__ void dw_pool_finish_kernel(const float* __restrict__ part, int NC, in
     float s = 0.f;
     for (int k = 0; k < nb; ++k) s += part[(long)i * nb + k];
     pooled[i] = s * inv_hw;
-}
-
-// dw[ch][9], db[ch] from part[N][C][nb][20]  (ch < C: first half, ch >= C: second half)
-__global__ void dw_param_finish_kernel(const float* __restrict__ part, int N, int C, int nb, float* __restrict__ dw,
-                                       float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over C*20
-    if (i >= C * 20) return;
-    const int c = i / 20, k = i % 20;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n)
-        for (int g = 0; g < nb; ++g) s += part[(((long)n * C + c) * nb + g) * 20 + k];
-    const int ch = k < 10 ? c : c + C, kk = k % 10;
-    if (kk < 9) dw[ch * 9 + kk] = s; else if (db) db[ch] = s;
 }
 
 struct DwGeom { int tprw_log2, rpt, ncb, nby, nb; };
@@ -259,9 +260,8 @@ extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, con
     du += (4 - (reinterpret_cast<uintptr_t>(du) / 4) % 4) % 4;   // 16-byte aligned scratch planes (ws holds one spare vector)
     DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
-    DwArgs a2{du, nullptr, w, b, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
+    DwArgs a2{du, nullptr, w, b, dt, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, dw, db};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
-    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, part, N, C, q.nb, dw, db);
     TDR_LAUNCH_CHECK("dwsg_bwd");
     return TDR_OK;
 }
@@ -289,9 +289,8 @@ extern "C" int tdr_dwgelu_bwd(const float* dg, const float* t, const float* w, c
     du += (4 - (reinterpret_cast<uintptr_t>(du) / 4) % 4) % 4;
     DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_GELU>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
-    DwArgs a2{du, nullptr, w, nullptr, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
+    DwArgs a2{du, nullptr, w, nullptr, dt, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, dw, db};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
-    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, part, N, C, q.nb, dw, db);
     TDR_LAUNCH_CHECK("dwgelu_bwd");
     return TDR_OK;
 }
@@ -318,9 +317,8 @@ extern "C" int tdr_dwconv_bwd(const float* dout, const float* t, const float* w,
     const DwGeom q = dw_geom(H, W);
     DwArgs a1{t, dout, w, nullptr, nullptr, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_NONE>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
-    DwArgs a2{dout, nullptr, w, nullptr, dt, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
+    DwArgs a2{dout, nullptr, w, nullptr, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, dw, db};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
-    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(tdr_cdiv(C * 20, 256)), dim3(256), 0, st, ws, N, C, q.nb, dw, db);
     TDR_LAUNCH_CHECK("dwconv_bwd");
     return TDR_OK;
 }
