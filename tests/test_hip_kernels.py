@@ -90,6 +90,43 @@ def test_conv_forward_plain(K, case):
     assert maxdiff(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4, 5])
+def test_conv1x1_every_tile_configuration(K, cfg):
+    """every (waves, tiles) configuration of the 1x1 kernels -- under hx2 with >= 4 K stages that is the float4-staged
+    kernel in all five shapes (128x128, 64x256, 64x128, 32x256, 256x64), otherwise the 16-channel pipeline."""
+    from textualdegremoval_amd import _lib
+    lib = _lib.load()
+    N, Cin, Cout, H, W = 2, 520, 200, 20, 36
+    x = rnd(N, Cin, H, W, seed=1); w = rnd(Cout, Cin, 1, 1, seed=2, scale=1.0 / Cin ** 0.5); b = rnd(Cout, seed=3, scale=0.3)
+    res = rnd(N, Cout, H, W, seed=4)
+    ref = F.conv2d(x, w, b) + res
+    wp, mp, *_ = K.pack_weights(dev(w), K.PACK_FWD)
+    lib.tdr_conv_force_cfg(1, cfg)
+    try:
+        out = K.conv_forward(dev(x), wp, mp, Cout, 1, bias=dev(b), res=dev(res))
+    finally:
+        lib.tdr_conv_force_cfg(1, 0)
+    assert maxdiff(out, ref) < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+def test_conv3x3_every_tile_configuration(K, cfg):
+    """128x256, 64x256, 64x128, 128x128 tiles of the 3x3 kernel (the one-m-tile-per-wave shapes run the 9-slot
+    weight-fragment ring at this launch size)."""
+    from textualdegremoval_amd import _lib
+    lib = _lib.load()
+    N, Cin, Cout, H, W = 2, 72, 136, 24, 40
+    x = rnd(N, Cin, H, W, seed=1); w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / (9 * Cin) ** 0.5); b = rnd(Cout, seed=3, scale=0.3)
+    ref = F.conv2d(x, w, b, padding=1)
+    wp, mp, *_ = K.pack_weights(dev(w), K.PACK_FWD)
+    lib.tdr_conv_force_cfg(3, cfg)
+    try:
+        out = K.conv_forward(dev(x), wp, mp, Cout, 3, pad=1, bias=dev(b))
+    finally:
+        lib.tdr_conv_force_cfg(3, 0)
+    assert maxdiff(out, ref) < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_forward_epilogue_chain(K):
     N, Cin, Cout, H, W = 2, 32, 48, 24, 40
     x = rnd(N, Cin, H, W, seed=1); w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.06); b = rnd(Cout, seed=3)
