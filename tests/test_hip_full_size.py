@@ -309,7 +309,7 @@ def test_restormer_full_size_gradients_against_oracle(rworld, monkeypatch):
     assert worst < 5e-3, (worst, worst_k)
 
 
-def test_full_size_graph_replay_matches_eager_steps():
+def test_full_size_graph_replay_matches_eager_steps(monkeypatch):
     """five optimize_parameters steps of the headline configuration (width 32, enc [1,1,1,28], 4 x 512x512): the captured
     hipGraph replay against the eager path (same kernels, no host work in between): losses to 1e-6 (the MASA-encoder
     gradients pass through an atomic scatter whose order is not fixed, so not bit for bit)."""
@@ -320,16 +320,17 @@ def test_full_size_graph_replay_matches_eager_steps():
     data = {k: v.cuda() for k, v in synthetic_pair(4, SIZE, SIZE, seed=4321).items()}
     losses = []
     for graph in (True, False):
+        monkeypatch.setenv('TDR_GRAPH', '1' if graph else '0')      # read when the model takes its first step
         torch.manual_seed(0)
         model = create_model(bench.make_opt(32, [1, 1, 1, 28], SIZE, False))
         randomize_gates(model.net_g)
-        model.use_hip_graph = graph
         ls = []
         for it in range(1, 6):
             model.update_learning_rate(it, warmup_iter=-1)
             model.feed_train_data(data)
             model.optimize_parameters(it)
             ls.append(model.get_current_log()['l_pix'])
+        assert model.use_hip_graph == graph
         losses.append(ls)
         del model
         torch.cuda.empty_cache()
