@@ -23,6 +23,21 @@ extern "C" {
 int tdr_version(void);
 const char* tdr_last_error(void);
 
+/* Device-resident verdict of a train step (10 words).  The fp16-split backward pass runs on gradients scaled by the
+ * power of two `scale` (tdr_l1_loss_guarded emits dpred * scale, tdr_multi_copy_guarded multiplies the parameter
+ * gradients by inv_scale -- both exact).  tdr_grad_sumsq_guarded sets `finite` from the global gradient norm: a
+ * non-finite norm (an operand left the fp16 range, or the forward pass overflowed) makes tdr_adamw_step_guarded a
+ * no-op for that step, halves `scale` and counts the step in `skipped`; after `growth_interval` finite steps the scale
+ * doubles again up to max_scale.  `step` is AdamW's t (applied steps only) and bc1/bc2_sqrt its bias corrections.
+ * Everything lives in device memory so the whole step replays from captured hipGraphs with step-invariant launch
+ * arguments; the reference has no counterpart (it runs torch fp32, image_restoration_ref_model.py:276-279). */
+typedef struct TdrStepGuard {
+    float scale, inv_scale, max_scale;
+    int good, growth_interval;
+    int step, skipped, finite;
+    float bc1, bc2_sqrt;
+} TdrStepGuard;
+
 /* ---------------------------------------------------------------------------
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32,
  * exact fp32).  One kernel family serves every dense conv on the path:
@@ -233,6 +248,9 @@ int tdr_relu_bwd(const float* go, const float* act, int64_t numel, float* out, v
  * gradient chain; the parameter gradients are divided by it again in tdr_multi_copy. */
 int tdr_l1_loss(const float* pred, const float* target, int64_t numel, float loss_weight, float grad_scale,
                 float* loss, float* dpred, float* ws, void* stream);
+/* the same with the loss scale read from the device-resident step guard (dpred = guard->scale * w*sign/numel) */
+int tdr_l1_loss_guarded(const float* pred, const float* target, int64_t numel, float loss_weight, const TdrStepGuard* guard,
+                        float* loss, float* dpred, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------
  * MASA match-and-transfer (network_nafnet_guided_arch.py:495-707)
@@ -356,6 +374,44 @@ int tdr_adamw_step_dev(float* const* params, const float* const* grads, float* c
                        const int64_t* sizes, const int* group, const int* chunk_tensor, const int* chunk_index, int n_chunks,
                        const double* sumsq, const float* hp, float max_norm, int use_clip, float beta1, float beta2,
                        float eps, float weight_decay, void* stream);
+/* ---------------------------------------------------------------------------
+ * Data-parallel exchange over RCCL / xGMI: replaces DistributedDataParallel's gradient all-reduce and
+ * constructor broadcast (models/base_model.py:76-82) and reduce_loss_dict's dist.reduce (:361-372), i.e. what the
+ * reference reaches through torch.distributed.launch + utils/utils_dist.py:10-83.  One process per GPU; the
+ * communicator binds to the caller's current HIP device.  Rendezvous: rank 0 calls tdr_comm_unique_id and hands the
+ * tdr_comm_unique_id_bytes() (=128) bytes to every rank by any side channel (env/TCP store/file), then ALL ranks call
+ * tdr_comm_init.  Collectives are in place on fp32 device buffers, enqueued on `stream`, capturable in a hipGraph.
+ * librccl.so.1 is bound at run time (the copy already resident in the process, else /opt/rocm/lib). */
+typedef struct TdrComm TdrComm;
+int tdr_comm_unique_id_bytes(void);
+int tdr_comm_unique_id(void* id_out);
+int tdr_comm_init(TdrComm** comm, int rank, int world, const void* unique_id);
+int tdr_comm_allreduce(TdrComm* comm, float* buf, int64_t count, int average, void* stream);  /* sum, or mean over ranks */
+int tdr_comm_reduce(TdrComm* comm, float* buf, int64_t count, int root, void* stream);        /* sum to `root` */
+int tdr_comm_broadcast(TdrComm* comm, float* buf, int64_t count, int root, void* stream);
+int tdr_comm_rank(const TdrComm* comm);
+int tdr_comm_world(const TdrComm* comm);
+int tdr_comm_destroy(TdrComm* comm);
+
+/* EMA of the weights, models/base_model.py:54-62 (`p_ema.mul_(decay).add_(p, alpha=1-decay)` per tensor): one launch
+ * over the same kind of (tensor, chunk) table. */
+int tdr_multi_ema(const float* const* src, float* const* dst, const int64_t* sizes, const int* chunk_tensor,
+                  const int* chunk_index, int n_chunks, float decay, void* stream);
+/* Guarded step (TdrStepGuard above): gather with scale = guard->inv_scale; gradient norm over the tensors with
+ * group[t] >= 0 (group[t] < 0 = frozen: the reference's requires_grad_(False) on the "masa" parameters while
+ * current_iter < fix_iterations, image_restoration_ref_model.py:205-212) + verdict / step count / bias corrections /
+ * loss-scale update; AdamW (coupled_decay 0) or torch.optim.Adam (coupled_decay 1: weight_decay * p added to the
+ * gradient, :176-178) update that is skipped when the verdict is "not finite".  hp = {lr[0..3]} in device memory. */
+int tdr_multi_copy_guarded(const float* const* src, float* const* dst, const int64_t* sizes, const int* chunk_tensor,
+                           const int* chunk_index, int n_chunks, const TdrStepGuard* guard, void* stream);
+int tdr_grad_sumsq_guarded(const float* const* grads, const int64_t* sizes, const int* group, const int* chunk_tensor,
+                           const int* chunk_index, int n_chunks, double* partial, double* sumsq, TdrStepGuard* guard,
+                           float beta1, float beta2, void* stream);
+int tdr_adamw_step_guarded(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                           const int64_t* sizes, const int* group, const int* chunk_tensor, const int* chunk_index,
+                           int n_chunks, const double* sumsq, const float* hp, const TdrStepGuard* guard, float max_norm,
+                           int use_clip, int coupled_decay, float beta1, float beta2, float eps, float weight_decay,
+                           void* stream);
 
 #ifdef __cplusplus
 }

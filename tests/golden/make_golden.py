@@ -279,7 +279,16 @@ def psnr_case():
 if __name__ == '__main__':
     torch.set_num_threads(8)
     arch = import_ref_arch()
-    only_net = len(sys.argv) > 1 and sys.argv[1] == 'net'
+    only_net = len(sys.argv) > 1 and sys.argv[1] in ('net', 'refsize')
+    small = O.default_cfg(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
+    # ref of another size than lq (validation / inference: the full generated reference against any lq,
+    # image_restoration_ref_model.py:286-330): block diameter follows the ref size (:606-607)
+    if len(sys.argv) < 2 or sys.argv[1] == 'refsize':
+        whole_net_case(arch, 'net_w8_256_ref384', small, 1, 256, 256, seed=8, ref_hw=(384, 384))      # 21x21 boxes in a 24x24 map
+        whole_net_case(arch, 'net_w8_128_ref256_wrap', small, 1, 128, 128, seed=9, ref_hw=(256, 256))  # 27x27 boxes wrap a 16x16 map
+        whole_net_case(arch, 'net_w8_200x136_ref300', small, 1, 200, 136, seed=10, ref_hw=(300, 300))  # zero-padded to 256x256 / 384x384
+        if len(sys.argv) > 1:
+            sys.exit(0)
     if not only_net:
         per_op_cases(arch)
         masa_ops_case(arch)

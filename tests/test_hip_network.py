@@ -103,7 +103,13 @@ CASES = [('net_w8_256_b2_clear', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], 
          ('net_w8_128_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_w8_256_b2', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_w8_120x100_pad', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
-         ('net_cfg1_w16_128', dict(width=16, nf=16, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2]))]
+         ('net_cfg1_w16_128', dict(width=16, nf=16, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2])),
+         # ref of another size than lq: two separate masa_enc passes, block diameter from the ref size (validation /
+         # inference path of the reference, image_restoration_ref_model.py:286-330)
+         ('net_w8_256_ref384', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+         ('net_w8_128_ref256_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+         ('net_w8_200x136_ref300', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1]))]
+REF_HW = {'net_w8_256_ref384': (384, 384), 'net_w8_128_ref256_wrap': (256, 256), 'net_w8_200x136_ref300': (300, 300)}
 
 
 @pytest.mark.parametrize('name,kw', CASES)
@@ -114,7 +120,7 @@ def test_whole_net_vs_reference_golden(E, name, kw):
     seed = int(g['seed'])
     P = O.synth_params(cfg, seed=seed)
     Pc = cuda_params(P)
-    lq, gt, ref = O.synth_pair(int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), seed=1234 + seed)
+    lq, gt, ref = O.synth_pair(int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), seed=1234 + seed, ref_hw=REF_HW.get(name))
     out, saved = E.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
     sv_masa = saved[6]
     index, index_all, soft_att = sv_masa[4], sv_masa[7], sv_masa[8]
@@ -125,7 +131,9 @@ def test_whole_net_vs_reference_golden(E, name, kw):
     # then compared teacher-forced (reference indices fed to the transfer kernels).
     ia = index_all.cpu().numpy().reshape(g['index_all'].shape)
     mism = ia != g['index_all']
-    assert mism.mean() <= 0.005, f'fine-search index agreement {1 - mism.mean()}'
+    # (the zero-padded ref300 case has whole blocks of EXACT ties -- constant features over the padding -- where any
+    # index is "the" arg-max; every flip must still sit on a tie of the reference's own scores)
+    assert mism.mean() <= (0.10 if name == 'net_w8_200x136_ref300' else 0.005), f'fine-search index agreement {1 - mism.mean()}'
     assert (g['fine_gap'].reshape(mism.shape)[mism] < 1e-5).all(), 'index flip at a non-tie'
     if mism.any():
         forced = torch.from_numpy(g['index_all'].reshape(index_all.shape)).int().cuda()

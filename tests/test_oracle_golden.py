@@ -89,7 +89,12 @@ def test_coarse_search_centre_tap_form(golden_dir):
 CASES = [('net_w8_128_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_w8_256_b2', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_w8_120x100_pad', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
-         ('net_cfg1_w16_128', dict(width=16, nf=16, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2]))]
+         ('net_cfg1_w16_128', dict(width=16, nf=16, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2])),
+         # ref of another size than lq (validation / inference, image_restoration_ref_model.py:286-330)
+         ('net_w8_256_ref384', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+         ('net_w8_128_ref256_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
+         ('net_w8_200x136_ref300', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1]))]
+REF_HW = {'net_w8_256_ref384': (384, 384), 'net_w8_128_ref256_wrap': (256, 256), 'net_w8_200x136_ref300': (300, 300)}
 
 
 @pytest.mark.parametrize('name,kw', CASES)
@@ -98,7 +103,7 @@ def test_whole_net_forward_backward(golden_dir, name, kw):
     cfg = O.default_cfg(**kw)
     seed = int(g['seed'])
     P = {k: v.requires_grad_(True) for k, v in O.synth_params(cfg, seed=seed).items()}
-    lq, gt, ref = O.synth_pair(int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), seed=1234 + seed)
+    lq, gt, ref = O.synth_pair(int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), seed=1234 + seed, ref_hw=REF_HW.get(name))
     out, aux = O.nafnet_ref_forward(P, cfg, lq, ref, return_aux=True)
     assert np.array_equal(aux['index'].numpy(), g['index'][..., 0] if g['index'].ndim == 3 else g['index'])
     assert np.array_equal(aux['index_all'].numpy(), g['index_all'])

@@ -63,6 +63,11 @@ class TdrWgradDesc(C.Structure):
     ]
 
 
+class TdrStepGuard(C.Structure):
+    _fields_ = [('scale', f32), ('inv_scale', f32), ('max_scale', f32), ('good', i32), ('growth_interval', i32),
+                ('step', i32), ('skipped', i32), ('finite', i32), ('bc1', f32), ('bc2_sqrt', f32)]
+
+
 # name -> (restype, argtypes); every symbol include/tdr.h declares
 SIGNATURES = {
     'tdr_version': (i32, []),
@@ -143,6 +148,20 @@ SIGNATURES = {
     'tdr_grad_sumsq': (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp]),
     'tdr_adamw_step': (i32, [c_fp] * 8 + [i32, c_fp, C.POINTER(f32), i32, f32, i32, f32, f32, f32, f32, i32, c_fp]),
     'tdr_adamw_step_dev': (i32, [c_fp] * 8 + [i32, c_fp, c_fp, f32, i32, f32, f32, f32, f32, c_fp]),
+    'tdr_comm_unique_id_bytes': (i32, []),
+    'tdr_comm_unique_id': (i32, [c_fp]),
+    'tdr_comm_init': (i32, [C.POINTER(c_fp), i32, i32, c_fp]),
+    'tdr_comm_allreduce': (i32, [c_fp, c_fp, i64, i32, c_fp]),
+    'tdr_comm_reduce': (i32, [c_fp, c_fp, i64, i32, c_fp]),
+    'tdr_comm_broadcast': (i32, [c_fp, c_fp, i64, i32, c_fp]),
+    'tdr_comm_rank': (i32, [c_fp]),
+    'tdr_comm_world': (i32, [c_fp]),
+    'tdr_comm_destroy': (i32, [c_fp]),
+    'tdr_multi_ema': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
+    'tdr_l1_loss_guarded': (i32, [c_fp, c_fp, i64, f32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_multi_copy_guarded': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp]),
+    'tdr_grad_sumsq_guarded': (i32, [c_fp] * 5 + [i32, c_fp, c_fp, c_fp, f32, f32, c_fp]),
+    'tdr_adamw_step_guarded': (i32, [c_fp] * 8 + [i32, c_fp, c_fp, c_fp, f32, i32, i32, f32, f32, f32, f32, c_fp]),
 }
 
 _lib = None

@@ -15,9 +15,13 @@ __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<u
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* const* __restrict__ grads, const int64_t* __restrict__ sizes,
                                                    const int* __restrict__ chunk_tensor, const int* __restrict__ chunk_index,
-                                                   double* __restrict__ partial) {
+                                                   double* __restrict__ partial, const int* __restrict__ group) {
     __shared__ double red[4];
     const int t = chunk_tensor[blockIdx.x];
+    if (group && group[t] < 0) {                       // frozen tensor (requires_grad False in the reference): not in the norm
+        if (threadIdx.x == 0) partial[blockIdx.x] = 0.0;
+        return;
+    }
     const long base = (long)chunk_index[blockIdx.x] * CHUNK;
     const long n = sizes[t];
     const float* g = grads[t];
@@ -55,11 +59,49 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const double* __restr
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// The same reduction, then the step verdict (see TdrStepGuard in include/tdr.h): a non-finite gradient norm means an
+// operand of the loss-scaled fp16-split backward pass left the fp16 range (or the forward pass produced inf/nan) --
+// the step is skipped and the loss scale halved; after `growth_interval` finite steps the scale doubles again, up to
+// max_scale.  Every rank sees the same all-reduced gradients, hence takes the same decision.
+__global__ __launch_bounds__(256) void sumsq_finish_guard_kernel(const double* __restrict__ partial, int n, double* __restrict__ out,
+                                                                 TdrStepGuard* __restrict__ g, double beta1, double beta2) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double tot = red[0];
+        out[0] = tot;
+        const bool ok = isfinite(tot);
+        g->finite = ok ? 1 : 0;
+        if (ok) {
+            const int t = ++g->step;
+            g->bc1 = (float)(1.0 - pow(beta1, (double)t));
+            g->bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
+            if (g->growth_interval > 0 && ++g->good >= g->growth_interval) {
+                g->good = 0;
+                if (g->scale < g->max_scale) { g->scale *= 2.f; g->inv_scale *= 0.5f; }
+            }
+        } else {
+            ++g->skipped;
+            g->good = 0;
+            if (g->scale > 1.f) { g->scale *= 0.5f; g->inv_scale *= 2.f; }
+        }
+    }
+}
+
 // dst[t][i] = src[t][i] for every tensor of a (tensor, chunk) table: gathers ~900 freshly produced gradient
 // tensors into the flat all-reduce / optimiser arena with ONE launch instead of one copy kernel per tensor.
 __global__ __launch_bounds__(256) void multi_copy_kernel(const float* const* __restrict__ src, float* const* __restrict__ dst,
                                                         const int64_t* __restrict__ sizes, const int* __restrict__ chunk_tensor,
-                                                        const int* __restrict__ chunk_index, float scale) {
+                                                        const int* __restrict__ chunk_index, float scale,
+                                                        const TdrStepGuard* __restrict__ guard) {
+    if (guard) scale = guard->inv_scale;
     const int t = chunk_tensor[blockIdx.x];
     const long base = (long)chunk_index[blockIdx.x] * CHUNK;
     const long n = sizes[t];
@@ -79,11 +121,27 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const float* const* __r
     for (long i = base + threadIdx.x; i < end; i += 256) d[i] = s[i] * scale;   // scale: 1 / (power-of-two loss scale)
 }
 
+// dst[t] = decay * dst[t] + (1 - decay) * src[t] over a (tensor, chunk) table: the EMA copy of the weights
+// (models/base_model.py:54-62) in one launch.
+__global__ __launch_bounds__(256) void multi_ema_kernel(const float* const* __restrict__ src, float* const* __restrict__ dst,
+                                                       const int64_t* __restrict__ sizes, const int* __restrict__ chunk_tensor,
+                                                       const int* __restrict__ chunk_index, float decay) {
+    const int t = chunk_tensor[blockIdx.x];
+    const long base = (long)chunk_index[blockIdx.x] * CHUNK;
+    const long end = min(base + CHUNK, (long)sizes[t]);
+    const float* s = src[t];
+    float* d = dst[t];
+    const float a = 1.f - decay;
+    for (long i = base + threadIdx.x; i < end; i += 256) d[i] = d[i] * decay + s[i] * a;     // torch: mul_(decay).add_(src, alpha=1-decay)
+}
+
 struct AdamArgs {
     float lr[4];
     float max_norm, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;
     int use_clip;
+    int coupled_decay;  // 0: AdamW (decoupled decay); 1: torch.optim.Adam (weight_decay * p added to the gradient)
     const float* hp;    // optional device-resident {lr[4], bc1, bc2_sqrt} (graph replay: values change, launch does not)
+    const TdrStepGuard* guard;   // optional: skip the update when !finite; bias corrections from the guard's own step count
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ params, const float* const* __restrict__ grads,
@@ -92,6 +150,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ p
                                                    const int* __restrict__ chunk_tensor, const int* __restrict__ chunk_index,
                                                    const double* __restrict__ sumsq, AdamArgs a) {
     const int t = chunk_tensor[blockIdx.x];
+    if (group[t] < 0) return;                           // frozen tensor
+    if (a.guard && !a.guard->finite) return;            // skipped step (uniform over the grid)
     const long base = (long)chunk_index[blockIdx.x] * CHUNK;
     const long n = sizes[t];
     float* p = params[t];
@@ -99,8 +159,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ p
     float* m = exp_avg[t];
     float* v = exp_avg_sq[t];
     const float lr = a.hp ? a.hp[group[t]] : a.lr[group[t]];
-    const float bc1 = a.hp ? a.hp[4] : a.bc1;
-    const float bc2_sqrt = a.hp ? a.hp[5] : a.bc2_sqrt;
+    const float bc1 = a.guard ? a.guard->bc1 : (a.hp ? a.hp[4] : a.bc1);
+    const float bc2_sqrt = a.guard ? a.guard->bc2_sqrt : (a.hp ? a.hp[5] : a.bc2_sqrt);
     float coef = 1.f;
     if (a.use_clip) {
         const float total = (float)sqrt(sumsq[0]);
@@ -108,8 +168,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ p
     }
     const float step = lr / bc1;
     auto upd = [&](float g0, float& pv, float& mv, float& vv) {
-        const float gv = g0 * coef;
-        pv *= (1.f - lr * a.weight_decay);
+        float gv = g0 * coef;
+        if (a.coupled_decay) gv += a.weight_decay * pv;
+        else pv *= (1.f - lr * a.weight_decay);
         mv = mv + (1.f - a.beta1) * (gv - mv);                            // lerp, as torch.optim
         vv = a.beta2 * vv + (1.f - a.beta2) * gv * gv;
         const float denom = sqrtf(vv) / bc2_sqrt + a.eps;
@@ -144,9 +205,23 @@ extern "C" int tdr_grad_sumsq(const float* const* grads, const int64_t* sizes, c
                               int n_chunks, double* partial, double* sumsq, void* stream) {
     TDR_REQUIRE(grads && sizes && chunk_tensor && chunk_index && partial && sumsq && n_chunks > 0, "tdr_grad_sumsq: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, grads, sizes, chunk_tensor, chunk_index, partial);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, grads, sizes, chunk_tensor, chunk_index, partial,
+                       (const int*)nullptr);
     hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, st, partial, n_chunks, sumsq);
     TDR_LAUNCH_CHECK("grad_sumsq");
+    return TDR_OK;
+}
+
+extern "C" int tdr_grad_sumsq_guarded(const float* const* grads, const int64_t* sizes, const int* group, const int* chunk_tensor,
+                                      const int* chunk_index, int n_chunks, double* partial, double* sumsq, TdrStepGuard* guard,
+                                      float beta1, float beta2, void* stream) {
+    TDR_REQUIRE(grads && sizes && group && chunk_tensor && chunk_index && partial && sumsq && guard && n_chunks > 0,
+                "tdr_grad_sumsq_guarded: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, grads, sizes, chunk_tensor, chunk_index, partial, group);
+    hipLaunchKernelGGL(sumsq_finish_guard_kernel, dim3(1), dim3(256), 0, st, partial, n_chunks, sumsq, guard, (double)beta1,
+                       (double)beta2);
+    TDR_LAUNCH_CHECK("grad_sumsq_guarded");
     return TDR_OK;
 }
 
@@ -163,7 +238,9 @@ extern "C" int tdr_adamw_step(float* const* params, const float* const* grads, f
     a.bc1 = (float)(1.0 - pow((double)beta1, step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
     a.use_clip = use_clip;
+    a.coupled_decay = 0;
     a.hp = nullptr;
+    a.guard = nullptr;
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes,
                        group, chunk_tensor, chunk_index, sumsq, a);
     TDR_LAUNCH_CHECK("adamw_step");
@@ -184,10 +261,36 @@ extern "C" int tdr_adamw_step_dev(float* const* params, const float* const* grad
     a.max_norm = max_norm; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
     a.bc1 = 1.f; a.bc2_sqrt = 1.f;
     a.use_clip = use_clip;
+    a.coupled_decay = 0;
     a.hp = hp;
+    a.guard = nullptr;
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes,
                        group, chunk_tensor, chunk_index, sumsq, a);
     TDR_LAUNCH_CHECK("adamw_step_dev");
+    return TDR_OK;
+}
+
+// The guarded step: learning rates from `hp` (4 floats, refreshed by the host every step), verdict / step count / bias
+// corrections from the device-resident TdrStepGuard that tdr_grad_sumsq_guarded just updated.  group[t] < 0 freezes a
+// tensor.  coupled_decay selects torch.optim.Adam's L2 term instead of AdamW's decoupled decay.
+extern "C" int tdr_adamw_step_guarded(float* const* params, const float* const* grads, float* const* exp_avg,
+                                      float* const* exp_avg_sq, const int64_t* sizes, const int* group, const int* chunk_tensor,
+                                      const int* chunk_index, int n_chunks, const double* sumsq, const float* hp,
+                                      const TdrStepGuard* guard, float max_norm, int use_clip, int coupled_decay, float beta1,
+                                      float beta2, float eps, float weight_decay, void* stream) {
+    TDR_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes && group && chunk_tensor && chunk_index && sumsq && hp && guard,
+                "tdr_adamw_step_guarded: null pointer");
+    AdamArgs a;
+    for (int i = 0; i < 4; ++i) a.lr[i] = 0.f;
+    a.max_norm = max_norm; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = 1.f; a.bc2_sqrt = 1.f;
+    a.use_clip = use_clip;
+    a.coupled_decay = coupled_decay;
+    a.hp = hp;
+    a.guard = guard;
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes,
+                       group, chunk_tensor, chunk_index, sumsq, a);
+    TDR_LAUNCH_CHECK("adamw_step_guarded");
     return TDR_OK;
 }
 
@@ -195,7 +298,25 @@ extern "C" int tdr_multi_copy(const float* const* src, float* const* dst, const 
                               const int* chunk_index, int n_chunks, float scale, void* stream) {
     TDR_REQUIRE(src && dst && sizes && chunk_tensor && chunk_index && n_chunks > 0, "tdr_multi_copy: bad argument");
     hipLaunchKernelGGL(multi_copy_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, src, dst, sizes, chunk_tensor,
-                       chunk_index, scale);
+                       chunk_index, scale, (const TdrStepGuard*)nullptr);
     TDR_LAUNCH_CHECK("multi_copy");
+    return TDR_OK;
+}
+
+extern "C" int tdr_multi_ema(const float* const* src, float* const* dst, const int64_t* sizes, const int* chunk_tensor,
+                             const int* chunk_index, int n_chunks, float decay, void* stream) {
+    TDR_REQUIRE(src && dst && sizes && chunk_tensor && chunk_index && n_chunks > 0, "tdr_multi_ema: bad argument");
+    hipLaunchKernelGGL(multi_ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, src, dst, sizes, chunk_tensor,
+                       chunk_index, decay);
+    TDR_LAUNCH_CHECK("multi_ema");
+    return TDR_OK;
+}
+
+extern "C" int tdr_multi_copy_guarded(const float* const* src, float* const* dst, const int64_t* sizes, const int* chunk_tensor,
+                                      const int* chunk_index, int n_chunks, const TdrStepGuard* guard, void* stream) {
+    TDR_REQUIRE(src && dst && sizes && chunk_tensor && chunk_index && guard && n_chunks > 0, "tdr_multi_copy_guarded: bad argument");
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, src, dst, sizes, chunk_tensor,
+                       chunk_index, 1.f, guard);
+    TDR_LAUNCH_CHECK("multi_copy_guarded");
     return TDR_OK;
 }

@@ -651,9 +651,11 @@ __global__ void relu_bwd_kernel(const float* __restrict__ go, const float* __res
 
 constexpr int L1_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ p, const float* __restrict__ t, long numel,
-                                                float gscale, float* __restrict__ dpred, double* __restrict__ part) {
+                                                float gscale, const TdrStepGuard* __restrict__ guard, float* __restrict__ dpred,
+                                                double* __restrict__ part) {
     __shared__ double red[4];
     double s = 0.0;
+    if (guard) gscale *= guard->scale;                 // power of two: exact
     for (long i = blockIdx.x * 256L + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
         const float d = p[i] - t[i];
         s += (double)fabsf(d);
@@ -865,8 +867,21 @@ extern "C" int tdr_l1_loss(const float* pred, const float* target, int64_t numel
     const int blocks = grid1d(numel, L1_BLOCKS);
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(l1_kernel, dim3(blocks), dim3(256), 0, st, pred, target, (long)numel,
-                       loss_weight / (float)numel * grad_scale, dpred, part);
+                       loss_weight / (float)numel * grad_scale, (const TdrStepGuard*)nullptr, dpred, part);
     hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, st, part, blocks, (double)loss_weight / (double)numel, loss);
     TDR_LAUNCH_CHECK("l1_loss");
+    return TDR_OK;
+}
+
+extern "C" int tdr_l1_loss_guarded(const float* pred, const float* target, int64_t numel, float loss_weight,
+                                   const TdrStepGuard* guard, float* loss, float* dpred, float* ws, void* stream) {
+    TDR_REQUIRE(pred && target && loss && dpred && ws && guard, "tdr_l1_loss_guarded: null pointer (ws needs 2*1024 floats)");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = grid1d(numel, L1_BLOCKS);
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(l1_kernel, dim3(blocks), dim3(256), 0, st, pred, target, (long)numel, loss_weight / (float)numel, guard,
+                       dpred, part);
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, st, part, blocks, (double)loss_weight / (double)numel, loss);
+    TDR_LAUNCH_CHECK("l1_loss_guarded");
     return TDR_OK;
 }

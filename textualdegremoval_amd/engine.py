@@ -287,23 +287,85 @@ class MasaGeom:
         self.side = self.dia_x + 2
 
 
-def masa_fwd(feats, N, geo, outs=None):
-    """feats: pyramid levels (finest first; 5 for NAFNet-ref, 4 for Restormer-ref) for the stacked batch
-    [lq(0..N-1), ref(N..2N-1)].  Returns (warp list finest->coarsest like the reference's warp_ref_l, saved).
-    outs: optional per-level destination views (the second half of the fusion blocks' concat buffers)."""
+class Pyramids:
+    """The two MASA feature pyramids of a forward pass (`feat_lq = masa_enc(inp)`, `feat_ref = masa_enc(ref)`, :617-618).
+    When lq and ref pad to the same size (training: the DINO window match makes them equal) both images are stacked
+    into ONE 2N batch and the encoder runs once; otherwise (validation / inference: the full generated reference
+    against an lq of any size, image_restoration_ref_model.py:286-330) it runs once per tensor.  `lq_deep` /
+    `ref_feats` are what the match-and-transfer stage reads in both cases."""
+    __slots__ = ('N', 'stacked', 'inp_p', 'geo', 'feats', 'sv_enc', 'lq_deep', 'ref_feats', 'levels')
+
+
+def pyramids_fwd(P, cfg, inp, ref, padder_log2, levels):
+    N, Ci, H0, W0 = inp.shape
+    mult = (2 ** padder_log2) * cfg['lr_block_size']
+    Hp, Wp = -(-H0 // mult) * mult, -(-W0 // mult) * mult
+    Hr0, Wr0 = ref.shape[-2:]
+    Hrp, Wrp = -(-Hr0 // mult) * mult, -(-Wr0 // mult) * mult
+    if ref.shape[0] != N:
+        raise ValueError('inp and ref must have the same batch size')
+    py = Pyramids()
+    py.N, py.levels = N, levels
+    py.geo = MasaGeom(Hp, Wp, Hrp, Wrp, padder_log2, cfg['lr_block_size'], cfg['ref_down_block_size'], cfg['dilations'])
+    py.stacked = (Hrp, Wrp) == (Hp, Wp)
+    if py.stacked:
+        both = torch.empty(2 * N, Ci, Hp, Wp, dtype=torch.float32, device=inp.device)
+        # zero-pad (:576-585) and stack [lq; ref] so masa_enc runs once over 2N images
+        _pad_into(inp.contiguous(), both[:N])
+        _pad_into(ref.contiguous(), both[N:])
+        py.inp_p = both[:N]
+        py.feats, py.sv_enc = encoder_fwd(both, P, 'masa_enc.', cfg['ext_n_blocks'], levels=levels)
+        py.lq_deep = py.feats[levels - 1][:N]
+        py.ref_feats = [f[N:] for f in py.feats]
+    else:
+        py.inp_p = torch.empty(N, Ci, Hp, Wp, dtype=torch.float32, device=inp.device)
+        ref_p = torch.empty(N, Ci, Hrp, Wrp, dtype=torch.float32, device=inp.device)
+        _pad_into(inp.contiguous(), py.inp_p)
+        _pad_into(ref.contiguous(), ref_p)
+        fl, svl = encoder_fwd(py.inp_p, P, 'masa_enc.', cfg['ext_n_blocks'], levels=levels)
+        fr, svr = encoder_fwd(ref_p, P, 'masa_enc.', cfg['ext_n_blocks'], levels=levels)
+        py.feats, py.sv_enc = (fl, fr), (svl, svr)
+        py.lq_deep, py.ref_feats = fl[levels - 1], fr
+    return py, (H0, W0, Hp, Wp)
+
+
+def pyramids_bwd(dwarp, py, P, cfg, sv_masa, G):
+    """MASA match/transfer backward + masa_enc backward (both pyramids share the encoder weights: one pass over the
+    stacked batch, or two passes whose weight gradients are added)."""
+    N, L = py.N, py.levels
+    if py.stacked:
+        dfeats = [torch.zeros_like(f) for f in py.feats]
+        masa_bwd(dwarp, py.lq_deep, py.ref_feats, N, py.geo, sv_masa, dfeats[L - 1][:N], [d[N:] for d in dfeats])
+        encoder_bwd(dfeats, P, 'masa_enc.', cfg['ext_n_blocks'], py.sv_enc, G)
+        return
+    fl, fr = py.feats
+    dlq = torch.empty_like(fl[L - 1])
+    dref = [torch.zeros_like(f) for f in fr]
+    masa_bwd(dwarp, py.lq_deep, py.ref_feats, N, py.geo, sv_masa, dlq, dref)
+    Gl, Gr = {}, {}
+    encoder_bwd([None] * (L - 1) + [dlq], P, 'masa_enc.', cfg['ext_n_blocks'], py.sv_enc[0], Gl)
+    encoder_bwd(dref, P, 'masa_enc.', cfg['ext_n_blocks'], py.sv_enc[1], Gr)
+    for k, g in Gr.items():          # levels above the deepest only see the ref pyramid (lq feeds the search alone)
+        G[k] = K.add_(g.contiguous().view(1, -1), Gl[k].contiguous().view(1, -1)).view(g.shape) if k in Gl else g
+
+
+def masa_fwd(lq4, ref_feats, N, geo, outs=None):
+    """lq4: deepest lq feature map [N,C,H,W]; ref_feats: the ref pyramid (finest first; 5 levels for NAFNet-ref, 4 for
+    Restormer-ref), each [N,C_l,Hr_l,Wr_l].  Returns (warp list finest->coarsest like the reference's warp_ref_l,
+    saved).  outs: optional per-level destination views (the second half of the fusion blocks' concat buffers)."""
     P, Kk, side = geo.P, geo.K, geo.side
-    L = len(feats)
-    deep = feats[L - 1]
-    _, Cc, H, W = deep.shape
-    lq4, ref4 = deep[:N], deep[N:]
-    Hr, Wr = H, W
+    L = len(ref_feats)
+    ref4 = ref_feats[L - 1]
+    _, Cc, H, W = lq4.shape
+    Hr, Wr = ref4.shape[-2:]
+    dev = lq4.device
     lrb = K.lr_blocks_fwd(lq4, geo.py, geo.px, Kk, Kk)                    # [N*P, C, K+2, K+2]
     # ---- coarse search (:515-536) on the MFMA conv with the LR centre taps as filters
     ND = len(geo.dilations)
     R = Hr * Wr
-    dots = torch.empty(ND, N, P, Hr, Wr, dtype=torch.float32, device=deep.device)
-    invq = torch.empty(ND, N * P, dtype=torch.float32, device=deep.device)
-    invk = torch.empty(ND, N, R, dtype=torch.float32, device=deep.device)
+    dots = torch.empty(ND, N, P, Hr, Wr, dtype=torch.float32, device=dev)
+    invq = torch.empty(ND, N * P, dtype=torch.float32, device=dev)
+    invk = torch.empty(ND, N, R, dtype=torch.float32, device=dev)
     cc = (Kk + 2) // 2
     for di, d in enumerate(geo.dilations):
         wp, mp, per_b = K.pack_patches(lrb, P, 1, 1, 1, d, cc - d)
@@ -323,30 +385,29 @@ def masa_fwd(feats, N, geo, outs=None):
     warp = []
     for lvl in range(L):
         s = 2 ** (L - 1 - lvl)
-        warp.append(K.transfer_fwd(feats[lvl][N:], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s,
+        warp.append(K.transfer_fwd(ref_feats[lvl], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s,
                                    out=None if outs is None else outs[lvl]))
     saved = (lrb, refb, finvq, finvk, index, y1, x1, index_all, soft_att)
     return warp, saved
 
 
-def masa_bwd(dwarp, feats, N, geo, saved):
-    """returns the gradients w.r.t. the stacked feats (zeros where unused)."""
+def masa_bwd(dwarp, lq4, ref_feats, N, geo, saved, dlq_out, dref_out):
+    """dlq_out [N,C,H,W] receives the gradient w.r.t. the deepest lq features (overwritten); dref_out: per-level
+    ZERO-INITIALISED tensors (dense batch slices are fine) that receive the gradients w.r.t. the ref pyramid."""
     lrb, refb, finvq, finvk, index, y1, x1, index_all, soft_att = saved
     P, Kk, side = geo.P, geo.K, geo.side
-    L = len(feats)
-    dev = feats[L - 1].device
-    dfeats = [torch.zeros_like(f) for f in feats]
+    L = len(ref_feats)
+    dev = lq4.device
     datt = torch.zeros(N * P, Kk * Kk, dtype=torch.float32, device=dev)
     for lvl in range(L):
         s = 2 ** (L - 1 - lvl)
-        K.transfer_bwd(dwarp[lvl], feats[lvl][N:], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s,
-                       dfeats[lvl][N:], datt)
+        K.transfer_bwd(dwarp[lvl], ref_feats[lvl], y1, x1, index_all, soft_att, geo.py, geo.px, Kk, side, s,
+                       dref_out[lvl], datt)
     dlrb, drefb = K.fine_search_bwd(datt, soft_att, index_all, lrb, refb, finvq, finvk, Kk, side)
-    K.scatter_ref_block(drefb, dfeats[L - 1][N:], y1, x1, P, side)
-    _, Cc, H, W = feats[L - 1].shape
+    K.scatter_ref_block(drefb, dref_out[L - 1], y1, x1, P, side)
+    _, Cc, H, W = lq4.shape
     dlq4 = K.lr_blocks_bwd(dlrb, N, Cc, H, W, geo.py, geo.px, Kk, Kk)
-    K.copy_rows(dlq4, Cc * H * W, dfeats[L - 1], Cc * H * W, N, Cc * H * W)
-    return dfeats
+    K.copy_rows(dlq4, Cc * H * W, dlq_out, Cc * H * W, N, Cc * H * W)
 
 
 # ---------------------------------------------------------------------------
@@ -355,31 +416,17 @@ def masa_bwd(dwarp, feats, N, geo, saved):
 def net_fwd(P, cfg, inp, ref):
     """inp, ref [N,3,H,W] -> (out [N,3,H,W], saved).  cfg: constructor kwargs."""
     n_enc = len(cfg['enc_blk_nums'])
-    N, Ci, H0, W0 = inp.shape
-    mult = (2 ** n_enc) * cfg['lr_block_size']
-    Hp, Wp = -(-H0 // mult) * mult, -(-W0 // mult) * mult
-    Hr0, Wr0 = ref.shape[-2:]
-    Hrp, Wrp = -(-Hr0 // mult) * mult, -(-Wr0 // mult) * mult
-    if (Hrp, Wrp) != (Hp, Wp):
-        raise NotImplementedError('ref and lq must pad to the same size on the fused path '
-                                  '(the DINO window match makes them equal, image_restoration_ref_model.py:219-243)')
-    both = torch.empty(2 * N, Ci, Hp, Wp, dtype=torch.float32, device=inp.device)
-    # zero-pad (:576-585) and stack [lq; ref] so masa_enc runs once over 2N images
-    _pad_into(inp.contiguous(), both[:N])
-    _pad_into(ref.contiguous(), both[N:])
-    inp_p = both[:N]
-    geo = MasaGeom(Hp, Wp, Hrp, Wrp, n_enc, cfg['lr_block_size'], cfg['ref_down_block_size'], cfg['dilations'])
-    feats, sv_enc = encoder_fwd(both, P, 'masa_enc.', cfg['ext_n_blocks'])
+    N = inp.shape[0]
+    pyr, (H0, W0, Hp, Wp) = pyramids_fwd(P, cfg, inp, ref, n_enc, n_enc + 1)
+    inp_p, geo = pyr.inp_p, pyr.geo
     # cat([x, warp], 1) of every fusion level (:719,727) without copies: the transfer kernel writes the warped reference
     # features into the second half of the level's concat buffer, the conv that produces x writes the first half
     chan = P['intro.weight'].shape[0]
     cats = []
     for lvl in range(n_enc + 1):
-        Cl, Hl, Wl = feats[lvl].shape[1:]            # warped-feature channels (nf * 2^lvl) next to the chan * 2^lvl of x
-        if (Hl, Wl) != (Hp >> lvl, Wp >> lvl):
-            raise ValueError('MASA feature pyramid does not match the fusion levels')
-        cats.append(torch.empty(N, (chan << lvl) + Cl, Hl, Wl, dtype=torch.float32, device=inp.device))
-    warp, sv_masa = masa_fwd(feats, N, geo, outs=[c[:, chan << lvl:] for lvl, c in enumerate(cats)])
+        Cl = pyr.ref_feats[lvl].shape[1]             # warped-feature channels (nf * 2^lvl) next to the chan * 2^lvl of x
+        cats.append(torch.empty(N, (chan << lvl) + Cl, Hp >> lvl, Wp >> lvl, dtype=torch.float32, device=inp.device))
+    warp, sv_masa = masa_fwd(pyr.lq_deep, pyr.ref_feats, N, geo, outs=[c[:, chan << lvl:] for lvl, c in enumerate(cats)])
 
     conv_fwd(inp_p, P['intro.weight'], P['intro.bias'], 1, 1, out=cats[0][:, :chan])
     sv_levels, skips = [], []
@@ -402,7 +449,7 @@ def net_fwd(P, cfg, inp, ref):
     xe = x
     out_p = conv_fwd(xe, P['ending.weight'], P['ending.bias'], 1, 1, res=inp_p)
     out = out_p if (Hp, Wp) == (H0, W0) else K.pad_crop(out_p, H0, W0)
-    saved = (N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe)
+    saved = (N, (H0, W0, Hp, Wp), geo, pyr, None, None, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe)
     return out, saved
 
 
@@ -426,10 +473,10 @@ def net_bwd(dout, P, cfg, saved, G=None):
 
 
 def _net_bwd(dout, P, cfg, saved, G):
-    N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe = saved
+    N, (H0, W0, Hp, Wp), geo, pyr, _, _, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe = saved
     n_enc = len(cfg['enc_blk_nums'])
     G = {} if G is None else G
-    inp_p = both[:N]
+    inp_p = pyr.inp_p
     dout = dout.contiguous()
     if (Hp, Wp) != (H0, W0):
         dout = K.pad_crop(dout, Hp, Wp)
@@ -459,6 +506,5 @@ def _net_bwd(dout, P, cfg, saved, G):
         d = dcat[:, :chan]                             # batch-strided view: every consumer takes an image stride
     # intro conv: input image needs no gradient
     _, G['intro.weight'], G['intro.bias'] = conv_bwd(d, inp_p, P['intro.weight'], 1, 1, need_dx=False)
-    dfeats = masa_bwd(dwarp, feats, N, geo, sv_masa)
-    encoder_bwd(dfeats, P, 'masa_enc.', cfg['ext_n_blocks'], sv_enc, G)
+    pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
     return G

@@ -156,6 +156,27 @@ def _vec_ns(v):
 
 
 _ws_cache = {}
+_ws_capture_refs = None
+
+
+class workspace_capture:
+    """While a hipGraph is being captured, every scratch buffer handed out is also recorded in `refs`: the graph's
+    owner keeps that list next to the graph, so a later eager call with a bigger shape (validation on a full-size
+    image between replays) that makes `workspace()` grow and drop its cached buffer cannot free memory the captured
+    kernels still address."""
+
+    def __init__(self, refs):
+        self.refs = refs
+
+    def __enter__(self):
+        global _ws_capture_refs
+        self.prev, _ws_capture_refs = _ws_capture_refs, self.refs
+        return self
+
+    def __exit__(self, *exc):
+        global _ws_capture_refs
+        _ws_capture_refs = self.prev
+        return False
 
 
 def workspace(nfloats, device, tag='main'):
@@ -167,6 +188,8 @@ def workspace(nfloats, device, tag='main'):
             _side_keep.append(buf)          # a side-stream kernel may still be using the smaller buffer
         buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
         _ws_cache[key] = buf
+    if _ws_capture_refs is not None:
+        _ws_capture_refs.append(buf)
     return buf
 
 
@@ -476,8 +499,14 @@ def channel_sum(x):
     return out
 
 
-def multi_copy(src_tab, dst_tab, sizes, chunk_tensor, chunk_index, n_chunks, scale=1.0):
-    """device pointer tables (int64 tensors); one launch copies (and scales) every listed tensor."""
+def multi_copy(src_tab, dst_tab, sizes, chunk_tensor, chunk_index, n_chunks, scale=1.0, guard=None):
+    """device pointer tables (int64 tensors); one launch copies (and scales) every listed tensor.  With a StepGuard the
+    scale is its device-resident 1 / loss scale."""
+    if guard is not None:
+        check(_lib.load().tdr_multi_copy_guarded(src_tab.data_ptr(), dst_tab.data_ptr(), sizes.data_ptr(), chunk_tensor.data_ptr(),
+                                                 chunk_index.data_ptr(), n_chunks, guard.data_ptr(), _stream()),
+              'tdr_multi_copy_guarded')
+        return
     check(_lib.load().tdr_multi_copy(src_tab.data_ptr(), dst_tab.data_ptr(), sizes.data_ptr(), chunk_tensor.data_ptr(),
                                      chunk_index.data_ptr(), n_chunks, float(scale), _stream()), 'tdr_multi_copy')
 
@@ -541,11 +570,16 @@ def relu_bwd(go, act):
     return out
 
 
-def l1_loss(pred, target, loss_weight=1.0, grad_scale=1.0):
+def l1_loss(pred, target, loss_weight=1.0, grad_scale=1.0, guard=None):
+    """guard: a StepGuard whose device-resident loss scale multiplies dpred (instead of the host value grad_scale)"""
     assert pred.is_contiguous() and target.is_contiguous()
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred)
     ws = workspace(4096, pred.device, 'l1')
+    if guard is not None:
+        check(_lib.load().tdr_l1_loss_guarded(pred.data_ptr(), target.data_ptr(), pred.numel(), float(loss_weight), guard.data_ptr(),
+                                              loss.data_ptr(), dpred.data_ptr(), ws.data_ptr(), _stream()), 'tdr_l1_loss_guarded')
+        return loss, dpred
     check(_lib.load().tdr_l1_loss(pred.data_ptr(), target.data_ptr(), pred.numel(), float(loss_weight), float(grad_scale), loss.data_ptr(),
                                   dpred.data_ptr(), ws.data_ptr(), _stream()), 'tdr_l1_loss')
     return loss, dpred

@@ -43,9 +43,35 @@ class BaseModel:
         return self.nondist_validation(dataloader, current_iter, tb_logger, save_img, rgb2bgr, use_image)
 
     def model_ema(self, decay=0.999):
+        """p_ema = decay * p_ema + (1 - decay) * p for every parameter (reference :54-62); on the GPU one
+        multi-tensor launch (tdr_multi_ema) over a pointer table built once."""
         src = dict(self.get_bare_model(self.net_g).named_parameters())
-        for k, p in self.net_g_ema.named_parameters():
-            p.data.mul_(decay).add_(src[k].data, alpha=1 - decay)
+        pairs = [(src[k].data, p.data) for k, p in self.net_g_ema.named_parameters()]
+        if not pairs or not pairs[0][0].is_cuda:
+            for a, b in pairs:
+                b.mul_(decay).add_(a, alpha=1 - decay)
+            return
+        from .. import _lib
+        from .. import kernels as K
+        key = tuple((a.data_ptr(), b.data_ptr()) for a, b in pairs)
+        tab = getattr(self, '_ema_tab', None)
+        if tab is None or tab['key'] != key:
+            chunk = _lib.load().tdr_optim_chunk()
+            ct, ci = [], []
+            for t, (a, _) in enumerate(pairs):
+                n = (a.numel() + chunk - 1) // chunk
+                ct += [t] * n
+                ci += list(range(n))
+            dev = pairs[0][0].device
+            tab = self._ema_tab = dict(
+                key=key, n=len(ct),
+                src=torch.tensor([k[0] for k in key], dtype=torch.int64).to(dev),
+                dst=torch.tensor([k[1] for k in key], dtype=torch.int64).to(dev),
+                sizes=torch.tensor([a.numel() for a, _ in pairs], dtype=torch.int64).to(dev),
+                ct=torch.tensor(ct, dtype=torch.int32).to(dev), ci=torch.tensor(ci, dtype=torch.int32).to(dev))
+        _lib.check(_lib.load().tdr_multi_ema(tab['src'].data_ptr(), tab['dst'].data_ptr(), tab['sizes'].data_ptr(),
+                                             tab['ct'].data_ptr(), tab['ci'].data_ptr(), tab['n'], float(decay), K._stream()),
+                   'tdr_multi_ema')
 
     def get_current_log(self):
         """floats, like the reference; the device->host read happens here (at print_freq), not in
@@ -59,12 +85,29 @@ class BaseModel:
         return out
 
     def model_to_device(self, net):
-        """to(device); in distributed mode a GradAllReducer (RCCL over xGMI) takes DDP's place."""
+        """to(device); in distributed mode a GradAllReducer (RCCL over xGMI) takes DDP's place -- including what the
+        DistributedDataParallel constructor does first (reference :76-82): every rank starts from rank 0's parameters
+        and buffers.  The trainer seeds rank r with manual_seed + r (main_train_restoration_with_ref_input.py:55), so
+        without the broadcast the replicas would start from different random weights."""
         net = net.to(self.device)
         if self.opt['dist']:
+            self.sync_from_rank0(net)
             self.grad_reducer = GradAllReducer(list(net.named_parameters()),
                                                bucket_mb=self.opt.get('dist_bucket_mb', 64))
         return net
+
+    def sync_from_rank0(self, net):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        from ..parallel import data_plane
+        comm = data_plane()
+        with torch.no_grad():
+            for t in list(self.get_bare_model(net).parameters()) + list(self.get_bare_model(net).buffers()):
+                if comm is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+                    comm.broadcast(t.data, root=0)
+                else:
+                    dist.broadcast(t.data, src=0)
 
     def setup_schedulers(self):
         train_opt = self.opt['train']
@@ -145,6 +188,8 @@ class BaseModel:
                     logger.warning(f'Size different, ignore [{k}]')
                     load_net[k + '.ignore'] = load_net.pop(k)
         net.load_state_dict(load_net, strict=strict)
+        if self.opt.get('dist'):
+            self.sync_from_rank0(net)      # a non-strict partial load leaves the unmatched tensors rank-specific
 
     @master_only
     def save_training_state(self, epoch, current_iter):

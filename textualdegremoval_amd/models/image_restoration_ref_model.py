@@ -82,13 +82,23 @@ class RefGuidedImageCleanModel(BaseModel):
                 self.optimizer_g = FusedClipAdamW(groups, lr=train_opt['optim_g']['lr'],
                                                   weight_decay=train_opt['optim_g']['weight_decay'],
                                                   betas=train_opt['optim_g']['betas'], max_norm=0.01, use_grad_clip=clip)
-            else:
+            else:       # host-only objects (scheduler tables, checkpoint plumbing); optimize_parameters refuses to run
                 self.optimizer_g = torch.optim.AdamW(groups, lr=train_opt['optim_g']['lr'],
                                                      weight_decay=train_opt['optim_g']['weight_decay'],
                                                      betas=train_opt['optim_g']['betas'])
         elif optim_type == 'Adam':
+            # reference :176-178 `torch.optim.Adam(groups, **train_opt['optim_g'])` (its YAMLs never select it): the same
+            # multi-tensor kernel with the L2 term in the gradient; keys other than lr/betas/eps/weight_decay are rejected
             kw = {k: v for k, v in train_opt['optim_g'].items() if k != 'ref_lr'}
-            self.optimizer_g = torch.optim.Adam(groups, **kw)
+            extra = set(kw) - {'lr', 'betas', 'eps', 'weight_decay'}
+            if extra:
+                raise NotImplementedError(f'Adam options {sorted(extra)} are not supported on the HIP optimiser')
+            if self.device.type == 'cuda':
+                self.optimizer_g = FusedClipAdamW(groups, lr=kw['lr'], weight_decay=kw.get('weight_decay', 0.0),
+                                                  betas=kw.get('betas', (0.9, 0.999)), eps=kw.get('eps', 1e-8), max_norm=0.01,
+                                                  use_grad_clip=clip, coupled_decay=True)
+            else:
+                self.optimizer_g = torch.optim.Adam(groups, **kw)
         else:
             raise NotImplementedError(f'optimizer {optim_type} is not supperted yet.')
         self.optimizers.append(self.optimizer_g)
@@ -116,13 +126,17 @@ class RefGuidedImageCleanModel(BaseModel):
         return ref_in
 
     def optimize_parameters(self, current_iter):
-        if self.param_fix_iters is not None and current_iter < self.param_fix_iters:
-            raise NotImplementedError('fix_iterations (frozen masa params) is not supported on the HIP path')
-        self.ref_in = self._match_reference_window()
         fused = self.device.type == 'cuda' and isinstance(self.cri_pix, loss_module.L1Loss) and \
-            self.cri_pix.reduction == 'mean'
+            self.cri_pix.reduction == 'mean' and isinstance(self.optimizer_g, FusedClipAdamW)
         if not fused:
-            raise NotImplementedError('HIP step needs a GPU and pixel_opt.type == L1Loss (the YAML default)')
+            raise NotImplementedError('HIP step needs a GPU, pixel_opt.type == L1Loss (the YAML default) and the fused optimiser')
+        # reference :205-212: while current_iter < fix_iterations the "masa" parameters get requires_grad_(False) -- and,
+        # as written there, nothing ever turns them back on (the `else` belongs to `param_fix_iters is not None`).  A
+        # frozen tensor has grad None: clip_grad_norm_ and AdamW (decay included) skip it.  Here: param group 1 frozen.
+        if self.param_fix_iters is not None and current_iter < self.param_fix_iters:
+            self._masa_frozen = True
+        self.optimizer_g.set_frozen_groups({1} if getattr(self, '_masa_frozen', False) else set())
+        self.ref_in = self._match_reference_window()
         if not hasattr(self, '_step_names'):
             net = self.get_bare_model(self.net_g)
             self._step_names = [k for k, _ in net.named_parameters()]
@@ -154,16 +168,21 @@ class RefGuidedImageCleanModel(BaseModel):
             lw = float(self.cri_pix.loss_weight)
             # exact (power-of-two) loss scale for the fp16-split data-gradient kernels: dpred = S*lw/numel ~ 2^9, which puts
             # max|g| of every gradient operand of the step between ~2^-1 and 2^10 (profiles/grad_range_survey.py)
+            # The scale lives in the optimiser's device-resident StepGuard: a non-finite gradient norm (an operand left the
+            # fp16 range) skips that step and halves it, 1000 finite steps double it again up to this starting value.
             gs = 1.0
             if K.MATH == 'hx2' and os.environ.get('TDR_GRAD_SCALE', '1') == '1' and lw > 0:
                 gs = 2.0 ** math.floor(math.log2(512.0 * lq.shape[0] * 3 * lq.shape[2] * lq.shape[3] / lw))
             K.set_grad_scaled(gs != 1.0)
-            self.grad_reducer.grad_unscale = 1.0 / gs
+            guard = self.optimizer_g.ensure_guard(lq.device)
+            if not torch.cuda.is_current_stream_capturing():
+                guard.set_max_scale(gs)        # (host read; the capture pass reuses the value of the eager warm-up steps)
+            self.grad_reducer.guard = guard
             self._pack_plan.run()              # all weights, all layouts, one launch (no-op on the recording step)
             eng = getattr(net, 'engine', E)    # RestormerRefFusion carries restormer_engine
             out, saved = eng.net_fwd(P, net.cfg, lq, ref_in)
             self.output = out
-            loss, dpred = K.l1_loss(out.contiguous(), gt.contiguous(), lw, grad_scale=gs)
+            loss, dpred = K.l1_loss(out.contiguous(), gt.contiguous(), lw, guard=guard)
             sink = self.grad_reducer.begin(defer_collectives=defer_collectives)
             eng.net_bwd(dpred, P, net.cfg, saved, G=sink)
             grads = self.grad_reducer.finish()
@@ -187,7 +206,8 @@ class RefGuidedImageCleanModel(BaseModel):
         replayed without host work; between them the flat gradient arena is all-reduced over RCCL when
         distributed.  Shapes are static per graph; the first two steps of a shape run eagerly (allocator /
         workspace / arena-layout warm-up)."""
-        key = (tuple(self.lq.shape), tuple(self.gt.shape), tuple(self.ref_in.shape), self.optimizer_g.use_grad_clip)
+        key = (tuple(self.lq.shape), tuple(self.gt.shape), tuple(self.ref_in.shape), self.optimizer_g.use_grad_clip,
+               tuple(sorted(self.optimizer_g.frozen_groups)))
         st = self._gstate
         if st is None or st['key'] != key:
             st = self._gstate = {'key': key, 'eager_left': 2, 'gA': None}
@@ -198,13 +218,14 @@ class RefGuidedImageCleanModel(BaseModel):
             st['lq'], st['gt'], st['ref'] = self.lq.clone(), self.gt.clone(), self.ref_in.clone()
             torch.cuda.synchronize()
             gA = torch.cuda.CUDAGraph()
+            st['ws_refs'] = []                 # scratch buffers the captured kernels address (kernels.workspace_capture)
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
-            with torch.cuda.graph(gA, capture_error_mode='thread_local'):
+            with torch.cuda.graph(gA, capture_error_mode='thread_local'), K.workspace_capture(st['ws_refs']):
                 st['loss'] = self._fwd_bwd(st['lq'], st['gt'], st['ref'], defer_collectives=True)
             st['pinned'] = self.grad_reducer.pinned_tables      # host blocks the captured table uploads re-read on replay
             self.optimizer_g.prepare()
             gB = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode='thread_local'):
+            with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode='thread_local'), K.workspace_capture(st['ws_refs']):
                 self.optimizer_g.launch()
             st['gA'], st['gB'] = gA, gB
             st['output'] = self.output
@@ -218,6 +239,22 @@ class RefGuidedImageCleanModel(BaseModel):
         st['gB'].replay()
         self.output = st['output']
         return st['loss']
+
+    skipped_steps = 0
+
+    def get_current_log(self):
+        """the base class's floats (a non-finite loss raises there); also the place where skipped optimiser steps become
+        visible to the host: the step guard lives in device memory and is only read here, at print_freq."""
+        out = super().get_current_log()
+        opt = getattr(self, 'optimizer_g', None)
+        if isinstance(opt, FusedClipAdamW) and opt.guard is not None:
+            g = opt.guard.read()
+            if g.skipped != self.skipped_steps:
+                logger.warning(f'{g.skipped - self.skipped_steps} optimiser step(s) skipped since the last log: non-finite '
+                               f'gradient norm (fp16-split backward pass out of range); loss scale now 2^{math.log2(g.scale):.0f}, '
+                               f'{g.step} steps applied.  TDR_MATH=bx3 runs the backward pass with the full fp32 range.')
+            self.skipped_steps = g.skipped
+        return out
 
     # ------------------------------------------------------------------ validation (reference :286-409)
     def pad_test(self, window_size):

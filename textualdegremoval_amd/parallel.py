@@ -23,6 +23,79 @@ def _align4(n):
     return (n + 3) // 4 * 4
 
 
+class TdrComm:
+    """The process's RCCL communicator behind the C ABI (include/tdr.h tdr_comm_*): the data plane of the
+    data-parallel step.  torch.distributed is only the side channel that carries rank 0's 128-byte unique id to the
+    other ranks (any backend); the collectives themselves are tdr_comm_allreduce / _reduce / _broadcast on fp32
+    device buffers, enqueued on a HIP stream of the caller's choice."""
+    _instance = None
+
+    def __init__(self, rank, world, unique_id):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
+        _lib.check(self._lib.tdr_comm_init(C.byref(h), int(rank), int(world), C.cast(buf, C.c_void_p)), 'tdr_comm_init')
+        self.handle, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def new_unique_id():
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        buf = C.create_string_buffer(lib.tdr_comm_unique_id_bytes())
+        _lib.check(lib.tdr_comm_unique_id(C.cast(buf, C.c_void_p)), 'tdr_comm_unique_id')
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        """one communicator per process, spanning the ranks of the (default) torch.distributed group"""
+        if cls._instance is None:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [cls.new_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            cls._instance = cls(rank, world, box[0])
+        return cls._instance
+
+    def _call(self, fn, name, t, arg, stream):
+        from . import _lib
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _lib.check(fn(self.handle, t.data_ptr(), t.numel(), int(arg), st), name)
+
+    def allreduce(self, t, average=True, stream=None):
+        self._call(self._lib.tdr_comm_allreduce, 'tdr_comm_allreduce', t, 1 if average else 0, stream)
+
+    def reduce(self, t, root=0, stream=None):
+        self._call(self._lib.tdr_comm_reduce, 'tdr_comm_reduce', t, root, stream)
+
+    def broadcast(self, t, root=0, stream=None):
+        self._call(self._lib.tdr_comm_broadcast, 'tdr_comm_broadcast', t, root, stream)
+
+    def destroy(self):
+        from . import _lib
+        if self.handle is not None:
+            _lib.check(self._lib.tdr_comm_destroy(self.handle), 'tdr_comm_destroy')
+            self.handle = None
+        if TdrComm._instance is self:
+            TdrComm._instance = None
+
+
+def data_plane(group=None):
+    """the TdrComm of this process when the job runs one rank per GPU over RCCL (torch backend 'nccl' or
+    TDR_COMM=rccl); None for single-process runs and for the gloo runs of the CPU / shared-GPU tests (TDR_COMM=torch
+    forces torch.distributed's own collectives)."""
+    if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()):
+        return None
+    mode = os.environ.get('TDR_COMM', 'auto')
+    if mode == 'torch' or (mode == 'auto' and dist.get_backend(group) != 'nccl'):
+        return None
+    if dist.get_world_size(group) == 1 and os.environ.get('TDR_FORCE_COLLECTIVES') != '1':
+        return None
+    return TdrComm.from_process_group(group)
+
+
 class GradSink(dict):
     """dict passed to engine.net_bwd as its gradient collector."""
 
@@ -43,6 +116,7 @@ class GradAllReducer:
         # single-rank process groups normally skip the collectives; TDR_FORCE_COLLECTIVES=1 issues them anyway (a 1-GPU box
         # then exercises the RCCL calls, the comm stream and their interplay with hipGraph capture -- tests/test_hip_dp_smoke.py)
         self.collective = self.world > 1 or (os.environ.get('TDR_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized())
+        self.comm = data_plane(process_group) if self.collective else None      # RCCL through the C ABI (tdr_comm_*)
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.order = None                                # arrival order (fixed after the first step)
         self.flat = None
@@ -98,6 +172,7 @@ class GradAllReducer:
 
     # ---- per step -----------------------------------------------------------
     grad_unscale = 1.0          # 1 / (power-of-two loss scale of the backward pass); applied while gathering
+    guard = None                # optim.StepGuard: the gather reads 1 / loss scale from device memory instead
 
     def begin(self, defer_collectives=False):
         """defer_collectives: do not launch per-bucket all-reduces while gradients arrive (hipGraph
@@ -115,7 +190,7 @@ class GradAllReducer:
     def _copy_in(self, key, g):
         dst = self.views[key]
         if g.is_cuda:
-            assert self.grad_unscale == 1.0, 'loss-scaled gradients go through the bucket gather'
+            assert self.grad_unscale == 1.0 and self.guard is None, 'loss-scaled gradients go through the bucket gather'
             K.copy_rows(g.contiguous(), 0, dst, 0, 1, g.numel())
         else:
             dst.copy_(g)                                  # CPU (gloo unit tests only)
@@ -127,7 +202,9 @@ class GradAllReducer:
         suit the point-to-point xGMI links); no-op on one rank."""
         if not self.collective or self.flat is None:
             return
-        if self.flat.is_cuda and dist.get_backend(self.pg) == 'nccl':
+        if self.comm is not None and self.flat.is_cuda:
+            self.comm.allreduce(self.flat, average=True)
+        elif self.flat.is_cuda and dist.get_backend(self.pg) == 'nccl':
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg)
         else:                                             # gloo (CPU unit tests, single-GPU multi-process smoke runs)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg)
@@ -152,7 +229,8 @@ class GradAllReducer:
         if not capturing:
             tb['done'][slot] = torch.cuda.Event()
             tb['done'][slot].record()
-        K.multi_copy(tb['src'], tb['dst'], tb['sizes'], tb['ct'], tb['ci'], tb['n_chunks'], scale=self.grad_unscale)
+        K.multi_copy(tb['src'], tb['dst'], tb['sizes'], tb['ct'], tb['ci'], tb['n_chunks'], scale=self.grad_unscale,
+                     guard=self.guard)
         self._keep = [self._pending.pop(k) for k in tb['names']]   # sources stay referenced until the next gather is enqueued
 
     def _launch(self, bi):
@@ -164,6 +242,9 @@ class GradAllReducer:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            if self.comm is not None:
+                self.comm.allreduce(buf, average=True, stream=self._comm_stream.cuda_stream)
+                return
             avg = dist.ReduceOp.AVG if dist.get_backend(self.pg) == 'nccl' else dist.ReduceOp.SUM
             with torch.cuda.stream(self._comm_stream):
                 self._works.append(dist.all_reduce(buf, op=avg, group=self.pg, async_op=True))
@@ -218,7 +299,12 @@ class GradAllReducer:
 def reduce_loss_to_rank0(loss_tensor, world, rank, group=None):
     """C2 of SURVEY 2.2: dist.reduce to rank 0, then / world on rank 0 (base_model.py:361-372)."""
     if world > 1:
-        dist.reduce(loss_tensor, dst=0, group=group)
+        comm = data_plane(group) if loss_tensor.is_cuda else None
+        if comm is not None:
+            loss_tensor = loss_tensor.contiguous()
+            comm.reduce(loss_tensor, root=0)
+        else:
+            dist.reduce(loss_tensor, dst=0, group=group)
         if rank == 0:
             loss_tensor = loss_tensor / world
     return loss_tensor

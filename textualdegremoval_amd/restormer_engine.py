@@ -192,20 +192,10 @@ def net_fwd(P, cfg, inp, ref):
     """inp, ref [N,3,H,W] -> (out [N,3,H,W], saved).  cfg: constructor kwargs of RestormerRefFusion."""
     if cfg.get('dual_pixel_task'):
         raise NotImplementedError('HIP path: dual_pixel_task=False (no reference YAML enables it)')
-    N, Ci, H0, W0 = inp.shape
-    mult = (2 ** PADDER_LOG2) * cfg['lr_block_size']
-    Hp, Wp = -(-H0 // mult) * mult, -(-W0 // mult) * mult
-    Hr0, Wr0 = ref.shape[-2:]
-    if (-(-Hr0 // mult) * mult, -(-Wr0 // mult) * mult) != (Hp, Wp):
-        raise NotImplementedError('ref and lq must pad to the same size on the fused path '
-                                  '(the DINO window match makes them equal, image_restoration_ref_model.py:219-243)')
-    both = torch.empty(2 * N, Ci, Hp, Wp, dtype=torch.float32, device=inp.device)
-    E._pad_into(inp.contiguous(), both[:N])
-    E._pad_into(ref.contiguous(), both[N:])
-    inp_p = both[:N]
-    geo = E.MasaGeom(Hp, Wp, Hp, Wp, PADDER_LOG2, cfg['lr_block_size'], cfg['ref_down_block_size'], cfg['dilations'])
-    feats, sv_enc = E.encoder_fwd(both, P, 'masa_enc.', cfg['ext_n_blocks'], levels=4)
-    warp, sv_masa = E.masa_fwd(feats, N, geo)
+    N = inp.shape[0]
+    pyr, (H0, W0, Hp, Wp) = E.pyramids_fwd(P, cfg, inp, ref, PADDER_LOG2, 4)
+    inp_p, geo = pyr.inp_p, pyr.geo
+    warp, sv_masa = E.masa_fwd(pyr.lq_deep, pyr.ref_feats, N, geo)
     hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
 
     x = E.conv_fwd(inp_p, P['patch_embed.proj.weight'], P.get('patch_embed.proj.bias'), 1, 1)
@@ -229,7 +219,7 @@ def net_fwd(P, cfg, inp, ref):
     rf, sv_rf = seq_fwd(d1, P, 'refinement.', cfg['num_refinement_blocks'], hd[0], ln)
     out_p = E.conv_fwd(rf, P['output.weight'], P.get('output.bias'), 1, 1, res=inp_p)
     out = out_p if (Hp, Wp) == (H0, W0) else K.pad_crop(out_p, H0, W0)
-    saved = (N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2,
+    saved = (N, (H0, W0, Hp, Wp), geo, pyr, None, None, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2,
              sv_d1, rf, sv_rf)
     return out, saved
 
@@ -240,12 +230,12 @@ def net_bwd(dout, P, cfg, saved, G=None):
 
 
 def _net_bwd(dout, P, cfg, saved, G):
-    (N, (H0, W0, Hp, Wp), geo, both, feats, sv_enc, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, rf,
+    (N, (H0, W0, Hp, Wp), geo, pyr, _, _, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, rf,
      sv_rf) = saved
     G = {} if G is None else G
     hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
     e1, e2, e3, lat = enc_out
-    inp_p = both[:N]
+    inp_p = pyr.inp_p
     dout = dout.contiguous()
     if (Hp, Wp) != (H0, W0):
         dout = K.pad_crop(dout, Hp, Wp)
@@ -285,6 +275,5 @@ def _net_bwd(dout, P, cfg, saved, G):
                                                              bias=has_pb)
             if has_pb:
                 G['patch_embed.proj.bias'] = db
-    dfeats = E.masa_bwd(dwarp, feats, N, geo, sv_masa)
-    E.encoder_bwd(dfeats, P, 'masa_enc.', cfg['ext_n_blocks'], sv_enc, G)
+    E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
     return G
