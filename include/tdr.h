@@ -375,6 +375,66 @@ int tdr_adamw_step_dev(float* const* params, const float* const* grads, float* c
                        const double* sumsq, const float* hp, float max_norm, int use_clip, float beta1, float beta2,
                        float eps, float weight_decay, void* stream);
 /* ---------------------------------------------------------------------------
+ * Fused second half of a NAFBlock (network_nafnet_guided_arch.py:226-238), one launch instead of four:
+ *   y = x + conv3(g * sca) * beta;  yn = norm2(y);  t4 = conv4(yn);  out = y + conv5(t4[:, :C] * t4[:, C:]) * gamma
+ * One workgroup owns 64 pixels x all channels; every tensor the backward pass keeps (y, mu, rs, yn, t4) is an output.
+ * w3/w4/w5: tdr_pack_weights_hx2(mode FWD) of conv3 (C x C), conv4 (2C x C), conv5 (C x C); w_fmt must be 2.
+ * Supported: tdr_naf_tail_supported(C, HW) (C == 256, HW % 64 == 0 -- the 64x64 level of BASELINE configs[1]). */
+typedef struct TdrNafTailDesc {
+    int N, C, HW, w_fmt;
+    float eps;
+    const float* g;   int64_t g_ns;          /* [N, C, HW] SimpleGate output of the first half */
+    const float* sca;                        /* [N, C] channel attention */
+    const float* x;   int64_t x_ns;          /* block input (residual) */
+    const void *w3, *w4, *w5;
+    const float *b3, *beta, *lnw, *lnb, *b4, *b5, *gamma;
+    float* y;   int64_t y_ns;
+    float *mu, *rs;                          /* [N, HW] LayerNorm statistics of y */
+    float* yn;  int64_t yn_ns;
+    float* t4;  int64_t t4_ns;               /* [N, 2C, HW] */
+    float* out; int64_t out_ns;
+} TdrNafTailDesc;
+int tdr_naf_tail_supported(int C, int HW);
+int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream);
+/* Data-gradient chain of the same half (autograd of :230-238), one launch instead of three:
+ *   dt4 = SimpleGate'(W5^T (dout * gamma); t4);  dyn = W4^T dt4;  dy = LayerNorm2d'(dyn; y, mu, rs, lnw) + dout
+ * plus the LayerNorm parameter gradients gw = sum dyn * yhat, gb = sum dyn (per-workgroup partials in ws, reduced in a
+ * fixed order).  dt4 is an output because conv4's weight gradient (tdr_conv_wgrad) reads it.
+ * w5t / w4t: tdr_pack_weights_hx2(mode DGRAD_S1) of conv5 / conv4.  ws: tdr_naf_tail_bwd_ws_floats(N, C, HW) floats. */
+typedef struct TdrNafTailBwdDesc {
+    int N, C, HW, w_fmt;
+    const float* dout; int64_t dout_ns;
+    const float* gamma;
+    const float* t4;   int64_t t4_ns;
+    const float* y;    int64_t y_ns;
+    const float *mu, *rs, *lnw;
+    const void *w5t, *w4t;
+    float* dt4; int64_t dt4_ns;
+    float* dy;  int64_t dy_ns;
+    float *gw, *gb;
+    float* ws;
+} TdrNafTailBwdDesc;
+int64_t tdr_naf_tail_bwd_ws_floats(int N, int C, int HW);
+int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream);
+/* The first half's data gradients (autograd of :216-225 from conv1 back), one launch instead of two:
+ *   dxn = W1^T dt1;  dx = LayerNorm2d'(dxn; x, mu, rs, lnw) + res        (res = gradient of the `inp + ...` skip)
+ * plus norm1's parameter gradients.  w1t: tdr_pack_weights_hx2(mode DGRAD_S1) of conv1 (2C x C).  Same support / ws. */
+typedef struct TdrNafHeadBwdDesc {
+    int N, C, HW, w_fmt;
+    const float* dt1; int64_t dt1_ns;        /* [N, 2C, HW] gradient of conv1's output */
+    const float* x;   int64_t x_ns;          /* block input */
+    const float *mu, *rs, *lnw;
+    const void* w1t;
+    const float* res; int64_t res_ns;
+    float* dx; int64_t dx_ns;
+    float *gw, *gb;
+    float* ws;
+} TdrNafHeadBwdDesc;
+int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream);
+/* part [nparts][2][C] -> o0[c] = sum_k part[k][0][c], o1[c] = sum_k part[k][1][c], fixed summation order */
+int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float* o1, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Data-parallel exchange over RCCL / xGMI: replaces DistributedDataParallel's gradient all-reduce and
  * constructor broadcast (models/base_model.py:76-82) and reduce_loss_dict's dist.reduce (:361-372), i.e. what the
  * reference reaches through torch.distributed.launch + utils/utils_dist.py:10-83.  One process per GPU; the

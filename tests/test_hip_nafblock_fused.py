@@ -1,0 +1,79 @@
+"""The fused NAFBlock kernels of the 64x64 level (csrc/tdr_nafblock.hip, c = 256) against the CPU oracle's naf_block
+(reference network_nafnet_guided_arch.py:216-238) and against the per-op launch sequence they replace: forward outputs,
+every tensor saved for the backward pass, and the whole block's gradients."""
+import pytest
+import torch
+
+from oracle import nafnet_ref_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def block_params(c, seed):
+    shapes = {'beta': (1, c, 1, 1), 'gamma': (1, c, 1, 1), 'conv1.weight': (2 * c, c, 1, 1), 'conv1.bias': (2 * c,),
+              'conv2.weight': (2 * c, 1, 3, 3), 'conv2.bias': (2 * c,), 'conv3.weight': (c, c, 1, 1), 'conv3.bias': (c,),
+              'sca.1.weight': (c, c, 1, 1), 'sca.1.bias': (c,), 'conv4.weight': (2 * c, c, 1, 1), 'conv4.bias': (2 * c,),
+              'conv5.weight': (c, c, 1, 1), 'conv5.bias': (c,), 'norm1.weight': (c,), 'norm1.bias': (c,),
+              'norm2.weight': (c,), 'norm2.bias': (c,)}
+    P = {}
+    for i, (k, s) in enumerate(shapes.items()):
+        if k.endswith('weight') and len(s) == 4:
+            fan = s[1] * s[2] * s[3]
+            P[k] = rnd(*s, seed=seed + i, scale=fan ** -0.5)
+        elif k.startswith('norm') and k.endswith('weight'):
+            P[k] = 1.0 + rnd(*s, seed=seed + i, scale=0.1)
+        else:
+            P[k] = rnd(*s, seed=seed + i, scale=0.3)
+    return P
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 16, 16), (1, 8, 24), (4, 64, 64)])
+def test_fused_tail_matches_oracle_and_unfused(N, H, W):
+    from textualdegremoval_amd import engine as E, kernels as K
+    if K.MATH != 'hx2':
+        pytest.skip('fused blocks run on the fp16-split path')
+    c = 256
+    P = block_params(c, seed=11)
+    Pc = {k: v.cuda() for k, v in P.items()}
+    x = rnd(N, c, H, W, seed=5)
+    assert K.naf_tail_supported(c, H * W)
+    outs = {}
+    for fuse in (True, False):
+        prev, E.FUSE_TAIL = E.FUSE_TAIL, fuse
+        # the fused backward chain runs on the fp16-split data-gradient weights of a loss-scaled backward pass
+        # (kernels.GRAD_SCALED); dout is O(1) here, i.e. already inside the fp16 window
+        prev_scaled = K.set_grad_scaled(True)
+        try:
+            out, saved = E.naf_fwd(x.cuda(), Pc)
+            dout = rnd(N, c, H, W, seed=6).cuda()
+            dx, G = E.naf_bwd(dout, Pc, saved)
+            torch.cuda.synchronize()
+            outs[fuse] = (out.cpu(), [t.cpu() if torch.is_tensor(t) else t for t in saved], dx.cpu(), {k: v.cpu() for k, v in G.items()})
+        finally:
+            E.FUSE_TAIL = prev
+            K.set_grad_scaled(prev_scaled)
+    # oracle (torch fp32 on the CPU, autograd)
+    Pr = {('b.' + k): v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    ro = O.naf_block(xr, Pr, 'b.')
+    ro.backward(rnd(N, c, H, W, seed=6))
+    fo, fs, fdx, fG = outs[True]
+    uo, us, udx, uG = outs[False]
+    scale = ro.abs().max().item()
+    assert (fo - ro.detach()).abs().max().item() < 2e-5 * max(1.0, scale)
+    assert (fo - uo).abs().max().item() < 2e-5 * max(1.0, scale)
+    names = ['x', 'xn', 'mu1', 'rs1', 't1', 'g', 'pooled', 's', 'y', 'yn', 'mu2', 'rs2', 't4']
+    for name, a, b in zip(names, fs, us):
+        tol = 3e-5 * max(1.0, b.abs().max().item())
+        assert a.shape == b.shape and (a - b).abs().max().item() < tol, name
+    print('dx: fused-oracle', (fdx - xr.grad).abs().max().item(), 'unfused-oracle', (udx - xr.grad).abs().max().item(),
+          'fused-unfused', (fdx - udx).abs().max().item(), 'max', udx.abs().max().item())
+    assert (fdx - udx).abs().max().item() < 1e-4 * udx.abs().max().item()
+    assert (fdx - xr.grad).abs().max().item() < 5e-4 * xr.grad.abs().max().item()
+    for k in P:
+        ref = Pr['b.' + k].grad
+        assert (fG[k].view_as(ref) - ref).abs().max().item() < 2e-3 * max(ref.abs().max().item(), 1e-6), k

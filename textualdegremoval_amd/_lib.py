@@ -63,6 +63,28 @@ class TdrWgradDesc(C.Structure):
     ]
 
 
+class TdrNafTailDesc(C.Structure):
+    _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32), ('eps', f32),
+                ('g', c_fp), ('g_ns', i64), ('sca', c_fp), ('x', c_fp), ('x_ns', i64),
+                ('w3', c_fp), ('w4', c_fp), ('w5', c_fp),
+                ('b3', c_fp), ('beta', c_fp), ('lnw', c_fp), ('lnb', c_fp), ('b4', c_fp), ('b5', c_fp), ('gamma', c_fp),
+                ('y', c_fp), ('y_ns', i64), ('mu', c_fp), ('rs', c_fp), ('yn', c_fp), ('yn_ns', i64),
+                ('t4', c_fp), ('t4_ns', i64), ('out', c_fp), ('out_ns', i64)]
+
+
+class TdrNafTailBwdDesc(C.Structure):
+    _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32),
+                ('dout', c_fp), ('dout_ns', i64), ('gamma', c_fp), ('t4', c_fp), ('t4_ns', i64), ('y', c_fp), ('y_ns', i64),
+                ('mu', c_fp), ('rs', c_fp), ('lnw', c_fp), ('w5t', c_fp), ('w4t', c_fp),
+                ('dt4', c_fp), ('dt4_ns', i64), ('dy', c_fp), ('dy_ns', i64), ('gw', c_fp), ('gb', c_fp), ('ws', c_fp)]
+
+
+class TdrNafHeadBwdDesc(C.Structure):
+    _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32),
+                ('dt1', c_fp), ('dt1_ns', i64), ('x', c_fp), ('x_ns', i64), ('mu', c_fp), ('rs', c_fp), ('lnw', c_fp),
+                ('w1t', c_fp), ('res', c_fp), ('res_ns', i64), ('dx', c_fp), ('dx_ns', i64), ('gw', c_fp), ('gb', c_fp), ('ws', c_fp)]
+
+
 class TdrStepGuard(C.Structure):
     _fields_ = [('scale', f32), ('inv_scale', f32), ('max_scale', f32), ('good', i32), ('growth_interval', i32),
                 ('step', i32), ('skipped', i32), ('finite', i32), ('bc1', f32), ('bc2_sqrt', f32)]
@@ -148,6 +170,12 @@ SIGNATURES = {
     'tdr_grad_sumsq': (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp]),
     'tdr_adamw_step': (i32, [c_fp] * 8 + [i32, c_fp, C.POINTER(f32), i32, f32, i32, f32, f32, f32, f32, i32, c_fp]),
     'tdr_adamw_step_dev': (i32, [c_fp] * 8 + [i32, c_fp, c_fp, f32, i32, f32, f32, f32, f32, c_fp]),
+    'tdr_naf_tail_supported': (i32, [i32, i32]),
+    'tdr_naf_tail_fwd': (i32, [C.POINTER(TdrNafTailDesc), c_fp]),
+    'tdr_naf_tail_bwd_ws_floats': (i64, [i32, i32, i32]),
+    'tdr_naf_tail_bwd': (i32, [C.POINTER(TdrNafTailBwdDesc), c_fp]),
+    'tdr_naf_head_bwd': (i32, [C.POINTER(TdrNafHeadBwdDesc), c_fp]),
+    'tdr_pair_sum_partials': (i32, [c_fp, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_comm_unique_id_bytes': (i32, []),
     'tdr_comm_unique_id': (i32, [c_fp]),
     'tdr_comm_init': (i32, [C.POINTER(c_fp), i32, i32, c_fp]),

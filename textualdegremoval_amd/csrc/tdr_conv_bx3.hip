@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                 if (GATE) v *= rin2[set][it][i];
                 v *= rks[set][i];
                 v = (ok && cbase + i < a.Cin) ? v : 0.f;
+                // pin the (gated / scaled) operand in a VGPR: the splits below must all start from the SAME fp32 value -- left
+                // free, the compiler may round the head from the exact product and the residual from the rounded one, and at
+                // an fp16 / bf16 tie the pair is then off by a whole ulp of the head (tdr_nafblock.hip, split_hm)
+                asm volatile("" : "+v"(v));
                 if constexpr (SCH == SCH_HX2) {
                     const _Float16 hh = (_Float16)v;
                     h.hv[i] = hh;
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
                     v *= px == 0 ? g4.x : (px == 1 ? g4.y : (px == 2 ? g4.z : g4.w));
                 }
                 v *= rks[set][i];
+                asm volatile("" : "+v"(v));        // one fp32 value for head and residual (see conv_bx3_kernel)
                 const _Float16 hh = (_Float16)v;
                 h.hv[i] = hh;
                 m.hv[i] = (_Float16)(v - (float)hh);

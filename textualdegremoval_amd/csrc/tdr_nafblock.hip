@@ -1,0 +1,685 @@
+// Fused second half of a NAFBlock for the deep U-Net level (c = 256 at 64x64: 28 of the 46 blocks of BASELINE
+// configs[1]) -- reference models/archs/network_nafnet_guided_arch.py:226-238:
+//
+//     y   = inp + conv3(g * sca) * beta                 (g = SimpleGate(conv2(conv1(norm1(inp)))), sca per image/channel)
+//     yn  = norm2(y)                                    (LayerNorm2d over channels, nafnet_arch_utils.py:264-300)
+//     t4  = conv4(yn)
+//     out = y + conv5(t4[:, :c] * t4[:, c:]) * gamma
+//
+// Everything here is per pixel, so one workgroup owns 64 pixels x ALL channels and walks the chain without leaving
+// the CU: three back-to-back implicit GEMMs on the 2-way fp16 split (3 x v_mfma_f32_32x32x16_f16 per fp32 product,
+// fp32 accumulate -- same arithmetic and packed weights as conv1x1_hx2_kernel), LayerNorm as a cross-wave reduction
+// through LDS, the SimpleGate product register-local (wave w owns channels [64w, 64w+64) and [256+64w, 256+64w+64) of
+// t4).  The four separate launches (conv3, norm2, conv4, conv5) move 201 MB per block at this level and are single-round,
+// latency-bound kernels (26.8 + 13.2 + 36.9 + 26.2 us); fused, the tile is read once (g, inp) and every tensor the
+// backward pass keeps (y, mu, rstd, yn, t4) is written once on the way: 118 MB, one launch, no phase of one kernel
+// waiting for the tail of the previous one.
+//
+// Layout notes (all as in tdr_conv_bx3.hip): A = packed weight fragments [group][mt][split][lane] read L2 -> VGPR with
+// a ring of PF groups in flight; B = activations in LDS as [split][octet][pixel] 16-byte slots (8 channels x f16), XOR
+// swizzled; accumulators in the gfx950 32x32 C/D layout (lane (j, kk): pixel j, rows (r&3) + 8(r>>2) + 4kk).
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+union HFrag {
+    uint4 u;
+    f16x8 hv;
+};
+
+#ifndef NB_PROBE
+#define NB_PROBE 0          // profiling builds only (profiles/probe_nafblock.py): 1 no side stores, 2 no MFMAs, 3 both
+#endif
+#if NB_PROBE & 8
+// timeline probe (profiling builds only): wave 0 and wave 5 of two workgroups stamp the cycle counter at the phase boundaries
+__device__ unsigned long long nb_ts[4][16];
+#define NB_STAMP(k) do { if (nb_slot >= 0 && lane == 0) nb_ts[nb_slot][k] = __builtin_readcyclecounter(); } while (0)
+extern "C" int tdr_nb_probe_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nb_ts), sizeof(nb_ts)); }
+#else
+#define NB_STAMP(k) do { } while (0)
+#endif
+constexpr int NPX = 64;                       // pixels per workgroup
+__device__ __forceinline__ int swz(int slot) { return slot ^ ((slot >> 4) & 3); }
+__device__ __forceinline__ int row_of(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
+
+// x -> (h, m), h = rn_f16(x), m = rn_f16(x - h).  The value is pinned in a VGPR first: when x is a product a * b the
+// compiler is otherwise free to form h from the exact product (v_fma_mixlo_f16) and the residual from the rounded one (or
+// the other way round) -- at an fp16 tie of the rounded product the two disagree about the neighbour and h + m is off by a
+// whole ulp of h (measured: 1e-4 outliers in the conv4 data gradient).
+__device__ __forceinline__ void split_hm(float x, _Float16& h, _Float16& m) {
+    asm volatile("" : "+v"(x));
+    h = (_Float16)x;
+    m = (_Float16)(x - (float)h);
+}
+
+// acc[tm][tn] += W[mt_of(tm)] (K = 16 * NG channels) x B(LDS planes).  PF groups of A fragments in flight.
+// side(g) is called once per 16-channel group, between the MFMAs: the caller's global stores of the PREVIOUS phase's
+// tiles ride there, a few per group, so the store stream drains under the matrix work instead of in front of it.
+template <int TMW, int NG, int PF, typename MtOf, typename Side>
+__device__ __forceinline__ void gemm_hx2(f32x16 (&acc)[TMW][2], const uint4* __restrict__ wp, int MT, MtOf mt_of, const uint4* sB,
+                                         int noct, int lane, int rot, Side side) {
+    // rot: every workgroup walks the K groups from a different starting group.  All workgroups of the launch stream the
+    // SAME weight fragments; started together they would ask the same few L2 lines at the same moment.
+    static_assert((NG & (NG - 1)) == 0, "NG must be a power of two");
+    const int j = lane & 31, kk = lane >> 5;
+    const uint4* wl = wp + lane;
+    HFrag af[PF][TMW][2];
+    auto load_a = [&](int slot, int g) {
+        const int gr = (g + rot) & (NG - 1);
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) af[slot][tm][s].u = wl[((long)gr * MT + mt_of(tm)) * 128 + s * 64];
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_a(p, p < NG ? p : NG - 1);
+    const int b0 = swz(j), b1 = swz(32 + j);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        HFrag bf[2][2];
+        const uint4* sg = sB + (2 * ((g + rot) & (NG - 1)) + kk) * NPX;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf[0][s].u = sg[s * noct * NPX + b0];
+            bf[1][s].u = sg[s * noct * NPX + b1];
+        }
+        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};       // m*h, h*m, h*h
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#if NB_PROBE & 2
+                    { if (q == 0) asm volatile("" ::"v"(__builtin_bit_cast(f32x4, af[g % PF][tm][0].u)), "v"(__builtin_bit_cast(f32x4, af[g % PF][tm][1].u)), "v"(__builtin_bit_cast(f32x4, bf[tn][0].u)), "v"(__builtin_bit_cast(f32x4, bf[tn][1].u))); }
+#else
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g % PF][tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
+#endif
+#if !(NB_PROBE & 16)
+        if (g + PF < NG) load_a(g % PF, g + PF);
+#endif
+#if !(NB_PROBE & 1)
+        side(g);
+#endif
+    }
+}
+
+// fp32 values of one accumulator tile (channel rows of octet-halves) -> the two f16 planes of the LDS B operand
+__device__ __forceinline__ void tile_to_planes(const float (&v)[16], uint4* sB, int noct, int oct0, int pix, int kk) {
+    // rows r = 4q..4q+3 are elements 4kk..4kk+3 of octet oct0 + q
+    char* base = reinterpret_cast<char*>(sB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f16x4 h, m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 hh, mm;
+            split_hm(v[4 * q + e], hh, mm);
+            h[e] = hh;
+            m[e] = mm;
+        }
+        const long slot = (long)(oct0 + q) * NPX + swz(pix);
+        *reinterpret_cast<f16x4*>(base + slot * 16 + 8 * kk) = h;
+        *reinterpret_cast<f16x4*>(base + ((long)noct * NPX + slot) * 16 + 8 * kk) = m;
+    }
+}
+
+struct TailArgs {
+    const float* g; long g_ns;
+    const float* sca;                 // [N][C]
+    const float* x; long x_ns;
+    const uint4 *w3, *w4, *w5;        // packed hx2 fragments (PACK_FWD): M = C, 2C, C; K = C
+    const float *b3, *beta, *lnw, *lnb, *b4, *b5, *gamma;
+    float eps;
+    float* y; long y_ns;
+    float *mu, *rs;                   // [N][HW]
+    float* yn; long yn_ns;
+    float* t4; long t4_ns;
+    float* out; long out_ns;
+    int HW;
+};
+
+// 512 threads = 8 waves, two per SIMD: wave w owns the 32 channels [32w, 32w + 32) of the C-row GEMMs and, in conv4,
+// also their SimpleGate partners [C + 32w, C + 32w + 32).  While one wave of a SIMD waits on LDS / L2 / the store
+// queue its partner's MFMAs run.
+template <int C>
+__global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
+    static_assert(C == 256, "8 waves x 32 channel rows: C = 256");
+    constexpr int NOCT = C / 8;               // octets of the K = C operands
+    constexpr int NG = C / 16;
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+    uint4* sB = smem4;                                        // 2 planes x NOCT x 64 px x 16 B = 64 KiB
+    float* red = reinterpret_cast<float*>(smem4 + 2 * NOCT * NPX);   // [2][8 waves][64 px]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kk = lane >> 5;
+    const int n = blockIdx.y;
+    const long p0 = (long)blockIdx.x * NPX;
+    const long HW = a.HW;
+    const int m0 = 32 * wave;                                 // first channel row of this wave
+#ifdef NB_NOROT
+    const int rot = 0;
+#else
+    const int rot = (int)(blockIdx.x * 5);   // (not a function of the image index: batch-permutation equivariance stays bit-exact)
+#endif
+    // row r of this lane: channel m0 + row_of(r, kk); element offset of (row r, pixel j of sub-tile tn) in an [*, HW] image
+    auto off = [&](int r, int tn) { return (long)(m0 + row_of(r, kk)) * HW + 32 * tn; };
+#if NB_PROBE & 8
+    const int nb_slot = ((blockIdx.x == 0 && blockIdx.y == 0) ? 0 : ((blockIdx.x == 37 && blockIdx.y == 2) ? 2 : -100)) + (wave == 0 ? 0 : (wave == 5 ? 1 : -100));
+#endif
+    NB_STAMP(0);
+
+    // ---- residual tile (inp) in accumulator layout: requested first, consumed after the first GEMM
+    float xr[2][16];
+    {
+        const float* xp = a.x + (long)n * a.x_ns + p0 + j;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xr[tn][r] = xp[off(r, tn)];
+    }
+    // ---- stage B = g * sca as f16 planes: thread (oct, q) owns pixels 4q..4q+3 of octet oct
+    {
+        const int q = tid & 15, oct = tid >> 4;
+        const float* gp = a.g + (long)n * a.g_ns + p0 + 4 * q;
+        const float* sp = a.sca + (long)n * C;
+        float4 v[8];
+        float sc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = *reinterpret_cast<const float4*>(gp + (long)(8 * oct + i) * HW);
+            sc[i] = sp[8 * oct + i];
+        }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            HFrag h, m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                _Float16 hh, mm;
+                split_hm((px == 0 ? v[i].x : (px == 1 ? v[i].y : (px == 2 ? v[i].z : v[i].w))) * sc[i], hh, mm);
+                h.hv[i] = hh;
+                m.hv[i] = mm;
+            }
+            const int slot = oct * NPX + swz(4 * q + px);
+            sB[slot] = h.u;
+            sB[NOCT * NPX + slot] = m.u;
+        }
+    }
+    // per-row vectors of this lane's 16 channel rows
+    float b3v[16], bev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        b3v[r] = a.b3[m0 + row_of(r, kk)];
+        bev[r] = a.beta[m0 + row_of(r, kk)];
+    }
+    __syncthreads();
+    NB_STAMP(1);
+
+    // ---- conv3: y = (W3 (g*sca) + b3) * beta + inp
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
+    gemm_hx2<1, NG, 4>(acc, a.w3, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [](int) {});
+
+    NB_STAMP(2);
+    float yv[2][16];
+    float psum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (acc[0][tn][r] + b3v[r]) * bev[r] + xr[tn][r];
+            yv[tn][r] = v;
+            psum[tn] += v;
+        }
+    // ---- norm2: mean, then centred second moment (two passes over the register tile)
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        psum[tn] += __shfl_xor(psum[tn], 32, 64);
+        if (kk == 0) red[wave * NPX + 32 * tn + j] = psum[tn];
+    }
+    __syncthreads();                                          // (all waves are past their conv3 reads of sB here)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const float* rp = red + 32 * tn + j;
+        mean[tn] = (((rp[0] + rp[NPX]) + (rp[2 * NPX] + rp[3 * NPX])) + ((rp[4 * NPX] + rp[5 * NPX]) + (rp[6 * NPX] + rp[7 * NPX]))) * (1.f / C);
+    }
+    float pvar[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = yv[tn][r] - mean[tn];
+            pvar[tn] += d * d;
+        }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        pvar[tn] += __shfl_xor(pvar[tn], 32, 64);
+        if (kk == 0) red[(NW + wave) * NPX + 32 * tn + j] = pvar[tn];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const float* rp = red + NW * NPX + 32 * tn + j;
+        const float var = (((rp[0] + rp[NPX]) + (rp[2 * NPX] + rp[3 * NPX])) + ((rp[4 * NPX] + rp[5 * NPX]) + (rp[6 * NPX] + rp[7 * NPX]))) * (1.f / C);
+        rstd[tn] = 1.f / sqrtf(var + a.eps);
+        if (wave == 0 && kk == 0) {
+            a.mu[(long)n * HW + p0 + 32 * tn + j] = mean[tn];
+            a.rs[(long)n * HW + p0 + 32 * tn + j] = rstd[tn];
+        }
+    }
+    // yn = (y - mu) * rstd * w + b : split into the LDS operand now; y and yn leave for HBM under conv4's MFMAs
+    float ynv[2][16];
+    {
+        float lw[16], lb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            lw[r] = a.lnw[m0 + row_of(r, kk)];
+            lb[r] = a.lnb[m0 + row_of(r, kk)];
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ynv[tn][r] = (yv[tn][r] - mean[tn]) * rstd[tn] * lw[r] + lb[r];
+            tile_to_planes(ynv[tn], sB, NOCT, 4 * wave, 32 * tn + j, kk);
+        }
+    }
+    __syncthreads();
+    NB_STAMP(3);
+
+    // ---- conv4: t4 = W4 yn + b4 ; rows [32w, 32w+32) and their gate partners [C + 32w, C + 32w + 32)
+    f32x16 acc4[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc4[tm][tn][r] = 0.f;
+    {
+        float* yp = a.y + (long)n * a.y_ns + p0 + j;
+        float* ynp = a.yn + (long)n * a.yn_ns + p0 + j;
+        gemm_hx2<2, NG, 3>(acc4, a.w4, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
+            // 64 dword stores (y, yn: 2 sub-tiles x 16 rows each) spread over the 16 groups: 4 per group
+            const int tn = g >> 3, r0 = 2 * (g & 7);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                yp[off(r0 + e, tn)] = yv[tn][r0 + e];
+                ynp[off(r0 + e, tn)] = ynv[tn][r0 + e];
+            }
+        });
+    }
+    NB_STAMP(4);
+    float b4v[2][16];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b4v[tm][r] = a.b4[tm * C + m0 + row_of(r, kk)];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc4[tm][tn][r] += b4v[tm][r];
+    __syncthreads();                                          // every wave has finished reading the yn planes
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc4[0][tn][r] * acc4[1][tn][r];      // SimpleGate (:170-175)
+        tile_to_planes(v, sB, NOCT, 4 * wave, 32 * tn + j, kk);
+    }
+    float b5v[16], gav[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        b5v[r] = a.b5[m0 + row_of(r, kk)];
+        gav[r] = a.gamma[m0 + row_of(r, kk)];
+    }
+    __syncthreads();
+    NB_STAMP(5);
+
+    // ---- conv5: out = (W5 gate + b5) * gamma + y ; the t4 tile leaves for HBM under its MFMAs
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
+    {
+        float* tp = a.t4 + (long)n * a.t4_ns + p0 + j;
+        gemm_hx2<1, NG, 4>(acc, a.w5, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
+            const int tm = g >> 3, tn = (g >> 2) & 1, r0 = 4 * (g & 3);          // 64 stores: 4 per group
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tp[(long)tm * C * HW + off(r0 + e, tn)] = acc4[tm][tn][r0 + e];
+        });
+    }
+    NB_STAMP(6);
+    {
+        float* op = a.out + (long)n * a.out_ns + p0 + j;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) op[off(r, tn)] = (acc[0][tn][r] + b5v[r]) * gav[r] + yv[tn][r];
+    }
+    NB_STAMP(7);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the same chain, data gradients only (the weight gradients stay on tdr_conv_wgrad, which reads the dt4
+// this kernel writes):
+//     dg2 = W5^T (dout * gamma)                          conv5 data gradient
+//     dt4 = [dg2 * t4[C:], dg2 * t4[:C]]                 SimpleGate backward (:170-175)
+//     dyn = W4^T dt4                                     conv4 data gradient
+//     dy  = LayerNorm2d backward(dyn; y, mu, rstd, w) + dout           (nafnet_arch_utils.py:283-300, + the y + x*gamma skip)
+//     per-workgroup partial sums of the LayerNorm parameter gradients (gw = sum dyn * yhat, gb = sum dyn)
+// replacing the launches conv1x1(GATEBWD) + conv1x1 + ln_bwd_cached (26 + 30 + 19 us at the 64x64 level).
+// ---------------------------------------------------------------------------------------------------------------
+struct TailBwdArgs {
+    const float* dout; long dout_ns;
+    const float* gamma;
+    const float* t4; long t4_ns;
+    const float* y; long y_ns;
+    const float *mu, *rs, *lnw;
+    const uint4 *w5t, *w4t;           // packed hx2 fragments, mode DGRAD_S1: M = C, K = C ; M = C, K = 2C
+    float* dt4; long dt4_ns;
+    const float* res; long res_ns;    // residual-branch gradient added to the LayerNorm data gradient
+    float* dy; long dy_ns;
+    float* part;                      // [gridDim.y * gridDim.x][2][C] LayerNorm parameter-gradient partials
+    int HW;
+};
+
+__device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 lanes of a wave half (same kk)
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// HEAD = true is the first half of the block instead (:216-225 backward): dxn = W1^T dt1 (conv1 data gradient, K = 2C,
+// `dout` = dt1 [N, 2C, HW], `w4t` = conv1's DGRAD_S1 fragments) followed by norm1's backward + the y-branch gradient in
+// `res`: the same K = 2C GEMM + LayerNorm epilogue without the conv5 / SimpleGate front.
+template <int C, bool HEAD>
+__global__ __launch_bounds__(512, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
+    static_assert(C == 256, "8 waves x 32 channel rows: C = 256");
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+    uint4* sB = smem4;                                        // up to 2 planes x (2C/8) octets x 64 px x 16 B = 128 KiB
+    float* red = reinterpret_cast<float*>(smem4 + 2 * (2 * C / 8) * NPX);   // [2][8 waves][64 px]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kk = lane >> 5;
+    const int n = blockIdx.y;
+    const long p0 = (long)blockIdx.x * NPX;
+    const long HW = a.HW;
+    const int m0 = 32 * wave;
+#ifdef NB_NOROT
+    const int rot = 0;
+#else
+    const int rot = (int)(blockIdx.x * 5);   // (not a function of the image index: batch-permutation equivariance stays bit-exact)
+#endif
+    auto off = [&](int r, int tn) { return (long)(m0 + row_of(r, kk)) * HW + 32 * tn; };
+
+    f32x16 acc[1][2];
+    float da[HEAD ? 1 : 2][16], db[HEAD ? 1 : 2][16];
+    if constexpr (HEAD) {
+        // ---- stage B = dt1 (K = 2C): thread (oct, q) owns pixels 4q..4q+3 of octets oct and oct + C/8
+        const int q = tid & 15, oct0 = tid >> 4;
+        const float* gp = a.dout + (long)n * a.dout_ns + p0 + 4 * q;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int oct = oct0 + pass * (C / 8);
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(gp + (long)(8 * oct + i) * HW);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                HFrag h, m;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    _Float16 hh, mm;
+                    split_hm(px == 0 ? v[i].x : (px == 1 ? v[i].y : (px == 2 ? v[i].z : v[i].w)), hh, mm);
+                    h.hv[i] = hh;
+                    m.hv[i] = mm;
+                }
+                const int slot = oct * NPX + swz(4 * q + px);
+                sB[slot] = h.u;
+                sB[(2 * C / 8) * NPX + slot] = m.u;
+            }
+        }
+    } else {
+    // ---- gate operands of this wave's rows (t4[c], t4[C + c]) in accumulator layout
+    float ta[2][16], tb[2][16];
+    {
+        const float* tp = a.t4 + (long)n * a.t4_ns + p0 + j;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ta[tn][r] = tp[off(r, tn)];
+                tb[tn][r] = tp[(long)C * HW + off(r, tn)];
+            }
+    }
+    // ---- stage B = dout * gamma (K = C)
+    {
+        constexpr int NOCT = C / 8;
+        const int q = tid & 15, oct = tid >> 4;
+        const float* gp = a.dout + (long)n * a.dout_ns + p0 + 4 * q;
+        float4 v[8];
+        float sc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = *reinterpret_cast<const float4*>(gp + (long)(8 * oct + i) * HW);
+            sc[i] = a.gamma[8 * oct + i];
+        }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            HFrag h, m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                _Float16 hh, mm;
+                split_hm((px == 0 ? v[i].x : (px == 1 ? v[i].y : (px == 2 ? v[i].z : v[i].w))) * sc[i], hh, mm);
+                h.hv[i] = hh;
+                m.hv[i] = mm;
+            }
+            const int slot = oct * NPX + swz(4 * q + px);
+            sB[slot] = h.u;
+            sB[NOCT * NPX + slot] = m.u;
+        }
+    }
+    __syncthreads();
+
+    // ---- conv5 data gradient: dg2 rows [32w, 32w + 32)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
+    gemm_hx2<1, C / 16, 4>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [](int) {});
+    __syncthreads();                                          // every wave is done with the dout planes
+
+    // ---- SimpleGate backward; dt4 rows c -> octets [4w, 4w+4), rows C + c -> octets [C/8 + 4w, ...) of the K = 2C operand
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            da[tn][r] = acc[0][tn][r] * tb[tn][r];
+            db[tn][r] = acc[0][tn][r] * ta[tn][r];
+        }
+        tile_to_planes(da[tn], sB, 2 * C / 8, 4 * wave, 32 * tn + j, kk);
+        tile_to_planes(db[tn], sB, 2 * C / 8, C / 8 + 4 * wave, 32 * tn + j, kk);
+    }
+    }   // !HEAD
+    // LayerNorm operands of this wave's rows
+    float yh[2][16], lw[16];
+    float mean_[2], rstd_[2];
+    {
+        const float* yp = a.y + (long)n * a.y_ns + p0 + j;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            mean_[tn] = a.mu[(long)n * HW + p0 + 32 * tn + j];
+            rstd_[tn] = a.rs[(long)n * HW + p0 + 32 * tn + j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yh[tn][r] = yp[off(r, tn)];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lw[r] = a.lnw[m0 + row_of(r, kk)];
+    }
+    __syncthreads();
+
+    // ---- conv4 data gradient: dyn rows [32w, 32w + 32), K = 2C ; the dt4 tile leaves for HBM under its MFMAs
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
+    if constexpr (HEAD) {
+        gemm_hx2<1, 2 * C / 16, 4>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [](int) {});
+    } else {
+        float* dp = a.dt4 + (long)n * a.dt4_ns + p0 + j;
+        gemm_hx2<1, 2 * C / 16, 4>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [&](int g) {
+            const int tn = g >> 4, r = g & 15;                 // 64 dword stores: 2 per group
+            dp[off(r, tn)] = da[tn][r];
+            dp[(long)C * HW + off(r, tn)] = db[tn][r];
+        });
+    }
+    // ---- LayerNorm backward: g = dyn * w ; dx = (g - yhat * mean_c(g * yhat) - mean_c(g)) * rstd ; + dout
+    float gv[2][16];
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float pw[16], pb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pw[r] = 0.f; pb[r] = 0.f; }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[0][tn][r];
+            const float yhat = (yh[tn][r] - mean_[tn]) * rstd_[tn];
+            yh[tn][r] = yhat;
+            pw[r] += d * yhat;
+            pb[r] += d;
+            const float g = d * lw[r];
+            gv[tn][r] = g;
+            s1[tn] += g * yhat;
+            s2[tn] += g;
+        }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        s1[tn] += __shfl_xor(s1[tn], 32, 64);
+        s2[tn] += __shfl_xor(s2[tn], 32, 64);
+        if (kk == 0) {
+            red[wave * NPX + 32 * tn + j] = s1[tn];
+            red[(NW + wave) * NPX + 32 * tn + j] = s2[tn];
+        }
+    }
+    // parameter-gradient partials of this workgroup: sum over its 64 pixels, one value per channel row
+    {
+        float* pp = a.part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float w_ = half_sum32(pw[r]), b_ = half_sum32(pb[r]);
+            if (j == 0) {
+                pp[m0 + row_of(r, kk)] = w_;
+                pp[C + m0 + row_of(r, kk)] = b_;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const float* dop = a.res + (long)n * a.res_ns + p0 + j;
+        float* dyp = a.dy + (long)n * a.dy_ns + p0 + j;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const float* r1 = red + 32 * tn + j;
+            const float* r2 = red + NW * NPX + 32 * tn + j;
+            const float m1 = (((r1[0] + r1[NPX]) + (r1[2 * NPX] + r1[3 * NPX])) + ((r1[4 * NPX] + r1[5 * NPX]) + (r1[6 * NPX] + r1[7 * NPX]))) * (1.f / C);
+            const float m2 = (((r2[0] + r2[NPX]) + (r2[2 * NPX] + r2[3 * NPX])) + ((r2[4 * NPX] + r2[5 * NPX]) + (r2[6 * NPX] + r2[7 * NPX]))) * (1.f / C);
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = dop[off(r, tn)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dyp[off(r, tn)] = (gv[tn][r] - yh[tn][r] * m1 - m2) * rstd_[tn] + res[r];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tdr_naf_tail_supported(int C, int HW) { return (C == 256 && HW % 64 == 0) ? 1 : 0; }
+
+extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
+    TDR_REQUIRE(d && d->g && d->sca && d->x && d->w3 && d->w4 && d->w5 && d->b3 && d->beta && d->lnw && d->lnb && d->b4 && d->b5 &&
+                    d->gamma && d->y && d->mu && d->rs && d->yn && d->t4 && d->out,
+                "tdr_naf_tail_fwd: null pointer");
+    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_fwd: needs C == 256 and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
+    TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_tail_fwd: weights must be packed with tdr_pack_weights_hx2 (mode FWD)");
+    TDR_REQUIRE(d->HW % 4 == 0 && d->g_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->g) & 15) == 0, "tdr_naf_tail_fwd: g must be 16-byte aligned");
+    TailArgs a;
+    a.g = d->g; a.g_ns = d->g_ns; a.sca = d->sca; a.x = d->x; a.x_ns = d->x_ns;
+    a.w3 = reinterpret_cast<const uint4*>(d->w3); a.w4 = reinterpret_cast<const uint4*>(d->w4); a.w5 = reinterpret_cast<const uint4*>(d->w5);
+    a.b3 = d->b3; a.beta = d->beta; a.lnw = d->lnw; a.lnb = d->lnb; a.b4 = d->b4; a.b5 = d->b5; a.gamma = d->gamma;
+    a.eps = d->eps;
+    a.y = d->y; a.y_ns = d->y_ns; a.mu = d->mu; a.rs = d->rs; a.yn = d->yn; a.yn_ns = d->yn_ns; a.t4 = d->t4; a.t4_ns = d->t4_ns;
+    a.out = d->out; a.out_ns = d->out_ns; a.HW = d->HW;
+    const size_t lds = (size_t)2 * (256 / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    auto kern = naf_tail_fwd_kernel<256>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(d->HW / NPX, d->N), dim3(512), lds, (hipStream_t)stream, a);
+    TDR_LAUNCH_CHECK("naf_tail_fwd_kernel");
+    return TDR_OK;
+}
+
+extern "C" int64_t tdr_naf_tail_bwd_ws_floats(int N, int C, int HW) { return (int64_t)N * (HW / NPX) * 2 * C; }
+
+extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
+    TDR_REQUIRE(d && d->dout && d->gamma && d->t4 && d->y && d->mu && d->rs && d->lnw && d->w5t && d->w4t && d->dt4 && d->dy && d->gw &&
+                    d->gb && d->ws,
+                "tdr_naf_tail_bwd: null pointer");
+    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_bwd: needs C == 256 and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
+    TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_tail_bwd: weights must be packed with tdr_pack_weights_hx2 (mode DGRAD_S1)");
+    TDR_REQUIRE(d->dout_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->dout) & 15) == 0, "tdr_naf_tail_bwd: dout must be 16-byte aligned");
+    TailBwdArgs a;
+    a.dout = d->dout; a.dout_ns = d->dout_ns; a.gamma = d->gamma; a.t4 = d->t4; a.t4_ns = d->t4_ns; a.y = d->y; a.y_ns = d->y_ns;
+    a.mu = d->mu; a.rs = d->rs; a.lnw = d->lnw;
+    a.w5t = reinterpret_cast<const uint4*>(d->w5t); a.w4t = reinterpret_cast<const uint4*>(d->w4t);
+    a.dt4 = d->dt4; a.dt4_ns = d->dt4_ns; a.dy = d->dy; a.dy_ns = d->dy_ns; a.part = d->ws; a.HW = d->HW;
+    a.res = d->dout; a.res_ns = d->dout_ns;
+    const size_t lds = (size_t)2 * (2 * 256 / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    auto kern = naf_tail_bwd_kernel<256, false>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(d->HW / NPX, d->N), dim3(512), lds, (hipStream_t)stream, a);
+    TDR_LAUNCH_CHECK("naf_tail_bwd_kernel");
+    return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, stream);
+}
+
+extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
+    TDR_REQUIRE(d && d->dt1 && d->x && d->mu && d->rs && d->lnw && d->w1t && d->res && d->dx && d->gw && d->gb && d->ws,
+                "tdr_naf_head_bwd: null pointer");
+    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_head_bwd: needs C == 256 and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
+    TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_head_bwd: weights must be packed with tdr_pack_weights_hx2 (mode DGRAD_S1)");
+    TDR_REQUIRE(d->dt1_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->dt1) & 15) == 0, "tdr_naf_head_bwd: dt1 must be 16-byte aligned");
+    TailBwdArgs a;
+    a.dout = d->dt1; a.dout_ns = d->dt1_ns; a.gamma = nullptr; a.t4 = nullptr; a.t4_ns = 0; a.y = d->x; a.y_ns = d->x_ns;
+    a.mu = d->mu; a.rs = d->rs; a.lnw = d->lnw;
+    a.w5t = nullptr; a.w4t = reinterpret_cast<const uint4*>(d->w1t);
+    a.dt4 = nullptr; a.dt4_ns = 0; a.res = d->res; a.res_ns = d->res_ns; a.dy = d->dx; a.dy_ns = d->dx_ns; a.part = d->ws; a.HW = d->HW;
+    const size_t lds = (size_t)2 * (2 * 256 / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    auto kern = naf_tail_bwd_kernel<256, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(d->HW / NPX, d->N), dim3(512), lds, (hipStream_t)stream, a);
+    TDR_LAUNCH_CHECK("naf_head_bwd_kernel");
+    return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, stream);
+}

@@ -750,6 +750,14 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
     return TDR_OK;
 }
 
+// part [nparts][2][C] -> o0[c] = sum_k part[k][0][c], o1[c] = sum_k part[k][1][c] (fixed order: deterministic)
+extern "C" int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float* o1, void* stream) {
+    TDR_REQUIRE(part && o0 && o1 && nparts > 0 && C > 0, "tdr_pair_sum_partials: bad argument");
+    hipLaunchKernelGGL(pair_sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 2), dim3(1024), 0, (hipStream_t)stream, part, nparts, C, o0, o1);
+    TDR_LAUNCH_CHECK("pair_sum_partials");
+    return TDR_OK;
+}
+
 extern "C" int tdr_sca_fwd(const float* pooled, const float* wsca, const float* bsca, int N, int C, float* s,
                            void* stream) {
     TDR_REQUIRE(pooled && wsca && bsca && s, "tdr_sca_fwd: null pointer");

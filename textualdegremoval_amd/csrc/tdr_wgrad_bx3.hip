@@ -40,7 +40,9 @@ __device__ __forceinline__ void wsplit3(float x, __bf16& h, __bf16& m, __bf16& l
 #define WSPLIT_ONE(x, i)                      \
     {                                         \
         __bf16 a0, a1, a2;                    \
-        wsplit3(x, a0, a1, a2);               \
+        float xp__ = (x);                     \
+        asm volatile("" : "+v"(xp__));        \
+        wsplit3(xp__, a0, a1, a2);            \
         hv[i] = a0; mv[i] = a1; lv[i] = a2;   \
     }
 
@@ -57,7 +59,8 @@ __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h
         wf16x8 hv, mv;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float x = i < 4 ? a[i & 3] : b[i & 3];
+            float x = i < 4 ? a[i & 3] : b[i & 3];
+            asm volatile("" : "+v"(x));          // head and residual from the same fp32 value (gated operands are products)
             const _Float16 hh = (_Float16)x;
             hv[i] = hh;
             mv[i] = (_Float16)(x - (float)hh);

@@ -6,12 +6,16 @@ as dicts keyed by the reference's state-dict names, gradients come back keyed
 the same way.  No ATen arithmetic runs on the device here: every tensor op is a
 call into libtdr_hip.so (torch only allocates and views memory).
 """
+import os
+
 import torch
 
 from . import kernels as K
 from .kernels import (EPI_GATEBWD, EPI_PSHUF, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2, PACK_DGRAD_S1, PACK_FWD)
 
 LN_EPS = 1e-6
+# fused NAFBlock halves (csrc/tdr_nafblock.hip) where the shape allows; TDR_FUSE_NAF=0 keeps the per-op launches
+FUSE_TAIL = os.environ.get('TDR_FUSE_NAF', '1') == '1'
 
 
 def _sub(P, pre):
@@ -63,6 +67,13 @@ def naf_fwd(x, P, c_out=None):
     t1 = K.conv_forward(xn, wp, mp, 2 * c, 1, bias=P['conv1.bias'])
     g, pooled = K.dwsg_fwd(t1, P['conv2.weight'], P['conv2.bias'])
     s = K.sca_fwd(pooled, P['sca.1.weight'], P['sca.1.bias'])
+    if FUSE_TAIL and K.naf_tail_supported(c, H * W, c_out) and x.is_contiguous():
+        # conv3 -> norm2 -> conv4 -> SimpleGate -> conv5 in one launch (one workgroup per 64 pixels x all channels)
+        w3p, w4p, w5p = (K.pack_weights(P[k], PACK_FWD)[0] for k in ('conv3.weight', 'conv4.weight', 'conv5.weight'))
+        out, y, mu2, rs2, yn, t4 = K.naf_tail_fwd(g, s, x, w3p, P['conv3.bias'], P['beta'].view(-1), P['norm2.weight'],
+                                                  P['norm2.bias'], LN_EPS, w4p, P['conv4.bias'], w5p, P['conv5.bias'],
+                                                  P['gamma'].view(-1))
+        return out, (x, xn, mu1, rs1, t1, g, pooled, s, y, yn, mu2, rs2, t4, c_out)
     wp, mp, *_ = K.pack_weights(P['conv3.weight'], PACK_FWD)
     y = K.conv_forward(g, wp, mp, c, 1, kscale=s, bias=P['conv3.bias'], scale=P['beta'].view(-1), res=x)
     yn, mu2, rs2 = K.layernorm2d_fwd(y, P['norm2.weight'], P['norm2.bias'], LN_EPS)
@@ -72,6 +83,11 @@ def naf_fwd(x, P, c_out=None):
     out = K.conv_forward(t4, wp, mp, c_out, 1, gate=True, bias=P['conv5.bias'], scale=P['gamma'].view(-1), res=y)
     saved = (x, xn, mu1, rs1, t1, g, pooled, s, y, yn, mu2, rs2, t4, c_out)
     return out, saved
+
+
+def _dgrad_is_hx2():
+    """data-gradient weights are packed in the fp16-split layout only inside a loss-scaled backward pass (kernels.GRAD_SCALED)"""
+    return K.MATH == 'hx2' and K.GRAD_SCALED
 
 
 def naf_bwd(dout, P, saved):
@@ -95,16 +111,24 @@ def naf_bwd(dout, P, saved):
             K.copy_rows(db5, 0, fb, 0, 1, c_out)
             K.copy_rows(dgam, 0, fg, 0, 1, c_out)
             G['conv5.weight'], G['conv5.bias'], G['gamma'] = fw, fb, fg
-    wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
-    dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
+    fused = FUSE_TAIL and K.naf_tail_supported(c, H * W, c_out) and dout.is_contiguous() and \
+        _dgrad_is_hx2()
+    if fused:
+        # conv5 dgrad -> SimpleGate bwd -> conv4 dgrad -> norm2 bwd (+ skip) in one launch
+        w5t, w4t = K.pack_weights(P['conv5.weight'], PACK_DGRAD_S1)[0], K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)[0]
+        dy, dt4, G['norm2.weight'], G['norm2.bias'] = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t, w4t)
+    else:
+        wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
+        dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
     # ---- conv4
     with K.on_side(yn, dt4):
         g4, G['conv4.bias'] = K.conv_wgrad(yn, dt4, 2 * c, c, 1, want_db=True)
         G['conv4.weight'] = g4.view(2 * c, c, 1, 1)
-    wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)
-    dyn = K.conv_forward(dt4, wp, mp, c, 1)
-    # ---- norm2 (+ residual branch of `y + x*gamma`)
-    dy, G['norm2.weight'], G['norm2.bias'] = K.layernorm2d_bwd(dyn, y, mu2, rs2, P['norm2.weight'], add=dout)
+    if not fused:
+        wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)
+        dyn = K.conv_forward(dt4, wp, mp, c, 1)
+        # ---- norm2 (+ residual branch of `y + x*gamma`)
+        dy, G['norm2.weight'], G['norm2.bias'] = K.layernorm2d_bwd(dyn, y, mu2, rs2, P['norm2.weight'], add=dout)
     # ---- conv3 / SCA / beta chain
     G3, S3 = K.conv_wgrad(g, dy, c, c, 1, per_image=True, want_db=True)
     dw3, db3, dbeta, dwsca, dbsca, dpooled = K.sca_bwd(G3, S3, P['conv3.weight'], P['conv3.bias'], beta, s, pooled,
@@ -119,9 +143,14 @@ def naf_bwd(dout, P, saved):
     with K.on_side(xn, dt1):
         g1, G['conv1.bias'] = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)
         G['conv1.weight'] = g1.view(2 * c, c, 1, 1)
-    wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)
-    dxn = K.conv_forward(dt1, wp, mp, c, 1)
-    dx, G['norm1.weight'], G['norm1.bias'] = K.layernorm2d_bwd(dxn, x, mu1, rs1, P['norm1.weight'], add=dy)
+    if FUSE_TAIL and K.naf_tail_supported(c, H * W) and _dgrad_is_hx2() and x.is_contiguous() and dy.is_contiguous():
+        # conv1 dgrad -> norm1 bwd (+ dy) in one launch
+        w1t = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)[0]
+        dx, G['norm1.weight'], G['norm1.bias'] = K.naf_head_bwd(dt1, x, mu1, rs1, P['norm1.weight'], w1t, dy)
+    else:
+        wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)
+        dxn = K.conv_forward(dt1, wp, mp, c, 1)
+        dx, G['norm1.weight'], G['norm1.bias'] = K.layernorm2d_bwd(dxn, x, mu1, rs1, P['norm1.weight'], add=dy)
     maybe_join()
     return dx, G
 

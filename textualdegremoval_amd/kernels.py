@@ -450,6 +450,81 @@ def dwsg_bwd(dg, t, w, b):
     return dt, dw, db
 
 
+def naf_tail_supported(c, hw, c_out=None):
+    return (c_out is None or c_out == c) and MATH == 'hx2' and bool(_lib.load().tdr_naf_tail_supported(int(c), int(hw)))
+
+
+def naf_tail_fwd(g, s, x, w3p, b3, beta, lnw, lnb, eps, w4p, b4, w5p, b5, gamma):
+    """fused conv3 -> +residual -> norm2 -> conv4 -> SimpleGate -> conv5 -> +residual (csrc/tdr_nafblock.hip).
+    Returns (out, y, mu2, rs2, yn, t4): exactly the tensors the unfused sequence saves for the backward pass."""
+    lib = _lib.load()
+    N, Cc, H, W = g.shape
+    dev = g.device
+    y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
+    yn = torch.empty_like(y)
+    out = torch.empty_like(y)
+    t4 = torch.empty(N, 2 * Cc, H, W, dtype=torch.float32, device=dev)
+    mu = torch.empty(N, H * W, dtype=torch.float32, device=dev)
+    rs = torch.empty_like(mu)
+    d = _lib.TdrNafTailDesc()
+    d.N, d.C, d.HW, d.eps = N, Cc, H * W, float(eps)
+    assert w3p.fmt == w4p.fmt == w5p.fmt
+    d.w_fmt = w3p.fmt
+    d.g, d.g_ns, d.sca, d.x, d.x_ns = g.data_ptr(), _dense_nchw(g), s.data_ptr(), x.data_ptr(), _dense_nchw(x)
+    d.w3, d.w4, d.w5 = w3p.data_ptr(), w4p.data_ptr(), w5p.data_ptr()
+    d.b3, d.beta, d.lnw, d.lnb = b3.data_ptr(), beta.data_ptr(), lnw.data_ptr(), lnb.data_ptr()
+    d.b4, d.b5, d.gamma = b4.data_ptr(), b5.data_ptr(), gamma.data_ptr()
+    d.y, d.y_ns, d.mu, d.rs, d.yn, d.yn_ns = y.data_ptr(), _dense_nchw(y), mu.data_ptr(), rs.data_ptr(), yn.data_ptr(), _dense_nchw(yn)
+    d.t4, d.t4_ns, d.out, d.out_ns = t4.data_ptr(), _dense_nchw(t4), out.data_ptr(), _dense_nchw(out)
+    check(lib.tdr_naf_tail_fwd(C.byref(d), _stream()), 'tdr_naf_tail_fwd')
+    return out, y, mu, rs, yn, t4
+
+
+def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp):
+    """fused conv5 dgrad -> SimpleGate bwd -> conv4 dgrad -> norm2 bwd (+ skip) (csrc/tdr_nafblock.hip).
+    Returns (dy, dt4, gw2, gb2)."""
+    lib = _lib.load()
+    N, Cc, H, W = y.shape
+    dev = y.device
+    assert dout.is_contiguous()
+    dt4 = torch.empty(N, 2 * Cc, H, W, dtype=torch.float32, device=dev)
+    dy = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
+    gw = torch.empty(Cc, dtype=torch.float32, device=dev)
+    gb = torch.empty_like(gw)
+    ws = workspace(lib.tdr_naf_tail_bwd_ws_floats(N, Cc, H * W), dev, 'naftail')
+    d = _lib.TdrNafTailBwdDesc()
+    d.N, d.C, d.HW = N, Cc, H * W
+    assert w5tp.fmt == w4tp.fmt
+    d.w_fmt = w5tp.fmt
+    d.dout, d.dout_ns, d.gamma = dout.data_ptr(), _dense_nchw(dout), gamma.data_ptr()
+    d.t4, d.t4_ns, d.y, d.y_ns = t4.data_ptr(), _dense_nchw(t4), y.data_ptr(), _dense_nchw(y)
+    d.mu, d.rs, d.lnw, d.w5t, d.w4t = mu.data_ptr(), rs.data_ptr(), lnw.data_ptr(), w5tp.data_ptr(), w4tp.data_ptr()
+    d.dt4, d.dt4_ns, d.dy, d.dy_ns = dt4.data_ptr(), _dense_nchw(dt4), dy.data_ptr(), _dense_nchw(dy)
+    d.gw, d.gb, d.ws = gw.data_ptr(), gb.data_ptr(), ws.data_ptr()
+    check(lib.tdr_naf_tail_bwd(C.byref(d), _stream()), 'tdr_naf_tail_bwd')
+    return dy, dt4, gw, gb
+
+
+def naf_head_bwd(dt1, x, mu, rs, lnw, w1tp, res):
+    """fused conv1 dgrad -> norm1 bwd (+ skip gradient `res`).  Returns (dx, gw1, gb1)."""
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    dev = x.device
+    assert dt1.is_contiguous()
+    dx = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
+    gw = torch.empty(Cc, dtype=torch.float32, device=dev)
+    gb = torch.empty_like(gw)
+    ws = workspace(lib.tdr_naf_tail_bwd_ws_floats(N, Cc, H * W), dev, 'naftail')
+    d = _lib.TdrNafHeadBwdDesc()
+    d.N, d.C, d.HW, d.w_fmt = N, Cc, H * W, w1tp.fmt
+    d.dt1, d.dt1_ns, d.x, d.x_ns = dt1.data_ptr(), _dense_nchw(dt1), x.data_ptr(), _dense_nchw(x)
+    d.mu, d.rs, d.lnw, d.w1t = mu.data_ptr(), rs.data_ptr(), lnw.data_ptr(), w1tp.data_ptr()
+    d.res, d.res_ns, d.dx, d.dx_ns = res.data_ptr(), _dense_nchw(res), dx.data_ptr(), _dense_nchw(dx)
+    d.gw, d.gb, d.ws = gw.data_ptr(), gb.data_ptr(), ws.data_ptr()
+    check(lib.tdr_naf_head_bwd(C.byref(d), _stream()), 'tdr_naf_head_bwd')
+    return dx, gw, gb
+
+
 def sca_fwd(pooled, wsca, bsca):
     lib = _lib.load()
     N, Cc = pooled.shape
