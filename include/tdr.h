@@ -283,13 +283,17 @@ int tdr_fine_search_bwd(const float* datt, const float* soft_att, const int* ind
 int tdr_transfer_fwd(const float* feat, int N, int C, int H, int W, const int* y1, const int* x1,
                      const int* index_all, const float* soft_att, int py, int px, int K, int side, int s,
                      float* out, int64_t out_ns, void* stream);
-/* backward: dfeat (accumulated with atomics, caller zeroes) and datt[B,K,K] partial for this scale (+=);
- * ws >= tdr_transfer_ws_floats(...) floats */
-int64_t tdr_transfer_ws_floats(int N, int C, int py, int px, int K, int s);
+/* backward: dfeat += adjoint of the gather (caller zeroes) and datt[B,K,K] partial for this scale (+=).
+ * deterministic = 0: float atomics (fast; the sum of >= 3 contributions to one address depends on arrival order, ~1e-7
+ * relative run-to-run differences); 1: the scatter accumulates 64-bit fixed-point integers whose quantum follows the
+ * launch's max |dout| -- integer addition is associative, the result is bit-identical from run to run (MI355X cfg2:
+ * +0.5 ms per step).  ws >= tdr_transfer_ws_floats(...) 4-byte words */
+int64_t tdr_transfer_ws_floats(int N, int C, int H, int W, int py, int px, int K, int s);
 int tdr_transfer_bwd(const float* dout, int64_t dout_ns, const float* feat, int N, int C, int H, int W,
                      const int* y1, const int* x1, const int* index_all, const float* soft_att, int py, int px,
-                     int K, int side, int s, float* dfeat, float* datt, float* ws, void* stream);
-/* scatter-add of the ref-block gradient back into the deepest ref feature (wrap-aware) */
+                     int K, int side, int s, int deterministic, float* dfeat, float* datt, float* ws, void* stream);
+/* adjoint of tdr_gather_ref_block: dfeat += the ref-block gradient at every feature pixel the blocks read (wrap-aware;
+ * a deterministic gather over the feature map, no atomics) */
 int tdr_scatter_ref_block(const float* dblk, int N, int C, int H, int W, const int* y1, const int* x1, int P,
                           int side, float* dfeat, void* stream);
 

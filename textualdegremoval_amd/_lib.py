@@ -156,8 +156,8 @@ SIGNATURES = {
     'tdr_fine_argmax': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_fine_search_bwd': (i32, [c_fp] * 7 + [i32] * 4 + [c_fp, c_fp, c_fp]),
     'tdr_transfer_fwd': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
-    'tdr_transfer_ws_floats': (i64, [i32, i32, i32, i32, i32, i32]),
-    'tdr_transfer_bwd': (i32, [c_fp, i64, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32,
+    'tdr_transfer_ws_floats': (i64, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    'tdr_transfer_bwd': (i32, [c_fp, i64, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32,
                                c_fp, c_fp, c_fp, c_fp]),
     'tdr_resize_bilinear': (i32, [c_fp, i32, i32, i32, c_fp, i32, i32, c_fp]),
     'tdr_unfold_windows': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),

@@ -179,16 +179,33 @@ __global__ void gather_ref_block_kernel(const float* __restrict__ feat, int C, i
     }
 }
 
+// adjoint of gather_ref_block as a GATHER over the feature map (deterministic: no atomics).  A feature pixel (y, x) is
+// read by block b at the block-local rows v with wrap(y1[b] + v) == y: v = y - y1[b], and v = y - H - y1[b] (the python
+// negative-index wrap, :672-678) -- each valid when inside [0, side).  Blocks, then rows, then columns in fixed order.
 __global__ void scatter_ref_block_kernel(const float* __restrict__ dblk, int C, int H, int W, const int* __restrict__ y1,
                                          const int* __restrict__ x1, int P, int side, long total,
                                          float* __restrict__ dfeat) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int u = (int)(i % side); long r = i / side;
-        const int v = (int)(r % side); r /= side;
-        const int c = (int)(r % C); const long b = r / C;
-        const long n = b / P;
-        const int y = wrap_idx(y1[b] + v, H), x = wrap_idx(x1[b] + u, W);
-        atomicAdd(&dfeat[((n * C + c) * H + y) * W + x], dblk[i]);
+        const int x = (int)(i % W); long r = i / W;
+        const int y = (int)(r % H); r /= H;
+        const int c = (int)(r % C); const long n = r / C;
+        float acc = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const long b = n * P + p;
+            const int by = y1[b], bx = x1[b];
+#pragma unroll
+            for (int wy = 0; wy < 2; ++wy) {
+                const int v = y - wy * H - by;
+                if (v < 0 || v >= side || (wy == 1) != (by + v < 0)) continue;
+#pragma unroll
+                for (int wx = 0; wx < 2; ++wx) {
+                    const int u = x - wx * W - bx;
+                    if (u < 0 || u >= side || (wx == 1) != (bx + u < 0)) continue;
+                    acc += dblk[((b * C + c) * side + v) * side + u];
+                }
+            }
+        }
+        dfeat[i] += acc;
     }
 }
 
@@ -374,18 +391,45 @@ __global__ __launch_bounds__(256) void transfer_fwd_kernel(const float* __restri
         if (c0 + i < C) out[(long)n * out_ns + (long)(c0 + i) * HWo + pix] = accs[i] * g.inv_cnt * g.wgt;
 }
 
-// backward pass 1: dfeat scatter (atomics) + per-pixel dA = sum_c dout * acc/cnt.
+// order-independent accumulation: every contribution is rounded to a multiple of 2^-shift (shift chosen from the
+// largest |dout| of the launch so that 2^16 contributions of that size still fit) and added as a 64-bit integer -- integer
+// addition is associative, so the sum does not depend on the order in which the workgroups arrive (float atomics did).
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, long x_ns, long per4, int N,
+                                                         unsigned* __restrict__ out) {
+    float m = 0.f;
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + (long)blockIdx.y * x_ns);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < per4; i += (long)gridDim.x * 256) {
+        const f32x4 v = p[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+__device__ __forceinline__ int fixed_shift(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xff) - 127;                   // floor(log2 absmax); -127 for 0 / subnormal
+    return 46 - (e + 1);                                                   // |value| * 2^shift < 2^46; 2^16 of them < 2^62
+}
+__global__ void fixed_to_float_kernel(const long long* __restrict__ acc, long n, const unsigned* __restrict__ amax_bits,
+                                      float* __restrict__ out) {
+    const double inv = ldexp(1.0, -fixed_shift(amax_bits[0]));
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] += (float)((double)acc[i] * inv);
+}
+
+// backward pass 1 (output-pixel parallel): dfeat scatter (64-bit fixed-point atomics: deterministic) + per-pixel
+// dA = sum_c dout * acc/cnt.
 // grid = (pixel blocks, channel chunks, N): the coarse levels have few pixels and many channels, so channels are
 // split across blocks (dA partial per chunk, summed by pass 2).  The <= 9 patches covering an output pixel usually
-// point at the SAME source pixel (coherent matches): duplicates are merged once per pixel, so a channel costs one
-// gather + one atomic per distinct source instead of nine.
+// point at the SAME source pixel (coherent matches): duplicates are merged once per pixel.
+template <bool FIXED>
 __global__ __launch_bounds__(256) void transfer_bwd_kernel(const float* __restrict__ dout, long dout_ns,
                                                           const float* __restrict__ feat, int C, int H, int W,
                                                           const int* __restrict__ y1, const int* __restrict__ x1,
                                                           const int* __restrict__ index_all,
                                                           const float* __restrict__ soft_att, int py, int px, int K,
                                                           int side, int s, int cpb /*channels per block*/, int N,
-                                                          float* __restrict__ dfeat,
+                                                          const unsigned* __restrict__ amax_bits,
+                                                          unsigned long long* __restrict__ dfacc /*[N][C][H*W] fixed point*/,
+                                                          float* __restrict__ dfeat /*[N][C][H*W], !FIXED*/,
                                                           float* __restrict__ dA /*[chunks][N][OH*OW]*/) {
     const int OW = px * K * s, OH = py * K * s;
     const int pix = blockIdx.x * 256 + threadIdx.x, n = blockIdx.z;
@@ -412,15 +456,19 @@ __global__ __launch_bounds__(256) void transfer_bwd_kernel(const float* __restri
     }
     float da = 0.f;
     const int c0 = blockIdx.y * cpb, c1 = min(c0 + cpb, C);
+    const float fscale = FIXED ? ldexpf(1.f, fixed_shift(amax_bits[0])) : 1.f;
     for (int c = c0; c < c1; ++c) {
         const float* f = feat + ((long)n * C + c) * HWf;
-        float* df = dfeat + ((long)n * C + c) * HWf;
         const float go = dout[(long)n * dout_ns + (long)c * HWo + pix];
         float acc = 0.f;
         const float gv = go * coef;
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            if (mult[k] > 0.f) { acc += mult[k] * f[g.src[k]]; atomicAdd(&df[g.src[k]], gv * mult[k]); }
+            if (mult[k] > 0.f) {
+                acc += mult[k] * f[g.src[k]];
+                if (FIXED) atomicAdd(&dfacc[((long)n * C + c) * HWf + g.src[k]], (unsigned long long)__float2ll_rn(gv * mult[k] * fscale));   // two's complement
+                else atomicAdd(&dfeat[((long)n * C + c) * HWf + g.src[k]], gv * mult[k]);
+            }
         da += go * acc * g.inv_cnt;
     }
     dA[((long)blockIdx.y * N + n) * HWo + pix] = da;
@@ -523,7 +571,7 @@ extern "C" int tdr_gather_ref_block(const float* feat, int N, int C, int H, int 
 extern "C" int tdr_scatter_ref_block(const float* dblk, int N, int C, int H, int W, const int* y1, const int* x1, int P,
                                      int side, float* dfeat, void* stream) {
     TDR_REQUIRE(dblk && y1 && x1 && dfeat, "tdr_scatter_ref_block: null pointer");
-    const long total = (long)N * P * C * side * side;
+    const long total = (long)N * C * H * W;
     hipLaunchKernelGGL(scatter_ref_block_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, dblk, C, H, W, y1, x1,
                        P, side, total, dfeat);
     TDR_LAUNCH_CHECK("scatter_ref_block");
@@ -572,20 +620,43 @@ static int tdr_transfer_chunks(int N, int C, int py, int px, int K, int s) {
     return (int)chunks;
 }
 
-extern "C" int64_t tdr_transfer_ws_floats(int N, int C, int py, int px, int K, int s) {
-    return (int64_t)tdr_transfer_chunks(N, C, py, px, K, s) * N * py * K * s * px * K * s;
+// workspace (4-byte words): dA [chunks][N][opix] | absmax word (+ padding to 8 bytes) | 64-bit accumulators [N][C][H*W]
+extern "C" int64_t tdr_transfer_ws_floats(int N, int C, int H, int W, int py, int px, int K, int s) {
+    const int64_t opix = (int64_t)py * K * s * px * K * s;
+    return (int64_t)tdr_transfer_chunks(N, C, py, px, K, s) * N * opix + 4 + 2 * (int64_t)N * C * H * W;
 }
 
 extern "C" int tdr_transfer_bwd(const float* dout, int64_t dout_ns, const float* feat, int N, int C, int H, int W,
                                 const int* y1, const int* x1, const int* index_all, const float* soft_att, int py, int px,
-                                int K, int side, int s, float* dfeat, float* datt, float* ws, void* stream) {
+                                int K, int side, int s, int deterministic, float* dfeat, float* datt, float* ws, void* stream) {
     TDR_REQUIRE(dout && feat && y1 && x1 && index_all && soft_att && dfeat && datt && ws, "tdr_transfer_bwd: null pointer");
     const long opix = (long)py * K * s * px * K * s;
     hipStream_t st = (hipStream_t)stream;
     const int chunks = tdr_transfer_chunks(N, C, py, px, K, s);
     const int cpb = tdr_cdiv(C, chunks);
-    hipLaunchKernelGGL(transfer_bwd_kernel, dim3((unsigned)((opix + 255) / 256), tdr_cdiv(C, cpb), N), dim3(256), 0, st, dout,
-                       (long)dout_ns, feat, C, H, W, y1, x1, index_all, soft_att, py, px, K, side, s, cpb, N, dfeat, ws);
+    float* dA = ws;
+    const dim3 grid((unsigned)((opix + 255) / 256), tdr_cdiv(C, cpb), N);
+    if (!deterministic) {
+        hipLaunchKernelGGL(transfer_bwd_kernel<false>, grid, dim3(256), 0, st, dout, (long)dout_ns, feat, C, H, W, y1, x1, index_all,
+                           soft_att, py, px, K, side, s, cpb, N, (const unsigned*)nullptr, (unsigned long long*)nullptr, dfeat, dA);
+    } else {
+        TDR_REQUIRE(opix % 4 == 0 && dout_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0, "tdr_transfer_bwd: dout must be 16-byte aligned");
+        char* tail = reinterpret_cast<char*>(ws + (long)chunks * N * opix);
+        tail += (8 - reinterpret_cast<uintptr_t>(tail) % 8) % 8;
+        unsigned* amax = reinterpret_cast<unsigned*>(tail);
+        unsigned long long* acc = reinterpret_cast<unsigned long long*>(tail + 8);
+        const long nacc = (long)N * C * H * W;
+        if (hipMemsetAsync(tail, 0, 8 + (size_t)nacc * 8, st) != hipSuccess) {
+            tdr_set_error("tdr_transfer_bwd: hipMemsetAsync failed");
+            return TDR_ERR_HIP;
+        }
+        const long per4 = (long)C * opix / 4;
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid1d(per4, 512), N), dim3(256), 0, st, dout, (long)dout_ns, per4, N, amax);
+        hipLaunchKernelGGL(transfer_bwd_kernel<true>, grid, dim3(256), 0, st, dout, (long)dout_ns, feat, C, H, W, y1, x1, index_all,
+                           soft_att, py, px, K, side, s, cpb, N, amax, acc, (float*)nullptr, dA);
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3(grid1d(nacc, 4096)), dim3(256), 0, st, reinterpret_cast<const long long*>(acc),
+                           nacc, amax, dfeat);
+    }
     hipLaunchKernelGGL(transfer_datt_kernel, dim3(N * py * px, K * K), dim3(64), 0, st, ws, py, px, K, s, tdr_cdiv(C, cpb),
                        (long)N * opix, datt);
     TDR_LAUNCH_CHECK("transfer_bwd");

@@ -743,12 +743,18 @@ def transfer_fwd(feat, y1, x1, index_all, soft_att, py, px, K, side, s, out=None
     return out
 
 
+# TDR_DETERMINISTIC=1: the MASA transfer backward accumulates its scatter in 64-bit fixed point (bit-identical results from
+# run to run; every other kernel of the step is deterministic already).  Default off: float atomics, +0.5 ms faster per step.
+DETERMINISTIC = os.environ.get('TDR_DETERMINISTIC', '0') == '1'
+
+
 def transfer_bwd(dout, feat, y1, x1, index_all, soft_att, py, px, K, side, s, dfeat, datt):
     N, Cc, H, W = feat.shape
-    ws = workspace(_lib.load().tdr_transfer_ws_floats(N, Cc, py, px, K, s), feat.device, 'transfer')
+    ws = workspace(_lib.load().tdr_transfer_ws_floats(N, Cc, H, W, py, px, K, s), feat.device, 'transfer')
     check(_lib.load().tdr_transfer_bwd(dout.data_ptr(), _dense_nchw(dout), feat.data_ptr(), N, Cc, H, W, y1.data_ptr(),
                                        x1.data_ptr(), index_all.data_ptr(), soft_att.data_ptr(), py, px, K, side, s,
-                                       dfeat.data_ptr(), datt.data_ptr(), ws.data_ptr(), _stream()), 'tdr_transfer_bwd')
+                                       1 if DETERMINISTIC else 0, dfeat.data_ptr(), datt.data_ptr(), ws.data_ptr(), _stream()),
+          'tdr_transfer_bwd')
 
 
 # ------------------------------------------------------------------ frozen ViT window matcher (DINOv2)
