@@ -297,6 +297,10 @@ int tdr_transfer_bwd(const float* dout, int64_t dout_ns, const float* feat, int 
 int tdr_scatter_ref_block(const float* dblk, int N, int C, int H, int W, const int* y1, const int* x1, int P,
                           int side, float* dfeat, void* stream);
 
+/* bit pattern of max |x| over x[n][0..per) (image stride x_ns), atomicMax-ed into *slot (caller zeroes; NaN / Inf give
+ * >= 0x7f800000).  The train step's fp16-range survey: which operands of the 2-way fp16 split leave its window. */
+int tdr_absmax_bits(const float* x, int64_t x_ns, int N, int64_t per, unsigned* slot, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Frozen ViT window matcher (DINOv2 ViT-B/14, forward only): models/image_restoration_ref_model.py:215-247,
  * models/dino/.  Activations are channel-major [B][D][T]: every Linear is tdr_conv_forward (1x1), the token

@@ -175,6 +175,7 @@ SIGNATURES = {
     'tdr_naf_tail_bwd_ws_floats': (i64, [i32, i32, i32]),
     'tdr_naf_tail_bwd': (i32, [C.POINTER(TdrNafTailBwdDesc), c_fp]),
     'tdr_naf_head_bwd': (i32, [C.POINTER(TdrNafHeadBwdDesc), c_fp]),
+    'tdr_absmax_bits': (i32, [c_fp, i64, i32, i64, c_fp, c_fp]),
     'tdr_pair_sum_partials': (i32, [c_fp, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_comm_unique_id_bytes': (i32, []),
     'tdr_comm_unique_id': (i32, [c_fp]),

@@ -662,3 +662,28 @@ extern "C" int tdr_transfer_bwd(const float* dout, int64_t dout_ns, const float*
     TDR_LAUNCH_CHECK("transfer_bwd");
     return TDR_OK;
 }
+
+// bits of max |x| over x[n][0..per) (n < N, image stride x_ns), atomically max-ed into *slot (order-independent: the
+// bit patterns of non-negative floats order like the values).  The caller zeroes the slot.  NaN / Inf inputs give a
+// pattern >= 0x7f800000.  Serves the fp16-range survey of the train step (kernels.RangeSurvey).
+__global__ __launch_bounds__(256) void absmax_bits_any_kernel(const float* __restrict__ x, long x_ns, long per, unsigned* __restrict__ slot) {
+    const float* p = x + (long)blockIdx.y * x_ns;
+    float m = 0.f;
+    unsigned bad = 0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        const float v = fabsf(p[i]);
+        if (!(v <= 3.4028235e38f)) bad = 0x7fc00000u;        // NaN or Inf
+        m = fmaxf(m, v);
+    }
+    unsigned b = __float_as_uint(m) | bad;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, b);
+}
+
+extern "C" int tdr_absmax_bits(const float* x, int64_t x_ns, int N, int64_t per, unsigned* slot, void* stream) {
+    TDR_REQUIRE(x && slot && N > 0 && per > 0, "tdr_absmax_bits: bad argument");
+    hipLaunchKernelGGL(absmax_bits_any_kernel, dim3(grid1d(per, 256), N), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, (long)per, slot);
+    TDR_LAUNCH_CHECK("absmax_bits");
+    return TDR_OK;
+}

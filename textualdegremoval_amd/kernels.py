@@ -31,6 +31,8 @@ FMT_F32, FMT_BX3, FMT_HX2 = 0, 1, 2
 # that brings dpred to ~2^9): the data-gradient convolutions of TDR_MATH=hx2 then use the fp16 split as well -- every
 # gradient operand of a cfg2 step has max|g| within 2^-0.4 .. 2^10 of that scale (profiles/grad_range_survey.py).
 GRAD_SCALED = False
+# True while the backward pass of a train step runs (tags the operands of kernels.RangeSurvey)
+BACKWARD_PHASE = False
 
 
 def set_grad_scaled(on):
@@ -43,6 +45,55 @@ def set_math(mode):
     global MATH
     assert mode in ('bx3', 'f32', 'hx2')
     MATH = mode
+
+
+class RangeSurvey:
+    """fp16-window survey of one (eager) train step.  While installed (`with survey:`), every operand that is about to
+    be split into two fp16 planes -- conv_forward / conv_wgrad inputs on the hx2 path, the inputs of the fused NAFBlock
+    kernels -- gets its max |x| recorded on the device (tdr_absmax_bits: one small launch per operand, order-independent
+    atomic max).  `read()` brings the table to the host once, after the step.  Operands are tagged 'fwd' (activations,
+    weights never leave the window) or 'grad' (operands of the loss-scaled backward pass); the model decides from the two
+    exponent ranges whether to move the loss scale or to leave the fp16 split (models/image_restoration_ref_model.py)."""
+    SLOTS = 8192
+
+    def __init__(self, device):
+        self.table = torch.zeros(self.SLOTS, dtype=torch.int32, device=device)
+        self.kinds = []
+
+    def __enter__(self):
+        global _survey
+        self.prev, _survey = _survey, self
+        return self
+
+    def __exit__(self, *exc):
+        global _survey
+        _survey = self.prev
+        return False
+
+    def probe(self, x, kind):
+        i = len(self.kinds)
+        if i >= self.SLOTS:
+            return
+        self.kinds.append(kind)
+        n = x.shape[0]
+        per = x[0].numel()
+        ns = x.stride(0) if n > 1 else per
+        assert x[0].is_contiguous()
+        check(_lib.load().tdr_absmax_bits(x.data_ptr(), ns, n, per, self.table.data_ptr() + 4 * i, _stream()), 'tdr_absmax_bits')
+
+    def read(self):
+        """-> {'fwd': (emin, emax, nonfinite), 'grad': (...)}: exponents floor(log2 max|x|) over the non-zero operands"""
+        bits = self.table[:len(self.kinds)].cpu().numpy().astype('int64') & 0xffffffff
+        out = {}
+        for kind in ('fwd', 'grad'):
+            b = [int(v) for v, k in zip(bits, self.kinds) if k == kind and v != 0]
+            bad = sum(1 for v in b if v >= 0x7f800000)
+            e = [((v >> 23) & 0xff) - 127 for v in b if v < 0x7f800000]
+            out[kind] = (min(e), max(e), bad) if e else (None, None, bad)
+        return out
+
+
+_survey = None
 
 
 class PackedWeights:
@@ -361,6 +412,8 @@ def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None
     d.mask, d.mask_ns = _p(mask), (_dense_nchw(mask) if mask is not None else 0)
     d.aux, d.aux_ns = _p(aux), (_dense_nchw(aux) if aux is not None else 0)
     d.relu = int(relu) if not isinstance(relu, bool) else (1 if relu else 0)      # 2 = exact GELU
+    if _survey is not None and d.wp_fmt == FMT_HX2:
+        _survey.probe(x, 'grad' if BACKWARD_PHASE else 'fwd')
     check(lib.tdr_conv_forward(C.byref(d), _stream()), 'tdr_conv_forward')
     return out
 
@@ -388,6 +441,8 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
         d.math = 2
     else:
         d.math = 1 if (MATH != 'f32' and (KH == 3 or WGRAD_1X1_BX3)) else 0
+    if _survey is not None and d.math == 2:
+        _survey.probe(dout, 'fwd' if fp16_range else 'grad')
     need = lib.tdr_wgrad_ws_floats(C.byref(d))
     ws = workspace(need, x.device, 'wgrad')
     d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
@@ -476,7 +531,12 @@ def naf_tail_fwd(g, s, x, w3p, b3, beta, lnw, lnb, eps, w4p, b4, w5p, b5, gamma)
     d.b4, d.b5, d.gamma = b4.data_ptr(), b5.data_ptr(), gamma.data_ptr()
     d.y, d.y_ns, d.mu, d.rs, d.yn, d.yn_ns = y.data_ptr(), _dense_nchw(y), mu.data_ptr(), rs.data_ptr(), yn.data_ptr(), _dense_nchw(yn)
     d.t4, d.t4_ns, d.out, d.out_ns = t4.data_ptr(), _dense_nchw(t4), out.data_ptr(), _dense_nchw(out)
+    if _survey is not None:
+        _survey.probe(g, 'fwd')
     check(lib.tdr_naf_tail_fwd(C.byref(d), _stream()), 'tdr_naf_tail_fwd')
+    if _survey is not None:                 # the operands formed inside the kernel: yn (LayerNorm output) and the gate product
+        _survey.probe(yn, 'fwd')
+        _survey.probe(t4, 'fwd')
     return out, y, mu, rs, yn, t4
 
 
@@ -501,7 +561,11 @@ def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp):
     d.mu, d.rs, d.lnw, d.w5t, d.w4t = mu.data_ptr(), rs.data_ptr(), lnw.data_ptr(), w5tp.data_ptr(), w4tp.data_ptr()
     d.dt4, d.dt4_ns, d.dy, d.dy_ns = dt4.data_ptr(), _dense_nchw(dt4), dy.data_ptr(), _dense_nchw(dy)
     d.gw, d.gb, d.ws = gw.data_ptr(), gb.data_ptr(), ws.data_ptr()
+    if _survey is not None:
+        _survey.probe(dout, 'grad')
     check(lib.tdr_naf_tail_bwd(C.byref(d), _stream()), 'tdr_naf_tail_bwd')
+    if _survey is not None:
+        _survey.probe(dt4, 'grad')            # the K = 2C operand formed inside the kernel
     return dy, dt4, gw, gb
 
 
@@ -521,6 +585,8 @@ def naf_head_bwd(dt1, x, mu, rs, lnw, w1tp, res):
     d.mu, d.rs, d.lnw, d.w1t = mu.data_ptr(), rs.data_ptr(), lnw.data_ptr(), w1tp.data_ptr()
     d.res, d.res_ns, d.dx, d.dx_ns = res.data_ptr(), _dense_nchw(res), dx.data_ptr(), _dense_nchw(dx)
     d.gw, d.gb, d.ws = gw.data_ptr(), gb.data_ptr(), ws.data_ptr()
+    if _survey is not None:
+        _survey.probe(dt1, 'grad')
     check(lib.tdr_naf_head_bwd(C.byref(d), _stream()), 'tdr_naf_head_bwd')
     return dx, gw, gb
 

@@ -147,13 +147,75 @@ class RefGuidedImageCleanModel(BaseModel):
             self.use_hip_graph = os.environ.get('TDR_GRAPH', '1') == '1'
             self._gstate = None
         self.optimizer_g.use_grad_clip = bool(self.opt['train']['use_grad_clip'])
-        if self.use_hip_graph:
+        if self._survey_due(current_iter):
+            loss = self._surveyed_step(current_iter)
+        elif self.use_hip_graph:
             loss = self._graph_step()
         else:
             loss = self._eager_step(self.lq, self.gt, self.ref_in)
         self.log_dict = self.reduce_loss_dict(OrderedDict(l_pix=loss[0]))
         if self.ema_decay > 0:
             self.model_ema(decay=self.ema_decay)
+
+    # ---- fp16-window survey (TDR_MATH=hx2).  The 2-way fp16 split needs its operands inside +-65504 with their leading
+    # magnitudes well above 2^-14; forward activations of these networks sit there (LayerNorm-ed, O(1)), the backward
+    # pass is put there by the loss scale.  Every TDR_RANGE_CHECK_EVERY steps (and on the first step of a shape) the step
+    # runs eagerly with kernels.RangeSurvey installed: max|x| of every split operand, one host read after the step.
+    #   gradients too large / too small for the window -> the loss scale moves by the measured number of binades
+    #   gradient operands span more binades than the window holds, or an activation exceeds 2^15 -> the affected pass
+    #   leaves the fp16 split for the 3-way bf16 split (full fp32 range) -- logged, graphs re-captured.
+    # Between surveys the step guard (skip + halve on a non-finite norm) catches what drifts out at the top.
+    GRAD_WINDOW = (-10, 14)          # allowed floor(log2 max|g|) of the scaled gradient operands
+    FWD_MAX_EXP = 14
+
+    def _survey_due(self, current_iter):
+        if K.MATH != 'hx2' or os.environ.get('TDR_RANGE_CHECK', '1') != '1':
+            return False
+        every = int(os.environ.get('TDR_RANGE_CHECK_EVERY', '1000'))
+        last = getattr(self, '_last_survey_iter', None)
+        return last is None or current_iter - last >= every
+
+    def _surveyed_step(self, current_iter):
+        self._last_survey_iter = current_iter
+        survey = K.RangeSurvey(self.lq.device)
+        with survey:
+            loss = self._eager_step(self.lq, self.gt, self.ref_in)
+        r = survey.read()
+        self.last_range_survey = r
+        fmin, fmax, fbad = r['fwd']
+        gmin, gmax, gbad = r['grad']
+        lo, hi = self.GRAD_WINDOW
+        changed = False
+        if fbad or (fmax is not None and fmax > self.FWD_MAX_EXP):
+            logger.warning(f'fp16-window survey (iter {current_iter}): forward operand with max|x| >= 2^{fmax} '
+                           f'({fbad} non-finite): leaving the fp16 split, TDR_MATH=bx3 from here on')
+            K.set_math('bx3')
+            changed = True
+        elif gmax is not None and not getattr(self, '_bwd_full_range', False):
+            guard = self.optimizer_g.guard.read()
+            shift = 0
+            if gmax > hi:
+                shift = hi - gmax
+            elif gmin < lo:
+                shift = min(lo - gmin, hi - gmax)
+            if gmax - gmin > hi - lo or gbad:
+                logger.warning(f'fp16-window survey (iter {current_iter}): scaled gradient operands span 2^{gmin}..2^{gmax} '
+                               f'({gbad} non-finite): the backward pass leaves the fp16 split (3-way bf16 split, unscaled)')
+                self._bwd_full_range = True
+                changed = True
+            elif shift != 0:
+                new = guard.scale * 2.0 ** shift
+                logger.warning(f'fp16-window survey (iter {current_iter}): scaled gradient operands span 2^{gmin}..2^{gmax}; '
+                               f'loss scale 2^{math.log2(guard.scale):.0f} -> 2^{math.log2(new):.0f}')
+                self._scale_shift = getattr(self, '_scale_shift', 0) + shift
+                self.optimizer_g.guard.write(scale=new, max_scale=new)
+                self._last_survey_iter = None         # starved operands flush to zero and hide the tensors behind them:
+                #                                       look again on the next step until the window holds
+        if changed:
+            self._last_survey_iter = None
+            self._gstate = None                       # graphs captured under the old arithmetic are stale
+            self._pack_plan = K.PackPlan()
+        return loss
 
     def _fwd_bwd(self, lq, gt, ref_in, defer_collectives=False):
         """forward, L1, hand-written backward; gradients land in the reducer's arena (RCCL-averaged when
@@ -171,8 +233,10 @@ class RefGuidedImageCleanModel(BaseModel):
             # The scale lives in the optimiser's device-resident StepGuard: a non-finite gradient norm (an operand left the
             # fp16 range) skips that step and halves it, 1000 finite steps double it again up to this starting value.
             gs = 1.0
-            if K.MATH == 'hx2' and os.environ.get('TDR_GRAD_SCALE', '1') == '1' and lw > 0:
-                gs = 2.0 ** math.floor(math.log2(512.0 * lq.shape[0] * 3 * lq.shape[2] * lq.shape[3] / lw))
+            if K.MATH == 'hx2' and os.environ.get('TDR_GRAD_SCALE', '1') == '1' and lw > 0 and \
+                    not getattr(self, '_bwd_full_range', False):
+                gs = 2.0 ** (math.floor(math.log2(512.0 * lq.shape[0] * 3 * lq.shape[2] * lq.shape[3] / lw)) +
+                             getattr(self, '_scale_shift', 0))
             K.set_grad_scaled(gs != 1.0)
             guard = self.optimizer_g.ensure_guard(lq.device)
             if not torch.cuda.is_current_stream_capturing():
@@ -184,7 +248,11 @@ class RefGuidedImageCleanModel(BaseModel):
             self.output = out
             loss, dpred = K.l1_loss(out.contiguous(), gt.contiguous(), lw, guard=guard)
             sink = self.grad_reducer.begin(defer_collectives=defer_collectives)
-            eng.net_bwd(dpred, P, net.cfg, saved, G=sink)
+            K.BACKWARD_PHASE = True
+            try:
+                eng.net_bwd(dpred, P, net.cfg, saved, G=sink)
+            finally:
+                K.BACKWARD_PHASE = False
             grads = self.grad_reducer.finish()
         finally:
             K.set_grad_scaled(prev_scaled)
