@@ -50,17 +50,26 @@ def make_opt(width, enc, batch_hw, dist_on, arch='nafnet'):
     }
 
 
-def _cpu_baseline_worker(width, enc, H, threads, budget):
-    """child process: the CPU oracle (a port of the reference's path, pinned to the reference by
-    tests/golden) timed on a bounded sample.  Prints one JSON object."""
+def _cpu_baseline_worker(width, enc, H, batch, budget):
+    """child process: the CPU oracle (a port of the reference's path, pinned to the reference by tests/golden) timed on
+    the metric's own workload: train steps of the same network on `batch` x H x H pairs.  The thread count is chosen by a
+    short scaling probe (steps at 128x128 under 8 / 16 / 32 / 64 threads): torch's MKLDNN fp32 convolutions stop scaling
+    -- and can collapse -- far below the 256 hardware threads of the GPU hosts.  Prints one JSON object."""
     from oracle import nafnet_ref_oracle as O
-    torch.set_num_threads(threads)
     cfg = O.default_cfg(width=width, nf=width, enc_blk_nums=enc, ext_n_blocks=[4, 4, 4, 4],
                         reffusion_n_blocks=[2, 2, 2, 2, 2])
     tr = O.OracleTrainer(O.synth_params(cfg, seed=0), cfg)
     lq, gt, ref = O.synth_pair(1, 128, 128, seed=1)
-    tr.step(lq, gt, ref)                                  # thread-pool / allocator warm-up
-    lq, gt, ref = O.synth_pair(1, H, H, seed=2)
+    probe = {}
+    for t in [t for t in (8, 16, 32, 64) if t <= (os.cpu_count() or 1)] or [1]:
+        torch.set_num_threads(t)
+        tr.step(lq, gt, ref)                              # thread-pool / allocator warm-up at this width
+        t0 = time.time()
+        tr.step(lq, gt, ref)
+        probe[t] = time.time() - t0
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    lq, gt, ref = O.synth_pair(batch, H, H, seed=2)
     t0 = time.time()
     n = 0
     while True:
@@ -68,28 +77,69 @@ def _cpu_baseline_worker(width, enc, H, threads, budget):
         n += 1
         if time.time() - t0 > budget or n >= 3:
             break
-    print(json.dumps({'n': n, 'dt': time.time() - t0, 'threads': torch.get_num_threads()}))
+    print(json.dumps({'n': n, 'dt': time.time() - t0, 'threads': threads, 'probe': {str(k): round(v, 3) for k, v in probe.items()}}))
 
 
-def cpu_baseline(width, enc, size, sample_size=256, threads=None, budget=20.0, hard_timeout=240.0):
-    """Reported baseline only (never the thing shipped): `oracle/` timed on this host's cores in a child
-    process with a hard timeout.  Sample = train steps of the same network on 1 x sample_size^2 pairs;
-    the rate is scaled by pixel count to the metric's 512x512 images/sec."""
+def cpu_baseline(width, enc, size, batch, budget=20.0, hard_timeout=300.0):
+    """Reported baseline only (never the thing shipped): `oracle/` timed on this host's cores in a child process with a
+    hard timeout, on the metric's own workload (batch x size x size, whole train steps)."""
     import subprocess
-    threads = threads or min(os.cpu_count() or 1, 16)     # MKLDNN fp32 convs stop scaling (and can collapse) beyond this
     code = (f'import sys; sys.path.insert(0, {ROOT!r}); import bench; '
-            f'bench._cpu_baseline_worker({width}, {enc!r}, {sample_size}, {threads}, {budget})')
+            f'bench._cpu_baseline_worker({width}, {enc!r}, {size}, {batch}, {budget})')
     try:
         out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=hard_timeout,
-                             env=dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES=''))
+                             env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
         r = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception as e:  # noqa: BLE001  (timeout / crash of the baseline must not lose the GPU measurement)
-        return {'value': None, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'sample': f'failed: {type(e).__name__}'}
-    scale = (sample_size * sample_size) / float(size * size)
-    return {'value': r['n'] / r['dt'] * scale, 'unit': 'images/sec', 'cores': r['threads'], 'kind': 'port',
+        return {'value': None, 'unit': 'images/sec', 'cores': None, 'kind': 'port', 'sample': f'failed: {type(e).__name__}'}
+    return {'value': r['n'] * batch / r['dt'], 'unit': 'images/sec', 'cores': r['threads'], 'kind': 'port',
             'host_cpus': os.cpu_count(),
-            'sample': f"{r['n']} train step(s) of the same network on 1 x {sample_size}x{sample_size} pairs in {r['dt']:.1f} s, "
-                      f"torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py), rate scaled by pixel count to {size}x{size} images"}
+            'sample': f"{r['n']} train step(s) of the same network on {batch} x {size}x{size} pairs (the metric's workload) in "
+                      f"{r['dt']:.1f} s, torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py); threads chosen by a scaling probe "
+                      f"(seconds per 128x128 step by thread count: {r['probe']})"}
+
+
+def f32_exact_run(args):
+    """the same workload on the exact-fp32 MFMA path (TDR_MATH=f32, v_mfma_f32_32x32x2_f32: bitwise an fmaf chain), a few
+    steps in a child process: the price of the split arithmetic's speed-up is visible next to the headline number"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '3', '--warmup', '1', '--arch', args.arch, '--batch',
+           str(args.batch), '--size', str(args.size), '--width', str(args.width), '--enc', args.enc, '--no-cpu-baseline',
+           '--no-roofline', '--no-f32-exact']
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TDR_MATH='f32'))
+        r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+        return {'ms_per_step': r['ms_per_step'], 'value': r['value'], 'unit': r['unit'], 'steps': r['steps'],
+                'math': 'exact fp32 MFMA (TDR_MATH=f32), same workload, same code path otherwise'}
+    except Exception as e:  # noqa: BLE001
+        return {'ms_per_step': None, 'note': f'failed: {type(e).__name__}'}
+
+
+def pmc_traffic(prefix):
+    """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/pmc_collect.sh -> profiles/r2/
+    pmc_traffic.json).  The file records the hash of the kernel source it was collected on: a mismatch means the counters
+    describe an older kernel and the figure is reported as stale (null) instead of being passed off as current."""
+    import hashlib
+    path = os.path.join(ROOT, 'profiles', 'r2', 'pmc_traffic.json')
+    src = os.path.join(ROOT, 'textualdegremoval_amd', 'csrc', 'tdr_conv_bx3.hip')
+    try:
+        with open(path) as fh:
+            pmc = json.load(fh)
+        with open(src, 'rb') as fh:
+            cur = hashlib.sha256(fh.read()).hexdigest()
+    except (OSError, ValueError):
+        return None, 'no PMC file (profiles/pmc_collect.sh not run this round)'
+    if pmc.get('meta', {}).get('tdr_conv_bx3_sha256') != cur:
+        return None, 'stale: profiles/r2/pmc_traffic.json was collected on another revision of csrc/tdr_conv_bx3.hip'
+    tot, n = 0.0, 0
+    for name, v in pmc['kernels'].items():
+        if name.startswith(prefix):
+            tot += (v['read_bytes_per_launch'] + v['write_bytes_per_launch']) * v['launches']
+            n += v['launches']
+    if not n:
+        return None, 'kernel family not in the PMC file'
+    return tot / n, ('bytes/launch of the KH=3,S=1 family (FETCH_SIZE + WRITE_SIZE in separate passes, calibrated on copies of '
+                     'known size, profiles/r2/pmc_traffic.json; collected on this revision of the kernel source)')
 
 
 def main():
@@ -106,6 +156,7 @@ def main():
     ap.add_argument('--enc', type=str, default='1,1,1,28')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-f32-exact', action='store_true', help='skip the exact-fp32 (TDR_MATH=f32) comparison run')
     ap.add_argument('--dino-ref-size', type=int, default=0,
                     help='feed a reference image of this size (> --size): the frozen DINOv2 ViT-B/14 window matcher runs every step '
                          '(random-init weights); 0 = ref of the lq size, where the match is the identity')
@@ -153,7 +204,8 @@ def main():
     it = 0
     # one-time set-up, like building the model: the first steps of a shape run eagerly (workspaces, gradient-arena
     # layout, weight-pack plan) and then the step is captured into hipGraphs; none of that is steady-state work.
-    for _ in range(3 if getattr(model, 'use_hip_graph', True) and os.environ.get('TDR_GRAPH', '1') == '1' else 1):
+    # (step 1 also carries the fp16-window survey; the capture happens on the first step after two eager ones)
+    for _ in range(5 if getattr(model, 'use_hip_graph', True) and os.environ.get('TDR_GRAPH', '1') == '1' else 1):
         it += 1
         step(it)
     for _ in range(a.warmup):
@@ -239,21 +291,8 @@ def main():
         roof = fams[order[0]]
         roof_other = [fams[f] for f in order[1:]]
         bx3 = order[0] != 0
-        # HBM bytes per launch of the same kernel family from the committed PMC passes (profiles/pmc_workload.py)
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r1', 'pmc_traffic.json')) as fh:
-                pmc = json.load(fh)
-            tot, n = 0.0, 0
-            for name, v in pmc['kernels'].items():
-                if name.startswith('conv_bx3_kernel<3, 1,' if bx3 else 'conv_mfma_kernel<3, 1, 1,'):
-                    tot += (v['read_bytes_per_launch'] + v['write_bytes_per_launch']) * v['launches']
-                    n += v['launches']
-            if n:
-                roof['traffic'] = tot / n
-                roof['traffic_unit'] = ('bytes/launch of the KH=3,S=1 family (FETCH_SIZE + WRITE_SIZE, calibrated, '
-                                        'profiles/r1/pmc_traffic.json)')
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM bytes per launch of the same kernel family from the PMC passes of this round
+        roof['traffic'], roof['traffic_unit'] = pmc_traffic('conv_bx3_kernel<3, 1,' if bx3 else 'conv_mfma_kernel<3, 1, 1,')
         for f in fams.values():
             f.pop('_total_ms', None)
 
@@ -281,16 +320,22 @@ def main():
                        'width': a.width if a.arch == 'nafnet' else 48, 'enc_blk_nums': enc if a.arch == 'nafnet' else [4, 6, 6, 8],
                        'global_batch': world * a.batch,
                        'parallelism': f'dp{world}',
+                       'collectives': ('none (1 GPU)' if world == 1 else
+                                       ('tdr_comm_* (RCCL through the C ABI)' if getattr(getattr(model, 'grad_reducer', None), 'comm', None) is not None
+                                        else f'torch.distributed ({a.backend})')),
                        'dino_match': ('skipped bit-identically (ref size == lq size, N=1 window)' if a.dino_ref_size <= a.size else
                                       f'DINOv2 ViT-B/14 window match every step, ref {a.dino_ref_size}x{a.dino_ref_size} '
                                       f'({((a.dino_ref_size - a.size) // max(a.size // 4, 1) + 1) ** 2} windows/image, random-init ViT)')},
             'final_loss': loss,
         }
         if is_cfg2:
+            nprod = {'hx2': 3.0, 'bx3': 6.0}.get(K.MATH)
             line['roofline_step'] = {'achieved_hbm_frac': CFG2['B_alg'] * per_gpu / PEAK_HBM,
                                      'achieved_f32_flop_frac': CFG2['F_alg'] * per_gpu / PEAK_F32,
-                                     'achieved_bx3_flop_frac': CFG2['F_alg'] * per_gpu / PEAK_BX3,
                                      'alg_bytes_per_image': CFG2['B_alg'], 'alg_flop_per_image': CFG2['F_alg']}
+            if nprod:      # fp32-equivalent ceiling of the split scheme in use: 2.5 PFLOP/s dense f16 / bf16 MFMA over its products
+                line['roofline_step']['achieved_split_flop_frac'] = CFG2['F_alg'] * per_gpu / (PEAK_BF16 / nprod)
+                line['roofline_step']['split_peak_tflops'] = PEAK_BF16 / nprod / 1e12
         if roof is not None:
             line['roofline'] = roof
             if roof_other:
@@ -300,8 +345,10 @@ def main():
             line['roofline_step'] = {'achieved_hbm_frac': CFG3['B_alg'] * per_gpu / PEAK_HBM,
                                      'achieved_f32_flop_frac': CFG3['F_alg'] * per_gpu / PEAK_F32,
                                      'alg_bytes_per_image': CFG3['B_alg'], 'alg_flop_per_image': CFG3['F_alg']}
+        if not a.no_f32_exact and world == 1 and K.MATH != 'f32':
+            line['f32_exact'] = f32_exact_run(a)
         if not a.no_cpu_baseline and world == 1 and a.arch == 'nafnet':
-            line['cpu_baseline'] = cpu_baseline(a.width, enc, a.size)
+            line['cpu_baseline'] = cpu_baseline(a.width, enc, a.size, a.batch)
         print(json.dumps(line), flush=True)
     if world > 1:
         barrier()

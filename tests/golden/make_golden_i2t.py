@@ -74,6 +74,37 @@ def clip_cases():
     np.savez_compressed(os.path.join(HERE, 'i2t_clip.npz'), **d)
 
 
+def clip_full_geometry_cases():
+    """BASELINE configs[3]'s encoders at their FULL width, 4 of their layers: CLIP ViT-L/14 (hidden 1024, 16 heads x 64,
+    MLP 4096, quick_gelu) and ViT-H/14 (hidden 1280, 16 heads x 80, MLP 5120, gelu) on a 224x224 image (257 tokens).
+    Weights (IO.synth_clip_params) and the image are regenerated from seeds by the test, so the fixture holds only a
+    strided sample of the output tokens and their statistics.  Pinned to the transformers version installed here
+    (the reference pins 4.31.0, requirements.txt:2 -- not vendored: parity unpinned against that exact version)."""
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    d = {'transformers_version': np.array(transformers.__version__)}
+    for tag, (hidden, inter, layers, heads, image, act) in {'L': (1024, 4096, 4, 16, 224, 'quick_gelu'),
+                                                            'H': (1280, 5120, 4, 16, 224, 'gelu')}.items():
+        cfg = CLIPVisionConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                               num_attention_heads=heads, image_size=image, patch_size=14, hidden_act=act)
+        m = CLIPVisionModel(cfg).eval()
+        sd = IO.synth_clip_params(hidden, inter, layers, 14, image, seed=ord(tag))
+        keys = list(m.state_dict().keys())
+        pref = 'vision_model.' if keys[0].startswith('vision_model.') else ''
+        missing = m.load_state_dict({pref + k: v for k, v in sd.items()}, strict=False)
+        assert not [k for k in missing.missing_keys if 'position_ids' not in k], missing
+        x = torch.rand(2, 3, image, image, generator=torch.Generator().manual_seed(200 + ord(tag)))
+        with torch.no_grad():
+            out = m(x, output_hidden_states=True)[0]
+        d[f'{tag}_cfg'] = np.array([hidden, inter, layers, heads, image])
+        d[f'{tag}_act'] = np.array(act)
+        d[f'{tag}_sample'] = out[:, ::8, ::4].numpy()
+        d[f'{tag}_stats'] = np.array([out.double().mean().item(), out.double().abs().mean().item(), out.double().std().item(),
+                                      out.double().abs().max().item()])
+        print('clip full geometry', tag, tuple(out.shape), d[f'{tag}_stats'])
+    np.savez_compressed(os.path.join(HERE, 'i2t_clip_full.npz'), **d)
+
+
 def mapper_case():
     ns = load_reference_defs({'Mapper'})
     din, dout, words, B, T = 48, 40, 2, 2, 16
@@ -136,6 +167,10 @@ def cross_attention_case():
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'clip_full':
+        clip_full_geometry_cases()
+        sys.exit(0)
     clip_cases()
+    clip_full_geometry_cases()
     mapper_case()
     cross_attention_case()

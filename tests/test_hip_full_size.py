@@ -134,7 +134,71 @@ def test_full_size_gradients_against_oracle(world, monkeypatch):
         if r > worst:
             worst, worst_k = r, k
     print(f'full-size gradients vs oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
-    assert worst < 5e-3, (worst, worst_k)
+    assert worst < 2e-3, (worst, worst_k)
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_batch4_against_oracle(world, monkeypatch):
+    """The headline workload itself -- 4 x 512x512, width 32, enc [1,1,1,28] -- straight against the oracle (torch fp32 on
+    the host cores; minutes): outputs to the north-star 1e-4 / 1e-3 dB, the loss, and every parameter gradient of the
+    product backward pass (loss-scaled fp16 split) against autograd through the oracle, the oracle following the HIP
+    match decisions where its own scores are a near-tie (same protocol as the single-pair tests above)."""
+    E, K, cfg, P, Pc = world
+    B = 4
+    lq, gt, ref = O.synth_pair(B, SIZE, SIZE, seed=83)
+    S = 2.0 ** math.floor(math.log2(512.0 * B * 3 * SIZE * SIZE))
+    prev = K.set_grad_scaled(True)
+    try:
+        out, saved = E.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
+        loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0, grad_scale=S)
+        G = {k: v.cpu() / S for k, v in E.net_bwd(dpred, Pc, cfg, saved).items()}
+    finally:
+        K.set_grad_scaled(prev)
+    sv_masa = saved[6]
+    hip_index, hip_index_all = sv_masa[4].cpu().long(), sv_masa[7].cpu().long()
+    seen = {}
+    orig_cs, orig_fs = O.coarse_search, O.fine_search
+
+    def cs(lrb, r4, dil):
+        total, index = orig_cs(lrb, r4, dil)
+        hi = hip_index.view_as(index)
+        gap = (total.gather(2, index.unsqueeze(2)) - total.gather(2, hi.unsqueeze(2))).squeeze(2)
+        seen['coarse'] = ((index != hi).sum().item(), index.numel(), gap.abs().max().item())
+        return total, hi
+
+    def fs(lrb_flat, refb):
+        val, idx, corr = orig_fs(lrb_flat, refb)
+        Bn = corr.shape[0]
+        hi = hip_index_all.view(Bn, -1)
+        v2 = corr.gather(2, hi.unsqueeze(2)).squeeze(2)
+        gap = val.reshape(Bn, -1) - v2
+        seen['fine'] = ((idx.reshape(Bn, -1) != hi).sum().item(), hi.numel(), gap.abs().max().item())
+        return v2.view_as(val), hi.view_as(idx), corr
+
+    monkeypatch.setattr(O, 'coarse_search', cs)
+    monkeypatch.setattr(O, 'fine_search', fs)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ro = O.nafnet_ref_forward(Pr, cfg, lq, ref)
+    rl = O.l1_loss(ro, gt)
+    rl.backward()
+    print('bs=4 match decisions (mismatches, total, largest oracle score gap at a mismatch):', seen)
+    assert seen['coarse'][0] <= 4 and seen['coarse'][2] < 1e-5, seen
+    assert seen['fine'][0] <= 32 and seen['fine'][2] < 1e-5, seen
+    o = out.cpu()
+    diff = (o - ro.detach()).abs()
+    print(f'bs=4 full size vs oracle: max {diff.max().item():.3e} mean {diff.mean().item():.3e}')
+    assert diff.max().item() < 1e-4
+    assert abs(psnr(o.clamp(0, 1), gt) - psnr(ro.detach().clamp(0, 1), gt)) < 1e-3
+    assert abs(loss.item() - rl.item()) < 1e-6
+    worst, worst_k = 0.0, None
+    for k, p in Pr.items():
+        if p.grad is None:
+            continue
+        r = (G[k].reshape(p.grad.shape) - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
+        if r > worst:
+            worst, worst_k = r, k
+    print(f'bs=4 full-size gradients vs oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
+    assert worst < 2e-3, (worst, worst_k)
 
 
 def test_full_size_batch_permutation_is_bit_exact(world):
@@ -306,7 +370,90 @@ def test_restormer_full_size_gradients_against_oracle(rworld, monkeypatch):
         if r > worst:
             worst, worst_k = r, k
     print(f'restormer full-size gradients vs oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
-    assert worst < 5e-3, (worst, worst_k)
+    assert worst < 2e-3, (worst, worst_k)
+
+
+@pytest.mark.timeout(1500)
+def test_restormer_configs4_shapes_512_batch2(rworld, monkeypatch):
+    """BASELINE configs[4]'s per-GPU workload -- Restormer-ref dim 48 [4,6,6,8] at 2 x 512x512 (64 LR blocks per image,
+    MDTA Gram matrices over 262 144 pixels): one 512x512 pair straight against the oracle (same two-step match protocol),
+    then the bs = 2 batch through size-independent properties: batch-permutation equivariance (bit-exact), the fp16-split
+    arithmetic against exact fp32 MFMA (north-star 1e-4 / 1e-3 dB), and a finite loss-scaled backward pass whose
+    gradients agree with the unscaled 3-way-bf16 backward."""
+    R, RO, K, cfg, P, Pc = rworld
+    S512 = 512
+    lq, gt, ref = O.synth_pair(1, S512, S512, seed=93)
+    out, saved = R.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
+    sv_masa = saved[6]
+    hip_index, hip_index_all = sv_masa[4].cpu().long(), sv_masa[7].cpu().long()
+    assert hip_index.numel() == 64 and hip_index_all.numel() == 64 * 64
+    seen = {}
+    orig_cs, orig_fs = O.coarse_search, O.fine_search
+
+    def cs(lrb, r4, dil):
+        total, index = orig_cs(lrb, r4, dil)
+        hi = hip_index.view_as(index)
+        gap = (total.gather(2, index.unsqueeze(2)) - total.gather(2, hi.unsqueeze(2))).squeeze(2)
+        seen['coarse'] = ((index != hi).sum().item(), index.numel(), gap.abs().max().item())
+        return total, hi
+
+    def fs(lrb_flat, refb):
+        val, idx, corr = orig_fs(lrb_flat, refb)
+        B = corr.shape[0]
+        hi = hip_index_all.view(B, -1)
+        v2 = corr.gather(2, hi.unsqueeze(2)).squeeze(2)
+        seen['fine'] = ((idx.reshape(B, -1) != hi).sum().item(), hi.numel(), (val.reshape(B, -1) - v2).abs().max().item())
+        return v2.view_as(val), hi.view_as(idx), corr
+
+    monkeypatch.setattr(O, 'coarse_search', cs)
+    monkeypatch.setattr(O, 'fine_search', fs)
+    with torch.no_grad():
+        ro = RO.restormer_ref_forward(P, cfg, lq, ref)
+    print('restormer 512 match decisions (mismatches, total, largest oracle score gap at a mismatch):', seen)
+    assert seen['coarse'][0] <= 4 and seen['coarse'][2] < 1e-5, seen
+    assert seen['fine'][0] <= 16 and seen['fine'][2] < 1e-5, seen
+    diff = (out.cpu() - ro).abs()
+    print(f'restormer 512x512 vs oracle: max {diff.max().item():.3e} mean {diff.mean().item():.3e}')
+    assert diff.max().item() < 1e-4
+    assert abs(psnr(out.cpu().clamp(0, 1), gt) - psnr(ro.clamp(0, 1), gt)) < 1e-3
+    del out, saved
+    # ---- bs = 2 properties
+    lq, gt, ref = O.synth_pair(2, S512, S512, seed=94)
+    lq, ref, gtc = lq.cuda(), ref.cuda(), gt.cuda()
+    out, saved = R.net_fwd(Pc, cfg, lq, ref)
+    outp, _ = R.net_fwd(Pc, cfg, lq[[1, 0]].contiguous(), ref[[1, 0]].contiguous())
+    assert torch.equal(outp, out[[1, 0]])
+    K.set_math('f32')
+    try:
+        exact, saved_x = R.net_fwd(Pc, cfg, lq, ref)
+    finally:
+        K.set_math('hx2')
+    d = (out - exact).abs()
+    flips = (saved[6][7] != saved_x[6][7]).sum().item() + (saved[6][4] != saved_x[6][4]).sum().item()
+    print(f'restormer 512x512 bs 2: fp16 split vs exact fp32: max {d.max().item():.2e} mean {d.mean().item():.2e}, {flips} of 8320 match decisions differ')
+    if flips == 0:
+        assert d.max().item() < 1e-4
+    else:       # a near-tie of the hard-attention arg-max resolved the other way (1e-7 feature differences): a patch of pixels moves
+        assert flips <= 4 and d.mean().item() < 1e-6 and (d > 1e-4).float().mean().item() < 2e-3
+    assert abs(psnr(out.clamp(0, 1), gtc) - psnr(exact.clamp(0, 1), gtc)) < 1e-3
+    del exact, outp, saved_x
+    Sg = 2.0 ** math.floor(math.log2(512.0 * 2 * 3 * S512 * S512))
+    grads = []
+    for gs in (1.0, Sg):
+        prev = K.set_grad_scaled(gs != 1.0)
+        try:
+            o2, sv = R.net_fwd(Pc, cfg, lq, ref)
+            loss, dpred = K.l1_loss(o2.contiguous(), gtc, 1.0, grad_scale=gs)
+            grads.append({k: v.clone() / gs for k, v in R.net_bwd(dpred, Pc, cfg, sv).items()})
+        finally:
+            K.set_grad_scaled(prev)
+        del o2, sv
+    worst = 0.0
+    for k, g0 in grads[0].items():
+        assert torch.isfinite(grads[1][k]).all(), k
+        worst = max(worst, (grads[1][k] - g0).abs().max().item() / max(g0.abs().max().item(), 1e-30))
+    print(f'restormer 512x512 bs 2: loss-scaled fp16-split backward vs unscaled bf16-split backward, worst relative {worst:.2e}')
+    assert worst < 3e-4, worst         # (Gram / attention contractions over 262 144 pixels; 1.3e-4 measured)
 
 
 def test_full_size_graph_replay_matches_eager_steps(monkeypatch):
@@ -339,3 +486,36 @@ def test_full_size_graph_replay_matches_eager_steps(monkeypatch):
     for a, b in zip(*losses):
         assert a == a and abs(a - b) < 1e-6, losses
     assert losses[0][-1] < losses[0][0]          # and it trains
+
+
+def test_full_size_deterministic_graph_replay_is_bit_exact(monkeypatch):
+    """TDR_DETERMINISTIC=1: with the MASA transfer backward on 64-bit fixed-point accumulation no reduction of the step
+    depends on arrival order any more -- the captured-graph steps and the eager steps of the headline configuration must
+    then agree BIT FOR BIT: every loss and every parameter after five steps."""
+    _need_gpu()
+    import bench
+    from textualdegremoval_amd import kernels as K
+    from textualdegremoval_amd.models import create_model
+    from textualdegremoval_amd.utils.synthetic import randomize_gates, synthetic_pair
+    data = {k: v.cuda() for k, v in synthetic_pair(4, SIZE, SIZE, seed=4321).items()}
+    monkeypatch.setattr(K, 'DETERMINISTIC', True)
+    losses, params = [], []
+    for graph in (True, False, False):
+        monkeypatch.setenv('TDR_GRAPH', '1' if graph else '0')
+        torch.manual_seed(0)
+        model = create_model(bench.make_opt(32, [1, 1, 1, 28], SIZE, False))
+        randomize_gates(model.net_g)
+        ls = []
+        for it in range(1, 6):
+            model.update_learning_rate(it, warmup_iter=-1)
+            model.feed_train_data(data)
+            model.optimize_parameters(it)
+            ls.append(model.get_current_log()['l_pix'])
+        assert model.use_hip_graph == graph
+        losses.append(ls)
+        params.append(torch.cat([p.detach().reshape(-1) for p in model.net_g.parameters()]).cpu())
+        del model
+        torch.cuda.empty_cache()
+    assert losses[0] == losses[1] == losses[2], losses
+    assert torch.equal(params[1], params[2])           # eager vs eager: run-to-run
+    assert torch.equal(params[0], params[1])           # graph replay vs eager

@@ -54,6 +54,30 @@ def test_clip_vision_encoder_vs_transformers_golden(K, tag):
     assert maxdiff(token_major(tok, Tn), T(g[tag + '_out'])) < 1e-4
 
 
+@pytest.mark.parametrize('tag', ['L', 'H'])
+def test_clip_full_geometry_vs_transformers_golden(K, tag):
+    """BASELINE configs[3]'s encoders at full width (ViT-L/14: 1024 / 16 heads / MLP 4096 / quick_gelu; ViT-H/14: 1280 / 16
+    heads of 80 / MLP 5120 / gelu), 4 layers, 224x224 -> 257 tokens, batch 2: against transformers' CLIPVisionModel as
+    installed in the build container (tests/golden/make_golden_i2t.py::clip_full_geometry_cases; weights and image are
+    regenerated here from the same seeds).  "Parity unpinned" against the reference's transformers 4.31.0, which is not
+    vendored.  Token magnitudes reach ~300 (no post-LayerNorm, random weights), hence the relative tolerance."""
+    from textualdegremoval_amd.clip_vision import ClipVisionEncoder
+    g = gold('i2t_clip_full')
+    hidden, inter, layers, heads, image = [int(v) for v in g[tag + '_cfg']]
+    sd = IO.synth_clip_params(hidden, inter, layers, 14, image, seed=ord(tag))
+    enc = ClipVisionEncoder({'vision_model.' + k: v for k, v in sd.items()}, 'cuda', heads, act=str(g[tag + '_act']))
+    x = torch.rand(2, 3, image, image, generator=torch.Generator().manual_seed(200 + ord(tag)))
+    tok, Tn = enc.tokens(x.cuda())
+    assert Tn == 256
+    out = token_major(tok, Tn).cpu()
+    assert out.shape == (2, 257, hidden)
+    ref = T(g[tag + '_sample'])
+    scale = float(g[tag + '_stats'][3])
+    assert maxdiff(out[:, ::8, ::4], ref) < 2e-5 * scale
+    st = np.array([out.double().mean().item(), out.double().abs().mean().item(), out.double().std().item(), out.double().abs().max().item()])
+    assert np.allclose(st, g[tag + '_stats'], rtol=0, atol=2e-5 * scale)
+
+
 def test_clip_encode_resizes_like_the_reference_call(K):
     """F.interpolate(image, (S, S), 'bilinear') then the encoder (main_train_i2t_mapping.py:726-730)."""
     import torch.nn.functional as F

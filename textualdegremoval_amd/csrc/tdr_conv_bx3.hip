@@ -29,26 +29,8 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// TDR_PROBE (profiling builds only, profiles/probes/): ablations of the main loop --
-// 1: no operand (pixel) global loads after the prologue   2: no MFMAs (operands kept live)
-// 3: no weight-fragment loads after the prologue          4: no LDS stores / barriers after the prologue
-// conv1x1_hx2_kernel: 11: no operand loads after the prologue   12: no MFMAs   13: no epilogue   14: return after the
-// prologue (launch + first stage)   15: no conversion / LDS stores after the prologue
-#ifndef TDR_PROBE
-#define TDR_PROBE 0
-#endif
-
-
-#if TDR_PROBE == 5
-// timeline probe: wave 0 of a few blocks stamps s_memtime at the phase boundaries of the main loop
-__device__ unsigned long long tdr_probe_ts[8][64];
-#define TDR_STAMP(slot) do { const int s__ = (slot); if (probe_on && s__ < 64) tdr_probe_ts[probe_blk][s__] = __builtin_readcyclecounter(); } while (0)
-extern "C" int tdr_probe_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tdr_probe_ts), sizeof(tdr_probe_ts));
-}
-#else
-#define TDR_STAMP(slot) do { } while (0)
-#endif
+// (the ablation / timeline probe variants of round 1 -- profiles/README.md -- were built from this file at commit 7d0042b;
+// the product source carries no probe code)
 
 namespace {
 
@@ -237,12 +219,6 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             for (int s = 0; s < NS; ++s) dst[tm][s].u = wfrag[tm][gt * wstep + s * 64];
     };
 
-#if TDR_PROBE == 5
-    const int probe_blk = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : 7));
-    const bool probe_on = tid == 0 && blockIdx.z == 0 && probe_blk < 7;
-    int probe_slot = 0;
-#endif
-    TDR_STAMP(probe_slot++);                      // 0: kernel start (after geometry)
     if constexpr (AD > 0) {
 #pragma unroll
         for (int d = 0; d < AD; ++d) load_a(aq[d], min((long)d, (long)ngroups * TAPS - 1));
@@ -252,11 +228,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < PF; ++p)
         if (p < ngroups) load_group(p, p);
-    TDR_STAMP(probe_slot++);                      // 1: prologue loads issued
     store_group(0, 0, 0);
-    TDR_STAMP(probe_slot++);                      // 2: group 0 converted + stored (includes the load wait)
     __syncthreads();
-    TDR_STAMP(probe_slot++);                      // 3: first barrier passed
 
     for (int g0 = 0; g0 < ngroups; g0 += PF) {
 #pragma unroll
@@ -265,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             if (g < ngroups) {
                 const int buf = a.single_buf ? 0 : (g & 1);
                 const uint4* sb = smem4 + buf * (2 * NS) * plane;
-                if (TDR_PROBE != 1 && PF == 1 && g + 1 < ngroups) load_group(g + 1, 0);
+                if (PF == 1 && g + 1 < ngroups) load_group(g + 1, 0);
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
                     const int tapoff = (tap / KH) * LW + (tap % KH);
@@ -273,9 +246,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                     // the fragments (in-order vmcnt) then leaves the operand loads in flight.
                     // (the last prefetch of the last group re-reads a valid slot)
                     const long gtn = min((long)g * TAPS + tap + 1, (long)ngroups * TAPS - 1);
-                    if (TDR_PROBE != 3 && AD == 0) load_a(afn, gtn);
+                    if (AD == 0) load_a(afn, gtn);
                     Frag (&afc)[TM][NS] = AD > 0 ? aq[AD > 0 ? tap % (AD > 0 ? AD : 1) : 0] : af;
-                    if (TDR_PROBE != 1 && PF > 1 && tap == 0 && g + PF < ngroups) load_group(g + PF, u);   // set u is free: group g already sits in LDS
+                    if (PF > 1 && tap == 0 && g + PF < ngroups) load_group(g + PF, u);   // set u is free: group g already sits in LDS
                     Frag bf[TN][NS];
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
@@ -290,20 +263,13 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn) {
-#if TDR_PROBE == 2
-                                if (q == 0)
-                                    asm volatile("" ::"v"(__builtin_bit_cast(f32x4, afc[tm][0].v)), "v"(__builtin_bit_cast(f32x4, afc[tm][1].v)),
-                                                 "v"(__builtin_bit_cast(f32x4, afc[tm][NS - 1].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][0].v)),
-                                                 "v"(__builtin_bit_cast(f32x4, bf[tn][1].v)), "v"(__builtin_bit_cast(f32x4, bf[tn][NS - 1].v)));
-#else
                                 if constexpr (SCH == SCH_HX2)
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
                                 else
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
-#endif
                             }
                     if constexpr (AD > 0) {      // the slot is consumed: request the fragments AD steps ahead into it
-                        if (TDR_PROBE != 3) load_a(aq[tap % (AD > 0 ? AD : 1)], min((long)g * TAPS + tap + AD, (long)ngroups * TAPS - 1));
+                        load_a(aq[tap % (AD > 0 ? AD : 1)], min((long)g * TAPS + tap + AD, (long)ngroups * TAPS - 1));
                     } else {
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm)
@@ -311,24 +277,19 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                             for (int s = 0; s < NS; ++s) af[tm][s] = afn[tm][s];
                     }
                 }
-                TDR_STAMP(probe_slot++);                  // 4+3g: MFMA phase of group g issued
-                if (TDR_PROBE != 4) {
+                {
                     if (a.single_buf) __syncthreads();        // one LDS buffer: every wave is done reading group g
                     if (g + 1 < ngroups) store_group(g + 1, (u + 1) % PF, a.single_buf ? 0 : (buf ^ 1));
-                    TDR_STAMP(probe_slot++);              // 5+3g: next group converted + stored
                     __syncthreads();
-                    TDR_STAMP(probe_slot++);              // 6+3g: barrier passed
                 }
             }
         }
     }
 
-    TDR_STAMP(probe_slot++);                      // main loop done
     if constexpr (EPI != EPI_PSHUF) {
         if (a.vec_epi) {
             __syncthreads();                              // every wave is done with the operand tiles
             conv_epilogue_vec<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, lane, reinterpret_cast<float*>(smem4) + wave * (32 * 36));
-            TDR_STAMP(probe_slot++);              // epilogue stores issued
             return;
         }
     }
@@ -472,9 +433,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
         if (p < nstages) load_stage(p, p);
     store_stage(0, 0);
     __syncthreads();
-#if TDR_PROBE == 14
-    if (a.Cin > 0) return;
-#endif
 
     for (int s0 = 0; s0 < nstages; s0 += PFD) {
 #pragma unroll
@@ -490,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
                         load_a(afn, min(g + 1, ngroups - 1));
                         // set u is free (stage st already sits in LDS): the loads of stage st + PFD go out behind the
                         // first weight-fragment prefetch, so the in-order wait for the fragments leaves them in flight
-                        if (TDR_PROBE != 11 && gg == 0 && st + PFD < nstages) load_stage(st + PFD, u);
+                        if (gg == 0 && st + PFD < nstages) load_stage(st + PFD, u);
                         Frag bf[TN][NS];
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
@@ -503,13 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
                             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                                 for (int tn = 0; tn < TN; ++tn) {
-#if TDR_PROBE == 12
-                                    if (q == 0)
-                                        asm volatile("" ::"v"(__builtin_bit_cast(f32x4, af[tm][0].u)), "v"(__builtin_bit_cast(f32x4, af[tm][1].u)),
-                                                     "v"(__builtin_bit_cast(f32x4, bf[tn][0].u)), "v"(__builtin_bit_cast(f32x4, bf[tn][1].u)));
-#else
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
-#endif
                                 }
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm)
@@ -517,29 +469,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
                             for (int s = 0; s < NS; ++s) af[tm][s] = afn[tm][s];
                     }
                 }
-#if TDR_PROBE == 15
-                __syncthreads();
-                continue;
-#endif
                 if (st + 1 < nstages) store_stage((u + 1) % PFD, buf ^ 1);
                 __syncthreads();
             }
         }
     }
 
-#if TDR_PROBE == 13
-    {
-        float sacc = 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[tm][tn][r];
-        if (sacc == 1.2345e33f) a.out[0] = sacc;
-        return;
-    }
-#endif
     if constexpr (EPI != EPI_PSHUF) {
         if (a.vec_epi) {
             conv_epilogue_vec<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, lane, reinterpret_cast<float*>(smem4) + wave * (32 * 36));

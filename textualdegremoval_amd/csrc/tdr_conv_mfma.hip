@@ -19,12 +19,6 @@
 #include "tdr_pack.h"
 #include "../../include/tdr.h"
 
-// TDR_PROBE (profiling builds only, see profiles/probes/): 1 = no global loads inside the K loop,
-// 2 = no LDS staging/barriers inside the K loop, 3 = no LDS fragment reads (MFMA + loop only).
-#ifndef TDR_PROBE
-#define TDR_PROBE 0
-#endif
-
 namespace {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -159,12 +153,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
     load_chunk(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (TDR_PROBE < 2 || ch == 0) {
+        {
             __syncthreads();
             store_chunk(ch);
             __syncthreads();
         }
-        if (TDR_PROBE == 0 && ch + 1 < nchunks) load_chunk(ch + 1);
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int tapoff = (tap / KH) * D * LW + (tap % KH) * D;
@@ -173,10 +167,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 float af[TM], bf[TN];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                    af[tm] = TDR_PROBE == 3 ? (float)(tap + c2 + tm) : s_w[abase + (tap * CK + 2 * c2) * BM + tm * 32];
+                    af[tm] = s_w[abase + (tap * CK + 2 * c2) * BM + tm * 32];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    bf[tn] = TDR_PROBE == 3 ? (float)(tap - c2 + tn + lane) : s_in[bbase[tn] + 2 * c2 * plane + tapoff];
+                    bf[tn] = s_in[bbase[tn] + 2 * c2 * plane + tapoff];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

@@ -30,17 +30,6 @@ union HFrag {
     f16x8 hv;
 };
 
-#ifndef NB_PROBE
-#define NB_PROBE 0          // profiling builds only (profiles/probe_nafblock.py): 1 no side stores, 2 no MFMAs, 3 both
-#endif
-#if NB_PROBE & 8
-// timeline probe (profiling builds only): wave 0 and wave 5 of two workgroups stamp the cycle counter at the phase boundaries
-__device__ unsigned long long nb_ts[4][16];
-#define NB_STAMP(k) do { if (nb_slot >= 0 && lane == 0) nb_ts[nb_slot][k] = __builtin_readcyclecounter(); } while (0)
-extern "C" int tdr_nb_probe_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nb_ts), sizeof(nb_ts)); }
-#else
-#define NB_STAMP(k) do { } while (0)
-#endif
 constexpr int NPX = 64;                       // pixels per workgroup
 __device__ __forceinline__ int swz(int slot) { return slot ^ ((slot >> 4) & 3); }
 __device__ __forceinline__ int row_of(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
@@ -93,17 +82,9 @@ __device__ __forceinline__ void gemm_hx2(f32x16 (&acc)[TMW][2], const uint4* __r
             for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
-#if NB_PROBE & 2
-                    { if (q == 0) asm volatile("" ::"v"(__builtin_bit_cast(f32x4, af[g % PF][tm][0].u)), "v"(__builtin_bit_cast(f32x4, af[g % PF][tm][1].u)), "v"(__builtin_bit_cast(f32x4, bf[tn][0].u)), "v"(__builtin_bit_cast(f32x4, bf[tn][1].u))); }
-#else
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g % PF][tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
-#endif
-#if !(NB_PROBE & 16)
         if (g + PF < NG) load_a(g % PF, g + PF);
-#endif
-#if !(NB_PROBE & 1)
         side(g);
-#endif
     }
 }
 
@@ -161,17 +142,9 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
     const long p0 = (long)blockIdx.x * NPX;
     const long HW = a.HW;
     const int m0 = 32 * wave;                                 // first channel row of this wave
-#ifdef NB_NOROT
-    const int rot = 0;
-#else
     const int rot = (int)(blockIdx.x * 5);   // (not a function of the image index: batch-permutation equivariance stays bit-exact)
-#endif
     // row r of this lane: channel m0 + row_of(r, kk); element offset of (row r, pixel j of sub-tile tn) in an [*, HW] image
     auto off = [&](int r, int tn) { return (long)(m0 + row_of(r, kk)) * HW + 32 * tn; };
-#if NB_PROBE & 8
-    const int nb_slot = ((blockIdx.x == 0 && blockIdx.y == 0) ? 0 : ((blockIdx.x == 37 && blockIdx.y == 2) ? 2 : -100)) + (wave == 0 ? 0 : (wave == 5 ? 1 : -100));
-#endif
-    NB_STAMP(0);
 
     // ---- residual tile (inp) in accumulator layout: requested first, consumed after the first GEMM
     float xr[2][16];
@@ -217,7 +190,6 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
         bev[r] = a.beta[m0 + row_of(r, kk)];
     }
     __syncthreads();
-    NB_STAMP(1);
 
     // ---- conv3: y = (W3 (g*sca) + b3) * beta + inp
     f32x16 acc[1][2];
@@ -227,7 +199,6 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
     gemm_hx2<1, NG, 4>(acc, a.w3, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [](int) {});
 
-    NB_STAMP(2);
     float yv[2][16];
     float psum[2] = {0.f, 0.f};
 #pragma unroll
@@ -292,7 +263,6 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
         }
     }
     __syncthreads();
-    NB_STAMP(3);
 
     // ---- conv4: t4 = W4 yn + b4 ; rows [32w, 32w+32) and their gate partners [C + 32w, C + 32w + 32)
     f32x16 acc4[2][2];
@@ -315,7 +285,6 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
             }
         });
     }
-    NB_STAMP(4);
     float b4v[2][16];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -342,7 +311,6 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
         gav[r] = a.gamma[m0 + row_of(r, kk)];
     }
     __syncthreads();
-    NB_STAMP(5);
 
     // ---- conv5: out = (W5 gate + b5) * gamma + y ; the t4 tile leaves for HBM under its MFMAs
 #pragma unroll
@@ -357,7 +325,6 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
             for (int e = 0; e < 4; ++e) tp[(long)tm * C * HW + off(r0 + e, tn)] = acc4[tm][tn][r0 + e];
         });
     }
-    NB_STAMP(6);
     {
         float* op = a.out + (long)n * a.out_ns + p0 + j;
 #pragma unroll
@@ -365,7 +332,6 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) op[off(r, tn)] = (acc[0][tn][r] + b5v[r]) * gav[r] + yv[tn][r];
     }
-    NB_STAMP(7);
 }
 
 
@@ -416,11 +382,7 @@ __global__ __launch_bounds__(512, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     const long p0 = (long)blockIdx.x * NPX;
     const long HW = a.HW;
     const int m0 = 32 * wave;
-#ifdef NB_NOROT
-    const int rot = 0;
-#else
     const int rot = (int)(blockIdx.x * 5);   // (not a function of the image index: batch-permutation equivariance stays bit-exact)
-#endif
     auto off = [&](int r, int tn) { return (long)(m0 + row_of(r, kk)) * HW + 32 * tn; };
 
     f32x16 acc[1][2];

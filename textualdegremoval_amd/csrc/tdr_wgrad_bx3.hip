@@ -84,11 +84,6 @@ __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h
 // the register budget a prefetch would need.  Tiles that start a column are staged synchronously.
 // CL = log2 of the tile width C (a template constant: the staging index arithmetic divides by C-derived sizes for
 // every item of every tile; with run-time divisors that integer math out-weighed the MFMAs)
-// TDR_WPROBE (profiling builds, profiles/probe_wgrad.py; 1x1 / PRE kernels): 1: no operand loads after the first tile
-// 2: no MFMAs   3: no conversion / LDS stores after the first tile   4: no partial-sum stores
-#ifndef TDR_WPROBE
-#define TDR_WPROBE 0
-#endif
 template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL, int SCH>
 __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     constexpr int NS = SCH == WSCH_HX2 ? 2 : 3;      // operand planes
@@ -330,11 +325,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     for (int t = t_begin; t < t_end; ++t) {
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA pieces have landed
         __syncthreads();
-        if constexpr (PRE) { if (TDR_WPROBE != 3 || t == t_begin) commit(); }
+        if constexpr (PRE) commit();
         else if constexpr (DMA) stage_sync(t, steady(t));
         else stage_sync(t);
         __syncthreads();
-        if (TDR_WPROBE != 1 && PRE && t + 1 < t_end) prefetch(t + 1);
+        if (PRE && t + 1 < t_end) prefetch(t + 1);
         if (DMA && t + 1 < t_end && steady(t + 1)) dma_issue(t + 1);
         int ring0 = 0;
         if (KH == 3) { int ox0_, ty_; tile_origin(t, ring0, ox0_, ty_); }
@@ -361,11 +356,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
                     for (int x = 0; x < TMW; ++x)
 #pragma unroll
                         for (int y = 0; y < TNW; ++y) {
-#if TDR_WPROBE == 2
-                            if (p == 0) asm volatile("" ::"v"(af[x][0]), "v"(af[x][1]), "v"(bf[y][0]), "v"(bf[y][1]));
-#else
                             acc[x][y][0] = mma(af[x][SA[p]], bf[y][SB[p]], acc[x][y][0]);
-#endif
                         }
             } else {
 #pragma unroll
@@ -439,20 +430,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         }
         if (wk != 0) return;
     }
-#if TDR_WPROBE == 4
-    {
-        float sacc = 0.f;
-#pragma unroll
-        for (int x = 0; x < TMW; ++x)
-#pragma unroll
-            for (int y = 0; y < TNW; ++y)
-#pragma unroll
-                for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc += acc[x][y][t][r];
-        if (sacc != 1.2345e33f) return;
-    }
-#endif
     // partial[split][co][ci][tap]
     float* part = a.part + (long)split * a.Cout * a.Cin * TAPS;
 #pragma unroll
