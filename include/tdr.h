@@ -387,7 +387,7 @@ int tdr_adamw_step_dev(float* const* params, const float* const* grads, float* c
  *   y = x + conv3(g * sca) * beta;  yn = norm2(y);  t4 = conv4(yn);  out = y + conv5(t4[:, :C] * t4[:, C:]) * gamma
  * One workgroup owns 64 pixels x all channels; every tensor the backward pass keeps (y, mu, rs, yn, t4) is an output.
  * w3/w4/w5: tdr_pack_weights_hx2(mode FWD) of conv3 (C x C), conv4 (2C x C), conv5 (C x C); w_fmt must be 2.
- * Supported: tdr_naf_tail_supported(C, HW) (C == 256, HW % 64 == 0 -- the 64x64 level of BASELINE configs[1]). */
+ * Supported: tdr_naf_tail_supported(C, HW): C in {32, 64, 128, 256} (C / 32 waves per workgroup), HW % 64 == 0. */
 typedef struct TdrNafTailDesc {
     int N, C, HW, w_fmt;
     float eps;

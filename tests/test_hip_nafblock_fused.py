@@ -31,12 +31,11 @@ def block_params(c, seed):
     return P
 
 
-@pytest.mark.parametrize('N,H,W', [(2, 16, 16), (1, 8, 24), (4, 64, 64)])
-def test_fused_tail_matches_oracle_and_unfused(N, H, W):
+@pytest.mark.parametrize('c,N,H,W', [(256, 2, 16, 16), (256, 1, 8, 24), (256, 4, 64, 64), (128, 2, 32, 32), (64, 1, 64, 32), (32, 2, 32, 64)])
+def test_fused_tail_matches_oracle_and_unfused(c, N, H, W):
     from textualdegremoval_amd import engine as E, kernels as K
     if K.MATH != 'hx2':
         pytest.skip('fused blocks run on the fp16-split path')
-    c = 256
     P = block_params(c, seed=11)
     Pc = {k: v.cuda() for k, v in P.items()}
     x = rnd(N, c, H, W, seed=5)

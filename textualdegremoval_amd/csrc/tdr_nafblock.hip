@@ -108,6 +108,15 @@ __device__ __forceinline__ void tile_to_planes(const float (&v)[16], uint4* sB, 
     }
 }
 
+// sum over the NW waves' partials of one pixel column (fixed order)
+template <int NW>
+__device__ __forceinline__ float wave_partials_sum(const float* rp) {
+    float t = rp[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += rp[w * NPX];
+    return t;
+}
+
 struct TailArgs {
     const float* g; long g_ns;
     const float* sca;                 // [N][C]
@@ -123,15 +132,15 @@ struct TailArgs {
     int HW;
 };
 
-// 512 threads = 8 waves, two per SIMD: wave w owns the 32 channels [32w, 32w + 32) of the C-row GEMMs and, in conv4,
+// 2C threads = C/32 waves (C = 256: 8 waves, two per SIMD): wave w owns the 32 channels [32w, 32w + 32) of the C-row GEMMs and, in conv4,
 // also their SimpleGate partners [C + 32w, C + 32w + 32).  While one wave of a SIMD waits on LDS / L2 / the store
 // queue its partner's MFMAs run.
 template <int C>
-__global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
-    static_assert(C == 256, "8 waves x 32 channel rows: C = 256");
+__global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
+    static_assert(C == 256 || C == 128 || C == 64 || C == 32, "C / 32 waves x 32 channel rows");
     constexpr int NOCT = C / 8;               // octets of the K = C operands
     constexpr int NG = C / 16;
-    constexpr int NW = 8;
+    constexpr int NW = C / 32;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     uint4* sB = smem4;                                        // 2 planes x NOCT x 64 px x 16 B = 64 KiB
     float* red = reinterpret_cast<float*>(smem4 + 2 * NOCT * NPX);   // [2][8 waves][64 px]
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const float* rp = red + 32 * tn + j;
-        mean[tn] = (((rp[0] + rp[NPX]) + (rp[2 * NPX] + rp[3 * NPX])) + ((rp[4 * NPX] + rp[5 * NPX]) + (rp[6 * NPX] + rp[7 * NPX]))) * (1.f / C);
+        mean[tn] = wave_partials_sum<NW>(rp) * (1.f / C);
     }
     float pvar[2] = {0.f, 0.f};
 #pragma unroll
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const float* rp = red + NW * NPX + 32 * tn + j;
-        const float var = (((rp[0] + rp[NPX]) + (rp[2 * NPX] + rp[3 * NPX])) + ((rp[4 * NPX] + rp[5 * NPX]) + (rp[6 * NPX] + rp[7 * NPX]))) * (1.f / C);
+        const float var = wave_partials_sum<NW>(rp) * (1.f / C);
         rstd[tn] = 1.f / sqrtf(var + a.eps);
         if (wave == 0 && kk == 0) {
             a.mu[(long)n * HW + p0 + 32 * tn + j] = mean[tn];
@@ -276,12 +285,13 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
         float* yp = a.y + (long)n * a.y_ns + p0 + j;
         float* ynp = a.yn + (long)n * a.yn_ns + p0 + j;
         gemm_hx2<2, NG, 3>(acc4, a.w4, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
-            // 64 dword stores (y, yn: 2 sub-tiles x 16 rows each) spread over the 16 groups: 4 per group
-            const int tn = g >> 3, r0 = 2 * (g & 7);
+            // 64 dword stores (y, yn: 2 sub-tiles x 16 rows each) spread evenly over the NG groups
+            constexpr int IPG = 32 / NG;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                yp[off(r0 + e, tn)] = yv[tn][r0 + e];
-                ynp[off(r0 + e, tn)] = ynv[tn][r0 + e];
+            for (int e = 0; e < IPG; ++e) {
+                const int idx = g * IPG + e, tn = idx >> 4, r = idx & 15;
+                yp[off(r, tn)] = yv[tn][r];
+                ynp[off(r, tn)] = ynv[tn][r];
             }
         });
     }
@@ -320,9 +330,12 @@ __global__ __launch_bounds__(512, 2) void naf_tail_fwd_kernel(TailArgs a) {
     {
         float* tp = a.t4 + (long)n * a.t4_ns + p0 + j;
         gemm_hx2<1, NG, 4>(acc, a.w5, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
-            const int tm = g >> 3, tn = (g >> 2) & 1, r0 = 4 * (g & 3);          // 64 stores: 4 per group
+            constexpr int IPG = 64 / NG;                                         // 64 stores spread evenly over the NG groups
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tp[(long)tm * C * HW + off(r0 + e, tn)] = acc4[tm][tn][r0 + e];
+            for (int e = 0; e < IPG; ++e) {
+                const int idx = g * IPG + e, tm = idx >> 5, tn = (idx >> 4) & 1, r = idx & 15;
+                tp[(long)tm * C * HW + off(r, tn)] = acc4[tm][tn][r];
+            }
         });
     }
     {
@@ -369,9 +382,9 @@ __device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 l
 // `dout` = dt1 [N, 2C, HW], `w4t` = conv1's DGRAD_S1 fragments) followed by norm1's backward + the y-branch gradient in
 // `res`: the same K = 2C GEMM + LayerNorm epilogue without the conv5 / SimpleGate front.
 template <int C, bool HEAD>
-__global__ __launch_bounds__(512, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
-    static_assert(C == 256, "8 waves x 32 channel rows: C = 256");
-    constexpr int NW = 8;
+__global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
+    static_assert(C == 256 || C == 128 || C == 64 || C == 32, "C / 32 waves x 32 channel rows");
+    constexpr int NW = C / 32;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     uint4* sB = smem4;                                        // up to 2 planes x (2C/8) octets x 64 px x 16 B = 128 KiB
     float* red = reinterpret_cast<float*>(smem4 + 2 * (2 * C / 8) * NPX);   // [2][8 waves][64 px]
@@ -501,9 +514,13 @@ __global__ __launch_bounds__(512, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     } else {
         float* dp = a.dt4 + (long)n * a.dt4_ns + p0 + j;
         gemm_hx2<1, 2 * C / 16, 4>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [&](int g) {
-            const int tn = g >> 4, r = g & 15;                 // 64 dword stores: 2 per group
-            dp[off(r, tn)] = da[tn][r];
-            dp[(long)C * HW + off(r, tn)] = db[tn][r];
+            constexpr int IPG = 32 / (2 * C / 16);             // 64 dword stores spread evenly over the groups
+#pragma unroll
+            for (int e = 0; e < IPG; ++e) {
+                const int idx = g * IPG + e, tn = idx >> 4, r = idx & 15;
+                dp[off(r, tn)] = da[tn][r];
+                dp[(long)C * HW + off(r, tn)] = db[tn][r];
+            }
         });
     }
     // ---- LayerNorm backward: g = dyn * w ; dx = (g - yhat * mean_c(g * yhat) - mean_c(g)) * rstd ; + dout
@@ -555,8 +572,8 @@ __global__ __launch_bounds__(512, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
         for (int tn = 0; tn < 2; ++tn) {
             const float* r1 = red + 32 * tn + j;
             const float* r2 = red + NW * NPX + 32 * tn + j;
-            const float m1 = (((r1[0] + r1[NPX]) + (r1[2 * NPX] + r1[3 * NPX])) + ((r1[4 * NPX] + r1[5 * NPX]) + (r1[6 * NPX] + r1[7 * NPX]))) * (1.f / C);
-            const float m2 = (((r2[0] + r2[NPX]) + (r2[2 * NPX] + r2[3 * NPX])) + ((r2[4 * NPX] + r2[5 * NPX]) + (r2[6 * NPX] + r2[7 * NPX]))) * (1.f / C);
+            const float m1 = wave_partials_sum<NW>(r1) * (1.f / C);
+            const float m2 = wave_partials_sum<NW>(r2) * (1.f / C);
             float res[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) res[r] = dop[off(r, tn)];
@@ -568,13 +585,24 @@ __global__ __launch_bounds__(512, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
 
 }  // namespace
 
-extern "C" int tdr_naf_tail_supported(int C, int HW) { return (C == 256 && HW % 64 == 0) ? 1 : 0; }
+extern "C" int tdr_naf_tail_supported(int C, int HW) { return ((C == 256 || C == 128 || C == 64 || C == 32) && HW % 64 == 0) ? 1 : 0; }
+
+#define NAF_DISPATCH_C(C_, KERNEL_EXPR, lds_, a_, d_, stream_)                                                                   \
+    do {                                                                                                                         \
+        auto kern = KERNEL_EXPR;                                                                                                 \
+        static bool attr_set = false;                                                                                            \
+        if (!attr_set) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                                     \
+        }                                                                                                                        \
+        hipLaunchKernelGGL(kern, dim3((d_)->HW / NPX, (d_)->N), dim3(2 * C_), lds_, (hipStream_t)stream_, a_);                    \
+    } while (0)
 
 extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
     TDR_REQUIRE(d && d->g && d->sca && d->x && d->w3 && d->w4 && d->w5 && d->b3 && d->beta && d->lnw && d->lnb && d->b4 && d->b5 &&
                     d->gamma && d->y && d->mu && d->rs && d->yn && d->t4 && d->out,
                 "tdr_naf_tail_fwd: null pointer");
-    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_fwd: needs C == 256 and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
+    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_fwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
     TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_tail_fwd: weights must be packed with tdr_pack_weights_hx2 (mode FWD)");
     TDR_REQUIRE(d->HW % 4 == 0 && d->g_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->g) & 15) == 0, "tdr_naf_tail_fwd: g must be 16-byte aligned");
     TailArgs a;
@@ -584,14 +612,11 @@ extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
     a.eps = d->eps;
     a.y = d->y; a.y_ns = d->y_ns; a.mu = d->mu; a.rs = d->rs; a.yn = d->yn; a.yn_ns = d->yn_ns; a.t4 = d->t4; a.t4_ns = d->t4_ns;
     a.out = d->out; a.out_ns = d->out_ns; a.HW = d->HW;
-    const size_t lds = (size_t)2 * (256 / 8) * NPX * 16 + 16 * NPX * sizeof(float);
-    auto kern = naf_tail_fwd_kernel<256>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(d->HW / NPX, d->N), dim3(512), lds, (hipStream_t)stream, a);
+    const size_t lds = (size_t)2 * (d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    if (d->C == 256) NAF_DISPATCH_C(256, naf_tail_fwd_kernel<256>, lds, a, d, stream);
+    else if (d->C == 128) NAF_DISPATCH_C(128, naf_tail_fwd_kernel<128>, lds, a, d, stream);
+    else if (d->C == 64) NAF_DISPATCH_C(64, naf_tail_fwd_kernel<64>, lds, a, d, stream);
+    else NAF_DISPATCH_C(32, naf_tail_fwd_kernel<32>, lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_tail_fwd_kernel");
     return TDR_OK;
 }
@@ -602,7 +627,7 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
     TDR_REQUIRE(d && d->dout && d->gamma && d->t4 && d->y && d->mu && d->rs && d->lnw && d->w5t && d->w4t && d->dt4 && d->dy && d->gw &&
                     d->gb && d->ws,
                 "tdr_naf_tail_bwd: null pointer");
-    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_bwd: needs C == 256 and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
+    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_bwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
     TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_tail_bwd: weights must be packed with tdr_pack_weights_hx2 (mode DGRAD_S1)");
     TDR_REQUIRE(d->dout_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->dout) & 15) == 0, "tdr_naf_tail_bwd: dout must be 16-byte aligned");
     TailBwdArgs a;
@@ -611,14 +636,11 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
     a.w5t = reinterpret_cast<const uint4*>(d->w5t); a.w4t = reinterpret_cast<const uint4*>(d->w4t);
     a.dt4 = d->dt4; a.dt4_ns = d->dt4_ns; a.dy = d->dy; a.dy_ns = d->dy_ns; a.part = d->ws; a.HW = d->HW;
     a.res = d->dout; a.res_ns = d->dout_ns;
-    const size_t lds = (size_t)2 * (2 * 256 / 8) * NPX * 16 + 16 * NPX * sizeof(float);
-    auto kern = naf_tail_bwd_kernel<256, false>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(d->HW / NPX, d->N), dim3(512), lds, (hipStream_t)stream, a);
+    const size_t lds = (size_t)2 * (2 * d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    if (d->C == 256) NAF_DISPATCH_C(256, (naf_tail_bwd_kernel<256, false>), lds, a, d, stream);
+    else if (d->C == 128) NAF_DISPATCH_C(128, (naf_tail_bwd_kernel<128, false>), lds, a, d, stream);
+    else if (d->C == 64) NAF_DISPATCH_C(64, (naf_tail_bwd_kernel<64, false>), lds, a, d, stream);
+    else NAF_DISPATCH_C(32, (naf_tail_bwd_kernel<32, false>), lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_tail_bwd_kernel");
     return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, stream);
 }
@@ -626,7 +648,7 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
 extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
     TDR_REQUIRE(d && d->dt1 && d->x && d->mu && d->rs && d->lnw && d->w1t && d->res && d->dx && d->gw && d->gb && d->ws,
                 "tdr_naf_head_bwd: null pointer");
-    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_head_bwd: needs C == 256 and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
+    TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_head_bwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
     TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_head_bwd: weights must be packed with tdr_pack_weights_hx2 (mode DGRAD_S1)");
     TDR_REQUIRE(d->dt1_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->dt1) & 15) == 0, "tdr_naf_head_bwd: dt1 must be 16-byte aligned");
     TailBwdArgs a;
@@ -634,14 +656,11 @@ extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
     a.mu = d->mu; a.rs = d->rs; a.lnw = d->lnw;
     a.w5t = nullptr; a.w4t = reinterpret_cast<const uint4*>(d->w1t);
     a.dt4 = nullptr; a.dt4_ns = 0; a.res = d->res; a.res_ns = d->res_ns; a.dy = d->dx; a.dy_ns = d->dx_ns; a.part = d->ws; a.HW = d->HW;
-    const size_t lds = (size_t)2 * (2 * 256 / 8) * NPX * 16 + 16 * NPX * sizeof(float);
-    auto kern = naf_tail_bwd_kernel<256, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(d->HW / NPX, d->N), dim3(512), lds, (hipStream_t)stream, a);
+    const size_t lds = (size_t)2 * (2 * d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    if (d->C == 256) NAF_DISPATCH_C(256, (naf_tail_bwd_kernel<256, true>), lds, a, d, stream);
+    else if (d->C == 128) NAF_DISPATCH_C(128, (naf_tail_bwd_kernel<128, true>), lds, a, d, stream);
+    else if (d->C == 64) NAF_DISPATCH_C(64, (naf_tail_bwd_kernel<64, true>), lds, a, d, stream);
+    else NAF_DISPATCH_C(32, (naf_tail_bwd_kernel<32, true>), lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_head_bwd_kernel");
     return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, stream);
 }
