@@ -390,6 +390,7 @@ int tdr_adamw_step_dev(float* const* params, const float* const* grads, float* c
  * Supported: tdr_naf_tail_supported(C, HW): C in {32, 64, 128, 256} (C / 32 waves per workgroup), HW % 64 == 0. */
 typedef struct TdrNafTailDesc {
     int N, C, HW, w_fmt;
+    int c_out;                               /* rows of conv5 produced: C, or C / 2 (the `[:, :chan]` slice of a fusion block); 0 = C */
     float eps;
     const float* g;   int64_t g_ns;          /* [N, C, HW] SimpleGate output of the first half */
     const float* sca;                        /* [N, C] channel attention */
@@ -411,6 +412,7 @@ int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream);
  * w5t / w4t: tdr_pack_weights_hx2(mode DGRAD_S1) of conv5 / conv4.  ws: tdr_naf_tail_bwd_ws_floats(N, C, HW) floats. */
 typedef struct TdrNafTailBwdDesc {
     int N, C, HW, w_fmt;
+    int c_out;                               /* channels of dout (C or C / 2; 0 = C) */
     const float* dout; int64_t dout_ns;
     const float* gamma;
     const float* t4;   int64_t t4_ns;
@@ -439,8 +441,10 @@ typedef struct TdrNafHeadBwdDesc {
     float* ws;
 } TdrNafHeadBwdDesc;
 int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream);
-/* part [nparts][2][C] -> o0[c] = sum_k part[k][0][c], o1[c] = sum_k part[k][1][c], fixed summation order */
-int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float* o1, void* stream);
+/* part [nparts][2][C] -> o0[c] = sum_k part[k][0][c], o1[c] = sum_k part[k][1][c], fixed summation order.
+ * mid: scratch of tdr_pair_sum_mid_floats(nparts, C) floats (a 256-to-1 first stage above 1024 rows; may be NULL when 0) */
+int64_t tdr_pair_sum_mid_floats(int nparts, int C);
+int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float* o1, float* mid, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Data-parallel exchange over RCCL / xGMI: replaces DistributedDataParallel's gradient all-reduce and

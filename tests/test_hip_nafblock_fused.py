@@ -76,3 +76,42 @@ def test_fused_tail_matches_oracle_and_unfused(c, N, H, W):
     for k in P:
         ref = Pr['b.' + k].grad
         assert (fG[k].view_as(ref) - ref).abs().max().item() < 2e-3 * max(ref.abs().max().item(), 1e-6), k
+
+
+@pytest.mark.parametrize('c,N,H,W', [(256, 2, 16, 16), (64, 1, 32, 32)])
+def test_fused_fusion_block_with_sliced_output(c, N, H, W):
+    """the last fusion block of a level keeps `[:, :chan]` of its output (reference :719,727): c_out = c / 2 rows of conv5"""
+    from textualdegremoval_amd import engine as E, kernels as K
+    if K.MATH != 'hx2':
+        pytest.skip('fused blocks run on the fp16-split path')
+    co = c // 2
+    P = block_params(c, seed=21)
+    Pc = {k: v.cuda() for k, v in P.items()}
+    x = rnd(N, c, H, W, seed=7)
+    dout = rnd(N, co, H, W, seed=8)
+    res = {}
+    for fuse in (True, False):
+        prev, E.FUSE_TAIL = E.FUSE_TAIL, fuse
+        prev_scaled = K.set_grad_scaled(True)
+        try:
+            out, saved = E.naf_fwd(x.cuda(), Pc, c_out=co)
+            dx, G = E.naf_bwd(dout.cuda(), Pc, saved)
+            torch.cuda.synchronize()
+            res[fuse] = (out.cpu(), dx.cpu(), {k: v.cpu() for k, v in G.items()})
+        finally:
+            E.FUSE_TAIL = prev
+            K.set_grad_scaled(prev_scaled)
+    Pr = {('b.' + k): v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    ro = O.naf_block(xr, Pr, 'b.')[:, :co]
+    ro.backward(dout)
+    fo, fdx, fG = res[True]
+    uo, udx, uG = res[False]
+    assert fo.shape == (N, co, H, W)
+    assert (fo - ro.detach()).abs().max().item() < 2e-5 * max(1.0, ro.abs().max().item())
+    assert (fo - uo).abs().max().item() < 2e-5 * max(1.0, ro.abs().max().item())
+    assert (fdx - udx).abs().max().item() < 1e-4 * udx.abs().max().item()
+    assert (fdx - xr.grad).abs().max().item() < 5e-4 * xr.grad.abs().max().item()
+    for k in P:
+        ref = Pr['b.' + k].grad
+        assert (fG[k].view_as(ref) - ref).abs().max().item() < 2e-3 * max(ref.abs().max().item(), 1e-6), k

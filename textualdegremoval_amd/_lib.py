@@ -64,7 +64,7 @@ class TdrWgradDesc(C.Structure):
 
 
 class TdrNafTailDesc(C.Structure):
-    _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32), ('eps', f32),
+    _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32), ('c_out', i32), ('eps', f32),
                 ('g', c_fp), ('g_ns', i64), ('sca', c_fp), ('x', c_fp), ('x_ns', i64),
                 ('w3', c_fp), ('w4', c_fp), ('w5', c_fp),
                 ('b3', c_fp), ('beta', c_fp), ('lnw', c_fp), ('lnb', c_fp), ('b4', c_fp), ('b5', c_fp), ('gamma', c_fp),
@@ -73,7 +73,7 @@ class TdrNafTailDesc(C.Structure):
 
 
 class TdrNafTailBwdDesc(C.Structure):
-    _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32),
+    _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32), ('c_out', i32),
                 ('dout', c_fp), ('dout_ns', i64), ('gamma', c_fp), ('t4', c_fp), ('t4_ns', i64), ('y', c_fp), ('y_ns', i64),
                 ('mu', c_fp), ('rs', c_fp), ('lnw', c_fp), ('w5t', c_fp), ('w4t', c_fp),
                 ('dt4', c_fp), ('dt4_ns', i64), ('dy', c_fp), ('dy_ns', i64), ('gw', c_fp), ('gb', c_fp), ('ws', c_fp)]
@@ -176,7 +176,8 @@ SIGNATURES = {
     'tdr_naf_tail_bwd': (i32, [C.POINTER(TdrNafTailBwdDesc), c_fp]),
     'tdr_naf_head_bwd': (i32, [C.POINTER(TdrNafHeadBwdDesc), c_fp]),
     'tdr_absmax_bits': (i32, [c_fp, i64, i32, i64, c_fp, c_fp]),
-    'tdr_pair_sum_partials': (i32, [c_fp, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_pair_sum_partials': (i32, [c_fp, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_pair_sum_mid_floats': (i64, [i32, i32]),
     'tdr_comm_unique_id_bytes': (i32, []),
     'tdr_comm_unique_id': (i32, [c_fp]),
     'tdr_comm_init': (i32, [C.POINTER(c_fp), i32, i32, c_fp]),

@@ -130,6 +130,7 @@ struct TailArgs {
     float* t4; long t4_ns;
     float* out; long out_ns;
     int HW;
+    int c_out;                        // rows of conv5 actually produced (the `[:, :chan]` slice of the fusion blocks, :719,727)
 };
 
 // 2C threads = C/32 waves (C = 256: 8 waves, two per SIMD): wave w owns the 32 channels [32w, 32w + 32) of the C-row GEMMs and, in conv4,
@@ -317,19 +318,20 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     float b5v[16], gav[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        b5v[r] = a.b5[m0 + row_of(r, kk)];
-        gav[r] = a.gamma[m0 + row_of(r, kk)];
+        b5v[r] = m0 < a.c_out ? a.b5[m0 + row_of(r, kk)] : 0.f;
+        gav[r] = m0 < a.c_out ? a.gamma[m0 + row_of(r, kk)] : 0.f;
     }
     __syncthreads();
 
-    // ---- conv5: out = (W5 gate + b5) * gamma + y ; the t4 tile leaves for HBM under its MFMAs
+    // ---- conv5: out = (W5 gate + b5) * gamma + y ; the t4 tile leaves for HBM under its MFMAs.  Only the first c_out rows
+    // exist (fusion blocks keep `[:, :chan]`): the waves above them just store their t4 tiles.
+    float* tp = a.t4 + (long)n * a.t4_ns + p0 + j;
+    if (m0 < a.c_out) {
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-    {
-        float* tp = a.t4 + (long)n * a.t4_ns + p0 + j;
-        gemm_hx2<1, NG, 4>(acc, a.w5, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
+            for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
+        gemm_hx2<1, NG, 4>(acc, a.w5, a.c_out / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
             constexpr int IPG = 64 / NG;                                         // 64 stores spread evenly over the NG groups
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -337,16 +339,20 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
                 tp[(long)tm * C * HW + off(r, tn)] = acc4[tm][tn][r];
             }
         });
-    }
-    {
         float* op = a.out + (long)n * a.out_ns + p0 + j;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) op[off(r, tn)] = (acc[0][tn][r] + b5v[r]) * gav[r] + yv[tn][r];
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tp[(long)tm * C * HW + off(r, tn)] = acc4[tm][tn][r];
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of the same chain, data gradients only (the weight gradients stay on tdr_conv_wgrad, which reads the dt4
@@ -370,6 +376,7 @@ struct TailBwdArgs {
     float* dy; long dy_ns;
     float* part;                      // [gridDim.y * gridDim.x][2][C] LayerNorm parameter-gradient partials
     int HW;
+    int c_out;                        // channels of dout (= rows of conv5 that exist); C or C / 2
 };
 
 __device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 lanes of a wave half (same kk)
@@ -438,9 +445,9 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
                 tb[tn][r] = tp[(long)C * HW + off(r, tn)];
             }
     }
-    // ---- stage B = dout * gamma (K = C)
-    {
-        constexpr int NOCT = C / 8;
+    // ---- stage B = dout * gamma (K = c_out)
+    const int NOCT = a.c_out / 8;
+    if ((tid >> 4) < NOCT) {
         const int q = tid & 15, oct = tid >> 4;
         const float* gp = a.dout + (long)n * a.dout_ns + p0 + 4 * q;
         float4 v[8];
@@ -472,7 +479,8 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-    gemm_hx2<1, C / 16, 4>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [](int) {});
+    if (a.c_out == C) gemm_hx2<1, C / 16, 4>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [](int) {});
+    else gemm_hx2<1, C / 32, 4>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 16, lane, rot, [](int) {});
     __syncthreads();                                          // every wave is done with the dout planes
 
     // ---- SimpleGate backward; dt4 rows c -> octets [4w, 4w+4), rows C + c -> octets [C/8 + 4w, ...) of the K = 2C operand
@@ -575,8 +583,9 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
             const float m1 = wave_partials_sum<NW>(r1) * (1.f / C);
             const float m2 = wave_partials_sum<NW>(r2) * (1.f / C);
             float res[16];
+            const bool has_res = HEAD || m0 < a.c_out;                    // the skip gradient exists for the first c_out channels only
 #pragma unroll
-            for (int r = 0; r < 16; ++r) res[r] = dop[off(r, tn)];
+            for (int r = 0; r < 16; ++r) res[r] = has_res ? dop[off(r, tn)] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dyp[off(r, tn)] = (gv[tn][r] - yh[tn][r] * m1 - m2) * rstd_[tn] + res[r];
         }
@@ -612,6 +621,8 @@ extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
     a.eps = d->eps;
     a.y = d->y; a.y_ns = d->y_ns; a.mu = d->mu; a.rs = d->rs; a.yn = d->yn; a.yn_ns = d->yn_ns; a.t4 = d->t4; a.t4_ns = d->t4_ns;
     a.out = d->out; a.out_ns = d->out_ns; a.HW = d->HW;
+    a.c_out = d->c_out > 0 ? d->c_out : d->C;
+    TDR_REQUIRE(a.c_out == d->C || (a.c_out * 2 == d->C && a.c_out % 32 == 0), "tdr_naf_tail_fwd: c_out must be C or C / 2 (a multiple of 32)");
     const size_t lds = (size_t)2 * (d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
     if (d->C == 256) NAF_DISPATCH_C(256, naf_tail_fwd_kernel<256>, lds, a, d, stream);
     else if (d->C == 128) NAF_DISPATCH_C(128, naf_tail_fwd_kernel<128>, lds, a, d, stream);
@@ -621,7 +632,10 @@ extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
     return TDR_OK;
 }
 
-extern "C" int64_t tdr_naf_tail_bwd_ws_floats(int N, int C, int HW) { return (int64_t)N * (HW / NPX) * 2 * C; }
+extern "C" int64_t tdr_naf_tail_bwd_ws_floats(int N, int C, int HW) {
+    const int nparts = N * (HW / NPX);
+    return (int64_t)nparts * 2 * C + tdr_pair_sum_mid_floats(nparts, C);
+}
 
 extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
     TDR_REQUIRE(d && d->dout && d->gamma && d->t4 && d->y && d->mu && d->rs && d->lnw && d->w5t && d->w4t && d->dt4 && d->dy && d->gw &&
@@ -636,13 +650,15 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
     a.w5t = reinterpret_cast<const uint4*>(d->w5t); a.w4t = reinterpret_cast<const uint4*>(d->w4t);
     a.dt4 = d->dt4; a.dt4_ns = d->dt4_ns; a.dy = d->dy; a.dy_ns = d->dy_ns; a.part = d->ws; a.HW = d->HW;
     a.res = d->dout; a.res_ns = d->dout_ns;
+    a.c_out = d->c_out > 0 ? d->c_out : d->C;
+    TDR_REQUIRE(a.c_out == d->C || (a.c_out * 2 == d->C && a.c_out % 32 == 0), "tdr_naf_tail_bwd: c_out must be C or C / 2 (a multiple of 32)");
     const size_t lds = (size_t)2 * (2 * d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
     if (d->C == 256) NAF_DISPATCH_C(256, (naf_tail_bwd_kernel<256, false>), lds, a, d, stream);
     else if (d->C == 128) NAF_DISPATCH_C(128, (naf_tail_bwd_kernel<128, false>), lds, a, d, stream);
     else if (d->C == 64) NAF_DISPATCH_C(64, (naf_tail_bwd_kernel<64, false>), lds, a, d, stream);
     else NAF_DISPATCH_C(32, (naf_tail_bwd_kernel<32, false>), lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_tail_bwd_kernel");
-    return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, stream);
+    return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, d->ws + (long)d->N * (d->HW / NPX) * 2 * d->C, stream);
 }
 
 extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
@@ -656,11 +672,12 @@ extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
     a.mu = d->mu; a.rs = d->rs; a.lnw = d->lnw;
     a.w5t = nullptr; a.w4t = reinterpret_cast<const uint4*>(d->w1t);
     a.dt4 = nullptr; a.dt4_ns = 0; a.res = d->res; a.res_ns = d->res_ns; a.dy = d->dx; a.dy_ns = d->dx_ns; a.part = d->ws; a.HW = d->HW;
+    a.c_out = d->C;
     const size_t lds = (size_t)2 * (2 * d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
     if (d->C == 256) NAF_DISPATCH_C(256, (naf_tail_bwd_kernel<256, true>), lds, a, d, stream);
     else if (d->C == 128) NAF_DISPATCH_C(128, (naf_tail_bwd_kernel<128, true>), lds, a, d, stream);
     else if (d->C == 64) NAF_DISPATCH_C(64, (naf_tail_bwd_kernel<64, true>), lds, a, d, stream);
     else NAF_DISPATCH_C(32, (naf_tail_bwd_kernel<32, true>), lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_head_bwd_kernel");
-    return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, stream);
+    return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, d->ws + (long)d->N * (d->HW / NPX) * 2 * d->C, stream);
 }

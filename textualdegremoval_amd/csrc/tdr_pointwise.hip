@@ -751,9 +751,38 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
 }
 
 // part [nparts][2][C] -> o0[c] = sum_k part[k][0][c], o1[c] = sum_k part[k][1][c] (fixed order: deterministic)
-extern "C" int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float* o1, void* stream) {
+// many partial rows (the fused NAFBlock backward kernels emit one per 64 pixels: 16384 at 512 x 512, N = 4): a first stage
+// folds them 256-to-1 with a grid wide enough to fill the chip -- the single-stage kernel is only C / 64 x 2 workgroups.
+// part [nparts][2][C] -> mid [S][2][C], S = ceil(nparts / 256); row s sums rows s*256 .. in order (deterministic).
+__global__ __launch_bounds__(256) void pair_fold_partials_kernel(const float* __restrict__ part, int nparts, int C2,
+                                                                float* __restrict__ mid) {
+    const int e = blockIdx.x * 256 + threadIdx.x;            // element of the [2][C] row
+    if (e >= C2) return;
+    const int r0 = blockIdx.y * 256, r1 = min(r0 + 256, nparts);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += part[(long)r * C2 + e]; s1 += part[(long)(r + 1) * C2 + e];
+        s2 += part[(long)(r + 2) * C2 + e]; s3 += part[(long)(r + 3) * C2 + e];
+    }
+    for (; r < r1; ++r) s0 += part[(long)r * C2 + e];
+    mid[(long)blockIdx.y * C2 + e] = (s0 + s1) + (s2 + s3);
+}
+
+extern "C" int64_t tdr_pair_sum_mid_floats(int nparts, int C) { return nparts > 1024 ? (int64_t)tdr_cdiv(nparts, 256) * 2 * C : 0; }
+
+// mid: scratch of tdr_pair_sum_mid_floats(nparts, C) floats (may be NULL when that is 0)
+extern "C" int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float* o1, float* mid, void* stream) {
     TDR_REQUIRE(part && o0 && o1 && nparts > 0 && C > 0, "tdr_pair_sum_partials: bad argument");
-    hipLaunchKernelGGL(pair_sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 2), dim3(1024), 0, (hipStream_t)stream, part, nparts, C, o0, o1);
+    hipStream_t st = (hipStream_t)stream;
+    if (nparts > 1024) {
+        TDR_REQUIRE(mid, "tdr_pair_sum_partials: %d partial rows need the fold scratch", nparts);
+        const int S = tdr_cdiv(nparts, 256);
+        hipLaunchKernelGGL(pair_fold_partials_kernel, dim3(tdr_cdiv(2 * C, 256), S), dim3(256), 0, st, part, nparts, 2 * C, mid);
+        part = mid;
+        nparts = S;
+    }
+    hipLaunchKernelGGL(pair_sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 2), dim3(1024), 0, st, part, nparts, C, o0, o1);
     TDR_LAUNCH_CHECK("pair_sum_partials");
     return TDR_OK;
 }

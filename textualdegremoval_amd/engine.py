@@ -69,10 +69,11 @@ def naf_fwd(x, P, c_out=None):
     s = K.sca_fwd(pooled, P['sca.1.weight'], P['sca.1.bias'])
     if FUSE_TAIL and K.naf_tail_supported(c, H * W, c_out) and x.is_contiguous():
         # conv3 -> norm2 -> conv4 -> SimpleGate -> conv5 in one launch (one workgroup per 64 pixels x all channels)
-        w3p, w4p, w5p = (K.pack_weights(P[k], PACK_FWD)[0] for k in ('conv3.weight', 'conv4.weight', 'conv5.weight'))
+        w3p, w4p = (K.pack_weights(P[k], PACK_FWD)[0] for k in ('conv3.weight', 'conv4.weight'))
+        w5p = K.pack_weights(P['conv5.weight'][:c_out], PACK_FWD)[0]
         out, y, mu2, rs2, yn, t4 = K.naf_tail_fwd(g, s, x, w3p, P['conv3.bias'], P['beta'].view(-1), P['norm2.weight'],
                                                   P['norm2.bias'], LN_EPS, w4p, P['conv4.bias'], w5p, P['conv5.bias'],
-                                                  P['gamma'].view(-1))
+                                                  P['gamma'].view(-1), c_out=c_out)
         return out, (x, xn, mu1, rs1, t1, g, pooled, s, y, yn, mu2, rs2, t4, c_out)
     wp, mp, *_ = K.pack_weights(P['conv3.weight'], PACK_FWD)
     y = K.conv_forward(g, wp, mp, c, 1, kscale=s, bias=P['conv3.bias'], scale=P['beta'].view(-1), res=x)
@@ -115,7 +116,7 @@ def naf_bwd(dout, P, saved):
         _dgrad_is_hx2()
     if fused:
         # conv5 dgrad -> SimpleGate bwd -> conv4 dgrad -> norm2 bwd (+ skip) in one launch
-        w5t, w4t = K.pack_weights(P['conv5.weight'], PACK_DGRAD_S1)[0], K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)[0]
+        w5t, w4t = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)[0], K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)[0]
         dy, dt4, G['norm2.weight'], G['norm2.bias'] = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t, w4t)
     else:
         wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)

@@ -506,23 +506,25 @@ def dwsg_bwd(dg, t, w, b):
 
 
 def naf_tail_supported(c, hw, c_out=None):
-    return (c_out is None or c_out == c) and MATH == 'hx2' and bool(_lib.load().tdr_naf_tail_supported(int(c), int(hw)))
+    ok_out = c_out is None or c_out == c or (2 * c_out == c and c_out % 32 == 0)
+    return ok_out and MATH == 'hx2' and bool(_lib.load().tdr_naf_tail_supported(int(c), int(hw)))
 
 
-def naf_tail_fwd(g, s, x, w3p, b3, beta, lnw, lnb, eps, w4p, b4, w5p, b5, gamma):
+def naf_tail_fwd(g, s, x, w3p, b3, beta, lnw, lnb, eps, w4p, b4, w5p, b5, gamma, c_out=None):
     """fused conv3 -> +residual -> norm2 -> conv4 -> SimpleGate -> conv5 -> +residual (csrc/tdr_nafblock.hip).
     Returns (out, y, mu2, rs2, yn, t4): exactly the tensors the unfused sequence saves for the backward pass."""
     lib = _lib.load()
     N, Cc, H, W = g.shape
     dev = g.device
+    c_out = Cc if c_out is None else c_out
     y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
     yn = torch.empty_like(y)
-    out = torch.empty_like(y)
+    out = torch.empty(N, c_out, H, W, dtype=torch.float32, device=dev)
     t4 = torch.empty(N, 2 * Cc, H, W, dtype=torch.float32, device=dev)
     mu = torch.empty(N, H * W, dtype=torch.float32, device=dev)
     rs = torch.empty_like(mu)
     d = _lib.TdrNafTailDesc()
-    d.N, d.C, d.HW, d.eps = N, Cc, H * W, float(eps)
+    d.N, d.C, d.HW, d.eps, d.c_out = N, Cc, H * W, float(eps), c_out
     assert w3p.fmt == w4p.fmt == w5p.fmt
     d.w_fmt = w3p.fmt
     d.g, d.g_ns, d.sca, d.x, d.x_ns = g.data_ptr(), _dense_nchw(g), s.data_ptr(), x.data_ptr(), _dense_nchw(x)
@@ -553,7 +555,7 @@ def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp):
     gb = torch.empty_like(gw)
     ws = workspace(lib.tdr_naf_tail_bwd_ws_floats(N, Cc, H * W), dev, 'naftail')
     d = _lib.TdrNafTailBwdDesc()
-    d.N, d.C, d.HW = N, Cc, H * W
+    d.N, d.C, d.HW, d.c_out = N, Cc, H * W, dout.shape[1]
     assert w5tp.fmt == w4tp.fmt
     d.w_fmt = w5tp.fmt
     d.dout, d.dout_ns, d.gamma = dout.data_ptr(), _dense_nchw(dout), gamma.data_ptr()
