@@ -303,7 +303,7 @@ def main():
         line = {
             'metric': f'train images/sec ({a.size}x{a.size}, bs={a.batch}/GPU)', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if K.MATH == 'h1' else 'f32', 'data': 'synthetic',
             'math': {'bx3': 'fp32 tensors; dense contractions as 3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate): '
                             'per-product error <= one fp32 rounding, see profiles/r1/bf16x3_probe_mi355x.log; TDR_MATH=f32 selects exact fp32 MFMA',
                      'hx2': 'fp32 tensors; dense contractions as 2-way fp16 split (3 f16 MFMA products per fp32 product, fp32 accumulate), '
@@ -311,6 +311,9 @@ def main():
                             'gradients are gathered); per-image correlations as 3-way bf16 split / exact fp32: measured error of the split '
                             'schemes = that of the exact fp32 MFMA chain (profiles/r1/fp16x2_probe_mi355x.log, bf16x3_probe_mi355x.log, '
                             'grad_range_survey_cfg2.log); TDR_MATH=bx3 / f32 select the all-bf16-split / exact fp32 MFMA paths',
+                     'h1': 'fp32 tensors; dense contractions on plain fp16 MFMA (operands rounded to one fp16 plane, ONE product, fp32 '
+                           'accumulate) with the loss-scaled backward pass -- REDUCED precision, the "fp16 MFMA" arithmetic of BASELINE '
+                           'configs[4]; not the headline arithmetic',
                      'f32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)'}[K.MATH],
             'config': {'workload': ('BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
                                     f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
@@ -329,7 +332,7 @@ def main():
             'final_loss': loss,
         }
         if is_cfg2:
-            nprod = {'hx2': 3.0, 'bx3': 6.0}.get(K.MATH)
+            nprod = {'hx2': 3.0, 'bx3': 6.0, 'h1': 1.0}.get(K.MATH)
             line['roofline_step'] = {'achieved_hbm_frac': CFG2['B_alg'] * per_gpu / PEAK_HBM,
                                      'achieved_f32_flop_frac': CFG2['F_alg'] * per_gpu / PEAK_F32,
                                      'alg_bytes_per_image': CFG2['B_alg'], 'alg_flop_per_image': CFG2['F_alg']}

@@ -65,7 +65,9 @@ typedef struct TdrConvDesc {
     const void* wp;  int64_t wp_ns;  int Mpad;    /* packed weights, see tdr_pack_weights / tdr_pack_weights_bx3 */
     int wp_fmt;                  /* 0: fp32 rows (tdr_pack_weights, exact fp32 MFMA)
                                     1: 3-way bf16 split fragments (tdr_pack_weights_bx3, bf16 MFMA x6, fp32-equivalent)
-                                    2: 2-way fp16 split fragments (tdr_pack_weights_hx2, f16 MFMA x3, operands in fp16 range) */
+                                    2: 2-way fp16 split fragments (tdr_pack_weights_hx2, f16 MFMA x3, operands in fp16 range)
+                                    3: the same pack read as plain fp16 (head plane only, ONE f16 MFMA product, fp32 accumulate):
+                                       reduced precision, BASELINE configs[4]'s "fp16 MFMA" arithmetic (TDR_MATH=h1) */
     float* out; int64_t out_ns;
     int epi;                     /* 0 STD, 1 GATEBWD, 2 PSHUF */
     const float* bias;  int64_t bias_ns;
@@ -144,7 +146,7 @@ typedef struct TdrWgradDesc {
     int math;          /* 0: exact fp32 MFMA; 1: 3-way bf16 split on the bf16 MFMA pipe where supported
                           (stride 1, 1x1 / 3x3), exact fp32 otherwise; 2: 2-way fp16 split (3 products) on the same
                           kernels -- both operands must lie in the fp16 range (activations; gradients of a loss-scaled
-                          backward pass, see tdr_l1_loss) */
+                          backward pass, see tdr_l1_loss); 3: plain fp16 (one product), same range requirement, reduced precision */
 } TdrWgradDesc;
 int64_t tdr_wgrad_ws_floats(const TdrWgradDesc* d);
 int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream);

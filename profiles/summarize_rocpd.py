@@ -17,7 +17,8 @@ def main():
     db, steps = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     c = sqlite3.connect(db)
     tot = list(c.execute('select sum(end-start) from kernels where name not like "%spin_kernel%"'))[0][0]
-    print(f'total kernel time {tot / 1e6 / steps:.2f} ms/step over {steps:g} steps')
+    nl = list(c.execute('select count(*) from kernels where name not like "%spin_kernel%"'))[0][0]
+    print(f'total kernel time {tot / 1e6 / steps:.2f} ms/step over {steps:g} steps; {nl / steps:.0f} launches/step')
     print('--- by kernel')
     for name, n, t, avg in c.execute('select name, count(*), sum(end-start), avg(end-start) from kernels where name not like "%spin_kernel%" group by name '
                                      'order by sum(end-start) desc limit 40'):

@@ -62,12 +62,15 @@ union Frag {
 //            measurably irrelevant, profiles/r1/fp16x2_probe_mi355x.log) -- half the matrix work and two operand planes
 //            instead of three, for operands inside the fp16 range (|x| < 65504, magnitudes of interest above ~2^-14):
 //            forward activations and weights; NOT raw gradients (3e-7-sized values lose everything without a pre-scale).
-enum { SCH_BX3 = 0, SCH_HX2 = 1 };
+//   SCH_H1   x ~ h, one fp16 plane, one product (plain fp16 MFMA, fp32 accumulate): reads the head plane of an hx2 weight pack.
+//            Reduced precision (2^-11 per operand) -- BASELINE configs[4]'s "fp16 MFMA" arithmetic, selected by TDR_MATH=h1 only.
+enum { SCH_BX3 = 0, SCH_HX2 = 1, SCH_H1 = 2 };
 
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH, int AD = 0>
 __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
-    constexpr int NS = SCH == SCH_HX2 ? 2 : 3;                  // operand planes
-    constexpr int NP = SCH == SCH_HX2 ? 3 : 6;                  // matrix products per fp32 product
+    constexpr int NS = SCH == SCH_BX3 ? 3 : (SCH == SCH_HX2 ? 2 : 1);   // operand planes (LDS, fragments)
+    constexpr int NSW = SCH == SCH_BX3 ? 3 : 2;                         // planes of the weight pack
+    constexpr int NP = SCH == SCH_BX3 ? 6 : (SCH == SCH_HX2 ? 3 : 1);   // matrix products per fp32 product
     constexpr int WN = 4 / WM;
     constexpr int BM = 32 * TM * WM;
     constexpr int NT = TN * WN;
@@ -165,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                 // free, the compiler may round the head from the exact product and the residual from the rounded one, and at
                 // an fp16 / bf16 tie the pair is then off by a whole ulp of the head (tdr_nafblock.hip, split_hm)
                 asm volatile("" : "+v"(v));
-                if constexpr (SCH == SCH_HX2) {
+                if constexpr (SCH == SCH_H1) {
+                    h.hv[i] = (_Float16)v;
+                } else if constexpr (SCH == SCH_HX2) {
                     const _Float16 hh = (_Float16)v;
                     h.hv[i] = hh;
                     m.hv[i] = (_Float16)(v - (float)hh);
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
             if ((inplane >> it) & 1u) {
                 const int p = sp0 + 128 * it;
                 sb[p] = h.u;
-                sb[2 * plane + p] = m.u;
+                if constexpr (NS >= 2) sb[2 * plane + p] = m.u;
                 if constexpr (NS == 3) sb[4 * plane + p] = l.u;
             }
         }
@@ -198,9 +203,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int mt = min((m0 >> 5) + wm * TM + tm, MT - 1);
-        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)n * (a.wp_ns >> 2) + (long)mt * (NS * 64) + lane;   // wp_ns: floats per image (0 = shared)
+        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)n * (a.wp_ns >> 2) + (long)mt * (NSW * 64) + lane;   // wp_ns: floats per image (0 = shared)
     }
-    const long wstep = (long)MT * (NS * 64);    // 16-byte units per (group, tap)
+    const long wstep = (long)MT * (NSW * 64);    // 16-byte units per (group, tap)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -263,7 +268,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
                         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn) {
-                                if constexpr (SCH == SCH_HX2)
+                                if constexpr (SCH == SCH_H1)
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[tm][0].hv, bf[tn][0].hv, acc[tm][tn], 0, 0, 0);
+                                else if constexpr (SCH == SCH_HX2)
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
                                 else
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[tm][SA[q]].v, bf[tn][SB[q]].v, acc[tm][tn], 0, 0, 0);
@@ -309,9 +316,9 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz1(int slot) { return slot ^ ((slot >> 4) & 3); }
 
-template <int WM, int TM, int TN, int EPI, bool GATE>
+template <int WM, int TM, int TN, int EPI, bool GATE, int SCH = SCH_HX2>
 __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
-    constexpr int NS = 2, NP = 3;
+    constexpr int NS = SCH == SCH_H1 ? 1 : 2, NSW = 2, NP = SCH == SCH_H1 ? 1 : 3;
     constexpr int WN = 4 / WM;
     constexpr int BM = 32 * TM * WM;
     constexpr int NT = TN * WN;
@@ -391,10 +398,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
                 asm volatile("" : "+v"(v));        // one fp32 value for head and residual (see conv_bx3_kernel)
                 const _Float16 hh = (_Float16)v;
                 h.hv[i] = hh;
-                m.hv[i] = (_Float16)(v - (float)hh);
+                if constexpr (NS == 2) m.hv[i] = (_Float16)(v - (float)hh);
             }
             sb[wslot[px]] = h.u;
-            sb[OCT * NPX + wslot[px]] = m.u;
+            if constexpr (NS == 2) sb[OCT * NPX + wslot[px]] = m.u;
         }
     };
 
@@ -407,9 +414,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int mt = min((m0 >> 5) + wm * TM + tm, MT - 1);
-        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)n * (a.wp_ns >> 2) + (long)mt * (NS * 64) + lane;
+        wfrag[tm] = reinterpret_cast<const uint4*>(a.wp) + (long)n * (a.wp_ns >> 2) + (long)mt * (NSW * 64) + lane;
     }
-    const long wstep = (long)MT * (NS * 64);
+    const long wstep = (long)MT * (NSW * 64);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -461,7 +468,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
                             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                                 for (int tn = 0; tn < TN; ++tn) {
-                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
+                                    if constexpr (SCH == SCH_H1)
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][0].hv, bf[tn][0].hv, acc[tm][tn], 0, 0, 0);
+                                    else
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
                                 }
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm)
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
     conv_epilogue<TM, TN, EPI>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
 }
 
-template <int WM, int TM, int TN, int EPI, bool GATE>
+template <int WM, int TM, int TN, int EPI, bool GATE, int SCH>
 int launch_c1_hx2(const ConvArgs& a, int N, hipStream_t st) {
     constexpr int WN = 4 / WM;
     constexpr int BM = 32 * TM * WM;
@@ -497,7 +507,7 @@ int launch_c1_hx2(const ConvArgs& a, int N, hipStream_t st) {
     dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
     b.single_buf = 0;
     const size_t lds = 2 * 32768;        // two stages of 2 splits x OCT octets x NPX pixels x 16 B = 32 KiB
-    auto kern = conv1x1_hx2_kernel<WM, TM, TN, EPI, GATE>;
+    auto kern = conv1x1_hx2_kernel<WM, TM, TN, EPI, GATE, SCH>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -525,9 +535,9 @@ inline bool c1_hx2_ok(const ConvArgs& a, int npx, int bm, int N) {
 
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH>
 int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
-    if constexpr (KH == 1 && S == 1 && SCH == SCH_HX2 && EPI != EPI_PSHUF)
-        if (c1_hx2_ok(a, 32 * TN * (4 / WM), 32 * TM * WM, N)) return launch_c1_hx2<WM, TM, TN, EPI, GATE>(a, N, st);
-    constexpr int NS = SCH == SCH_HX2 ? 2 : 3;
+    if constexpr (KH == 1 && S == 1 && SCH != SCH_BX3 && EPI != EPI_PSHUF)
+        if (c1_hx2_ok(a, 32 * TN * (4 / WM), 32 * TM * WM, N)) return launch_c1_hx2<WM, TM, TN, EPI, GATE, SCH>(a, N, st);
+    constexpr int NS = SCH == SCH_BX3 ? 3 : (SCH == SCH_HX2 ? 2 : 1);
     constexpr int WN = 4 / WM;
     constexpr int BM = 32 * TM * WM;
     constexpr int NT = TN * WN;
@@ -575,6 +585,7 @@ int g_force_cfg[2] = {getenv("TDR_BX_CFG1") ? atoi(getenv("TDR_BX_CFG1")) : 0, g
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE>
 int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {
     if (a.scheme == SCH_HX2) return launch_bx_cfg_s<KH, S, WM, TM, TN, EPI, GATE, SCH_HX2>(a, N, st);
+    if (a.scheme == SCH_H1) return launch_bx_cfg_s<KH, S, WM, TM, TN, EPI, GATE, SCH_H1>(a, N, st);
     return launch_bx_cfg_s<KH, S, WM, TM, TN, EPI, GATE, SCH_BX3>(a, N, st);
 }
 
@@ -714,7 +725,7 @@ int tdr_conv_forward_bx3(const TdrConvDesc* d, void* stream) {
     ConvArgs a;
     a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
     a.wp = (const float*)d->wp; a.wp_ns = d->wp_ns; a.Mpad = d->Mpad; a.Cout = d->Cout;
-    a.scheme = d->wp_fmt == 2 ? SCH_HX2 : SCH_BX3;
+    a.scheme = d->wp_fmt == 3 ? SCH_H1 : (d->wp_fmt == 2 ? SCH_HX2 : SCH_BX3);   // 3: an hx2 pack read as plain fp16 (TDR_MATH=h1)
     a.out = d->out; a.out_ns = d->out_ns; a.OH = d->OH; a.OW = d->OW;
     a.pad = d->pad;
     a.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);

@@ -299,7 +299,7 @@ extern "C" int tdr_conv_forward(const TdrConvDesc* d, void* stream) {
     TDR_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->OH > 0 && d->OW > 0, "tdr_conv_forward: bad shape");
     TDR_REQUIRE(d->Mpad % 32 == 0 && d->Mpad >= d->Cout, "tdr_conv_forward: Mpad %d invalid for Cout %d", d->Mpad, d->Cout);
     TDR_REQUIRE(d->epi != EPI_GATEBWD || d->aux, "tdr_conv_forward: GATEBWD needs aux");
-    if (d->wp_fmt == 1 || d->wp_fmt == 2) return tdr_conv_forward_bx3(d, stream);
+    if (d->wp_fmt >= 1 && d->wp_fmt <= 3) return tdr_conv_forward_bx3(d, stream);
     TDR_REQUIRE(d->wp_fmt == 0, "tdr_conv_forward: unknown wp_fmt %d", d->wp_fmt);
     ConvArgs a;
     a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;

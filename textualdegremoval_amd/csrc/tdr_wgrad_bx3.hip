@@ -26,7 +26,8 @@ namespace {
 
 // operand schemes, as in tdr_conv_bx3.hip: 0 = 3-way bf16 split (6 products), 1 = 2-way fp16 split (3 products; both
 // operands inside the fp16 range: activations, and gradients of a loss-scaled backward pass)
-enum { WSCH_BX3 = 0, WSCH_HX2 = 1 };
+// WSCH_H1: head plane only, one fp16 product (plain fp16 MFMA with fp32 accumulation; TDR_MATH=h1, reduced precision)
+enum { WSCH_BX3 = 0, WSCH_HX2 = 1, WSCH_H1 = 2 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte fragment (8 bf16) as dwords
 
@@ -55,7 +56,14 @@ constexpr int wb_max_nch(int KH, int P) {
 
 template <int SCH>
 __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h, u32x4& m, u32x4& l) {
-    if constexpr (SCH == WSCH_HX2) {
+    if constexpr (SCH == WSCH_H1) {
+        wf16x8 hv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hv[i] = (_Float16)(i < 4 ? a[i & 3] : b[i & 3]);
+        h = __builtin_bit_cast(u32x4, hv);
+        m = h;
+        l = h;
+    } else if constexpr (SCH == WSCH_HX2) {
         wf16x8 hv, mv;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -86,8 +94,8 @@ __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h
 // every item of every tile; with run-time divisors that integer math out-weighed the MFMAs)
 template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL, int SCH>
 __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
-    constexpr int NS = SCH == WSCH_HX2 ? 2 : 3;      // operand planes
-    constexpr int NP = SCH == WSCH_HX2 ? 3 : 6;      // matrix products per fp32 product
+    constexpr int NS = SCH == WSCH_BX3 ? 3 : (SCH == WSCH_HX2 ? 2 : 1);      // operand planes
+    constexpr int NP = SCH == WSCH_BX3 ? 6 : (SCH == WSCH_HX2 ? 3 : 1);      // matrix products per fp32 product
     static_assert(!DMA || (KH == 3 && !PRE && !GATE), "DMA staging: 3x3 only");
     static_assert(WMw * WNw * WKw == 4, "4 waves");
     static_assert(KH == 1 || (TMW == 1 && TNW == 1), "3x3: one 32x32 tile pair (9 accumulators) per wave");
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         split8v<SCH>(v0, v1, h, m, l);
         u32x4* dst = reinterpret_cast<u32x4*>(s_d + ldsoff);
         dst[0] = h;
-        dst[(BMc * DPITCH) >> 3] = m;
+        if constexpr (NS >= 2) dst[(BMc * DPITCH) >> 3] = m;
         if constexpr (NS == 3) dst[(2 * BMc * DPITCH) >> 3] = l;
     };
     auto i_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live, bool from_raw = false) {
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         split8v<SCH>(v0, v1, h, m, l);
         u32x4* dst = reinterpret_cast<u32x4*>(s_i + ldsoff);
         dst[0] = h;
-        dst[(BNc * IPITCH) >> 3] = m;
+        if constexpr (NS >= 2) dst[(BNc * IPITCH) >> 3] = m;
         if constexpr (NS == 3) dst[(2 * BNc * IPITCH) >> 3] = l;
     };
     // prefetch registers (PRE only): every index below is a compile-time constant after unrolling
@@ -312,10 +320,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
                 for (int r = 0; r < 16; ++r) acc[x][y][t][r] = 0.f;
 
     // bx3: lh hl mm mh hm hh; hx2: mh hm hh (small cross terms first)
-    constexpr int SA[6] = {SCH == WSCH_HX2 ? 1 : 2, 0, SCH == WSCH_HX2 ? 0 : 1, 1, 0, 0};
-    constexpr int SB[6] = {0, SCH == WSCH_HX2 ? 1 : 2, SCH == WSCH_HX2 ? 0 : 1, 0, 1, 0};
+    constexpr int SA[6] = {SCH == WSCH_HX2 ? 1 : (SCH == WSCH_H1 ? 0 : 2), 0, SCH == WSCH_HX2 ? 0 : 1, 1, 0, 0};
+    constexpr int SB[6] = {0, SCH == WSCH_HX2 ? 1 : (SCH == WSCH_H1 ? 0 : 2), SCH == WSCH_HX2 ? 0 : 1, 0, 1, 0};
     auto mma = [](const u32x4& x, const u32x4& y, const f32x16& c) {
-        if constexpr (SCH == WSCH_HX2)
+        if constexpr (SCH != WSCH_BX3)
             return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, x), __builtin_bit_cast(wf16x8, y), c, 0, 0, 0);
         else
             return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
 
 template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL, int SCH>
 int launch_wgb_cl_s(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
-    constexpr int NS = SCH == WSCH_HX2 ? 2 : 3;
+    constexpr int NS = SCH == WSCH_BX3 ? 3 : (SCH == WSCH_HX2 ? 2 : 1);
     constexpr int BMc = 32 * TMW * WMw, BNc = 32 * TNW * WNw;
     constexpr int C = 1 << CL, R = P / C;
     constexpr int CP = KH == 3 ? C + 8 : C, LR = KH == 3 ? R + 2 : R;
@@ -473,6 +481,7 @@ int launch_wgb_cl_s(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
 template <int KH, int P, int WMw, int WNw, int WKw, int TMW, int TNW, bool GATE, bool PRE, bool DMA, int CL>
 int launch_wgb_cl(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
     if (a.scheme == WSCH_HX2) return launch_wgb_cl_s<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, CL, WSCH_HX2>(a, p, N, st);
+    if (a.scheme == WSCH_H1) return launch_wgb_cl_s<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, CL, WSCH_H1>(a, p, N, st);
     return launch_wgb_cl_s<KH, P, WMw, WNw, WKw, TMW, TNW, GATE, PRE, DMA, CL, WSCH_BX3>(a, p, N, st);
 }
 

@@ -295,7 +295,7 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     const bool g = d->gate != 0;
     int rc = TDR_ERR_UNSUPPORTED;
     const int key = d->KH * 10 + d->stride;
-    a.scheme = d->math == 2 ? 1 : 0;
+    a.scheme = d->math == 3 ? 2 : (d->math == 2 ? 1 : 0);   // 3: plain fp16 (TDR_MATH=h1)
     static const bool dbg = getenv("TDR_WG_DEBUG") != nullptr;   // which shapes miss the split kernel
     if (dbg && !(d->math >= 1 && tdr_wgrad_bx3_supported(d)))
         fprintf(stderr, "[tdr] exact wgrad: math %d N %d %d->%d @%dx%d k%d s%d pad %d gate %d per_image %d in_ns %ld dout_ns %ld\n", d->math,

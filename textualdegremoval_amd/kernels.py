@@ -20,11 +20,19 @@ PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2 = 0, 1, 2, 3
 #           split, 3 f16 MFMA products per fp32 product -- half the matrix work of 'bx3' at the same measured accuracy
 #           (profiles/r1/fp16x2_probe_mi355x.log) for operands inside the fp16 range, which forward activations and weights
 #           are; data-gradient and weight-gradient kernels see 1e-7-sized operands and stay on the 3-way bf16 split.
+#   'h1'  : plain fp16 MFMA with fp32 accumulation (operands rounded to ONE fp16 plane, one product): the "fp16 MFMA"
+#           arithmetic BASELINE configs[4] is quoted on.  Reduced precision (2^-11 per operand), judged on PSNR, never the
+#           default; same kernels, weight packs, loss scale and range survey as 'hx2' (the m plane is simply not used).
 # The MASA arg-max searches always run on the exact path (near-tie indices must not move).
 MATH = os.environ.get('TDR_MATH', 'hx2')
 # weight gradients of 1x1 convs on the split-bf16 kernel as well (0: exact fp32 kernel)
 WGRAD_1X1_BX3 = os.environ.get('TDR_WGRAD_1X1_BX3', '1') == '1'
-FMT_F32, FMT_BX3, FMT_HX2 = 0, 1, 2
+FMT_F32, FMT_BX3, FMT_HX2, FMT_H1 = 0, 1, 2, 3
+
+
+def fp16_path():
+    """True when the dense contractions take fp16 operands (2-way split or plain): loss scale + range survey apply."""
+    return MATH in ('hx2', 'h1')
 
 
 # True while a backward pass runs on loss-scaled gradients (models/image_restoration_ref_model.py picks the power of two
@@ -43,7 +51,7 @@ def set_grad_scaled(on):
 
 def set_math(mode):
     global MATH
-    assert mode in ('bx3', 'f32', 'hx2')
+    assert mode in ('bx3', 'f32', 'hx2', 'h1')
     MATH = mode
 
 
@@ -266,10 +274,10 @@ def _pack_dims(w, mode):
 def _packed_buffer(w, mode, math):
     lib = _lib.load()
     M, Kch, KHe = _pack_dims(w, mode)
-    if math == 'hx2' and (mode == PACK_FWD or GRAD_SCALED):
+    if math in ('hx2', 'h1') and (mode == PACK_FWD or GRAD_SCALED):
         n = lib.tdr_packed_weight_bytes_hx2(M, Kch, KHe) // 4
-        fmt = FMT_HX2
-    elif math in ('bx3', 'hx2'):
+        fmt = FMT_HX2 if math == 'hx2' else FMT_H1      # h1 reads the head plane of the same pack
+    elif math in ('bx3', 'hx2', 'h1'):
         n = lib.tdr_packed_weight_bytes_bx3(M, Kch, KHe) // 4
         fmt = FMT_BX3
     else:
@@ -313,7 +321,7 @@ class PackPlan:
             blocks = 0
             for j, (w, mode, math, pw) in enumerate(self.entries.values()):
                 Cout, Cin, KH, _ = w.shape
-                check(lib.tdr_pack_job_init(C.byref(jobs[j]), w.data_ptr(), Cout, Cin, KH, mode, pw.fmt, pw.data_ptr()),
+                check(lib.tdr_pack_job_init(C.byref(jobs[j]), w.data_ptr(), Cout, Cin, KH, mode, min(pw.fmt, FMT_HX2), pw.data_ptr()),
                       'tdr_pack_job_init')
                 jobs[j].first_block = blocks
                 blocks += (jobs[j].total + 255) // 256
@@ -344,7 +352,7 @@ def _pack_into(w, mode, pw):
     lib = _lib.load()
     Cout, Cin, KH, _ = w.shape
     assert w.is_contiguous()
-    if pw.fmt == FMT_HX2:
+    if pw.fmt in (FMT_HX2, FMT_H1):
         check(lib.tdr_pack_weights_hx2(w.data_ptr(), Cout, Cin, KH, mode, pw.data_ptr(), _stream()), 'tdr_pack_weights_hx2')
     elif pw.fmt == FMT_BX3:
         check(lib.tdr_pack_weights_bx3(w.data_ptr(), Cout, Cin, KH, mode, pw.data_ptr(), _stream()), 'tdr_pack_weights_bx3')
@@ -412,7 +420,7 @@ def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None
     d.mask, d.mask_ns = _p(mask), (_dense_nchw(mask) if mask is not None else 0)
     d.aux, d.aux_ns = _p(aux), (_dense_nchw(aux) if aux is not None else 0)
     d.relu = int(relu) if not isinstance(relu, bool) else (1 if relu else 0)      # 2 = exact GELU
-    if _survey is not None and d.wp_fmt == FMT_HX2:
+    if _survey is not None and d.wp_fmt in (FMT_HX2, FMT_H1):
         _survey.probe(x, 'grad' if BACKWARD_PHASE else 'fwd')
     check(lib.tdr_conv_forward(C.byref(d), _stream()), 'tdr_conv_forward')
     return out
@@ -437,11 +445,11 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
     d.per_image = 1 if per_image else 0
     # fp16_range: both operands are forward activations (Restormer's q k^T Gram); otherwise `dout` is a gradient and the
     # fp16 split needs the loss-scaled backward pass (GRAD_SCALED)
-    if MATH == 'hx2' and (fp16_range or GRAD_SCALED) and (KH == 3 or WGRAD_1X1_BX3):
-        d.math = 2
+    if fp16_path() and (fp16_range or GRAD_SCALED) and (KH == 3 or WGRAD_1X1_BX3):
+        d.math = 2 if MATH == 'hx2' else 3
     else:
         d.math = 1 if (MATH != 'f32' and (KH == 3 or WGRAD_1X1_BX3)) else 0
-    if _survey is not None and d.math == 2:
+    if _survey is not None and d.math >= 2:
         _survey.probe(dout, 'fwd' if fp16_range else 'grad')
     need = lib.tdr_wgrad_ws_floats(C.byref(d))
     ws = workspace(need, x.device, 'wgrad')

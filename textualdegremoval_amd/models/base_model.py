@@ -80,7 +80,7 @@ class BaseModel:
         if any(v != v or v in (float('inf'), float('-inf')) for v in out.values()):
             from .. import kernels as K
             hint = (' -- under TDR_MATH=hx2 the forward convolutions need activations inside the fp16 range (|x| < 65504); '
-                    'TDR_MATH=bx3 has the full fp32 range') if K.MATH == 'hx2' else ''
+                    'TDR_MATH=bx3 has the full fp32 range') if K.fp16_path() else ''
             raise FloatingPointError(f'non-finite loss {dict(out)}{hint}')
         return out
 

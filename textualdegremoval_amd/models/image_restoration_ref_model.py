@@ -169,7 +169,7 @@ class RefGuidedImageCleanModel(BaseModel):
     FWD_MAX_EXP = 14
 
     def _survey_due(self, current_iter):
-        if K.MATH != 'hx2' or os.environ.get('TDR_RANGE_CHECK', '1') != '1':
+        if not K.fp16_path() or os.environ.get('TDR_RANGE_CHECK', '1') != '1':
             return False
         every = int(os.environ.get('TDR_RANGE_CHECK_EVERY', '1000'))
         last = getattr(self, '_last_survey_iter', None)
@@ -233,7 +233,7 @@ class RefGuidedImageCleanModel(BaseModel):
             # The scale lives in the optimiser's device-resident StepGuard: a non-finite gradient norm (an operand left the
             # fp16 range) skips that step and halves it, 1000 finite steps double it again up to this starting value.
             gs = 1.0
-            if K.MATH == 'hx2' and os.environ.get('TDR_GRAD_SCALE', '1') == '1' and lw > 0 and \
+            if K.fp16_path() and os.environ.get('TDR_GRAD_SCALE', '1') == '1' and lw > 0 and \
                     not getattr(self, '_bwd_full_range', False):
                 gs = 2.0 ** (math.floor(math.log2(512.0 * lq.shape[0] * 3 * lq.shape[2] * lq.shape[3] / lw)) +
                              getattr(self, '_scale_shift', 0))
