@@ -191,7 +191,7 @@ int tdr_dwconv_fwd(const float* t, const float* w, const float* b, int N, int pl
 int tdr_dwconv_bwd(const float* dout, const float* t, const float* w, int N, int planes, int H, int W, float* dt,
                    float* dw, float* db, float* ws, void* stream);
 
-/* ---- Restormer-ref MDTA core (:246-277), per image and head over CHANNEL tokens (c = C/heads <= 120).
+/* ---- Restormer-ref MDTA core (:246-277), per image and head over CHANNEL tokens (c = C/heads <= 192).
  * The pixel contractions run on tdr_conv_wgrad (per_image Gram q k^T) and tdr_conv_forward (1x1, per-image weights);
  * these entry points do the c x c part.  Cp = tdr_mdta_pad(C) = C rounded up to 32.
  * out[n][r] = sum_p x[n][r][p]^2  (F.normalize denominators of q and k, :266-267) */
@@ -302,6 +302,27 @@ int tdr_scatter_ref_block(const float* dblk, int N, int C, int H, int W, const i
 /* bit pattern of max |x| over x[n][0..per) (image stride x_ns), atomicMax-ed into *slot (caller zeroes; NaN / Inf give
  * >= 0x7f800000).  The train step's fp16-range survey: which operands of the 2-way fp16 split leave its window. */
 int tdr_absmax_bits(const float* x, int64_t x_ns, int N, int64_t per, unsigned* slot, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * PromptIR-ref PromptGenBlock (network_promptir_guided_arch.py:417-441), everything around its 3x3 convolution:
+ *   emb = mean_hw x (tdr_plane_mean);  w = softmax(Linear(emb)) (tdr_prompt_weights_*);
+ *   prompt[n] = sum_k w[n][k] * P[k] (tdr_prompt_mix_*), P = the L parameter planes after the bilinear resize to (H, W)
+ *   (tdr_resize_bilinear / tdr_resize_bilinear_bwd: weighted sum and resize commute, the resize runs once per step).
+ * prompt_len L <= 16.  All reductions fixed-order.
+ * ------------------------------------------------------------------------- */
+int tdr_plane_mean(const float* x, int64_t x_ns, int N, int C, int HW, float* out /*[N][C]*/, void* stream);
+/* x[n][c][:] += v[n][c] * scale   (gradient of the mean: scale = 1/HW) */
+int tdr_plane_add(float* x, int64_t x_ns, const float* v, float scale, int N, int C, int HW, void* stream);
+int tdr_prompt_weights_fwd(const float* emb, const float* W /*[L][C]*/, const float* b /*[L] or NULL*/, int N, int C, int L,
+                           float* w /*[N][L]*/, void* stream);
+int tdr_prompt_weights_bwd(const float* emb, const float* W, const float* w, const float* dw, int N, int C, int L,
+                           float* dW, float* db /*or NULL*/, float* demb /*[N][C]*/, void* stream);
+int tdr_prompt_mix_fwd(const float* w, const float* P /*[L][E]*/, int N, int L, int64_t E, float* out /*[N][E]*/, void* stream);
+int64_t tdr_prompt_mix_bwd_ws_floats(int N, int L);
+int tdr_prompt_mix_bwd(const float* w, const float* P, const float* d /*[N][E]*/, int N, int L, int64_t E, float* dP /*[L][E]*/,
+                       float* dw /*[N][L]*/, float* ws, void* stream);
+/* adjoint of tdr_resize_bilinear: ddst [planes][Hd][Wd] -> dsrc [planes][Hs][Ws] (gather, no atomics) */
+int tdr_resize_bilinear_bwd(const float* ddst, int planes, int Hs, int Ws, int Hd, int Wd, float* dsrc, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Frozen ViT window matcher (DINOv2 ViT-B/14, forward only): models/image_restoration_ref_model.py:215-247,

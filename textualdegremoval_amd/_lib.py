@@ -178,6 +178,14 @@ SIGNATURES = {
     'tdr_absmax_bits': (i32, [c_fp, i64, i32, i64, c_fp, c_fp]),
     'tdr_pair_sum_partials': (i32, [c_fp, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_pair_sum_mid_floats': (i64, [i32, i32]),
+    'tdr_plane_mean': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp]),
+    'tdr_plane_add': (i32, [c_fp, i64, c_fp, f32, i32, i32, i32, c_fp]),
+    'tdr_prompt_weights_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp]),
+    'tdr_prompt_weights_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_prompt_mix_fwd': (i32, [c_fp, c_fp, i32, i32, i64, c_fp, c_fp]),
+    'tdr_prompt_mix_bwd_ws_floats': (i64, [i32, i32]),
+    'tdr_prompt_mix_bwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i64, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_resize_bilinear_bwd': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_comm_unique_id_bytes': (i32, []),
     'tdr_comm_unique_id': (i32, [c_fp]),
     'tdr_comm_init': (i32, [C.POINTER(c_fp), i32, i32, c_fp]),

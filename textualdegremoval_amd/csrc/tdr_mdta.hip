@@ -1,6 +1,6 @@
 // Restormer-ref pieces that are not plain convolutions (network_restormer_guided_arch.py):
 //   MDTA core (:246-277): attn = softmax_j( t_h * q^_i . k^_j ),  out = attn v, per image and head, where the
-//   "tokens" are CHANNELS (c = C/heads <= 120 per head) and the contraction runs over all H*W pixels.
+//   "tokens" are CHANNELS (c = C/heads <= 192 per head) and the contraction runs over all H*W pixels.
 //   The two big contractions are convolution-shaped and run on the MFMA kernels of this library:
 //     G = q k^T over pixels        -> tdr_conv_wgrad(per_image)  (a C x C Gram matrix per image)
 //     out = attn v                 -> tdr_conv_forward, 1x1, per-image weights (wp_ns)
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[(long)n * rows + r] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// grid (heads, N); wave per row i of the head's c x c block; lane handles columns j = lane, lane + 64
+// grid (heads, N); wave per row i of the head's c x c block; lane handles columns j = lane + 64 u, u < NU (c <= 64 NU)
+template <int NU>
 __global__ __launch_bounds__(256) void mdta_softmax_kernel(const float* __restrict__ G, const float* __restrict__ ss,
                                                           const float* __restrict__ temp, int C, int c, int Cp,
                                                           float* __restrict__ A, float* __restrict__ AT) {
@@ -54,33 +55,33 @@ __global__ __launch_bounds__(256) void mdta_softmax_kernel(const float* __restri
     const float* sq = ss + (long)n * 2 * C;
     float* An = A + (long)n * Cp * Cp;
     float* ATn = AT + (long)n * Cp * Cp;
-    float ink[2];
+    float ink[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int j = lane + 64 * u;
         ink[u] = j < c ? 1.0f / fmaxf(sqrtf(sq[C + h * c + j]), NORM_EPS) : 0.f;
     }
     for (int i = wv; i < c; i += 4) {
         const int gi = h * c + i;
         const float inq = 1.0f / fmaxf(sqrtf(sq[gi]), NORM_EPS);
-        float L[2];
+        float L[NU];
         float m = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int j = lane + 64 * u;
             L[u] = j < c ? t * (Gn[(long)gi * C + h * c + j] * inq * ink[u]) : -INFINITY;
             m = fmaxf(m, L[u]);
         }
         m = wave_max(m);
-        float e[2], s = 0.f;
+        float e[NU], s = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             e[u] = (lane + 64 * u) < c ? expf(L[u] - m) : 0.f;
             s += e[u];
         }
         s = wave_sum(s);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int j = lane + 64 * u;
             if (j < c) {
                 const float p = e[u] / s;
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void mdta_softmax_kernel(const float* __restri
 }
 
 // grid (heads, N), dynamic LDS: E [c][c+1] + rowt[c]
+template <int NU>
 __global__ __launch_bounds__(256) void mdta_bwd_kernel(const float* __restrict__ G, const float* __restrict__ ss,
                                                       const float* __restrict__ temp, const float* __restrict__ A,
                                                       const float* __restrict__ dA, int C, int c, int Cp, int Wp,
@@ -107,9 +109,9 @@ __global__ __launch_bounds__(256) void mdta_bwd_kernel(const float* __restrict__
     const float* An = A + (long)n * Cp * Cp;
     const float* sq = ss + (long)n * 2 * C;
     float* Wn = W + (long)n * Wp * Wp;
-    float ink[2];
+    float ink[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int j = lane + 64 * u;
         ink[u] = j < c ? 1.0f / fmaxf(sqrtf(sq[C + h * c + j]), NORM_EPS) : 0.f;
     }
@@ -117,9 +119,9 @@ __global__ __launch_bounds__(256) void mdta_bwd_kernel(const float* __restrict__
         const int gi = h * c + i;
         const float nq = sqrtf(sq[gi]);
         const float inq = 1.0f / fmaxf(nq, NORM_EPS);
-        float P[2], dP[2], Gh[2], pd = 0.f;
+        float P[NU], dP[NU], Gh[NU], pd = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int j = lane + 64 * u;
             const bool ok = j < c;
             P[u] = ok ? An[(long)gi * Cp + h * c + j] : 0.f;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void mdta_bwd_kernel(const float* __restrict__
         pd = wave_sum(pd);
         float rt = 0.f, rho = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int j = lane + 64 * u;
             const float dL = P[u] * (dP[u] - pd);
             rt += dL * Gh[u];
@@ -233,7 +235,7 @@ extern "C" int tdr_mdta_pad(int C) { return (C + 31) / 32 * 32; }
 extern "C" int tdr_mdta_softmax(const float* G, const float* ss, const float* temp, int N, int C, int heads, float* A,
                                 float* AT, void* stream) {
     TDR_REQUIRE(G && ss && temp && A && AT, "tdr_mdta_softmax: null pointer");
-    TDR_REQUIRE(heads > 0 && C % heads == 0 && C / heads <= 120, "tdr_mdta_softmax: need C %% heads == 0 and C/heads <= 120 (C=%d heads=%d)", C, heads);
+    TDR_REQUIRE(heads > 0 && C % heads == 0 && C / heads <= 192, "tdr_mdta_softmax: need C %% heads == 0 and C/heads <= 192 (C=%d heads=%d)", C, heads);
     hipStream_t st = (hipStream_t)stream;
     const int Cp = tdr_mdta_pad(C);
     const size_t bytes = (size_t)N * Cp * Cp * sizeof(float);
@@ -241,7 +243,10 @@ extern "C" int tdr_mdta_softmax(const float* G, const float* ss, const float* te
         tdr_set_error("tdr_mdta_softmax: memset failed");
         return TDR_ERR_HIP;
     }
-    hipLaunchKernelGGL(mdta_softmax_kernel, dim3(heads, N), dim3(256), 0, st, G, ss, temp, C, C / heads, Cp, A, AT);
+    if (C / heads <= 128)
+        hipLaunchKernelGGL(mdta_softmax_kernel<2>, dim3(heads, N), dim3(256), 0, st, G, ss, temp, C, C / heads, Cp, A, AT);
+    else      // PromptIR-ref's 704-channel block (4 heads of 176, network_promptir_guided_arch.py:736)
+        hipLaunchKernelGGL(mdta_softmax_kernel<3>, dim3(heads, N), dim3(256), 0, st, G, ss, temp, C, C / heads, Cp, A, AT);
     TDR_LAUNCH_CHECK("mdta_softmax");
     return TDR_OK;
 }
@@ -249,7 +254,7 @@ extern "C" int tdr_mdta_softmax(const float* G, const float* ss, const float* te
 extern "C" int tdr_mdta_bwd(const float* G, const float* ss, const float* temp, const float* A, const float* dA, int N, int C,
                             int heads, float* W, float* dtemp, float* ws, void* stream) {
     TDR_REQUIRE(G && ss && temp && A && dA && W && dtemp && ws, "tdr_mdta_bwd: null pointer (ws needs N*heads floats)");
-    TDR_REQUIRE(heads > 0 && C % heads == 0 && C / heads <= 120, "tdr_mdta_bwd: need C %% heads == 0 and C/heads <= 120 (C=%d heads=%d)", C, heads);
+    TDR_REQUIRE(heads > 0 && C % heads == 0 && C / heads <= 192, "tdr_mdta_bwd: need C %% heads == 0 and C/heads <= 192 (C=%d heads=%d)", C, heads);
     hipStream_t st = (hipStream_t)stream;
     const int c = C / heads, Cp = tdr_mdta_pad(C), Wp = tdr_mdta_pad(2 * C);
     if (hipMemsetAsync(W, 0, (size_t)N * Wp * Wp * sizeof(float), st) != hipSuccess) {
@@ -257,7 +262,17 @@ extern "C" int tdr_mdta_bwd(const float* G, const float* ss, const float* temp, 
         return TDR_ERR_HIP;
     }
     const size_t lds = ((size_t)c * (c + 1) + c) * sizeof(float);
-    hipLaunchKernelGGL(mdta_bwd_kernel, dim3(heads, N), dim3(256), lds, st, G, ss, temp, A, dA, C, c, Cp, Wp, W, ws);
+    if (c <= 128) {
+        auto kern = mdta_bwd_kernel<2>;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(heads, N), dim3(256), lds, st, G, ss, temp, A, dA, C, c, Cp, Wp, W, ws);
+    } else {
+        auto kern = mdta_bwd_kernel<3>;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(heads, N), dim3(256), lds, st, G, ss, temp, A, dA, C, c, Cp, Wp, W, ws);
+    }
     hipLaunchKernelGGL(mdta_dtemp_kernel, dim3(tdr_cdiv(heads, 64)), dim3(64), 0, st, ws, N, heads, dtemp);
     TDR_LAUNCH_CHECK("mdta_bwd");
     return TDR_OK;

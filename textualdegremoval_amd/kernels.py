@@ -1093,3 +1093,69 @@ def cross_attention_bwd(q, k, v, out, dout, lse, heads, scale, Tq, Tk):
                                               lse.data_ptr(), B, Cc, heads, Tq, LDq, Tk, LDk, float(scale), dq.data_ptr(),
                                               dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), _stream()), 'tdr_cross_attention_bwd')
     return dq, dk, dv
+
+
+# ---------------------------------------------------------------------------
+# PromptIR-ref PromptGenBlock pieces (csrc/tdr_prompt.hip)
+# ---------------------------------------------------------------------------
+def plane_mean(x):
+    """x [N,C,H,W] (dense NCHW view) -> [N,C] mean over H*W."""
+    N, Cc, H, W = x.shape
+    out = torch.empty(N, Cc, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_plane_mean(x.data_ptr(), _dense_nchw(x), N, Cc, H * W, out.data_ptr(), _stream()), 'tdr_plane_mean')
+    return out
+
+
+def plane_add_(x, v, scale):
+    """x[n,c,:,:] += v[n,c] * scale, in place."""
+    N, Cc, H, W = x.shape
+    check(_lib.load().tdr_plane_add(x.data_ptr(), _dense_nchw(x), v.data_ptr(), float(scale), N, Cc, H * W, _stream()), 'tdr_plane_add')
+    return x
+
+
+def prompt_weights_fwd(emb, W, b):
+    N, Cc = emb.shape
+    L = W.shape[0]
+    w = torch.empty(N, L, dtype=torch.float32, device=emb.device)
+    check(_lib.load().tdr_prompt_weights_fwd(emb.data_ptr(), W.data_ptr(), _p(b), N, Cc, L, w.data_ptr(), _stream()),
+          'tdr_prompt_weights_fwd')
+    return w
+
+
+def prompt_weights_bwd(emb, W, w, dw, want_db=True):
+    N, Cc = emb.shape
+    L = W.shape[0]
+    dW = torch.empty_like(W)
+    db = torch.empty(L, dtype=torch.float32, device=emb.device) if want_db else None
+    demb = torch.empty_like(emb)
+    check(_lib.load().tdr_prompt_weights_bwd(emb.data_ptr(), W.data_ptr(), w.data_ptr(), dw.data_ptr(), N, Cc, L, dW.data_ptr(),
+                                             _p(db), demb.data_ptr(), _stream()), 'tdr_prompt_weights_bwd')
+    return dW, db, demb
+
+
+def prompt_mix_fwd(w, P):
+    """w [N,L], P [L,C,H,W] -> [N,C,H,W] = sum_k w[n,k] P[k]."""
+    N, L = w.shape
+    out = torch.empty(N, *P.shape[1:], dtype=torch.float32, device=P.device)
+    check(_lib.load().tdr_prompt_mix_fwd(w.data_ptr(), P.data_ptr(), N, L, P[0].numel(), out.data_ptr(), _stream()), 'tdr_prompt_mix_fwd')
+    return out
+
+
+def prompt_mix_bwd(w, P, d):
+    lib = _lib.load()
+    N, L = w.shape
+    assert d.is_contiguous() and P.is_contiguous()
+    dP = torch.empty_like(P)
+    dw = torch.empty_like(w)
+    ws = workspace(lib.tdr_prompt_mix_bwd_ws_floats(N, L), P.device)
+    check(lib.tdr_prompt_mix_bwd(w.data_ptr(), P.data_ptr(), d.data_ptr(), N, L, P[0].numel(), dP.data_ptr(), dw.data_ptr(),
+                                 ws.data_ptr(), _stream()), 'tdr_prompt_mix_bwd')
+    return dP, dw
+
+
+def resize_bilinear_bwd(dd, Hs, Ws):
+    B, Cc, Hd, Wd = dd.shape
+    assert dd.is_contiguous()
+    ds = torch.empty(B, Cc, Hs, Ws, dtype=torch.float32, device=dd.device)
+    check(_lib.load().tdr_resize_bilinear_bwd(dd.data_ptr(), B * Cc, Hs, Ws, Hd, Wd, ds.data_ptr(), _stream()), 'tdr_resize_bilinear_bwd')
+    return ds
