@@ -527,7 +527,8 @@ class OracleTrainer:
         out = self.forward_fn(self.P, self.cfg, lq, ref)
         loss = l1_loss(out, gt)
         loss.backward()
-        grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in self.P.items()}
+        # a tensor the network never uses keeps grad None: clip_grad_norm_ and torch.optim.AdamW (decay included) skip it
+        grads = {k: p.grad for k, p in self.P.items() if p.grad is not None}
         total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
         if self.use_grad_clip:
             coef = min(1.0, float(self.max_norm / (total + 1e-6)))
@@ -537,6 +538,8 @@ class OracleTrainer:
         b1, b2 = self.betas
         with torch.no_grad():
             for k, p in self.P.items():
+                if k not in grads:
+                    continue
                 g = grads[k] * coef
                 lr = self.lr[k]
                 p.mul_(1 - lr * self.wd)

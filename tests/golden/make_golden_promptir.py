@@ -56,7 +56,7 @@ def build_ref_net(arch, cfg, P=None, decoder=True):
         dilations=cfg['dilations'], psize=cfg['psize'])
     if P is not None:
         sd = net.state_dict()
-        assert sorted(sd.keys()) == sorted(P.keys()), (sorted(set(sd) ^ set(P)))
+        assert list(sd.keys()) == list(P.keys()), 'registration order mismatch'
         for k in sd:
             assert tuple(sd[k].shape) == tuple(P[k].shape), (k, sd[k].shape, P[k].shape)
         net.load_state_dict(P)

@@ -66,12 +66,19 @@ class RefGuidedImageCleanModel(BaseModel):
         self.setup_optimizers()
         self.setup_schedulers()
 
+    def _trainable_named_parameters(self):
+        """named_parameters() minus the tensors an architecture registers but never uses (PromptIR-ref's chnl_reduce* /
+        reduce_noise_channel_*): in the reference their .grad stays None, so clip_grad_norm_ and AdamW skip them."""
+        net = self.get_bare_model(self.net_g)
+        unused = tuple(getattr(net, 'unused_parameter_prefixes', ()))
+        return [(k, v) for k, v in self.net_g.named_parameters() if not (unused and k.replace('module.', '', 1).startswith(unused))]
+
     def setup_optimizers(self):
         train_opt = self.opt['train']
         # reference quirk R3: the key read is 'fix_iterations' (YAMLs set 'param_fix_iterations')
         self.param_fix_iters = train_opt['fix_iterations'] if 'fix_iterations' in train_opt else None
         optim_params, optim_ref_params = [], []
-        for k, v in self.net_g.named_parameters():
+        for k, v in self._trainable_named_parameters():
             (optim_ref_params if 'masa' in k else optim_params).append(v)
         groups = [{'params': optim_params, 'lr': train_opt['optim_g']['lr']},
                   {'params': optim_ref_params, 'lr': train_opt['optim_g']['ref_lr']}]
@@ -139,8 +146,10 @@ class RefGuidedImageCleanModel(BaseModel):
         self.ref_in = self._match_reference_window()
         if not hasattr(self, '_step_names'):
             net = self.get_bare_model(self.net_g)
-            self._step_names = [k for k, _ in net.named_parameters()]
-            self._step_params = [p for _, p in net.named_parameters()]
+            unused = tuple(getattr(net, 'unused_parameter_prefixes', ()))
+            named = [(k, p) for k, p in net.named_parameters() if not (unused and k.startswith(unused))]
+            self._step_names = [k for k, _ in named]
+            self._step_params = [p for _, p in named]
             if not hasattr(self, 'grad_reducer'):
                 from ..parallel import GradAllReducer
                 self.grad_reducer = GradAllReducer(list(zip(self._step_names, self._step_params)))
