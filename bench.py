@@ -34,6 +34,10 @@ def make_opt(width, enc, batch_hw, dist_on, arch='nafnet'):
                    num_refinement_blocks=4, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
                    LayerNorm_type='WithBias', dual_pixel_task=False, nf=48, ext_n_blocks=[4, 4, 4, 4],
                    reffusion_n_blocks=[2, 2, 2, 2])
+    elif arch == 'promptir':     # the reference's 001_promptir_all_in_one_restoration.yml network, with decoder=True (False raises: R4)
+        net = dict(type='PromptIRRefFusion', inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8],
+                   num_refinement_blocks=4, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
+                   LayerNorm_type='WithBias', decoder=True, nf=48, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2])
     else:
         net = dict(type='NAFNetRefFusion', width=width, nf=width, enc_blk_nums=enc, dec_blk_nums=[1, 1, 1, 1],
                    middle_blk_num=1, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2])
@@ -147,7 +151,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer'],
+    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer', 'promptir'],
                     help="nafnet: the headline workload (BASELINE configs[1]); restormer: configs[2]'s per-GPU workload "
                          '(Restormer-ref dim 48, 256x256, bs 8) -- a secondary measurement, not the metric line')
     ap.add_argument('--batch', type=int, default=None)
@@ -163,9 +167,9 @@ def main():
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (multi-process smoke test on one GPU)')
     a = ap.parse_args()
     if a.batch is None:
-        a.batch = 8 if a.arch == 'restormer' else 4
+        a.batch = 8 if a.arch in ('restormer', 'promptir') else 4
     if a.size is None:
-        a.size = 256 if a.arch == 'restormer' else 512
+        a.size = {'restormer': 256, 'promptir': 384}.get(a.arch, 512)
     enc = [int(v) for v in a.enc.split(',')]
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -318,8 +322,11 @@ def main():
             'config': {'workload': ('BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
                                     f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
                                     if a.arch == 'nafnet' else
-                                    'BASELINE configs[2] per-GPU workload: Restormer-ref dim48 blocks[4,6,6,8] refine4 heads[1,2,4,8] '
-                                    f'fusion[2,2,2,2], {a.size}x{a.size} synthetic pairs, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'),
+                                    ('BASELINE configs[2] per-GPU workload: Restormer-ref dim48 blocks[4,6,6,8] refine4 heads[1,2,4,8] '
+                                     f'fusion[2,2,2,2], {a.size}x{a.size} synthetic pairs, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
+                                     if a.arch == 'restormer' else
+                                     'PromptIR-ref (001_promptir_all_in_one_restoration.yml network, decoder=True): dim48 blocks[4,6,6,8] '
+                                     f'refine4 prompts 64/128/320, {a.size}x{a.size} synthetic pairs, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW')),
                        'width': a.width if a.arch == 'nafnet' else 48, 'enc_blk_nums': enc if a.arch == 'nafnet' else [4, 6, 6, 8],
                        'global_batch': world * a.batch,
                        'parallelism': f'dp{world}',
@@ -344,7 +351,8 @@ def main():
             if roof_other:
                 line['roofline_other'] = roof_other
         if a.arch == 'restormer':
-            CFG3 = dict(B_alg=69.4e9, F_alg=1.86e12)       # SURVEY 8(d), per 256x256 image
+            px = (a.size / 256.0) ** 2                     # SURVEY 8(d) quotes the figures per 256x256 image
+            CFG3 = dict(B_alg=69.4e9 * px, F_alg=1.86e12 * px)
             line['roofline_step'] = {'achieved_hbm_frac': CFG3['B_alg'] * per_gpu / PEAK_HBM,
                                      'achieved_f32_flop_frac': CFG3['F_alg'] * per_gpu / PEAK_F32,
                                      'alg_bytes_per_image': CFG3['B_alg'], 'alg_flop_per_image': CFG3['F_alg']}
