@@ -449,6 +449,19 @@ typedef struct TdrNafTailBwdDesc {
 } TdrNafTailBwdDesc;
 int64_t tdr_naf_tail_bwd_ws_floats(int N, int C, int HW);
 int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream);
+/* First half of a NAFBlock up to the depthwise conv (network_nafnet_guided_arch.py:216-219), one launch:
+ *   xn = LayerNorm2d(x; lnw, lnb, eps)   (mu, rs kept for the backward pass)        t1 = conv1(xn) + b1
+ * w1: tdr_pack_weights_hx2(mode FWD) of conv1 (2C x C).  Same support as tdr_naf_tail_fwd. */
+typedef struct TdrNafHeadFwdDesc {
+    int N, C, HW, w_fmt;
+    const float* x; int64_t x_ns;
+    const float *lnw, *lnb; float eps;
+    const void* w1; const float* b1;
+    float *mu, *rs;                          /* [N, HW] */
+    float* xn; int64_t xn_ns;                /* [N, C, HW] */
+    float* t1; int64_t t1_ns;                /* [N, 2C, HW] */
+} TdrNafHeadFwdDesc;
+int tdr_naf_head_fwd(const TdrNafHeadFwdDesc* d, void* stream);
 /* The first half's data gradients (autograd of :216-225 from conv1 back), one launch instead of two:
  *   dxn = W1^T dt1;  dx = LayerNorm2d'(dxn; x, mu, rs, lnw) + res        (res = gradient of the `inp + ...` skip)
  * plus norm1's parameter gradients.  w1t: tdr_pack_weights_hx2(mode DGRAD_S1) of conv1 (2C x C).  Same support / ws. */

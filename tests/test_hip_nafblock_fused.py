@@ -43,6 +43,7 @@ def test_fused_tail_matches_oracle_and_unfused(c, N, H, W):
     outs = {}
     for fuse in (True, False):
         prev, E.FUSE_TAIL = E.FUSE_TAIL, fuse
+        prev_head, E.FUSE_HEAD = E.FUSE_HEAD, fuse
         # the fused backward chain runs on the fp16-split data-gradient weights of a loss-scaled backward pass
         # (kernels.GRAD_SCALED); dout is O(1) here, i.e. already inside the fp16 window
         prev_scaled = K.set_grad_scaled(True)
@@ -54,6 +55,7 @@ def test_fused_tail_matches_oracle_and_unfused(c, N, H, W):
             outs[fuse] = (out.cpu(), [t.cpu() if torch.is_tensor(t) else t for t in saved], dx.cpu(), {k: v.cpu() for k, v in G.items()})
         finally:
             E.FUSE_TAIL = prev
+            E.FUSE_HEAD = prev_head
             K.set_grad_scaled(prev_scaled)
     # oracle (torch fp32 on the CPU, autograd)
     Pr = {('b.' + k): v.clone().requires_grad_(True) for k, v in P.items()}
@@ -92,6 +94,7 @@ def test_fused_fusion_block_with_sliced_output(c, N, H, W):
     res = {}
     for fuse in (True, False):
         prev, E.FUSE_TAIL = E.FUSE_TAIL, fuse
+        prev_head, E.FUSE_HEAD = E.FUSE_HEAD, fuse
         prev_scaled = K.set_grad_scaled(True)
         try:
             out, saved = E.naf_fwd(x.cuda(), Pc, c_out=co)
@@ -100,6 +103,7 @@ def test_fused_fusion_block_with_sliced_output(c, N, H, W):
             res[fuse] = (out.cpu(), dx.cpu(), {k: v.cpu() for k, v in G.items()})
         finally:
             E.FUSE_TAIL = prev
+            E.FUSE_HEAD = prev_head
             K.set_grad_scaled(prev_scaled)
     Pr = {('b.' + k): v.clone().requires_grad_(True) for k, v in P.items()}
     xr = x.clone().requires_grad_(True)

@@ -85,6 +85,12 @@ class TdrNafHeadBwdDesc(C.Structure):
                 ('w1t', c_fp), ('res', c_fp), ('res_ns', i64), ('dx', c_fp), ('dx_ns', i64), ('gw', c_fp), ('gb', c_fp), ('ws', c_fp)]
 
 
+class TdrNafHeadFwdDesc(C.Structure):
+    _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32),
+                ('x', c_fp), ('x_ns', i64), ('lnw', c_fp), ('lnb', c_fp), ('eps', f32), ('w1', c_fp), ('b1', c_fp),
+                ('mu', c_fp), ('rs', c_fp), ('xn', c_fp), ('xn_ns', i64), ('t1', c_fp), ('t1_ns', i64)]
+
+
 class TdrStepGuard(C.Structure):
     _fields_ = [('scale', f32), ('inv_scale', f32), ('max_scale', f32), ('good', i32), ('growth_interval', i32),
                 ('step', i32), ('skipped', i32), ('finite', i32), ('bc1', f32), ('bc2_sqrt', f32)]
@@ -175,6 +181,7 @@ SIGNATURES = {
     'tdr_naf_tail_bwd_ws_floats': (i64, [i32, i32, i32]),
     'tdr_naf_tail_bwd': (i32, [C.POINTER(TdrNafTailBwdDesc), c_fp]),
     'tdr_naf_head_bwd': (i32, [C.POINTER(TdrNafHeadBwdDesc), c_fp]),
+    'tdr_naf_head_fwd': (i32, [C.POINTER(TdrNafHeadFwdDesc), c_fp]),
     'tdr_absmax_bits': (i32, [c_fp, i64, i32, i64, c_fp, c_fp]),
     'tdr_pair_sum_partials': (i32, [c_fp, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_pair_sum_mid_floats': (i64, [i32, i32]),

@@ -16,6 +16,7 @@ from .kernels import (EPI_GATEBWD, EPI_PSHUF, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2
 LN_EPS = 1e-6
 # fused NAFBlock halves (csrc/tdr_nafblock.hip) where the shape allows; TDR_FUSE_NAF=0 keeps the per-op launches
 FUSE_TAIL = os.environ.get('TDR_FUSE_NAF', '1') == '1'
+FUSE_HEAD = FUSE_TAIL and os.environ.get('TDR_FUSE_HEAD', '1') == '1'      # norm1 -> conv1 (forward)
 
 
 def _sub(P, pre):
@@ -62,9 +63,13 @@ def naf_fwd(x, P, c_out=None):
     produced, the `[:, :chan]` slice of :719/:727 folded into conv5)."""
     N, c, H, W = x.shape
     c_out = c if c_out is None else c_out
-    xn, mu1, rs1 = K.layernorm2d_fwd(x, P['norm1.weight'], P['norm1.bias'], LN_EPS)
     wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_FWD)
-    t1 = K.conv_forward(xn, wp, mp, 2 * c, 1, bias=P['conv1.bias'])
+    if FUSE_HEAD and K.naf_tail_supported(c, H * W) and wp.fmt == K.FMT_HX2:
+        # norm1 -> conv1 in one launch (the workgroup that owns 64 pixels x all channels reduces the statistics itself)
+        xn, mu1, rs1, t1 = K.naf_head_fwd(x, P['norm1.weight'], P['norm1.bias'], LN_EPS, wp, P['conv1.bias'])
+    else:
+        xn, mu1, rs1 = K.layernorm2d_fwd(x, P['norm1.weight'], P['norm1.bias'], LN_EPS)
+        t1 = K.conv_forward(xn, wp, mp, 2 * c, 1, bias=P['conv1.bias'])
     g, pooled = K.dwsg_fwd(t1, P['conv2.weight'], P['conv2.bias'])
     s = K.sca_fwd(pooled, P['sca.1.weight'], P['sca.1.bias'])
     if FUSE_TAIL and K.naf_tail_supported(c, H * W, c_out) and x.is_contiguous():

@@ -579,6 +579,26 @@ def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp):
     return dy, dt4, gw, gb
 
 
+def naf_head_fwd(x, lnw, lnb, eps, w1p, b1):
+    """fused norm1 -> conv1.  Returns (xn, mu, rs, t1)."""
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    dev = x.device
+    xn = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
+    t1 = torch.empty(N, 2 * Cc, H, W, dtype=torch.float32, device=dev)
+    mu = torch.empty(N, H * W, dtype=torch.float32, device=dev)
+    rs = torch.empty_like(mu)
+    d = _lib.TdrNafHeadFwdDesc()
+    d.N, d.C, d.HW, d.w_fmt = N, Cc, H * W, w1p.fmt
+    d.x, d.x_ns, d.lnw, d.lnb, d.eps = x.data_ptr(), _dense_nchw(x), lnw.data_ptr(), lnb.data_ptr(), float(eps)
+    d.w1, d.b1 = w1p.data_ptr(), b1.data_ptr()
+    d.mu, d.rs, d.xn, d.xn_ns, d.t1, d.t1_ns = mu.data_ptr(), rs.data_ptr(), xn.data_ptr(), _dense_nchw(xn), t1.data_ptr(), _dense_nchw(t1)
+    if _survey is not None:
+        _survey.probe(x, 'fwd')
+    check(lib.tdr_naf_head_fwd(C.byref(d), _stream()), 'tdr_naf_head_fwd')
+    return xn, mu, rs, t1
+
+
 def naf_head_bwd(dt1, x, mu, rs, lnw, w1tp, res):
     """fused conv1 dgrad -> norm1 bwd (+ skip gradient `res`).  Returns (dx, gw1, gb1)."""
     lib = _lib.load()
