@@ -177,6 +177,10 @@ int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int N, int C, i
 /* backward: dg [N,C,H,W] -> dt [N,2C,H,W], dw [2C,9], db [2C] */
 int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
                  float* dt, float* dw, float* db, float* ws, void* stream);
+/* same, the incoming gradient being dg[n][c][:] + dg_bias[n][c] * dg_bias_mul (the SCA branch's pooled gradient / HW,
+ * which the reference's autograd adds through the adaptive-average-pool backward, :192-196) */
+int tdr_dwsg_bwd_biased(const float* dg, const float* dg_bias, float dg_bias_mul, const float* t, const float* w, const float* b,
+                        int N, int C, int H, int W, float* dt, float* dw, float* db, float* ws, void* stream);
 
 /* ---- Restormer-ref depthwise stencils (models/archs/network_restormer_guided_arch.py); b / db may be NULL (bias=False).
  * GDFN gate (:236-239): t [N,2C,H,W] -> g [N,C,H,W] = gelu(dw(t)[:C]) * dw(t)[C:]  (erf GELU) */
@@ -446,6 +450,11 @@ typedef struct TdrNafTailBwdDesc {
     float* dy;  int64_t dy_ns;
     float *gw, *gb;
     float* ws;
+    /* optional conv3 data-gradient stage in the same launch (NULL w3t = off): dgp = sca[n] * (W3^T (beta * dy)), i.e. the
+     * gradient of g through `y = inp + conv3(g * sca) * beta` (:226-230) WITHOUT the pooled-gradient term of the SCA branch,
+     * which tdr_dwsg_bwd_biased adds per (image, channel) plane.  w3t: tdr_pack_weights_hx2(mode DGRAD_S1) of conv3. */
+    const void* w3t; const float* beta; const float* sca /*[N, C]*/;
+    float* dgp; int64_t dgp_ns;
 } TdrNafTailBwdDesc;
 int64_t tdr_naf_tail_bwd_ws_floats(int N, int C, int HW);
 int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream);

@@ -76,7 +76,8 @@ class TdrNafTailBwdDesc(C.Structure):
     _fields_ = [('N', i32), ('C', i32), ('HW', i32), ('w_fmt', i32), ('c_out', i32),
                 ('dout', c_fp), ('dout_ns', i64), ('gamma', c_fp), ('t4', c_fp), ('t4_ns', i64), ('y', c_fp), ('y_ns', i64),
                 ('mu', c_fp), ('rs', c_fp), ('lnw', c_fp), ('w5t', c_fp), ('w4t', c_fp),
-                ('dt4', c_fp), ('dt4_ns', i64), ('dy', c_fp), ('dy_ns', i64), ('gw', c_fp), ('gb', c_fp), ('ws', c_fp)]
+                ('dt4', c_fp), ('dt4_ns', i64), ('dy', c_fp), ('dy_ns', i64), ('gw', c_fp), ('gb', c_fp), ('ws', c_fp),
+                ('w3t', c_fp), ('beta', c_fp), ('sca', c_fp), ('dgp', c_fp), ('dgp_ns', i64)]
 
 
 class TdrNafHeadBwdDesc(C.Structure):
@@ -118,6 +119,7 @@ SIGNATURES = {
     'tdr_dwsg_ws_floats': (i64, [i32, i32, i32, i32]),
     'tdr_dwsg_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwsg_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_dwsg_bwd_biased': (i32, [c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwgelu_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_dwgelu_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwconv_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp]),

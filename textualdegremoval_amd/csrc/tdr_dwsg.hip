@@ -39,6 +39,8 @@ struct DwArgs {
     float pscale;        // FWD: factor on the pool partial (1, or 1/(H*W) when one block covers the plane and writes `pooled` itself)
     float* pdw;          // DT: dw [2C][9] / db [2C] (db may be NULL) finished from the DU pass's `part` by block (0, c, 0) --
     float* pdb;          //     the parameter-gradient finish rides on the second pass instead of its own launch
+    const float* dgb;    // DU (GATE_MUL): optional [N][C] plane constant added to dg, times dgb_mul
+    float dgb_mul;
 };
 
 struct Row6 { float v[6]; };
@@ -130,7 +132,10 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
                 }
             } else {
                 f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-                if (live) gv = *reinterpret_cast<const f32x4*>(a.dg + ((long)n * C + c) * HW + (long)y * W + x0);
+                if (live) {
+                    gv = *reinterpret_cast<const f32x4*>(a.dg + ((long)n * C + c) * HW + (long)y * W + x0);
+                    if (a.dgb) gv += a.dgb[(long)n * C + c] * a.dgb_mul;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (GATE == GATE_GELU) {
@@ -251,6 +256,12 @@ extern "C" int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int 
 
 extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
                             float* dt, float* dw, float* db, float* ws, void* stream) {
+    return tdr_dwsg_bwd_biased(dg, nullptr, 0.f, t, w, b, N, C, H, W, dt, dw, db, ws, stream);
+}
+
+extern "C" int tdr_dwsg_bwd_biased(const float* dg, const float* dg_bias, float dg_bias_mul, const float* t, const float* w,
+                                   const float* b, int N, int C, int H, int W, float* dt, float* dw, float* db, float* ws,
+                                   void* stream) {
     TDR_REQUIRE(dg && t && w && b && dt && dw && db && ws, "tdr_dwsg_bwd: null pointer");
     TDR_REQUIRE(W % 4 == 0, "tdr_dwsg_bwd: W must be a multiple of 4 (got %d)", W);
     hipStream_t st = (hipStream_t)stream;
@@ -258,7 +269,7 @@ extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, con
     float* part = ws;
     float* du = ws + (int64_t)N * C * q.nb * 20;
     du += (4 - (reinterpret_cast<uintptr_t>(du) / 4) % 4) % 4;   // 16-byte aligned scratch planes (ws holds one spare vector)
-    DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
+    DwArgs a1{t, dg, w, b, du, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
     DwArgs a2{du, nullptr, w, b, dt, part, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, dw, db};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);

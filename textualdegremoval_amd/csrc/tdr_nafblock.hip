@@ -503,6 +503,9 @@ struct TailBwdArgs {
     float* part;                      // [gridDim.y * gridDim.x][2][C] LayerNorm parameter-gradient partials
     int HW;
     int c_out;                        // channels of dout (= rows of conv5 that exist); C or C / 2
+    // optional conv3 data-gradient stage (tail only): dgp = s[n] * (W3^T (beta * dy)); the pooled-gradient term of the SCA
+    // branch is added by the depthwise backward when it reads dgp (tdr_dwsg_bwd_biased)
+    const uint4* w3t; const float* beta; const float* sca; float* dgp; long dgp_ns;
 };
 
 __device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 lanes of a wave half (same kk)
@@ -713,7 +716,49 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) res[r] = has_res ? dop[off(r, tn)] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dyp[off(r, tn)] = (gv[tn][r] - yh[tn][r] * m1 - m2) * rstd_[tn] + res[r];
+            for (int r = 0; r < 16; ++r) gv[tn][r] = (gv[tn][r] - yh[tn][r] * m1 - m2) * rstd_[tn] + res[r];      // = dy
+            if (HEAD || !a.w3t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dyp[off(r, tn)] = gv[tn][r];
+            }
+        }
+    }
+    if constexpr (!HEAD) {
+        if (a.w3t) {
+            // ---- conv3 data gradient on the way out (:226-230 backward): u = W3^T (beta * dy), dgp = u * sca[n]; dy itself
+            // leaves for HBM under the MFMAs.  (sB: every wave passed the barrier after conv4's GEMM.)
+            float be[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) be[r] = a.beta[m0 + row_of(r, kk)];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = gv[tn][r] * be[r];
+                tile_to_planes(v, sB, C / 8, 4 * wave, 32 * tn + j, kk);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
+            float* dyp = a.dy + (long)n * a.dy_ns + p0 + j;
+            gemm_hx2<1, C / 16, 4>(acc, a.w3t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [&](int g) {
+                constexpr int IPG = 32 / (C / 16);
+#pragma unroll
+                for (int e = 0; e < IPG; ++e) {
+                    const int idx = g * IPG + e, tn = idx >> 4, r = idx & 15;
+                    dyp[off(r, tn)] = gv[tn][r];
+                }
+            });
+            float sc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = a.sca[(long)n * C + m0 + row_of(r, kk)];
+            float* gp = a.dgp + (long)n * a.dgp_ns + p0 + j;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gp[off(r, tn)] = acc[0][tn][r] * sc[r];
         }
     }
 }
@@ -795,6 +840,8 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
     a.res = d->dout; a.res_ns = d->dout_ns;
     a.c_out = d->c_out > 0 ? d->c_out : d->C;
     TDR_REQUIRE(a.c_out == d->C || (a.c_out * 2 == d->C && a.c_out % 32 == 0), "tdr_naf_tail_bwd: c_out must be C or C / 2 (a multiple of 32)");
+    a.w3t = reinterpret_cast<const uint4*>(d->w3t); a.beta = d->beta; a.sca = d->sca; a.dgp = d->dgp; a.dgp_ns = d->dgp_ns;
+    TDR_REQUIRE(!d->w3t || (d->beta && d->sca && d->dgp), "tdr_naf_tail_bwd: the conv3 stage needs beta, sca and dgp");
     const size_t lds = (size_t)2 * (2 * d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
     if (d->C == 256) NAF_DISPATCH_C(256, (naf_tail_bwd_kernel<256, false>), lds, a, d, stream);
     else if (d->C == 128) NAF_DISPATCH_C(128, (naf_tail_bwd_kernel<128, false>), lds, a, d, stream);
@@ -816,6 +863,7 @@ extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
     a.w5t = nullptr; a.w4t = reinterpret_cast<const uint4*>(d->w1t);
     a.dt4 = nullptr; a.dt4_ns = 0; a.res = d->res; a.res_ns = d->res_ns; a.dy = d->dx; a.dy_ns = d->dx_ns; a.part = d->ws; a.HW = d->HW;
     a.c_out = d->C;
+    a.w3t = nullptr; a.beta = nullptr; a.sca = nullptr; a.dgp = nullptr; a.dgp_ns = 0;
     const size_t lds = (size_t)2 * (2 * d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
     if (d->C == 256) NAF_DISPATCH_C(256, (naf_tail_bwd_kernel<256, true>), lds, a, d, stream);
     else if (d->C == 128) NAF_DISPATCH_C(128, (naf_tail_bwd_kernel<128, true>), lds, a, d, stream);

@@ -17,6 +17,7 @@ LN_EPS = 1e-6
 # fused NAFBlock halves (csrc/tdr_nafblock.hip) where the shape allows; TDR_FUSE_NAF=0 keeps the per-op launches
 FUSE_TAIL = os.environ.get('TDR_FUSE_NAF', '1') == '1'
 FUSE_HEAD = FUSE_TAIL and os.environ.get('TDR_FUSE_HEAD', '1') == '1'      # norm1 -> conv1 (forward)
+FUSE_CONV3_DGRAD = os.environ.get('TDR_FUSE_CONV3_DGRAD', '1') == '1'     # conv3's data gradient at the end of the tail backward
 
 
 def _sub(P, pre):
@@ -122,7 +123,12 @@ def naf_bwd(dout, P, saved):
     if fused:
         # conv5 dgrad -> SimpleGate bwd -> conv4 dgrad -> norm2 bwd (+ skip) in one launch
         w5t, w4t = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)[0], K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)[0]
-        dy, dt4, G['norm2.weight'], G['norm2.bias'] = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t, w4t)
+        if FUSE_CONV3_DGRAD:
+            w3t = K.pack_weights(P['conv3.weight'], PACK_DGRAD_S1)[0]
+            dy, dt4, G['norm2.weight'], G['norm2.bias'], dgp = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t,
+                                                                              w4t, w3tp=w3t, beta=beta, sca=s.contiguous())
+        else:
+            dy, dt4, G['norm2.weight'], G['norm2.bias'] = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t, w4t)
     else:
         wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
         dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
@@ -141,10 +147,15 @@ def naf_bwd(dout, P, saved):
                                                        P['sca.1.weight'])
     G['conv3.weight'], G['conv3.bias'], G['beta'] = dw3, db3, dbeta
     G['sca.1.weight'], G['sca.1.bias'] = dwsca, dbsca
-    wp, mp, *_ = K.pack_weights(P['conv3.weight'], PACK_DGRAD_S1)
-    dg = K.conv_forward(dy, wp, mp, c, 1, kscale=beta, scale=s, bias2=dpooled, bias2_mul=1.0 / (H * W))
     # ---- depthwise + SimpleGate
-    dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'])
+    if fused and FUSE_CONV3_DGRAD:
+        # conv3's data gradient already left the tail kernel; its pooled-gradient term joins as a per-plane constant
+        dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dgp, t1, P['conv2.weight'], P['conv2.bias'], dg_bias=dpooled,
+                                                             dg_bias_mul=1.0 / (H * W))
+    else:
+        wp, mp, *_ = K.pack_weights(P['conv3.weight'], PACK_DGRAD_S1)
+        dg = K.conv_forward(dy, wp, mp, c, 1, kscale=beta, scale=s, bias2=dpooled, bias2_mul=1.0 / (H * W))
+        dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'])
     # ---- conv1
     with K.on_side(xn, dt1):
         g1, G['conv1.bias'] = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)

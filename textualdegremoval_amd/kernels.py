@@ -499,7 +499,9 @@ def dwsg_fwd(t, w, b):
     return g, pooled
 
 
-def dwsg_bwd(dg, t, w, b):
+def dwsg_bwd(dg, t, w, b, dg_bias=None, dg_bias_mul=1.0):
+    """dg_bias [N, C]: per-plane constant added to dg (times dg_bias_mul) as it is read -- the pooled gradient of the SCA
+    branch when the conv3 data gradient comes out of the fused tail kernel without it."""
     lib = _lib.load()
     N, C2, H, W = t.shape
     Cc = C2 // 2
@@ -508,8 +510,8 @@ def dwsg_bwd(dg, t, w, b):
     dw = torch.empty(C2, 1, 3, 3, dtype=torch.float32, device=t.device)
     db = torch.empty(C2, dtype=torch.float32, device=t.device)
     ws = workspace(lib.tdr_dwsg_ws_floats(N, Cc, H, W), t.device)
-    check(lib.tdr_dwsg_bwd(dg.data_ptr(), t.data_ptr(), w.data_ptr(), b.data_ptr(), N, Cc, H, W, dt.data_ptr(),
-                           dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream()), 'tdr_dwsg_bwd')
+    check(lib.tdr_dwsg_bwd_biased(dg.data_ptr(), _p(dg_bias), float(dg_bias_mul), t.data_ptr(), w.data_ptr(), b.data_ptr(), N, Cc,
+                                  H, W, dt.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream()), 'tdr_dwsg_bwd')
     return dt, dw, db
 
 
@@ -550,9 +552,10 @@ def naf_tail_fwd(g, s, x, w3p, b3, beta, lnw, lnb, eps, w4p, b4, w5p, b5, gamma,
     return out, y, mu, rs, yn, t4
 
 
-def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp):
+def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp, w3tp=None, beta=None, sca=None):
     """fused conv5 dgrad -> SimpleGate bwd -> conv4 dgrad -> norm2 bwd (+ skip) (csrc/tdr_nafblock.hip).
-    Returns (dy, dt4, gw2, gb2)."""
+    Returns (dy, dt4, gw2, gb2[, dgp]); with w3tp / beta / sca the conv3 data gradient dgp = sca * W3^T (beta * dy) comes out
+    of the same launch (without the pooled-gradient term: dwsg_bwd(dg_bias=...) adds it)."""
     lib = _lib.load()
     N, Cc, H, W = y.shape
     dev = y.device
@@ -571,12 +574,19 @@ def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp):
     d.mu, d.rs, d.lnw, d.w5t, d.w4t = mu.data_ptr(), rs.data_ptr(), lnw.data_ptr(), w5tp.data_ptr(), w4tp.data_ptr()
     d.dt4, d.dt4_ns, d.dy, d.dy_ns = dt4.data_ptr(), _dense_nchw(dt4), dy.data_ptr(), _dense_nchw(dy)
     d.gw, d.gb, d.ws = gw.data_ptr(), gb.data_ptr(), ws.data_ptr()
+    dgp = None
+    if w3tp is not None:
+        assert w3tp.fmt == w4tp.fmt and sca.is_contiguous()
+        dgp = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
+        d.w3t, d.beta, d.sca, d.dgp, d.dgp_ns = w3tp.data_ptr(), beta.data_ptr(), sca.data_ptr(), dgp.data_ptr(), _dense_nchw(dgp)
     if _survey is not None:
         _survey.probe(dout, 'grad')
     check(lib.tdr_naf_tail_bwd(C.byref(d), _stream()), 'tdr_naf_tail_bwd')
     if _survey is not None:
         _survey.probe(dt4, 'grad')            # the K = 2C operand formed inside the kernel
-    return dy, dt4, gw, gb
+        if dgp is not None:
+            _survey.probe(dy, 'grad')         # (times beta: the K = C operand of the conv3 stage)
+    return (dy, dt4, gw, gb) if dgp is None else (dy, dt4, gw, gb, dgp)
 
 
 def naf_head_fwd(x, lnw, lnb, eps, w1p, b1):
