@@ -245,6 +245,12 @@ int tdr_add_rows(const float* src, int64_t src_ns, float* dst, int64_t dst_ns, i
 int tdr_pixel_unshuffle2(const float* in, int N, int C, int H, int W, float* out, void* stream);
 /* zero-pad / crop: dst[N,C,Hd,Wd] <- src[N,C,Hs,Ws] top-left aligned, zero fill (:576-585,740) */
 int tdr_pad_crop(const float* src, int N, int C, int Hs, int Ws, float* dst, int Hd, int Wd, void* stream);
+/* Input pipeline on the device: paired random crop (data/transforms.py:24-84) + the 8 flip / rot90 modes of
+ * data_augmentation (:223-270, numpy semantics) + optional sigma-noise synthesis (restoration_dataset.py:464-476), one
+ * gather per batch.  src [N][C][Hs][Ws] (per-image stride src_ns), per-sample top / left / mode int32 device arrays (NULL:
+ * 0), noise [N][C][P][P] and sigma [N] (NULL: no noise / sigma 1), out [N][C][P][P].  The caller draws the parameters. */
+int tdr_crop_augment(const float* src, int64_t src_ns, int N, int C, int Hs, int Ws, const int* top, const int* left,
+                     const int* mode, const float* noise, const float* sigma, int P, float* out, void* stream);
 
 /* ReLU backward: out = act > 0 ? go : 0 (Encoder/ResidualBlock nn.ReLU, :52,132) */
 int tdr_relu_bwd(const float* go, const float* act, int64_t numel, float* out, void* stream);

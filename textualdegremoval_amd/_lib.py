@@ -187,6 +187,7 @@ SIGNATURES = {
     'tdr_absmax_bits': (i32, [c_fp, i64, i32, i64, c_fp, c_fp]),
     'tdr_pair_sum_partials': (i32, [c_fp, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_pair_sum_mid_floats': (i64, [i32, i32]),
+    'tdr_crop_augment': (i32, [c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp]),
     'tdr_plane_mean': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp]),
     'tdr_plane_add': (i32, [c_fp, i64, c_fp, f32, i32, i32, i32, c_fp]),
     'tdr_prompt_weights_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp]),

@@ -881,6 +881,51 @@ extern "C" int tdr_pixel_unshuffle2(const float* in, int N, int C, int H, int W,
     return TDR_OK;
 }
 
+namespace {
+// paired random crop + the 8 flip / rot90 modes of the reference's data_augmentation, gathered on the device
+//   a = src[n][:, top:top+P, left:left+P];  out[n] = T_mode(a)      (numpy semantics of np.flipud / np.rot90 on the H, W axes)
+// and, optionally, the sigma-noise synthesis of the denoising datasets: out += noise * sigma[n].
+__global__ void crop_augment_kernel(const float* __restrict__ src, long src_ns, int C, int Hs, int Ws, const int* __restrict__ top,
+                                    const int* __restrict__ left, const int* __restrict__ mode, const float* __restrict__ noise,
+                                    const float* __restrict__ sigma, int P, long total, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % P);
+        long r = i / P;
+        const int y = (int)(r % P); r /= P;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        const int q = P - 1;
+        int sy, sx;
+        switch (mode ? mode[n] : 0) {
+            case 1: sy = q - y; sx = x; break;            // flipud
+            case 2: sy = x; sx = q - y; break;            // rot90 (counter-clockwise)
+            case 3: sy = x; sx = y; break;                // flipud(rot90) = transpose
+            case 4: sy = q - y; sx = q - x; break;        // rot180
+            case 5: sy = y; sx = q - x; break;            // flipud(rot180) = fliplr
+            case 6: sy = q - x; sx = y; break;            // rot270
+            case 7: sy = q - x; sx = q - y; break;        // flipud(rot270) = anti-transpose
+            default: sy = y; sx = x; break;
+        }
+        float v = src[(long)n * src_ns + ((long)c * Hs + (top ? top[n] : 0) + sy) * Ws + (left ? left[n] : 0) + sx];
+        if (noise) v += noise[i] * (sigma ? sigma[n] : 1.f);
+        out[i] = v;
+    }
+}
+}  // namespace
+
+/* data/transforms.py:24-84 (paired_random_crop), :223-270 (data_augmentation modes 0-7), restoration_dataset.py:464-476 (noise) */
+extern "C" int tdr_crop_augment(const float* src, int64_t src_ns, int N, int C, int Hs, int Ws, const int* top, const int* left,
+                                const int* mode, const float* noise, const float* sigma, int P, float* out, void* stream) {
+    TDR_REQUIRE(src && out && N > 0 && C > 0 && P > 0 && P <= Hs && P <= Ws, "tdr_crop_augment: bad argument (patch %d of %d x %d)", P, Hs, Ws);
+    const long total = (long)N * C * P * P;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(crop_augment_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, src, (long)src_ns, C, Hs, Ws, top, left,
+                       mode, noise, sigma, P, total, out);
+    TDR_LAUNCH_CHECK("crop_augment");
+    return TDR_OK;
+}
+
 extern "C" int tdr_pad_crop(const float* src, int N, int C, int Hs, int Ws, float* dst, int Hd, int Wd, void* stream) {
     TDR_REQUIRE(src && dst, "tdr_pad_crop: null pointer");
     const long total = (long)N * C * Hd * Wd;

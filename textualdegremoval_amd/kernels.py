@@ -1189,3 +1189,15 @@ def resize_bilinear_bwd(dd, Hs, Ws):
     ds = torch.empty(B, Cc, Hs, Ws, dtype=torch.float32, device=dd.device)
     check(_lib.load().tdr_resize_bilinear_bwd(dd.data_ptr(), B * Cc, Hs, Ws, Hd, Wd, ds.data_ptr(), _stream()), 'tdr_resize_bilinear_bwd')
     return ds
+
+
+def crop_augment(src, top, left, mode, patch, noise=None, sigma=None):
+    """src [N,C,H,W] -> [N,C,patch,patch]: per-sample crop at (top, left) + augmentation mode 0-7 (+ noise * sigma).
+    top / left / mode: int32 device tensors [N] (or None); noise [N,C,patch,patch], sigma [N] float32 (or None)."""
+    N, Cc, H, W = src.shape
+    out = torch.empty(N, Cc, patch, patch, dtype=torch.float32, device=src.device)
+    for t in (top, left, mode):
+        assert t is None or (t.dtype == torch.int32 and t.is_cuda and t.numel() == N)
+    check(_lib.load().tdr_crop_augment(src.data_ptr(), _dense_nchw(src), N, Cc, H, W, _p(top), _p(left), _p(mode), _p(noise), _p(sigma),
+                                       int(patch), out.data_ptr(), _stream()), 'tdr_crop_augment')
+    return out

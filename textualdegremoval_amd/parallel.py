@@ -93,7 +93,23 @@ def data_plane(group=None):
         return None
     if dist.get_world_size(group) == 1 and os.environ.get('TDR_FORCE_COLLECTIVES') != '1':
         return None
-    return TdrComm.from_process_group(group)
+    # every rank tries; the ranks then agree (MIN over a success flag) -- a node where the RCCL binding cannot be
+    # brought up (librccl missing / two incompatible copies) falls back to torch.distributed's collectives, which are
+    # RCCL as well, instead of failing the job.  The fallback is logged and visible in bench.py's `collectives` field.
+    comm, err = None, None
+    try:
+        comm = TdrComm.from_process_group(group)
+    except Exception as e:          # noqa: BLE001 -- any failure of the optional binding takes the torch path
+        err = e
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device='cuda')
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        return comm
+    if comm is not None:
+        comm.destroy()
+    import logging
+    logging.getLogger('tdr').warning('tdr_comm (RCCL through the C ABI) unavailable on some rank (%s): using torch.distributed collectives', err)
+    return None
 
 
 class GradSink(dict):
