@@ -1,0 +1,142 @@
+// Generic grouped "depthwise-like" convolutions of DRSformer-ref's mixed-scale feed-forward (network_drsformer_guided_arch*.py
+// :216-253): K x K (K = 3, 5), stride 1, pad K/2, no bias, groups = Cout with `mult` = 1 or 2 input planes per output plane
+// (dwconv3x3 / dwconv5x5: mult 1 over 2h planes; dwconv3x3_1 / dwconv5x5_1: Conv2d(2h, h, groups=h), mult 2), optional ReLU:
+//     y[n][c] = act( sum_{i < mult} w[c][i] (*) x[n][c * mult + i] )
+// Straightforward streaming kernels (HBM-bound stencils: each input plane is read once per launch, neighbours come from
+// L1/L2); the weight gradient is one workgroup per (c, i) plane pair with a fixed-order in-block reduction (deterministic).
+// First implementation of this family: correctness and the C ABI first, tiling later.
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+namespace {
+
+__global__ void dwk_fwd_kernel(const float* __restrict__ x, long x_ns, const float* __restrict__ w, int Cout, int mult, int H, int W,
+                               int K, int relu, long total, float* __restrict__ y, long y_ns) {
+    const int pad = K / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % W);
+        long r = i / W;
+        const int py = (int)(r % H); r /= H;
+        const int c = (int)(r % Cout);
+        const long n = r / Cout;
+        float s = 0.f;
+        for (int q = 0; q < mult; ++q) {
+            const float* xp = x + n * x_ns + ((long)c * mult + q) * H * W;
+            const float* wp = w + ((long)c * mult + q) * K * K;
+            for (int ky = 0; ky < K; ++ky) {
+                const int yy = py + ky - pad;
+                if (yy < 0 || yy >= H) continue;
+                for (int kx = 0; kx < K; ++kx) {
+                    const int xx = px + kx - pad;
+                    if (xx >= 0 && xx < W) s += wp[ky * K + kx] * xp[(long)yy * W + xx];
+                }
+            }
+        }
+        y[n * y_ns + ((long)c * H + py) * W + px] = relu ? fmaxf(s, 0.f) : s;
+    }
+}
+
+// dx[n][c*mult + q][p] = sum_taps w[c][q][ky][kx] * g[n][c][p - (tap - pad)],  g = dy (* [y > 0])
+__global__ void dwk_bwd_data_kernel(const float* __restrict__ dy, long dy_ns, const float* __restrict__ yact, long y_ns,
+                                    const float* __restrict__ w, int Cout, int mult, int H, int W, int K, long total,
+                                    float* __restrict__ dx, long dx_ns) {
+    const int pad = K / 2;
+    const int Cin = Cout * mult;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % W);
+        long r = i / W;
+        const int py = (int)(r % H); r /= H;
+        const int ci = (int)(r % Cin);
+        const long n = r / Cin;
+        const int c = ci / mult;
+        const float* gp = dy + n * dy_ns + (long)c * H * W;
+        const float* ap = yact ? yact + n * y_ns + (long)c * H * W : nullptr;
+        const float* wp = w + (long)ci * K * K;
+        float s = 0.f;
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = py - (ky - pad);
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int xx = px - (kx - pad);
+                if (xx < 0 || xx >= W) continue;
+                const long o = (long)yy * W + xx;
+                const float g = (!ap || ap[o] > 0.f) ? gp[o] : 0.f;
+                s += wp[ky * K + kx] * g;
+            }
+        }
+        dx[n * dx_ns + ((long)ci * H + py) * W + px] = s;
+    }
+}
+
+// one workgroup per input plane ci (= c * mult + q): dw[ci][tap] = sum_{n, p} g[n][c][p] * x[n][ci][p + tap - pad]
+template <int K>
+__global__ __launch_bounds__(256) void dwk_bwd_weight_kernel(const float* __restrict__ dy, long dy_ns, const float* __restrict__ yact,
+                                                            long y_ns, const float* __restrict__ x, long x_ns, int N, int mult, int H,
+                                                            int W, float* __restrict__ dw) {
+    __shared__ float red[4][K * K];
+    const int ci = blockIdx.x, c = ci / mult;
+    constexpr int pad = K / 2;
+    const long HW = (long)H * W;
+    float acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
+    for (long i = threadIdx.x; i < N * HW; i += 256) {
+        const long n = i / HW;
+        const long p = i - n * HW;
+        const int py = (int)(p / W), px = (int)(p - (long)py * W);
+        float g = dy[n * dy_ns + c * HW + p];
+        if (yact && !(yact[n * y_ns + c * HW + p] > 0.f)) g = 0.f;
+        const float* xp = x + n * x_ns + (long)ci * HW;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = py + ky - pad;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int xx = px + kx - pad;
+                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                acc[ky * K + kx] += ok ? g * xp[(long)yy * W + xx] : 0.f;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        const float s = wave_sum(acc[t]);
+        if (lane == 0) red[wv][t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K) dw[(long)ci * K * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+inline int dgrid(long total, int cap = 16384) {
+    long b = (total + 255) / 256;
+    return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+}  // namespace
+
+extern "C" int tdr_dwk_fwd(const float* x, int64_t x_ns, const float* w, int N, int Cout, int mult, int H, int W, int K, int relu,
+                           float* y, int64_t y_ns, void* stream) {
+    TDR_REQUIRE(x && w && y && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7),
+                "tdr_dwk_fwd: bad argument (mult 1|2, K 1|3|5|7; got mult=%d K=%d)", mult, K);
+    const long total = (long)N * Cout * H * W;
+    hipLaunchKernelGGL(dwk_fwd_kernel, dim3(dgrid(total)), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, w, Cout, mult, H, W, K, relu,
+                       total, y, (long)y_ns);
+    TDR_LAUNCH_CHECK("dwk_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w,
+                           int N, int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, void* stream) {
+    TDR_REQUIRE(dy && x && w && dx && dw && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7),
+                "tdr_dwk_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * Cout * mult * H * W;
+    hipLaunchKernelGGL(dwk_bwd_data_kernel, dim3(dgrid(total)), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, Cout, mult, H, W, K,
+                       total, dx, (long)dx_ns);
+#define DWK_W(K_) hipLaunchKernelGGL(dwk_bwd_weight_kernel<K_>, dim3(Cout * mult), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, N, mult, H, W, dw)
+    if (K == 1) DWK_W(1); else if (K == 3) DWK_W(3); else if (K == 5) DWK_W(5); else DWK_W(7);
+#undef DWK_W
+    TDR_LAUNCH_CHECK("dwk_bwd");
+    return TDR_OK;
+}

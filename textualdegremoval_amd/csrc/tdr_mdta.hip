@@ -169,6 +169,193 @@ __global__ __launch_bounds__(256) void mdta_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// DRSformer-ref's Top-K Sparse Attention (network_drsformer_guided_arch*.py:260-331): the same channel-token attention, but
+//   out = sum_m a_m * softmax(mask_m(L)) v,   mask_m keeps the k_m largest logits of a row (k = c/2, 2c/3, 3c/4, 4c/5)
+// All four branches multiply the same v, so they collapse into ONE c x c matrix A = sum_m a_m P_m and the rest of the
+// MDTA machinery (attn v and the q / k gradients as per-image 1x1 convs) is unchanged.  Top-k by rank: entry j is kept
+// iff fewer than k entries of its row are larger (ties: lower index first).
+// grid (heads, N); wave per row; lane holds columns lane + 64 u.  LDS: 4 rows of logits.
+// ---------------------------------------------------------------------------------------------------------------
+struct TksaK { int k[4]; };
+
+template <int NU>
+__device__ __forceinline__ void tksa_row(const float* __restrict__ Grow, const float* __restrict__ sq, int C, int c, int h, float t,
+                                         float inq, const float (&ink)[NU], float* __restrict__ lrow, const TksaK& kk, int lane,
+                                         float (&Gh)[NU], float (&Pm)[4][NU]) {
+    float L[NU], m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int j = lane + 64 * u;
+        Gh[u] = j < c ? Grow[h * c + j] * inq * ink[u] : 0.f;
+        L[u] = j < c ? t * Gh[u] : -INFINITY;
+        if (j < c) lrow[j] = L[u];
+        m = fmaxf(m, L[u]);
+    }
+    m = wave_max(m);
+    __builtin_amdgcn_wave_barrier();
+    int rank[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) rank[u] = 0;
+    for (int jj = 0; jj < c; ++jj) {
+        const float v = lrow[jj];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int j = lane + 64 * u;
+            rank[u] += (v > L[u] || (v == L[u] && jj < j)) ? 1 : 0;
+        }
+    }
+    float e[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) e[u] = (lane + 64 * u) < c ? expf(L[u] - m) : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) s += rank[u] < kk.k[q] ? e[u] : 0.f;
+        s = wave_sum(s);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) Pm[q][u] = rank[u] < kk.k[q] ? e[u] / s : 0.f;
+    }
+    (void)sq; (void)C;
+}
+
+template <int NU>
+__global__ __launch_bounds__(256) void tksa_softmax_kernel(const float* __restrict__ G, const float* __restrict__ ss,
+                                                          const float* __restrict__ temp, const float* __restrict__ am, TksaK kk,
+                                                          int C, int c, int Cp, float* __restrict__ A, float* __restrict__ AT) {
+    __shared__ float lrow[4][64 * NU];
+    const int h = blockIdx.x, n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float t = temp[h];
+    const float a0 = am[0], a1 = am[1], a2 = am[2], a3 = am[3];
+    const float* Gn = G + (long)n * C * C;
+    const float* sq = ss + (long)n * 2 * C;
+    float* An = A + (long)n * Cp * Cp;
+    float* ATn = AT + (long)n * Cp * Cp;
+    float ink[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int j = lane + 64 * u;
+        ink[u] = j < c ? 1.0f / fmaxf(sqrtf(sq[C + h * c + j]), NORM_EPS) : 0.f;
+    }
+    for (int i = wv; i < c; i += 4) {
+        const int gi = h * c + i;
+        const float inq = 1.0f / fmaxf(sqrtf(sq[gi]), NORM_EPS);
+        float Gh[NU], Pm[4][NU];
+        tksa_row<NU>(Gn + (long)gi * C, sq, C, c, h, t, inq, ink, lrow[wv], kk, lane, Gh, Pm);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int j = lane + 64 * u;
+            if (j < c) {
+                const float p = ((a0 * Pm[0][u] + a1 * Pm[1][u]) + a2 * Pm[2][u]) + a3 * Pm[3][u];
+                An[(long)gi * Cp + h * c + j] = p;
+                ATn[(long)(h * c + j) * Cp + gi] = p;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// backward: dL = sum_m a_m P_m (dA - <P_m, dA>);  da_m partial = <P_m, dA>;  then exactly mdta_bwd_kernel's tail.
+// dynamic LDS: E [c][c+1] + rowt[c] + rowa[c][4] + lrow[4][64 NU]
+template <int NU>
+__global__ __launch_bounds__(256) void tksa_bwd_kernel(const float* __restrict__ G, const float* __restrict__ ss,
+                                                      const float* __restrict__ temp, const float* __restrict__ am, TksaK kk,
+                                                      const float* __restrict__ dA, int C, int c, int Wp, float* __restrict__ W,
+                                                      float* __restrict__ dt_part, float* __restrict__ da_part) {
+    extern __shared__ float lds[];
+    float* E = lds;                         // [c][c+1]
+    float* rowt = lds + c * (c + 1);        // [c]
+    float* rowa = rowt + c;                 // [c][4]
+    float* lrow = rowa + 4 * c;             // [4][64 NU]
+    const int h = blockIdx.x, n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int heads = gridDim.x;
+    const float t = temp[h];
+    const float a[4] = {am[0], am[1], am[2], am[3]};
+    const float* Gn = G + (long)n * C * C;
+    const float* dAn = dA + (long)n * C * C;
+    const float* sq = ss + (long)n * 2 * C;
+    float* Wn = W + (long)n * Wp * Wp;
+    float ink[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int j = lane + 64 * u;
+        ink[u] = j < c ? 1.0f / fmaxf(sqrtf(sq[C + h * c + j]), NORM_EPS) : 0.f;
+    }
+    for (int i = wv; i < c; i += 4) {
+        const int gi = h * c + i;
+        const float nq = sqrtf(sq[gi]);
+        const float inq = 1.0f / fmaxf(nq, NORM_EPS);
+        float Gh[NU], Pm[4][NU], dP[NU], dL[NU];
+        tksa_row<NU>(Gn + (long)gi * C, sq, C, c, h, t, inq, ink, lrow + wv * 64 * NU, kk, lane, Gh, Pm);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int j = lane + 64 * u;
+            dP[u] = j < c ? dAn[(long)gi * C + h * c + j] : 0.f;
+            dL[u] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float pd = 0.f;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) pd += Pm[q][u] * dP[u];
+            pd = wave_sum(pd);
+            if (lane == 0) rowa[i * 4 + q] = pd;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) dL[u] += a[q] * Pm[q][u] * (dP[u] - pd);
+        }
+        float rt = 0.f, rho = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int j = lane + 64 * u;
+            rt += dL[u] * Gh[u];
+            const float dGh = t * dL[u];
+            const float e = dGh * Gh[u];
+            rho += e;
+            if (j < c) {
+                E[i * (c + 1) + j] = e;
+                const float w = dGh * inq * ink[u];
+                Wn[(long)gi * Wp + C + h * c + j] = w;
+                Wn[(long)(C + h * c + j) * Wp + gi] = w;
+            }
+        }
+        rt = wave_sum(rt);
+        rho = wave_sum(rho);
+        if (lane == 0) {
+            rowt[i] = rt;
+            Wn[(long)gi * Wp + gi] = nq > NORM_EPS ? -rho * inq * inq : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < c; j += 256) {
+        float s = 0.f;
+        for (int i = 0; i < c; ++i) s += E[i * (c + 1) + j];
+        const float nk = sqrtf(sq[C + h * c + j]);
+        const float inkj = 1.0f / fmaxf(nk, NORM_EPS);
+        const long d = C + h * c + j;
+        Wn[d * Wp + d] = nk > NORM_EPS ? -s * inkj * inkj : 0.f;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < c; ++i) s += rowt[i];
+        dt_part[(long)n * heads + h] = s;
+    }
+    if (threadIdx.x < 4) {
+        float s = 0.f;
+        for (int i = 0; i < c; ++i) s += rowa[i * 4 + threadIdx.x];
+        da_part[((long)n * heads + h) * 4 + threadIdx.x] = s;
+    }
+}
+
+__global__ void tksa_da_kernel(const float* __restrict__ part, int nparts, float* __restrict__ da) {
+    const int q = threadIdx.x;
+    if (q >= 4) return;
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += part[(long)i * 4 + q];
+    da[q] = s;
+}
+
 __global__ void mdta_dtemp_kernel(const float* __restrict__ part, int N, int heads, float* __restrict__ dtemp) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= heads) return;
@@ -275,6 +462,57 @@ extern "C" int tdr_mdta_bwd(const float* G, const float* ss, const float* temp, 
     }
     hipLaunchKernelGGL(mdta_dtemp_kernel, dim3(tdr_cdiv(heads, 64)), dim3(64), 0, st, ws, N, heads, dtemp);
     TDR_LAUNCH_CHECK("mdta_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_tksa_softmax(const float* G, const float* ss, const float* temp, const float* am, const int* k4, int N, int C,
+                                int heads, float* A, float* AT, void* stream) {
+    TDR_REQUIRE(G && ss && temp && am && k4 && A && AT, "tdr_tksa_softmax: null pointer");
+    TDR_REQUIRE(heads > 0 && C % heads == 0 && C / heads <= 192, "tdr_tksa_softmax: need C %% heads == 0 and C/heads <= 192 (C=%d heads=%d)", C, heads);
+    hipStream_t st = (hipStream_t)stream;
+    const int Cp = tdr_mdta_pad(C);
+    const size_t bytes = (size_t)N * Cp * Cp * sizeof(float);
+    if (hipMemsetAsync(A, 0, bytes, st) != hipSuccess || hipMemsetAsync(AT, 0, bytes, st) != hipSuccess) {
+        tdr_set_error("tdr_tksa_softmax: memset failed");
+        return TDR_ERR_HIP;
+    }
+    TksaK kk{{k4[0], k4[1], k4[2], k4[3]}};
+    if (C / heads <= 128)
+        hipLaunchKernelGGL(tksa_softmax_kernel<2>, dim3(heads, N), dim3(256), 0, st, G, ss, temp, am, kk, C, C / heads, Cp, A, AT);
+    else
+        hipLaunchKernelGGL(tksa_softmax_kernel<3>, dim3(heads, N), dim3(256), 0, st, G, ss, temp, am, kk, C, C / heads, Cp, A, AT);
+    TDR_LAUNCH_CHECK("tksa_softmax");
+    return TDR_OK;
+}
+
+extern "C" int tdr_tksa_bwd(const float* G, const float* ss, const float* temp, const float* am, const int* k4, const float* dA,
+                            int N, int C, int heads, float* W, float* dtemp, float* dam, float* ws, void* stream) {
+    TDR_REQUIRE(G && ss && temp && am && k4 && dA && W && dtemp && dam && ws, "tdr_tksa_bwd: null pointer (ws needs 5*N*heads floats)");
+    TDR_REQUIRE(heads > 0 && C % heads == 0 && C / heads <= 192, "tdr_tksa_bwd: need C %% heads == 0 and C/heads <= 192 (C=%d heads=%d)", C, heads);
+    hipStream_t st = (hipStream_t)stream;
+    const int c = C / heads, Wp = tdr_mdta_pad(2 * C);
+    if (hipMemsetAsync(W, 0, (size_t)N * Wp * Wp * sizeof(float), st) != hipSuccess) {
+        tdr_set_error("tdr_tksa_bwd: memset failed");
+        return TDR_ERR_HIP;
+    }
+    TksaK kk{{k4[0], k4[1], k4[2], k4[3]}};
+    const int NU = c <= 128 ? 2 : 3;
+    const size_t lds = ((size_t)c * (c + 1) + c + 4 * c + 4 * 64 * NU) * sizeof(float);
+    float* da_part = ws + (long)N * heads;
+    if (NU == 2) {
+        auto kern = tksa_bwd_kernel<2>;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(heads, N), dim3(256), lds, st, G, ss, temp, am, kk, dA, C, c, Wp, W, ws, da_part);
+    } else {
+        auto kern = tksa_bwd_kernel<3>;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(heads, N), dim3(256), lds, st, G, ss, temp, am, kk, dA, C, c, Wp, W, ws, da_part);
+    }
+    hipLaunchKernelGGL(mdta_dtemp_kernel, dim3(tdr_cdiv(heads, 64)), dim3(64), 0, st, ws, N, heads, dtemp);
+    hipLaunchKernelGGL(tksa_da_kernel, dim3(1), dim3(64), 0, st, da_part, N * heads, dam);
+    TDR_LAUNCH_CHECK("tksa_bwd");
     return TDR_OK;
 }
 

@@ -1201,3 +1201,59 @@ def crop_augment(src, top, left, mode, patch, noise=None, sigma=None):
     check(_lib.load().tdr_crop_augment(src.data_ptr(), _dense_nchw(src), N, Cc, H, W, _p(top), _p(left), _p(mode), _p(noise), _p(sigma),
                                        int(patch), out.data_ptr(), _stream()), 'tdr_crop_augment')
     return out
+
+
+# ---------------------------------------------------------------------------
+# DRSformer-ref pieces (csrc/tdr_mdta.hip: top-k sparse attention; csrc/tdr_dwk.hip: grouped depthwise convs)
+# ---------------------------------------------------------------------------
+def tksa_ks(c):
+    """the four top-k sizes of a head with c channels, as the reference computes them (python int() of float expressions,
+    network_drsformer_guided_arch.py:293-306)"""
+    return (C.c_int * 4)(int(c / 2), int(c * 2 / 3), int(c * 3 / 4), int(c * 4 / 5))
+
+
+def tksa_softmax(G, ss, temp, am, heads):
+    """G [N,C,C], ss [N,2C], am [4] (attn1..4) -> (A, AT) packed like mdta_softmax, A = sum_m am[m] softmax(topk_m(logits))"""
+    N, Cc = G.shape[0], G.shape[-1]
+    Cp = mdta_pad(Cc)
+    A = torch.empty(N, Cp, Cp, dtype=torch.float32, device=G.device)
+    AT = torch.empty_like(A)
+    check(_lib.load().tdr_tksa_softmax(G.data_ptr(), ss.data_ptr(), temp.data_ptr(), am.data_ptr(), tksa_ks(Cc // heads), N, Cc, heads,
+                                       A.data_ptr(), AT.data_ptr(), _stream()), 'tdr_tksa_softmax')
+    return A, AT
+
+
+def tksa_bwd(G, ss, temp, am, dA, heads):
+    """-> (W [N,Wp,Wp], dtemp [heads,1,1], dam [4])"""
+    N, Cc = G.shape[0], G.shape[-1]
+    Wp = mdta_pad(2 * Cc)
+    W = torch.empty(N, Wp, Wp, dtype=torch.float32, device=G.device)
+    dtemp = torch.empty(heads, 1, 1, dtype=torch.float32, device=G.device)
+    dam = torch.empty(4, dtype=torch.float32, device=G.device)
+    ws = torch.empty(5 * N * heads, dtype=torch.float32, device=G.device)
+    check(_lib.load().tdr_tksa_bwd(G.data_ptr(), ss.data_ptr(), temp.data_ptr(), am.data_ptr(), tksa_ks(Cc // heads), dA.data_ptr(), N, Cc,
+                                   heads, W.data_ptr(), dtemp.data_ptr(), dam.data_ptr(), ws.data_ptr(), _stream()), 'tdr_tksa_bwd')
+    return W, dtemp, dam
+
+
+def dwk_fwd(x, w, relu=False):
+    """grouped depthwise-like conv: w [Cout, mult, K, K] (mult 1 | 2), stride 1, pad K//2, no bias, optional fused ReLU"""
+    N, Cin, H, W = x.shape
+    Cout, mult, Kk, _ = w.shape
+    assert Cin == Cout * mult and w.is_contiguous()
+    y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_dwk_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, 1 if relu else 0, y.data_ptr(),
+                                  _dense_nchw(y), _stream()), 'tdr_dwk_fwd')
+    return y
+
+
+def dwk_bwd(dy, y_act, x, w):
+    """-> (dx, dw); y_act: the forward output when a ReLU was fused (its mask), else None"""
+    N, Cin, H, W = x.shape
+    Cout, mult, Kk, _ = w.shape
+    dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=x.device)
+    dw = torch.empty_like(w)
+    check(_lib.load().tdr_dwk_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
+                                  _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, dx.data_ptr(), _dense_nchw(dx), dw.data_ptr(),
+                                  _stream()), 'tdr_dwk_bwd')
+    return dx, dw
