@@ -319,17 +319,17 @@ int tdr_absmax_bits(const float* x, int64_t x_ns, int N, int64_t per, unsigned* 
  * tdr_tksa_softmax (:282-318): like tdr_mdta_softmax, but A = sum_m am[m] * softmax(mask_m(logits)), mask_m keeping the k4[m]
  * largest logits of a row (k = int(c/2), int(c*2/3), int(c*3/4), int(c*4/5), c = C/heads: host-computed); am = attn1..attn4.
  * tdr_tksa_bwd: dA -> W (as tdr_mdta_bwd), dtemp[heads], dam[4]; ws: 5*N*heads floats.
- * tdr_dwk_fwd/bwd (:221-247): y[n][c] = act(sum_{i<mult} w[c][i] (*) x[n][c*mult+i]), K x K (1|3|5|7), stride 1, pad K/2, no
- * bias, mult 1 | 2 (Conv2d(2h, h, groups=h)); relu: fused ReLU (backward masks with yact = the forward output, or NULL).
+ * tdr_dwk_fwd/bwd (:221-247): y[n][c] = act(sum_{i<mult} w[c][i] (*) x[n][c*mult+i]), K x K (1|3|5|7), stride 1, pad K/2,
+ * optional bias, mult 1 | 2 (Conv2d(2h, h, groups=h)); relu: fused ReLU (backward masks with yact = the forward output, or NULL).
  * ------------------------------------------------------------------------- */
 int tdr_tksa_softmax(const float* G, const float* ss, const float* temp, const float* am, const int* k4 /*host*/, int N, int C,
                      int heads, float* A, float* AT, void* stream);
 int tdr_tksa_bwd(const float* G, const float* ss, const float* temp, const float* am, const int* k4 /*host*/, const float* dA, int N,
                  int C, int heads, float* W, float* dtemp, float* dam, float* ws, void* stream);
-int tdr_dwk_fwd(const float* x, int64_t x_ns, const float* w, int N, int Cout, int mult, int H, int W, int K, int relu, float* y,
-                int64_t y_ns, void* stream);
+int tdr_dwk_fwd(const float* x, int64_t x_ns, const float* w, const float* b /*[Cout] or NULL*/, int N, int Cout, int mult, int H, int W,
+                int K, int relu, float* y, int64_t y_ns, void* stream);
 int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w, int N,
-                int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, void* stream);
+                int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, float* db /*or NULL*/, void* stream);
 
 /* ---------------------------------------------------------------------------
  * PromptIR-ref PromptGenBlock (network_promptir_guided_arch.py:417-441), everything around its 3x3 convolution:

@@ -10,7 +10,7 @@
 
 namespace {
 
-__global__ void dwk_fwd_kernel(const float* __restrict__ x, long x_ns, const float* __restrict__ w, int Cout, int mult, int H, int W,
+__global__ void dwk_fwd_kernel(const float* __restrict__ x, long x_ns, const float* __restrict__ w, const float* __restrict__ b, int Cout, int mult, int H, int W,
                                int K, int relu, long total, float* __restrict__ y, long y_ns) {
     const int pad = K / 2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -19,7 +19,7 @@ __global__ void dwk_fwd_kernel(const float* __restrict__ x, long x_ns, const flo
         const int py = (int)(r % H); r /= H;
         const int c = (int)(r % Cout);
         const long n = r / Cout;
-        float s = 0.f;
+        float s = b ? b[c] : 0.f;
         for (int q = 0; q < mult; ++q) {
             const float* xp = x + n * x_ns + ((long)c * mult + q) * H * W;
             const float* wp = w + ((long)c * mult + q) * K * K;
@@ -72,8 +72,10 @@ __global__ void dwk_bwd_data_kernel(const float* __restrict__ dy, long dy_ns, co
 template <int K>
 __global__ __launch_bounds__(256) void dwk_bwd_weight_kernel(const float* __restrict__ dy, long dy_ns, const float* __restrict__ yact,
                                                             long y_ns, const float* __restrict__ x, long x_ns, int N, int mult, int H,
-                                                            int W, float* __restrict__ dw) {
+                                                            int W, float* __restrict__ dw, float* __restrict__ db) {
     __shared__ float red[4][K * K];
+    __shared__ float redb[4];
+    float accb = 0.f;
     const int ci = blockIdx.x, c = ci / mult;
     constexpr int pad = K / 2;
     const long HW = (long)H * W;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void dwk_bwd_weight_kernel(const float* __rest
         const int py = (int)(p / W), px = (int)(p - (long)py * W);
         float g = dy[n * dy_ns + c * HW + p];
         if (yact && !(yact[n * y_ns + c * HW + p] > 0.f)) g = 0.f;
+        accb += g;
         const float* xp = x + n * x_ns + (long)ci * HW;
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
@@ -104,7 +107,12 @@ __global__ __launch_bounds__(256) void dwk_bwd_weight_kernel(const float* __rest
         const float s = wave_sum(acc[t]);
         if (lane == 0) red[wv][t] = s;
     }
+    {
+        const float sb = wave_sum(accb);
+        if (lane == 0) redb[wv] = sb;
+    }
     __syncthreads();
+    if (db && threadIdx.x == 0 && ci == c * mult) db[c] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
     if (threadIdx.x < K * K) dw[(long)ci * K * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
@@ -115,26 +123,26 @@ inline int dgrid(long total, int cap = 16384) {
 
 }  // namespace
 
-extern "C" int tdr_dwk_fwd(const float* x, int64_t x_ns, const float* w, int N, int Cout, int mult, int H, int W, int K, int relu,
-                           float* y, int64_t y_ns, void* stream) {
+extern "C" int tdr_dwk_fwd(const float* x, int64_t x_ns, const float* w, const float* b, int N, int Cout, int mult, int H, int W, int K,
+                           int relu, float* y, int64_t y_ns, void* stream) {
     TDR_REQUIRE(x && w && y && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7),
                 "tdr_dwk_fwd: bad argument (mult 1|2, K 1|3|5|7; got mult=%d K=%d)", mult, K);
     const long total = (long)N * Cout * H * W;
-    hipLaunchKernelGGL(dwk_fwd_kernel, dim3(dgrid(total)), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, w, Cout, mult, H, W, K, relu,
+    hipLaunchKernelGGL(dwk_fwd_kernel, dim3(dgrid(total)), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, w, b, Cout, mult, H, W, K, relu,
                        total, y, (long)y_ns);
     TDR_LAUNCH_CHECK("dwk_fwd");
     return TDR_OK;
 }
 
 extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w,
-                           int N, int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, void* stream) {
+                           int N, int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, float* db, void* stream) {
     TDR_REQUIRE(dy && x && w && dx && dw && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7),
                 "tdr_dwk_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)N * Cout * mult * H * W;
     hipLaunchKernelGGL(dwk_bwd_data_kernel, dim3(dgrid(total)), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, Cout, mult, H, W, K,
                        total, dx, (long)dx_ns);
-#define DWK_W(K_) hipLaunchKernelGGL(dwk_bwd_weight_kernel<K_>, dim3(Cout * mult), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, N, mult, H, W, dw)
+#define DWK_W(K_) hipLaunchKernelGGL(dwk_bwd_weight_kernel<K_>, dim3(Cout * mult), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, N, mult, H, W, dw, db)
     if (K == 1) DWK_W(1); else if (K == 3) DWK_W(3); else if (K == 5) DWK_W(5); else DWK_W(7);
 #undef DWK_W
     TDR_LAUNCH_CHECK("dwk_bwd");

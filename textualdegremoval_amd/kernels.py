@@ -1236,24 +1236,25 @@ def tksa_bwd(G, ss, temp, am, dA, heads):
     return W, dtemp, dam
 
 
-def dwk_fwd(x, w, relu=False):
-    """grouped depthwise-like conv: w [Cout, mult, K, K] (mult 1 | 2), stride 1, pad K//2, no bias, optional fused ReLU"""
+def dwk_fwd(x, w, b=None, relu=False):
+    """grouped depthwise-like conv: w [Cout, mult, K, K] (mult 1 | 2), stride 1, pad K//2, optional bias, optional fused ReLU"""
     N, Cin, H, W = x.shape
     Cout, mult, Kk, _ = w.shape
     assert Cin == Cout * mult and w.is_contiguous()
     y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
-    check(_lib.load().tdr_dwk_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, 1 if relu else 0, y.data_ptr(),
+    check(_lib.load().tdr_dwk_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), _p(b), N, Cout, mult, H, W, Kk, 1 if relu else 0, y.data_ptr(),
                                   _dense_nchw(y), _stream()), 'tdr_dwk_fwd')
     return y
 
 
-def dwk_bwd(dy, y_act, x, w):
-    """-> (dx, dw); y_act: the forward output when a ReLU was fused (its mask), else None"""
+def dwk_bwd(dy, y_act, x, w, want_db=False):
+    """-> (dx, dw, db); y_act: the forward output when a ReLU was fused (its mask), else None"""
     N, Cin, H, W = x.shape
     Cout, mult, Kk, _ = w.shape
     dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=x.device)
     dw = torch.empty_like(w)
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
     check(_lib.load().tdr_dwk_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
                                   _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, dx.data_ptr(), _dense_nchw(dx), dw.data_ptr(),
-                                  _stream()), 'tdr_dwk_bwd')
-    return dx, dw
+                                  _p(db), _stream()), 'tdr_dwk_bwd')
+    return dx, dw, db
