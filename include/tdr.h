@@ -329,7 +329,9 @@ int tdr_tksa_bwd(const float* G, const float* ss, const float* temp, const float
 int tdr_dwk_fwd(const float* x, int64_t x_ns, const float* w, const float* b /*[Cout] or NULL*/, int N, int Cout, int mult, int H, int W,
                 int K, int relu, float* y, int64_t y_ns, void* stream);
 int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w, int N,
-                int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, float* db /*or NULL*/, void* stream);
+                int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, float* db /*or NULL*/,
+                float* ws /*tdr_dwk_bwd_ws_floats floats: tiled K = 3 / 5 path; NULL = the untiled kernels*/, void* stream);
+int64_t tdr_dwk_bwd_ws_floats(int N, int Cout, int mult, int H, int W, int K);
 
 /* ---------------------------------------------------------------------------
  * PromptIR-ref PromptGenBlock (network_promptir_guided_arch.py:417-441), everything around its 3x3 convolution:

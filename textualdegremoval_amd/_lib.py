@@ -190,7 +190,8 @@ SIGNATURES = {
     'tdr_tksa_softmax': (i32, [c_fp, c_fp, c_fp, c_fp, C.POINTER(i32), i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_tksa_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, C.POINTER(i32), c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwk_fwd': (i32, [c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
-    'tdr_dwk_bwd': (i32, [c_fp, i64, c_fp, i64, c_fp, i64, c_fp, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp, c_fp, c_fp]),
+    'tdr_dwk_bwd': (i32, [c_fp, i64, c_fp, i64, c_fp, i64, c_fp, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_dwk_bwd_ws_floats': (i64, [i32, i32, i32, i32, i32, i32]),
     'tdr_crop_augment': (i32, [c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp]),
     'tdr_plane_mean': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp]),
     'tdr_plane_add': (i32, [c_fp, i64, c_fp, f32, i32, i32, i32, c_fp]),

@@ -1254,7 +1254,10 @@ def dwk_bwd(dy, y_act, x, w, want_db=False):
     dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=x.device)
     dw = torch.empty_like(w)
     db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
-    check(_lib.load().tdr_dwk_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
-                                  _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, dx.data_ptr(), _dense_nchw(dx), dw.data_ptr(),
-                                  _p(db), _stream()), 'tdr_dwk_bwd')
+    lib = _lib.load()
+    need = lib.tdr_dwk_bwd_ws_floats(N, Cout, mult, H, W, Kk)
+    ws = workspace(need, x.device, 'dwk') if need else None
+    check(lib.tdr_dwk_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
+                          _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, dx.data_ptr(), _dense_nchw(dx), dw.data_ptr(),
+                          _p(db), _p(ws), _stream()), 'tdr_dwk_bwd')
     return dx, dw, db
