@@ -245,3 +245,149 @@ def loss_and_grads(P, cfg, inp, ref, gt):
     names = [k for k, v in Pg.items() if v.requires_grad]
     gs = torch.autograd.grad(loss, [Pg[k] for k in names])
     return out.detach(), loss.detach(), OrderedDict(zip(names, gs))
+
+
+# --------------------------------------------------------------------------
+# The full class: DRSformerRefFusion (network_drsformer_guided_arch.py:679-1123) = the network above with a working level-1
+# fusion (no R6 there; functools is imported) plus the Mixture-of-Experts Feature Compensator (`subnet`, :522-548) after the
+# patch embedding (`encoder_level0`, dim channels) and before the output conv (`refinement`, 2 dim channels).
+# --------------------------------------------------------------------------
+OPS = ('sep_conv_1x1', 'sep_conv_3x3', 'sep_conv_5x5', 'sep_conv_7x7', 'dil_conv_3x3', 'dil_conv_5x5', 'dil_conv_7x7', 'avg_pool_3x3')
+STEPS = 4
+
+
+def _dw(x, w, pad, dil=1):
+    return F.conv2d(x, w, None, padding=pad, dilation=dil, groups=x.shape[1])
+
+
+def mefc_op(x, P, pre, j):
+    """OPS[j](C, 1, affine=False) (:437-447, :477-520); every conv bias-free"""
+    name = OPS[j]
+    if name == 'avg_pool_3x3':
+        return F.avg_pool2d(x, 3, stride=1, padding=1, count_include_pad=False)
+    k = int(name[-1])
+    if name.startswith('sep_conv'):
+        p = k // 2
+        t = F.conv2d(_dw(x, P[pre + 'op.0.weight'], p), P[pre + 'op.1.weight'])
+        t = F.relu(t)
+        return F.conv2d(_dw(t, P[pre + 'op.3.weight'], p), P[pre + 'op.4.weight'])
+    return F.conv2d(_dw(x, P[pre + 'op.0.weight'], k - 1, 2), P[pre + 'op.1.weight'])          # dil_conv: dilation 2, pad k-1
+
+
+def mefc_subnet(x, P, pre):
+    """subnet.forward (:539-548), layer_num = 1: OALayer -> softmax over the 8 ops -> GroupOLs (4 weighted-operation steps)"""
+    N = x.shape[0]
+    y = x.mean(dim=(-2, -1))
+    y = F.linear(F.relu(F.linear(y, P[pre + 'layers.0.ca_fc.0.weight'], P[pre + 'layers.0.ca_fc.0.bias'])),
+                 P[pre + 'layers.0.ca_fc.2.weight'], P[pre + 'layers.0.ca_fc.2.bias'])
+    wts = F.softmax(y.view(N, STEPS, len(OPS)), dim=-1)
+    g = pre + 'layers.1.'
+    s0 = F.relu(F.conv2d(x, P[g + 'preprocess.op.0.weight']))                                  # ReLUConv = conv THEN relu (:466-474)
+    for i in range(STEPS):
+        res = s0
+        states = [mefc_op(s0, P, f'{g}_ops.{i}._ops.{j}.', j) * wts[:, i, j].view(-1, 1, 1, 1) for j in range(len(OPS))]
+        s0 = F.relu(F.conv2d(torch.cat(states, dim=1), P[f'{g}_ops.{i}._out.0.weight']))
+        s0 = F.relu(s0 + res)
+    return s0
+
+
+def mefc_param_shapes(S, pre, C):
+    k, nops = STEPS, len(OPS)
+    S[pre + 'layers.0.ca_fc.0.weight'] = (2 * k * nops, C)
+    S[pre + 'layers.0.ca_fc.0.bias'] = (2 * k * nops,)
+    S[pre + 'layers.0.ca_fc.2.weight'] = (k * nops, 2 * k * nops)
+    S[pre + 'layers.0.ca_fc.2.bias'] = (k * nops,)
+    g = pre + 'layers.1.'
+    S[g + 'preprocess.op.0.weight'] = (C, C, 1, 1)
+    for i in range(STEPS):
+        for j, name in enumerate(OPS):
+            p = f'{g}_ops.{i}._ops.{j}.'
+            if name == 'avg_pool_3x3':
+                continue
+            kk = int(name[-1])
+            S[p + 'op.0.weight'] = (C, 1, kk, kk)
+            S[p + 'op.1.weight'] = (C, C, 1, 1)
+            if name.startswith('sep_conv'):
+                S[p + 'op.3.weight'] = (C, 1, kk, kk)
+                S[p + 'op.4.weight'] = (C, C, 1, 1)
+        S[f'{g}_ops.{i}._out.0.weight'] = (C, C * nops, 1, 1)
+
+
+def full_param_shapes(cfg):
+    """names / shapes / registration order of DRSformerRefFusion.__init__ (:679-806)"""
+    base = param_shapes(cfg)
+    S = OrderedDict()
+    dim = cfg['dim']
+    for k, v in base.items():
+        if k.startswith('masa_blk_enc_level1.') and 'encoder_level0.layers.0.ca_fc.0.weight' not in S:
+            mefc_param_shapes(S, 'encoder_level0.', dim)
+        if k == 'output.weight':
+            mefc_param_shapes(S, 'refinement.', 2 * dim)
+        S[k] = v
+    return S
+
+
+def full_synth_params(cfg, seed=0, alpha_std=0.1):
+    P = OrderedDict()
+    for i, (name, shape) in enumerate(full_param_shapes(cfg).items()):
+        g = torch.Generator().manual_seed(seed * 100003 + 32452843 + i)
+        if name.endswith('alpha'):
+            t = torch.randn(shape, generator=g) * alpha_std
+        elif name.endswith('temperature'):
+            t = 4.0 * (1.0 + 0.2 * torch.randn(shape, generator=g))
+        elif '.attn.attn' in name:
+            t = 0.2 + 0.1 * torch.randn(shape, generator=g)
+        elif 'ca_fc' in name:
+            t = torch.randn(shape, generator=g) * (0.5 if name.endswith('bias') else 2.0 / math.sqrt(shape[-1]))
+        elif 'norm' in name:
+            t = torch.randn(shape, generator=g) * 0.1
+            if name.endswith('weight'):
+                t = t + 1.0
+        elif name.endswith('weight'):
+            b = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+            t = (torch.rand(shape, generator=g) * 2 - 1) * b * (1.6 if ('_ops.' in name or 'preprocess' in name) else 1.0)
+        else:
+            t = (torch.rand(shape, generator=g) * 2 - 1) * 0.05
+        P[name] = t
+    return P
+
+
+def drsformer_full_forward(P, cfg, inp, ref, return_aux=False):
+    H0, W0 = inp.shape[-2:]
+    mult = PADDER * cfg['lr_block_size']
+    inp = NO.pad_to_multiple(inp, mult)
+    ref = NO.pad_to_multiple(ref, mult)
+    h, w = inp.shape[-2:]
+    hr, wr = ref.shape[-2:]
+    feat_lq = NO.masa_encoder(inp, P, 'masa_enc.', cfg['ext_n_blocks'], levels=4)
+    feat_ref = NO.masa_encoder(ref, P, 'masa_enc.', cfg['ext_n_blocks'], levels=4)
+    res = NO.masa_match_and_transfer(feat_lq, feat_ref, cfg, h, w, hr, wr, return_aux, padder=PADDER)
+    warp, aux = res if return_aux else (res, None)
+    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
+    seq = block_sequence
+    x = F.conv2d(inp, P['patch_embed.proj.weight'], P.get('patch_embed.proj.bias'), padding=1)
+    x = mefc_subnet(x, P, 'encoder_level0.')
+    x = seq(torch.cat([x, warp[0]], 1), P, 'masa_blk_enc_level1.', nfz[0], hd[0], ln, True)[:, :dim]
+    e1 = seq(x, P, 'encoder_level1.', nb[0], hd[0], ln)
+    x = RO.downsample(e1, P, 'down1_2.')
+    x = seq(torch.cat([x, warp[1]], 1), P, 'masa_blk_enc_level2.', nfz[1], hd[1], ln, True)[:, :2 * dim]
+    e2 = seq(x, P, 'encoder_level2.', nb[1], hd[1], ln)
+    x = RO.downsample(e2, P, 'down2_3.')
+    x = seq(torch.cat([x, warp[2]], 1), P, 'masa_blk_enc_level3.', nfz[2], hd[2], ln, True)[:, :4 * dim]
+    e3 = seq(x, P, 'encoder_level3.', nb[2], hd[2], ln)
+    x = RO.downsample(e3, P, 'down3_4.')
+    x = seq(torch.cat([x, warp[3]], 1), P, 'masa_blk_enc_level4.', nfz[3], hd[3], ln, True)[:, :8 * dim]
+    x = seq(x, P, 'latent.', nb[3], hd[3], ln)
+    x = torch.cat([RO.upsample(x, P, 'up4_3.'), e3], 1)
+    x = seq(F.conv2d(x, P['reduce_chan_level3.weight'], P.get('reduce_chan_level3.bias')), P, 'decoder_level3.', nb[2], hd[2], ln)
+    x = torch.cat([RO.upsample(x, P, 'up3_2.'), e2], 1)
+    x = seq(F.conv2d(x, P['reduce_chan_level2.weight'], P.get('reduce_chan_level2.bias')), P, 'decoder_level2.', nb[1], hd[1], ln)
+    x = torch.cat([RO.upsample(x, P, 'up2_1.'), e1], 1)
+    x = seq(x, P, 'decoder_level1.', nb[0], hd[0], ln)
+    x = mefc_subnet(x, P, 'refinement.')
+    x = F.conv2d(x, P['output.weight'], P.get('output.bias'), padding=1) + inp
+    out = x[:, :, :H0, :W0]
+    if return_aux:
+        aux['warp'] = warp
+        return out, aux
+    return out

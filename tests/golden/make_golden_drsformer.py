@@ -116,6 +116,68 @@ def whole_net_case(arch, name, cfg, B, H, W, seed):
           'no-grad params', sorted({names[i].split('.')[0] for i in range(len(names)) if not has_grad[i]}))
 
 
+def import_full_arch():
+    return importlib.import_module('models.archs.network_drsformer_guided_arch')
+
+
+def full_net_case(arch_full, name, cfg, B, H, W, seed):
+    """DRSformerRefFusion (with the MEFC sub-networks, network_drsformer_guided_arch.py:679-1123); only R1 is wrapped."""
+    P = DO.full_synth_params(cfg, seed=seed)
+    net = arch_full.DRSformerRefFusion(
+        inp_channels=cfg['inp_channels'], out_channels=cfg['out_channels'], dim=cfg['dim'], num_blocks=cfg['num_blocks'],
+        heads=cfg['heads'], ffn_expansion_factor=cfg['ffn_expansion_factor'], bias=cfg['bias'], LayerNorm_type=cfg['LayerNorm_type'],
+        nf=cfg['nf'], ext_n_blocks=cfg['ext_n_blocks'], reffusion_n_blocks=cfg['reffusion_n_blocks'],
+        lr_block_size=cfg['lr_block_size'], ref_down_block_size=cfg['ref_down_block_size'], dilations=cfg['dilations'], psize=cfg['psize'])
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(P.keys()), 'registration order mismatch'
+    net.load_state_dict(P)
+    enc_forward = net.masa_enc.forward
+    net.masa_enc.forward = lambda x: [None] + list(enc_forward(x))          # R1
+    lq, gt, ref = NO.synth_pair(B, H, W, seed=8765 + seed)
+    out = net(lq, ref)
+    loss = (out - gt).abs().mean()
+    loss.backward()
+    names = list(P.keys())
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    gnorm = np.zeros(len(names)); gsample = np.zeros((len(names), 8), dtype=np.float32); has_grad = np.zeros(len(names), dtype=bool)
+    for i, k in enumerate(names):
+        g = grads[k]
+        has_grad[i] = g is not None
+        g = g if g is not None else torch.zeros_like(P[k])
+        gnorm[i] = g.double().norm().item()
+        sm = sample(g, 8); gsample[i, :len(sm)] = sm
+    with torch.no_grad():
+        _, aux = DO.drsformer_full_forward(P, cfg, lq, ref, return_aux=True)
+    t2 = aux['corr_fine'].topk(2, dim=2).values
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), out=out.detach().numpy(), loss=np.float64(loss.item()),
+                        index_all=aux['index_all'].numpy(), fine_gap=(t2[..., 0] - t2[..., 1]).numpy(), names=np.array(names),
+                        grad_norm=gnorm, grad_sample=gsample, has_grad=has_grad, cfg_B=B, cfg_H=H, cfg_W=W, seed=seed,
+                        total_grad_norm=np.float64(np.sqrt((gnorm ** 2).sum())))
+    print(name, 'loss', loss.item(), 'gnorm', np.sqrt((gnorm ** 2).sum()), 'all params have grads:', bool(has_grad.all()))
+
+
+def mefc_case(arch_full):
+    """`subnet` alone (:522-548): OALayer gating + 4 weighted-operation steps over the 8 candidate operations"""
+    d = {}
+    g = torch.Generator().manual_seed(31)
+    for tag, (C, H, W) in {'mefc_a': (8, 12, 16), 'mefc_b': (12, 9, 10)}.items():
+        sub = arch_full.subnet(C)
+        with torch.no_grad():
+            for i, (k, p) in enumerate(sub.named_parameters()):
+                gg = torch.Generator().manual_seed(900 + i)
+                p.copy_(torch.randn(p.shape, generator=gg) * (0.5 if 'ca_fc' in k else 0.35))
+        x = torch.randn(2, C, H, W, generator=g).requires_grad_()
+        y = sub(x)
+        go = torch.randn(y.shape, generator=g)
+        y.backward(go)
+        d[tag + '_x'] = x.detach().numpy(); d[tag + '_go'] = go.numpy(); d[tag + '_y'] = y.detach().numpy(); d[tag + '_gx'] = x.grad.numpy()
+        d[tag + '_names'] = np.array([k for k, _ in sub.named_parameters()])
+        for k, p in sub.named_parameters():
+            d[f'{tag}_p_{k}'] = p.detach().numpy(); d[f'{tag}_g_{k}'] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'drsformer_mefc.npz'), **d)
+    print('mefc cases done')
+
+
 def per_op_cases(arch):
     """the two block classes that differ from Restormer-ref: Attention (TKSA, :257-328) and FeedForward (MSFN, :213-253)"""
     d = {}
@@ -179,3 +241,7 @@ if __name__ == '__main__':
     whole_net_case(arch, 'drsformer_d8_64', cfg, 1, 64, 64, seed=1)
     whole_net_case(arch, 'drsformer_d8_128_b2_biasfree', DO.default_cfg(LayerNorm_type='BiasFree', num_blocks=[1, 1, 2, 1]), 2, 128, 128, seed=2)
     whole_net_case(arch, 'drsformer_d16_100x72_pad', DO.default_cfg(dim=16, nf=16, bias=True), 1, 100, 72, seed=3)
+    full = import_full_arch()
+    mefc_case(full)
+    full_net_case(full, 'drsformer_full_d8_64', DO.default_cfg(), 1, 64, 64, seed=4)
+    full_net_case(full, 'drsformer_full_d8_128_b2', DO.default_cfg(LayerNorm_type='BiasFree'), 2, 128, 128, seed=5)

@@ -70,3 +70,28 @@ def test_whole_net_forward_backward(golden_dir, name, kw):
     assert set(names) - set(unused) == set(grads.keys())
     gn = np.array([grads[n].double().norm().item() if n in grads else 0.0 for n in names])
     assert np.allclose(gn, g['grad_norm'], rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize('tag', ['mefc_a', 'mefc_b'])
+def test_mefc_subnet(golden_dir, tag):
+    """`subnet` (:522-548): gating MLP + softmax over the 8 candidate operations, 4 weighted steps."""
+    _run(load(golden_dir, 'drsformer_mefc'), tag, DO.mefc_subnet, 's.')
+
+
+@pytest.mark.parametrize('name,kw', [('drsformer_full_d8_64', dict()), ('drsformer_full_d8_128_b2', dict(LayerNorm_type='BiasFree'))])
+def test_full_class_with_mefc(golden_dir, name, kw):
+    g = load(golden_dir, name)
+    cfg = DO.default_cfg(**kw)
+    seed = int(g['seed'])
+    P0 = DO.full_synth_params(cfg, seed=seed)
+    assert [str(n) for n in g['names']] == list(P0.keys())
+    lq, gt, ref = NO.synth_pair(int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), seed=8765 + seed)
+    P = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+    out = DO.drsformer_full_forward(P, cfg, lq, ref)
+    assert np.abs(out.detach().numpy() - g['out']).max() < 2e-5
+    loss = (out - gt).abs().mean()
+    assert abs(loss.item() - float(g['loss'])) < 1e-6
+    loss.backward()
+    assert g['has_grad'].all()
+    gn = np.array([p.grad.double().norm().item() for p in P.values()])
+    assert np.allclose(gn, g['grad_norm'], rtol=2e-3, atol=2e-6)
