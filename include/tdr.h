@@ -327,11 +327,24 @@ int tdr_tksa_softmax(const float* G, const float* ss, const float* temp, const f
 int tdr_tksa_bwd(const float* G, const float* ss, const float* temp, const float* am, const int* k4 /*host*/, const float* dA, int N,
                  int C, int heads, float* W, float* dtemp, float* dam, float* ws, void* stream);
 int tdr_dwk_fwd(const float* x, int64_t x_ns, const float* w, const float* b /*[Cout] or NULL*/, int N, int Cout, int mult, int H, int W,
-                int K, int relu, float* y, int64_t y_ns, void* stream);
-int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w, int N,
-                int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, float* db /*or NULL*/,
-                float* ws /*tdr_dwk_bwd_ws_floats floats: tiled K = 3 / 5 path; NULL = the untiled kernels*/, void* stream);
+                int K, int dil /*1 | 2*/, int relu, float* y, int64_t y_ns, void* stream);
 int64_t tdr_dwk_bwd_ws_floats(int N, int Cout, int mult, int H, int W, int K);
+int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w, int N,
+                int Cout, int mult, int H, int W, int K, int dil, float* dx, int64_t dx_ns, float* dw, float* db /*or NULL*/,
+                float* ws /*tdr_dwk_bwd_ws_floats floats*/, void* stream);
+/* MEFC sub-network pieces (network_drsformer_guided_arch.py:371-548): the 3x3 average pool with count_include_pad=False
+ * (adjoint = 1: its backward), the gating MLP's Linears (tiny: N x Cin -> Cout, one wave per output), row softmax (dy != NULL:
+ * backward from the softmax output), dst[n] = src[n] * w[n * w_stride] (the per-image operation weights), per-image dot
+ * products (their gradients; ws: 64 * N floats). */
+int tdr_avgpool3(const float* in, int planes, int H, int W, int adjoint, float* out, void* stream);
+int tdr_linear_small_fwd(const float* x, const float* W, const float* b, int N, int Cin, int Cout, int relu, float* y, void* stream);
+int tdr_linear_small_bwd(const float* dy, const float* yact /*or NULL*/, const float* x, const float* W, int N, int Cin, int Cout,
+                         float* dx, float* dW, float* db, void* stream);
+int tdr_softmax_rows(const float* x, const float* dy /*NULL: forward*/, int rows, int L, float* out, void* stream);
+int tdr_scale_copy(const float* src, int64_t src_ns, const float* w, int w_stride, int N, int64_t len, float* dst, int64_t dst_ns,
+                   void* stream);
+int tdr_rows_dot(const float* a, int64_t a_ns, const float* b, int64_t b_ns, int N, int64_t len, float* out, int out_stride, float* ws,
+                 void* stream);
 
 /* ---------------------------------------------------------------------------
  * PromptIR-ref PromptGenBlock (network_promptir_guided_arch.py:417-441), everything around its 3x3 convolution:

@@ -189,8 +189,14 @@ SIGNATURES = {
     'tdr_pair_sum_mid_floats': (i64, [i32, i32]),
     'tdr_tksa_softmax': (i32, [c_fp, c_fp, c_fp, c_fp, C.POINTER(i32), i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_tksa_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, C.POINTER(i32), c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
-    'tdr_dwk_fwd': (i32, [c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
-    'tdr_dwk_bwd': (i32, [c_fp, i64, c_fp, i64, c_fp, i64, c_fp, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_dwk_fwd': (i32, [c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
+    'tdr_dwk_bwd': (i32, [c_fp, i64, c_fp, i64, c_fp, i64, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_avgpool3': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_linear_small_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_linear_small_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_softmax_rows': (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp]),
+    'tdr_scale_copy': (i32, [c_fp, i64, c_fp, i32, i32, i64, c_fp, i64, c_fp]),
+    'tdr_rows_dot': (i32, [c_fp, i64, c_fp, i64, i32, i64, c_fp, i32, c_fp, c_fp]),
     'tdr_dwk_bwd_ws_floats': (i64, [i32, i32, i32, i32, i32, i32]),
     'tdr_crop_augment': (i32, [c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp]),
     'tdr_plane_mean': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp]),

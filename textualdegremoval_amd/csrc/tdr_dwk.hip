@@ -2,131 +2,24 @@
 // :216-253): K x K (K = 3, 5), stride 1, pad K/2, no bias, groups = Cout with `mult` = 1 or 2 input planes per output plane
 // (dwconv3x3 / dwconv5x5: mult 1 over 2h planes; dwconv3x3_1 / dwconv5x5_1: Conv2d(2h, h, groups=h), mult 2), optional ReLU:
 //     y[n][c] = act( sum_{i < mult} w[c][i] (*) x[n][c * mult + i] )
-// Straightforward streaming kernels (HBM-bound stencils: each input plane is read once per launch, neighbours come from
-// L1/L2); the weight gradient is one workgroup per (c, i) plane pair with a fixed-order in-block reduction (deterministic).
-// First implementation of this family: correctness and the C ABI first, tiling later.
+// HBM-bound stencils: each input plane goes through LDS once per launch (tile + halo); the weight gradient writes per-tile
+// partials that a second kernel sums in a fixed order (deterministic).
 #include "tdr_common.h"
 #include "../../include/tdr.h"
 
 namespace {
 
-__global__ void dwk_fwd_kernel(const float* __restrict__ x, long x_ns, const float* __restrict__ w, const float* __restrict__ b, int Cout, int mult, int H, int W,
-                               int K, int relu, long total, float* __restrict__ y, long y_ns) {
-    const int pad = K / 2;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int px = (int)(i % W);
-        long r = i / W;
-        const int py = (int)(r % H); r /= H;
-        const int c = (int)(r % Cout);
-        const long n = r / Cout;
-        float s = b ? b[c] : 0.f;
-        for (int q = 0; q < mult; ++q) {
-            const float* xp = x + n * x_ns + ((long)c * mult + q) * H * W;
-            const float* wp = w + ((long)c * mult + q) * K * K;
-            for (int ky = 0; ky < K; ++ky) {
-                const int yy = py + ky - pad;
-                if (yy < 0 || yy >= H) continue;
-                for (int kx = 0; kx < K; ++kx) {
-                    const int xx = px + kx - pad;
-                    if (xx >= 0 && xx < W) s += wp[ky * K + kx] * xp[(long)yy * W + xx];
-                }
-            }
-        }
-        y[n * y_ns + ((long)c * H + py) * W + px] = relu ? fmaxf(s, 0.f) : s;
-    }
-}
-
-// dx[n][c*mult + q][p] = sum_taps w[c][q][ky][kx] * g[n][c][p - (tap - pad)],  g = dy (* [y > 0])
-__global__ void dwk_bwd_data_kernel(const float* __restrict__ dy, long dy_ns, const float* __restrict__ yact, long y_ns,
-                                    const float* __restrict__ w, int Cout, int mult, int H, int W, int K, long total,
-                                    float* __restrict__ dx, long dx_ns) {
-    const int pad = K / 2;
-    const int Cin = Cout * mult;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int px = (int)(i % W);
-        long r = i / W;
-        const int py = (int)(r % H); r /= H;
-        const int ci = (int)(r % Cin);
-        const long n = r / Cin;
-        const int c = ci / mult;
-        const float* gp = dy + n * dy_ns + (long)c * H * W;
-        const float* ap = yact ? yact + n * y_ns + (long)c * H * W : nullptr;
-        const float* wp = w + (long)ci * K * K;
-        float s = 0.f;
-        for (int ky = 0; ky < K; ++ky) {
-            const int yy = py - (ky - pad);
-            if (yy < 0 || yy >= H) continue;
-            for (int kx = 0; kx < K; ++kx) {
-                const int xx = px - (kx - pad);
-                if (xx < 0 || xx >= W) continue;
-                const long o = (long)yy * W + xx;
-                const float g = (!ap || ap[o] > 0.f) ? gp[o] : 0.f;
-                s += wp[ky * K + kx] * g;
-            }
-        }
-        dx[n * dx_ns + ((long)ci * H + py) * W + px] = s;
-    }
-}
-
-// one workgroup per input plane ci (= c * mult + q): dw[ci][tap] = sum_{n, p} g[n][c][p] * x[n][ci][p + tap - pad]
-template <int K>
-__global__ __launch_bounds__(256) void dwk_bwd_weight_kernel(const float* __restrict__ dy, long dy_ns, const float* __restrict__ yact,
-                                                            long y_ns, const float* __restrict__ x, long x_ns, int N, int mult, int H,
-                                                            int W, float* __restrict__ dw, float* __restrict__ db) {
-    __shared__ float red[4][K * K];
-    __shared__ float redb[4];
-    float accb = 0.f;
-    const int ci = blockIdx.x, c = ci / mult;
-    constexpr int pad = K / 2;
-    const long HW = (long)H * W;
-    float acc[K * K];
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
-    for (long i = threadIdx.x; i < N * HW; i += 256) {
-        const long n = i / HW;
-        const long p = i - n * HW;
-        const int py = (int)(p / W), px = (int)(p - (long)py * W);
-        float g = dy[n * dy_ns + c * HW + p];
-        if (yact && !(yact[n * y_ns + c * HW + p] > 0.f)) g = 0.f;
-        accb += g;
-        const float* xp = x + n * x_ns + (long)ci * HW;
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int yy = py + ky - pad;
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int xx = px + kx - pad;
-                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                acc[ky * K + kx] += ok ? g * xp[(long)yy * W + xx] : 0.f;
-            }
-        }
-    }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) {
-        const float s = wave_sum(acc[t]);
-        if (lane == 0) red[wv][t] = s;
-    }
-    {
-        const float sb = wave_sum(accb);
-        if (lane == 0) redb[wv] = sb;
-    }
-    __syncthreads();
-    if (db && threadIdx.x == 0 && ci == c * mult) db[c] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
-    if (threadIdx.x < K * K) dw[(long)ci * K * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// LDS-tiled versions for K = 3 / 5 (the shapes DRSformer-ref uses): a workgroup owns a 64 x 16 output tile of one
+// LDS-tiled kernels, K in {1, 3, 5, 7}, dilation 1 or 2 (MEFC's dil_conv ops): a workgroup owns a 64 x 16 output tile of one
 // (image, output plane); the input tile + halo of each of its `mult` input planes goes through LDS once, a thread computes 4
 // adjacent outputs from a (4 + K - 1)-wide register window per kernel row.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TW_ = 64, TH_ = 16;
 
-template <int K>
+template <int K, int DIL>
 __device__ __forceinline__ void load_tile(float* __restrict__ t, const float* __restrict__ plane, const float* __restrict__ maskp,
                                           int y0, int x0, int H, int W) {
-    constexpr int LW = TW_ + K - 1, LH = TH_ + K - 1, P = K / 2;
+    constexpr int LW = TW_ + (K - 1) * DIL, LH = TH_ + (K - 1) * DIL, P = (K / 2) * DIL;
     for (int i = threadIdx.x; i < LW * LH; i += 256) {
         const int r = i / LW, c = i - r * LW;
         const int y = y0 + r - P, x = x0 + c - P;
@@ -141,13 +34,13 @@ __device__ __forceinline__ void load_tile(float* __restrict__ t, const float* __
 
 // FLIP = false: y[c] = act(b + sum_q w[c][q] (*) x[c*mult+q])            grid (tiles, Cout, N)
 // FLIP = true : dx[c*mult+q] = w[c][q]^flip (*) (dy[c] masked by yact)   (same tile of g serves both q)
-template <int K, bool FLIP>
+template <int K, int DIL, bool FLIP>
 __global__ __launch_bounds__(256) void dwk_tiled_kernel(const float* __restrict__ in, long in_ns, const float* __restrict__ maskp_,
                                                        long mask_ns, const float* __restrict__ w, const float* __restrict__ b,
                                                        int Cout, int mult, int H, int W, int tiles_x, int relu,
                                                        float* __restrict__ out, long out_ns) {
-    constexpr int LW = TW_ + K - 1;
-    __shared__ float tile[(TW_ + K - 1) * (TH_ + K - 1)];
+    constexpr int LW = TW_ + (K - 1) * DIL;
+    __shared__ float tile[(TW_ + (K - 1) * DIL) * (TH_ + (K - 1) * DIL)];
     const int c = blockIdx.y, n = blockIdx.z;
     const int ty0 = (blockIdx.x / tiles_x) * TH_, tx0 = (blockIdx.x % tiles_x) * TW_;
     const int ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4;
@@ -161,7 +54,7 @@ __global__ __launch_bounds__(256) void dwk_tiled_kernel(const float* __restrict_
         const int pin = FLIP ? c : c * mult + q;
         if (!FLIP || q == 0) {
             __syncthreads();
-            load_tile<K>(tile, in + (long)n * in_ns + (long)pin * HW, (FLIP && maskp_) ? maskp_ + (long)n * mask_ns + (long)c * HW : nullptr,
+            load_tile<K, DIL>(tile, in + (long)n * in_ns + (long)pin * HW, (FLIP && maskp_) ? maskp_ + (long)n * mask_ns + (long)c * HW : nullptr,
                          ty0, tx0, H, W);
             __syncthreads();
         }
@@ -169,14 +62,14 @@ __global__ __launch_bounds__(256) void dwk_tiled_kernel(const float* __restrict_
         float* a = FLIP ? acc[q] : acc[0];
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
-            float win[4 + K - 1];
+            float win[4 + (K - 1) * DIL];
 #pragma unroll
-            for (int i = 0; i < 4 + K - 1; ++i) win[i] = tile[(ly + ky) * LW + lx + i];
+            for (int i = 0; i < 4 + (K - 1) * DIL; ++i) win[i] = tile[(ly + ky * DIL) * LW + lx + i];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
                 const float wv = FLIP ? wp[(K - 1 - ky) * K + (K - 1 - kx)] : wp[ky * K + kx];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] += wv * win[kx + j];
+                for (int j = 0; j < 4; ++j) a[j] += wv * win[kx * DIL + j];
             }
         }
     }
@@ -202,18 +95,18 @@ __global__ __launch_bounds__(256) void dwk_tiled_kernel(const float* __restrict_
 }
 
 // weight gradient, tiled: partial[ci][n * tiles + tile][K*K] (+ bias partial as element K*K), then a fixed-order finish
-template <int K>
+template <int K, int DIL>
 __global__ __launch_bounds__(256) void dwk_wgrad_tiled_kernel(const float* __restrict__ dy, long dy_ns, const float* __restrict__ yact,
                                                              long y_ns, const float* __restrict__ x, long x_ns, int mult, int H,
                                                              int W, int tiles_x, float* __restrict__ part) {
-    constexpr int LW = TW_ + K - 1, KK = K * K;
-    __shared__ float tile[(TW_ + K - 1) * (TH_ + K - 1)];
+    constexpr int LW = TW_ + (K - 1) * DIL, KK = K * K;
+    __shared__ float tile[(TW_ + (K - 1) * DIL) * (TH_ + (K - 1) * DIL)];
     __shared__ float red[4][KK + 1];
     const int ci = blockIdx.y, n = blockIdx.z, c = ci / mult;
     const int ty0 = (blockIdx.x / tiles_x) * TH_, tx0 = (blockIdx.x % tiles_x) * TW_;
     const int ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4;
     const long HW = (long)H * W;
-    load_tile<K>(tile, x + (long)n * x_ns + (long)ci * HW, nullptr, ty0, tx0, H, W);
+    load_tile<K, DIL>(tile, x + (long)n * x_ns + (long)ci * HW, nullptr, ty0, tx0, H, W);
     float g[4] = {0.f, 0.f, 0.f, 0.f};
     const int y = ty0 + ly;
     if (y < H) {
@@ -229,11 +122,12 @@ __global__ __launch_bounds__(256) void dwk_wgrad_tiled_kernel(const float* __res
     float acc[KK + 1];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
-        float win[4 + K - 1];
+        float win[4 + (K - 1) * DIL];
 #pragma unroll
-        for (int i = 0; i < 4 + K - 1; ++i) win[i] = tile[(ly + ky) * LW + lx + i];
+        for (int i = 0; i < 4 + (K - 1) * DIL; ++i) win[i] = tile[(ly + ky * DIL) * LW + lx + i];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) acc[ky * K + kx] = (g[0] * win[kx] + g[1] * win[kx + 1]) + (g[2] * win[kx + 2] + g[3] * win[kx + 3]);
+        for (int kx = 0; kx < K; ++kx)
+            acc[ky * K + kx] = (g[0] * win[kx * DIL] + g[1] * win[kx * DIL + 1]) + (g[2] * win[kx * DIL + 2] + g[3] * win[kx * DIL + 3]);
     }
     acc[KK] = (g[0] + g[1]) + (g[2] + g[3]);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -271,6 +165,126 @@ __global__ __launch_bounds__(256) void dwk_wgrad_finish_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small pieces of DRSformer-ref's MEFC sub-network (network_drsformer_guided_arch.py:371-548)
+// ---------------------------------------------------------------------------------------------------------------
+// nn.AvgPool2d(3, stride=1, padding=1, count_include_pad=False) and its adjoint
+__global__ void avgpool3_kernel(const float* __restrict__ in, int H, int W, long total, int adjoint, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const float* p = in + (i - (long)y * W - x);
+        float s = 0.f;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                if (adjoint) {       // dx[p] = sum_{q in N(p)} dy[q] / count(q)
+                    const int cy = min(yy + 1, H - 1) - max(yy - 1, 0) + 1, cx = min(xx + 1, W - 1) - max(xx - 1, 0) + 1;
+                    s += p[(long)yy * W + xx] / (float)(cy * cx);
+                } else {
+                    s += p[(long)yy * W + xx];
+                }
+            }
+        }
+        if (!adjoint) {
+            const int cy = min(y + 1, H - 1) - max(y - 1, 0) + 1, cx = min(x + 1, W - 1) - max(x - 1, 0) + 1;
+            s /= (float)(cy * cx);
+        }
+        out[i] = s;
+    }
+}
+
+// y[n][o] = act(b[o] + sum_i W[o][i] x[n][i]); one wave per output element
+__global__ __launch_bounds__(64) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                             const float* __restrict__ b, int Cin, int Cout, int relu,
+                                                             float* __restrict__ y) {
+    const int o = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    float s = 0.f;
+    for (int i = lane; i < Cin; i += 64) s += W[(long)o * Cin + i] * x[(long)n * Cin + i];
+    s = wave_sum(s);
+    if (lane == 0) {
+        s += b ? b[o] : 0.f;
+        y[(long)n * Cout + o] = relu ? fmaxf(s, 0.f) : s;
+    }
+}
+// single workgroup: g = dy (* [y > 0]); dW[o][i] = sum_n g[n][o] x[n][i]; db[o] = sum_n g[n][o]; dx[n][i] = sum_o g[n][o] W[o][i]
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
+                                                              const float* __restrict__ x, const float* __restrict__ W, int N,
+                                                              int Cin, int Cout, float* __restrict__ dx, float* __restrict__ dW,
+                                                              float* __restrict__ db) {
+    extern __shared__ float g[];          // [N][Cout]
+    for (int i = threadIdx.x; i < N * Cout; i += 256) g[i] = (!yact || yact[i] > 0.f) ? dy[i] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cout * Cin; i += 256) {
+        const int o = i / Cin, c = i - o * Cin;
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += g[n * Cout + o] * x[(long)n * Cin + c];
+        dW[i] = s;
+    }
+    for (int o = threadIdx.x; o < Cout; o += 256) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += g[n * Cout + o];
+        if (db) db[o] = s;
+    }
+    for (int i = threadIdx.x; i < N * Cin; i += 256) {
+        const int n = i / Cin, c = i - n * Cin;
+        float s = 0.f;
+        for (int o = 0; o < Cout; ++o) s += g[n * Cout + o] * W[(long)o * Cin + c];
+        dx[i] = s;
+    }
+}
+
+// softmax over rows of length L (L <= 64), forward and backward (one thread per row)
+__global__ void softmax_rows_kernel(const float* __restrict__ x, const float* __restrict__ dy, int rows, int L, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = x + (long)r * L;
+    if (!dy) {
+        float m = -INFINITY, z = 0.f;
+        for (int i = 0; i < L; ++i) m = fmaxf(m, p[i]);
+        for (int i = 0; i < L; ++i) z += expf(p[i] - m);
+        for (int i = 0; i < L; ++i) out[(long)r * L + i] = expf(p[i] - m) / z;
+    } else {                 // x = the softmax output here
+        float dot = 0.f;
+        for (int i = 0; i < L; ++i) dot += p[i] * dy[(long)r * L + i];
+        for (int i = 0; i < L; ++i) out[(long)r * L + i] = p[i] * (dy[(long)r * L + i] - dot);
+    }
+}
+
+// dst[n][:len] = src[n][:len] * w[n * w_stride]
+__global__ void scale_copy_kernel(const float* __restrict__ src, long src_ns, const float* __restrict__ w, int w_stride, long len,
+                                  long total, float* __restrict__ dst, long dst_ns) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / len, e = i - n * len;
+        dst[n * dst_ns + e] = src[n * src_ns + e] * w[n * w_stride];
+    }
+}
+
+constexpr int RD_BLOCKS = 64;
+// part[n][b] = sum over block b's slice of a[n] . b[n]; finish sums the RD_BLOCKS partials in order
+__global__ __launch_bounds__(256) void rows_dot_kernel(const float* __restrict__ a, long a_ns, const float* __restrict__ b, long b_ns,
+                                                      long len, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    const long per = (len + RD_BLOCKS - 1) / RD_BLOCKS, e0 = blockIdx.x * per, e1 = e0 + per < len ? e0 + per : len;
+    float s = 0.f;
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) s += a[n * a_ns + e] * b[n * b_ns + e];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)n * RD_BLOCKS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void rows_dot_finish_kernel(const float* __restrict__ part, int N, int out_stride, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < RD_BLOCKS; ++b) s += part[(long)n * RD_BLOCKS + b];
+    out[(long)n * out_stride] = s;
+}
+
 inline int dgrid(long total, int cap = 16384) {
     long b = (total + 255) / 256;
     return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
@@ -278,53 +292,93 @@ inline int dgrid(long total, int cap = 16384) {
 
 }  // namespace
 
+#define DWK_CASES(X)  X(1, 1) X(3, 1) X(5, 1) X(7, 1) X(3, 2) X(5, 2) X(7, 2)
+
 extern "C" int tdr_dwk_fwd(const float* x, int64_t x_ns, const float* w, const float* b, int N, int Cout, int mult, int H, int W, int K,
-                           int relu, float* y, int64_t y_ns, void* stream) {
-    TDR_REQUIRE(x && w && y && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7),
-                "tdr_dwk_fwd: bad argument (mult 1|2, K 1|3|5|7; got mult=%d K=%d)", mult, K);
-    if (K == 3 || K == 5) {
-        const int tiles_x = tdr_cdiv(W, TW_), tiles = tiles_x * tdr_cdiv(H, TH_);
-        if (K == 3) hipLaunchKernelGGL((dwk_tiled_kernel<3, false>), dim3(tiles, Cout, N), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, nullptr, 0L, w, b, Cout, mult, H, W, tiles_x, relu, y, (long)y_ns);
-        else hipLaunchKernelGGL((dwk_tiled_kernel<5, false>), dim3(tiles, Cout, N), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, nullptr, 0L, w, b, Cout, mult, H, W, tiles_x, relu, y, (long)y_ns);
-        TDR_LAUNCH_CHECK("dwk_tiled_fwd");
-        return TDR_OK;
-    }
-    const long total = (long)N * Cout * H * W;
-    hipLaunchKernelGGL(dwk_fwd_kernel, dim3(dgrid(total)), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, w, b, Cout, mult, H, W, K, relu,
-                       total, y, (long)y_ns);
-    TDR_LAUNCH_CHECK("dwk_fwd");
+                           int dil, int relu, float* y, int64_t y_ns, void* stream) {
+    TDR_REQUIRE(x && w && y && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7) && (dil == 1 || (dil == 2 && K > 1)),
+                "tdr_dwk_fwd: bad argument (mult 1|2, K 1|3|5|7, dil 1|2; got mult=%d K=%d dil=%d)", mult, K, dil);
+    const int tiles_x = tdr_cdiv(W, TW_), tiles = tiles_x * tdr_cdiv(H, TH_);
+#define X(K_, D_) if (K == K_ && dil == D_) hipLaunchKernelGGL((dwk_tiled_kernel<K_, D_, false>), dim3(tiles, Cout, N), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, nullptr, 0L, w, b, Cout, mult, H, W, tiles_x, relu, y, (long)y_ns);
+    DWK_CASES(X)
+#undef X
+    TDR_LAUNCH_CHECK("dwk_tiled_fwd");
     return TDR_OK;
 }
 
 extern "C" int64_t tdr_dwk_bwd_ws_floats(int N, int Cout, int mult, int H, int W, int K) {
-    if (K != 3 && K != 5) return 0;
     return (int64_t)Cout * mult * N * tdr_cdiv(W, TW_) * tdr_cdiv(H, TH_) * (K * K + 1);
 }
 
 extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w,
-                           int N, int Cout, int mult, int H, int W, int K, float* dx, int64_t dx_ns, float* dw, float* db, float* ws, void* stream) {
-    TDR_REQUIRE(dy && x && w && dx && dw && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7),
-                "tdr_dwk_bwd: bad argument");
+                           int N, int Cout, int mult, int H, int W, int K, int dil, float* dx, int64_t dx_ns, float* dw, float* db,
+                           float* ws, void* stream) {
+    TDR_REQUIRE(dy && x && w && dx && dw && ws && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7) &&
+                    (dil == 1 || (dil == 2 && K > 1)), "tdr_dwk_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if ((K == 3 || K == 5) && ws) {
-        const int tiles_x = tdr_cdiv(W, TW_), tiles = tiles_x * tdr_cdiv(H, TH_);
-        if (K == 3) {
-            hipLaunchKernelGGL((dwk_tiled_kernel<3, true>), dim3(tiles, Cout, N), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, nullptr, Cout, mult, H, W, tiles_x, 0, dx, (long)dx_ns);
-            hipLaunchKernelGGL(dwk_wgrad_tiled_kernel<3>, dim3(tiles, Cout * mult, N), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, mult, H, W, tiles_x, ws);
-        } else {
-            hipLaunchKernelGGL((dwk_tiled_kernel<5, true>), dim3(tiles, Cout, N), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, nullptr, Cout, mult, H, W, tiles_x, 0, dx, (long)dx_ns);
-            hipLaunchKernelGGL(dwk_wgrad_tiled_kernel<5>, dim3(tiles, Cout * mult, N), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, mult, H, W, tiles_x, ws);
-        }
-        hipLaunchKernelGGL(dwk_wgrad_finish_kernel, dim3(Cout * mult), dim3(256), 0, st, ws, N * tiles, K * K, mult, dw, db);
-        TDR_LAUNCH_CHECK("dwk_tiled_bwd");
-        return TDR_OK;
+    const int tiles_x = tdr_cdiv(W, TW_), tiles = tiles_x * tdr_cdiv(H, TH_);
+#define X(K_, D_)                                                                                                                          \
+    if (K == K_ && dil == D_) {                                                                                                            \
+        hipLaunchKernelGGL((dwk_tiled_kernel<K_, D_, true>), dim3(tiles, Cout, N), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, \
+                           nullptr, Cout, mult, H, W, tiles_x, 0, dx, (long)dx_ns);                                                        \
+        hipLaunchKernelGGL((dwk_wgrad_tiled_kernel<K_, D_>), dim3(tiles, Cout * mult, N), dim3(256), 0, st, dy, (long)dy_ns, yact,         \
+                           (long)y_ns, x, (long)x_ns, mult, H, W, tiles_x, ws);                                                            \
     }
-    const long total = (long)N * Cout * mult * H * W;
-    hipLaunchKernelGGL(dwk_bwd_data_kernel, dim3(dgrid(total)), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, Cout, mult, H, W, K,
-                       total, dx, (long)dx_ns);
-#define DWK_W(K_) hipLaunchKernelGGL(dwk_bwd_weight_kernel<K_>, dim3(Cout * mult), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, N, mult, H, W, dw, db)
-    if (K == 1) DWK_W(1); else if (K == 3) DWK_W(3); else if (K == 5) DWK_W(5); else DWK_W(7);
-#undef DWK_W
-    TDR_LAUNCH_CHECK("dwk_bwd");
+    DWK_CASES(X)
+#undef X
+    hipLaunchKernelGGL(dwk_wgrad_finish_kernel, dim3(Cout * mult), dim3(256), 0, st, ws, N * tiles, K * K, mult, dw, db);
+    TDR_LAUNCH_CHECK("dwk_tiled_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_avgpool3(const float* in, int planes, int H, int W, int adjoint, float* out, void* stream) {
+    TDR_REQUIRE(in && out && planes > 0 && H > 0 && W > 0, "tdr_avgpool3: bad argument");
+    const long total = (long)planes * H * W;
+    hipLaunchKernelGGL(avgpool3_kernel, dim3(dgrid(total)), dim3(256), 0, (hipStream_t)stream, in, H, W, total, adjoint, out);
+    TDR_LAUNCH_CHECK("avgpool3");
+    return TDR_OK;
+}
+
+extern "C" int tdr_linear_small_fwd(const float* x, const float* W, const float* b, int N, int Cin, int Cout, int relu, float* y,
+                                    void* stream) {
+    TDR_REQUIRE(x && W && y && N > 0 && Cin > 0 && Cout > 0, "tdr_linear_small_fwd: bad argument");
+    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3(Cout, N), dim3(64), 0, (hipStream_t)stream, x, W, b, Cin, Cout, relu, y);
+    TDR_LAUNCH_CHECK("linear_small_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_linear_small_bwd(const float* dy, const float* yact, const float* x, const float* W, int N, int Cin, int Cout,
+                                    float* dx, float* dW, float* db, void* stream) {
+    TDR_REQUIRE(dy && x && W && dx && dW && N > 0 && (long)N * Cout <= 16384, "tdr_linear_small_bwd: bad argument (N * Cout <= 16384)");
+    hipLaunchKernelGGL(linear_small_bwd_kernel, dim3(1), dim3(256), (size_t)N * Cout * sizeof(float), (hipStream_t)stream, dy, yact, x, W, N,
+                       Cin, Cout, dx, dW, db);
+    TDR_LAUNCH_CHECK("linear_small_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_softmax_rows(const float* x, const float* dy, int rows, int L, float* out, void* stream) {
+    TDR_REQUIRE(x && out && rows > 0 && L > 0 && L <= 64, "tdr_softmax_rows: bad argument (L <= 64)");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(tdr_cdiv(rows, 64)), dim3(64), 0, (hipStream_t)stream, x, dy, rows, L, out);
+    TDR_LAUNCH_CHECK("softmax_rows");
+    return TDR_OK;
+}
+
+extern "C" int tdr_scale_copy(const float* src, int64_t src_ns, const float* w, int w_stride, int N, int64_t len, float* dst,
+                              int64_t dst_ns, void* stream) {
+    TDR_REQUIRE(src && w && dst && N > 0 && len > 0, "tdr_scale_copy: bad argument");
+    const long total = (long)N * len;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(dgrid(total)), dim3(256), 0, (hipStream_t)stream, src, (long)src_ns, w, w_stride, (long)len,
+                       total, dst, (long)dst_ns);
+    TDR_LAUNCH_CHECK("scale_copy");
+    return TDR_OK;
+}
+
+extern "C" int tdr_rows_dot(const float* a, int64_t a_ns, const float* b, int64_t b_ns, int N, int64_t len, float* out, int out_stride,
+                            float* ws, void* stream) {
+    TDR_REQUIRE(a && b && out && ws && N > 0 && len > 0, "tdr_rows_dot: bad argument (ws: 64 * N floats)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rows_dot_kernel, dim3(RD_BLOCKS, N), dim3(256), 0, st, a, (long)a_ns, b, (long)b_ns, (long)len, ws);
+    hipLaunchKernelGGL(rows_dot_finish_kernel, dim3(tdr_cdiv(N, 64)), dim3(64), 0, st, ws, N, out_stride, out);
+    TDR_LAUNCH_CHECK("rows_dot");
     return TDR_OK;
 }

@@ -1236,18 +1236,18 @@ def tksa_bwd(G, ss, temp, am, dA, heads):
     return W, dtemp, dam
 
 
-def dwk_fwd(x, w, b=None, relu=False):
-    """grouped depthwise-like conv: w [Cout, mult, K, K] (mult 1 | 2), stride 1, pad K//2, optional bias, optional fused ReLU"""
+def dwk_fwd(x, w, b=None, relu=False, dil=1):
+    """grouped depthwise-like conv: w [Cout, mult, K, K] (mult 1 | 2), stride 1, pad dil * (K // 2), optional bias / fused ReLU"""
     N, Cin, H, W = x.shape
     Cout, mult, Kk, _ = w.shape
     assert Cin == Cout * mult and w.is_contiguous()
     y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
-    check(_lib.load().tdr_dwk_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), _p(b), N, Cout, mult, H, W, Kk, 1 if relu else 0, y.data_ptr(),
-                                  _dense_nchw(y), _stream()), 'tdr_dwk_fwd')
+    check(_lib.load().tdr_dwk_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), _p(b), N, Cout, mult, H, W, Kk, int(dil), 1 if relu else 0,
+                                  y.data_ptr(), _dense_nchw(y), _stream()), 'tdr_dwk_fwd')
     return y
 
 
-def dwk_bwd(dy, y_act, x, w, want_db=False):
+def dwk_bwd(dy, y_act, x, w, want_db=False, dil=1):
     """-> (dx, dw, db); y_act: the forward output when a ReLU was fused (its mask), else None"""
     N, Cin, H, W = x.shape
     Cout, mult, Kk, _ = w.shape
@@ -1255,9 +1255,60 @@ def dwk_bwd(dy, y_act, x, w, want_db=False):
     dw = torch.empty_like(w)
     db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
     lib = _lib.load()
-    need = lib.tdr_dwk_bwd_ws_floats(N, Cout, mult, H, W, Kk)
-    ws = workspace(need, x.device, 'dwk') if need else None
+    ws = workspace(lib.tdr_dwk_bwd_ws_floats(N, Cout, mult, H, W, Kk), x.device, 'dwk')
     check(lib.tdr_dwk_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
-                          _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, dx.data_ptr(), _dense_nchw(dx), dw.data_ptr(),
-                          _p(db), _p(ws), _stream()), 'tdr_dwk_bwd')
+                          _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, int(dil), dx.data_ptr(), _dense_nchw(dx), dw.data_ptr(),
+                          _p(db), ws.data_ptr(), _stream()), 'tdr_dwk_bwd')
     return dx, dw, db
+
+
+def avgpool3(x, adjoint=False):
+    """nn.AvgPool2d(3, 1, 1, count_include_pad=False) (adjoint: its backward)"""
+    N, Cc, H, W = x.shape
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    check(_lib.load().tdr_avgpool3(x.data_ptr(), N * Cc, H, W, 1 if adjoint else 0, out.data_ptr(), _stream()), 'tdr_avgpool3')
+    return out
+
+
+def linear_small_fwd(x, W, b=None, relu=False):
+    N, Cin = x.shape
+    y = torch.empty(N, W.shape[0], dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_linear_small_fwd(x.data_ptr(), W.data_ptr(), _p(b), N, Cin, W.shape[0], 1 if relu else 0, y.data_ptr(), _stream()),
+          'tdr_linear_small_fwd')
+    return y
+
+
+def linear_small_bwd(dy, y_act, x, W, want_db=True):
+    N, Cin = x.shape
+    dx, dW = torch.empty_like(x), torch.empty_like(W)
+    db = torch.empty(W.shape[0], dtype=torch.float32, device=x.device) if want_db else None
+    check(_lib.load().tdr_linear_small_bwd(dy.data_ptr(), _p(y_act), x.data_ptr(), W.data_ptr(), N, Cin, W.shape[0], dx.data_ptr(),
+                                           dW.data_ptr(), _p(db), _stream()), 'tdr_linear_small_bwd')
+    return dx, dW, db
+
+
+def softmax_rows(x, dy=None):
+    """x [rows, L]: softmax over L; with dy: backward, x being the softmax OUTPUT"""
+    rows, L = x.shape
+    out = torch.empty_like(x)
+    check(_lib.load().tdr_softmax_rows(x.data_ptr(), _p(dy), rows, L, out.data_ptr(), _stream()), 'tdr_softmax_rows')
+    return out
+
+
+def scale_copy(src, w, w_stride, dst):
+    """dst[n] = src[n] * w[n * w_stride] (w: a view into the [N, steps, ops] weight tensor starting at the wanted element)"""
+    N = src.shape[0]
+    length = src[0].numel()
+    check(_lib.load().tdr_scale_copy(src.data_ptr(), _dense_nchw(src), w.data_ptr(), int(w_stride), N, length, dst.data_ptr(),
+                                     _dense_nchw(dst), _stream()), 'tdr_scale_copy')
+    return dst
+
+
+def rows_dot(a, b, out, out_stride):
+    """out[n * out_stride] = <a[n], b[n]>"""
+    N = a.shape[0]
+    ws = workspace(64 * N, a.device, 'rowsdot')
+    check(_lib.load().tdr_rows_dot(a.data_ptr(), _dense_nchw(a), b.data_ptr(), _dense_nchw(b), N, a[0].numel(), out.data_ptr(),
+                                   int(out_stride), ws.data_ptr(), _stream()), 'tdr_rows_dot')
+    return out
