@@ -38,6 +38,10 @@ def make_opt(width, enc, batch_hw, dist_on, arch='nafnet'):
         net = dict(type='DRSformer200L_SPA_RefFusion', inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8],
                    heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias', nf=48,
                    ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2])
+    elif arch == 'drsformer_mefc':   # 008/009/010_drsformer_*.yml network (DRSformerRefFusion, with the MEFC sub-networks)
+        net = dict(type='DRSformerRefFusion', inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8],
+                   heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias', nf=48,
+                   ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2])
     elif arch == 'promptir':     # the reference's 001_promptir_all_in_one_restoration.yml network, with decoder=True (False raises: R4)
         net = dict(type='PromptIRRefFusion', inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8],
                    num_refinement_blocks=4, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
@@ -155,7 +159,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer', 'promptir', 'drsformer'],
+    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc'],
                     help="nafnet: the headline workload (BASELINE configs[1]); restormer: configs[2]'s per-GPU workload "
                          '(Restormer-ref dim 48, 256x256, bs 8) -- a secondary measurement, not the metric line')
     ap.add_argument('--batch', type=int, default=None)
@@ -171,9 +175,9 @@ def main():
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (multi-process smoke test on one GPU)')
     a = ap.parse_args()
     if a.batch is None:
-        a.batch = 8 if a.arch in ('restormer', 'promptir', 'drsformer') else 4
+        a.batch = 8 if a.arch in ('restormer', 'promptir', 'drsformer', 'drsformer_mefc') else 4
     if a.size is None:
-        a.size = {'restormer': 256, 'promptir': 384, 'drsformer': 256}.get(a.arch, 512)
+        a.size = {'restormer': 256, 'promptir': 384, 'drsformer': 256, 'drsformer_mefc': 256}.get(a.arch, 512)
     enc = [int(v) for v in a.enc.split(',')]
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -332,6 +336,9 @@ def main():
                                      'DRSformer-ref without MEFC (007_drsformer_image_deraining_rain200l.yml network): dim48 blocks[4,6,6,8] '
                                      f'top-k sparse attention + mixed-scale FFN, {a.size}x{a.size} synthetic pairs, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
                                      if a.arch == 'drsformer' else
+                                     'DRSformer-ref with MEFC (008/009/010_drsformer_*.yml network): dim48 blocks[4,6,6,8], '
+                                     f'{a.size}x{a.size} synthetic pairs, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
+                                     if a.arch == 'drsformer_mefc' else
                                      'PromptIR-ref (001_promptir_all_in_one_restoration.yml network, decoder=True): dim48 blocks[4,6,6,8] '
                                      f'refine4 prompts 64/128/320, {a.size}x{a.size} synthetic pairs, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW')),
                        'width': a.width if a.arch == 'nafnet' else 48, 'enc_blk_nums': enc if a.arch == 'nafnet' else [4, 6, 6, 8],

@@ -337,6 +337,7 @@ int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns,
  * backward from the softmax output), dst[n] = src[n] * w[n * w_stride] (the per-image operation weights), per-image dot
  * products (their gradients; ws: 64 * N floats). */
 int tdr_avgpool3(const float* in, int planes, int H, int W, int adjoint, float* out, void* stream);
+int tdr_add_relu(const float* a, const float* b, int64_t numel, float* out, void* stream);      /* relu(a + b) (:407) */
 int tdr_linear_small_fwd(const float* x, const float* W, const float* b, int N, int Cin, int Cout, int relu, float* y, void* stream);
 int tdr_linear_small_bwd(const float* dy, const float* yact /*or NULL*/, const float* x, const float* W, int N, int Cin, int Cout,
                          float* dx, float* dW, float* db, void* stream);

@@ -198,3 +198,119 @@ def test_train_step_matches_oracle_trainer():
         if k.startswith(DO.UNUSED):
             assert torch.equal(sd[k].cpu(), P[k]), k
     assert maxdiff(model.output, out_o) < 1e-4
+
+
+# ------------------------------------------------------------------ the full class: MEFC sub-networks
+@pytest.mark.parametrize('K,dil', [(1, 1), (7, 1), (3, 2), (5, 2), (7, 2)])
+def test_dilated_depthwise_vs_torch(K, dil):
+    from textualdegremoval_amd import kernels as Kn
+    g = torch.Generator().manual_seed(K * 10 + dil)
+    C, N, H, W = 6, 2, 20, 36
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, K, K, generator=g) * 0.3
+    go = torch.randn(N, C, H, W, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, padding=dil * (K // 2), dilation=dil, groups=C)
+    yr.backward(go)
+    y = Kn.dwk_fwd(x.cuda(), w.cuda(), dil=dil)
+    assert maxdiff(y, yr) < 2e-5
+    dx, dw, _ = Kn.dwk_bwd(go.cuda(), None, x.cuda(), w.cuda(), dil=dil)
+    assert maxdiff(dx, xr.grad) < 2e-5
+    assert maxdiff(dw, wr.grad) < 1e-4 * max(1.0, wr.grad.abs().max().item())
+
+
+def test_avgpool_and_small_pieces_vs_torch():
+    from textualdegremoval_amd import kernels as Kn
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 5, 9, 13, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.avg_pool2d(xr, 3, stride=1, padding=1, count_include_pad=False)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+    assert maxdiff(Kn.avgpool3(x.cuda()), yr) < 1e-6
+    assert maxdiff(Kn.avgpool3(go.cuda(), adjoint=True), xr.grad) < 1e-6
+    a, Wm, b = torch.randn(3, 10, generator=g), torch.randn(7, 10, generator=g), torch.randn(7, generator=g)
+    ar, Wr, br = a.clone().requires_grad_(True), Wm.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yl = torch.relu(torch.nn.functional.linear(ar, Wr, br))
+    gl = torch.randn(yl.shape, generator=g)
+    yl.backward(gl)
+    y = Kn.linear_small_fwd(a.cuda(), Wm.cuda(), b.cuda(), relu=True)
+    assert maxdiff(y, yl) < 1e-5
+    dx, dW, db = Kn.linear_small_bwd(gl.cuda(), y, a.cuda(), Wm.cuda())
+    assert maxdiff(dx, ar.grad) < 1e-5 and maxdiff(dW, Wr.grad) < 1e-5 and maxdiff(db, br.grad) < 1e-5
+    s = torch.randn(6, 8, generator=g)
+    sr = s.clone().requires_grad_(True)
+    ys = torch.softmax(sr, dim=-1)
+    gs = torch.randn(ys.shape, generator=g)
+    ys.backward(gs)
+    p = Kn.softmax_rows(s.cuda())
+    assert maxdiff(p, ys) < 1e-6 and maxdiff(Kn.softmax_rows(p, dy=gs.cuda()), sr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('tag', ['mefc_a', 'mefc_b'])
+def test_mefc_subnet_vs_reference_golden(DE, tag):
+    """`subnet` (:522-548) against the reference's own class: forward, input gradient, every parameter gradient."""
+    g = gold('drsformer_mefc')
+    P = {'s.' + str(k): dev(g[f'{tag}_p_{k}']) for k in g[tag + '_names']}
+    y, saved = DE.mefc_fwd(dev(g[tag + '_x']), P, 's.')
+    G = {}
+    dx = DE.mefc_bwd(dev(g[tag + '_go']), P, 's.', saved, G)
+    assert maxdiff(y, T(g[tag + '_y'])) < 5e-5
+    assert maxdiff(dx, T(g[tag + '_gx'])) < 2e-4
+    for k in g[tag + '_names']:
+        ref = T(g[f'{tag}_g_{k}'])
+        assert maxdiff(G['s.' + str(k)].view_as(ref), ref) < 3e-4 * max(1.0, ref.abs().max().item()), k
+
+
+@pytest.mark.parametrize('name,kw', [('drsformer_full_d8_64', dict()), ('drsformer_full_d8_128_b2', dict(LayerNorm_type='BiasFree'))])
+def test_full_class_vs_reference_golden(DE, name, kw):
+    g = gold(name)
+    cfg = dict(DO.default_cfg(**kw), mefc=True)
+    seed = int(g['seed'])
+    P = DO.full_synth_params(cfg, seed=seed)
+    lq, gt, ref = NO.synth_pair(int(g['cfg_B']), int(g['cfg_H']), int(g['cfg_W']), seed=8765 + seed)
+    Pc = {k: v.cuda().contiguous() for k, v in P.items()}
+    out, saved = DE.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
+    assert maxdiff(out, T(g['out'])) < 1e-4
+    from textualdegremoval_amd import kernels as K
+    loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0)
+    assert abs(loss.item() - float(g['loss'])) < 2e-6
+    G = DE.net_bwd(dpred, Pc, cfg, saved)
+    names = [str(n) for n in g['names']]
+    assert set(G.keys()) == set(names)
+    for i, k in enumerate(names):
+        gn = G[k].double().norm().item()
+        assert abs(gn - g['grad_norm'][i]) <= 5e-3 * g['grad_norm'][i] + 1e-5, (k, gn, g['grad_norm'][i])
+
+
+def test_full_class_module_and_train_step():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd.models import create_model
+    cfg = DO.default_cfg()
+    opt = {
+        'model_type': 'RefGuidedImageCleanModel', 'num_gpu': 1, 'dist': False, 'is_train': True,
+        'network_g': dict(type='DRSformerRefFusion', **_kw(cfg)), 'path': {},
+        'train': {'optim_g': {'type': 'AdamW', 'lr': 2e-4, 'ref_lr': 1e-4, 'weight_decay': 1e-4, 'betas': [0.9, 0.999]},
+                  'scheduler': {'type': 'CosineAnnealingRestartCyclicLR', 'periods': [30, 70], 'restart_weights': [1, 1],
+                                'eta_mins': [3e-4, 1e-6]},
+                  'pixel_opt': {'type': 'L1Loss', 'loss_weight': 1, 'reduction': 'mean'},
+                  'use_grad_clip': True, 'total_iter': 100, 'warmup_iter': -1},
+        'logger': {'check_freq': 10 ** 9}, 'val': {}, 'scale': 1,
+    }
+    model = create_model(opt)
+    P = DO.full_synth_params(cfg, seed=6)
+    assert list(model.net_g.state_dict().keys()) == list(P.keys())
+    model.net_g.load_state_dict(P, strict=True)
+    tr = NO.OracleTrainer(P, cfg, forward_fn=DO.drsformer_full_forward)
+    lq, gt, ref = NO.synth_pair(1, 64, 64, seed=56)
+    periods, rw, em = [30, 70], [1, 1], [3e-4, 1e-6]
+    for it in range(1, 5):
+        t = it - 1
+        tr.set_lrs(NO.cosine_restart_cyclic_lr(t, 2e-4, periods, rw, em), NO.cosine_restart_cyclic_lr(t, 1e-4, periods, rw, em))
+        loss_o, _, out_o = tr.step(lq, gt, ref)
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.feed_train_data({'lq': lq, 'gt': gt, 'ref': ref})
+        model.optimize_parameters(it)
+        assert abs(model.get_current_log()['l_pix'] - loss_o) < 5e-6, (it, model.get_current_log()['l_pix'], loss_o)
+    assert maxdiff(model.output, out_o) < 1e-4

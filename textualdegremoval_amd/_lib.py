@@ -192,6 +192,7 @@ SIGNATURES = {
     'tdr_dwk_fwd': (i32, [c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
     'tdr_dwk_bwd': (i32, [c_fp, i64, c_fp, i64, c_fp, i64, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp, c_fp, c_fp, c_fp]),
     'tdr_avgpool3': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_add_relu': (i32, [c_fp, c_fp, i64, c_fp, c_fp]),
     'tdr_linear_small_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_linear_small_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_softmax_rows': (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp]),

@@ -263,6 +263,10 @@ __global__ void scale_copy_kernel(const float* __restrict__ src, long src_ns, co
     }
 }
 
+__global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = fmaxf(a[i] + b[i], 0.f);
+}
+
 constexpr int RD_BLOCKS = 64;
 // part[n][b] = sum over block b's slice of a[n] . b[n]; finish sums the RD_BLOCKS partials in order
 __global__ __launch_bounds__(256) void rows_dot_kernel(const float* __restrict__ a, long a_ns, const float* __restrict__ b, long b_ns,
@@ -380,5 +384,12 @@ extern "C" int tdr_rows_dot(const float* a, int64_t a_ns, const float* b, int64_
     hipLaunchKernelGGL(rows_dot_kernel, dim3(RD_BLOCKS, N), dim3(256), 0, st, a, (long)a_ns, b, (long)b_ns, (long)len, ws);
     hipLaunchKernelGGL(rows_dot_finish_kernel, dim3(tdr_cdiv(N, 64)), dim3(64), 0, st, ws, N, out_stride, out);
     TDR_LAUNCH_CHECK("rows_dot");
+    return TDR_OK;
+}
+
+extern "C" int tdr_add_relu(const float* a, const float* b, int64_t numel, float* out, void* stream) {
+    TDR_REQUIRE(a && b && out && numel > 0, "tdr_add_relu: bad argument");
+    hipLaunchKernelGGL(add_relu_kernel, dim3(dgrid(numel)), dim3(256), 0, (hipStream_t)stream, a, b, (long)numel, out);
+    TDR_LAUNCH_CHECK("add_relu");
     return TDR_OK;
 }

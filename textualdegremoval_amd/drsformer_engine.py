@@ -156,12 +156,16 @@ def net_fwd(P, cfg, inp, ref):
     inp_p, geo = pyr.inp_p, pyr.geo
     warp, sv_masa = E.masa_fwd(pyr.lq_deep, pyr.ref_feats, N, geo)
     hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
+    full = bool(cfg.get('mefc'))       # DRSformerRefFusion: MEFC sub-networks + a working level-1 fusion; else the 200L_SPA class
     x = E.conv_fwd(inp_p, P['patch_embed.proj.weight'], P.get('patch_embed.proj.bias'), 1, 1)
+    x_embed, sv_m0 = x, None
+    if full:
+        x, sv_m0 = mefc_fwd(x, P, 'encoder_level0.')
     sv_lv, enc_out = [], []
     for l in range(4):
         c = dim * 2 ** l
         sv_f = None
-        if l > 0:                  # R6: the reference discards the level-1 fusion; it is not computed here
+        if l > 0 or full:          # R6 (200L_SPA only): the reference discards the level-1 fusion; it is not computed there
             f, sv_f = seq_fwd(K.concat2(x, warp[l]), P, R._FUS[l], nfz[l], hd[l], ln, fusion=True)
             x = K.slice_channels(f, 0, c)
         e, sv_e = seq_fwd(x, P, R._ENC[l], nb[l], hd[l], ln)
@@ -176,9 +180,12 @@ def net_fwd(P, cfg, inp, ref):
     d2, sv_d2 = seq_fwd(R._pw_fwd(cat2, P, 'reduce_chan_level2'), P, 'decoder_level2.', nb[1], hd[1], ln)
     cat1 = K.concat2(R.up_fwd(d2, P['up2_1.body.0.weight']), e1)
     d1, sv_d1 = seq_fwd(cat1, P, 'decoder_level1.', nb[0], hd[0], ln)
+    sv_m1 = None
+    if full:
+        d1, sv_m1 = mefc_fwd(d1, P, 'refinement.')
     out_p = E.conv_fwd(d1, P['output.weight'], P.get('output.bias'), 1, 1, res=inp_p)
     out = out_p if (Hp, Wp) == (H0, W0) else K.pad_crop(out_p, H0, W0)
-    saved = (N, (H0, W0, Hp, Wp), geo, pyr, None, None, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, d1)
+    saved = (N, (H0, W0, Hp, Wp), geo, pyr, sv_m0, sv_m1, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, d1)
     return out, saved
 
 
@@ -188,7 +195,8 @@ def net_bwd(dout, P, cfg, saved, G=None):
 
 
 def _net_bwd(dout, P, cfg, saved, G):
-    (N, (H0, W0, Hp, Wp), geo, pyr, _, _, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, d1) = saved
+    (N, (H0, W0, Hp, Wp), geo, pyr, sv_m0, sv_m1, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, d1) = saved
+    full = bool(cfg.get('mefc'))
     G = {} if G is None else G
     hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
     e1, e2, e3, lat = enc_out
@@ -200,6 +208,8 @@ def _net_bwd(dout, P, cfg, saved, G):
     d, G['output.weight'], db = E.conv_bwd(dout, d1, P['output.weight'], 1, 1, bias=has_ob)
     if has_ob:
         G['output.bias'] = db
+    if full:
+        d = mefc_bwd(d, P, 'refinement.', sv_m1, G)
     d = seq_bwd(d, P, 'decoder_level1.', nb[0], hd[0], ln, sv_d1, G)
     de1 = d[:, dim:]
     d, G['up2_1.body.0.weight'] = R.up_bwd(K.slice_channels(d, 0, dim), d2, P['up2_1.body.0.weight'])
@@ -217,19 +227,123 @@ def _net_bwd(dout, P, cfg, saved, G):
         c = dim * 2 ** l
         sv_f, sv_e = sv_lv[l]
         d = seq_bwd(d, P, R._ENC[l], nb[l], hd[l], ln, sv_e, G)
-        if l > 0:
+        if l > 0 or full:
             df = torch.zeros(N, 2 * c, d.shape[2], d.shape[3], dtype=torch.float32, device=d.device)
             K.copy_rows(d, c * d.shape[2] * d.shape[3], df, 2 * c * d.shape[2] * d.shape[3], N, c * d.shape[2] * d.shape[3])
             dcat = seq_bwd(df, P, R._FUS[l], nfz[l], hd[l], ln, sv_f, G, fusion=True)
             dwarp[l] = dcat[:, c:]
-            dx = K.slice_channels(dcat, 0, c)
-            d, G[R._DOWN[l - 1]] = R.down_bwd(dx, enc_out[l - 1], P[R._DOWN[l - 1]])
+            d = K.slice_channels(dcat, 0, c)
+        if l > 0:
+            d, G[R._DOWN[l - 1]] = R.down_bwd(d, enc_out[l - 1], P[R._DOWN[l - 1]])
             d = K.add_(d, dskip[l - 1])
         else:
-            dwarp[0] = torch.zeros(N, c, d.shape[2], d.shape[3], dtype=torch.float32, device=d.device)     # R6: unused warp level
+            if full:
+                d = mefc_bwd(d, P, 'encoder_level0.', sv_m0, G)
+            else:
+                dwarp[0] = torch.zeros(N, c, d.shape[2], d.shape[3], dtype=torch.float32, device=d.device)     # R6: unused warp level
             has_pb = 'patch_embed.proj.bias' in P
             _, G['patch_embed.proj.weight'], db = E.conv_bwd(d, inp_p, P['patch_embed.proj.weight'], 1, 1, need_dx=False, bias=has_pb)
             if has_pb:
                 G['patch_embed.proj.bias'] = db
     E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
     return G
+
+
+# ---------------------------------------------------------------------------
+# MEFC sub-network (`subnet`, network_drsformer_guided_arch.py:522-548) and the full DRSformerRefFusion (:679-1123)
+# ---------------------------------------------------------------------------
+OPS = ('sep_conv_1x1', 'sep_conv_3x3', 'sep_conv_5x5', 'sep_conv_7x7', 'dil_conv_3x3', 'dil_conv_5x5', 'dil_conv_7x7', 'avg_pool_3x3')
+STEPS = 4
+
+
+def _pw(x, w, relu=False, out=None):
+    wp, mp, *_ = K.pack_weights(w, R.PACK_FWD)
+    return K.conv_forward(x, wp, mp, w.shape[0], 1, relu=relu, out=out)
+
+
+def _op_fwd(x, P, pre, j):
+    name = OPS[j]
+    if name == 'avg_pool_3x3':
+        return K.avgpool3(x), None
+    if name.startswith('sep_conv'):
+        a = K.dwk_fwd(x, P[pre + 'op.0.weight'])
+        r = _pw(a, P[pre + 'op.1.weight'], relu=True)
+        c = K.dwk_fwd(r, P[pre + 'op.3.weight'])
+        return _pw(c, P[pre + 'op.4.weight']), (a, r, c)
+    a = K.dwk_fwd(x, P[pre + 'op.0.weight'], dil=2)
+    return _pw(a, P[pre + 'op.1.weight']), (a,)
+
+
+def _op_bwd(do, x, P, pre, j, sv, G):
+    name = OPS[j]
+    if name == 'avg_pool_3x3':
+        return K.avgpool3(do.contiguous(), adjoint=True)
+    if name.startswith('sep_conv'):
+        a, r, c = sv
+        dc = R._pw_bwd(do, c, P, pre + 'op.4', G)
+        dr, G[pre + 'op.3.weight'], _ = K.dwk_bwd(dc, None, r, P[pre + 'op.3.weight'])
+        da = R._pw_bwd(K.relu_bwd(dr, r), a, P, pre + 'op.1', G)
+        dx, G[pre + 'op.0.weight'], _ = K.dwk_bwd(da, None, x, P[pre + 'op.0.weight'])
+        return dx
+    a, = sv
+    da = R._pw_bwd(do, a, P, pre + 'op.1', G)
+    dx, G[pre + 'op.0.weight'], _ = K.dwk_bwd(da, None, x, P[pre + 'op.0.weight'], dil=2)
+    return dx
+
+
+def mefc_fwd(x, P, pre):
+    """x [N,C,H,W] -> subnet(x).  Gating: mean_hw -> Linear -> ReLU -> Linear -> softmax over the 8 operations of each step;
+    the per-image operation weights scale the (saved, unscaled) operation outputs while they are copied into the concat."""
+    N, C, H, W = x.shape
+    nops = len(OPS)
+    emb = K.plane_mean(x)
+    h1 = K.linear_small_fwd(emb, P[pre + 'layers.0.ca_fc.0.weight'], P[pre + 'layers.0.ca_fc.0.bias'], relu=True)
+    lg = K.linear_small_fwd(h1, P[pre + 'layers.0.ca_fc.2.weight'], P[pre + 'layers.0.ca_fc.2.bias'])
+    wts = K.softmax_rows(lg.view(N * STEPS, nops))                      # [(n, step), op]
+    wflat = wts.view(-1)
+    g = pre + 'layers.1.'
+    s0 = _pw(x, P[g + 'preprocess.op.0.weight'], relu=True)
+    steps = []
+    for i in range(STEPS):
+        cat = torch.empty(N, nops * C, H, W, dtype=torch.float32, device=x.device)
+        ops = []
+        for j in range(nops):
+            o, sv = _op_fwd(s0, P, f'{g}_ops.{i}._ops.{j}.', j)
+            K.scale_copy(o, wflat[i * nops + j:], STEPS * nops, cat[:, j * C:(j + 1) * C])
+            ops.append((o, sv))
+        t = _pw(cat, P[f'{g}_ops.{i}._out.0.weight'], relu=True)
+        s1 = K.add_relu(t, s0)
+        steps.append((s0, cat, t, s1, ops))
+        s0 = s1
+    return s0, (x, emb, h1, wts, steps)
+
+
+def mefc_bwd(dout, P, pre, saved, G):
+    x, emb, h1, wts, steps = saved
+    N, C, H, W = x.shape
+    nops = len(OPS)
+    g = pre + 'layers.1.'
+    wflat = wts.view(-1)
+    dwts = torch.empty_like(wts)
+    dwflat = dwts.view(-1)
+    d = dout.contiguous()
+    for i in reversed(range(STEPS)):
+        s0, cat, t, s1, ops = steps[i]
+        d = K.relu_bwd(d, s1)                                           # relu(t + res)
+        dt = K.relu_bwd(d, t)                                           # _out's ReLU
+        dcat = R._pw_bwd(dt, cat, P, f'{g}_ops.{i}._out.0', G)
+        ds0 = d                                                         # the `res` branch
+        for j in range(nops):
+            o, sv = ops[j]
+            dsl = dcat[:, j * C:(j + 1) * C]
+            K.rows_dot(dsl, o, dwflat[i * nops + j:], STEPS * nops)
+            do = K.scale_copy(dsl, wflat[i * nops + j:], STEPS * nops, torch.empty(N, C, H, W, dtype=torch.float32, device=x.device))
+            ds0 = K.add_(_op_bwd(do, s0, P, f'{g}_ops.{i}._ops.{j}.', j, sv, G), ds0)
+        d = ds0
+    dpre = K.relu_bwd(d, steps[0][0])
+    dx = R._pw_bwd(dpre, x, P, g + 'preprocess.op.0', G)
+    dlg = K.softmax_rows(wts, dy=dwts).view(N, STEPS * nops)
+    dh1, G[pre + 'layers.0.ca_fc.2.weight'], G[pre + 'layers.0.ca_fc.2.bias'] = K.linear_small_bwd(dlg, None, h1, P[pre + 'layers.0.ca_fc.2.weight'])
+    demb, G[pre + 'layers.0.ca_fc.0.weight'], G[pre + 'layers.0.ca_fc.0.bias'] = K.linear_small_bwd(dh1, h1, emb, P[pre + 'layers.0.ca_fc.0.weight'])
+    E.maybe_join()
+    return K.plane_add_(dx, demb, 1.0 / (H * W))

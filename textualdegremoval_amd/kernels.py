@@ -1312,3 +1312,10 @@ def rows_dot(a, b, out, out_stride):
     check(_lib.load().tdr_rows_dot(a.data_ptr(), _dense_nchw(a), b.data_ptr(), _dense_nchw(b), N, a[0].numel(), out.data_ptr(),
                                    int(out_stride), ws.data_ptr(), _stream()), 'tdr_rows_dot')
     return out
+
+
+def add_relu(a, b):
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.empty_like(a)
+    check(_lib.load().tdr_add_relu(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()), 'tdr_add_relu')
+    return out
