@@ -62,8 +62,13 @@ def mlp_bwd(dout, P, pre, saved, G):
         d, G[f'{pre}{j}.weight'], G[f'{pre}{j}.bias'] = _lin_bwd(dz, x, P[f'{pre}{j}.weight'], j > 0)
 
 
+LANES = int(__import__('os').environ.get('TDR_MAPPER_LANES', '4'))   # HIP streams the 2 x num_words independent MLPs are spread over
+
+
 def mapper_fwd(tok, T, P, num_words):
-    """tok [B, Din, LD/32, 32] channel-major (column 0 class token, 1..T patches) -> ([B, words, Dout], saved)."""
+    """tok [B, Din, LD/32, 32] channel-major (column 0 class token, 1..T patches) -> ([B, words, Dout], saved).
+    The words are independent chains of small launches (a 1280 x 1280 Linear over 4 x 257 tokens fills a third of the chip, the
+    class-token MLPs are pure latency): word i runs on lane i % LANES (kernels.lane), forward and backward on the same lane."""
     B = tok.shape[0]
     if B > 32:
         raise NotImplementedError('HIP Mapper: batch <= 32 per call (class tokens travel as one 32-pixel row)')
@@ -72,10 +77,12 @@ def mapper_fwd(tok, T, P, num_words):
     out = torch.empty(B, num_words, dout_dim, dtype=torch.float32, device=tok.device)
     saved = []
     for i in range(num_words):
-        c, sv_c = mlp_fwd(cls_in, P, f'mapping_{i}.')
-        p, sv_p = mlp_fwd(tok, P, f'mapping_patch_{i}.')
-        K.mapper_combine(c, p, T, out, i)
-        saved.append((sv_c, sv_p))
+        with K.lane(i % LANES):
+            c, sv_c = mlp_fwd(cls_in, P, f'mapping_{i}.')
+            p, sv_p = mlp_fwd(tok, P, f'mapping_patch_{i}.')
+            K.mapper_combine(c, p, T, out, i)
+            saved.append((sv_c, sv_p, c, p))                          # (c, p stay referenced: their lane may still be reading them)
+    K.lanes_join()
     return out, (saved, tok.shape[2] * tok.shape[3], T)
 
 
@@ -83,10 +90,17 @@ def mapper_bwd(dout, P, num_words, saved):
     sv, LD, T = saved
     G = {}
     dout = dout.contiguous()
+    cur = torch.cuda.current_stream()
     for i in range(num_words):
-        dc, dp = K.mapper_combine_bwd(dout, LD, T, i)
-        mlp_bwd(dc, P, f'mapping_{i}.', sv[i][0], G)
-        mlp_bwd(dp, P, f'mapping_patch_{i}.', sv[i][1], G)
+        with K.lane(i % LANES):
+            dc, dp = K.mapper_combine_bwd(dout, LD, T, i)
+            Gi = {}
+            mlp_bwd(dc, P, f'mapping_{i}.', sv[i][0], Gi)
+            mlp_bwd(dp, P, f'mapping_patch_{i}.', sv[i][1], Gi)
+            for g in Gi.values():
+                g.record_stream(cur)                                  # consumed by the caller's stream after the join
+            G.update(Gi)
+    K.lanes_join()
     return G
 
 

@@ -188,6 +188,45 @@ class side_suspended:
         return False
 
 
+# ---- lanes: independent chains of small launches (the 40 MLPs of the stage-A Mapper) on a few HIP streams.  Inside `with lane(i)`
+# torch's CURRENT stream is lane i, so this module's launches go there and the caching allocator ties every tensor allocated in
+# the block to that stream (stream-ordered reuse stays correct); scratch buffers are per lane.  lanes_join() makes the caller's
+# stream wait for all lanes; results that cross to another stream are handed over with record_stream by the caller.
+_lane_streams = []
+_lane_dirty = {}
+_lane_active = False
+
+
+class lane:
+    def __init__(self, i):
+        self.i = i
+
+    def __enter__(self):
+        global _lane_active
+        while len(_lane_streams) <= self.i:
+            _lane_streams.append(torch.cuda.Stream())
+        st = _lane_streams[self.i]
+        if self.i not in _lane_dirty:
+            st.wait_stream(torch.cuda.current_stream())
+            _lane_dirty[self.i] = st
+        self.ctx = torch.cuda.stream(st)
+        self.ctx.__enter__()
+        self.prev, _lane_active = _lane_active, True
+        return self
+
+    def __exit__(self, *exc):
+        global _lane_active
+        _lane_active = self.prev
+        return self.ctx.__exit__(*exc)
+
+
+def lanes_join():
+    cur = torch.cuda.current_stream()
+    for st in _lane_dirty.values():
+        cur.wait_stream(st)
+    _lane_dirty.clear()
+
+
 def _stream():
     if _side_active:
         return _side_stream.cuda_stream
@@ -240,7 +279,8 @@ class workspace_capture:
 
 def workspace(nfloats, device, tag='main'):
     """grow-only scratch buffer (stream-ordered reuse)."""
-    key = (tag + ('@side' if _side_active else ''), device.index if hasattr(device, 'index') else device)
+    key = (tag + ('@side' if _side_active else '') + (f'@lane{torch.cuda.current_stream().cuda_stream}' if _lane_active else ''),
+           device.index if hasattr(device, 'index') else device)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
         if buf is not None and _side_active:
