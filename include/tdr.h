@@ -252,6 +252,14 @@ int tdr_pad_crop(const float* src, int N, int C, int Hs, int Ws, float* dst, int
 int tdr_crop_augment(const float* src, int64_t src_ns, int N, int C, int Hs, int Ws, const int* top, const int* left,
                      const int* mode, const float* noise, const float* sigma, int P, float* out, void* stream);
 
+/* Validation SSIM on the device -- metrics/psnr_ssim.py:131-176 (_ssim_3d: 11^3 Gaussian, sigma 1.5, over the [H,W,C]
+ * volume with replicate borders; the reference runs it on the GPU too).  img1 / img2 [H][W][C] float32, C <= 4; max_value 1
+ * or 255 (C1 = (0.01 max)^2, C2 = (0.03 max)^2); ws: tdr_ssim3d_ws_floats(H, W) floats; out: 1 float = mean of the SSIM map.
+ * With C = 1 the channel axis drops out and the result is the 2-D replicate-border SSIM of _ssim_cly (:184-222). */
+int64_t tdr_ssim3d_ws_floats(int H, int W);
+int tdr_ssim3d(const float* img1, const float* img2, int H, int W, int C, float max_value, float* ws, float* out,
+               void* stream);
+
 /* ReLU backward: out = act > 0 ? go : 0 (Encoder/ResidualBlock nn.ReLU, :52,132) */
 int tdr_relu_bwd(const float* go, const float* act, int64_t numel, float* out, void* stream);
 

@@ -200,6 +200,8 @@ SIGNATURES = {
     'tdr_rows_dot': (i32, [c_fp, i64, c_fp, i64, i32, i64, c_fp, i32, c_fp, c_fp]),
     'tdr_dwk_bwd_ws_floats': (i64, [i32, i32, i32, i32, i32, i32]),
     'tdr_crop_augment': (i32, [c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp]),
+    'tdr_ssim3d_ws_floats': (i64, [i32, i32]),
+    'tdr_ssim3d': (i32, [c_fp, c_fp, i32, i32, i32, f32, c_fp, c_fp, c_fp]),
     'tdr_plane_mean': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp]),
     'tdr_plane_add': (i32, [c_fp, i64, c_fp, f32, i32, i32, i32, c_fp]),
     'tdr_prompt_weights_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp]),

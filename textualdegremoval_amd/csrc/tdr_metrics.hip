@@ -1,0 +1,138 @@
+// Validation metrics on the device: SSIM over the [H,W,C] volume with an 11^3 Gaussian window (sigma 1.5) and replicate
+// borders -- the reference's _ssim_3d (metrics/psnr_ssim.py:131-176), which also runs on the GPU there (conv3d .cuda()).
+//
+// One workgroup owns a 16x16 pixel tile x all C channels (one channel of the volume at a time).  The 11^3 window is
+// separable: the channel axis (C <= 4, replicate padded by 5 either side) collapses into a C x C matrix applied while the
+// haloed tile is staged into LDS, then an 11-tap pass along W and one along H.  The five filtered fields (a, b, a^2, b^2,
+// ab) never leave the chip; the kernel writes one partial sum of the SSIM map per workgroup, the finish kernel folds them
+// in double.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr int T = 16;            // tile edge
+constexpr int R = 5;             // window radius
+constexpr int E = T + 2 * R;     // haloed edge
+constexpr int NF = 5;            // a, b, a^2, b^2, ab
+
+struct SsimArgs {
+    const float* a;
+    const float* b;
+    int H, W;
+    float c1, c2;
+    float g[11];
+    float mc[16];                // [c][c'] channel-axis matrix
+    float* partial;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void ssim3d_kernel(SsimArgs p) {
+    __shared__ float s0[NF][E][E + 1];
+    __shared__ float s1[NF][E][T + 1];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
+    const int ty = tid >> 4, tx = tid & 15;
+    float sum = 0.f;
+    for (int k = 0; k < C; ++k) {                 // output channel of the volume
+        // stage: the five raw fields at replicate-clamped coordinates, channel axis mixed on the way in
+        for (int i = tid; i < E * E; i += 256) {
+            const int r = i / E, c = i - r * E;
+            const int y = min(max(y0 + r - R, 0), p.H - 1), x = min(max(x0 + c - R, 0), p.W - 1);
+            const float* pa = p.a + ((int64_t)y * p.W + x) * C;
+            const float* pb = p.b + ((int64_t)y * p.W + x) * C;
+            float acc[NF] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const float va = pa[j], vb = pb[j], m = p.mc[k * 4 + j];
+                acc[0] += m * va; acc[1] += m * vb; acc[2] += m * (va * va); acc[3] += m * (vb * vb); acc[4] += m * (va * vb);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) s0[f][r][c] = acc[f];
+        }
+        __syncthreads();
+        // W pass
+        for (int i = tid; i < NF * E * T; i += 256) {
+            const int f = i / (E * T), rem = i - f * (E * T), r = rem / T, x = rem - r * T;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 11; ++j) acc += p.g[j] * s0[f][r][x + j];
+            s1[f][r][x] = acc;
+        }
+        __syncthreads();
+        // H pass + the SSIM map
+        if (y0 + ty < p.H && x0 + tx < p.W) {
+            float v[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 11; ++j) acc += p.g[j] * s1[f][ty + j][tx];
+                v[f] = acc;
+            }
+            const float mu1 = v[0], mu2 = v[1];
+            const float m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
+            const float s11 = v[2] - m11, s22 = v[3] - m22, s12 = v[4] - m12;
+            sum += ((2.f * m12 + p.c1) * (2.f * s12 + p.c2)) / ((m11 + m22 + p.c1) * (s11 + s22 + p.c2));
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void ssim_finish_kernel(const float* partial, int n, double inv_count, float* out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * inv_count);
+}
+
+}  // namespace
+
+extern "C" int64_t tdr_ssim3d_ws_floats(int H, int W) {
+    return (int64_t)((H + T - 1) / T) * ((W + T - 1) / T);
+}
+
+extern "C" int tdr_ssim3d(const float* img1, const float* img2, int H, int W, int C, float max_value, float* ws, float* out,
+                          void* stream) {
+    if (!img1 || !img2 || !ws || !out || H < 1 || W < 1 || C < 1 || C > 4) return 1;
+    SsimArgs p;
+    p.a = img1; p.b = img2; p.H = H; p.W = W;
+    p.c1 = (0.01f * max_value) * (0.01f * max_value);
+    p.c2 = (0.03f * max_value) * (0.03f * max_value);
+    // cv2.getGaussianKernel(11, 1.5): exp(-(i-5)^2 / (2 sigma^2)) normalised in double, used as float32 weights
+    double gd[11], gs = 0.0;
+    for (int i = 0; i < 11; ++i) { gd[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); gs += gd[i]; }
+    for (int i = 0; i < 11; ++i) { gd[i] /= gs; p.g[i] = (float)gd[i]; }
+    for (int i = 0; i < 16; ++i) p.mc[i] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        double row[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 11; ++k) {
+            int j = c + k - 5;
+            j = j < 0 ? 0 : (j > C - 1 ? C - 1 : j);
+            row[j] += gd[k];
+        }
+        for (int j = 0; j < C; ++j) p.mc[c * 4 + j] = (float)row[j];
+    }
+    p.partial = ws;
+    dim3 grid((W + T - 1) / T, (H + T - 1) / T);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 1: hipLaunchKernelGGL(ssim3d_kernel<1>, grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(ssim3d_kernel<2>, grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(ssim3d_kernel<3>, grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(ssim3d_kernel<4>, grid, dim3(256), 0, st, p); break;
+    }
+    hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(256), 0, st, ws, (int)(grid.x * grid.y),
+                       1.0 / ((double)H * W * C), out);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}

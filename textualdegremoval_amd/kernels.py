@@ -1243,6 +1243,19 @@ def crop_augment(src, top, left, mode, patch, noise=None, sigma=None):
     return out
 
 
+def ssim3d(img1, img2, max_value):
+    """img1 / img2 [H,W,C] float32 device tensors (C <= 4) -> 1-element tensor: mean SSIM over the volume with the 11^3
+    Gaussian window and replicate borders (metrics/psnr_ssim.py:131-176)."""
+    assert img1.shape == img2.shape and img1.dim() == 3 and img1.is_contiguous() and img2.is_contiguous()
+    H, W, Cc = img1.shape
+    lib = _lib.load()
+    ws = workspace(lib.tdr_ssim3d_ws_floats(H, W), img1.device, 'ssim')
+    out = torch.empty(1, dtype=torch.float32, device=img1.device)
+    check(lib.tdr_ssim3d(img1.data_ptr(), img2.data_ptr(), H, W, Cc, float(max_value), ws.data_ptr(), out.data_ptr(), _stream()),
+          'tdr_ssim3d')
+    return out
+
+
 # ---------------------------------------------------------------------------
 # DRSformer-ref pieces (csrc/tdr_mdta.hip: top-k sparse attention; csrc/tdr_dwk.hip: grouped depthwise convs)
 # ---------------------------------------------------------------------------
