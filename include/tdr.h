@@ -272,6 +272,14 @@ int tdr_l1_loss(const float* pred, const float* target, int64_t numel, float los
 int tdr_l1_loss_guarded(const float* pred, const float* target, int64_t numel, float loss_weight, const TdrStepGuard* guard,
                         float* loss, float* dpred, float* ws, void* stream);
 
+/* Every pixel criterion of losses/losses.py, value + gradient in one pass (the train step takes whichever `pixel_opt.type`
+ * names).  kind 0: L1Loss (:26-53), 1: MSELoss (:55-82), 2: CharbonnierLoss (:111-122: mean sqrt(d^2 + eps^2), loss_weight
+ * ignored as there), 3: PSNRLoss (:84-109: w * 10/ln10 * mean_n log(mean_chw d^2 + 1e-8)), 4: PSNRLoss toY=True (BT.601 luma
+ * of 3-channel images, /255).  pred / target [N][chw] dense, hw = H*W; dpred = grad_scale (* guard->scale when guard != NULL)
+ * * dloss/dpred; ws: 2*1024 + 2*64*N floats. */
+int tdr_pixel_loss(int kind, const float* pred, const float* target, int N, int64_t chw, int64_t hw, float loss_weight, float eps,
+                   float grad_scale, const TdrStepGuard* guard, float* loss, float* dpred, float* ws, void* stream);
+
 /* ---------------------------------------------------------------------------
  * MASA match-and-transfer (network_nafnet_guided_arch.py:495-707)
  * ------------------------------------------------------------------------- */

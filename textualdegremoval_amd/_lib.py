@@ -220,6 +220,7 @@ SIGNATURES = {
     'tdr_comm_world': (i32, [c_fp]),
     'tdr_comm_destroy': (i32, [c_fp]),
     'tdr_multi_ema': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
+    'tdr_pixel_loss': (i32, [i32, c_fp, c_fp, i32, i64, i64, f32, f32, f32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_l1_loss_guarded': (i32, [c_fp, c_fp, i64, f32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_multi_copy_guarded': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp]),
     'tdr_grad_sumsq_guarded': (i32, [c_fp] * 5 + [i32, c_fp, c_fp, c_fp, f32, f32, c_fp]),

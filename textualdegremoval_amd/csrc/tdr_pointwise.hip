@@ -676,6 +676,89 @@ __global__ void l1_finish_kernel(const double* __restrict__ part, int nparts, do
     if (threadIdx.x == 0) loss[0] = (float)(s * scale);
 }
 
+// The other criteria of losses/losses.py (MSELoss :55-82, CharbonnierLoss :111-122, PSNRLoss :84-109): value + gradient in one pass,
+// same deterministic two-level reduction as l1_kernel.  KIND 1: d^2, KIND 2: sqrt(d^2 + eps^2).
+template <int KIND>
+__global__ __launch_bounds__(256) void pixloss_kernel(const float* __restrict__ p, const float* __restrict__ t, long numel,
+                                                     float gscale, float eps2, const TdrStepGuard* __restrict__ guard,
+                                                     float* __restrict__ dpred, double* __restrict__ part) {
+    __shared__ double red[4];
+    double s = 0.0;
+    if (guard) gscale *= guard->scale;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
+        const float d = p[i] - t[i];
+        if (KIND == 1) {
+            s += (double)(d * d);
+            dpred[i] = 2.f * d * gscale;
+        } else {
+            const float r = sqrtf(d * d + eps2);
+            s += (double)r;
+            dpred[i] = d / r * gscale;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// PSNRLoss: per-image mean of d^2 (toY: d = sum_c coef_c (p_c - t_c) / 255 on the 1-channel luma, the +16 cancels)
+constexpr int PSNR_BLOCKS = 64;        // per image
+__device__ __forceinline__ float psnr_diff(const float* p, const float* t, long base, long HW, long i, int toY) {
+    if (!toY) return p[base + i] - t[base + i];
+    const float d0 = p[base + i] - t[base + i], d1 = p[base + HW + i] - t[base + HW + i],
+                d2 = p[base + 2 * HW + i] - t[base + 2 * HW + i];
+    return (65.481f * d0 + 128.553f * d1 + 24.966f * d2) / 255.f;
+}
+__global__ __launch_bounds__(256) void psnr_sum_kernel(const float* __restrict__ p, const float* __restrict__ t, long CHW, long HW,
+                                                      int toY, double* __restrict__ part) {
+    __shared__ double red[4];
+    const long base = (long)blockIdx.y * CHW, cnt = toY ? HW : CHW;
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < cnt; i += (long)gridDim.x * 256) {
+        const float d = psnr_diff(p, t, base, HW, i, toY);
+        s += (double)(d * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.y * PSNR_BLOCKS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double psnr_image_mse(const double* part, int n, long cnt) {
+    double s = 0.0;                                    // fixed order: every caller gets the same bits
+    for (int k = 0; k < PSNR_BLOCKS; ++k) s += part[n * PSNR_BLOCKS + k];
+    return s / (double)cnt;
+}
+__global__ __launch_bounds__(256) void psnr_grad_kernel(const float* __restrict__ p, const float* __restrict__ t, long CHW, long HW,
+                                                       int toY, int N, float wscale, const TdrStepGuard* __restrict__ guard,
+                                                       const double* __restrict__ part, float* __restrict__ dpred) {
+    const int n = blockIdx.y;
+    const long base = (long)n * CHW, cnt = toY ? HW : CHW;
+    float gscale = wscale;
+    if (guard) gscale *= guard->scale;
+    // d/dp of w*scale/N * log(mse_n + 1e-8), mse_n = mean d^2
+    const float f = (float)((double)gscale / (double)N / (psnr_image_mse(part, n, cnt) + 1e-8) * 2.0 / (double)cnt);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < cnt; i += (long)gridDim.x * 256) {
+        const float d = psnr_diff(p, t, base, HW, i, toY);
+        if (!toY) {
+            dpred[base + i] = f * d;
+        } else {
+            dpred[base + i] = f * d * (65.481f / 255.f);
+            dpred[base + HW + i] = f * d * (128.553f / 255.f);
+            dpred[base + 2 * HW + i] = f * d * (24.966f / 255.f);
+        }
+    }
+}
+__global__ void psnr_finish_kernel(const double* __restrict__ part, int N, long cnt, double wscale, float* __restrict__ loss) {
+    double s = 0.0;
+    for (int n = threadIdx.x; n < N; n += 64) s += log(psnr_image_mse(part, n, cnt) + 1e-8);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) loss[0] = (float)(s / (double)N * wscale);
+}
+
 inline int grid1d(long total, int cap = 8192) {
     long b = (total + 255) / 256;
     return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
@@ -952,6 +1035,38 @@ extern "C" int tdr_l1_loss(const float* pred, const float* target, int64_t numel
                        loss_weight / (float)numel * grad_scale, (const TdrStepGuard*)nullptr, dpred, part);
     hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, st, part, blocks, (double)loss_weight / (double)numel, loss);
     TDR_LAUNCH_CHECK("l1_loss");
+    return TDR_OK;
+}
+
+extern "C" int tdr_pixel_loss(int kind, const float* pred, const float* target, int N, int64_t chw, int64_t hw, float loss_weight,
+                              float eps, float grad_scale, const TdrStepGuard* guard, float* loss, float* dpred, float* ws,
+                              void* stream) {
+    TDR_REQUIRE(pred && target && loss && dpred && ws, "tdr_pixel_loss: null pointer");
+    TDR_REQUIRE(kind >= 0 && kind <= 4 && N > 0 && chw > 0 && hw > 0 && chw % hw == 0, "tdr_pixel_loss: bad kind / shape");
+    TDR_REQUIRE(kind != 4 || chw == 3 * hw, "tdr_pixel_loss: PSNRLoss toY needs 3 channels");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t numel = (int64_t)N * chw;
+    double* part = reinterpret_cast<double*>(ws);
+    if (kind <= 2) {
+        const int blocks = grid1d(numel, L1_BLOCKS);
+        // CharbonnierLoss ignores its loss_weight (losses/losses.py:114-122)
+        const float w = kind == 2 ? 1.f : loss_weight;
+        const float gs = w / (float)numel * grad_scale;
+        if (kind == 0) hipLaunchKernelGGL(l1_kernel, dim3(blocks), dim3(256), 0, st, pred, target, (long)numel, gs, guard, dpred, part);
+        else if (kind == 1) hipLaunchKernelGGL(pixloss_kernel<1>, dim3(blocks), dim3(256), 0, st, pred, target, (long)numel, gs, 0.f, guard, dpred, part);
+        else hipLaunchKernelGGL(pixloss_kernel<2>, dim3(blocks), dim3(256), 0, st, pred, target, (long)numel, gs, eps * eps, guard, dpred, part);
+        hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, st, part, blocks, (double)w / (double)numel, loss);
+    } else {
+        TDR_REQUIRE(N <= 1024, "tdr_pixel_loss: PSNRLoss batch > 1024");
+        const int toY = kind == 4;
+        const double wscale = (double)loss_weight * (10.0 / log(10.0));
+        dim3 grid(PSNR_BLOCKS, N);
+        hipLaunchKernelGGL(psnr_sum_kernel, grid, dim3(256), 0, st, pred, target, (long)chw, (long)hw, toY, part);
+        hipLaunchKernelGGL(psnr_grad_kernel, grid, dim3(256), 0, st, pred, target, (long)chw, (long)hw, toY, N,
+                           (float)wscale * grad_scale, guard, (const double*)part, dpred);
+        hipLaunchKernelGGL(psnr_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)part, N, (long)(toY ? hw : chw), wscale, loss);
+    }
+    TDR_LAUNCH_CHECK("pixel_loss");
     return TDR_OK;
 }
 

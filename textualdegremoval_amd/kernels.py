@@ -806,6 +806,22 @@ def l1_loss(pred, target, loss_weight=1.0, grad_scale=1.0, guard=None):
     return loss, dpred
 
 
+LOSS_L1, LOSS_MSE, LOSS_CHARBONNIER, LOSS_PSNR, LOSS_PSNR_Y = range(5)
+
+
+def pixel_loss(kind, pred, target, loss_weight=1.0, eps=1e-3, grad_scale=1.0, guard=None):
+    """pred / target [N,C,H,W] -> (loss [1], dpred): the criteria of losses/losses.py (LOSS_* kinds), mean reduction"""
+    assert pred.is_contiguous() and target.is_contiguous() and pred.shape == target.shape and pred.dim() == 4
+    N, Cc, H, W = pred.shape
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred)
+    ws = workspace(4096 + 128 * N, pred.device, 'l1')
+    check(_lib.load().tdr_pixel_loss(int(kind), pred.data_ptr(), target.data_ptr(), N, Cc * H * W, H * W, float(loss_weight), float(eps),
+                                     float(grad_scale), guard.data_ptr() if guard is not None else None, loss.data_ptr(),
+                                     dpred.data_ptr(), ws.data_ptr(), _stream()), 'tdr_pixel_loss')
+    return loss, dpred
+
+
 # ------------------------------------------------------------------ MASA
 def lr_blocks_fwd(feat, py, px, ky, kx):
     N, Cc, H, W = feat.shape

@@ -1,6 +1,6 @@
-"""Pixel losses with the reference's names (losses/losses.py:26-122).  L1Loss -- the
-loss every shipped YAML selects -- runs on the HIP kernel (fwd value + gradient in
-one pass); the other criteria are thin torch expressions kept for config parity."""
+"""Pixel losses with the reference's names (losses/losses.py:26-122).  On the device every criterion with mean reduction is
+the HIP kernel tdr_pixel_loss (value + gradient in one pass); `step_kind()` tells the train step which one to fuse.  The
+torch expressions below serve host tensors and the weighted / 'none' / 'sum' variants no shipped YAML selects."""
 import numpy as np
 import torch
 from torch import nn
@@ -10,17 +10,21 @@ from .. import kernels as K
 _reduction_modes = ['none', 'mean', 'sum']
 
 
-class _L1Fn(torch.autograd.Function):
+class _PixFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, loss_weight):
-        loss, dpred = K.l1_loss(pred.contiguous(), target.contiguous(), loss_weight)
+    def forward(ctx, pred, target, kind, loss_weight, eps):
+        loss, dpred = K.pixel_loss(kind, pred.contiguous(), target.contiguous(), loss_weight, eps)
         ctx.save_for_backward(dpred)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return dpred * g, None, None
+        return dpred * g, None, None, None, None
+
+
+def _on_device(pred, target):
+    return pred.is_cuda and pred.dim() == 4 and pred.dtype == torch.float32 and target.dtype == torch.float32
 
 
 class L1Loss(nn.Module):
@@ -32,8 +36,8 @@ class L1Loss(nn.Module):
         self.reduction = reduction
 
     def forward(self, pred, target, weight=None, **kwargs):
-        if pred.is_cuda and weight is None and self.reduction == 'mean':
-            return _L1Fn.apply(pred, target, float(self.loss_weight))
+        if _on_device(pred, target) and weight is None and self.reduction == 'mean':
+            return _PixFn.apply(pred, target, K.LOSS_L1, float(self.loss_weight), 0.0)
         d = (pred - target).abs()
         if weight is not None:
             d = d * weight
@@ -42,6 +46,9 @@ class L1Loss(nn.Module):
         elif self.reduction == 'sum':
             d = d.sum()
         return self.loss_weight * d
+
+    def step_kind(self):
+        return (K.LOSS_L1, float(self.loss_weight), 0.0) if self.reduction == 'mean' else None
 
 
 class MSELoss(nn.Module):
@@ -53,9 +60,19 @@ class MSELoss(nn.Module):
         self.reduction = reduction
 
     def forward(self, pred, target, weight=None, **kwargs):
+        if _on_device(pred, target) and weight is None and self.reduction == 'mean':
+            return _PixFn.apply(pred, target, K.LOSS_MSE, float(self.loss_weight), 0.0)
         d = (pred - target) ** 2
-        d = d.mean() if self.reduction == 'mean' else (d.sum() if self.reduction == 'sum' else d)
+        if weight is not None:
+            d = d * weight
+        if self.reduction == 'mean':
+            d = d.mean() if weight is None else d.sum() / weight.sum().clamp_min(1e-12)
+        elif self.reduction == 'sum':
+            d = d.sum()
         return self.loss_weight * d
+
+    def step_kind(self):
+        return (K.LOSS_MSE, float(self.loss_weight), 0.0) if self.reduction == 'mean' else None
 
 
 class PSNRLoss(nn.Module):
@@ -64,7 +81,13 @@ class PSNRLoss(nn.Module):
         assert reduction == 'mean'
         self.loss_weight, self.scale, self.toY = loss_weight, 10 / np.log(10), toY
 
+    def step_kind(self):
+        return (K.LOSS_PSNR_Y if self.toY else K.LOSS_PSNR, float(self.loss_weight), 0.0)
+
     def forward(self, pred, target):
+        assert len(pred.size()) == 4
+        if _on_device(pred, target) and (not self.toY or pred.shape[1] == 3):
+            return _PixFn.apply(pred, target, *self.step_kind())
         if self.toY:
             coef = torch.tensor([65.481, 128.553, 24.966], device=pred.device).reshape(1, 3, 1, 1)
             pred = ((pred * coef).sum(dim=1, keepdim=True) + 16.) / 255.
@@ -76,7 +99,13 @@ class CharbonnierLoss(nn.Module):
     def __init__(self, loss_weight=1.0, reduction='mean', eps=1e-3):
         super().__init__()
         self.eps = eps
+        self.loss_weight, self.reduction = loss_weight, reduction      # stored for the step; the value ignores both (reference :114-122)
+
+    def step_kind(self):
+        return (K.LOSS_CHARBONNIER, 1.0, float(self.eps))
 
     def forward(self, x, y):
+        if _on_device(x, y):
+            return _PixFn.apply(x, y, *self.step_kind())
         diff = x - y
         return torch.mean(torch.sqrt(diff * diff + self.eps * self.eps))

@@ -133,10 +133,10 @@ class RefGuidedImageCleanModel(BaseModel):
         return ref_in
 
     def optimize_parameters(self, current_iter):
-        fused = self.device.type == 'cuda' and isinstance(self.cri_pix, loss_module.L1Loss) and \
-            self.cri_pix.reduction == 'mean' and isinstance(self.optimizer_g, FusedClipAdamW)
+        kind = self.cri_pix.step_kind() if hasattr(self.cri_pix, 'step_kind') else None
+        fused = self.device.type == 'cuda' and kind is not None and isinstance(self.optimizer_g, FusedClipAdamW)
         if not fused:
-            raise NotImplementedError('HIP step needs a GPU, pixel_opt.type == L1Loss (the YAML default) and the fused optimiser')
+            raise NotImplementedError('HIP step needs a GPU, a mean-reduced pixel criterion of losses/ and the fused optimiser')
         # reference :205-212: while current_iter < fix_iterations the "masa" parameters get requires_grad_(False) -- and,
         # as written there, nothing ever turns them back on (the `else` belongs to `param_fix_iters is not None`).  A
         # frozen tensor has grad None: clip_grad_norm_ and AdamW (decay included) skip it.  Here: param group 1 frozen.
@@ -236,7 +236,7 @@ class RefGuidedImageCleanModel(BaseModel):
         prev_plan = K.set_pack_plan(self._pack_plan)
         prev_scaled = K.GRAD_SCALED
         try:
-            lw = float(self.cri_pix.loss_weight)
+            kind, lw, eps = self.cri_pix.step_kind()
             # exact (power-of-two) loss scale for the fp16-split data-gradient kernels: dpred = S*lw/numel ~ 2^9, which puts
             # max|g| of every gradient operand of the step between ~2^-1 and 2^10 (profiles/grad_range_survey.py)
             # The scale lives in the optimiser's device-resident StepGuard: a non-finite gradient norm (an operand left the
@@ -244,8 +244,9 @@ class RefGuidedImageCleanModel(BaseModel):
             gs = 1.0
             if K.fp16_path() and os.environ.get('TDR_GRAD_SCALE', '1') == '1' and lw > 0 and \
                     not getattr(self, '_bwd_full_range', False):
+                # PSNRLoss: dpred ~ lw*(10/ln10)*2d / (N*CHW*mse_n), ~2^8 above an L1 gradient at d ~ 0.1: start lower
                 gs = 2.0 ** (math.floor(math.log2(512.0 * lq.shape[0] * 3 * lq.shape[2] * lq.shape[3] / lw)) +
-                             getattr(self, '_scale_shift', 0))
+                             getattr(self, '_scale_shift', 0) - (8 if kind in (K.LOSS_PSNR, K.LOSS_PSNR_Y) else 0))
             K.set_grad_scaled(gs != 1.0)
             guard = self.optimizer_g.ensure_guard(lq.device)
             if not torch.cuda.is_current_stream_capturing():
@@ -255,7 +256,7 @@ class RefGuidedImageCleanModel(BaseModel):
             eng = getattr(net, 'engine', E)    # RestormerRefFusion carries restormer_engine
             out, saved = eng.net_fwd(P, net.cfg, lq, ref_in)
             self.output = out
-            loss, dpred = K.l1_loss(out.contiguous(), gt.contiguous(), lw, guard=guard)
+            loss, dpred = K.pixel_loss(kind, out.contiguous(), gt.contiguous(), lw, eps, guard=guard)
             sink = self.grad_reducer.begin(defer_collectives=defer_collectives)
             K.BACKWARD_PHASE = True
             try:
