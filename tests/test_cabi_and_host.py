@@ -67,6 +67,11 @@ def test_registry_and_step_api_error_behaviour():
     with pytest.raises(ValueError):                      # nf != width (concat widths)
         define_network(dict(type='NAFNetRefFusion', width=8, nf=16, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
                             reffusion_n_blocks=[1] * 5))
+    r7 = str(np.load(os.path.join(GOLDEN, 'reference_defects.npz'))['r7_nafnetlocal_reffusion'])
+    assert r7.startswith('TypeError')                    # what the reference does (make_golden_defects.py) ...
+    with pytest.raises(TypeError, match='ref'):          # ... and the same here: TLSC wrapper of the guided NAFNet, defect R7
+        define_network(dict(type='NAFNetLocal_RefFusion', width=8, nf=8, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
+                            reffusion_n_blocks=[1] * 5))
     with pytest.raises(IndexError):                      # reference quirk R2: needs len(enc)+1 fusion counts
         define_network(dict(type='NAFNetRefFusion', width=8, nf=8, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
                             reffusion_n_blocks=[1] * 4))

@@ -216,3 +216,14 @@ class NAFNetRefFusion(_NAFBase):
     def forward(self, inp, ref):
         names, params = _named(self)
         return _NetFn.apply(inp, ref, names, self.cfg, *params)
+
+
+class NAFNetLocal_RefFusion(NAFNetRefFusion):
+    """The reference's TLSC test-time wrapper of the guided NAFNet (network_nafnet_guided_arch.py:743-753) cannot be
+    constructed there: Local_Base.convert (nafnet_local_arch.py:99-104) runs `self.forward(imgs)` with one argument, and the
+    guided forward needs (inp, ref) -- defect R7, recorded by tests/golden/make_golden_defects.py.  Same error here."""
+
+    def __init__(self, *args, train_size=(1, 3, 256, 256), fast_imp=False, **kwargs):
+        raise TypeError("NAFNetRefFusion.forward() missing 1 required positional argument: 'ref' "
+                        "(NAFNetLocal_RefFusion cannot be constructed in the reference either: defect R7)")
+
