@@ -72,6 +72,11 @@ def test_registry_and_step_api_error_behaviour():
     with pytest.raises(TypeError, match='ref'):          # ... and the same here: TLSC wrapper of the guided NAFNet, defect R7
         define_network(dict(type='NAFNetLocal_RefFusion', width=8, nf=8, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
                             reffusion_n_blocks=[1] * 5))
+    r8 = [str(v) for v in np.load(os.path.join(GOLDEN, 'reference_defects.npz'))['r8_sfnet_reffusion']]
+    assert all(v.startswith('RuntimeError') for v in r8)         # the reference's SFNet-ref never completes a forward (R8)
+    sf = define_network(dict(type='SFNetRefFusion', mode='train', num_res=2, nf=32))
+    with pytest.raises(RuntimeError, match='R8'):
+        sf(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
     with pytest.raises(IndexError):                      # reference quirk R2: needs len(enc)+1 fusion counts
         define_network(dict(type='NAFNetRefFusion', width=8, nf=8, enc_blk_nums=[1] * 4, dec_blk_nums=[1] * 4,
                             reffusion_n_blocks=[1] * 4))
