@@ -279,7 +279,15 @@ def psnr_case():
 if __name__ == '__main__':
     torch.set_num_threads(8)
     arch = import_ref_arch()
-    only_net = len(sys.argv) > 1 and sys.argv[1] in ('net', 'refsize')
+    only_net = len(sys.argv) > 1 and sys.argv[1] in ('net', 'refsize', 'yaml64')
+    if len(sys.argv) > 1 and sys.argv[1] == 'yaml64':
+        # the widths of the one shipped NAFNet YAML (002_nafnet_single_image_motion_deblurring.yml:45-61: width = nf = 64,
+        # enc [1,1,1,28], dec [1,1,1,1], ext [4,4,4,4]); the deep stack cut to 3 blocks, and reffusion_n_blocks given the five
+        # entries the class needs (the YAML's four raise IndexError, quirk R2).  Channels reach 2048 in the middle fusion block.
+        y64 = O.default_cfg(width=64, nf=64, enc_blk_nums=[1, 1, 1, 3], dec_blk_nums=[1, 1, 1, 1], middle_blk_num=1,
+                            ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 1])
+        whole_net_case(arch, 'net_yaml_w64_128', y64, 1, 128, 128, seed=12)
+        sys.exit(0)
     small = O.default_cfg(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
     # ref of another size than lq (validation / inference: the full generated reference against any lq,
     # image_restoration_ref_model.py:286-330): block diameter follows the ref size (:606-607)

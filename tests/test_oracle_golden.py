@@ -90,6 +90,9 @@ CASES = [('net_w8_128_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reff
          ('net_w8_256_b2', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_w8_120x100_pad', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_cfg1_w16_128', dict(width=16, nf=16, ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2])),
+         # the shipped NAFNet YAML's widths (width = nf = 64: up to 2048 channels in the middle fusion block), make_golden.py yaml64
+         ('net_yaml_w64_128', dict(width=64, nf=64, enc_blk_nums=[1, 1, 1, 3], dec_blk_nums=[1, 1, 1, 1], middle_blk_num=1,
+                                   ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 1])),
          # ref of another size than lq (validation / inference, image_restoration_ref_model.py:286-330)
          ('net_w8_256_ref384', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
          ('net_w8_128_ref256_wrap', dict(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])),
