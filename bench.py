@@ -327,8 +327,9 @@ def main():
                            'accumulate) with the loss-scaled backward pass -- REDUCED precision, the "fp16 MFMA" arithmetic of BASELINE '
                            'configs[4]; not the headline arithmetic',
                      'f32': 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)'}[K.MATH],
-            'config': {'workload': ('BASELINE configs[1]: NAFNet-width32 enc[1,1,1,28] + ref fusion [2,2,2,2,2], '
-                                    f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'
+            'config': {'workload': ((('BASELINE configs[1]: ' if is_cfg2 else '') +
+                                     f"NAFNet-width{a.width} enc{str(enc).replace(' ', '')} + ref fusion [2,2,2,2,2], " +
+                                     f'{a.size}x{a.size} color denoise sigma=15, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW')
                                     if a.arch == 'nafnet' else
                                     ('BASELINE configs[2] per-GPU workload: Restormer-ref dim48 blocks[4,6,6,8] refine4 heads[1,2,4,8] '
                                      f'fusion[2,2,2,2], {a.size}x{a.size} synthetic pairs, bs={a.batch}/GPU, fwd+L1+bwd+clip+AdamW'

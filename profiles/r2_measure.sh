@@ -14,8 +14,10 @@ python bench.py --arch restormer --size 512 --batch 2 --no-cpu-baseline --no-f32
 TDR_MATH=h1 python bench.py --arch restormer --size 512 --batch 2 --no-cpu-baseline --no-f32-exact --no-roofline > gpurun_out/r2m/bench_restormer_cfg5_h1.log 2>&1
 python bench.py --arch promptir --no-cpu-baseline --no-f32-exact --no-roofline > gpurun_out/r2m/bench_promptir_384_bs8.log 2>&1
 python bench.py --arch drsformer --no-cpu-baseline --no-f32-exact --no-roofline > gpurun_out/r2m/bench_drsformer_256_bs8.log 2>&1
+python bench.py --arch drsformer_mefc --no-cpu-baseline --no-f32-exact --no-roofline > gpurun_out/r2m/bench_drsformer_mefc_256_bs8.log 2>&1
+python bench.py --width 64 --size 384 --batch 8 --no-cpu-baseline --no-f32-exact --no-roofline > gpurun_out/r2m/bench_nafnet_yaml_w64_384_bs8.log 2>&1
 python bench.py --dino-ref-size 640 --no-cpu-baseline --no-f32-exact --no-roofline > gpurun_out/r2m/bench_dino640.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r2m/smoke.log 2>&1
 python -m pytest tests -q -m gpu 2>&1 | tail -12 > gpurun_out/r2m/pytest_gpu.log
-for f in bench_default bench_restormer_cfg3 bench_restormer_cfg5 bench_restormer_cfg5_h1 bench_promptir_384_bs8 bench_drsformer_256_bs8 bench_dino640; do echo "$f: $(tail -1 gpurun_out/r2m/$f.log | cut -c1-170)"; done
+for f in bench_default bench_restormer_cfg3 bench_restormer_cfg5 bench_restormer_cfg5_h1 bench_promptir_384_bs8 bench_drsformer_256_bs8 bench_drsformer_mefc_256_bs8 bench_nafnet_yaml_w64_384_bs8 bench_dino640; do echo "$f: $(tail -1 gpurun_out/r2m/$f.log | cut -c1-170)"; done
 tail -1 gpurun_out/r2m/smoke.log; tail -2 gpurun_out/r2m/pytest_gpu.log; head -2 gpurun_out/r2m/rocprofv3_kernel_summary_steps.txt
