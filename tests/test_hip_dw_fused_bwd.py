@@ -1,0 +1,87 @@
+"""One-pass backward of the depthwise 3x3 stencils (csrc/tdr_dwsg.hip dwsg_bwd_fused_kernel: SimpleGate of NAFNet-ref,
+network_nafnet_guided_arch.py:170-187; GDFN gate and qkv_dwconv of Restormer-ref, network_restormer_guided_arch.py:236-260)
+against a torch fp32 autograd reference of the same op and against the two-pass kernels (TDR_DWSG_TWO_PASS=1), on shapes
+that exercise every neighbour path: rows inside one wave, several row strips per wave, rows spanning 2 / 4 waves (LDS edge
+exchange), widths that are not a power of two, heights that are not a multiple of the strip length."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 6, 64, 64), (1, 4, 37, 96), (2, 3, 130, 256), (1, 5, 100, 384), (1, 4, 70, 512), (1, 2, 40, 1024),
+          (1, 3, 9, 8), (2, 2, 256, 128), (1, 2, 33, 1028)]      # the last one is wider than one column block: two-pass kernels
+
+
+def _ref(kind, t, w, b, dg):
+    t = t.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    b = None if b is None else b.clone().requires_grad_(True)
+    u = F.conv2d(t, w, b, padding=1, groups=t.shape[1])
+    c = t.shape[1] // 2
+    if kind == 'mul':
+        g = u[:, :c] * u[:, c:]
+    elif kind == 'gelu':
+        g = F.gelu(u[:, :c]) * u[:, c:]
+    else:
+        g = u
+    g.backward(dg)
+    return t.grad, w.grad, None if b is None else b.grad
+
+
+def _run(kind, K, dg, t, w, b, dgb=None):
+    if kind == 'mul':
+        return K.dwsg_bwd(dg, t, w, b, dgb, 0.5) if dgb is not None else K.dwsg_bwd(dg, t, w, b)
+    if kind == 'gelu':
+        return K.dwgelu_bwd(dg, t, w, b)
+    return K.dwconv_bwd(dg, t, w, want_db=True)
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('kind', ['mul', 'gelu', 'none'])
+def test_one_pass_backward_matches_autograd_and_two_pass(kind, shape):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    t = torch.randn(N, 2 * C, H, W, generator=g).cuda()
+    w = (torch.randn(2 * C, 1, 3, 3, generator=g) * 0.4).cuda()
+    b = (torch.randn(2 * C, generator=g) * 0.2).cuda() if kind != 'none' else None
+    dg = torch.randn(N, C if kind != 'none' else 2 * C, H, W, generator=g).cuda()
+    want = _ref(kind, t, w, b, dg)
+    got = _run(kind, K, dg, t, w, b)
+    os.environ['TDR_DWSG_TWO_PASS'] = '1'
+    try:
+        two = _run(kind, K, dg, t, w, b)
+    finally:
+        os.environ.pop('TDR_DWSG_TWO_PASS')
+    scale = [1.0, (H * W * N) ** 0.5, (H * W * N) ** 0.5]
+    for i, (a, r, s2) in enumerate(zip(got, want, two)):
+        if r is None:
+            continue
+        tol = 2e-5 * scale[i] * max(1.0, float(r.abs().max()) / scale[i])
+        assert float((a.view_as(r) - r).abs().max()) < tol, (i, float((a.view_as(r) - r).abs().max()), tol)
+        assert float((a - s2).abs().max()) < tol, ('two-pass', i)
+    # dt is computed with the same arithmetic in both versions
+    assert torch.equal(got[0], two[0]) or float((got[0] - two[0]).abs().max()) < 1e-5
+
+
+def test_one_pass_backward_with_pooled_gradient_bias():
+    """the SCA branch's pooled gradient enters as a per-plane constant on dg (engine.naf_bwd)"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    N, C, H, W = 2, 8, 48, 512
+    g = torch.Generator().manual_seed(3)
+    t = torch.randn(N, 2 * C, H, W, generator=g).cuda()
+    w = (torch.randn(2 * C, 1, 3, 3, generator=g) * 0.4).cuda()
+    b = (torch.randn(2 * C, generator=g) * 0.2).cuda()
+    dg = torch.randn(N, C, H, W, generator=g).cuda()
+    dgb = torch.randn(N, C, generator=g).cuda()
+    want = _ref('mul', t, w, b, dg + 0.5 * dgb[:, :, None, None])
+    got = _run('mul', K, dg, t, w, b, dgb)
+    assert float((got[0] - want[0]).abs().max()) < 5e-5
+    assert float((got[1].view_as(want[1]) - want[1]).abs().max()) < 2e-5 * (H * W * N) ** 0.5 * 4

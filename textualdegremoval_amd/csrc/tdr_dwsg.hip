@@ -15,6 +15,7 @@
 //   GATE_GELU : GDFN gate  g = gelu(dw1(t1)) * dw2(t2)  (:236-239, erf GELU), no pooling
 //   GATE_NONE : the plain depthwise conv of MDTA's qkv_dwconv (:254,260): planes handled in pairs (c, c+C),
 //               FWD writes both filtered planes, DU only accumulates dW/db from dout (nothing to recompute)
+#include <stdlib.h>
 #include "tdr_common.h"
 #include "../../include/tdr.h"
 
@@ -23,9 +24,34 @@ namespace {
 enum { MODE_FWD = 0, MODE_DU = 1, MODE_DT = 2 };
 enum { GATE_MUL = 0, GATE_GELU = 1, GATE_NONE = 2 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// erf in fp32 with < 1 ulp error (two minimax polynomials, one exp: N. Juffa's erff; checked against scipy over [-6, 6] at
+// 3 * 10^-6 spacing: 0.974 ulp).  The library erff costs ~100 FMAs and several exps per value, which made the GDFN kernels
+// VALU-bound (profiles/README.md, round 2); both branches are evaluated and selected, no divergence.
+__device__ __forceinline__ float erf_1ulp(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_1ulp(x * 0.70710678118654752f)); }
+// value and derivative from one erf
+__device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
+    const float h = 0.5f * (1.0f + erf_1ulp(x * 0.70710678118654752f));
+    g = x * h;
+    dg = h + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
 struct DwArgs {
@@ -57,6 +83,30 @@ __device__ __forceinline__ Row6 fetch_row(const float* __restrict__ plane, int y
     if (!right_lane) r = (rok && x0 + 4 < W) ? row[x0 + 4] : 0.f;
     Row6 o;
     o.v[0] = l; o.v[1] = m[0]; o.v[2] = m[1]; o.v[3] = m[2]; o.v[4] = m[3]; o.v[5] = r;
+    return o;
+}
+
+// fetch_row in two halves, so that a row can be requested one loop iteration before its neighbours are exchanged
+struct RawRow { f32x4 m; float le, re; };
+__device__ __forceinline__ RawRow load_raw(const float* __restrict__ plane, int y, int x0, int H, int W, bool active,
+                                           bool left_lane, bool right_lane) {
+    RawRow r;
+    r.m = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.le = 0.f; r.re = 0.f;
+    if (active && y >= 0 && y < H) {
+        const float* row = plane + (long)y * W;
+        r.m = *reinterpret_cast<const f32x4*>(row + x0);
+        if (!left_lane && x0 > 0) r.le = row[x0 - 1];
+        if (!right_lane && x0 + 4 < W) r.re = row[x0 + 4];
+    }
+    return r;
+}
+__device__ __forceinline__ Row6 finish_row(const RawRow& r, bool left_lane, bool right_lane) {
+    float l = __shfl_up(r.m[3], 1, 64), rr = __shfl_down(r.m[0], 1, 64);
+    if (!left_lane) l = r.le;
+    if (!right_lane) rr = r.re;
+    Row6 o;
+    o.v[0] = l; o.v[1] = r.m[0]; o.v[2] = r.m[1]; o.v[3] = r.m[2]; o.v[4] = r.m[3]; o.v[5] = rr;
     return o;
 }
 
@@ -139,8 +189,10 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (GATE == GATE_GELU) {
-                        d1[e] = gv[e] * o2[e] * gelu_erf_grad(o1[e]);
-                        d2[e] = gv[e] * gelu_erf(o1[e]);
+                        float gl, gd;
+                        gelu_erf_both(o1[e], gl, gd);
+                        d1[e] = gv[e] * o2[e] * gd;
+                        d2[e] = gv[e] * gl;
                     } else {
                         d1[e] = gv[e] * o2[e];
                         d2[e] = gv[e] * o1[e];
@@ -201,6 +253,195 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
     }
 }
 
+// Backward in ONE pass (one column block, W <= 1024: a strip's horizontal neighbour is in its wave, in the next wave of the
+// same workgroup, or outside the image).
+// A thread still owns a 4-column strip and walks rows, now with two register windows: three rows of t (to recompute u and to
+// accumulate dW) and three rows of du = d(loss)/d(u).  Row y of du is produced from the t window and the dg row, exchanged with
+// the neighbouring lanes by DPP shuffles, and row y-1 of dt = dw^T(du) leaves from the du window -- du never exists in memory
+// (the two-pass version writes and re-reads 2c planes).  A strip recomputes the du row above and below its rpt rows.
+// GATE_NONE (plain depthwise conv): du IS dout, so its window is fetched like t and the kernel serves any width.
+template <int GATE>
+__global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
+    __shared__ float red[4][20];
+    __shared__ float edge[2][4][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int c = blockIdx.y, n = blockIdx.z, C = a.C, H = a.H, W = a.W;
+    const int TPRW = 1 << a.tprw_log2;
+    const int cg = tid & (TPRW - 1), strip = tid >> a.tprw_log2;
+    const int bx = blockIdx.x % a.ncb, by = blockIdx.x / a.ncb;
+    const int x0 = (bx * TPRW + cg) * 4;
+    const int ybeg = (by * (256 >> a.tprw_log2) + strip) * a.rpt;
+    const bool active = x0 < W && ybeg < H;
+    const bool left_lane = lane != 0 && cg != 0;
+    const bool right_lane = lane != 63 && cg != TPRW - 1;
+    const long HW = (long)H * W;
+    const float* p1 = a.a + ((long)n * 2 * C + c) * HW;
+    const float* p2 = p1 + (long)C * HW;
+    const float* q1 = GATE == GATE_NONE ? a.dg + ((long)n * 2 * C + c) * HW : a.dg + ((long)n * C + c) * HW;
+    const float* q2 = q1 + (long)C * HW;                      // GATE_NONE only
+    float w1[9], w2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        w1[i] = a.w[c * 9 + i];
+        w2[i] = a.w[(c + C) * 9 + i];
+    }
+    const float b1 = a.b ? a.b[c] : 0.f, b2 = a.b ? a.b[c + C] : 0.f;
+    float dgb = 0.f;
+    if (GATE == GATE_MUL && a.dgb) dgb = a.dgb[(long)n * C + c] * a.dgb_mul;
+    float acc[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) acc[i] = 0.f;
+
+    Row6 t1[3], t2[3], e1[3], e2[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { e1[0].v[k] = e1[1].v[k] = e2[0].v[k] = e2[1].v[k] = 0.f; }
+    t1[0] = fetch_row(p1, ybeg - 2, x0, H, W, active, left_lane, right_lane);
+    t2[0] = fetch_row(p2, ybeg - 2, x0, H, W, active, left_lane, right_lane);
+    t1[1] = fetch_row(p1, ybeg - 1, x0, H, W, active, left_lane, right_lane);
+    t2[1] = fetch_row(p2, ybeg - 1, x0, H, W, active, left_lane, right_lane);
+    // software pipeline: the rows of iteration i+1 are requested before iteration i computes (3 waves / SIMD do not hide
+    // the latency of a load that is consumed in the iteration that issues it)
+    constexpr bool PF = true;
+    RawRow n1, n2, m1, m2;
+    f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+    if (PF) {
+        n1 = load_raw(p1, ybeg, x0, H, W, active, left_lane, right_lane);
+        n2 = load_raw(p2, ybeg, x0, H, W, active, left_lane, right_lane);
+        if (GATE == GATE_NONE) {
+            m1 = load_raw(q1, ybeg - 1, x0, H, W, active, left_lane, right_lane);
+            m2 = load_raw(q2, ybeg - 1, x0, H, W, active, left_lane, right_lane);
+        } else if (active && ybeg - 1 >= 0) {
+            gn = *reinterpret_cast<const f32x4*>(q1 + (long)(ybeg - 1) * W + x0);
+        }
+    }
+    for (int i = 0; i < a.rpt + 2; ++i) {
+        const int y = ybeg - 1 + i;                              // the du row of this iteration
+        f32x4 gv = gn;
+        if (PF) {
+            t1[2] = finish_row(n1, left_lane, right_lane);
+            t2[2] = finish_row(n2, left_lane, right_lane);
+            if (GATE == GATE_NONE) {
+                e1[2] = finish_row(m1, left_lane, right_lane);
+                e2[2] = finish_row(m2, left_lane, right_lane);
+            }
+            const bool more = active && i <= a.rpt;             // nothing is consumed after the last iteration
+            n1 = load_raw(p1, y + 2, x0, H, W, more, left_lane, right_lane);
+            n2 = load_raw(p2, y + 2, x0, H, W, more, left_lane, right_lane);
+            if (GATE == GATE_NONE) {
+                m1 = load_raw(q1, y + 1, x0, H, W, more, left_lane, right_lane);
+                m2 = load_raw(q2, y + 1, x0, H, W, more, left_lane, right_lane);
+            } else {
+                gn = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (more && y + 1 >= 0 && y + 1 < H) gn = *reinterpret_cast<const f32x4*>(q1 + (long)(y + 1) * W + x0);
+            }
+        } else {
+            t1[2] = fetch_row(p1, y + 1, x0, H, W, active, left_lane, right_lane);
+            t2[2] = fetch_row(p2, y + 1, x0, H, W, active, left_lane, right_lane);
+            gv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (active && y >= 0 && y < H) gv = *reinterpret_cast<const f32x4*>(q1 + (long)y * W + x0);
+        }
+        const bool in_img = active && y >= 0 && y < H;
+        if (GATE != GATE_NONE) {
+            float o1[4] = {b1, b1, b1, b1}, o2[4] = {b2, b2, b2, b2};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o1[e] += w1[ky * 3 + kx] * t1[ky].v[e + kx];
+                        o2[e] += w2[ky * 3 + kx] * t2[ky].v[e + kx];
+                    }
+            if (GATE == GATE_MUL && in_img) gv += dgb;
+            float d1[4], d2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (GATE == GATE_GELU) {
+                    float gl, gd;
+                    gelu_erf_both(o1[e], gl, gd);
+                    d1[e] = gv[e] * o2[e] * gd;
+                    d2[e] = gv[e] * gl;
+                } else {
+                    d1[e] = gv[e] * o2[e];
+                    d2[e] = gv[e] * o1[e];
+                }
+                if (!in_img) { d1[e] = 0.f; d2[e] = 0.f; }         // (gv = 0 already; keeps NaN/Inf of the recomputation out)
+            }
+            float l1 = __shfl_up(d1[3], 1, 64), r1 = __shfl_down(d1[0], 1, 64);
+            float l2 = __shfl_up(d2[3], 1, 64), r2 = __shfl_down(d2[0], 1, 64);
+            if (!left_lane) { l1 = 0.f; l2 = 0.f; }                 // no lane to the left: image border, or ...
+            if (!right_lane) { r1 = 0.f; r2 = 0.f; }
+            if (TPRW > 64) {                                        // ... a row spans 2 / 4 waves: their edge values go through LDS
+                const int wv = tid >> 6, par = i & 1;               // (one barrier per row; parity double-buffers the slots)
+                if (lane == 0) { edge[par][wv][0] = d1[0]; edge[par][wv][1] = d2[0]; }
+                if (lane == 63) { edge[par][wv][2] = d1[3]; edge[par][wv][3] = d2[3]; }
+                __syncthreads();
+                if (lane == 0 && cg != 0) { l1 = edge[par][wv - 1][2]; l2 = edge[par][wv - 1][3]; }
+                if (lane == 63 && cg != TPRW - 1) { r1 = edge[par][wv + 1][0]; r2 = edge[par][wv + 1][1]; }
+            }
+            e1[2].v[0] = l1; e1[2].v[5] = r1; e2[2].v[0] = l2; e2[2].v[5] = r2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { e1[2].v[e + 1] = d1[e]; e2[2].v[e + 1] = d2[e]; }
+        }
+        if (i >= 1 && i <= a.rpt && in_img) {                       // parameter gradients: the strip's own rows only
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[ky * 3 + kx] += e1[2].v[e + 1] * t1[ky].v[e + kx];
+                        acc[10 + ky * 3 + kx] += e2[2].v[e + 1] * t2[ky].v[e + kx];
+                    }
+            acc[9] += (e1[2].v[1] + e1[2].v[2]) + (e1[2].v[3] + e1[2].v[4]);
+            acc[19] += (e2[2].v[1] + e2[2].v[2]) + (e2[2].v[3] + e2[2].v[4]);
+        }
+        if (i >= 2) {                                               // dt row y-1 = transposed conv of the du window
+            const int yo = y - 1;
+            float o1[4] = {0.f, 0.f, 0.f, 0.f}, o2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o1[e] += w1[8 - (ky * 3 + kx)] * e1[ky].v[e + kx];
+                        o2[e] += w2[8 - (ky * 3 + kx)] * e2[ky].v[e + kx];
+                    }
+            if (active && yo < H) {
+                const f32x4 v1 = {o1[0], o1[1], o1[2], o1[3]}, v2 = {o2[0], o2[1], o2[2], o2[3]};
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)yo * W + x0) = v1;
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)yo * W + x0) = v2;
+            }
+        }
+        t1[0] = t1[1]; t1[1] = t1[2];
+        t2[0] = t2[1]; t2[1] = t2[2];
+        e1[0] = e1[1]; e1[1] = e1[2];
+        e2[0] = e2[1]; e2[1] = e2[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0) red[tid >> 6][i] = s;
+    }
+    __syncthreads();
+    if (tid < 20)
+        a.part[(((long)n * C + c) * gridDim.x + blockIdx.x) * 20 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// dw[ch][9], db[ch] from part[N][C][nb][20] (ch < C: first half of a pair, ch >= C: second half); fixed summation order
+__global__ void dw_param_finish_kernel(const float* __restrict__ part, int N, int C, int nb, float* __restrict__ dw,
+                                       float* __restrict__ db) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    if (tid >= 20) return;
+    float sacc = 0.f;
+    for (int m = 0; m < N; ++m)
+        for (int g = 0; g < nb; ++g) sacc += part[(((long)m * C + c) * nb + g) * 20 + tid];
+    const int ch = tid < 10 ? c : c + C, kk = tid % 10;
+    if (kk < 9) dw[ch * 9 + kk] = sacc;
+    else if (db) db[ch] = sacc;
+}
+
 __global__ void dw_pool_finish_kernel(const float* __restrict__ part, int NC, int nb, float inv_hw, float* __restrict__ pooled) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NC) return;
@@ -225,6 +466,34 @@ DwGeom dw_geom(int H, int W) {
     g.nby = tdr_cdiv(H, spb * rpt);
     g.nb = g.ncb * g.nby;
     return g;
+}
+
+// one-pass backward: longer strips (the two recomputed du rows amortise over rpt), one column block
+DwGeom dw_geom_fused(int H, int W) {
+    DwGeom g = dw_geom(H, W);
+    const int spb = 256 >> g.tprw_log2;
+    int rpt = tdr_cdiv(H, spb);
+    if (rpt > 16) rpt = 16;
+    if (rpt < 1) rpt = 1;
+    g.rpt = rpt;
+    g.nby = tdr_cdiv(H, spb * rpt);
+    g.nb = g.ncb * g.nby;
+    return g;
+}
+
+bool dw_two_pass() {                                     // TDR_DWSG_TWO_PASS=1: the round-1 two-pass backward (A/B tests)
+    const char* e = getenv("TDR_DWSG_TWO_PASS");
+    return e && e[0] == '1';
+}
+
+template <int GATE>
+int dw_bwd_fused(const float* t, const float* dg, const float* dg_bias, float dg_bias_mul, const float* w, const float* b, int N,
+                 int C, int H, int W, float* dt, float* dw, float* db, float* ws, hipStream_t st) {
+    const DwGeom q = dw_geom_fused(H, W);
+    DwArgs a{t, dg, w, b, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul};
+    hipLaunchKernelGGL((dwsg_bwd_fused_kernel<GATE>), dim3(q.nb, C, N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, st, ws, N, C, q.nb, dw, db);
+    return 0;
 }
 
 }  // namespace
@@ -265,6 +534,11 @@ extern "C" int tdr_dwsg_bwd_biased(const float* dg, const float* dg_bias, float 
     TDR_REQUIRE(dg && t && w && b && dt && dw && db && ws, "tdr_dwsg_bwd: null pointer");
     TDR_REQUIRE(W % 4 == 0, "tdr_dwsg_bwd: W must be a multiple of 4 (got %d)", W);
     hipStream_t st = (hipStream_t)stream;
+    if (W <= 1024 && !dw_two_pass()) {
+        dw_bwd_fused<GATE_MUL>(t, dg, dg_bias, dg_bias_mul, w, b, N, C, H, W, dt, dw, db, ws, st);
+        TDR_LAUNCH_CHECK("dwsg_bwd_fused");
+        return TDR_OK;
+    }
     const DwGeom q = dw_geom(H, W);
     float* part = ws;
     float* du = ws + (int64_t)N * C * q.nb * 20;
@@ -294,6 +568,11 @@ extern "C" int tdr_dwgelu_bwd(const float* dg, const float* t, const float* w, c
     TDR_REQUIRE(dg && t && w && dt && dw && ws, "tdr_dwgelu_bwd: null pointer");
     TDR_REQUIRE(W % 4 == 0, "tdr_dwgelu_bwd: W must be a multiple of 4 (got %d)", W);
     hipStream_t st = (hipStream_t)stream;
+    if (W <= 1024 && !dw_two_pass()) {
+        dw_bwd_fused<GATE_GELU>(t, dg, nullptr, 0.f, w, b, N, C, H, W, dt, dw, db, ws, st);
+        TDR_LAUNCH_CHECK("dwgelu_bwd_fused");
+        return TDR_OK;
+    }
     const DwGeom q = dw_geom(H, W);
     float* part = ws;
     float* du = ws + (int64_t)N * C * q.nb * 20;
@@ -325,6 +604,11 @@ extern "C" int tdr_dwconv_bwd(const float* dout, const float* t, const float* w,
     TDR_REQUIRE(W % 4 == 0 && planes % 2 == 0, "tdr_dwconv_bwd: W %% 4 and planes %% 2 must be 0 (got %d, %d)", W, planes);
     hipStream_t st = (hipStream_t)stream;
     const int C = planes / 2;
+    if (!dw_two_pass()) {
+        dw_bwd_fused<GATE_NONE>(t, dout, nullptr, 0.f, w, nullptr, N, C, H, W, dt, dw, db, ws, st);
+        TDR_LAUNCH_CHECK("dwconv_bwd_fused");
+        return TDR_OK;
+    }
     const DwGeom q = dw_geom(H, W);
     DwArgs a1{t, dout, w, nullptr, nullptr, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DU, GATE_NONE>), dim3(q.nb, C, N), dim3(256), 0, st, a1);
