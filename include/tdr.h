@@ -194,6 +194,12 @@ int tdr_dwconv_fwd(const float* t, const float* w, const float* b, int N, int pl
 /* dout -> dt = dw^T(dout), dw [planes,9], db [planes]; ws >= tdr_dwsg_ws_floats(N,planes/2,H,W) */
 int tdr_dwconv_bwd(const float* dout, const float* t, const float* w, int N, int planes, int H, int W, float* dt,
                    float* dw, float* db, float* ws, void* stream);
+/* the same pair with a trailing ReLU (DRSformer-ref MSFN, network_drsformer_guided_arch.py:226-253: relu(dwconv3x3(x))):
+ * relu != 0 clamps the forward output; act (the saved forward output, may be NULL) masks dout in the backward. */
+int tdr_dwconv_act_fwd(const float* t, const float* w, const float* b, int N, int planes, int H, int W, int relu, float* out,
+                       void* stream);
+int tdr_dwconv_act_bwd(const float* dout, const float* act, const float* t, const float* w, int N, int planes, int H, int W,
+                       float* dt, float* dw, float* db, float* ws, void* stream);
 
 /* ---- Restormer-ref MDTA core (:246-277), per image and head over CHANNEL tokens (c = C/heads <= 192).
  * The pixel contractions run on tdr_conv_wgrad (per_image Gram q k^T) and tdr_conv_forward (1x1, per-image weights);

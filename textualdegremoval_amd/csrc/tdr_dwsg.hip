@@ -67,6 +67,7 @@ struct DwArgs {
     float* pdb;          //     the parameter-gradient finish rides on the second pass instead of its own launch
     const float* dgb;    // DU (GATE_MUL): optional [N][C] plane constant added to dg, times dgb_mul
     float dgb_mul;
+    const float* act;    // GATE_NONE: ReLU after the conv -- FWD: any non-null value; one-pass backward: the saved output [N][2C][H][W]
 };
 
 struct Row6 { float v[6]; };
@@ -160,6 +161,10 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
                     o2[e] += w2[ky * 3 + kx] * r2[ky].v[e + kx];
                 }
         if (MODE == MODE_FWD && GATE == GATE_NONE) {
+            if (a.act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o1[e] = fmaxf(o1[e], 0.f); o2[e] = fmaxf(o2[e], 0.f); }
+            }
             if (live) {
                 const f32x4 q1 = {o1[0], o1[1], o1[2], o1[3]}, q2 = {o2[0], o2[1], o2[2], o2[3]};
                 *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)y * W + x0) = q1;
@@ -303,6 +308,15 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
     // the latency of a load that is consumed in the iteration that issues it)
     constexpr bool PF = true;
     RawRow n1, n2, m1, m2;
+    const float* r1p = (GATE == GATE_NONE && a.act) ? a.act + ((long)n * 2 * C + c) * HW : nullptr;   // ReLU outputs of the two planes
+    const float* r2p = r1p ? r1p + (long)C * HW : nullptr;
+    auto relu_mask = [&](RawRow& d, const float* plane, int y, bool on) {                              // d *= (act > 0)
+        const RawRow k = load_raw(plane, y, x0, H, W, on, left_lane, right_lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d.m[e] = k.m[e] > 0.f ? d.m[e] : 0.f;
+        d.le = k.le > 0.f ? d.le : 0.f;
+        d.re = k.re > 0.f ? d.re : 0.f;
+    };
     f32x4 gn = {0.f, 0.f, 0.f, 0.f};
     if (PF) {
         n1 = load_raw(p1, ybeg, x0, H, W, active, left_lane, right_lane);
@@ -310,6 +324,7 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
         if (GATE == GATE_NONE) {
             m1 = load_raw(q1, ybeg - 1, x0, H, W, active, left_lane, right_lane);
             m2 = load_raw(q2, ybeg - 1, x0, H, W, active, left_lane, right_lane);
+            if (r1p) { relu_mask(m1, r1p, ybeg - 1, active); relu_mask(m2, r2p, ybeg - 1, active); }
         } else if (active && ybeg - 1 >= 0) {
             gn = *reinterpret_cast<const f32x4*>(q1 + (long)(ybeg - 1) * W + x0);
         }
@@ -330,6 +345,7 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
             if (GATE == GATE_NONE) {
                 m1 = load_raw(q1, y + 1, x0, H, W, more, left_lane, right_lane);
                 m2 = load_raw(q2, y + 1, x0, H, W, more, left_lane, right_lane);
+                if (r1p) { relu_mask(m1, r1p, y + 1, more); relu_mask(m2, r2p, y + 1, more); }
             } else {
                 gn = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (more && y + 1 >= 0 && y + 1 < H) gn = *reinterpret_cast<const f32x4*>(q1 + (long)(y + 1) * W + x0);
@@ -472,8 +488,9 @@ DwGeom dw_geom(int H, int W) {
 DwGeom dw_geom_fused(int H, int W) {
     DwGeom g = dw_geom(H, W);
     const int spb = 256 >> g.tprw_log2;
+    static const int cap = getenv("TDR_DWF_RPT") ? atoi(getenv("TDR_DWF_RPT")) : 16;     // tuning aid
     int rpt = tdr_cdiv(H, spb);
-    if (rpt > 16) rpt = 16;
+    if (rpt > cap) rpt = cap;
     if (rpt < 1) rpt = 1;
     g.rpt = rpt;
     g.nby = tdr_cdiv(H, spb * rpt);
@@ -488,9 +505,9 @@ bool dw_two_pass() {                                     // TDR_DWSG_TWO_PASS=1:
 
 template <int GATE>
 int dw_bwd_fused(const float* t, const float* dg, const float* dg_bias, float dg_bias_mul, const float* w, const float* b, int N,
-                 int C, int H, int W, float* dt, float* dw, float* db, float* ws, hipStream_t st) {
+                 int C, int H, int W, float* dt, float* dw, float* db, float* ws, hipStream_t st, const float* act = nullptr) {
     const DwGeom q = dw_geom_fused(H, W);
-    DwArgs a{t, dg, w, b, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul};
+    DwArgs a{t, dg, w, b, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul, act};
     hipLaunchKernelGGL((dwsg_bwd_fused_kernel<GATE>), dim3(q.nb, C, N), dim3(256), 0, st, a);
     hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, st, ws, N, C, q.nb, dw, db);
     return 0;
@@ -585,13 +602,19 @@ extern "C" int tdr_dwgelu_bwd(const float* dg, const float* t, const float* w, c
     return TDR_OK;
 }
 
-// planes = 2*C (even); out[n][p] = dw_p * t[n][p] (+ b[p])
+// planes = 2*C (even); out[n][p] = dw_p * t[n][p] (+ b[p]), then ReLU if relu != 0
 extern "C" int tdr_dwconv_fwd(const float* t, const float* w, const float* b, int N, int planes, int H, int W, float* out,
                               void* stream) {
+    return tdr_dwconv_act_fwd(t, w, b, N, planes, H, W, 0, out, stream);
+}
+
+extern "C" int tdr_dwconv_act_fwd(const float* t, const float* w, const float* b, int N, int planes, int H, int W, int relu,
+                                  float* out, void* stream) {
     TDR_REQUIRE(t && w && out, "tdr_dwconv_fwd: null pointer");
     TDR_REQUIRE(W % 4 == 0 && planes % 2 == 0, "tdr_dwconv_fwd: W %% 4 and planes %% 2 must be 0 (got %d, %d)", W, planes);
     const DwGeom q = dw_geom(H, W);
-    DwArgs a{t, nullptr, w, b, out, nullptr, planes / 2, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f};
+    DwArgs a{t, nullptr, w, b, out, nullptr, planes / 2, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, nullptr, 0.f,
+             relu ? out : nullptr};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_NONE>), dim3(q.nb, planes / 2, N), dim3(256), 0, (hipStream_t)stream, a);
     TDR_LAUNCH_CHECK("dwconv_fwd");
     return TDR_OK;
@@ -600,12 +623,19 @@ extern "C" int tdr_dwconv_fwd(const float* t, const float* w, const float* b, in
 // dt = dw^T(dout); dw[p][9] = sum dout[p] * shifted t[p]; db[p] = sum dout[p] (db may be NULL).  ws >= tdr_dwsg_ws_floats(N, planes/2, H, W)
 extern "C" int tdr_dwconv_bwd(const float* dout, const float* t, const float* w, int N, int planes, int H, int W, float* dt,
                               float* dw, float* db, float* ws, void* stream) {
+    return tdr_dwconv_act_bwd(dout, nullptr, t, w, N, planes, H, W, dt, dw, db, ws, stream);
+}
+
+// act != NULL: the forward ended in a ReLU and act is its output -- dout is masked by act > 0 as it is read (one-pass kernel only)
+extern "C" int tdr_dwconv_act_bwd(const float* dout, const float* act, const float* t, const float* w, int N, int planes, int H,
+                                  int W, float* dt, float* dw, float* db, float* ws, void* stream) {
     TDR_REQUIRE(dout && t && w && dt && dw && ws, "tdr_dwconv_bwd: null pointer");
+    TDR_REQUIRE(!act || !dw_two_pass(), "tdr_dwconv_act_bwd: the ReLU mask needs the one-pass kernel (unset TDR_DWSG_TWO_PASS)");
     TDR_REQUIRE(W % 4 == 0 && planes % 2 == 0, "tdr_dwconv_bwd: W %% 4 and planes %% 2 must be 0 (got %d, %d)", W, planes);
     hipStream_t st = (hipStream_t)stream;
     const int C = planes / 2;
     if (!dw_two_pass()) {
-        dw_bwd_fused<GATE_NONE>(t, dout, nullptr, 0.f, w, nullptr, N, C, H, W, dt, dw, db, ws, st);
+        dw_bwd_fused<GATE_NONE>(t, dout, nullptr, 0.f, w, nullptr, N, C, H, W, dt, dw, db, ws, st, act);
         TDR_LAUNCH_CHECK("dwconv_bwd_fused");
         return TDR_OK;
     }
