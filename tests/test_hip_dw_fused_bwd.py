@@ -85,3 +85,42 @@ def test_one_pass_backward_with_pooled_gradient_bias():
     got = _run('mul', K, dg, t, w, b, dgb)
     assert float((got[0] - want[0]).abs().max()) < 5e-5
     assert float((got[1].view_as(want[1]) - want[1]).abs().max()) < 2e-5 * (H * W * N) ** 0.5 * 4
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 64, 64), (1, 4, 37, 96), (1, 5, 100, 384), (1, 4, 70, 512), (1, 2, 40, 1024)])
+@pytest.mark.parametrize('mult,relu,bias', [(1, True, True), (1, False, False), (2, True, True), (2, True, False), (2, False, True)])
+def test_msfn_depthwise_3x3_on_the_stencils(shape, mult, relu, bias):
+    """DRSformer-ref MSFN (network_drsformer_guided_arch.py:226-253): relu(dwconv3x3(x)) with one (groups = channels) or two
+    (groups = channels / 2) inputs per output, through kernels.dwk_fwd / dwk_bwd, which route K = 3 to tdr_dwsg.hip"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    N, C, H, W = shape
+    Cout = 2 * C
+    g = torch.Generator().manual_seed(H + W + mult)
+    x = torch.randn(N, Cout * mult, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, mult, 3, 3, generator=g) * 0.4).cuda()
+    b = (torch.randn(Cout, generator=g) * 0.3).cuda() if bias else None
+    dy = torch.randn(N, Cout, H, W, generator=g).cuda()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, padding=1, groups=Cout)
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(dy)
+    y = K.dwk_fwd(x, w, b, relu=relu)
+    assert float((y - yr).abs().max()) < 2e-5
+    dx, dw, db = K.dwk_bwd(dy, y if relu else None, x, w, want_db=bias)
+    assert float((dx - xr.grad).abs().max()) < 5e-5
+    s = (N * H * W) ** 0.5
+    assert float((dw - wr.grad).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)
+    if bias:
+        assert float((db - br.grad).abs().max()) < 2e-5 * s * max(1.0, float(br.grad.abs().max()) / s)
+    os.environ['TDR_DWK_GENERIC'] = '1'              # the LDS-tiled generic kernels of tdr_dwk.hip agree
+    try:
+        y2 = K.dwk_fwd(x, w, b, relu=relu)
+        dx2, dw2, _ = K.dwk_bwd(dy, y2 if relu else None, x, w, want_db=bias)
+    finally:
+        os.environ.pop('TDR_DWK_GENERIC')
+    assert float((y - y2).abs().max()) < 2e-5 and float((dx - dx2).abs().max()) < 5e-5
+    assert float((dw - dw2).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)

@@ -15,6 +15,9 @@
 //   GATE_GELU : GDFN gate  g = gelu(dw1(t1)) * dw2(t2)  (:236-239, erf GELU), no pooling
 //   GATE_NONE : the plain depthwise conv of MDTA's qkv_dwconv (:254,260): planes handled in pairs (c, c+C),
 //               FWD writes both filtered planes, DU only accumulates dW/db from dout (nothing to recompute)
+//   GATE_SUM  : grouped conv with two inputs per output (DRSformer-ref MSFN dwconv3x3_1, network_drsformer_guided_arch.py:
+//               231-232): out[c] = relu?(dw(t[2c]) + dw(t[2c+1]) + b[c]) -- the pair is (2c, 2c+1) instead of (c, c+C); forward
+//               and one-pass backward only
 #include <stdlib.h>
 #include "tdr_common.h"
 #include "../../include/tdr.h"
@@ -22,7 +25,7 @@
 namespace {
 
 enum { MODE_FWD = 0, MODE_DU = 1, MODE_DT = 2 };
-enum { GATE_MUL = 0, GATE_GELU = 1, GATE_NONE = 2 };
+enum { GATE_MUL = 0, GATE_GELU = 1, GATE_NONE = 2, GATE_SUM = 3 };
 
 // erf in fp32 with < 1 ulp error (two minimax polynomials, one exp: N. Juffa's erff; checked against scipy over [-6, 6] at
 // 3 * 10^-6 spacing: 0.974 ulp).  The library erff costs ~100 FMAs and several exps per value, which made the GDFN kernels
@@ -126,16 +129,18 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
     const bool left_lane = lane != 0 && cg != 0;
     const bool right_lane = lane != 63 && cg != TPRW - 1;
     const long HW = (long)H * W;
-    const float* p1 = a.a + ((long)n * 2 * C + c) * HW;
-    const float* p2 = p1 + (long)C * HW;
+    const int pl1 = GATE == GATE_SUM ? 2 * c : c, pl2 = GATE == GATE_SUM ? 2 * c + 1 : c + C;     // the two planes of this block
+    const float* p1 = a.a + ((long)n * 2 * C + pl1) * HW;
+    const float* p2 = a.a + ((long)n * 2 * C + pl2) * HW;
     float w1[9], w2[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int k = MODE == MODE_DT ? 8 - i : i;           // transposed conv = correlation with flipped taps
-        w1[i] = a.w[c * 9 + k];
-        w2[i] = a.w[(c + C) * 9 + k];
+        w1[i] = a.w[pl1 * 9 + k];
+        w2[i] = a.w[pl2 * 9 + k];
     }
-    const float b1 = (MODE == MODE_DT || !a.b) ? 0.f : a.b[c], b2 = (MODE == MODE_DT || !a.b) ? 0.f : a.b[c + C];
+    const float b1 = (MODE == MODE_DT || !a.b) ? 0.f : a.b[c];
+    const float b2 = (MODE == MODE_DT || !a.b || GATE == GATE_SUM) ? 0.f : a.b[c + C];
     float acc[MODE == MODE_DU ? 20 : 1];
 #pragma unroll
     for (int i = 0; i < (MODE == MODE_DU ? 20 : 1); ++i) acc[i] = 0.f;
@@ -170,6 +175,11 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
                 *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)y * W + x0) = q1;
                 *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)y * W + x0) = q2;
             }
+        } else if (MODE == MODE_FWD && GATE == GATE_SUM) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = a.act ? fmaxf(o1[e] + o2[e], 0.f) : o1[e] + o2[e];
+            if (live) *reinterpret_cast<f32x4*>(a.out + ((long)n * C + c) * HW + (long)y * W + x0) = o;
         } else if (MODE == MODE_FWD) {
             f32x4 o;
 #pragma unroll
@@ -280,17 +290,19 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
     const bool left_lane = lane != 0 && cg != 0;
     const bool right_lane = lane != 63 && cg != TPRW - 1;
     const long HW = (long)H * W;
-    const float* p1 = a.a + ((long)n * 2 * C + c) * HW;
-    const float* p2 = p1 + (long)C * HW;
+    constexpr bool DIRECT = GATE == GATE_NONE || GATE == GATE_SUM;       // du is (masked) dout: nothing to recompute
+    const int pl1 = GATE == GATE_SUM ? 2 * c : c, pl2 = GATE == GATE_SUM ? 2 * c + 1 : c + C;
+    const float* p1 = a.a + ((long)n * 2 * C + pl1) * HW;
+    const float* p2 = a.a + ((long)n * 2 * C + pl2) * HW;
     const float* q1 = GATE == GATE_NONE ? a.dg + ((long)n * 2 * C + c) * HW : a.dg + ((long)n * C + c) * HW;
     const float* q2 = q1 + (long)C * HW;                      // GATE_NONE only
     float w1[9], w2[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        w1[i] = a.w[c * 9 + i];
-        w2[i] = a.w[(c + C) * 9 + i];
+        w1[i] = a.w[pl1 * 9 + i];
+        w2[i] = a.w[pl2 * 9 + i];
     }
-    const float b1 = a.b ? a.b[c] : 0.f, b2 = a.b ? a.b[c + C] : 0.f;
+    const float b1 = a.b ? a.b[c] : 0.f, b2 = (a.b && !DIRECT) ? a.b[c + C] : 0.f;
     float dgb = 0.f;
     if (GATE == GATE_MUL && a.dgb) dgb = a.dgb[(long)n * C + c] * a.dgb_mul;
     float acc[20];
@@ -308,8 +320,8 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
     // the latency of a load that is consumed in the iteration that issues it)
     constexpr bool PF = true;
     RawRow n1, n2, m1, m2;
-    const float* r1p = (GATE == GATE_NONE && a.act) ? a.act + ((long)n * 2 * C + c) * HW : nullptr;   // ReLU outputs of the two planes
-    const float* r2p = r1p ? r1p + (long)C * HW : nullptr;
+    const float* r1p = (DIRECT && a.act) ? a.act + ((long)n * (GATE == GATE_SUM ? 1 : 2) * C + c) * HW : nullptr;   // ReLU outputs
+    const float* r2p = r1p ? r1p + (long)C * HW : nullptr;                                                        // (GATE_NONE: two planes)
     auto relu_mask = [&](RawRow& d, const float* plane, int y, bool on) {                              // d *= (act > 0)
         const RawRow k = load_raw(plane, y, x0, H, W, on, left_lane, right_lane);
 #pragma unroll
@@ -321,10 +333,13 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
     if (PF) {
         n1 = load_raw(p1, ybeg, x0, H, W, active, left_lane, right_lane);
         n2 = load_raw(p2, ybeg, x0, H, W, active, left_lane, right_lane);
-        if (GATE == GATE_NONE) {
+        if (DIRECT) {
             m1 = load_raw(q1, ybeg - 1, x0, H, W, active, left_lane, right_lane);
-            m2 = load_raw(q2, ybeg - 1, x0, H, W, active, left_lane, right_lane);
-            if (r1p) { relu_mask(m1, r1p, ybeg - 1, active); relu_mask(m2, r2p, ybeg - 1, active); }
+            if (r1p) relu_mask(m1, r1p, ybeg - 1, active);
+            if (GATE == GATE_NONE) {
+                m2 = load_raw(q2, ybeg - 1, x0, H, W, active, left_lane, right_lane);
+                if (r1p) relu_mask(m2, r2p, ybeg - 1, active);
+            }
         } else if (active && ybeg - 1 >= 0) {
             gn = *reinterpret_cast<const f32x4*>(q1 + (long)(ybeg - 1) * W + x0);
         }
@@ -335,17 +350,20 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
         if (PF) {
             t1[2] = finish_row(n1, left_lane, right_lane);
             t2[2] = finish_row(n2, left_lane, right_lane);
-            if (GATE == GATE_NONE) {
+            if (DIRECT) {
                 e1[2] = finish_row(m1, left_lane, right_lane);
-                e2[2] = finish_row(m2, left_lane, right_lane);
+                e2[2] = GATE == GATE_NONE ? finish_row(m2, left_lane, right_lane) : e1[2];
             }
             const bool more = active && i <= a.rpt;             // nothing is consumed after the last iteration
             n1 = load_raw(p1, y + 2, x0, H, W, more, left_lane, right_lane);
             n2 = load_raw(p2, y + 2, x0, H, W, more, left_lane, right_lane);
-            if (GATE == GATE_NONE) {
+            if (DIRECT) {
                 m1 = load_raw(q1, y + 1, x0, H, W, more, left_lane, right_lane);
-                m2 = load_raw(q2, y + 1, x0, H, W, more, left_lane, right_lane);
-                if (r1p) { relu_mask(m1, r1p, y + 1, more); relu_mask(m2, r2p, y + 1, more); }
+                if (r1p) relu_mask(m1, r1p, y + 1, more);
+                if (GATE == GATE_NONE) {
+                    m2 = load_raw(q2, y + 1, x0, H, W, more, left_lane, right_lane);
+                    if (r1p) relu_mask(m2, r2p, y + 1, more);
+                }
             } else {
                 gn = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (more && y + 1 >= 0 && y + 1 < H) gn = *reinterpret_cast<const f32x4*>(q1 + (long)(y + 1) * W + x0);
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
             if (active && y >= 0 && y < H) gv = *reinterpret_cast<const f32x4*>(q1 + (long)y * W + x0);
         }
         const bool in_img = active && y >= 0 && y < H;
-        if (GATE != GATE_NONE) {
+        if (!DIRECT) {
             float o1[4] = {b1, b1, b1, b1}, o2[4] = {b2, b2, b2, b2};
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -426,8 +444,8 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
                     }
             if (active && yo < H) {
                 const f32x4 v1 = {o1[0], o1[1], o1[2], o1[3]}, v2 = {o2[0], o2[1], o2[2], o2[3]};
-                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)yo * W + x0) = v1;
-                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)yo * W + x0) = v2;
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + pl1) * HW + (long)yo * W + x0) = v1;
+                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + pl2) * HW + (long)yo * W + x0) = v2;
             }
         }
         t1[0] = t1[1]; t1[1] = t1[2];
@@ -447,13 +465,19 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
 
 // dw[ch][9], db[ch] from part[N][C][nb][20] (ch < C: first half of a pair, ch >= C: second half); fixed summation order
 __global__ void dw_param_finish_kernel(const float* __restrict__ part, int N, int C, int nb, float* __restrict__ dw,
-                                       float* __restrict__ db) {
+                                       float* __restrict__ db, int sum_pairs) {
     const int c = blockIdx.x, tid = threadIdx.x;
     if (tid >= 20) return;
     float sacc = 0.f;
     for (int m = 0; m < N; ++m)
         for (int g = 0; g < nb; ++g) sacc += part[(((long)m * C + c) * nb + g) * 20 + tid];
-    const int ch = tid < 10 ? c : c + C, kk = tid % 10;
+    const int kk = tid % 10;
+    if (sum_pairs) {                                     // GATE_SUM: planes (2c, 2c+1) share the output channel c and its bias
+        if (kk < 9) dw[(2 * c + (tid >= 10)) * 9 + kk] = sacc;
+        else if (db && tid == 9) db[c] = sacc;
+        return;
+    }
+    const int ch = tid < 10 ? c : c + C;
     if (kk < 9) dw[ch * 9 + kk] = sacc;
     else if (db) db[ch] = sacc;
 }
@@ -509,7 +533,7 @@ int dw_bwd_fused(const float* t, const float* dg, const float* dg_bias, float dg
     const DwGeom q = dw_geom_fused(H, W);
     DwArgs a{t, dg, w, b, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul, act};
     hipLaunchKernelGGL((dwsg_bwd_fused_kernel<GATE>), dim3(q.nb, C, N), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, st, ws, N, C, q.nb, dw, db);
+    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, st, ws, N, C, q.nb, dw, db, GATE == GATE_SUM ? 1 : 0);
     return 0;
 }
 
@@ -645,5 +669,28 @@ extern "C" int tdr_dwconv_act_bwd(const float* dout, const float* act, const flo
     DwArgs a2{dout, nullptr, w, nullptr, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, dw, db};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_DT, GATE_MUL>), dim3(q.nb, C, N), dim3(256), 0, st, a2);
     TDR_LAUNCH_CHECK("dwconv_bwd");
+    return TDR_OK;
+}
+
+// ---- DRSformer-ref MSFN second stage: grouped 3x3 with two inputs per output.  t [N][2C][H][W], w [C][2][3][3], b [C] | NULL,
+// out [N][C][H][W] = relu?(sum of the two filtered planes + b).  Backward (one pass, W <= 1024): act = saved output | NULL.
+extern "C" int tdr_dwpair_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, int relu, float* out,
+                              void* stream) {
+    TDR_REQUIRE(t && w && out, "tdr_dwpair_fwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0, "tdr_dwpair_fwd: W must be a multiple of 4 (got %d)", W);
+    const DwGeom q = dw_geom(H, W);
+    DwArgs a{t, nullptr, w, b, out, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, nullptr, 0.f,
+             relu ? out : nullptr};
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_SUM>), dim3(q.nb, C, N), dim3(256), 0, (hipStream_t)stream, a);
+    TDR_LAUNCH_CHECK("dwpair_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_dwpair_bwd(const float* dout, const float* act, const float* t, const float* w, int N, int C, int H, int W,
+                              float* dt, float* dw, float* db, float* ws, void* stream) {
+    TDR_REQUIRE(dout && t && w && dt && dw && ws, "tdr_dwpair_bwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0 && W <= 1024, "tdr_dwpair_bwd: W must be a multiple of 4, at most 1024 (got %d)", W);
+    dw_bwd_fused<GATE_SUM>(t, dout, nullptr, 0.f, w, nullptr, N, C, H, W, dt, dw, db, ws, (hipStream_t)stream, act);
+    TDR_LAUNCH_CHECK("dwpair_bwd");
     return TDR_OK;
 }

@@ -1311,6 +1311,12 @@ def _dw3_plain(x, w, dil):
         os.environ.get('TDR_DWK_GENERIC', '0') != '1'
 
 
+def _dw3_pair(x, w, dil):
+    Cout, mult, Kk, _ = w.shape
+    return Kk == 3 and mult == 2 and dil == 1 and x.shape[-1] % 4 == 0 and x.is_contiguous() and \
+        os.environ.get('TDR_DWK_GENERIC', '0') != '1'
+
+
 def _DW_TWO_PASS():
     return os.environ.get('TDR_DWSG_TWO_PASS', '0') == '1'
 
@@ -1324,6 +1330,10 @@ def dwk_fwd(x, w, b=None, relu=False, dil=1):
     if _dw3_plain(x, w, dil):     # plain depthwise 3x3: the register-window stencil of tdr_dwsg.hip (plane pairs c, c + Cout/2)
         check(_lib.load().tdr_dwconv_act_fwd(x.data_ptr(), w.data_ptr(), _p(b), N, Cout, H, W, 1 if relu else 0, y.data_ptr(), _stream()),
               'tdr_dwconv_act_fwd')
+        return y
+    if _dw3_pair(x, w, dil):      # two inputs per output, 3x3: the same stencil with (2c, 2c+1) plane pairs
+        check(_lib.load().tdr_dwpair_fwd(x.data_ptr(), w.data_ptr(), _p(b), N, Cout, H, W, 1 if relu else 0, y.data_ptr(), _stream()),
+              'tdr_dwpair_fwd')
         return y
     check(_lib.load().tdr_dwk_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), _p(b), N, Cout, mult, H, W, Kk, int(dil), 1 if relu else 0,
                                   y.data_ptr(), _dense_nchw(y), _stream()), 'tdr_dwk_fwd')
@@ -1342,6 +1352,11 @@ def dwk_bwd(dy, y_act, x, w, want_db=False, dil=1):
         ws = workspace(lib.tdr_dwsg_ws_floats(N, Cout // 2, H, W), x.device)
         check(lib.tdr_dwconv_act_bwd(dy.data_ptr(), _p(y_act), x.data_ptr(), w.data_ptr(), N, Cout, H, W, dx.data_ptr(), dw.data_ptr(),
                                      _p(db), ws.data_ptr(), _stream()), 'tdr_dwconv_act_bwd')
+        return dx, dw, db
+    if _dw3_pair(x, w, dil) and dy.is_contiguous() and (y_act is None or y_act.is_contiguous()) and W <= 1024:
+        ws = workspace(lib.tdr_dwsg_ws_floats(N, Cout, H, W), x.device)
+        check(lib.tdr_dwpair_bwd(dy.data_ptr(), _p(y_act), x.data_ptr(), w.data_ptr(), N, Cout, H, W, dx.data_ptr(), dw.data_ptr(),
+                                 _p(db), ws.data_ptr(), _stream()), 'tdr_dwpair_bwd')
         return dx, dw, db
     ws = workspace(lib.tdr_dwk_bwd_ws_floats(N, Cout, mult, H, W, Kk), x.device, 'dwk')
     check(lib.tdr_dwk_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
