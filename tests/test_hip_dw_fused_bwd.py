@@ -89,9 +89,11 @@ def test_one_pass_backward_with_pooled_gradient_bias():
 
 @pytest.mark.parametrize('shape', [(2, 6, 64, 64), (1, 4, 37, 96), (1, 5, 100, 384), (1, 4, 70, 512), (1, 2, 40, 1024)])
 @pytest.mark.parametrize('mult,relu,bias', [(1, True, True), (1, False, False), (2, True, True), (2, True, False), (2, False, True)])
-def test_msfn_depthwise_3x3_on_the_stencils(shape, mult, relu, bias):
-    """DRSformer-ref MSFN (network_drsformer_guided_arch.py:226-253): relu(dwconv3x3(x)) with one (groups = channels) or two
-    (groups = channels / 2) inputs per output, through kernels.dwk_fwd / dwk_bwd, which route K = 3 to tdr_dwsg.hip"""
+@pytest.mark.parametrize('Kk', [3, 5])
+def test_msfn_depthwise_on_the_stencils(shape, mult, relu, bias, Kk):
+    """DRSformer-ref MSFN (network_drsformer_guided_arch.py:226-253): relu(dwconv3x3(x)) / relu(dwconv5x5(x)) with one (groups =
+    channels) or two (groups = channels / 2) inputs per output, through kernels.dwk_fwd / dwk_bwd: K = 3 runs on tdr_dwsg.hip,
+    the K = 5 backward on tdr_dwk.hip's one-pass kernel"""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from textualdegremoval_amd import kernels as K
@@ -99,12 +101,12 @@ def test_msfn_depthwise_3x3_on_the_stencils(shape, mult, relu, bias):
     Cout = 2 * C
     g = torch.Generator().manual_seed(H + W + mult)
     x = torch.randn(N, Cout * mult, H, W, generator=g).cuda()
-    w = (torch.randn(Cout, mult, 3, 3, generator=g) * 0.4).cuda()
+    w = (torch.randn(Cout, mult, Kk, Kk, generator=g) * (0.4 if Kk == 3 else 0.25)).cuda()
     b = (torch.randn(Cout, generator=g) * 0.3).cuda() if bias else None
     dy = torch.randn(N, Cout, H, W, generator=g).cuda()
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     br = b.clone().requires_grad_(True) if bias else None
-    yr = F.conv2d(xr, wr, br, padding=1, groups=Cout)
+    yr = F.conv2d(xr, wr, br, padding=Kk // 2, groups=Cout)
     if relu:
         yr = F.relu(yr)
     yr.backward(dy)
@@ -116,6 +118,8 @@ def test_msfn_depthwise_3x3_on_the_stencils(shape, mult, relu, bias):
     assert float((dw - wr.grad).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)
     if bias:
         assert float((db - br.grad).abs().max()) < 2e-5 * s * max(1.0, float(br.grad.abs().max()) / s)
+    if Kk != 3:
+        return
     os.environ['TDR_DWK_GENERIC'] = '1'              # the LDS-tiled generic kernels of tdr_dwk.hip agree
     try:
         y2 = K.dwk_fwd(x, w, b, relu=relu)

@@ -4,6 +4,7 @@
 //     y[n][c] = act( sum_{i < mult} w[c][i] (*) x[n][c * mult + i] )
 // HBM-bound stencils: each input plane goes through LDS once per launch (tile + halo); the weight gradient writes per-tile
 // partials that a second kernel sums in a fixed order (deterministic).
+#include <stdlib.h>
 #include "tdr_common.h"
 #include "../../include/tdr.h"
 
@@ -140,6 +141,124 @@ __global__ __launch_bounds__(256) void dwk_wgrad_tiled_kernel(const float* __res
     if (threadIdx.x <= KK) {
         const long slot = ((long)ci * gridDim.z + n) * gridDim.x + blockIdx.x;
         part[slot * (KK + 1) + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 5 x 5, dilation 1: data gradient and weight gradient in ONE pass over dy and x (the register-window scheme of tdr_dwsg.hip's
+// one-pass backward).  A thread owns a 4-column strip of one input plane and walks `rpt` rows with two 5-row windows (x and the
+// ReLU-masked dy) of 4 + 4 columns; the two columns either side come from the neighbouring lanes by DPP shuffles, or from memory
+// at wave / row-block edges.  Rows are requested one iteration ahead.  Per row: dx = w^T (*) dy from the dy window, dW += centre
+// dy row x the x window.  The tiled pair above reads dy twice and moves both operands through LDS; this reads each once.
+// ---------------------------------------------------------------------------------------------------------------
+struct Row8 { float v[8]; };
+struct Raw8 { f32x4 m; float l0, l1, r0, r1; };
+
+__device__ __forceinline__ Raw8 load_raw8(const float* __restrict__ plane, const float* __restrict__ maskp, int y, int x0, int H, int W,
+                                          bool on, bool left_lane, bool right_lane) {
+    Raw8 r;
+    r.m = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.l0 = r.l1 = r.r0 = r.r1 = 0.f;
+    if (on && y >= 0 && y < H) {
+        const float* row = plane + (long)y * W;
+        r.m = *reinterpret_cast<const f32x4*>(row + x0);
+        if (!left_lane && x0 >= 4) { r.l0 = row[x0 - 2]; r.l1 = row[x0 - 1]; }
+        if (!right_lane && x0 + 4 < W) { r.r0 = row[x0 + 4]; r.r1 = row[x0 + 5]; }          // W % 4 == 0: x0 + 5 < W too
+        if (maskp) {
+            const float* mr = maskp + (long)y * W;
+            const f32x4 k = *reinterpret_cast<const f32x4*>(mr + x0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r.m[e] = k[e] > 0.f ? r.m[e] : 0.f;
+            if (!left_lane && x0 >= 4) { r.l0 = mr[x0 - 2] > 0.f ? r.l0 : 0.f; r.l1 = mr[x0 - 1] > 0.f ? r.l1 : 0.f; }
+            if (!right_lane && x0 + 4 < W) { r.r0 = mr[x0 + 4] > 0.f ? r.r0 : 0.f; r.r1 = mr[x0 + 5] > 0.f ? r.r1 : 0.f; }
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ Row8 finish_row8(const Raw8& r, bool left_lane, bool right_lane) {
+    float l0 = __shfl_up(r.m[2], 1, 64), l1 = __shfl_up(r.m[3], 1, 64);
+    float r0 = __shfl_down(r.m[0], 1, 64), r1 = __shfl_down(r.m[1], 1, 64);
+    if (!left_lane) { l0 = r.l0; l1 = r.l1; }
+    if (!right_lane) { r0 = r.r0; r1 = r.r1; }
+    Row8 o;
+    o.v[0] = l0; o.v[1] = l1; o.v[2] = r.m[0]; o.v[3] = r.m[1]; o.v[4] = r.m[2]; o.v[5] = r.m[3]; o.v[6] = r0; o.v[7] = r1;
+    return o;
+}
+
+struct Dw5Args {
+    const float* dy; long dy_ns;
+    const float* yact; long y_ns;
+    const float* x; long x_ns;
+    const float* w;
+    float* dx; long dx_ns;
+    float* part;
+    int mult, H, W, tprw_log2, rpt, ncb;
+};
+
+__global__ __launch_bounds__(256) void dwk5_bwd_fused_kernel(Dw5Args a) {
+    constexpr int K = 5, R = 2, KK = 25;
+    __shared__ float red[4][KK + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pl = blockIdx.y, n = blockIdx.z, co = pl / a.mult, H = a.H, W = a.W;
+    const int TPRW = 1 << a.tprw_log2;
+    const int cg = tid & (TPRW - 1), strip = tid >> a.tprw_log2;
+    const int bx = blockIdx.x % a.ncb, by = blockIdx.x / a.ncb;
+    const int x0 = (bx * TPRW + cg) * 4;
+    const int ybeg = (by * (256 >> a.tprw_log2) + strip) * a.rpt;
+    const bool active = x0 < W && ybeg < H;
+    const bool left_lane = lane != 0 && cg != 0;
+    const bool right_lane = lane != 63 && cg != TPRW - 1;
+    const long HW = (long)H * W;
+    const float* xp = a.x + (long)n * a.x_ns + (long)pl * HW;
+    const float* dyp = a.dy + (long)n * a.dy_ns + (long)co * HW;
+    const float* mp = a.yact ? a.yact + (long)n * a.y_ns + (long)co * HW : nullptr;
+    float* dxp = a.dx + (long)n * a.dx_ns + (long)pl * HW;
+    float w[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) w[i] = a.w[(long)pl * KK + i];
+    float acc[KK + 1];
+#pragma unroll
+    for (int i = 0; i <= KK; ++i) acc[i] = 0.f;
+
+    Row8 xw[K], gw[K];
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) {                            // rows ybeg - 2 .. ybeg + 1
+        xw[k] = finish_row8(load_raw8(xp, nullptr, ybeg - R + k, x0, H, W, active, left_lane, right_lane), left_lane, right_lane);
+        gw[k] = finish_row8(load_raw8(dyp, mp, ybeg - R + k, x0, H, W, active, left_lane, right_lane), left_lane, right_lane);
+    }
+    Raw8 nx = load_raw8(xp, nullptr, ybeg + R, x0, H, W, active, left_lane, right_lane);
+    Raw8 ng = load_raw8(dyp, mp, ybeg + R, x0, H, W, active, left_lane, right_lane);
+    for (int i = 0; i < a.rpt; ++i) {
+        const int yc = ybeg + i;                                 // centre row of both windows
+        xw[K - 1] = finish_row8(nx, left_lane, right_lane);
+        gw[K - 1] = finish_row8(ng, left_lane, right_lane);
+        const bool more = active && i + 1 < a.rpt;
+        nx = load_raw8(xp, nullptr, yc + R + 1, x0, H, W, more, left_lane, right_lane);
+        ng = load_raw8(dyp, mp, yc + R + 1, x0, H, W, more, left_lane, right_lane);
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] += w[KK - 1 - (ky * K + kx)] * gw[ky].v[e + kx];                   // transposed conv: flipped taps
+                    acc[ky * K + kx] += gw[R].v[e + R] * xw[ky].v[e + kx];
+                }
+        acc[KK] += (gw[R].v[2] + gw[R].v[3]) + (gw[R].v[4] + gw[R].v[5]);
+        if (active && yc < H) *reinterpret_cast<f32x4*>(dxp + (long)yc * W + x0) = f32x4{o[0], o[1], o[2], o[3]};
+#pragma unroll
+        for (int k = 0; k < K - 1; ++k) { xw[k] = xw[k + 1]; gw[k] = gw[k + 1]; }
+    }
+#pragma unroll
+    for (int i = 0; i <= KK; ++i) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0) red[tid >> 6][i] = s;
+    }
+    __syncthreads();
+    if (tid <= KK) {
+        const long slot = ((long)pl * gridDim.z + n) * gridDim.x + blockIdx.x;
+        a.part[slot * (KK + 1) + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
 }
 
@@ -321,6 +440,24 @@ extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, in
                     (dil == 1 || (dil == 2 && K > 1)), "tdr_dwk_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int tiles_x = tdr_cdiv(W, TW_), tiles = tiles_x * tdr_cdiv(H, TH_);
+    static const bool tiled_only = getenv("TDR_DWK_TILED") != nullptr;                     // A/B aid: the two-kernel backward
+    if (K == 5 && dil == 1 && W % 4 == 0 && !tiled_only && ((dy_ns | y_ns | x_ns | dx_ns) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+          reinterpret_cast<uintptr_t>(yact)) & 15) == 0) {
+        int groups = W / 4, lg = 0;
+        while ((1 << lg) < groups && lg < 8) ++lg;
+        const int spb = 256 >> lg, ncb = tdr_cdiv(groups, 1 << lg);
+        int rpt = tdr_cdiv(H, spb);
+        if (rpt > 32) rpt = 32;
+        const int nb = ncb * tdr_cdiv(H, spb * rpt);
+        if (nb <= tiles) {                                                              // (the partials fit the tiled layout's scratch)
+            Dw5Args a{dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, w, dx, (long)dx_ns, ws, mult, H, W, lg, rpt, ncb};
+            hipLaunchKernelGGL(dwk5_bwd_fused_kernel, dim3(nb, Cout * mult, N), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(dwk_wgrad_finish_kernel, dim3(Cout * mult), dim3(256), 0, st, ws, N * nb, K * K, mult, dw, db);
+            TDR_LAUNCH_CHECK("dwk5_bwd_fused");
+            return TDR_OK;
+        }
+    }
 #define X(K_, D_)                                                                                                                          \
     if (K == K_ && dil == D_) {                                                                                                            \
         hipLaunchKernelGGL((dwk_tiled_kernel<K_, D_, true>), dim3(tiles, Cout, N), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, \
