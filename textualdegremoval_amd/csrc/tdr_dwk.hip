@@ -316,6 +316,48 @@ __global__ void avgpool3_kernel(const float* __restrict__ in, int H, int W, long
     }
 }
 
+// W % 4 == 0: a thread owns 4 adjacent outputs of one row -- three float4 rows + two edge values each instead of 36 scalar loads,
+// no per-element integer division (row sums first, then the three rows: rounding differs from the scalar kernel in the last bit).
+__global__ __launch_bounds__(256) void avgpool3_vec_kernel(const float* __restrict__ in, int H, int W, long planes, int adjoint,
+                                                          float* __restrict__ out) {
+    const int qpr = W >> 2;                                   // quads per row
+    const long quads = planes * H * qpr;
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+        const int qx = (int)(q % qpr);
+        const long row = q / qpr;
+        const int y = (int)(row % H), x0 = qx * 4;
+        const float* base = in + (row - y) * W;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            const float* r = base + (long)yy * W;
+            const f32x4 m = *reinterpret_cast<const f32x4*>(r + x0);
+            float v[6] = {x0 > 0 ? r[x0 - 1] : 0.f, m[0], m[1], m[2], m[3], x0 + 4 < W ? r[x0 + 4] : 0.f};
+            if (adjoint) {
+                const float cy = (float)(min(yy + 1, H - 1) - max(yy - 1, 0) + 1);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int xx = x0 - 1 + k;
+                    const int cx = min(xx + 1, W - 1) - max(xx - 1, 0) + 1;
+                    v[k] = (xx >= 0 && xx < W) ? v[k] / (cy * (float)cx) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += (v[e] + v[e + 1]) + v[e + 2];
+        }
+        if (!adjoint) {
+            const int cy = min(y + 1, H - 1) - max(y - 1, 0) + 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = x0 + e, cx = min(x + 1, W - 1) - max(x - 1, 0) + 1;
+                s[e] /= (float)(cy * cx);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + row * W + x0) = f32x4{s[0], s[1], s[2], s[3]};
+    }
+}
+
 // y[n][o] = act(b[o] + sum_i W[o][i] x[n][i]); one wave per output element
 __global__ __launch_bounds__(64) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                              const float* __restrict__ b, int Cin, int Cout, int relu,
@@ -394,7 +436,19 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const float* __restrict__
     const int n = blockIdx.y;
     const long per = (len + RD_BLOCKS - 1) / RD_BLOCKS, e0 = blockIdx.x * per, e1 = e0 + per < len ? e0 + per : len;
     float s = 0.f;
-    for (long e = e0 + threadIdx.x; e < e1; e += 256) s += a[n * a_ns + e] * b[n * b_ns + e];
+    const float* pa = a + n * a_ns;
+    const float* pb = b + n * b_ns;
+    if ((per & 3) == 0 && (((uintptr_t)pa | (uintptr_t)pb) & 15) == 0) {      // 16-byte path: 4 x fewer, independent loads
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (long e = e0 + threadIdx.x * 4L; e + 3 < e1; e += 1024) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(pa + e), v = *reinterpret_cast<const f32x4*>(pb + e);
+            acc += u * v;
+        }
+        s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        for (long e = e0 + ((e1 - e0) & ~3L) + threadIdx.x; e < e1; e += 256) s += pa[e] * pb[e];
+    } else {
+        for (long e = e0 + threadIdx.x; e < e1; e += 256) s += pa[e] * pb[e];
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -475,7 +529,10 @@ extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, in
 extern "C" int tdr_avgpool3(const float* in, int planes, int H, int W, int adjoint, float* out, void* stream) {
     TDR_REQUIRE(in && out && planes > 0 && H > 0 && W > 0, "tdr_avgpool3: bad argument");
     const long total = (long)planes * H * W;
-    hipLaunchKernelGGL(avgpool3_kernel, dim3(dgrid(total)), dim3(256), 0, (hipStream_t)stream, in, H, W, total, adjoint, out);
+    if (W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+        hipLaunchKernelGGL(avgpool3_vec_kernel, dim3(dgrid(total / 4)), dim3(256), 0, (hipStream_t)stream, in, H, W, (long)planes, adjoint, out);
+    else
+        hipLaunchKernelGGL(avgpool3_kernel, dim3(dgrid(total)), dim3(256), 0, (hipStream_t)stream, in, H, W, total, adjoint, out);
     TDR_LAUNCH_CHECK("avgpool3");
     return TDR_OK;
 }
