@@ -99,38 +99,46 @@ __global__ __launch_bounds__(256) void dwk_tiled_kernel(const float* __restrict_
 template <int K, int DIL>
 __global__ __launch_bounds__(256) void dwk_wgrad_tiled_kernel(const float* __restrict__ dy, long dy_ns, const float* __restrict__ yact,
                                                              long y_ns, const float* __restrict__ x, long x_ns, int mult, int H,
-                                                             int W, int tiles_x, float* __restrict__ part) {
+                                                             int W, int tiles_x, int tiles_y, int tpb, float* __restrict__ part) {
     constexpr int LW = TW_ + (K - 1) * DIL, KK = K * K;
     __shared__ float tile[(TW_ + (K - 1) * DIL) * (TH_ + (K - 1) * DIL)];
     __shared__ float red[4][KK + 1];
     const int ci = blockIdx.y, n = blockIdx.z, c = ci / mult;
-    const int ty0 = (blockIdx.x / tiles_x) * TH_, tx0 = (blockIdx.x % tiles_x) * TW_;
+    const int tx0 = (blockIdx.x % tiles_x) * TW_, tg = blockIdx.x / tiles_x;
     const int ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4;
     const long HW = (long)H * W;
-    load_tile<K, DIL>(tile, x + (long)n * x_ns + (long)ci * HW, nullptr, ty0, tx0, H, W);
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    const int y = ty0 + ly;
-    if (y < H) {
-        const float* gp = dy + (long)n * dy_ns + (long)c * HW + (long)y * W;
-        const float* ap = yact ? yact + (long)n * y_ns + (long)c * HW + (long)y * W : nullptr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int xx = tx0 + lx + j;
-            if (xx < W) g[j] = (!ap || ap[xx] > 0.f) ? gp[xx] : 0.f;
-        }
-    }
-    __syncthreads();
     float acc[KK + 1];
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-        float win[4 + (K - 1) * DIL];
+    for (int t = 0; t <= KK; ++t) acc[t] = 0.f;
+    // a workgroup walks `tpb` vertically adjacent tiles and reduces once: the K*K + 1 wave reductions per tile were most of the
+    // time of this kernel (K = 7: 568 us per launch at 8 x 48 x 256 x 256 with one tile per workgroup)
+    for (int tt = tg * tpb; tt < min(tiles_y, (tg + 1) * tpb); ++tt) {
+        const int ty0 = tt * TH_;
+        load_tile<K, DIL>(tile, x + (long)n * x_ns + (long)ci * HW, nullptr, ty0, tx0, H, W);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        const int y = ty0 + ly;
+        if (y < H) {
+            const float* gp = dy + (long)n * dy_ns + (long)c * HW + (long)y * W;
+            const float* ap = yact ? yact + (long)n * y_ns + (long)c * HW + (long)y * W : nullptr;
 #pragma unroll
-        for (int i = 0; i < 4 + (K - 1) * DIL; ++i) win[i] = tile[(ly + ky * DIL) * LW + lx + i];
+            for (int j = 0; j < 4; ++j) {
+                const int xx = tx0 + lx + j;
+                if (xx < W) g[j] = (!ap || ap[xx] > 0.f) ? gp[xx] : 0.f;
+            }
+        }
+        __syncthreads();
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx)
-            acc[ky * K + kx] = (g[0] * win[kx * DIL] + g[1] * win[kx * DIL + 1]) + (g[2] * win[kx * DIL + 2] + g[3] * win[kx * DIL + 3]);
+        for (int ky = 0; ky < K; ++ky) {
+            float win[4 + (K - 1) * DIL];
+#pragma unroll
+            for (int i = 0; i < 4 + (K - 1) * DIL; ++i) win[i] = tile[(ly + ky * DIL) * LW + lx + i];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+                acc[ky * K + kx] += (g[0] * win[kx * DIL] + g[1] * win[kx * DIL + 1]) + (g[2] * win[kx * DIL + 2] + g[3] * win[kx * DIL + 3]);
+        }
+        acc[KK] += (g[0] + g[1]) + (g[2] + g[3]);
+        __syncthreads();                                      // the tile is reloaded
     }
-    acc[KK] = (g[0] + g[1]) + (g[2] + g[3]);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t <= KK; ++t) {
@@ -493,7 +501,8 @@ extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, in
     TDR_REQUIRE(dy && x && w && dx && dw && ws && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7) &&
                     (dil == 1 || (dil == 2 && K > 1)), "tdr_dwk_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const int tiles_x = tdr_cdiv(W, TW_), tiles = tiles_x * tdr_cdiv(H, TH_);
+    const int tiles_x = tdr_cdiv(W, TW_), tiles_y = tdr_cdiv(H, TH_), tiles = tiles_x * tiles_y;
+    const int tpb = 8, wtiles = tiles_x * tdr_cdiv(tiles_y, tpb);                          // weight-gradient workgroups per plane
     static const bool tiled_only = getenv("TDR_DWK_TILED") != nullptr;                     // A/B aid: the two-kernel backward
     if (K == 5 && dil == 1 && W % 4 == 0 && !tiled_only && ((dy_ns | y_ns | x_ns | dx_ns) & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
@@ -516,12 +525,12 @@ extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, in
     if (K == K_ && dil == D_) {                                                                                                            \
         hipLaunchKernelGGL((dwk_tiled_kernel<K_, D_, true>), dim3(tiles, Cout, N), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, \
                            nullptr, Cout, mult, H, W, tiles_x, 0, dx, (long)dx_ns);                                                        \
-        hipLaunchKernelGGL((dwk_wgrad_tiled_kernel<K_, D_>), dim3(tiles, Cout * mult, N), dim3(256), 0, st, dy, (long)dy_ns, yact,         \
-                           (long)y_ns, x, (long)x_ns, mult, H, W, tiles_x, ws);                                                            \
+        hipLaunchKernelGGL((dwk_wgrad_tiled_kernel<K_, D_>), dim3(wtiles, Cout * mult, N), dim3(256), 0, st, dy, (long)dy_ns, yact,        \
+                           (long)y_ns, x, (long)x_ns, mult, H, W, tiles_x, tiles_y, tpb, ws);                                              \
     }
     DWK_CASES(X)
 #undef X
-    hipLaunchKernelGGL(dwk_wgrad_finish_kernel, dim3(Cout * mult), dim3(256), 0, st, ws, N * tiles, K * K, mult, dw, db);
+    hipLaunchKernelGGL(dwk_wgrad_finish_kernel, dim3(Cout * mult), dim3(256), 0, st, ws, N * wtiles, K * K, mult, dw, db);
     TDR_LAUNCH_CHECK("dwk_tiled_bwd");
     return TDR_OK;
 }
