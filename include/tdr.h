@@ -202,10 +202,12 @@ int tdr_dwconv_act_bwd(const float* dout, const float* act, const float* t, cons
                        float* dt, float* dw, float* db, float* ws, void* stream);
 /* grouped 3x3 with two inputs per output channel (DRSformer-ref MSFN dwconv3x3_1, network_drsformer_guided_arch.py:231-232,
  * 246-247): t [N][2C][H][W], w [C][2][3][3], b [C] | NULL, out [N][C][H][W] = relu?(dw(t[2c]) + dw(t[2c+1]) + b[c]).
- * Backward in one pass (W <= 1024); act: the saved forward output when relu was set, else NULL; ws: tdr_dwsg_ws_floats. */
-int tdr_dwpair_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, int relu, float* out, void* stream);
-int tdr_dwpair_bwd(const float* dout, const float* act, const float* t, const float* w, int N, int C, int H, int W, float* dt,
-                   float* dw, float* db, float* ws, void* stream);
+ * Backward in one pass (W <= 1024); act: the saved forward output when relu was set, else NULL; ws: tdr_dwsg_ws_floats.
+ * out / dout / act may be channel slices of wider tensors: *_ns is their per-image stride in floats (multiples of 4). */
+int tdr_dwpair_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, int relu, float* out,
+                   int64_t out_ns, void* stream);
+int tdr_dwpair_bwd(const float* dout, int64_t dout_ns, const float* act, int64_t act_ns, const float* t, const float* w, int N,
+                   int C, int H, int W, float* dt, float* dw, float* db, float* ws, void* stream);
 
 /* ---- Restormer-ref MDTA core (:246-277), per image and head over CHANNEL tokens (c = C/heads <= 192).
  * The pixel contractions run on tdr_conv_wgrad (per_image Gram q k^T) and tdr_conv_forward (1x1, per-image weights);

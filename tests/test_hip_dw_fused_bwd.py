@@ -128,3 +128,29 @@ def test_msfn_depthwise_on_the_stencils(shape, mult, relu, bias, Kk):
         os.environ.pop('TDR_DWK_GENERIC')
     assert float((y - y2).abs().max()) < 2e-5 and float((dx - dx2).abs().max()) < 5e-5
     assert float((dw - dw2).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)
+
+
+@pytest.mark.parametrize('Kk', [3, 5])
+def test_msfn_second_stage_writes_into_and_reads_from_channel_slices(Kk):
+    """z1 / z2 of MSFN go straight into the concatenated buffer, and their gradients / ReLU masks are read from channel slices of
+    wider tensors (drsformer_engine.ffn_fwd / ffn_bwd): per-image strides through the pair stencil (K = 3) and the 5x5 kernels"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    N, h, H, W = 2, 7, 40, 64
+    g = torch.Generator().manual_seed(Kk)
+    x = torch.randn(N, 2 * h, H, W, generator=g).cuda()
+    w = (torch.randn(h, 2, Kk, Kk, generator=g) * 0.3).cuda()
+    cat = torch.full((N, 2 * h + 3, H, W), 7.0, device='cuda')
+    dcat = torch.randn(N, 2 * h + 3, H, W, generator=g).cuda()
+    y = K.dwk_fwd(x, w, None, relu=True, out=cat[:, 2:2 + h])
+    assert y.data_ptr() == cat[:, 2:2 + h].data_ptr()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.relu(F.conv2d(xr, wr, None, padding=Kk // 2, groups=h))
+    assert float((cat[:, 2:2 + h] - yr).abs().max()) < 2e-5
+    assert float((cat[:, :2] - 7).abs().max()) == 0 and float((cat[:, 2 + h:] - 7).abs().max()) == 0     # neighbours untouched
+    yr.backward(dcat[:, 1:1 + h])
+    dx, dw, _ = K.dwk_bwd(dcat[:, 1:1 + h], cat[:, 2:2 + h], x, w)
+    assert float((dx - xr.grad).abs().max()) < 5e-5
+    s = (N * H * W) ** 0.5
+    assert float((dw - wr.grad).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)

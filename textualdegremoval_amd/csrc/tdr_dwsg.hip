@@ -70,7 +70,9 @@ struct DwArgs {
     float* pdb;          //     the parameter-gradient finish rides on the second pass instead of its own launch
     const float* dgb;    // DU (GATE_MUL): optional [N][C] plane constant added to dg, times dgb_mul
     float dgb_mul;
-    const float* act;    // GATE_NONE: ReLU after the conv -- FWD: any non-null value; one-pass backward: the saved output [N][2C][H][W]
+    const float* act;    // GATE_NONE / GATE_SUM: ReLU after the conv -- FWD: any non-null value; one-pass backward: the saved output
+    long sum_ns[3];      // GATE_SUM: per-image strides (floats) of out (FWD) | dg, act (backward); the C-plane tensors may be channel
+                         // slices of wider ones (MSFN writes z1 / z2 straight into the concatenated buffer)
 };
 
 struct Row6 { float v[6]; };
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = a.act ? fmaxf(o1[e] + o2[e], 0.f) : o1[e] + o2[e];
-            if (live) *reinterpret_cast<f32x4*>(a.out + ((long)n * C + c) * HW + (long)y * W + x0) = o;
+            if (live) *reinterpret_cast<f32x4*>(a.out + (long)n * a.sum_ns[0] + (long)c * HW + (long)y * W + x0) = o;
         } else if (MODE == MODE_FWD) {
             f32x4 o;
 #pragma unroll
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
     const int pl1 = GATE == GATE_SUM ? 2 * c : c, pl2 = GATE == GATE_SUM ? 2 * c + 1 : c + C;
     const float* p1 = a.a + ((long)n * 2 * C + pl1) * HW;
     const float* p2 = a.a + ((long)n * 2 * C + pl2) * HW;
-    const float* q1 = GATE == GATE_NONE ? a.dg + ((long)n * 2 * C + c) * HW : a.dg + ((long)n * C + c) * HW;
+    const float* q1 = GATE == GATE_NONE ? a.dg + ((long)n * 2 * C + c) * HW
+                      : (GATE == GATE_SUM ? a.dg + (long)n * a.sum_ns[1] + (long)c * HW : a.dg + ((long)n * C + c) * HW);
     const float* q2 = q1 + (long)C * HW;                      // GATE_NONE only
     float w1[9], w2[9];
 #pragma unroll
@@ -320,7 +323,8 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
     // the latency of a load that is consumed in the iteration that issues it)
     constexpr bool PF = true;
     RawRow n1, n2, m1, m2;
-    const float* r1p = (DIRECT && a.act) ? a.act + ((long)n * (GATE == GATE_SUM ? 1 : 2) * C + c) * HW : nullptr;   // ReLU outputs
+    const float* r1p = (DIRECT && a.act) ? (GATE == GATE_SUM ? a.act + (long)n * a.sum_ns[2] + (long)c * HW
+                                                             : a.act + ((long)n * 2 * C + c) * HW) : nullptr;   // ReLU outputs
     const float* r2p = r1p ? r1p + (long)C * HW : nullptr;                                                        // (GATE_NONE: two planes)
     auto relu_mask = [&](RawRow& d, const float* plane, int y, bool on) {                              // d *= (act > 0)
         const RawRow k = load_raw(plane, y, x0, H, W, on, left_lane, right_lane);
@@ -529,9 +533,11 @@ bool dw_two_pass() {                                     // TDR_DWSG_TWO_PASS=1:
 
 template <int GATE>
 int dw_bwd_fused(const float* t, const float* dg, const float* dg_bias, float dg_bias_mul, const float* w, const float* b, int N,
-                 int C, int H, int W, float* dt, float* dw, float* db, float* ws, hipStream_t st, const float* act = nullptr) {
+                 int C, int H, int W, float* dt, float* dw, float* db, float* ws, hipStream_t st, const float* act = nullptr,
+                 long dg_ns = 0, long act_ns = 0) {
     const DwGeom q = dw_geom_fused(H, W);
-    DwArgs a{t, dg, w, b, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul, act};
+    DwArgs a{t, dg, w, b, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul, act,
+             {0, dg_ns, act_ns}};
     hipLaunchKernelGGL((dwsg_bwd_fused_kernel<GATE>), dim3(q.nb, C, N), dim3(256), 0, st, a);
     hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, st, ws, N, C, q.nb, dw, db, GATE == GATE_SUM ? 1 : 0);
     return 0;
@@ -675,22 +681,26 @@ extern "C" int tdr_dwconv_act_bwd(const float* dout, const float* act, const flo
 // ---- DRSformer-ref MSFN second stage: grouped 3x3 with two inputs per output.  t [N][2C][H][W], w [C][2][3][3], b [C] | NULL,
 // out [N][C][H][W] = relu?(sum of the two filtered planes + b).  Backward (one pass, W <= 1024): act = saved output | NULL.
 extern "C" int tdr_dwpair_fwd(const float* t, const float* w, const float* b, int N, int C, int H, int W, int relu, float* out,
-                              void* stream) {
+                              int64_t out_ns, void* stream) {
     TDR_REQUIRE(t && w && out, "tdr_dwpair_fwd: null pointer");
-    TDR_REQUIRE(W % 4 == 0, "tdr_dwpair_fwd: W must be a multiple of 4 (got %d)", W);
+    TDR_REQUIRE(W % 4 == 0 && out_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                "tdr_dwpair_fwd: W and out_ns must be multiples of 4, out 16-byte aligned (got %d)", W);
     const DwGeom q = dw_geom(H, W);
     DwArgs a{t, nullptr, w, b, out, nullptr, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, nullptr, 0.f,
-             relu ? out : nullptr};
+             relu ? out : nullptr, {(long)out_ns, 0, 0}};
     hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_SUM>), dim3(q.nb, C, N), dim3(256), 0, (hipStream_t)stream, a);
     TDR_LAUNCH_CHECK("dwpair_fwd");
     return TDR_OK;
 }
 
-extern "C" int tdr_dwpair_bwd(const float* dout, const float* act, const float* t, const float* w, int N, int C, int H, int W,
-                              float* dt, float* dw, float* db, float* ws, void* stream) {
+extern "C" int tdr_dwpair_bwd(const float* dout, int64_t dout_ns, const float* act, int64_t act_ns, const float* t, const float* w,
+                              int N, int C, int H, int W, float* dt, float* dw, float* db, float* ws, void* stream) {
     TDR_REQUIRE(dout && t && w && dt && dw && ws, "tdr_dwpair_bwd: null pointer");
     TDR_REQUIRE(W % 4 == 0 && W <= 1024, "tdr_dwpair_bwd: W must be a multiple of 4, at most 1024 (got %d)", W);
-    dw_bwd_fused<GATE_SUM>(t, dout, nullptr, 0.f, w, nullptr, N, C, H, W, dt, dw, db, ws, (hipStream_t)stream, act);
+    TDR_REQUIRE(((dout_ns | act_ns) & 3) == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(act)) & 15) == 0,
+                "tdr_dwpair_bwd: dout / act strides must be multiples of 4 floats, pointers 16-byte aligned");
+    dw_bwd_fused<GATE_SUM>(t, dout, nullptr, 0.f, w, nullptr, N, C, H, W, dt, dw, db, ws, (hipStream_t)stream, act, (long)dout_ns,
+                           (long)act_ns);
     TDR_LAUNCH_CHECK("dwpair_bwd");
     return TDR_OK;
 }

@@ -70,9 +70,9 @@ def ffn_fwd(yn, P, res=None):
     a5 = K.dwk_fwd(t2, P['ffn.dwconv5x5.weight'], P.get('ffn.dwconv5x5.bias'), relu=True)
     x1 = K.concat2(a3[:, :h], a5[:, :h])
     x2 = K.concat2(a3[:, h:], a5[:, h:])
-    z1 = K.dwk_fwd(x1, P['ffn.dwconv3x3_1.weight'], P.get('ffn.dwconv3x3_1.bias'), relu=True)
-    z2 = K.dwk_fwd(x2, P['ffn.dwconv5x5_1.weight'], P.get('ffn.dwconv5x5_1.bias'), relu=True)
-    cat = K.concat2(z1, z2)
+    cat = torch.empty(t2.shape[0], 2 * h, t2.shape[2], t2.shape[3], dtype=torch.float32, device=t2.device)
+    z1 = K.dwk_fwd(x1, P['ffn.dwconv3x3_1.weight'], P.get('ffn.dwconv3x3_1.bias'), relu=True, out=cat[:, :h])   # straight into
+    z2 = K.dwk_fwd(x2, P['ffn.dwconv5x5_1.weight'], P.get('ffn.dwconv5x5_1.bias'), relu=True, out=cat[:, h:])   # the concatenation
     out = R._pw_fwd(cat, P, 'ffn.project_out', res=res)
     return out, (yn, t2, a3, a5, x1, x2, z1, z2, cat)
 
@@ -86,9 +86,9 @@ def ffn_bwd(dout, P, saved, G):
         if db is not None:
             G[name + '.bias'] = db
     dcat = R._pw_bwd(dout, cat, P, 'ffn.project_out', G)
-    dx1, dw, db = K.dwk_bwd(K.slice_channels(dcat, 0, h), z1, x1, P['ffn.dwconv3x3_1.weight'], want_db='ffn.dwconv3x3_1.bias' in P)
-    put('ffn.dwconv3x3_1', dw, db)
-    dx2, dw, db = K.dwk_bwd(K.slice_channels(dcat, h, 2 * h), z2, x2, P['ffn.dwconv5x5_1.weight'], want_db='ffn.dwconv5x5_1.bias' in P)
+    dx1, dw, db = K.dwk_bwd(dcat[:, :h], z1, x1, P['ffn.dwconv3x3_1.weight'], want_db='ffn.dwconv3x3_1.bias' in P)   # batch-strided
+    put('ffn.dwconv3x3_1', dw, db)                                                                                      # views, no copies
+    dx2, dw, db = K.dwk_bwd(dcat[:, h:], z2, x2, P['ffn.dwconv5x5_1.weight'], want_db='ffn.dwconv5x5_1.bias' in P)
     put('ffn.dwconv5x5_1', dw, db)
     da3 = K.concat2(dx1[:, :h], dx2[:, :h])
     da5 = K.concat2(dx1[:, h:], dx2[:, h:])

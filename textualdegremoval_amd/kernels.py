@@ -1321,19 +1321,21 @@ def _DW_TWO_PASS():
     return os.environ.get('TDR_DWSG_TWO_PASS', '0') == '1'
 
 
-def dwk_fwd(x, w, b=None, relu=False, dil=1):
-    """grouped depthwise-like conv: w [Cout, mult, K, K] (mult 1 | 2), stride 1, pad dil * (K // 2), optional bias / fused ReLU"""
+def dwk_fwd(x, w, b=None, relu=False, dil=1, out=None):
+    """grouped depthwise-like conv: w [Cout, mult, K, K] (mult 1 | 2), stride 1, pad dil * (K // 2), optional bias / fused ReLU.
+    out: optional destination [N, Cout, H, W], dense per image -- e.g. a channel slice of a concatenation buffer"""
     N, Cin, H, W = x.shape
     Cout, mult, Kk, _ = w.shape
     assert Cin == Cout * mult and w.is_contiguous()
-    y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
-    if _dw3_plain(x, w, dil):     # plain depthwise 3x3: the register-window stencil of tdr_dwsg.hip (plane pairs c, c + Cout/2)
+    y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device) if out is None else out
+    assert y.shape == (N, Cout, H, W)
+    if _dw3_plain(x, w, dil) and y.is_contiguous():     # plain depthwise 3x3: the register-window stencil of tdr_dwsg.hip (plane pairs c, c + Cout/2)
         check(_lib.load().tdr_dwconv_act_fwd(x.data_ptr(), w.data_ptr(), _p(b), N, Cout, H, W, 1 if relu else 0, y.data_ptr(), _stream()),
               'tdr_dwconv_act_fwd')
         return y
     if _dw3_pair(x, w, dil):      # two inputs per output, 3x3: the same stencil with (2c, 2c+1) plane pairs
-        check(_lib.load().tdr_dwpair_fwd(x.data_ptr(), w.data_ptr(), _p(b), N, Cout, H, W, 1 if relu else 0, y.data_ptr(), _stream()),
-              'tdr_dwpair_fwd')
+        check(_lib.load().tdr_dwpair_fwd(x.data_ptr(), w.data_ptr(), _p(b), N, Cout, H, W, 1 if relu else 0, y.data_ptr(), _dense_nchw(y),
+                                         _stream()), 'tdr_dwpair_fwd')
         return y
     check(_lib.load().tdr_dwk_fwd(x.data_ptr(), _dense_nchw(x), w.data_ptr(), _p(b), N, Cout, mult, H, W, Kk, int(dil), 1 if relu else 0,
                                   y.data_ptr(), _dense_nchw(y), _stream()), 'tdr_dwk_fwd')
@@ -1353,10 +1355,11 @@ def dwk_bwd(dy, y_act, x, w, want_db=False, dil=1):
         check(lib.tdr_dwconv_act_bwd(dy.data_ptr(), _p(y_act), x.data_ptr(), w.data_ptr(), N, Cout, H, W, dx.data_ptr(), dw.data_ptr(),
                                      _p(db), ws.data_ptr(), _stream()), 'tdr_dwconv_act_bwd')
         return dx, dw, db
-    if _dw3_pair(x, w, dil) and dy.is_contiguous() and (y_act is None or y_act.is_contiguous()) and W <= 1024:
+    if _dw3_pair(x, w, dil) and W <= 1024:
         ws = workspace(lib.tdr_dwsg_ws_floats(N, Cout, H, W), x.device)
-        check(lib.tdr_dwpair_bwd(dy.data_ptr(), _p(y_act), x.data_ptr(), w.data_ptr(), N, Cout, H, W, dx.data_ptr(), dw.data_ptr(),
-                                 _p(db), ws.data_ptr(), _stream()), 'tdr_dwpair_bwd')
+        check(lib.tdr_dwpair_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
+                                 w.data_ptr(), N, Cout, H, W, dx.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(), _stream()),
+              'tdr_dwpair_bwd')
         return dx, dw, db
     ws = workspace(lib.tdr_dwk_bwd_ws_floats(N, Cout, mult, H, W, Kk), x.device, 'dwk')
     check(lib.tdr_dwk_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
