@@ -208,6 +208,14 @@ int tdr_dwpair_fwd(const float* t, const float* w, const float* b, int N, int C,
                    int64_t out_ns, void* stream);
 int tdr_dwpair_bwd(const float* dout, int64_t dout_ns, const float* act, int64_t act_ns, const float* t, const float* w, int N,
                    int C, int H, int W, float* dt, float* dw, float* db, float* ws, void* stream);
+/* the plain depthwise 3x3 (+ ReLU) whose 2C output planes live in two tensors (MSFN's cross-concatenation, :244-247: x1 = [a3[:h] |
+ * a5[:h]], x2 = [a3[h:] | a5[h:]] is written in place instead of copied): planes [0, C) at outA, planes [C, 2C) at outB, both
+ * [N][C][H][W] with per-image stride out_ns.  The one-pass backward reads dout / act split the same way (actA = actB = NULL: no ReLU). */
+int tdr_dwconv_halves_fwd(const float* t, const float* w, const float* b, int N, int planes, int H, int W, int relu, float* outA,
+                          float* outB, int64_t out_ns, void* stream);
+int tdr_dwconv_halves_bwd(const float* doutA, const float* doutB, int64_t dout_ns, const float* actA, const float* actB,
+                          int64_t act_ns, const float* t, const float* w, int N, int planes, int H, int W, float* dt, float* dw,
+                          float* db, float* ws, void* stream);
 
 /* ---- Restormer-ref MDTA core (:246-277), per image and head over CHANNEL tokens (c = C/heads <= 192).
  * The pixel contractions run on tdr_conv_wgrad (per_image Gram q k^T) and tdr_conv_forward (1x1, per-image weights);

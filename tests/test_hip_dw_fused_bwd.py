@@ -154,3 +154,36 @@ def test_msfn_second_stage_writes_into_and_reads_from_channel_slices(Kk):
     assert float((dx - xr.grad).abs().max()) < 5e-5
     s = (N * H * W) ** 0.5
     assert float((dw - wr.grad).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)
+
+
+@pytest.mark.parametrize('relu,bias', [(True, True), (False, False)])
+def test_plain_depthwise_3x3_with_split_halves(relu, bias):
+    """MSFN's cross-concatenation in place (drsformer_engine.ffn_fwd): the 3x3 stencil stores planes [0, h) and [h, 2h) of its
+    output into channel slices of two different buffers, and the backward reads dout / the ReLU mask split the same way"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    N, h, H, W = 2, 7, 37, 96
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, 2 * h, H, W, generator=g).cuda()
+    w = (torch.randn(2 * h, 1, 3, 3, generator=g) * 0.4).cuda()
+    b = (torch.randn(2 * h, generator=g) * 0.3).cuda() if bias else None
+    x1 = torch.full((N, 2 * h, H, W), 5.0, device='cuda')
+    x2 = torch.full((N, 2 * h, H, W), 6.0, device='cuda')
+    ya, yb = K.dwk_fwd(x, w, b, relu=relu, out=(x1[:, :h], x2[:, h:]))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, padding=1, groups=2 * h)
+    if relu:
+        yr = F.relu(yr)
+    assert float((x1[:, :h] - yr[:, :h]).abs().max()) < 2e-5 and float((x2[:, h:] - yr[:, h:]).abs().max()) < 2e-5
+    assert float((x1[:, h:] - 5).abs().max()) == 0 and float((x2[:, :h] - 6).abs().max()) == 0
+    d1 = torch.randn(N, 2 * h, H, W, generator=g).cuda()
+    d2 = torch.randn(N, 2 * h, H, W, generator=g).cuda()
+    yr.backward(torch.cat([d1[:, h:], d2[:, :h]], dim=1))
+    dx, dw, db = K.dwk_bwd((d1[:, h:], d2[:, :h]), (ya, yb) if relu else None, x, w, want_db=bias)
+    assert float((dx - xr.grad).abs().max()) < 5e-5
+    s = (N * H * W) ** 0.5
+    assert float((dw - wr.grad).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)
+    if bias:
+        assert float((db - br.grad).abs().max()) < 2e-5 * s * max(1.0, float(br.grad.abs().max()) / s)

@@ -127,6 +127,8 @@ SIGNATURES = {
     'tdr_dwconv_act_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwpair_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
     'tdr_dwpair_bwd': (i32, [c_fp, i64, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_dwconv_halves_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp, i64, c_fp]),
+    'tdr_dwconv_halves_bwd': (i32, [c_fp, c_fp, i64, c_fp, c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwconv_bwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_row_sumsq': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp]),
     'tdr_mdta_pad': (i32, [i32]),

@@ -73,6 +73,12 @@ struct DwArgs {
     const float* act;    // GATE_NONE / GATE_SUM: ReLU after the conv -- FWD: any non-null value; one-pass backward: the saved output
     long sum_ns[3];      // GATE_SUM: per-image strides (floats) of out (FWD) | dg, act (backward); the C-plane tensors may be channel
                          // slices of wider ones (MSFN writes z1 / z2 straight into the concatenated buffer)
+    // GATE_NONE, "split halves": the first C planes and the last C planes of out (FWD) | dg, act (one-pass backward) live in two
+    // tensors (base pointers X / XB, common per-image stride) -- MSFN's cross-concatenation [a3[:h] | a5[:h]], [a3[h:] | a5[h:]]
+    // is then never copied.  XB == NULL: the dense [N][2C] layout.
+    float* outB; long out_hns;
+    const float* dgB; long dg_hns;
+    const float* actB; long act_hns;
 };
 
 struct Row6 { float v[6]; };
@@ -174,8 +180,10 @@ __global__ __launch_bounds__(256) void dwsg_stencil_kernel(DwArgs a) {
             }
             if (live) {
                 const f32x4 q1 = {o1[0], o1[1], o1[2], o1[3]}, q2 = {o2[0], o2[1], o2[2], o2[3]};
-                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c) * HW + (long)y * W + x0) = q1;
-                *reinterpret_cast<f32x4*>(a.out + ((long)n * 2 * C + c + C) * HW + (long)y * W + x0) = q2;
+                float* d1 = a.outB ? a.out + (long)n * a.out_hns + (long)c * HW : a.out + ((long)n * 2 * C + c) * HW;
+                float* d2 = a.outB ? a.outB + (long)n * a.out_hns + (long)c * HW : a.out + ((long)n * 2 * C + c + C) * HW;
+                *reinterpret_cast<f32x4*>(d1 + (long)y * W + x0) = q1;
+                *reinterpret_cast<f32x4*>(d2 + (long)y * W + x0) = q2;
             }
         } else if (MODE == MODE_FWD && GATE == GATE_SUM) {
             f32x4 o;
@@ -296,9 +304,9 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
     const int pl1 = GATE == GATE_SUM ? 2 * c : c, pl2 = GATE == GATE_SUM ? 2 * c + 1 : c + C;
     const float* p1 = a.a + ((long)n * 2 * C + pl1) * HW;
     const float* p2 = a.a + ((long)n * 2 * C + pl2) * HW;
-    const float* q1 = GATE == GATE_NONE ? a.dg + ((long)n * 2 * C + c) * HW
+    const float* q1 = GATE == GATE_NONE ? (a.dgB ? a.dg + (long)n * a.dg_hns + (long)c * HW : a.dg + ((long)n * 2 * C + c) * HW)
                       : (GATE == GATE_SUM ? a.dg + (long)n * a.sum_ns[1] + (long)c * HW : a.dg + ((long)n * C + c) * HW);
-    const float* q2 = q1 + (long)C * HW;                      // GATE_NONE only
+    const float* q2 = (GATE == GATE_NONE && a.dgB) ? a.dgB + (long)n * a.dg_hns + (long)c * HW : q1 + (long)C * HW;   // GATE_NONE only
     float w1[9], w2[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -324,8 +332,9 @@ __global__ __launch_bounds__(256) void dwsg_bwd_fused_kernel(DwArgs a) {
     constexpr bool PF = true;
     RawRow n1, n2, m1, m2;
     const float* r1p = (DIRECT && a.act) ? (GATE == GATE_SUM ? a.act + (long)n * a.sum_ns[2] + (long)c * HW
-                                                             : a.act + ((long)n * 2 * C + c) * HW) : nullptr;   // ReLU outputs
-    const float* r2p = r1p ? r1p + (long)C * HW : nullptr;                                                        // (GATE_NONE: two planes)
+                                            : (a.actB ? a.act + (long)n * a.act_hns + (long)c * HW
+                                                      : a.act + ((long)n * 2 * C + c) * HW)) : nullptr;          // ReLU outputs
+    const float* r2p = !r1p ? nullptr : (a.actB ? a.actB + (long)n * a.act_hns + (long)c * HW : r1p + (long)C * HW);   // (GATE_NONE)
     auto relu_mask = [&](RawRow& d, const float* plane, int y, bool on) {                              // d *= (act > 0)
         const RawRow k = load_raw(plane, y, x0, H, W, on, left_lane, right_lane);
 #pragma unroll
@@ -534,10 +543,10 @@ bool dw_two_pass() {                                     // TDR_DWSG_TWO_PASS=1:
 template <int GATE>
 int dw_bwd_fused(const float* t, const float* dg, const float* dg_bias, float dg_bias_mul, const float* w, const float* b, int N,
                  int C, int H, int W, float* dt, float* dw, float* db, float* ws, hipStream_t st, const float* act = nullptr,
-                 long dg_ns = 0, long act_ns = 0) {
+                 long dg_ns = 0, long act_ns = 0, const float* dgB = nullptr, const float* actB = nullptr) {
     const DwGeom q = dw_geom_fused(H, W);
     DwArgs a{t, dg, w, b, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul, act,
-             {0, dg_ns, act_ns}};
+             {0, dg_ns, act_ns}, nullptr, 0, dgB, dg_ns, actB, act_ns};
     hipLaunchKernelGGL((dwsg_bwd_fused_kernel<GATE>), dim3(q.nb, C, N), dim3(256), 0, st, a);
     hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, st, ws, N, C, q.nb, dw, db, GATE == GATE_SUM ? 1 : 0);
     return 0;
@@ -702,5 +711,35 @@ extern "C" int tdr_dwpair_bwd(const float* dout, int64_t dout_ns, const float* a
     dw_bwd_fused<GATE_SUM>(t, dout, nullptr, 0.f, w, nullptr, N, C, H, W, dt, dw, db, ws, (hipStream_t)stream, act, (long)dout_ns,
                            (long)act_ns);
     TDR_LAUNCH_CHECK("dwpair_bwd");
+    return TDR_OK;
+}
+
+// ---- the plain depthwise 3x3 (+ ReLU) with its 2C output planes split over two tensors: planes [0, C) at outA, planes [C, 2C) at
+// outB, both [N][C][H][W] with per-image stride out_ns (channel slices of wider buffers).  The backward reads dout and act the same way.
+extern "C" int tdr_dwconv_halves_fwd(const float* t, const float* w, const float* b, int N, int planes, int H, int W, int relu,
+                                     float* outA, float* outB, int64_t out_ns, void* stream) {
+    TDR_REQUIRE(t && w && outA && outB, "tdr_dwconv_halves_fwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0 && planes % 2 == 0 && out_ns % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(outA) | reinterpret_cast<uintptr_t>(outB)) & 15) == 0,
+                "tdr_dwconv_halves_fwd: W %% 4, planes %% 2, out_ns %% 4 must be 0 and the outputs 16-byte aligned");
+    const DwGeom q = dw_geom(H, W);
+    DwArgs a{t, nullptr, w, b, outA, nullptr, planes / 2, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, nullptr, 0.f,
+             relu ? outA : nullptr, {0, 0, 0}, outB, (long)out_ns, nullptr, 0, nullptr, 0};
+    hipLaunchKernelGGL((dwsg_stencil_kernel<MODE_FWD, GATE_NONE>), dim3(q.nb, planes / 2, N), dim3(256), 0, (hipStream_t)stream, a);
+    TDR_LAUNCH_CHECK("dwconv_halves_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_dwconv_halves_bwd(const float* doutA, const float* doutB, int64_t dout_ns, const float* actA, const float* actB,
+                                     int64_t act_ns, const float* t, const float* w, int N, int planes, int H, int W, float* dt,
+                                     float* dw, float* db, float* ws, void* stream) {
+    TDR_REQUIRE(doutA && doutB && t && w && dt && dw && ws && (!actA == !actB), "tdr_dwconv_halves_bwd: null pointer");
+    TDR_REQUIRE(W % 4 == 0 && planes % 2 == 0 && ((dout_ns | act_ns) & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(doutA) | reinterpret_cast<uintptr_t>(doutB) | reinterpret_cast<uintptr_t>(actA) |
+                      reinterpret_cast<uintptr_t>(actB)) & 15) == 0,
+                "tdr_dwconv_halves_bwd: W %% 4, planes %% 2, strides %% 4 must be 0 and the inputs 16-byte aligned");
+    dw_bwd_fused<GATE_NONE>(t, doutA, nullptr, 0.f, w, nullptr, N, planes / 2, H, W, dt, dw, db, ws, (hipStream_t)stream, actA,
+                            (long)dout_ns, (long)act_ns, doutB, actB);
+    TDR_LAUNCH_CHECK("dwconv_halves_bwd");
     return TDR_OK;
 }

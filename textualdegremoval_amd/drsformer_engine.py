@@ -13,6 +13,8 @@ Reference defects (oracle/drsformer_ref_oracle.py): R1 (pyramid index), R5 (miss
 R6: the level-1 reference fusion is computed and discarded -- here it is not computed at all; `masa_blk_enc_level1.*` never
 reach the engine (no gradient, as in the reference).
 """
+import os
+
 import torch
 
 from . import engine as E
@@ -62,14 +64,30 @@ def attn_bwd(dy, P, heads, saved, G):
     return R._pw_bwd(dt, xn, P, 'attn.qkv', G)
 
 
+def _split_ok(t2, h):
+    """the in-place cross-concatenation needs 16-byte aligned plane slices and the 3x3 stencil route (W % 4 == 0)"""
+    return t2.shape[-1] % 4 == 0 and (h * t2.shape[2] * t2.shape[3]) % 4 == 0 and os.environ.get('TDR_DWK_GENERIC', '0') != '1' and \
+        os.environ.get('TDR_DWSG_TWO_PASS', '0') != '1' and os.environ.get('TDR_MSFN_COPY', '0') != '1'
+
+
 def ffn_fwd(yn, P, res=None):
     """FeedForward.forward (:240-253)."""
     t2 = R._pw_fwd(yn, P, 'ffn.project_in')                                         # [N, 2h, H, W]
     h = t2.shape[1] // 2
-    a3 = K.dwk_fwd(t2, P['ffn.dwconv3x3.weight'], P.get('ffn.dwconv3x3.bias'), relu=True)
-    a5 = K.dwk_fwd(t2, P['ffn.dwconv5x5.weight'], P.get('ffn.dwconv5x5.bias'), relu=True)
-    x1 = K.concat2(a3[:, :h], a5[:, :h])
-    x2 = K.concat2(a3[:, h:], a5[:, h:])
+    # x1 = [a3[:h] | a5[:h]], x2 = [a3[h:] | a5[h:]] (:244-247) are written in place: the 3x3 stencil owns the plane pair (c, c + h)
+    # and stores its two planes to x1 / x2; the 5x5 conv runs per half.  a3 / a5 only exist as these slices.
+    x1, x2 = torch.empty_like(t2), torch.empty_like(t2)
+    w5, b5 = P['ffn.dwconv5x5.weight'], P.get('ffn.dwconv5x5.bias')
+    if _split_ok(t2, h):
+        a3 = K.dwk_fwd(t2, P['ffn.dwconv3x3.weight'], P.get('ffn.dwconv3x3.bias'), relu=True, out=(x1[:, :h], x2[:, :h]))
+        K.dwk_fwd(t2[:, :h], w5[:h], None if b5 is None else b5[:h], relu=True, out=x1[:, h:])
+        K.dwk_fwd(t2[:, h:], w5[h:], None if b5 is None else b5[h:], relu=True, out=x2[:, h:])
+        a5 = (x1[:, h:], x2[:, h:])
+    else:
+        a3 = K.dwk_fwd(t2, P['ffn.dwconv3x3.weight'], P.get('ffn.dwconv3x3.bias'), relu=True)
+        a5 = K.dwk_fwd(t2, w5, b5, relu=True)
+        x1 = K.concat2(a3[:, :h], a5[:, :h])
+        x2 = K.concat2(a3[:, h:], a5[:, h:])
     cat = torch.empty(t2.shape[0], 2 * h, t2.shape[2], t2.shape[3], dtype=torch.float32, device=t2.device)
     z1 = K.dwk_fwd(x1, P['ffn.dwconv3x3_1.weight'], P.get('ffn.dwconv3x3_1.bias'), relu=True, out=cat[:, :h])   # straight into
     z2 = K.dwk_fwd(x2, P['ffn.dwconv5x5_1.weight'], P.get('ffn.dwconv5x5_1.bias'), relu=True, out=cat[:, h:])   # the concatenation
@@ -90,12 +108,24 @@ def ffn_bwd(dout, P, saved, G):
     put('ffn.dwconv3x3_1', dw, db)                                                                                      # views, no copies
     dx2, dw, db = K.dwk_bwd(dcat[:, h:], z2, x2, P['ffn.dwconv5x5_1.weight'], want_db='ffn.dwconv5x5_1.bias' in P)
     put('ffn.dwconv5x5_1', dw, db)
-    da3 = K.concat2(dx1[:, :h], dx2[:, :h])
-    da5 = K.concat2(dx1[:, h:], dx2[:, h:])
-    dt2, dw, db = K.dwk_bwd(da3, a3, t2, P['ffn.dwconv3x3.weight'], want_db='ffn.dwconv3x3.bias' in P)
-    put('ffn.dwconv3x3', dw, db)
-    dt2b, dw, db = K.dwk_bwd(da5, a5, t2, P['ffn.dwconv5x5.weight'], want_db='ffn.dwconv5x5.bias' in P)
-    put('ffn.dwconv5x5', dw, db)
+    w5 = P['ffn.dwconv5x5.weight']
+    if isinstance(a3, tuple):
+        # da3 = [dx1[:h] | dx2[:h]], da5 = [dx1[h:] | dx2[h:]] are read where they are (split halves / channel slices)
+        dt2, dw, db = K.dwk_bwd((dx1[:, :h], dx2[:, :h]), a3, t2, P['ffn.dwconv3x3.weight'], want_db='ffn.dwconv3x3.bias' in P)
+        put('ffn.dwconv3x3', dw, db)
+        has_b = 'ffn.dwconv5x5.bias' in P
+        dt2b, dw5 = torch.empty_like(t2), torch.empty_like(w5)
+        db5 = torch.empty(2 * h, dtype=torch.float32, device=t2.device) if has_b else None
+        K.dwk_bwd(dx1[:, h:], a5[0], t2[:, :h], w5[:h], want_db=has_b, dx_out=dt2b[:, :h], dw_out=dw5[:h], db_out=None if db5 is None else db5[:h])
+        K.dwk_bwd(dx2[:, h:], a5[1], t2[:, h:], w5[h:], want_db=has_b, dx_out=dt2b[:, h:], dw_out=dw5[h:], db_out=None if db5 is None else db5[h:])
+        put('ffn.dwconv5x5', dw5, db5)
+    else:
+        da3 = K.concat2(dx1[:, :h], dx2[:, :h])
+        da5 = K.concat2(dx1[:, h:], dx2[:, h:])
+        dt2, dw, db = K.dwk_bwd(da3, a3, t2, P['ffn.dwconv3x3.weight'], want_db='ffn.dwconv3x3.bias' in P)
+        put('ffn.dwconv3x3', dw, db)
+        dt2b, dw, db = K.dwk_bwd(da5, a5, t2, w5, want_db='ffn.dwconv5x5.bias' in P)
+        put('ffn.dwconv5x5', dw, db)
     return R._pw_bwd(K.add_(dt2, dt2b), yn, P, 'ffn.project_in', G)
 
 

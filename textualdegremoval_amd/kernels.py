@@ -1327,6 +1327,12 @@ def dwk_fwd(x, w, b=None, relu=False, dil=1, out=None):
     N, Cin, H, W = x.shape
     Cout, mult, Kk, _ = w.shape
     assert Cin == Cout * mult and w.is_contiguous()
+    if isinstance(out, tuple):    # plain depthwise 3x3 only: planes [0, Cout/2) -> out[0], planes [Cout/2, Cout) -> out[1] (channel slices)
+        ya, yb = out
+        assert _dw3_plain(x, w, dil) and ya.shape == yb.shape == (N, Cout // 2, H, W) and _dense_nchw(ya) == _dense_nchw(yb)
+        check(_lib.load().tdr_dwconv_halves_fwd(x.data_ptr(), w.data_ptr(), _p(b), N, Cout, H, W, 1 if relu else 0, ya.data_ptr(),
+                                                yb.data_ptr(), _dense_nchw(ya), _stream()), 'tdr_dwconv_halves_fwd')
+        return out
     y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device) if out is None else out
     assert y.shape == (N, Cout, H, W)
     if _dw3_plain(x, w, dil) and y.is_contiguous():     # plain depthwise 3x3: the register-window stencil of tdr_dwsg.hip (plane pairs c, c + Cout/2)
@@ -1342,20 +1348,33 @@ def dwk_fwd(x, w, b=None, relu=False, dil=1, out=None):
     return y
 
 
-def dwk_bwd(dy, y_act, x, w, want_db=False, dil=1):
-    """-> (dx, dw, db); y_act: the forward output when a ReLU was fused (its mask), else None"""
+def dwk_bwd(dy, y_act, x, w, want_db=False, dil=1, dx_out=None, dw_out=None, db_out=None):
+    """-> (dx, dw, db); y_act: the forward output when a ReLU was fused (its mask), else None.  dy / y_act may be (first half, second
+    half) tuples of channel slices for the plain depthwise 3x3 (see dwk_fwd); dx_out / dw_out / db_out: optional destinations (dx_out
+    dense per image, e.g. a channel slice)"""
     N, Cin, H, W = x.shape
     Cout, mult, Kk, _ = w.shape
-    dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=x.device)
-    dw = torch.empty_like(w)
-    db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
+    dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=x.device) if dx_out is None else dx_out
+    dw = torch.empty_like(w) if dw_out is None else dw_out
+    db = (torch.empty(Cout, dtype=torch.float32, device=x.device) if db_out is None else db_out) if want_db else None
+    assert dx.shape == (N, Cin, H, W) and dw.is_contiguous() and dw.shape == w.shape
     lib = _lib.load()
-    if _dw3_plain(x, w, dil) and dy.is_contiguous() and (y_act is None or y_act.is_contiguous()) and not _DW_TWO_PASS():
+    if isinstance(dy, tuple):
+        da, db_ = dy
+        aa, ab = y_act if y_act is not None else (None, None)
+        assert _dw3_plain(x, w, dil) and dx.is_contiguous() and _dense_nchw(da) == _dense_nchw(db_)
+        assert aa is None or _dense_nchw(aa) == _dense_nchw(ab)
+        ws = workspace(lib.tdr_dwsg_ws_floats(N, Cout // 2, H, W), x.device)
+        check(lib.tdr_dwconv_halves_bwd(da.data_ptr(), db_.data_ptr(), _dense_nchw(da), _p(aa), _p(ab), _dense_nchw(aa) if aa is not None else 0,
+                                        x.data_ptr(), w.data_ptr(), N, Cout, H, W, dx.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(),
+                                        _stream()), 'tdr_dwconv_halves_bwd')
+        return dx, dw, db
+    if _dw3_plain(x, w, dil) and dy.is_contiguous() and (y_act is None or y_act.is_contiguous()) and not _DW_TWO_PASS() and dx.is_contiguous():
         ws = workspace(lib.tdr_dwsg_ws_floats(N, Cout // 2, H, W), x.device)
         check(lib.tdr_dwconv_act_bwd(dy.data_ptr(), _p(y_act), x.data_ptr(), w.data_ptr(), N, Cout, H, W, dx.data_ptr(), dw.data_ptr(),
                                      _p(db), ws.data_ptr(), _stream()), 'tdr_dwconv_act_bwd')
         return dx, dw, db
-    if _dw3_pair(x, w, dil) and W <= 1024:
+    if _dw3_pair(x, w, dil) and W <= 1024 and dx.is_contiguous():
         ws = workspace(lib.tdr_dwsg_ws_floats(N, Cout, H, W), x.device)
         check(lib.tdr_dwpair_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
                                  w.data_ptr(), N, Cout, H, W, dx.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(), _stream()),
