@@ -370,6 +370,12 @@ int64_t tdr_dwk_bwd_ws_floats(int N, int Cout, int mult, int H, int W, int K);
 int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w, int N,
                 int Cout, int mult, int H, int W, int K, int dil, float* dx, int64_t dx_ns, float* dw, float* db /*or NULL*/,
                 float* ws /*tdr_dwk_bwd_ws_floats floats*/, void* stream);
+/* the same with dx += (accumulate != 0) -- the two first-stage branches of MSFN both feed project_in's output gradient; only the
+ * one-pass 5x5 kernel accumulates, tdr_dwk_bwd_can_accumulate(...) != 0 tells whether the arguments take it */
+int tdr_dwk_bwd_can_accumulate(int W, int K, int dil, int64_t dy_ns, int64_t y_ns, int64_t x_ns, int64_t dx_ns);
+int tdr_dwk_bwd_acc(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w,
+                    int N, int Cout, int mult, int H, int W, int K, int dil, float* dx, int64_t dx_ns, int accumulate, float* dw,
+                    float* db, float* ws, void* stream);
 /* MEFC sub-network pieces (network_drsformer_guided_arch.py:371-548): the 3x3 average pool with count_include_pad=False
  * (adjoint = 1: its backward), the gating MLP's Linears (tiny: N x Cin -> Cout, one wave per output), row softmax (dy != NULL:
  * backward from the softmax output), dst[n] = src[n] * w[n * w_stride] (the per-image operation weights), per-image dot

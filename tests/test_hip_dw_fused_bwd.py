@@ -187,3 +187,24 @@ def test_plain_depthwise_3x3_with_split_halves(relu, bias):
     assert float((dw - wr.grad).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)
     if bias:
         assert float((db - br.grad).abs().max()) < 2e-5 * s * max(1.0, float(br.grad.abs().max()) / s)
+
+
+@pytest.mark.parametrize('Kk', [5, 7])
+def test_depthwise_backward_accumulates_into_dx(Kk):
+    """dx_out += (MSFN: the 5x5 branch adds its input gradient onto the 3x3 branch's): inside the one-pass 5x5 kernel, through a
+    temporary + add for the kernels that cannot (K = 7 here)"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    N, C, H, W = 2, 6, 33, 64
+    g = torch.Generator().manual_seed(Kk)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    w = (torch.randn(C, 1, Kk, Kk, generator=g) * 0.2).cuda()
+    dy = torch.randn(N, C, H, W, generator=g).cuda()
+    base = torch.randn(N, C, H, W, generator=g).cuda()
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, None, padding=Kk // 2, groups=C).backward(dy)
+    dx = base.clone()
+    out, _, _ = K.dwk_bwd(dy, None, x, w, dx_out=dx, accumulate=True)
+    assert out.data_ptr() == dx.data_ptr()
+    assert float((dx - (base + xr.grad)).abs().max()) < 5e-5

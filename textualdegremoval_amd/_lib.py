@@ -196,6 +196,8 @@ SIGNATURES = {
     'tdr_tksa_softmax': (i32, [c_fp, c_fp, c_fp, c_fp, C.POINTER(i32), i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_tksa_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, C.POINTER(i32), c_fp, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwk_fwd': (i32, [c_fp, i64, c_fp, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
+    'tdr_dwk_bwd_can_accumulate': (i32, [i32, i32, i32, i64, i64, i64, i64]),
+    'tdr_dwk_bwd_acc': (i32, [c_fp, i64, c_fp, i64, c_fp, i64, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwk_bwd': (i32, [c_fp, i64, c_fp, i64, c_fp, i64, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, i64, c_fp, c_fp, c_fp, c_fp]),
     'tdr_avgpool3': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_add_relu': (i32, [c_fp, c_fp, i64, c_fp, c_fp]),

@@ -201,6 +201,7 @@ struct Dw5Args {
     float* dx; long dx_ns;
     float* part;
     int mult, H, W, tprw_log2, rpt, ncb;
+    int accumulate;      // dx += instead of dx = (the sum of two branches' input gradients without a separate add pass)
 };
 
 __global__ __launch_bounds__(256) void dwk5_bwd_fused_kernel(Dw5Args a) {
@@ -254,7 +255,11 @@ __global__ __launch_bounds__(256) void dwk5_bwd_fused_kernel(Dw5Args a) {
                     acc[ky * K + kx] += gw[R].v[e + R] * xw[ky].v[e + kx];
                 }
         acc[KK] += (gw[R].v[2] + gw[R].v[3]) + (gw[R].v[4] + gw[R].v[5]);
-        if (active && yc < H) *reinterpret_cast<f32x4*>(dxp + (long)yc * W + x0) = f32x4{o[0], o[1], o[2], o[3]};
+        if (active && yc < H) {
+            f32x4 v = {o[0], o[1], o[2], o[3]};
+            if (a.accumulate) v += *reinterpret_cast<const f32x4*>(dxp + (long)yc * W + x0);
+            *reinterpret_cast<f32x4*>(dxp + (long)yc * W + x0) = v;
+        }
 #pragma unroll
         for (int k = 0; k < K - 1; ++k) { xw[k] = xw[k + 1]; gw[k] = gw[k + 1]; }
     }
@@ -498,6 +503,17 @@ extern "C" int64_t tdr_dwk_bwd_ws_floats(int N, int Cout, int mult, int H, int W
 extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns, const float* w,
                            int N, int Cout, int mult, int H, int W, int K, int dil, float* dx, int64_t dx_ns, float* dw, float* db,
                            float* ws, void* stream) {
+    return tdr_dwk_bwd_acc(dy, dy_ns, yact, y_ns, x, x_ns, w, N, Cout, mult, H, W, K, dil, dx, dx_ns, 0, dw, db, ws, stream);
+}
+
+// accumulate != 0: dx += (one-pass 5x5 kernel only; tdr_dwk_bwd_can_accumulate tells whether these arguments take it)
+extern "C" int tdr_dwk_bwd_can_accumulate(int W, int K, int dil, int64_t dy_ns, int64_t y_ns, int64_t x_ns, int64_t dx_ns) {
+    return K == 5 && dil == 1 && W % 4 == 0 && ((dy_ns | y_ns | x_ns | dx_ns) & 3) == 0 && getenv("TDR_DWK_TILED") == nullptr;
+}
+
+extern "C" int tdr_dwk_bwd_acc(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns,
+                               const float* w, int N, int Cout, int mult, int H, int W, int K, int dil, float* dx, int64_t dx_ns,
+                               int accumulate, float* dw, float* db, float* ws, void* stream) {
     TDR_REQUIRE(dy && x && w && dx && dw && ws && N > 0 && Cout > 0 && (mult == 1 || mult == 2) && (K == 1 || K == 3 || K == 5 || K == 7) &&
                     (dil == 1 || (dil == 2 && K > 1)), "tdr_dwk_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -514,13 +530,14 @@ extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, in
         if (rpt > 32) rpt = 32;
         const int nb = ncb * tdr_cdiv(H, spb * rpt);
         if (nb <= tiles) {                                                              // (the partials fit the tiled layout's scratch)
-            Dw5Args a{dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, w, dx, (long)dx_ns, ws, mult, H, W, lg, rpt, ncb};
+            Dw5Args a{dy, (long)dy_ns, yact, (long)y_ns, x, (long)x_ns, w, dx, (long)dx_ns, ws, mult, H, W, lg, rpt, ncb, accumulate};
             hipLaunchKernelGGL(dwk5_bwd_fused_kernel, dim3(nb, Cout * mult, N), dim3(256), 0, st, a);
             hipLaunchKernelGGL(dwk_wgrad_finish_kernel, dim3(Cout * mult), dim3(256), 0, st, ws, N * nb, K * K, mult, dw, db);
             TDR_LAUNCH_CHECK("dwk5_bwd_fused");
             return TDR_OK;
         }
     }
+    TDR_REQUIRE(!accumulate, "tdr_dwk_bwd_acc: accumulate needs the one-pass 5x5 kernel (see tdr_dwk_bwd_can_accumulate)");
 #define X(K_, D_)                                                                                                                          \
     if (K == K_ && dil == D_) {                                                                                                            \
         hipLaunchKernelGGL((dwk_tiled_kernel<K_, D_, true>), dim3(tiles, Cout, N), dim3(256), 0, st, dy, (long)dy_ns, yact, (long)y_ns, w, \

@@ -114,11 +114,15 @@ def ffn_bwd(dout, P, saved, G):
         dt2, dw, db = K.dwk_bwd((dx1[:, :h], dx2[:, :h]), a3, t2, P['ffn.dwconv3x3.weight'], want_db='ffn.dwconv3x3.bias' in P)
         put('ffn.dwconv3x3', dw, db)
         has_b = 'ffn.dwconv5x5.bias' in P
-        dt2b, dw5 = torch.empty_like(t2), torch.empty_like(w5)
+        dw5 = torch.empty_like(w5)
         db5 = torch.empty(2 * h, dtype=torch.float32, device=t2.device) if has_b else None
-        K.dwk_bwd(dx1[:, h:], a5[0], t2[:, :h], w5[:h], want_db=has_b, dx_out=dt2b[:, :h], dw_out=dw5[:h], db_out=None if db5 is None else db5[:h])
-        K.dwk_bwd(dx2[:, h:], a5[1], t2[:, h:], w5[h:], want_db=has_b, dx_out=dt2b[:, h:], dw_out=dw5[h:], db_out=None if db5 is None else db5[h:])
+        # the 5x5 branch adds its input gradient onto the 3x3 branch's inside the kernel
+        K.dwk_bwd(dx1[:, h:], a5[0], t2[:, :h], w5[:h], want_db=has_b, dx_out=dt2[:, :h], dw_out=dw5[:h],
+                  db_out=None if db5 is None else db5[:h], accumulate=True)
+        K.dwk_bwd(dx2[:, h:], a5[1], t2[:, h:], w5[h:], want_db=has_b, dx_out=dt2[:, h:], dw_out=dw5[h:],
+                  db_out=None if db5 is None else db5[h:], accumulate=True)
         put('ffn.dwconv5x5', dw5, db5)
+        return R._pw_bwd(dt2, yn, P, 'ffn.project_in', G)
     else:
         da3 = K.concat2(dx1[:, :h], dx2[:, :h])
         da5 = K.concat2(dx1[:, h:], dx2[:, h:])

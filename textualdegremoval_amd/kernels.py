@@ -1348,10 +1348,10 @@ def dwk_fwd(x, w, b=None, relu=False, dil=1, out=None):
     return y
 
 
-def dwk_bwd(dy, y_act, x, w, want_db=False, dil=1, dx_out=None, dw_out=None, db_out=None):
+def dwk_bwd(dy, y_act, x, w, want_db=False, dil=1, dx_out=None, dw_out=None, db_out=None, accumulate=False):
     """-> (dx, dw, db); y_act: the forward output when a ReLU was fused (its mask), else None.  dy / y_act may be (first half, second
     half) tuples of channel slices for the plain depthwise 3x3 (see dwk_fwd); dx_out / dw_out / db_out: optional destinations (dx_out
-    dense per image, e.g. a channel slice)"""
+    dense per image, e.g. a channel slice); accumulate: dx_out += instead of = (inside the one-pass 5x5 kernel, else a separate add)"""
     N, Cin, H, W = x.shape
     Cout, mult, Kk, _ = w.shape
     dx = torch.empty(N, Cin, H, W, dtype=torch.float32, device=x.device) if dx_out is None else dx_out
@@ -1381,9 +1381,14 @@ def dwk_bwd(dy, y_act, x, w, want_db=False, dil=1, dx_out=None, dw_out=None, db_
               'tdr_dwpair_bwd')
         return dx, dw, db
     ws = workspace(lib.tdr_dwk_bwd_ws_floats(N, Cout, mult, H, W, Kk), x.device, 'dwk')
-    check(lib.tdr_dwk_bwd(dy.data_ptr(), _dense_nchw(dy), _p(y_act), _dense_nchw(y_act) if y_act is not None else 0, x.data_ptr(),
-                          _dense_nchw(x), w.data_ptr(), N, Cout, mult, H, W, Kk, int(dil), dx.data_ptr(), _dense_nchw(dx), dw.data_ptr(),
-                          _p(db), ws.data_ptr(), _stream()), 'tdr_dwk_bwd')
+    y_ns = _dense_nchw(y_act) if y_act is not None else 0
+    acc_in_kernel = accumulate and lib.tdr_dwk_bwd_can_accumulate(W, Kk, int(dil), _dense_nchw(dy), y_ns, _dense_nchw(x), _dense_nchw(dx)) != 0
+    tgt = dx if (not accumulate or acc_in_kernel) else torch.empty(N, Cin, H, W, dtype=torch.float32, device=x.device)
+    check(lib.tdr_dwk_bwd_acc(dy.data_ptr(), _dense_nchw(dy), _p(y_act), y_ns, x.data_ptr(), _dense_nchw(x), w.data_ptr(), N, Cout, mult,
+                              H, W, Kk, int(dil), tgt.data_ptr(), _dense_nchw(tgt), 1 if acc_in_kernel else 0, dw.data_ptr(), _p(db),
+                              ws.data_ptr(), _stream()), 'tdr_dwk_bwd')
+    if tgt is not dx:
+        add_(dx, tgt)
     return dx, dw, db
 
 
