@@ -430,6 +430,10 @@ int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int 
 /* multi-head softmax(q k^T scale) v over the first T columns; qkv [B][3C][LD] -> out [B][C][LD] (padding columns zeroed);
  * head dim C/heads in {16,32,64} (attention.py:56-71) */
 int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream);
+/* the same with the arithmetic named: math 0 = exact fp32 MFMA (what tdr_attention_fwd runs), 2 = 2-way fp16 split (3 f16 MFMA
+ * products per fp32 product, fp32 accumulate and softmax) for the frozen no-grad ViTs -- q, k, v must lie in the fp16 range */
+int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, float* out,
+                           void* stream);
 /* cosine similarity of flattened patch-token maps (columns 1..T1-1), first arg-max, window gather:
  * fl [B][D][LD], fr [B*N][D][LD], windows [B*N][per] -> corr [B][N], index [B] (int32), ref_in [B][per] (:230-243) */
 int tdr_token_match(const float* fl, const float* fr, const float* windows, int B, int N, int D, int T1, int LD, int64_t per,

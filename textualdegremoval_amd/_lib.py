@@ -177,6 +177,7 @@ SIGNATURES = {
     'tdr_unfold_windows': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_patchify': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_vit_assemble': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
+    'tdr_attention_fwd_math': (i32, [c_fp, i32, i32, i32, i32, i32, f32, i32, c_fp, c_fp]),
     'tdr_attention_fwd': (i32, [c_fp, i32, i32, i32, i32, i32, f32, c_fp, c_fp]),
     'tdr_token_match': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i64, c_fp, c_fp, c_fp, c_fp]),
     'tdr_optim_chunk': (i32, []),

@@ -181,6 +181,176 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+// The same attention on the 2-way fp16 split (TDR_MATH=hx2: every fp32 product as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate and fp32 softmax) for the frozen, no-grad ViTs (DINOv2 matcher, CLIP image encoder):
+// 12 + 12 f16 MFMAs of 32 cycles per 32-key tile instead of 32 + 32 fp32 MFMAs of 64 cycles.  Same skeleton: S^T = K Q^T with a
+// lane owning one query column; P^T is split in registers and is already the B operand of O^T += V^T P^T, whose contraction
+// walks the keys in the accumulator's row order -- slot (s, kk, i) of a 16-key step is key 16 s + 4 kk + (i & 3) + 8 (i >> 2), so
+// the A operand is two 8-byte LDS reads.  K / V tiles are converted to hi / lo halves once per workgroup while they are staged.
+typedef _Float16 vh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vh4 __attribute__((ext_vector_type(4)));
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
+    constexpr int NDT = (HD + 31) / 32, KS = HD / 16, NOCT = HD / 8;
+    constexpr int VP = 40;                                  // halves per d row of the V tile
+    constexpr int KIT = (NOCT * 32 + 255) / 256;            // K slots (8 d x 1 key, 16 bytes per plane) per thread and tile
+    constexpr int VIT = HD * 32 / 256;                      // V elements per thread and tile
+    static_assert(HD % 16 == 0, "head dim must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) vh8 sK[2][NOCT][32];          // [hi | lo][d octet][key]: one fragment per slot
+    __shared__ __attribute__((aligned(16))) _Float16 sV[2][NDT * 32][VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
+    const int C = a.C, T = a.Tk, LD = a.LDk, LDq = a.LDq;
+    float* out = a.out;
+    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * LDq;
+    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * LD;
+    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * LD;
+    const bool qok = q0 + j < a.Tq;
+    vh8 qh[KS], ql[KS];                                     // B operand of S^T: Q[q = j][d = 16 s + 8 kk + i] * scale, hi / lo
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = qok ? Q[(long)(16 * s + 8 * kk + i) * LDq + q0 + j] * a.scale : 0.f;
+            asm volatile("" : "+v"(v));                     // one fp32 value for head and residual
+            const _Float16 hh = (_Float16)v;
+            qh[s][i] = hh;
+            ql[s][i] = (_Float16)(v - (float)hh);
+        }
+    for (int e = tid; e < 2 * (NDT * 32 - HD) * VP; e += 256)   // d rows beyond the head dim (HD = 16, 80): zero once
+        (&sV[0][0][0])[(e / ((NDT * 32 - HD) * VP)) * (NDT * 32 * VP) + HD * VP + e % ((NDT * 32 - HD) * VP)] = (_Float16)0.f;
+    // K / V of the next tile are requested while the current one is multiplied (registers), converted and stored after it
+    float rk[KIT][8], rv[VIT];
+    auto load_tile = [&](int key0) {
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int slot = tid + 256 * it, oc = slot >> 5, kx = slot & 31;
+            const bool ok = oc < NOCT && key0 + kx < T;
+            const int kc = key0 + kx < T ? key0 + kx : T - 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rk[it][i] = ok ? Kp[(long)(8 * (oc < NOCT ? oc : 0) + i) * LD + kc] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int e = tid + 256 * it, d = e >> 5, kx = e & 31;
+            const int kc = key0 + kx < T ? key0 + kx : T - 1;
+            const float vv = Vp[(long)d * LD + kc];
+            rv[it] = key0 + kx < T ? vv : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int slot = tid + 256 * it, oc = slot >> 5, kx = slot & 31;
+            vh8 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = rk[it][i];
+                asm volatile("" : "+v"(v));
+                const _Float16 hh = (_Float16)v;
+                hi[i] = hh;
+                lo[i] = (_Float16)(v - (float)hh);
+            }
+            if (oc < NOCT) { sK[0][oc][kx] = hi; sK[1][oc][kx] = lo; }
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int e = tid + 256 * it, d = e >> 5, kx = e & 31;
+            float v = rv[it];
+            asm volatile("" : "+v"(v));
+            const _Float16 hh = (_Float16)v;
+            sV[0][d][kx] = hh;
+            sV[1][d][kx] = (_Float16)(v - (float)hh);
+        }
+    };
+    f32x16 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    load_tile(0);
+    for (int key0 = 0; key0 < T; key0 += 32) {
+        __syncthreads();                                   // everyone is done with the previous K/V tile
+        store_tile();
+        __syncthreads();
+        if (key0 + 32 < T) load_tile(key0 + 32);
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const vh8 kh = sK[0][2 * s + kk][j];
+            const vh8 kl = sK[1][2 * s + kk][j];
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], st, 0, 0, 0);       // small cross terms first
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], st, 0, 0, 0);
+        }
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            st[r] = key < T ? st[r] : -1e30f;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            st[r] = key < T ? __expf(st[r] - mnew) : 0.f;
+            sum += st[r];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float alpha = __expf(m - mnew);
+        l = l * alpha + sum;
+        m = mnew;
+        vh8 ph[2], pl[2];                                   // P^T, two 16-key steps, in the accumulator's row order
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float pv = st[8 * s + i];
+                asm volatile("" : "+v"(pv));
+                const _Float16 hh = (_Float16)pv;
+                ph[s][i] = hh;
+                pl[s][i] = (_Float16)(pv - (float)hh);
+            }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            const int d = dt * 32 + j;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int kb = 16 * s + 4 * kk;
+                vh8 vh, vl;
+                const vh4 a0 = *reinterpret_cast<const vh4*>(&sV[0][d][kb]), a1 = *reinterpret_cast<const vh4*>(&sV[0][d][kb + 8]);
+                const vh4 b0 = *reinterpret_cast<const vh4*>(&sV[1][d][kb]), b1 = *reinterpret_cast<const vh4*>(&sV[1][d][kb + 8]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { vh[i] = a0[i]; vh[4 + i] = a1[i]; vl[i] = b0[i]; vl[4 + i] = b1[i]; }
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[dt], 0, 0, 0);
+            }
+        }
+    }
+    const float inv = 1.f / l;
+    if (q0 + j < LDq) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (d < HD) out[((long)b * C + h * HD + d) * LDq + q0 + j] = qok ? o[dt][r] * inv : 0.f;
+            }
+        if (a.lse && kk == 0) a.lse[((long)b * gridDim.y + h) * LDq + q0 + j] = qok ? m + __logf(l) : 0.f;
+    }
+}
+
 // ---- backward (injected cross-attention of the stage-A trainers, main_train_i2t_mapping.py:197-233) ----------------
 // Two deterministic passes instead of one with atomics:
 //   attn_bwd_dq : one wave per 32 queries, walks the key tiles (same skeleton as the forward: S^T, then dP^T = V dO^T
@@ -457,9 +627,17 @@ extern "C" int tdr_vit_assemble(float* tok, const float* cls, const float* pos, 
     return TDR_OK;
 }
 
-static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st) {
+static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st, int math = 0) {
     const int hd = a.C / heads;
     dim3 grid(tdr_cdiv(a.LDq, 128), heads, B);
+    if (math == 2 && (hd == 80 || hd == 64 || hd == 32 || hd == 16)) {
+        if (hd == 80) hipLaunchKernelGGL(attn_fwd_hx2_kernel<80>, grid, dim3(256), 0, st, a);
+        else if (hd == 64) hipLaunchKernelGGL(attn_fwd_hx2_kernel<64>, grid, dim3(256), 0, st, a);
+        else if (hd == 32) hipLaunchKernelGGL(attn_fwd_hx2_kernel<32>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_fwd_hx2_kernel<16>, grid, dim3(256), 0, st, a);
+        TDR_LAUNCH_CHECK("attention_fwd_hx2");
+        return TDR_OK;
+    }
     if (hd == 80) hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, dim3(256), 0, st, a);
     else if (hd == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, a);
     else if (hd == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, a);
@@ -470,9 +648,15 @@ static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st) 
 }
 
 extern "C" int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream) {
-    TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T, "tdr_attention_fwd: bad argument");
+    return tdr_attention_fwd_math(qkv, B, C, heads, T, LD, scale, 0, out, stream);
+}
+
+// math 0: exact fp32 MFMA; 2: 2-way fp16 split (operands within the fp16 range: LayerNorm-ed ViT activations)
+extern "C" int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, float* out,
+                                      void* stream) {
+    TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T && (math == 0 || math == 2), "tdr_attention_fwd: bad argument");
     AttnArgs a{qkv, 3L * C * LD, LD, T, qkv + (long)C * LD, qkv + 2L * C * LD, 3L * C * LD, LD, T, C, scale, out, nullptr};
-    return attn_fwd_launch(a, B, heads, (hipStream_t)stream);
+    return attn_fwd_launch(a, B, heads, (hipStream_t)stream, math);
 }
 
 extern "C" int tdr_cross_attention_fwd(const float* q, const float* k, const float* v, int B, int C, int heads, int Tq, int LDq,

@@ -966,7 +966,9 @@ def attention_fwd(qkv, heads, scale, T1):
     Cc, LD = C3 // 3, qkv.shape[2] * qkv.shape[3]
     assert qkv.is_contiguous()
     out = torch.empty(B, Cc, qkv.shape[2], qkv.shape[3], dtype=torch.float32, device=qkv.device)
-    check(_lib.load().tdr_attention_fwd(qkv.data_ptr(), B, Cc, heads, T1, LD, float(scale), out.data_ptr(), _stream()),
+    # the frozen ViTs (no gradient flows through this attention): on the fp16 split whenever the dense contractions are
+    math = 2 if (MATH in ('hx2', 'h1') and os.environ.get('TDR_ATTN_F32', '0') != '1') else 0
+    check(_lib.load().tdr_attention_fwd_math(qkv.data_ptr(), B, Cc, heads, T1, LD, float(scale), math, out.data_ptr(), _stream()),
           'tdr_attention_fwd')
     return out
 
