@@ -538,15 +538,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
 }
 
 // corr[b][n] = <L_b, R_{b,n}> / (max(|L_b|,1e-12) max(|R_{b,n}|,1e-12)) over the patch tokens (columns 1..T of [D][1+T])
+// Two stages: CORR_SPLIT workgroups per (image, window), each over a band of the D rows, write (dot, |L|^2, |R|^2) partials; the
+// finish sums them in a fixed order.  (One workgroup per pair was 16 workgroups streaming 8.4 MB each: 1.9 ms per step.)
+constexpr int CORR_SPLIT = 48;
 __global__ __launch_bounds__(256) void token_corr_kernel(const float* __restrict__ fl, const float* __restrict__ fr, int D, int T1,
-                                                        int LD, int N, float* __restrict__ corr) {
+                                                        int LD, int N, float* __restrict__ part) {
     __shared__ float red[3][4];
-    const int n = blockIdx.x, b = blockIdx.y;
+    const int n = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int rows = (D + CORR_SPLIT - 1) / CORR_SPLIT, d0 = sp * rows, d1 = min(D, d0 + rows);
     const float* L = fl + (long)b * D * LD;
     const float* R = fr + ((long)b * N + n) * D * LD;
     float dot = 0.f, nl = 0.f, nr = 0.f;
-    const long tot = (long)D * LD;
-    for (long i = threadIdx.x; i < tot; i += 256) {
+    for (long i = (long)d0 * LD + threadIdx.x; i < (long)d1 * LD; i += 256) {
         const int col = (int)(i % LD);
         if (col == 0 || col >= T1) continue;         // class token column, padding
         const float a = L[i], c = R[i];
@@ -555,12 +558,20 @@ __global__ __launch_bounds__(256) void token_corr_kernel(const float* __restrict
     dot = wave_sum(dot); nl = wave_sum(nl); nr = wave_sum(nr);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dot; red[1][threadIdx.x >> 6] = nl; red[2][threadIdx.x >> 6] = nr; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float d = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        const float a = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        const float c = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-        corr[(long)b * N + n] = d / (fmaxf(sqrtf(a), 1e-12f) * fmaxf(sqrtf(c), 1e-12f));
+    if (threadIdx.x < 3)
+        part[(((long)b * N + n) * CORR_SPLIT + sp) * 3 + threadIdx.x] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+__global__ void token_corr_finish_kernel(const float* __restrict__ part, int pairs, float* __restrict__ corr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pairs) return;
+    float d = 0.f, a = 0.f, c = 0.f;
+    for (int sp = 0; sp < CORR_SPLIT; ++sp) {
+        d += part[((long)i * CORR_SPLIT + sp) * 3];
+        a += part[((long)i * CORR_SPLIT + sp) * 3 + 1];
+        c += part[((long)i * CORR_SPLIT + sp) * 3 + 2];
     }
+    corr[i] = d / (fmaxf(sqrtf(a), 1e-12f) * fmaxf(sqrtf(c), 1e-12f));
 }
 
 // index[b] = argmax_n corr[b][n] (first maximum, like torch.topk); out[b] = windows[b][index[b]]
@@ -696,7 +707,10 @@ extern "C" int tdr_token_match(const float* fl, const float* fr, const float* wi
                                float* corr, int* index, float* ref_in, void* stream) {
     TDR_REQUIRE(fl && fr && windows && corr && index && ref_in && N > 0, "tdr_token_match: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(token_corr_kernel, dim3(N, B), dim3(256), 0, st, fl, fr, D, T1, LD, N, corr);
+    // the partials live at the start of ref_in until select_window_kernel overwrites it (stream order): B*N*48*3 floats << B*per
+    TDR_REQUIRE((int64_t)B * per >= (int64_t)B * N * CORR_SPLIT * 3, "tdr_token_match: ref_in too small for the correlation partials");
+    hipLaunchKernelGGL(token_corr_kernel, dim3(N, B, CORR_SPLIT), dim3(256), 0, st, fl, fr, D, T1, LD, N, ref_in);
+    hipLaunchKernelGGL(token_corr_finish_kernel, dim3(tdr_cdiv(B * N, 64)), dim3(64), 0, st, ref_in, B * N, corr);
     hipLaunchKernelGGL(select_window_kernel, dim3(vgrid(per, 256), B), dim3(256), 0, st, corr, windows, N, (long)per, index, ref_in);
     TDR_LAUNCH_CHECK("token_match");
     return TDR_OK;
