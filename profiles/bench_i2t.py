@@ -49,6 +49,25 @@ def main():
         out = mp([tok])
         out.backward(torch.ones_like(out))
     res['mapper20_fwd_bwd_ms_bs4'] = timeit(mapper_step, n=3, warm=1)
+    # the same forward + backward replayed as one hipGraph (what a trainer's captured step does: the ~1 200 launches and the four
+    # stream lanes become graph nodes / branches, no host launch time)
+    try:
+        from textualdegremoval_amd import kernels as KK
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                mapper_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        refs = []
+        with torch.cuda.graph(g, capture_error_mode='thread_local'), KK.workspace_capture(refs):
+            mapper_step()
+        torch.cuda.synchronize()
+        res['mapper20_fwd_bwd_ms_bs4_hipgraph'] = timeit(g.replay, n=5, warm=2)
+    except Exception as e:  # noqa: BLE001
+        res['mapper20_fwd_bwd_ms_bs4_hipgraph'] = f'capture failed: {type(e).__name__}: {str(e)[:120]}'
     ctx = torch.randn(B, 77, 1024, device='cuda', requires_grad=True)
     for Tq, dim, heads in ((4096, 320, 5), (1024, 640, 10), (256, 1280, 20), (64, 1280, 20)):
         g = torch.Generator().manual_seed(dim)

@@ -138,6 +138,49 @@ def test_mapper_on_channel_major_clip_tokens_matches_oracle(K):
     assert maxdiff(out, ref) < 1e-4
 
 
+def test_mapper_forward_backward_replayed_as_hipgraph_matches_eager(K):
+    """the Mapper's forward + backward (40 small MLP chains on four stream lanes) captured once and replayed as one hipGraph, the
+    way a trainer's captured step runs it: outputs and every parameter gradient equal the eager ones on fresh inputs"""
+    from textualdegremoval_amd import kernels as KK
+    from textualdegremoval_amd.i2t import Mapper
+    P = IO.synth_mapper_params(64, 1280, 24, 6, seed=9)
+    mp = Mapper(64, 24, 6).cuda()
+    mp.load_state_dict(P)
+    gen = torch.Generator().manual_seed(3)
+    emb = torch.randn(2, 9, 64, generator=gen).cuda()
+    go = torch.randn(2, 6, 24, generator=gen).cuda()
+
+    def step():
+        for p in mp.parameters():
+            p.grad = None
+        out = mp([emb])
+        (out * go).sum().backward()
+        return out
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g, refs = torch.cuda.CUDAGraph(), []
+    with torch.cuda.graph(g, capture_error_mode='thread_local'), KK.workspace_capture(refs):
+        out_g = step()
+    grads_g = {k: p.grad for k, p in mp.named_parameters()}
+    emb.copy_(torch.randn(2, 9, 64, generator=gen).cuda())      # new inputs in the captured buffers
+    go.copy_(torch.randn(2, 6, 24, generator=gen).cuda())
+    g.replay()
+    torch.cuda.synchronize()
+    got_out = out_g.clone()
+    got = {k: v.clone() for k, v in grads_g.items()}
+    want_out = step()
+    torch.cuda.synchronize()
+    assert maxdiff(got_out, want_out) == 0
+    for k, p in mp.named_parameters():
+        assert maxdiff(got[k], p.grad) <= 1e-6 * max(1.0, p.grad.abs().max().item()), k
+
+
 @pytest.mark.parametrize('tag', ['x', 's'])
 def test_injected_cross_attention_vs_reference_golden(K, tag):
     """inj_forward_crossattention forward + all gradients (hidden, context, the five weight tensors)."""
