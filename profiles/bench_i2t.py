@@ -38,6 +38,25 @@ def main():
         res[name + '_fwd_ms_bs4'] = ms
         if flop:
             res[name + '_fwd_tflops'] = flop * B / (ms * 1e-3) / 1e12
+        try:      # the frozen encoder as one hipGraph (how a captured trainer step would hold it)
+            from textualdegremoval_amd import kernels as KK
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                enc.encode(img)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g, refs = torch.cuda.CUDAGraph(), []
+            with torch.cuda.graph(g, capture_error_mode='thread_local'), KK.workspace_capture(refs):
+                held = enc.encode(img)
+            torch.cuda.synchronize()
+            gms = timeit(g.replay)
+            res[name + '_fwd_ms_bs4_hipgraph'] = gms
+            if flop:
+                res[name + '_fwd_tflops_hipgraph'] = flop * B / (gms * 1e-3) / 1e12
+            del g, held
+        except Exception as e:  # noqa: BLE001
+            res[name + '_fwd_ms_bs4_hipgraph'] = f'capture failed: {type(e).__name__}: {str(e)[:120]}'
         if name == 'vit_h14':
             tok = enc.encode(img)
         del enc
