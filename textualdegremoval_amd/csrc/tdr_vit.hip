@@ -5,6 +5,7 @@
 //   models/dino/attention.py:36-71                  softmax(q k^T * d^-1/2) v, all heads
 // Activations are channel-major [B][D][T] so every Linear of the ViT is a 1x1 convolution on the matrix-core
 // kernels and the token LayerNorm is the channel LayerNorm kernel (eps 1e-6 in both networks).
+#include <stdlib.h>
 #include "tdr_common.h"
 #include "../../include/tdr.h"
 
@@ -190,14 +191,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 typedef _Float16 vh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 vh4 __attribute__((ext_vector_type(4)));
 
-template <int HD>
+template <int HD, int KT>
 __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
-    constexpr int NDT = (HD + 31) / 32, KS = HD / 16, NOCT = HD / 8;
-    constexpr int VP = 40;                                  // halves per d row of the V tile
-    constexpr int KIT = (NOCT * 32 + 255) / 256;            // K slots (8 d x 1 key, 16 bytes per plane) per thread and tile
-    constexpr int VIT = HD * 32 / 256;                      // V elements per thread and tile
-    static_assert(HD % 16 == 0, "head dim must be a multiple of 16");
-    __shared__ __attribute__((aligned(16))) vh8 sK[2][NOCT][32];          // [hi | lo][d octet][key]: one fragment per slot
+    constexpr int NDT = (HD + 31) / 32, KS = HD / 16, NOCT = HD / 8, NKB = KT / 32;
+    constexpr int VP = KT + 8;                              // halves per d row of the V tile
+    constexpr int KIT = (NOCT * KT + 255) / 256;            // K slots (8 d x 1 key, 16 bytes per plane) per thread and tile
+    constexpr int VIT = HD * KT / 256;                      // V elements per thread and tile
+    static_assert(HD % 16 == 0 && (KT == 32 || KT == 64), "head dim must be a multiple of 16, key tile 32 or 64");
+    __shared__ __attribute__((aligned(16))) vh8 sK[2][NOCT][KT];          // [hi | lo][d octet][key]: one fragment per slot
     __shared__ __attribute__((aligned(16))) _Float16 sV[2][NDT * 32][VP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
     const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
     auto load_tile = [&](int key0) {
 #pragma unroll
         for (int it = 0; it < KIT; ++it) {
-            const int slot = tid + 256 * it, oc = slot >> 5, kx = slot & 31;
+            const int slot = tid + 256 * it, oc = slot / KT, kx = slot % KT;
             const bool ok = oc < NOCT && key0 + kx < T;
             const int kc = key0 + kx < T ? key0 + kx : T - 1;
 #pragma unroll
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
-            const int e = tid + 256 * it, d = e >> 5, kx = e & 31;
+            const int e = tid + 256 * it, d = e / KT, kx = e % KT;
             const int kc = key0 + kx < T ? key0 + kx : T - 1;
             const float vv = Vp[(long)d * LD + kc];
             rv[it] = key0 + kx < T ? vv : 0.f;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < KIT; ++it) {
-            const int slot = tid + 256 * it, oc = slot >> 5, kx = slot & 31;
+            const int slot = tid + 256 * it, oc = slot / KT, kx = slot % KT;
             vh8 hi, lo;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
-            const int e = tid + 256 * it, d = e >> 5, kx = e & 31;
+            const int e = tid + 256 * it, d = e / KT, kx = e % KT;
             float v = rv[it];
             asm volatile("" : "+v"(v));
             const _Float16 hh = (_Float16)v;
@@ -272,61 +273,68 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
     float m = -1e30f, l = 0.f;
 
     load_tile(0);
-    for (int key0 = 0; key0 < T; key0 += 32) {
+    for (int key0 = 0; key0 < T; key0 += KT) {
         __syncthreads();                                   // everyone is done with the previous K/V tile
         store_tile();
         __syncthreads();
-        if (key0 + 32 < T) load_tile(key0 + 32);
-        f32x16 st;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const vh8 kh = sK[0][2 * s + kk][j];
-            const vh8 kl = sK[1][2 * s + kk][j];
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], st, 0, 0, 0);       // small cross terms first
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], st, 0, 0, 0);
-        }
+        if (key0 + KT < T) load_tile(key0 + KT);
+        f32x16 st[NKB];
         float mx = -1e30f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            st[r] = key < T ? st[r] : -1e30f;
-            mx = fmaxf(mx, st[r]);
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const vh8 kh = sK[0][2 * s + kk][kb * 32 + j];
+                const vh8 kl = sK[1][2 * s + kk][kb * 32 + j];
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], st[kb], 0, 0, 0);       // small cross terms first
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], st[kb], 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], st[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                st[kb][r] = key < T ? st[kb][r] : -1e30f;
+                mx = fmaxf(mx, st[kb][r]);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(m, mx);
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            st[r] = key < T ? __expf(st[r] - mnew) : 0.f;
-            sum += st[r];
-        }
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                st[kb][r] = key < T ? __expf(st[kb][r] - mnew) : 0.f;
+                sum += st[kb][r];
+            }
         sum += __shfl_xor(sum, 32, 64);
         const float alpha = __expf(m - mnew);
         l = l * alpha + sum;
         m = mnew;
-        vh8 ph[2], pl[2];                                   // P^T, two 16-key steps, in the accumulator's row order
+        vh8 ph[2 * NKB], pl[2 * NKB];                       // P^T in 16-key steps, in the accumulator's row order
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float pv = st[8 * s + i];
-                asm volatile("" : "+v"(pv));
-                const _Float16 hh = (_Float16)pv;
-                ph[s][i] = hh;
-                pl[s][i] = (_Float16)(pv - (float)hh);
-            }
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float pv = st[kb][8 * s + i];
+                    asm volatile("" : "+v"(pv));
+                    const _Float16 hh = (_Float16)pv;
+                    ph[2 * kb + s][i] = hh;
+                    pl[2 * kb + s][i] = (_Float16)(pv - (float)hh);
+                }
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             const int d = dt * 32 + j;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int kb = 16 * s + 4 * kk;
+            for (int s = 0; s < 2 * NKB; ++s) {
+                const int kb = (s >> 1) * 32 + 16 * (s & 1) + 4 * kk;
                 vh8 vh, vl;
                 const vh4 a0 = *reinterpret_cast<const vh4*>(&sV[0][d][kb]), a1 = *reinterpret_cast<const vh4*>(&sV[0][d][kb + 8]);
                 const vh4 b0 = *reinterpret_cast<const vh4*>(&sV[1][d][kb]), b1 = *reinterpret_cast<const vh4*>(&sV[1][d][kb + 8]);
@@ -642,10 +650,12 @@ static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st, 
     const int hd = a.C / heads;
     dim3 grid(tdr_cdiv(a.LDq, 128), heads, B);
     if (math == 2 && (hd == 80 || hd == 64 || hd == 32 || hd == 16)) {
-        if (hd == 80) hipLaunchKernelGGL(attn_fwd_hx2_kernel<80>, grid, dim3(256), 0, st, a);
-        else if (hd == 64) hipLaunchKernelGGL(attn_fwd_hx2_kernel<64>, grid, dim3(256), 0, st, a);
-        else if (hd == 32) hipLaunchKernelGGL(attn_fwd_hx2_kernel<32>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(attn_fwd_hx2_kernel<16>, grid, dim3(256), 0, st, a);
+        static const int kt = getenv("TDR_ATTN_KT") ? atoi(getenv("TDR_ATTN_KT")) : 32;       // key tile (tuning aid)
+        if (hd == 80) hipLaunchKernelGGL((attn_fwd_hx2_kernel<80, 32>), grid, dim3(256), 0, st, a);
+        else if (hd == 64 && kt == 64) hipLaunchKernelGGL((attn_fwd_hx2_kernel<64, 64>), grid, dim3(256), 0, st, a);
+        else if (hd == 64) hipLaunchKernelGGL((attn_fwd_hx2_kernel<64, 32>), grid, dim3(256), 0, st, a);
+        else if (hd == 32) hipLaunchKernelGGL((attn_fwd_hx2_kernel<32, 32>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_hx2_kernel<16, 32>), grid, dim3(256), 0, st, a);
         TDR_LAUNCH_CHECK("attention_fwd_hx2");
         return TDR_OK;
     }
