@@ -3,7 +3,11 @@
 (BASELINE.json configs[1]: NAFNet-width32 + ref fusion, 512x512, sigma=15, bs=4/GPU).
 
     python bench.py --gpus N --steps K --warmup W
-(N>1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI.)
+N>1: one rank per GPU, RCCL over xGMI.  Either the caller launches the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: WORLD_SIZE is set), or -- called
+plainly, without WORLD_SIZE -- this script re-executes itself under torch.distributed.run with N ranks (the reference's
+entry is `python -m torch.distributed.launch --nproc_per_node=N ...`, README.md:116).  Either way ONE JSON line with
+n_gpus = the number of ranks that took part (`ranks_seen`, read back from the RCCL communicator).
 
 A step = feed_train_data + optimize_parameters of RefGuidedImageCleanModel:
 forward, L1, hand-written backward, gradient all-reduce (N>1), global-norm clip,
@@ -28,7 +32,7 @@ PEAK_BF16 = 2.5e15                    # dense bf16 MFMA (MI355X_MICROARCH.md); t
 PEAK_BX3 = PEAK_BF16 / 6.0
 
 
-def make_opt(width, enc, batch_hw, dist_on, arch='nafnet'):
+def make_opt(width, enc, batch_hw, dist_on, arch='nafnet', bucket_mb=64):
     if arch == 'restormer':      # BASELINE configs[2] / SURVEY 8d cfg3: Restormer-ref dim=nf=48
         net = dict(type='RestormerRefFusion', inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8],
                    num_refinement_blocks=4, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
@@ -58,7 +62,7 @@ def make_opt(width, enc, batch_hw, dist_on, arch='nafnet'):
                                 'restart_weights': [1, 1], 'eta_mins': [3e-4, 1e-6]},
                   'pixel_opt': {'type': 'L1Loss', 'loss_weight': 1, 'reduction': 'mean'},
                   'use_grad_clip': True, 'total_iter': 1000000, 'warmup_iter': -1},
-        'logger': {'check_freq': 10 ** 9}, 'val': {}, 'scale': 1,
+        'logger': {'check_freq': 10 ** 9}, 'val': {}, 'scale': 1, 'dist_bucket_mb': bucket_mb,
     }
 
 
@@ -82,19 +86,23 @@ def _cpu_baseline_worker(width, enc, H, batch, budget):
     threads = min(probe, key=probe.get)
     torch.set_num_threads(threads)
     lq, gt, ref = O.synth_pair(batch, H, H, seed=2)
+    tr.step(lq, gt, ref)                                  # 1 warm-up step at the sample's shape
     t0 = time.time()
     n = 0
     while True:
         tr.step(lq, gt, ref)
         n += 1
-        if time.time() - t0 > budget or n >= 3:
+        if n >= 2 and (time.time() - t0 > budget or n >= 4):
             break
     print(json.dumps({'n': n, 'dt': time.time() - t0, 'threads': threads, 'probe': {str(k): round(v, 3) for k, v in probe.items()}}))
 
 
 def cpu_baseline(width, enc, size, batch, budget=20.0, hard_timeout=300.0):
     """Reported baseline only (never the thing shipped): `oracle/` timed on this host's cores in a child process with a
-    hard timeout, on the metric's own workload (batch x size x size, whole train steps)."""
+    hard timeout, on a bounded sample of the metric's workload: whole train steps of the same network on ONE size x size
+    pair (a quarter of the per-GPU batch; the CPU path is per-sample work, so img/s does not depend on the batch),
+    1 warm-up + >= 2 timed steps."""
+    batch = 1
     import subprocess
     code = (f'import sys; sys.path.insert(0, {ROOT!r}); import bench; '
             f'bench._cpu_baseline_worker({width}, {enc!r}, {size}, {batch}, {budget})')
@@ -106,23 +114,42 @@ def cpu_baseline(width, enc, size, batch, budget=20.0, hard_timeout=300.0):
         return {'value': None, 'unit': 'images/sec', 'cores': None, 'kind': 'port', 'sample': f'failed: {type(e).__name__}'}
     return {'value': r['n'] * batch / r['dt'], 'unit': 'images/sec', 'cores': r['threads'], 'kind': 'port',
             'host_cpus': os.cpu_count(),
-            'sample': f"{r['n']} train step(s) of the same network on {batch} x {size}x{size} pairs (the metric's workload) in "
-                      f"{r['dt']:.1f} s, torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py); threads chosen by a scaling probe "
+            'sample': f"1 warm-up + {r['n']} timed train steps of the same network on {batch} x {size}x{size} pair(s) (the metric's "
+                      f"per-GPU batch is 4 of them) in {r['dt']:.1f} s, torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py); threads chosen by a scaling probe "
                       f"(seconds per 128x128 step by thread count: {r['probe']})"}
+
+
+def _child_bench(args, extra, env=None, timeout=600):
+    """this script again in a child process (1 GPU, no secondary legs); returns its parsed JSON line"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--arch', args.arch, '--batch', str(args.batch), '--size',
+           str(args.size), '--width', str(args.width), '--enc', args.enc, '--no-cpu-baseline', '--no-roofline', '--no-f32-exact',
+           '--no-matcher-active'] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
 
 
 def f32_exact_run(args):
     """the same workload on the exact-fp32 MFMA path (TDR_MATH=f32, v_mfma_f32_32x32x2_f32: bitwise an fmaf chain), a few
     steps in a child process: the price of the split arithmetic's speed-up is visible next to the headline number"""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '3', '--warmup', '1', '--arch', args.arch, '--batch',
-           str(args.batch), '--size', str(args.size), '--width', str(args.width), '--enc', args.enc, '--no-cpu-baseline',
-           '--no-roofline', '--no-f32-exact']
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TDR_MATH='f32'))
-        r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+        r = _child_bench(args, ['--steps', '3', '--warmup', '1'], env={'TDR_MATH': 'f32'})
+        out = {'ms_per_step': r['ms_per_step'], 'value': r['value'], 'unit': r['unit'], 'steps': r['steps'], 'dtype': r['dtype'],
+               'arithmetic': 'exact fp32 MFMA (TDR_MATH=f32), same workload, same code path otherwise'}
+        if 'roofline_step' in r:
+            out['roofline_step'] = r['roofline_step']
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {'ms_per_step': None, 'note': f'failed: {type(e).__name__}'}
+
+
+def matcher_active_run(args, ref_size=640):
+    """the same step with a reference LARGER than lq (the situation of the shipped YAMLs: 384x384 crops against 512x512
+    generated references, image_restoration_ref_model.py:219-247): the frozen DINOv2 ViT-B/14 window matcher runs every step"""
+    try:
+        r = _child_bench(args, ['--steps', '5', '--warmup', '2', '--dino-ref-size', str(ref_size)])
         return {'ms_per_step': r['ms_per_step'], 'value': r['value'], 'unit': r['unit'], 'steps': r['steps'],
-                'math': 'exact fp32 MFMA (TDR_MATH=f32), same workload, same code path otherwise'}
+                'dino_match': r['config']['dino_match'], 'guard': r.get('guard')}
     except Exception as e:  # noqa: BLE001
         return {'ms_per_step': None, 'note': f'failed: {type(e).__name__}'}
 
@@ -169,9 +196,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-f32-exact', action='store_true', help='skip the exact-fp32 (TDR_MATH=f32) comparison run')
+    ap.add_argument('--no-matcher-active', action='store_true', help='skip the DINOv2-matcher-active comparison run (ref 640x640)')
     ap.add_argument('--dino-ref-size', type=int, default=0,
                     help='feed a reference image of this size (> --size): the frozen DINOv2 ViT-B/14 window matcher runs every step '
                          '(random-init weights); 0 = ref of the lq size, where the match is the identity')
+    ap.add_argument('--bucket-mb', type=float, default=64.0, help='gradient all-reduce bucket size (MiB) of the data-parallel step')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (multi-process smoke test on one GPU)')
     a = ap.parse_args()
     if a.batch is None:
@@ -179,19 +208,34 @@ def main():
     if a.size is None:
         a.size = {'restormer': 256, 'promptir': 384, 'drsformer': 256, 'drsformer_mefc': 256}.get(a.arch, 512)
     enc = [int(v) for v in a.enc.split(',')]
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # called plainly: become the launcher (one rank per GPU; rank 0's JSON line and every rank's stderr pass through)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr',
+               '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')).returncode)
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        sys.exit(f'bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks')
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if a.backend == 'nccl':
+            # the N-GPU line is an RCCL-through-the-C-ABI measurement or it is an error: no silent torch.distributed fallback
+            os.environ.setdefault('TDR_COMM', 'rccl')
         dist.init_process_group(a.backend)
     from textualdegremoval_amd.models import create_model
     from textualdegremoval_amd.utils.synthetic import randomize_gates, synthetic_pair
     from textualdegremoval_amd import kernels as K
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    opt = make_opt(a.width, enc, a.size, world > 1, a.arch)
+    opt = make_opt(a.width, enc, a.size, world > 1, a.arch, bucket_mb=a.bucket_mb)
     if a.dino_ref_size > a.size:
         from textualdegremoval_amd.dino import random_vit_b14_state_dict
         ck = f'/tmp/tdr_dino_vitb14_rank{rank}.pth'
@@ -229,6 +273,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def guard_state():
+        g = getattr(getattr(model, 'optimizer_g', None), 'guard', None)
+        return g.read() if g is not None else None
+
+    g_before = guard_state()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -241,6 +290,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss = model.get_current_log()['l_pix']
+    g_after = guard_state()
+    red = getattr(model, 'grad_reducer', None)
+    comm = getattr(red, 'comm', None)
+    if world > 1:
+        from textualdegremoval_amd import _lib
+        ranks_seen = _lib.load().tdr_comm_world(comm.handle) if comm is not None else dist.get_world_size()
+        if a.backend == 'nccl' and comm is None:
+            sys.exit('bench.py: backend nccl but the RCCL data plane (tdr_comm_*) is not in use -- refusing to report an N-GPU line')
+    else:
+        ranks_seen = 1
 
     # ---- roofline of the dominant kernel family (3x3 stride-1 implicit GEMM on the fp32 matrix
     # cores: masa_enc forward + data-gradient launches), measured with HIP events on the launch stream
@@ -313,10 +372,25 @@ def main():
         per_gpu = ips / world
         is_cfg2 = (a.arch, a.width, enc, a.size, a.batch) == ('nafnet', 32, [1, 1, 1, 28], 512, 4)
         line = {
-            'metric': f'train images/sec ({a.size}x{a.size}, bs={a.batch}/GPU)', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
+            'metric': f'train images/sec ({a.size}x{a.size}, bs={a.batch}/GPU)', 'value': ips, 'unit': 'images/sec', 'n_gpus': ranks_seen,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if K.MATH == 'h1' else 'f32', 'data': 'synthetic',
-            'math': {'bx3': 'fp32 tensors; dense contractions as 3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate): '
+            'scaling': 'weak', 'vs_baseline': None,
+            # what the number is: tensors, accumulators, optimiser and reductions are fp32 in every mode; `dtype` names how the dense
+            # contractions are evaluated on the matrix cores (the only place the modes differ)
+            'dtype': {'hx2': 'f32 (2xfp16-split MFMA: 22-bit operand significands, fp32 accumulate; loss-scaled backward)',
+                      'bx3': 'f32 (3xbf16-split MFMA: 24-bit operand significands, fp32 accumulate)',
+                      'h1': 'f16 (single fp16 MFMA product, fp32 accumulate; reduced precision)',
+                      'f32': 'f32 (exact fp32 MFMA)'}[K.MATH],
+            'data': 'synthetic',
+            'guard': (None if g_after is None else
+                      {'skipped_total': int(g_after.skipped),
+                       'skipped_in_timed_region': int(g_after.skipped) - int(g_before.skipped if g_before is not None else 0),
+                       'applied_steps': int(g_after.step),
+                       'scale_log2': __import__('math').log2(g_after.scale) if g_after.scale > 0 else None,
+                       'note': 'device-resident step guard of the loss-scaled fp16-split backward: a non-finite gradient norm skips the '
+                               'optimiser step and halves the scale (the reference never skips); a timed region with skipped steps is '
+                               'not a clean measurement'}),
+            'arithmetic': {'bx3': 'fp32 tensors; dense contractions as 3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate): '
                             'per-product error <= one fp32 rounding, see profiles/r1/bf16x3_probe_mi355x.log; TDR_MATH=f32 selects exact fp32 MFMA',
                      'hx2': 'fp32 tensors; dense contractions as 2-way fp16 split (3 f16 MFMA products per fp32 product, fp32 accumulate), '
                             'the backward pass on gradients scaled by an exact power of two (dpred ~ 2^9, removed when the parameter '
@@ -346,8 +420,14 @@ def main():
                        'global_batch': world * a.batch,
                        'parallelism': f'dp{world}',
                        'collectives': ('none (1 GPU)' if world == 1 else
-                                       ('tdr_comm_* (RCCL through the C ABI)' if getattr(getattr(model, 'grad_reducer', None), 'comm', None) is not None
-                                        else f'torch.distributed ({a.backend})')),
+                                       ('tdr_comm_* (RCCL through the C ABI)' if comm is not None else f'torch.distributed ({a.backend})')),
+                       'ranks_seen': ranks_seen,
+                       'grad_exchange': ('none' if world == 1 else
+                                         (f'{len(red.buckets)} buckets of <= 64 MiB, each all-reduced on the comm stream between the segments of '
+                                          f'the captured backward ({red.bucket_launches} bucket exchanges issued so far)'
+                                          if getattr(model, '_gstate', None) and model._gstate.get('split') else
+                                          'one flat all-reduce between the captured graphs' if getattr(model, 'use_hip_graph', False)
+                                          else 'per-bucket all-reduce overlapped with the eager backward')),
                        'dino_match': ('skipped bit-identically (ref size == lq size, N=1 window)' if a.dino_ref_size <= a.size else
                                       f'DINOv2 ViT-B/14 window match every step, ref {a.dino_ref_size}x{a.dino_ref_size} '
                                       f'({((a.dino_ref_size - a.size) // max(a.size // 4, 1) + 1) ** 2} windows/image, random-init ViT)')},
@@ -373,6 +453,8 @@ def main():
                                      'alg_bytes_per_image': CFG3['B_alg'], 'alg_flop_per_image': CFG3['F_alg']}
         if not a.no_f32_exact and world == 1 and K.MATH != 'f32':
             line['f32_exact'] = f32_exact_run(a)
+        if not a.no_matcher_active and world == 1 and is_cfg2 and a.dino_ref_size <= a.size:
+            line['matcher_active'] = matcher_active_run(a)
         if not a.no_cpu_baseline and world == 1 and a.arch == 'nafnet':
             line['cpu_baseline'] = cpu_baseline(a.width, enc, a.size, a.batch)
         print(json.dumps(line), flush=True)

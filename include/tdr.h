@@ -270,7 +270,10 @@ int tdr_pad_crop(const float* src, int N, int C, int Hs, int Ws, float* dst, int
 /* Input pipeline on the device: paired random crop (data/transforms.py:24-84) + the 8 flip / rot90 modes of
  * data_augmentation (:223-270, numpy semantics) + optional sigma-noise synthesis (restoration_dataset.py:464-476), one
  * gather per batch.  src [N][C][Hs][Ws] (per-image stride src_ns), per-sample top / left / mode int32 device arrays (NULL:
- * 0), noise [N][C][P][P] and sigma [N] (NULL: no noise / sigma 1), out [N][C][P][P].  The caller draws the parameters. */
+ * 0), noise [N][C][P][P] and sigma [N] (NULL: no noise / sigma 1), out [N][C][P][P].  The caller draws the parameters.
+ * An image smaller than the patch (P > Hs or P > Ws) is read as if padded at the bottom / right by reflection including the
+ * edge pixel -- the reference's padding() before the crop (utils/utils_image.py:243-259, cv2.BORDER_REFLECT); top / left
+ * then index the padded image. */
 int tdr_crop_augment(const float* src, int64_t src_ns, int N, int C, int Hs, int Ws, const int* top, const int* left,
                      const int* mode, const float* noise, const float* sigma, int P, float* out, void* stream);
 
@@ -588,6 +591,7 @@ int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float
  * tdr_comm_init.  Collectives are in place on fp32 device buffers, enqueued on `stream`, capturable in a hipGraph.
  * librccl.so.1 is bound at run time (the copy already resident in the process, else /opt/rocm/lib). */
 typedef struct TdrComm TdrComm;
+int tdr_comm_available(void);          /* 1 when librccl.so.1 and every entry point used here resolve in this process, else 0 (no side effect) */
 int tdr_comm_unique_id_bytes(void);
 int tdr_comm_unique_id(void* id_out);
 int tdr_comm_init(TdrComm** comm, int rank, int world, const void* unique_id);

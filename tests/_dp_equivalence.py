@@ -25,7 +25,9 @@ if __name__ == '__main__':
     if world > 1:
         dist.init_process_group('gloo')
     torch.manual_seed(100 + rank)
-    model = create_model(bench.make_opt(8, [1, 1, 1, 1], 128, world > 1))
+    # 0.25 MiB buckets: several buckets even for this small network, so the captured step of the 2-rank run is cut into
+    # several graph segments with a bucket exchange between them (image_restoration_ref_model._graph_step)
+    model = create_model(bench.make_opt(8, [1, 1, 1, 1], 128, world > 1, bucket_mb=0.25))
     if rank == 0:
         randomize_gates(model.net_g, seed=5)       # a rank-0-only change BEFORE the sync below would be lost; after it, ranks differ ->
     if world > 1:
@@ -41,6 +43,10 @@ if __name__ == '__main__':
         model.feed_train_data(data)
         model.optimize_parameters(it)
         losses.append(model.get_current_log()['l_pix'])
+    if world > 1:
+        st, red = model._gstate, model.grad_reducer
+        assert st['split'] and len(st['segs']) == len(red.buckets) >= 3, (len(st['segs']), len(red.buckets))
+        assert red.bucket_launches >= 2 * len(red.buckets)
     if rank == 0:
         torch.save({'losses': losses, 'params': {k: v.detach().cpu() for k, v in model.net_g.state_dict().items()}}, out_path)
     if world > 1:

@@ -27,5 +27,17 @@ for name, crit in CASES.items():
     loss.backward()
     out[name + '_loss'] = np.float64(loss.item())
     out[name + '_grad'] = p.grad.numpy()
+# weighted / non-mean reductions (losses/loss_util.py:25-54 weight_reduce_loss): one-channel and per-channel weights
+w1 = rng.random((3, 1, 20, 28)).astype(np.float32)
+w3 = rng.random((3, 3, 20, 28)).astype(np.float32)
+out['w1'], out['w3'] = w1, w3
+for name, crit, w in (('l1_w1_mean', L1Loss(loss_weight=0.7), w1), ('l1_w3_mean', L1Loss(), w3), ('mse_w1_mean', MSELoss(loss_weight=2.0), w1),
+                      ('mse_w3_sum', MSELoss(reduction='sum'), w3), ('l1_sum', L1Loss(reduction='sum'), None),
+                      ('l1_w1_none', L1Loss(reduction='none'), w1)):
+    p = torch.tensor(pred, requires_grad=True)
+    loss = crit(p, torch.tensor(target), weight=None if w is None else torch.tensor(w))
+    out[name + '_loss'] = loss.detach().numpy().astype(np.float64)
+    loss.sum().backward()
+    out[name + '_grad'] = p.grad.numpy()
 np.savez_compressed(os.path.join(HERE, 'losses.npz'), **out)
-print({k: float(v) for k, v in out.items() if k.endswith('_loss')})
+print({k: float(np.sum(v)) for k, v in out.items() if k.endswith('_loss')})

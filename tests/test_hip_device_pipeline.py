@@ -1,5 +1,7 @@
-"""tdr_crop_augment / DevicePairedAugmenter against the numpy restatement of the reference's host pipeline:
-bit-exact (a gather, plus one fp32 multiply-add for the noise)."""
+"""tdr_crop_augment / DevicePairedAugmenter against vectors produced by the reference's own data/transforms.py
+(tests/golden/transforms.npz, make_golden_transforms.py) and the pinned oracle: bit-exact (a gather, plus one fp32
+multiply-add for the noise)."""
+import os
 import random
 
 import numpy as np
@@ -9,6 +11,53 @@ import torch
 from oracle import data_pipeline_oracle as DO
 
 pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'transforms.npz'))
+
+
+def _image(seed, h, w):
+    return np.random.RandomState(seed).rand(h, w, 3).astype(np.float32)
+
+
+@pytest.mark.parametrize('case', [tuple(int(v) for v in c) for c in G['cases']])
+def test_augmenter_reproduces_the_reference_pipeline(case):
+    """same python-`random` seed -> same draws, same pixels as paired_random_crop + random_augmentation of the reference"""
+    from textualdegremoval_amd.data.device_pipeline import DevicePairedAugmenter
+    seed, h, w, patch = case
+    aug = DevicePairedAugmenter({'gt_size': patch, 'geometric_augs': True}, rng=random.Random(seed))
+    chw = lambda a: torch.from_numpy(a.transpose(2, 0, 1).copy())[None].cuda()
+    ref = torch.rand(1, 3, h + 9, w + 5).cuda()
+    out = aug(chw(_image(seed, h, w)), lq=chw(_image(seed + 1000, h, w)), ref=ref)
+    assert [aug.last['top'][0], aug.last['left'][0], aug.last['mode'][0]] == [int(v) for v in G[f'c{seed}_draws']]
+    assert np.array_equal(out['gt'][0].cpu().numpy().transpose(1, 2, 0), G[f'c{seed}_gt'])
+    assert np.array_equal(out['lq'][0].cpu().numpy().transpose(1, 2, 0), G[f'c{seed}_lq'])
+    assert out['ref'] is ref                   # the WithRef datasets never crop or augment img_ref
+
+
+def test_noise_vs_reference_statements():
+    """lq = gt + randn * sigma / 255 against the dataset's own statements (restoration_dataset.py:465-476), mode 0, full image"""
+    from textualdegremoval_amd import kernels as K
+    img = torch.from_numpy(_image(30, 24, 20).transpose(2, 0, 1).copy())
+    torch.manual_seed(78)
+    randn = torch.randn(3, 24, 20)
+    for tag in ('const', 'rand', 'choice'):
+        sig = torch.tensor([float(G[f'noise_{tag}_sigma'])], dtype=torch.float32) / 255.0
+        # the kernel crops squares: two overlapping 20x20 crops cover the 24x20 image
+        for top in (0, 4):
+            out = K.crop_augment(img[None].cuda(), torch.tensor([top], dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda(),
+                                 torch.zeros(1, dtype=torch.int32).cuda(), 20, noise=randn[None, :, top:top + 20].contiguous().cuda(),
+                                 sigma=sig.cuda())
+            assert np.abs(out[0].cpu().numpy() - G[f'noise_{tag}_out'][:, top:top + 20]).max() <= 6e-8
+
+
+def test_small_images_are_reflect_padded_like_padding():
+    from textualdegremoval_amd.data.device_pipeline import DevicePairedAugmenter
+    aug = DevicePairedAugmenter({'gt_size': 32, 'geometric_augs': True}, rng=random.Random(3))
+    gt = torch.rand(3, 3, 20, 27)
+    out = aug(gt.cuda())
+    for n in range(3):
+        want = DO.crop_augment(gt[n].numpy(), aug.last['top'][n], aug.last['left'][n], 32, aug.last['mode'][n])
+        assert np.array_equal(out['gt'][n].cpu().numpy(), want)
+
 
 
 def test_all_modes_and_offsets_bit_exact():
@@ -46,7 +95,7 @@ def test_noise_synthesis_and_shared_parameters():
         assert np.array_equal(out['gt'][n].cpu().numpy(), clean)
         lq = clean + noise[n] * np.float32(p['sigma'][n] / 255.0)
         assert np.abs(out['lq'][n].cpu().numpy() - lq).max() < 1e-6
-        assert np.array_equal(out['ref'][n].cpu().numpy(), DO.crop_augment(ref[n].cpu().numpy(), 0, 0, 96, p['mode'][n]))
+    assert out['ref'] is ref
     res = (out['lq'] - out['gt']).cpu()
     for n in range(4):
         assert abs(res[n].std().item() - p['sigma'][n] / 255.0) < 0.05 * p['sigma'][n] / 255.0

@@ -13,25 +13,42 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(nproc, port):
+def _bench(nproc, port, wrap):
+    """wrap=False: exactly `python bench.py --gpus N ...` (the script launches its own ranks); wrap=True: the driver's form,
+    `python -m torch.distributed.run ... bench.py --gpus N ...`"""
     cmd = [sys.executable]
-    if nproc > 1:
+    if wrap:
         cmd += ['-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
                 '--master-port', str(port)]
     cmd += [os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc), '--steps', '2', '--warmup', '1', '--width', '8', '--enc', '1,1,1,1',
-            '--size', '128', '--batch', '1', '--backend', 'gloo', '--no-cpu-baseline']     # roofline leg on: every rank must run its instrumented step
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            '--size', '128', '--batch', '1', '--backend', 'gloo', '--bucket-mb', '0.25',
+            '--no-cpu-baseline']     # roofline leg on: every rank must run its instrumented step
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
     return json.loads(line)
 
 
-def test_two_rank_graph_step_runs():
+@pytest.mark.parametrize('wrap', [False, True])
+def test_two_rank_graph_step_runs(wrap):
+    """`python bench.py --gpus 2` with no launcher around it must produce a 2-rank line (and so must the driver's
+    torch.distributed.run form); the gradient exchange is per bucket between the segments of the captured backward."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
-    r2 = _bench(2, 29541)
-    assert r2['n_gpus'] == 2 and r2['value'] > 0 and r2['final_loss'] == r2['final_loss']      # finite
+    r2 = _bench(2, 29541, wrap)
+    assert r2['n_gpus'] == 2 and r2['config']['ranks_seen'] == 2
+    assert r2['value'] > 0 and r2['final_loss'] == r2['final_loss']      # finite
     assert r2['config']['global_batch'] == 2
+    assert 'buckets' in r2['config']['grad_exchange'] and r2['guard']['skipped_in_timed_region'] == 0
+
+
+def test_gpus_flag_must_match_the_launched_world():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '0']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(os.environ, WORLD_SIZE='2', RANK='0'))
+    assert out.returncode != 0 and 'WORLD_SIZE=2' in out.stderr
 
 
 def test_single_rank_rccl_collectives_under_graph_capture():

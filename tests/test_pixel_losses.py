@@ -47,6 +47,26 @@ def test_host_tensors_keep_the_torch_expressions():
     assert L.L1Loss(reduction='sum').step_kind() is None and L.MSELoss().step_kind() is not None
 
 
+WEIGHTED = [('l1_w1_mean', 'L1Loss', dict(loss_weight=0.7), 'w1'), ('l1_w3_mean', 'L1Loss', {}, 'w3'),
+            ('mse_w1_mean', 'MSELoss', dict(loss_weight=2.0), 'w1'), ('mse_w3_sum', 'MSELoss', dict(reduction='sum'), 'w3'),
+            ('l1_sum', 'L1Loss', dict(reduction='sum'), None), ('l1_w1_none', 'L1Loss', dict(reduction='none'), 'w1')]
+
+
+@pytest.mark.parametrize('name,cls,kw,wk', WEIGHTED)
+def test_weighted_and_non_mean_reductions_follow_weight_reduce_loss(name, cls, kw, wk):
+    """losses/loss_util.py:25-54 through the reference's own classes: a one-channel weight divides by weight.sum() * C"""
+    from textualdegremoval_amd import losses as L
+    g = np.load(os.path.join(GOLDEN, 'losses.npz'))
+    p = torch.tensor(g['pred'], requires_grad=True)
+    v = getattr(L, cls)(**kw)(p, torch.tensor(g['target']), weight=None if wk is None else torch.tensor(g[wk]))
+    assert np.allclose(v.detach().numpy().astype(np.float64), g[name + '_loss'], rtol=3e-6, atol=1e-9)
+    v.sum().backward()
+    assert np.allclose(p.grad.numpy(), g[name + '_grad'], rtol=1e-5, atol=1e-9)
+    if wk == 'w1':
+        with pytest.raises(AssertionError):
+            getattr(L, cls)(**kw)(p, torch.tensor(g['target']), weight=torch.tensor(g['w3'][:, :2]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,cls,kw', CASES)
 def test_hip_pixel_loss_matches_golden_and_oracle(name, cls, kw):

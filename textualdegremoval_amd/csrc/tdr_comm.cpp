@@ -69,6 +69,8 @@ struct TdrComm {
     int rank, world;
 };
 
+extern "C" int tdr_comm_available(void) { return rccl().ok ? 1 : 0; }
+
 extern "C" int tdr_comm_unique_id_bytes(void) { return NCCL_UNIQUE_ID_BYTES; }
 
 extern "C" int tdr_comm_unique_id(void* id_out) {

@@ -989,7 +989,12 @@ __global__ void crop_augment_kernel(const float* __restrict__ src, long src_ns, 
             case 7: sy = q - x; sx = q - y; break;        // flipud(rot270) = anti-transpose
             default: sy = y; sx = x; break;
         }
-        float v = src[(long)n * src_ns + ((long)c * Hs + (top ? top[n] : 0) + sy) * Ws + (left ? left[n] : 0) + sx];
+        // rows / columns past the image (only when P > Hs or P > Ws): the reference pads bottom / right by reflection first
+        // (utils/utils_image.py:243-259, cv2.BORDER_REFLECT: ...cba|abc...|cba...), period 2*Hs
+        int yy = (top ? top[n] : 0) + sy, xx = (left ? left[n] : 0) + sx;
+        if (yy >= Hs) { yy %= 2 * Hs; if (yy >= Hs) yy = 2 * Hs - 1 - yy; }
+        if (xx >= Ws) { xx %= 2 * Ws; if (xx >= Ws) xx = 2 * Ws - 1 - xx; }
+        float v = src[(long)n * src_ns + ((long)c * Hs + yy) * Ws + xx];
         if (noise) v += noise[i] * (sigma ? sigma[n] : 1.f);
         out[i] = v;
     }
@@ -999,7 +1004,7 @@ __global__ void crop_augment_kernel(const float* __restrict__ src, long src_ns, 
 /* data/transforms.py:24-84 (paired_random_crop), :223-270 (data_augmentation modes 0-7), restoration_dataset.py:464-476 (noise) */
 extern "C" int tdr_crop_augment(const float* src, int64_t src_ns, int N, int C, int Hs, int Ws, const int* top, const int* left,
                                 const int* mode, const float* noise, const float* sigma, int P, float* out, void* stream) {
-    TDR_REQUIRE(src && out && N > 0 && C > 0 && P > 0 && P <= Hs && P <= Ws, "tdr_crop_augment: bad argument (patch %d of %d x %d)", P, Hs, Ws);
+    TDR_REQUIRE(src && out && N > 0 && C > 0 && P > 0 && Hs > 0 && Ws > 0, "tdr_crop_augment: bad argument (patch %d of %d x %d)", P, Hs, Ws);
     const long total = (long)N * C * P * P;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;

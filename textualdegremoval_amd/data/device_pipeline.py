@@ -3,7 +3,11 @@
 :223-275 (data_augmentation / random_augmentation), data/restoration_dataset.py:464-476 (sigma-noise synthesis).  On an
 MI355X the batch is already resident in HBM, so the same three steps are one gather kernel over the whole batch
 (`tdr_crop_augment`); only the few random PARAMETERS are drawn on the host, with python's `random` module in the same order
-per sample as the reference (top, left, then the augmentation flag, then sigma), so a seeded run picks the same crops."""
+per sample as the reference (top, left, then the augmentation flag, then sigma), so a seeded run picks the same crops.
+Images smaller than gt_size are reflect-padded at the bottom / right first, as the reference's padding() does
+(utils/utils_image.py:243-259; folded into the gather).  The reference image `ref` is returned UNTOUCHED: the WithRef
+datasets crop and augment only (img_gt, img_lq) -- `random_augmentation(img_gt, img_lq)`, restoration_dataset.py:140,235,
+459,601,756 -- and hand img_ref through as loaded; the model matches / crops it itself with DINOv2."""
 import random
 
 import torch
@@ -30,6 +34,7 @@ class DevicePairedAugmenter:
     def draw(self, N, H, W):
         """host side: the per-sample parameters, drawn as the reference draws them (random.randint is inclusive)."""
         top, left, mode, sigma = [], [], [], []
+        H, W = max(H, self.patch), max(W, self.patch)     # after the reference's padding() to at least gt_size
         for _ in range(N):
             top.append(self.rng.randint(0, H - self.patch))
             left.append(self.rng.randint(0, W - self.patch))
@@ -58,8 +63,6 @@ class DevicePairedAugmenter:
             s = torch.tensor(sigma, dtype=torch.float32, device=dev) / 255.0
             out['lq'] = K.crop_augment(gt, t, l, m, self.patch, noise=noise, sigma=s)
         if ref is not None:
-            # the reference image goes through the same geometric mode (random_augmentation(*args) applies one flag to all
-            # its arguments, transforms.py:271-275); it is not cropped here -- the model matches / crops it itself
-            out['ref'] = K.crop_augment(ref, None, None, m, ref.shape[-1]) if ref.shape[-1] == ref.shape[-2] else ref
+            out['ref'] = ref          # never cropped, never augmented by the reference's datasets (module docstring)
         self.last = dict(top=top, left=left, mode=mode, sigma=sigma)
         return out

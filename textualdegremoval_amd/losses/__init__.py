@@ -23,6 +23,20 @@ class _PixFn(torch.autograd.Function):
         return dpred * g, None, None, None, None
 
 
+def _weight_reduce(loss, weight, reduction):
+    """losses/loss_util.py:25-54 (weight_reduce_loss): element-wise weight, then the reduction; the weighted mean divides by
+    the weight mass -- weight.sum() for a per-channel weight, weight.sum() * C for a one-channel weight (no clamp)."""
+    if weight is not None:
+        assert weight.dim() == loss.dim()
+        assert weight.size(1) == 1 or weight.size(1) == loss.size(1)
+        loss = loss * weight
+    if weight is None or reduction == 'sum':
+        return loss.mean() if reduction == 'mean' else (loss.sum() if reduction == 'sum' else loss)
+    if reduction == 'mean':
+        return loss.sum() / (weight.sum() if weight.size(1) > 1 else weight.sum() * loss.size(1))
+    return loss
+
+
 def _on_device(pred, target):
     return pred.is_cuda and pred.dim() == 4 and pred.dtype == torch.float32 and target.dtype == torch.float32
 
@@ -38,14 +52,7 @@ class L1Loss(nn.Module):
     def forward(self, pred, target, weight=None, **kwargs):
         if _on_device(pred, target) and weight is None and self.reduction == 'mean':
             return _PixFn.apply(pred, target, K.LOSS_L1, float(self.loss_weight), 0.0)
-        d = (pred - target).abs()
-        if weight is not None:
-            d = d * weight
-        if self.reduction == 'mean':
-            d = d.mean() if weight is None else d.sum() / weight.sum().clamp_min(1e-12)
-        elif self.reduction == 'sum':
-            d = d.sum()
-        return self.loss_weight * d
+        return self.loss_weight * _weight_reduce((pred - target).abs(), weight, self.reduction)
 
     def step_kind(self):
         return (K.LOSS_L1, float(self.loss_weight), 0.0) if self.reduction == 'mean' else None
@@ -62,14 +69,7 @@ class MSELoss(nn.Module):
     def forward(self, pred, target, weight=None, **kwargs):
         if _on_device(pred, target) and weight is None and self.reduction == 'mean':
             return _PixFn.apply(pred, target, K.LOSS_MSE, float(self.loss_weight), 0.0)
-        d = (pred - target) ** 2
-        if weight is not None:
-            d = d * weight
-        if self.reduction == 'mean':
-            d = d.mean() if weight is None else d.sum() / weight.sum().clamp_min(1e-12)
-        elif self.reduction == 'sum':
-            d = d.sum()
-        return self.loss_weight * d
+        return self.loss_weight * _weight_reduce((pred - target) ** 2, weight, self.reduction)
 
     def step_kind(self):
         return (K.LOSS_MSE, float(self.loss_weight), 0.0) if self.reduction == 'mean' else None

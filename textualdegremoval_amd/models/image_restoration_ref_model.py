@@ -226,9 +226,9 @@ class RefGuidedImageCleanModel(BaseModel):
             self._pack_plan = K.PackPlan()
         return loss
 
-    def _fwd_bwd(self, lq, gt, ref_in, defer_collectives=False):
+    def _fwd_bwd(self, lq, gt, ref_in, defer_collectives=False, on_bucket=None):
         """forward, L1, hand-written backward; gradients land in the reducer's arena (RCCL-averaged when
-        distributed, unless `defer_collectives`).  Returns the loss tensor [1]."""
+        distributed, unless `defer_collectives`; `on_bucket`: GradAllReducer.begin).  Returns the loss tensor [1]."""
         net = self.get_bare_model(self.net_g)
         P = {k: p.data for k, p in zip(self._step_names, self._step_params)}
         if not hasattr(self, '_pack_plan'):
@@ -257,7 +257,7 @@ class RefGuidedImageCleanModel(BaseModel):
             out, saved = eng.net_fwd(P, net.cfg, lq, ref_in)
             self.output = out
             loss, dpred = K.pixel_loss(kind, out.contiguous(), gt.contiguous(), lw, eps, guard=guard)
-            sink = self.grad_reducer.begin(defer_collectives=defer_collectives)
+            sink = self.grad_reducer.begin(defer_collectives=defer_collectives, on_bucket=on_bucket)
             K.BACKWARD_PHASE = True
             try:
                 eng.net_bwd(dpred, P, net.cfg, saved, G=sink)
@@ -280,40 +280,78 @@ class RefGuidedImageCleanModel(BaseModel):
         return loss
 
     def _graph_step(self):
-        """The step as two captured hipGraphs (forward+backward | clip+AdamW): ~4000 kernel launches are
-        replayed without host work; between them the flat gradient arena is all-reduced over RCCL when
-        distributed.  Shapes are static per graph; the first two steps of a shape run eagerly (allocator /
-        workspace / arena-layout warm-up)."""
+        """The step as captured hipGraphs (forward+backward | clip+AdamW): ~1500 kernel launches are replayed without
+        host work.  Shapes are static per graph; the first two steps of a shape run eagerly (allocator / workspace /
+        arena-layout warm-up).
+        Distributed: DDP overlaps bucketed all-reduces with the backward pass (reference models/base_model.py:76-82), and
+        so does the captured step -- the forward+backward capture is CUT where a gradient bucket has just been gathered
+        into the arena (GradAllReducer `on_bucket`), giving segments A_0 .. A_k that share one memory pool; the replay
+        enqueues A_0, the RCCL all-reduce of bucket 0 on the comm stream (behind an event of the compute stream), A_1,
+        bucket 1, ... so every exchange but the last runs under the remaining backward segments; graph B (clip + AdamW)
+        waits for the comm stream.  TDR_GRAPH_BUCKETS=0 restores the single graph + one flat all-reduce."""
         key = (tuple(self.lq.shape), tuple(self.gt.shape), tuple(self.ref_in.shape), self.optimizer_g.use_grad_clip,
                tuple(sorted(self.optimizer_g.frozen_groups)))
+        red = self.grad_reducer
         st = self._gstate
         if st is None or st['key'] != key:
-            st = self._gstate = {'key': key, 'eager_left': 2, 'gA': None}
-        if st['gA'] is None:
+            st = self._gstate = {'key': key, 'eager_left': 2, 'segs': None}
+        if st['segs'] is None:
             if st['eager_left'] > 0:
                 st['eager_left'] -= 1
                 return self._eager_step(self.lq, self.gt, self.ref_in)
             st['lq'], st['gt'], st['ref'] = self.lq.clone(), self.gt.clone(), self.ref_in.clone()
             torch.cuda.synchronize()
-            gA = torch.cuda.CUDAGraph()
             st['ws_refs'] = []                 # scratch buffers the captured kernels address (kernels.workspace_capture)
+            split = red.collective and os.environ.get('TDR_GRAPH_BUCKETS', '1') == '1'
+            pool = torch.cuda.graph_pool_handle()
+            segs = []                          # [(graph, bucket index to exchange after it | None)]
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
-            with torch.cuda.graph(gA, capture_error_mode='thread_local'), K.workspace_capture(st['ws_refs']):
-                st['loss'] = self._fwd_bwd(st['lq'], st['gt'], st['ref'], defer_collectives=True)
-            st['pinned'] = self.grad_reducer.pinned_tables      # host blocks the captured table uploads re-read on replay
-            self.optimizer_g.prepare()
-            gB = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode='thread_local'), K.workspace_capture(st['ws_refs']):
-                self.optimizer_g.launch()
-            st['gA'], st['gB'] = gA, gB
+            with torch.cuda.stream(cap), K.workspace_capture(st['ws_refs']):
+                cur = [torch.cuda.CUDAGraph()]
+                cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
+
+                tail = [None]
+
+                def cut(bi):
+                    if not any(red._bucket_left):          # the last bucket: nothing follows it, no (empty) segment after it
+                        tail[0] = bi
+                        return
+                    cur[0].capture_end()
+                    segs.append((cur[0], bi))
+                    cur[0] = torch.cuda.CUDAGraph()
+                    cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
+                try:
+                    st['loss'] = self._fwd_bwd(st['lq'], st['gt'], st['ref'], defer_collectives=True,
+                                               on_bucket=cut if split else None)
+                finally:
+                    cur[0].capture_end()
+                segs.append((cur[0], tail[0]))
+                st['pinned'] = red.pinned_tables      # host blocks the captured table uploads re-read on replay
+                self.optimizer_g.prepare()
+                gB = torch.cuda.CUDAGraph()
+                gB.capture_begin(pool=pool, capture_error_mode='thread_local')
+                try:
+                    self.optimizer_g.launch()
+                finally:
+                    gB.capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
+            st['segs'], st['gB'], st['split'] = segs, gB, split
             st['output'] = self.output
         else:
             st['lq'].copy_(self.lq, non_blocking=True)
             st['gt'].copy_(self.gt, non_blocking=True)
             st['ref'].copy_(self.ref_in, non_blocking=True)
             self.optimizer_g.prepare()
-        st['gA'].replay()
-        self.grad_reducer.allreduce_flat()
+        for g, bi in st['segs']:
+            g.replay()
+            if bi is not None:
+                red.launch_bucket(bi)
+        if st['split']:
+            red.wait_buckets()
+        else:
+            red.allreduce_flat()
         st['gB'].replay()
         self.output = st['output']
         return st['loss']

@@ -28,7 +28,6 @@ class TdrComm:
     data-parallel step.  torch.distributed is only the side channel that carries rank 0's 128-byte unique id to the
     other ranks (any backend); the collectives themselves are tdr_comm_allreduce / _reduce / _broadcast on fp32
     device buffers, enqueued on a HIP stream of the caller's choice."""
-    _instance = None
 
     def __init__(self, rank, world, unique_id):
         import ctypes as C
@@ -50,13 +49,8 @@ class TdrComm:
 
     @classmethod
     def from_process_group(cls, group=None):
-        """one communicator per process, spanning the ranks of the (default) torch.distributed group"""
-        if cls._instance is None:
-            rank, world = dist.get_rank(group), dist.get_world_size(group)
-            box = [cls.new_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, group=group)
-            cls._instance = cls(rank, world, box[0])
-        return cls._instance
+        """the communicator of the (default) torch.distributed group, brought up once (see data_plane)"""
+        return data_plane(group)
 
     def _call(self, fn, name, t, arg, stream):
         from . import _lib
@@ -78,38 +72,93 @@ class TdrComm:
         if self.handle is not None:
             _lib.check(self._lib.tdr_comm_destroy(self.handle), 'tdr_comm_destroy')
             self.handle = None
-        if TdrComm._instance is self:
-            TdrComm._instance = None
+        for k in [k for k, c in _PLANE.items() if c is self]:
+            del _PLANE[k]
 
 
-def data_plane(group=None):
-    """the TdrComm of this process when the job runs one rank per GPU over RCCL (torch backend 'nccl' or
-    TDR_COMM=rccl); None for single-process runs and for the gloo runs of the CPU / shared-GPU tests (TDR_COMM=torch
-    forces torch.distributed's own collectives)."""
-    if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()):
-        return None
-    mode = os.environ.get('TDR_COMM', 'auto')
+class DataPlaneUnavailable(RuntimeError):
+    """TDR_COMM=rccl (strict) and the RCCL binding behind the C ABI could not be brought up on every rank."""
+
+
+_PLANE = {}        # process-group key -> TdrComm or None: the verdict is reached ONCE per group and reused by every step
+
+
+def _agree(flag, group):
+    """MIN over the ranks of a 0/1 flag, on the side channel (torch.distributed, whatever its backend)."""
+    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item()) == 1
+
+
+def _resolve_plane(group):
+    mode = os.environ.get('TDR_COMM', 'auto')          # auto | rccl (strict: raise instead of falling back) | torch
     if mode == 'torch' or (mode == 'auto' and dist.get_backend(group) != 'nccl'):
         return None
     if dist.get_world_size(group) == 1 and os.environ.get('TDR_FORCE_COLLECTIVES') != '1':
         return None
-    # every rank tries; the ranks then agree (MIN over a success flag) -- a node where the RCCL binding cannot be
-    # brought up (librccl missing / two incompatible copies) falls back to torch.distributed's collectives, which are
-    # RCCL as well, instead of failing the job.  The fallback is logged and visible in bench.py's `collectives` field.
-    comm, err = None, None
-    try:
-        comm = TdrComm.from_process_group(group)
-    except Exception as e:          # noqa: BLE001 -- any failure of the optional binding takes the torch path
-        err = e
-    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device='cuda')
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-    if int(ok.item()) == 1:
-        return comm
-    if comm is not None:
-        comm.destroy()
     import logging
-    logging.getLogger('tdr').warning('tdr_comm (RCCL through the C ABI) unavailable on some rank (%s): using torch.distributed collectives', err)
-    return None
+    log = logging.getLogger('tdr')
+
+    def unavailable(why):
+        if mode == 'rccl':
+            raise DataPlaneUnavailable(f'TDR_COMM=rccl: {why}')
+        log.warning('tdr_comm (RCCL through the C ABI) unavailable (%s): using torch.distributed collectives', why)
+        return None
+    # Every rank takes the same sequence of side-channel collectives whatever fails locally, so a rank-local failure can
+    # never leave the ranks in mismatched collectives:
+    #   1. all ranks agree that librccl resolves in their process BEFORE anyone touches ncclGetUniqueId / ncclCommInitRank
+    from . import _lib
+    try:
+        loaded = bool(_lib.load().tdr_comm_available())
+    except Exception:   # noqa: BLE001
+        loaded = False
+    if not _agree(loaded, group):
+        return unavailable('librccl.so.1 does not resolve on some rank')
+    #   2. rank 0 makes the id; a failure there travels in the broadcast as None (the broadcast itself always happens)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box, err = [None], None
+    if rank == 0:
+        try:
+            box[0] = TdrComm.new_unique_id()
+        except Exception as e:   # noqa: BLE001
+            err = e
+    dist.broadcast_object_list(box, src=0, group=group)
+    if box[0] is None:
+        return unavailable(f'ncclGetUniqueId failed on rank 0: {err}')
+    #   3. all ranks enter ncclCommInitRank together, then agree on the outcome
+    comm = None
+    try:
+        comm = TdrComm(rank, world, box[0])
+    except Exception as e:   # noqa: BLE001
+        err = e
+    if not _agree(comm is not None, group):
+        if comm is not None:
+            comm.destroy()
+        return unavailable(f'ncclCommInitRank failed on some rank: {err}')
+    return comm
+
+
+def data_plane(group=None):
+    """the TdrComm of this process when the job runs one rank per GPU over RCCL (torch backend 'nccl', or
+    TDR_COMM=rccl which additionally makes a failed bring-up an error instead of a fallback); None for single-process
+    runs, for the gloo runs of the CPU / shared-GPU tests and under TDR_COMM=torch.  The verdict -- including
+    "unavailable" -- is resolved once per process group and cached: the per-step callers (gradient all-reduce,
+    reduce_loss_to_rank0, sync_from_rank0) never issue a collective or a host sync to find it again."""
+    if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()):
+        return None
+    key = id(group) if group is not None else None
+    if key not in _PLANE:
+        _PLANE[key] = _resolve_plane(group)
+    return _PLANE[key]
+
+
+def reset_data_plane():
+    """forget the cached verdicts (process-group teardown in tests)"""
+    for c in list(_PLANE.values()):
+        if c is not None:
+            c.destroy()
+    _PLANE.clear()
 
 
 class GradSink(dict):
@@ -190,10 +239,13 @@ class GradAllReducer:
     grad_unscale = 1.0          # 1 / (power-of-two loss scale of the backward pass); applied while gathering
     guard = None                # optim.StepGuard: the gather reads 1 / loss scale from device memory instead
 
-    def begin(self, defer_collectives=False):
+    def begin(self, defer_collectives=False, on_bucket=None):
         """defer_collectives: do not launch per-bucket all-reduces while gradients arrive (hipGraph
-        capture of the backward pass); the caller runs allreduce_flat() afterwards."""
+        capture of the backward pass); the caller runs allreduce_flat() afterwards -- or, with `on_bucket`, is called
+        back with the bucket index right after each bucket's gather has been enqueued (the captured step cuts its graph
+        there and replays `launch_bucket(bi)` between the segments, so the exchange overlaps the rest of the backward)."""
         self._defer = defer_collectives
+        self._on_bucket = on_bucket
         self.relaid = False
         self._arrived = []
         self._works = []
@@ -250,14 +302,24 @@ class GradAllReducer:
         self._keep = [self._pending.pop(k) for k in tb['names']]   # sources stay referenced until the next gather is enqueued
 
     def _launch(self, bi):
-        if not self.collective or getattr(self, '_defer', False):
+        if not self.collective:
             return
+        if getattr(self, '_defer', False):
+            if getattr(self, '_on_bucket', None) is not None:
+                self._on_bucket(bi)
+            return
+        self.launch_bucket(bi)
+
+    def launch_bucket(self, bi):
+        """all-reduce (mean) of bucket `bi` on the comm stream, ordered after everything enqueued so far on the current
+        stream; wait_buckets() makes the current stream wait for the exchanges."""
         s, e, _ = self.buckets[bi]
         buf = self.flat[s:e]
         if buf.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            self.bucket_launches += 1
             if self.comm is not None:
                 self.comm.allreduce(buf, average=True, stream=self._comm_stream.cuda_stream)
                 return
@@ -269,6 +331,16 @@ class GradAllReducer:
                     buf.div_(self.world)
         else:
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    bucket_launches = 0          # per-bucket exchanges issued so far (bench.py / tests: the overlapped path really ran)
+
+    def wait_buckets(self):
+        """the current stream waits for every bucket exchange launched since the last wait"""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._comm_stream is not None and self.flat is not None and self.flat.is_cuda:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     def _arrive(self, key, g):
         self._arrived.append((key, g))
@@ -315,7 +387,7 @@ class GradAllReducer:
 def reduce_loss_to_rank0(loss_tensor, world, rank, group=None):
     """C2 of SURVEY 2.2: dist.reduce to rank 0, then / world on rank 0 (base_model.py:361-372)."""
     if world > 1:
-        comm = data_plane(group) if loss_tensor.is_cuda else None
+        comm = data_plane(group) if loss_tensor.is_cuda else None      # cached verdict: no collective, no host sync here
         if comm is not None:
             loss_tensor = loss_tensor.contiguous()
             comm.reduce(loss_tensor, root=0)
