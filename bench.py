@@ -154,6 +154,73 @@ def matcher_active_run(args, ref_size=640):
         return {'ms_per_step': None, 'note': f'failed: {type(e).__name__}'}
 
 
+def bench_i2t(a, world, rank, local):
+    """BASELINE configs[3]: the stage-A image-to-text mapping train step of
+    scripts/train/main_train_i2t_mapping.py:704-760 -- frozen CLIP ViT-H/14 (1280 / 32 layers / 16 heads / MLP 5120) on the batch
+    resized to 224x224, Mapper(1280 -> 1024, 20 words) forward + backward, the injected cross-attention at the four SD shapes with
+    trainable to_k_global / to_v_global, MSE, clip_grad_norm_ 1.0, AdamW; the absent third-party SD UNet / VAE / text transformer are
+    the fixed random linear stand-in SURVEY prescribes (textualdegremoval_amd/stage_a.py).  Random-init weights, synthetic batch."""
+    from textualdegremoval_amd import kernels as K
+    from textualdegremoval_amd import stage_a as SA
+    from textualdegremoval_amd.clip_vision import random_clip_state_dict
+    vit = {'H': (1280, 5120, 32, 16, 'gelu', 0.334e12), 'L': (1024, 4096, 24, 16, 'quick_gelu', 0.1626e12)}[a.clip]
+    torch.manual_seed(0)
+    tr = SA.I2TMappingTrainer(random_clip_state_dict(vit[0], vit[1], vit[2]), vit[3], SA.stage_a_stub(seed=0), clip_act=vit[4],
+                              num_words=20, lr=1e-4 * a.batch * world, dist_on=world > 1, bucket_mb=a.bucket_mb)
+    batch = {k: v.cuda() for k, v in SA.synthetic_batch(a.batch, size=a.size, seed=rank).items()}
+    for _ in range(4 + a.warmup):
+        tr.step(batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    comm = tr.reducer.comm
+    if world > 1 and a.backend == 'nccl' and comm is None:
+        sys.exit('bench.py: backend nccl but the RCCL data plane (tdr_comm_*) is not in use')
+    if rank != 0:
+        return
+    g = tr.optimizer.guard.read()
+    n_map = sum(p.numel() for k, p in zip(tr.names, tr.params) if k.startswith('mapping_'))
+    tokens = 257
+    # dense FLOPs per image: CLIP forward (SURVEY 8d) + Mapper fwd + 2x bwd (2 * tokens * params of the patch MLPs; the class-token
+    # MLPs see one token) + the cross-attention projections / products of the four levels (fwd + the dk / dv side of the backward)
+    f_mapper = 3 * 2 * (tokens - 1 + 1) * (n_map / 2)
+    ips = world * a.batch * a.steps / dt
+    line = {'metric': f'train images/sec (stage-A I2T mapping, {a.size}x{a.size}, bs={a.batch}/GPU)', 'value': ips, 'unit': 'images/sec',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {'hx2': 'f32 (2xfp16-split MFMA forward, 3xbf16-split MFMA backward; fp32 accumulate)', 'bx3': 'f32 (3xbf16-split MFMA)',
+                      'f32': 'f32 (exact fp32 MFMA)', 'h1': 'f16 (single fp16 MFMA product)'}[K.MATH],
+            'data': 'synthetic',
+            'guard': {'skipped_total': int(g.skipped), 'applied_steps': int(g.step)},
+            'config': {'workload': f'BASELINE configs[3]: I2T-mapper training step, CLIP ViT-{a.clip}/14 frozen + Mapper(1280->1024, 20 words) + injected '
+                                   f'cross-attention at 4096/1024/256/64 tokens (to_k_global/to_v_global trained), MSE, clip 1.0, AdamW; SD UNet/VAE/text '
+                                   f'transformer = fixed random linear stand-in (SURVEY 8d cfg4), {a.size}x{a.size}, bs={a.batch}/GPU',
+                       'global_batch': world * a.batch, 'parallelism': f'dp{world}', 'trained_parameters': sum(p.numel() for p in tr.params),
+                       'collectives': ('none (1 GPU)' if world == 1 else
+                                       ('tdr_comm_* (RCCL through the C ABI)' if comm is not None else f'torch.distributed ({a.backend})')),
+                       'hip_graph': bool(tr.use_hip_graph)},
+            'final_loss': float(loss.item()),
+            'roofline_step': {'alg_flop_per_image': vit[5] + f_mapper, 'clip_fwd_flop_per_image': vit[5], 'mapper_fwd_bwd_flop_per_image': f_mapper,
+                              'achieved_tflops': (vit[5] + f_mapper) * ips / world / 1e12,
+                              'achieved_split_flop_frac': (vit[5] + f_mapper) * ips / world / (PEAK_BF16 / 3.0),
+                              'weight_bytes_touched_per_step': 28.0 * sum(p.numel() for p in tr.params),
+                              'note': 'fp32-equivalent FLOPs against the 2-way-split ceiling (833 TF); the Mapper also streams 28 B per '
+                                      'trained parameter per step (weights fwd + bwd, gradients, AdamW state)'}}
+    print(json.dumps(line), flush=True)
+
+
 def pmc_traffic(prefix):
     """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/pmc_collect.sh -> profiles/r2/
     pmc_traffic.json).  The file records the hash of the kernel source it was collected on: a mismatch means the counters
@@ -186,7 +253,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc'],
+    ap.add_argument('--clip', default='H', choices=['H', 'L'], help='--arch i2t: CLIP ViT-H/14 (SD-2.1, the Mapper input width 1280) or ViT-L/14 geometry')
+    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc', 'i2t'],
                     help="nafnet: the headline workload (BASELINE configs[1]); restormer: configs[2]'s per-GPU workload "
                          '(Restormer-ref dim 48, 256x256, bs 8) -- a secondary measurement, not the metric line')
     ap.add_argument('--batch', type=int, default=None)
@@ -230,6 +298,12 @@ def main():
             # the N-GPU line is an RCCL-through-the-C-ABI measurement or it is an error: no silent torch.distributed fallback
             os.environ.setdefault('TDR_COMM', 'rccl')
         dist.init_process_group(a.backend)
+    if a.arch == 'i2t':
+        bench_i2t(a, world, rank, local)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from textualdegremoval_amd.models import create_model
     from textualdegremoval_amd.utils.synthetic import randomize_gates, synthetic_pair
     from textualdegremoval_amd import kernels as K

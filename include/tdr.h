@@ -465,12 +465,31 @@ int tdr_mapper_combine_bwd(const float* go, int B, int D, int LD, int T, int wor
 int tdr_cross_attention_fwd(const float* q, const float* k, const float* v, int B, int C, int heads, int Tq, int LDq,
                             int Tk, int LDk, float scale, float* out, float* lse, void* stream);
 /* gradient of the above: dout [B][C][LDq] -> dq [B][C][LDq], dk, dv [B][C][LDk] (padding columns zeroed).
- * Two deterministic passes (per-query-tile dq, per-key-tile dk/dv), no atomics.  ws >= B*heads*LDq floats. */
+ * Two deterministic passes (per-query-tile dq, per-key-tile dk/dv), no atomics.  ws >= B*heads*LDq floats.
+ * dq may be NULL (queries from a frozen producer: the stage-A step only needs dk / dv): the dq pass is skipped. */
 int tdr_cross_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                             const float* lse, int B, int C, int heads, int Tq, int LDq, int Tk, int LDk, float scale,
                             float* dq, float* dk, float* dv, float* ws, void* stream);
 /* dst[b][c][r] = src[b][r][c] (r < R), 0 for R <= r < LDd: token-major [B][T][D] <-> channel-major [B][D][LD] */
 int tdr_transpose_pad(const float* src, int B, int R, int C, int LDd, float* dst, void* stream);
+/* Stage-A train step glue (main_train_i2t_mapping.py:704-760).
+ * inj_forward_text's embedding injection (:139-151) + position embedding, written channel-major [B][D][LD]: the L mapper words
+ * inj [B][L][D] replace the placeholder token at position idx[b] of the prompt ids [B][S] (int32), the rest of the prompt moves
+ * up by L - 1, what no longer fits in S positions is dropped; tok_emb [V][D], pos_emb [S][D]; columns S..LD-1 are zero. */
+int tdr_text_inject_fwd(const int* ids, const float* tok_emb, const float* pos_emb, const float* inj, const int* idx,
+                        int B, int S, int D, int L, int LD, float* out, void* stream);
+/* its gradient w.r.t. inj: dinj[b][j][:] = dnew[b][:][idx[b] + j] (0 past the end of the prompt) */
+int tdr_text_inject_bwd(const float* dnew, const int* idx, int B, int S, int D, int L, int LD, float* dinj, void* stream);
+/* DDIMScheduler.add_noise (:717; diffusers, third party): out = sqrt(ac[t_b]) x + sqrt(1 - ac[t_b]) noise, t [B] int32 */
+int tdr_add_noise(const float* x, const float* noise, const int* t, const float* alphas_cumprod, int B, int64_t per,
+                  float* out, void* stream);
+/* The stand-in for the frozen SD UNet (third party, absent: SURVEY 8d cfg4 "fixed random linear stub") needs three pieces of
+ * glue around the real injected cross-attention: the level input [B][C+4][H/f][W/f] = f x f average pool of x [B][C][H][W]
+ * followed by 4 planes of time features sin / cos(2 pi k t_b / 1000), k = 1, 2; nearest-neighbour upsampling by f
+ * (optionally accumulated into dst); and its adjoint, the f x f block sum. */
+int tdr_pool_time(const float* x, const int* t, int B, int C, int H, int W, int f, float* out, void* stream);
+int tdr_upsample_nearest_add(const float* src, int planes, int H, int W, int f, int accumulate, float* dst, void* stream);
+int tdr_pool_sum(const float* src, int planes, int H, int W, int f, float* dst, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Optimiser: global-norm clip (max_norm 0.01) + AdamW, multi-tensor

@@ -38,7 +38,10 @@ def sample(t, n=16):
 def load_reference_defs(names):
     src = open(REF_SCRIPT).read()
     tree = ast.parse(src)
-    ns = {'torch': torch, 'nn': nn, 'F': F}
+    import types
+    from typing import Optional, Tuple, Union
+    ns = {'torch': torch, 'nn': nn, 'F': F, 'Optional': Optional, 'Tuple': Tuple, 'Union': Union,
+          'BaseModelOutputWithPooling': lambda **kw: types.SimpleNamespace(**kw)}
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)) and node.name in names:
             node.decorator_list = []
@@ -165,8 +168,58 @@ def cross_attention_case():
     np.savez_compressed(os.path.join(HERE, 'i2t_xattn.npz'), **d)
 
 
+def text_injection_case():
+    """`inj_forward_text` (:108-194), the patched CLIPTextTransformer.__call__: the reference's own function is executed on a
+    stand-in `self` that carries what it reads -- embeddings.token_embedding, embeddings(...) (adds the position embedding to
+    inputs_embeds), encoder (ONE Linear here, the stage-A stand-in for the 23 third-party transformer layers), final_layer_norm
+    and config.  The placeholder-token injection (:139-151) and the final LayerNorm (:176) are the reference's lines."""
+    import types
+    from typing import Optional, Tuple, Union
+    ns = load_reference_defs({'inj_forward_text', '_build_causal_attention_mask'})
+    fn = ns['inj_forward_text']
+    V, D, S, L, B = 50, 24, 77, 5, 3
+    g = torch.Generator().manual_seed(21)
+
+    class Emb(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.token_embedding = nn.Embedding(V, D)
+            self.position_embedding = nn.Embedding(S, D)
+
+        def forward(self, input_ids=None, position_ids=None, inputs_embeds=None):
+            return inputs_embeds + self.position_embedding.weight[None, :inputs_embeds.shape[1]]
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = nn.Linear(D, D)
+
+        def forward(self, inputs_embeds=None, **kw):
+            return (self.proj(inputs_embeds),)
+    me = types.SimpleNamespace(embeddings=Emb(), encoder=Enc(), final_layer_norm=nn.LayerNorm(D),
+                               config=types.SimpleNamespace(output_attentions=False, output_hidden_states=False, use_return_dict=False))
+    with torch.no_grad():
+        for p in list(me.embeddings.parameters()) + list(me.encoder.parameters()) + list(me.final_layer_norm.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.2) + (1.0 if p.dim() == 1 and p is me.final_layer_norm.weight else 0.0))
+    ids = torch.randint(0, V, (B, S), generator=g)
+    inj = torch.randn(B, L, D, generator=g, requires_grad=True)
+    idx = torch.tensor([1, 40, S - L])                          # first slot after BOS, middle, last position that still fits
+    out = fn(me, {'input_ids': ids, 'inj_embedding': inj, 'inj_index': idx})[0]
+    go = torch.randn(out.shape, generator=g)
+    (out * go).sum().backward()
+    d = dict(ids=ids.numpy(), inj=inj.detach().numpy(), idx=idx.numpy(), out=out.detach().numpy(), go=go.numpy(), ginj=inj.grad.numpy(),
+             tok=me.embeddings.token_embedding.weight.detach().numpy(), pos=me.embeddings.position_embedding.weight.detach().numpy(),
+             proj_w=me.encoder.proj.weight.detach().numpy(), proj_b=me.encoder.proj.bias.detach().numpy(),
+             ln_w=me.final_layer_norm.weight.detach().numpy(), ln_b=me.final_layer_norm.bias.detach().numpy())
+    np.savez_compressed(os.path.join(HERE, 'i2t_text_inject.npz'), **d)
+    print('text injection', out.shape, float(out.abs().mean()))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'text_inject':
+        text_injection_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'clip_full':
         clip_full_geometry_cases()
         sys.exit(0)
@@ -174,3 +227,4 @@ if __name__ == '__main__':
     clip_full_geometry_cases()
     mapper_case()
     cross_attention_case()
+    text_injection_case()

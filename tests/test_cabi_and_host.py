@@ -133,3 +133,23 @@ def test_masa_geometry_matches_reference_formulas():
     assert (g.py, g.px, g.K, g.dia_x, g.side) == (1, 1, 8, 13, 15)                    # cfg1 (wrap case)
     with pytest.raises(ValueError):
         MasaGeom(128, 256, 128, 128, 4, 8, 1.5, [1, 2, 3])                            # non-square: reference crashes too
+
+
+def test_optimizer_param_indices_follow_the_reference_for_unused_tensors():
+    """PromptIR-ref registers six convolutions it never uses.  The reference's setup_optimizers (image_restoration_ref_model.py:
+    160-170) puts EVERY named parameter into the two groups (their .grad stays None, AdamW skips them), so the parameter indices
+    inside optimizer.state_dict() -- what a `.state` resume file is keyed by -- count them.  Same here."""
+    import bench
+    from textualdegremoval_amd.models import create_model
+    opt = bench.make_opt(32, [1, 1, 1, 1], 64, False, arch='promptir')
+    opt['num_gpu'] = 0
+    m = create_model(opt)
+    named = list(m.net_g.named_parameters())
+    groups = m.optimizer_g.param_groups
+    assert len(groups) == 2
+    assert [id(p) for p in groups[0]['params']] == [id(p) for k, p in named if 'masa' not in k]
+    assert [id(p) for p in groups[1]['params']] == [id(p) for k, p in named if 'masa' in k]
+    unused = [k for k, _ in named if k.startswith(m.net_g.unused_parameter_prefixes)]
+    assert len(unused) >= 6
+    sd = m.optimizer_g.state_dict()
+    assert sum(len(g['params']) for g in sd['param_groups']) == len(named)

@@ -219,6 +219,12 @@ SIGNATURES = {
     'tdr_prompt_mix_bwd_ws_floats': (i64, [i32, i32]),
     'tdr_prompt_mix_bwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i64, c_fp, c_fp, c_fp, c_fp]),
     'tdr_resize_bilinear_bwd': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_text_inject_fwd': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_text_inject_bwd': (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_add_noise': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp]),
+    'tdr_pool_time': (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_upsample_nearest_add': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_pool_sum': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_comm_available': (i32, []),
     'tdr_comm_unique_id_bytes': (i32, []),
     'tdr_comm_unique_id': (i32, [c_fp]),

@@ -92,6 +92,100 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// ---- stage-A train step glue (scripts/train/main_train_i2t_mapping.py:704-760) -------------------------------------------
+// inj_forward_text's embedding injection (:139-151) fused with the position embedding, written channel-major:
+//   new[b][p] = tok[ids[b][p]]                    p <  idx_b
+//             = inj[b][p - idx_b]                 idx_b <= p < idx_b + L          (the L mapper words replace the placeholder)
+//             = tok[ids[b][p - L + 1]]            p >= idx_b + L                  (the rest of the prompt shifted by L - 1)
+//   out[b][d][p] = new[b][p][d] + pos[p][d]  for p < S, 0 for S <= p < LD
+__global__ void text_inject_fwd_kernel(const int* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
+                                       const float* __restrict__ inj, const int* __restrict__ idx, int S, int D, int L, int LD,
+                                       long total, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % LD);
+        const long r = i / LD;
+        const int d = (int)(r % D), b = (int)(r / D);
+        float v = 0.f;
+        if (p < S) {
+            const int i0 = idx[b];
+            if (p >= i0 && p < i0 + L) v = inj[((long)b * L + (p - i0)) * D + d];
+            else v = tok[(long)ids[b * S + (p < i0 ? p : p - L + 1)] * D + d];
+            v += pos[(long)p * D + d];
+        }
+        out[i] = v;
+    }
+}
+// dinj[b][j][d] = dnew[b][d][idx_b + j]  (0 where idx_b + j >= S: words pushed past the end of the prompt are dropped)
+__global__ void text_inject_bwd_kernel(const float* __restrict__ dnew, const int* __restrict__ idx, int S, int D, int L, int LD,
+                                       long total, float* __restrict__ dinj) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const long r = i / D;
+        const int j = (int)(r % L), b = (int)(r / L);
+        const int p = idx[b] + j;
+        dinj[i] = p < S ? dnew[((long)b * D + d) * LD + p] : 0.f;
+    }
+}
+// DDIMScheduler.add_noise (:717): out = sqrt(ac[t_b]) x + sqrt(1 - ac[t_b]) noise
+__global__ void add_noise_kernel(const float* __restrict__ x, const float* __restrict__ noise, const int* __restrict__ t,
+                                 const float* __restrict__ ac, long per, long total, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float a = ac[t[i / per]];
+        out[i] = sqrtf(a) * x[i] + sqrtf(1.f - a) * noise[i];
+    }
+}
+// the stub UNet's level input: channels 0..C-1 = f x f average pool of x [B][C][H][W], channels C..C+3 = the time features
+// sin(2 pi tau), cos(2 pi tau), sin(4 pi tau), cos(4 pi tau), tau = t_b / 1000, constant over the plane.  out [B][C+4][H/f][W/f]
+__global__ void pool_time_kernel(const float* __restrict__ x, const int* __restrict__ t, int C, int H, int W, int f, long total,
+                                 float* __restrict__ out) {
+    const int h = H / f, w = W / f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % w);
+        long r = i / w;
+        const int oy = (int)(r % h); r /= h;
+        const int c = (int)(r % (C + 4)), b = (int)(r / (C + 4));
+        float v;
+        if (c < C) {
+            const float* p = x + (((long)b * C + c) * H + (long)oy * f) * W + (long)ox * f;
+            float s = 0.f;
+            for (int y = 0; y < f; ++y)
+                for (int xx = 0; xx < f; ++xx) s += p[(long)y * W + xx];
+            v = s / (float)(f * f);
+        } else {
+            const float tau = (float)t[b] * 1e-3f, w2 = 6.283185307179586f * (float)(1 + ((c - C) >> 1));
+            v = ((c - C) & 1) ? cosf(w2 * tau) : sinf(w2 * tau);
+        }
+        out[i] = v;
+    }
+}
+// nearest-neighbour upsample by f, accumulated: dst[b][c][y][x] (+)= src[b][c][y/f][x/f]
+__global__ void upsample_add_kernel(const float* __restrict__ src, int H, int W, int f, int accumulate, long total, float* __restrict__ dst) {
+    const int h = H / f, w = W / f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long r = i / W;
+        const int y = (int)(r % H);
+        const long plane = r / H;
+        const float v = src[(plane * h + y / f) * w + x / f];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+// its adjoint: dst[b][c][oy][ox] = sum over the f x f block of src
+__global__ void pool_sum_kernel(const float* __restrict__ src, int H, int W, int f, long total, float* __restrict__ dst) {
+    const int h = H / f, w = W / f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % w);
+        const long r = i / w;
+        const int oy = (int)(r % h);
+        const long plane = r / h;
+        const float* p = src + (plane * H + (long)oy * f) * W + (long)ox * f;
+        float s = 0.f;
+        for (int y = 0; y < f; ++y)
+            for (int xx = 0; xx < f; ++xx) s += p[(long)y * W + xx];
+        dst[i] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" int tdr_leaky_relu_fwd(const float* x, int64_t numel, float slope, float* y, void* stream) {
@@ -138,5 +232,57 @@ extern "C" int tdr_transpose_pad(const float* src, int B, int R, int C, int LDd,
     hipLaunchKernelGGL(transpose_kernel, dim3(tdr_cdiv(C, 32), tdr_cdiv(LDd, 32), B), dim3(256), 0, (hipStream_t)stream, src, R, C,
                        LDd, dst);
     TDR_LAUNCH_CHECK("transpose_pad");
+    return TDR_OK;
+}
+
+extern "C" int tdr_text_inject_fwd(const int* ids, const float* tok_emb, const float* pos_emb, const float* inj, const int* idx,
+                                   int B, int S, int D, int L, int LD, float* out, void* stream) {
+    TDR_REQUIRE(ids && tok_emb && pos_emb && inj && idx && out && B > 0 && S > 0 && L >= 1 && LD >= S, "tdr_text_inject_fwd: bad argument");
+    const long total = (long)B * D * LD;
+    hipLaunchKernelGGL(text_inject_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, ids, tok_emb, pos_emb, inj, idx,
+                       S, D, L, LD, total, out);
+    TDR_LAUNCH_CHECK("text_inject_fwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_text_inject_bwd(const float* dnew, const int* idx, int B, int S, int D, int L, int LD, float* dinj, void* stream) {
+    TDR_REQUIRE(dnew && idx && dinj && B > 0 && S > 0 && L >= 1 && LD >= S, "tdr_text_inject_bwd: bad argument");
+    const long total = (long)B * L * D;
+    hipLaunchKernelGGL(text_inject_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dnew, idx, S, D, L, LD, total, dinj);
+    TDR_LAUNCH_CHECK("text_inject_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_add_noise(const float* x, const float* noise, const int* t, const float* alphas_cumprod, int B, int64_t per,
+                             float* out, void* stream) {
+    TDR_REQUIRE(x && noise && t && alphas_cumprod && out && B > 0 && per > 0, "tdr_add_noise: bad argument");
+    const long total = (long)B * per;
+    hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, noise, t, alphas_cumprod, (long)per,
+                       total, out);
+    TDR_LAUNCH_CHECK("add_noise");
+    return TDR_OK;
+}
+
+extern "C" int tdr_pool_time(const float* x, const int* t, int B, int C, int H, int W, int f, float* out, void* stream) {
+    TDR_REQUIRE(x && t && out && f >= 1 && H % f == 0 && W % f == 0, "tdr_pool_time: bad argument");
+    const long total = (long)B * (C + 4) * (H / f) * (W / f);
+    hipLaunchKernelGGL(pool_time_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, t, C, H, W, f, total, out);
+    TDR_LAUNCH_CHECK("pool_time");
+    return TDR_OK;
+}
+
+extern "C" int tdr_upsample_nearest_add(const float* src, int planes, int H, int W, int f, int accumulate, float* dst, void* stream) {
+    TDR_REQUIRE(src && dst && f >= 1 && H % f == 0 && W % f == 0, "tdr_upsample_nearest_add: bad argument");
+    const long total = (long)planes * H * W;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, H, W, f, accumulate, total, dst);
+    TDR_LAUNCH_CHECK("upsample_nearest_add");
+    return TDR_OK;
+}
+
+extern "C" int tdr_pool_sum(const float* src, int planes, int H, int W, int f, float* dst, void* stream) {
+    TDR_REQUIRE(src && dst && f >= 1 && H % f == 0 && W % f == 0, "tdr_pool_sum: bad argument");
+    const long total = (long)planes * (H / f) * (W / f);
+    hipLaunchKernelGGL(pool_sum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, H, W, f, total, dst);
+    TDR_LAUNCH_CHECK("pool_sum");
     return TDR_OK;
 }

@@ -35,6 +35,12 @@ __global__ __launch_bounds__(256) void ssim3d_kernel(SsimArgs p) {
     const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
     const int ty = tid >> 4, tx = tid & 15;
     float sum = 0.f;
+    // Variances are differences of window means, E[x^2] - E[x]^2: on [0,255] images both terms are ~6e4 and a float32 difference
+    // loses the signal on smooth regions (the reference's _ssim_cly runs in float64, metrics/psnr_ssim.py:184-222).  The window
+    // weights sum to 1, so variances and the covariance are invariant under x -> x - c: every workgroup subtracts ONE constant
+    // per image (its tile-centre sample) while staging and adds it back to the means -- the squares then hold local deviations only.
+    const int yc = min(y0 + T / 2, p.H - 1), xc = min(x0 + T / 2, p.W - 1);
+    const float ca = p.a[((int64_t)yc * p.W + xc) * C], cb = p.b[((int64_t)yc * p.W + xc) * C];
     for (int k = 0; k < C; ++k) {                 // output channel of the volume
         // stage: the five raw fields at replicate-clamped coordinates, channel axis mixed on the way in
         for (int i = tid; i < E * E; i += 256) {
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(256) void ssim3d_kernel(SsimArgs p) {
             float acc[NF] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < C; ++j) {
-                const float va = pa[j], vb = pb[j], m = p.mc[k * 4 + j];
+                const float va = pa[j] - ca, vb = pb[j] - cb, m = p.mc[k * 4 + j];
                 acc[0] += m * va; acc[1] += m * vb; acc[2] += m * (va * va); acc[3] += m * (vb * vb); acc[4] += m * (va * vb);
             }
 #pragma unroll
@@ -71,9 +77,9 @@ __global__ __launch_bounds__(256) void ssim3d_kernel(SsimArgs p) {
                 for (int j = 0; j < 11; ++j) acc += p.g[j] * s1[f][ty + j][tx];
                 v[f] = acc;
             }
-            const float mu1 = v[0], mu2 = v[1];
+            const float s11 = v[2] - v[0] * v[0], s22 = v[3] - v[1] * v[1], s12 = v[4] - v[0] * v[1];   // shift-invariant
+            const float mu1 = v[0] + ca, mu2 = v[1] + cb;
             const float m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
-            const float s11 = v[2] - m11, s22 = v[3] - m22, s12 = v[4] - m12;
             sum += ((2.f * m12 + p.c1) * (2.f * s12 + p.c2)) / ((m11 + m22 + p.c1) * (s11 + s22 + p.c2));
         }
         __syncthreads();

@@ -691,7 +691,7 @@ extern "C" int tdr_cross_attention_fwd(const float* q, const float* k, const flo
 extern "C" int tdr_cross_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                        const float* lse, int B, int C, int heads, int Tq, int LDq, int Tk, int LDk, float scale,
                                        float* dq, float* dk, float* dv, float* ws, void* stream) {
-    TDR_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && ws, "tdr_cross_attention_bwd: null pointer (ws: B*heads*LDq floats)");
+    TDR_REQUIRE(q && k && v && out && dout && lse && dk && dv && ws, "tdr_cross_attention_bwd: null pointer (ws: B*heads*LDq floats)");
     TDR_REQUIRE(heads > 0 && C % heads == 0 && LDq >= Tq && LDk >= Tk && Tq > 0 && Tk > 0, "tdr_cross_attention_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int hd = C / heads;
@@ -700,7 +700,7 @@ extern "C" int tdr_cross_attention_bwd(const float* q, const float* k, const flo
     dim3 gq(tdr_cdiv(LDq, 128), heads, B), gk(tdr_cdiv(LDk, 128), heads, B);
 #define ATTN_BWD(H)                                                                            \
     do {                                                                                       \
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<H>, gq, dim3(256), 0, st, a);                    \
+        if (dq) hipLaunchKernelGGL(attn_bwd_dq_kernel<H>, gq, dim3(256), 0, st, a);            \
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<H>, gk, dim3(256), 0, st, a);                   \
     } while (0)
     if (hd == 80) ATTN_BWD(80);

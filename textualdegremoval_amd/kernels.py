@@ -1171,16 +1171,73 @@ def cross_attention_fwd(q, k, v, heads, scale, Tq, Tk):
     return out, lse
 
 
-def cross_attention_bwd(q, k, v, out, dout, lse, heads, scale, Tq, Tk):
+def cross_attention_bwd(q, k, v, out, dout, lse, heads, scale, Tq, Tk, need_dq=True):
     B, Cc = q.shape[0], q.shape[1]
     LDq, LDk = q.shape[2] * q.shape[3], k.shape[2] * k.shape[3]
     assert dout.is_contiguous() and out.is_contiguous()
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dq, dk, dv = (torch.empty_like(q) if need_dq else None), torch.empty_like(k), torch.empty_like(v)
     ws = workspace(B * heads * LDq, q.device, 'xattn')
     check(_lib.load().tdr_cross_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
-                                              lse.data_ptr(), B, Cc, heads, Tq, LDq, Tk, LDk, float(scale), dq.data_ptr(),
+                                              lse.data_ptr(), B, Cc, heads, Tq, LDq, Tk, LDk, float(scale), _p(dq),
                                               dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), _stream()), 'tdr_cross_attention_bwd')
     return dq, dk, dv
+
+
+# ---- stage-A train step glue (csrc/tdr_i2t.hip; main_train_i2t_mapping.py:704-760)
+def _i32(t):
+    assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
+    return t.data_ptr()
+
+
+def text_inject_fwd(ids, tok_emb, pos_emb, inj, idx):
+    """ids [B,S] int32, tok_emb [V,D], pos_emb [S,D], inj [B,L,D], idx [B] int32 -> channel-major [B, D, LD/32, 32]"""
+    B, S = ids.shape
+    D, L = tok_emb.shape[1], inj.shape[1]
+    LD = token_ld(S - 1)
+    out = torch.empty(B, D, LD // 32, 32, dtype=torch.float32, device=inj.device)
+    check(_lib.load().tdr_text_inject_fwd(_i32(ids), tok_emb.data_ptr(), pos_emb.data_ptr(), inj.contiguous().data_ptr(), _i32(idx),
+                                          B, S, D, L, LD, out.data_ptr(), _stream()), 'tdr_text_inject_fwd')
+    return out
+
+
+def text_inject_bwd(dnew, idx, S, L):
+    B, D = dnew.shape[0], dnew.shape[1]
+    LD = dnew.shape[2] * dnew.shape[3]
+    dinj = torch.empty(B, L, D, dtype=torch.float32, device=dnew.device)
+    check(_lib.load().tdr_text_inject_bwd(dnew.data_ptr(), _i32(idx), B, S, D, L, LD, dinj.data_ptr(), _stream()), 'tdr_text_inject_bwd')
+    return dinj
+
+
+def add_noise(x, noise, t, alphas_cumprod):
+    assert x.is_contiguous() and noise.is_contiguous() and x.shape == noise.shape
+    out = torch.empty_like(x)
+    check(_lib.load().tdr_add_noise(x.data_ptr(), noise.data_ptr(), _i32(t), alphas_cumprod.data_ptr(), x.shape[0],
+                                    x.numel() // x.shape[0], out.data_ptr(), _stream()), 'tdr_add_noise')
+    return out
+
+
+def pool_time(x, t, f):
+    B, Cc, H, W = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(B, Cc + 4, H // f, W // f, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_pool_time(x.data_ptr(), _i32(t), B, Cc, H, W, f, out.data_ptr(), _stream()), 'tdr_pool_time')
+    return out
+
+
+def upsample_nearest_add_(dst, src, f, accumulate=True):
+    B, Cc, H, W = dst.shape
+    assert dst.is_contiguous() and src.is_contiguous() and src.shape == (B, Cc, H // f, W // f)
+    check(_lib.load().tdr_upsample_nearest_add(src.data_ptr(), B * Cc, H, W, f, 1 if accumulate else 0, dst.data_ptr(), _stream()),
+          'tdr_upsample_nearest_add')
+    return dst
+
+
+def pool_sum(src, f):
+    B, Cc, H, W = src.shape
+    assert src.is_contiguous()
+    out = torch.empty(B, Cc, H // f, W // f, dtype=torch.float32, device=src.device)
+    check(_lib.load().tdr_pool_sum(src.data_ptr(), B * Cc, H, W, f, out.data_ptr(), _stream()), 'tdr_pool_sum')
+    return out
 
 
 # ---------------------------------------------------------------------------

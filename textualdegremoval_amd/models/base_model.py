@@ -197,6 +197,8 @@ class BaseModel:
             state = {'epoch': epoch, 'iter': current_iter,
                      'optimizers': [o.state_dict() for o in self.optimizers],
                      'schedulers': [s.state_dict() for s in self.schedulers]}
+            if hasattr(self, 'extra_training_state'):
+                state['tdr'] = self.extra_training_state()
             torch.save(state, os.path.join(self.opt['path']['training_states'], f'{current_iter}.state'))
 
     def resume_training(self, resume_state):
@@ -207,6 +209,8 @@ class BaseModel:
             self.optimizers[i].load_state_dict(o)
         for i, s in enumerate(rs):
             self.schedulers[i].load_state_dict(s)
+        if hasattr(self, 'load_extra_training_state'):
+            self.load_extra_training_state(resume_state.get('tdr'))
 
     def reduce_loss_dict(self, loss_dict):
         """dist.reduce to rank 0 then / world (reference :353-378); returns python floats."""

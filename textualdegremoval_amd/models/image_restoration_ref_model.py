@@ -66,19 +66,20 @@ class RefGuidedImageCleanModel(BaseModel):
         self.setup_optimizers()
         self.setup_schedulers()
 
-    def _trainable_named_parameters(self):
-        """named_parameters() minus the tensors an architecture registers but never uses (PromptIR-ref's chnl_reduce* /
-        reduce_noise_channel_*): in the reference their .grad stays None, so clip_grad_norm_ and AdamW skip them."""
-        net = self.get_bare_model(self.net_g)
-        unused = tuple(getattr(net, 'unused_parameter_prefixes', ()))
-        return [(k, v) for k, v in self.net_g.named_parameters() if not (unused and k.replace('module.', '', 1).startswith(unused))]
+    def _optimizer_named_parameters(self):
+        """ALL named_parameters(), in registration order, like the reference's setup_optimizers (:160-170).  Tensors an
+        architecture registers but never uses (PromptIR-ref's chnl_reduce* / reduce_noise_channel_*, DRSformer-200L's
+        masa_blk_enc_level1.*) stay in the param groups exactly as there: their .grad stays None, so clip_grad_norm_ and
+        AdamW skip them (FusedClipAdamW._build does the same) -- and the parameter INDICES of optimizer.state_dict() are the
+        reference's, so its `.state` resume files load aligned."""
+        return list(self.net_g.named_parameters())
 
     def setup_optimizers(self):
         train_opt = self.opt['train']
         # reference quirk R3: the key read is 'fix_iterations' (YAMLs set 'param_fix_iterations')
         self.param_fix_iters = train_opt['fix_iterations'] if 'fix_iterations' in train_opt else None
         optim_params, optim_ref_params = [], []
-        for k, v in self._trainable_named_parameters():
+        for k, v in self._optimizer_named_parameters():
             (optim_ref_params if 'masa' in k else optim_params).append(v)
         groups = [{'params': optim_params, 'lr': train_opt['optim_g']['lr']},
                   {'params': optim_ref_params, 'lr': train_opt['optim_g']['ref_lr']}]
@@ -431,6 +432,28 @@ class RefGuidedImageCleanModel(BaseModel):
         if hasattr(self, 'gt'):
             out['gt'] = self.gt.detach().cpu()
         return out
+
+    # ---- what the reference's `.state` file does not know about: the loss scale of the fp16-split backward (device-resident
+    # StepGuard), the shift the range survey applied to it, and the one-way "masa" freeze (R3).  Extra key 'tdr' in the file;
+    # the reference's resume_training ignores unknown keys, ours restores them.
+    def extra_training_state(self):
+        st = {'masa_frozen': bool(getattr(self, '_masa_frozen', False)), 'scale_shift': int(getattr(self, '_scale_shift', 0)),
+              'bwd_full_range': bool(getattr(self, '_bwd_full_range', False))}
+        g = getattr(self.optimizer_g, 'guard', None)
+        if g is not None:
+            r = g.read()
+            st.update(guard_scale=float(r.scale), guard_max_scale=float(r.max_scale), skipped=int(r.skipped))
+        return st
+
+    def load_extra_training_state(self, st):
+        if not st:
+            return
+        self._masa_frozen = bool(st.get('masa_frozen', False))
+        self._scale_shift = int(st.get('scale_shift', 0))
+        self._bwd_full_range = bool(st.get('bwd_full_range', False))
+        if 'guard_scale' in st and isinstance(self.optimizer_g, FusedClipAdamW):
+            g = self.optimizer_g.ensure_guard(self.device)
+            g.write(scale=st['guard_scale'], max_scale=st.get('guard_max_scale', st['guard_scale']))
 
     def save(self, epoch, current_iter):
         if self.ema_decay > 0:
