@@ -426,17 +426,20 @@ int tdr_resize_bilinear(const float* src, int planes, int Hs, int Ws, float* dst
 int tdr_unfold_windows(const float* ref, int B, int C, int Hr, int Wr, int h, int stride, float* out, void* stream);
 /* Token tensors use a padded row length LD (multiple of 32, >= 1+T): column 0 class token, 1..T patches, rest padding,
  * so the 1x1-conv kernels see [B][D][LD] as an [LD/32] x 32 image.
+ * `flat` != 0 selects the BATCH-FLATTENED layout [D][B*LD] instead (image b's tokens at columns b*LD .. b*LD+LD-1 of one pixel
+ * axis): every Linear of the encoder is then ONE GEMM over B*LD pixels (full 128-pixel tiles, one pass over the weights)
+ * instead of B GEMMs over LD = 288 -- what the stage-A CLIP encoder uses (main_train_i2t_mapping.py:726-731).
  * p x p stride-p patch gather: x [B][Ci][H][W] -> [B][Ci*p*p][LD], patch t at column 1+t (patch_embed.py:26-80) */
-int tdr_patchify(const float* x, int B, int Ci, int H, int W, int p, int LD, float* out, void* stream);
+int tdr_patchify(const float* x, int B, int Ci, int H, int W, int p, int LD, int flat, float* out, void* stream);
 /* in place: column 0 = cls + pos[:,0], columns 1..T += pos, padding = 0 (pos channel-major [D][1+T]; vision_transformers.py:209-221) */
-int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int D, int T, int LD, void* stream);
+int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int D, int T, int LD, int flat, void* stream);
 /* multi-head softmax(q k^T scale) v over the first T columns; qkv [B][3C][LD] -> out [B][C][LD] (padding columns zeroed);
  * head dim C/heads in {16,32,64} (attention.py:56-71) */
 int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream);
 /* the same with the arithmetic named: math 0 = exact fp32 MFMA (what tdr_attention_fwd runs), 2 = 2-way fp16 split (3 f16 MFMA
  * products per fp32 product, fp32 accumulate and softmax) for the frozen no-grad ViTs -- q, k, v must lie in the fp16 range */
-int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, float* out,
-                           void* stream);
+int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, int flat,
+                           float* out, void* stream);
 /* cosine similarity of flattened patch-token maps (columns 1..T1-1), first arg-max, window gather:
  * fl [B][D][LD], fr [B*N][D][LD], windows [B*N][per] -> corr [B][N], index [B] (int32), ref_in [B][per] (:230-243) */
 int tdr_token_match(const float* fl, const float* fr, const float* windows, int B, int N, int D, int T1, int LD, int64_t per,
@@ -472,6 +475,24 @@ int tdr_cross_attention_bwd(const float* q, const float* k, const float* v, cons
                             float* dq, float* dk, float* dv, float* ws, void* stream);
 /* dst[b][c][r] = src[b][r][c] (r < R), 0 for R <= r < LDd: token-major [B][T][D] <-> channel-major [B][D][LD] */
 int tdr_transpose_pad(const float* src, int B, int R, int C, int LDd, float* dst, void* stream);
+/* Grouped Mapper (:40-81): the 2 x num_words independent MLPs run as G-way grouped GEMMs (tdr_conv_forward / tdr_conv_wgrad with
+ * N = G "images", per-image weights wp_ns and biases bias_ns, in_ns = 0 for the shared first-layer input) over tensors
+ * [G][C][P] (P = the tokens of ALL images along one axis).  What the GEMMs leave:
+ * nn.LayerNorm(C, eps) + nn.LeakyReLU(slope) fused, per-word affine parameters w, b [G][C]; mu, rstd [G][P] saved */
+int tdr_group_ln_act_fwd(const float* z, const float* w, const float* b, float eps, float slope, int G, int C, int P,
+                         float* y, float* mu, float* rstd, void* stream);
+/* its backward from dy (w.r.t. the activation output) and y (that output): dz [G][C][P], gw, gb [G][C], and gs [G][C] = the
+ * pixel sums of dz (the bias gradient of the Linear that produced z) -- fixed-order two-stage sums; ws >= tdr_group_ln_ws_floats */
+int64_t tdr_group_ln_ws_floats(int G, int C, int P);
+int tdr_group_ln_act_bwd(const float* dy, const float* y, const float* z, const float* mu, const float* rstd, const float* w,
+                         float slope, int G, int C, int P, float* dz, float* gw, float* gb, float* gs, float* ws, void* stream);
+/* out[b][g][d] = cls[g][d][b] + mean_{t=1..T} patch[g][d][b*LD + t] for all G words at once (:77-79; cls [G][D][32] holds the B
+ * class tokens as one 32-pixel row, patch [G][D][B*LD], out [B][G][D]), and its gradient */
+int tdr_mapper_combine_all(const float* cls, const float* patch, int B, int G, int D, int LD, int T, float* out, void* stream);
+int tdr_mapper_combine_all_bwd(const float* go, int B, int G, int D, int LD, int T, float* dcls, float* dpatch,
+                               float* gsum /* [G][D] = sum_b go: the pixel sum of dcls and of dpatch */, void* stream);
+/* tdr_gather_col for any token layout: dst[d][b] = src[b*img_stride + d*ch_stride + col] */
+int tdr_gather_col_strided(const float* src, int B, int D, int64_t img_stride, int64_t ch_stride, int col, float* dst, void* stream);
 /* Stage-A train step glue (main_train_i2t_mapping.py:704-760).
  * inj_forward_text's embedding injection (:139-151) + position embedding, written channel-major [B][D][LD]: the L mapper words
  * inj [B][L][D] replace the placeholder token at position idx[b] of the prompt ids [B][S] (int32), the rest of the prompt moves

@@ -46,7 +46,8 @@ def test_noise_vs_reference_statements():
             out = K.crop_augment(img[None].cuda(), torch.tensor([top], dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda(),
                                  torch.zeros(1, dtype=torch.int32).cuda(), 20, noise=randn[None, :, top:top + 20].contiguous().cuda(),
                                  sigma=sig.cuda())
-            assert np.abs(out[0].cpu().numpy() - G[f'noise_{tag}_out'][:, top:top + 20]).max() <= 6e-8
+            # (the kernel may contract the multiply-add into one FMA: half an ulp of 1.0 either way)
+            assert np.abs(out[0].cpu().numpy() - G[f"noise_{tag}_out"][:, top:top + 20]).max() <= 1.3e-7
 
 
 def test_small_images_are_reflect_padded_like_padding():

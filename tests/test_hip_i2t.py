@@ -232,3 +232,46 @@ def test_cross_attention_kernels_vs_torch(K, hd, Tq, Tk):
     assert maxdiff(dk.reshape(B, C, LDk)[:, :, :Tk], k.grad) < 5e-5
     assert maxdiff(dv.reshape(B, C, LDk)[:, :, :Tk], v.grad) < 5e-5
     assert dq.reshape(B, C, LDq)[:, :, Tq:].abs().max().item() == 0 and dk.reshape(B, C, LDk)[:, :, Tk:].abs().max().item() == 0
+
+
+def test_clip_batch_flattened_layout_equals_per_image_layout(K):
+    """ClipVisionEncoder.tokens(flat=True): the tokens of all images along ONE pixel axis ([1, D, B*LD/32, 32]) -- the same
+    per-pixel contractions in the same order, so the result must equal the per-image layout bit for bit"""
+    from textualdegremoval_amd.clip_vision import ClipVisionEncoder
+    sd = IO.synth_clip_params(160, 320, 2, 14, 56, seed=3)            # head dim 80 (ViT-H geometry)
+    enc = ClipVisionEncoder(sd, 'cuda', 2, act='gelu')
+    x = torch.rand(3, 3, 56, 56, generator=torch.Generator().manual_seed(1)).cuda()
+    a, Tn = enc.tokens(x)
+    f, Tf = enc.tokens(x, flat=True)
+    B, D, LD = 3, 160, a.shape[2] * a.shape[3]
+    assert Tn == Tf and f.shape == (1, D, B * LD // 32, 32)
+    back = f.reshape(D, B, LD).permute(1, 0, 2)[:, :, :Tn + 1]
+    assert torch.equal(back, a.reshape(B, D, LD)[:, :, :Tn + 1])
+
+
+def test_grouped_mapper_equals_the_per_word_chains(K):
+    """i2t.mapper_fwd_grouped / mapper_bwd_grouped (G-way grouped GEMMs, fused per-word LayerNorm + LeakyReLU, batch-flattened tokens)
+    against the per-word launches of mapper_fwd / mapper_bwd: same arithmetic per element up to the summation order of the reductions"""
+    from textualdegremoval_amd import i2t
+    torch.manual_seed(4)
+    words, B, Tn, din = 3, 3, 16, 64
+    mp = i2t.Mapper(din, 1024, words).cuda()
+    P = {k: p.data for k, p in mp.named_parameters()}
+    LD = K.token_ld(Tn)
+    emb = torch.randn(B, 1 + Tn, din, generator=torch.Generator().manual_seed(2)).cuda()
+    tok = K.transpose_pad(emb, LD).view(B, din, LD // 32, 32)
+    flat = tok.reshape(B, din, LD).permute(1, 0, 2).reshape(1, din, B * LD // 32, 32).contiguous()
+    out0, sv0 = i2t.mapper_fwd(tok, Tn, P, words)
+    go = torch.randn(out0.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    G0 = i2t.mapper_bwd(go, P, words, sv0)
+    st = i2t.MapperStacks(mp)
+    out1, sv1 = i2t.mapper_fwd_grouped(flat, B, Tn, st)
+    G1 = i2t.mapper_bwd_grouped(go, st, sv1)
+    assert maxdiff(out1, out0) < 2e-5 * max(1.0, out0.abs().max().item())
+    assert sorted(G0) == sorted(G1)
+    for k in G0:
+        assert maxdiff(G1[k], G0[k]) <= 2e-4 * G0[k].abs().max().item() + 1e-9, k
+    # the parameters now live in the stacks: an in-place update of one is visible through the other
+    p = dict(mp.named_parameters())['mapping_patch_1.3.weight']
+    p.data.add_(1.0)
+    assert torch.equal(st.W['mapping_patch_', 3][1], p.data)

@@ -175,9 +175,9 @@ SIGNATURES = {
                                c_fp, c_fp, c_fp, c_fp]),
     'tdr_resize_bilinear': (i32, [c_fp, i32, i32, i32, c_fp, i32, i32, c_fp]),
     'tdr_unfold_windows': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
-    'tdr_patchify': (i32, [c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
-    'tdr_vit_assemble': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
-    'tdr_attention_fwd_math': (i32, [c_fp, i32, i32, i32, i32, i32, f32, i32, c_fp, c_fp]),
+    'tdr_patchify': (i32, [c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_vit_assemble': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    'tdr_attention_fwd_math': (i32, [c_fp, i32, i32, i32, i32, i32, f32, i32, i32, c_fp, c_fp]),
     'tdr_attention_fwd': (i32, [c_fp, i32, i32, i32, i32, i32, f32, c_fp, c_fp]),
     'tdr_token_match': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i64, c_fp, c_fp, c_fp, c_fp]),
     'tdr_optim_chunk': (i32, []),
@@ -219,6 +219,12 @@ SIGNATURES = {
     'tdr_prompt_mix_bwd_ws_floats': (i64, [i32, i32]),
     'tdr_prompt_mix_bwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i64, c_fp, c_fp, c_fp, c_fp]),
     'tdr_resize_bilinear_bwd': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_group_ln_act_fwd': (i32, [c_fp, c_fp, c_fp, f32, f32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_group_ln_ws_floats': (i64, [i32, i32, i32]),
+    'tdr_group_ln_act_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_mapper_combine_all': (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_mapper_combine_all_bwd': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_gather_col_strided': (i32, [c_fp, i32, i32, i64, i64, i32, c_fp, c_fp]),
     'tdr_text_inject_fwd': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_text_inject_bwd': (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_add_noise': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp]),

@@ -68,22 +68,25 @@ class ClipVisionEncoder:
         return K.conv_forward(x, wp, mp, cout, 1, bias=bias, **kw)
 
     @torch.no_grad()
-    def tokens(self, x):
-        """x [B,3,H,W] at the encoder's input size -> (last hidden state, channel-major [B, D, LD/32, 32], T)."""
+    def tokens(self, x, flat=False):
+        """x [B,3,H,W] at the encoder's input size -> (last hidden state, channel-major [B, D, LD/32, 32], T).
+        flat=True: batch-flattened [1, D, B*LD/32, 32] (image b's tokens at columns b*LD ..): every Linear is one GEMM over all
+        B*LD tokens -- full pixel tiles and one pass over the weights per layer instead of B."""
         B, _, H, W = x.shape
         P = self.P
-        xp, T = K.patchify(x.contiguous(), self.patch)
+        fb = B if flat else 0
+        xp, T = K.patchify(x.contiguous(), self.patch, flat=flat)
         if T + 1 != self.pos.shape[1]:
             raise ValueError(f'CLIP encoder built for {self.pos.shape[1] - 1} patches, input gives {T} '
                              '(position embeddings are not interpolated, transformers CLIPVisionEmbeddings)')
-        t = K.vit_assemble_(self._linear(xp, 'patch', None), self.cls, self.pos, T)
+        t = K.vit_assemble_(self._linear(xp, 'patch', None), self.cls, self.pos, T, flat_batch=fb)
         t, _, _ = K.layernorm2d_fwd(t, P['pre_layrnorm.weight'], P['pre_layrnorm.bias'], self.eps)
         scale = (self.D // self.heads) ** -0.5
         for i in range(self.depth):
             p = f'encoder.layers.{i}.'
             h, _, _ = K.layernorm2d_fwd(t, P[p + 'layer_norm1.weight'], P[p + 'layer_norm1.bias'], self.eps)
             qkv = self._linear(h, p + 'qkv', P[p + 'qkv.bias'])
-            a = K.attention_fwd(qkv, self.heads, scale, T + 1)
+            a = K.attention_fwd(qkv, self.heads, scale, T + 1, flat_batch=fb)
             t = self._linear(a, p + 'out', P[p + 'out.bias'], res=t)
             h, _, _ = K.layernorm2d_fwd(t, P[p + 'layer_norm2.weight'], P[p + 'layer_norm2.bias'], self.eps)
             h = self._linear(h, p + 'mlp.fc1', P[p + 'mlp.fc1.bias'], relu=self.act)
@@ -91,12 +94,12 @@ class ClipVisionEncoder:
         return t, T
 
     @torch.no_grad()
-    def encode(self, image, size=224):
+    def encode(self, image, size=224, flat=False):
         """the reference call: F.interpolate(image, (224, 224), mode='bilinear') then image_features[0]."""
         x = image.contiguous()
         if tuple(x.shape[-2:]) != (size, size):
             x = K.resize_bilinear(x, size, size)
-        return self.tokens(x)
+        return self.tokens(x, flat=flat)
 
 
 def random_clip_state_dict(hidden=1024, inter=4096, layers=24, patch=14, image=224, seed=0):

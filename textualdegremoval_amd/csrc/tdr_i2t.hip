@@ -186,6 +186,182 @@ __global__ void pool_sum_kernel(const float* __restrict__ src, int H, int W, int
     }
 }
 
+// ---- grouped Mapper (the 2 x num_words MLPs of :40-81 as G-way grouped GEMMs + these fused glue kernels) ----------------------
+// Every tensor is [G][C][P]: G words, C channels, P pixels (tokens of ALL images of the batch along one axis).  nn.LayerNorm over C
+// (eps 1e-5) followed by nn.LeakyReLU, with PER-WORD affine parameters w, b [G][C]:
+//   y = lrelu(w_g (z - mu) rstd + b_g);  mu, rstd [G][P] saved
+// One workgroup = 64 pixels x 16 channel slices; a thread keeps its CPT = C/16 values of z in registers (one read of z).
+template <int CPT>
+__global__ __launch_bounds__(1024) void group_ln_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float eps, float slope, int C, int P,
+                                                               float* __restrict__ y, float* __restrict__ mu, float* __restrict__ rstd) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int px = blockIdx.x * 64 + lane, g = blockIdx.y;
+    const bool pok = px < P;
+    const unsigned pxc = pok ? px : P - 1;
+    const float* zg = z + (long)g * C * P;
+    float v[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + 16 * i;
+        v[i] = c < C ? (zg + (long)c * P)[pxc] : 0.f;
+        s += v[i];
+    }
+    red[slice][lane] = s;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    const float mean = t / (float)C;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const float d = (slice + 16 * i < C) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    red[slice][lane] = q;
+    __syncthreads();
+    t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    const float rs = 1.0f / sqrtf(t / (float)C + eps);
+    if (!pok) return;
+    float* yg = y + (long)g * C * P;
+    const float* wg = w + (long)g * C;
+    const float* bg = b + (long)g * C;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + 16 * i;
+        if (c < C) {
+            const float zn = (v[i] - mean) * rs * wg[c] + bg[c];
+            (yg + (long)c * P)[px] = zn > 0.f ? zn : zn * slope;
+        }
+    }
+    if (slice == 0) {
+        mu[(long)g * P + px] = mean;
+        rstd[(long)g * P + px] = rs;
+    }
+}
+
+// backward of the pair: dy (gradient w.r.t. the LeakyReLU output), y (that output: its sign is the sign of the LayerNorm
+// output), z, mu, rstd ->  dzn = dy * (y > 0 ? 1 : slope);  g = dzn * w;  dz = rstd (g - yhat mean_c(g yhat) - mean_c(g));
+// per-workgroup partials of the per-word parameter gradients  gw = sum_p dzn yhat,  gb = sum_p dzn, and of  gs = sum_p dz  (the
+// bias gradient of the Linear that produced z: a pass over dz saved)  -> part[g][tile][3][C].
+// Two passes over the workgroup's 64-pixel x C tile (the second one re-reads it from L2 / MALL): caching C/16 = 80 values
+// of three tensors per thread does not fit the 128 VGPRs a 1024-thread workgroup has.
+__global__ __launch_bounds__(1024) void group_ln_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               const float* __restrict__ z, const float* __restrict__ mu,
+                                                               const float* __restrict__ rstd, const float* __restrict__ w,
+                                                               float slope, int C, int P, float* __restrict__ dz,
+                                                               float* __restrict__ part) {
+    __shared__ float red[2][16][64];
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int px = blockIdx.x * 64 + lane, g = blockIdx.y;
+    const bool pok = px < P;
+    const unsigned pxc = pok ? px : P - 1;
+    const long base = (long)g * C * P;
+    const float m = mu[(long)g * P + pxc], rs = rstd[(long)g * P + pxc];
+    const float* wg = w + (long)g * C;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+    for (int c = slice; c < C; c += 16) {
+        const long row = base + (long)c * P;
+        const float gy = (dy + row)[pxc], yy = (y + row)[pxc], zz = (z + row)[pxc];
+        const float gg = (yy > 0.f ? gy : gy * slope) * wg[c];
+        s1 += gg;
+        s2 += gg * ((zz - m) * rs);
+    }
+    red[0][slice][lane] = s1; red[1][slice][lane] = s2;
+    __syncthreads();
+    float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { S1 += red[0][k][lane]; S2 += red[1][k][lane]; }
+    const float mg = S1 / (float)C, mgy = S2 / (float)C;
+    float* pb = part + (((long)g * gridDim.x + blockIdx.x) * 3) * C;
+#pragma unroll 4
+    for (int c = slice; c < C; c += 16) {             // c is wave-uniform
+        const long row = base + (long)c * P;
+        const float gy = (dy + row)[pxc], yy = (y + row)[pxc], zz = (z + row)[pxc];
+        const float dn = pok ? (yy > 0.f ? gy : gy * slope) : 0.f;
+        const float yh = (zz - m) * rs;
+        const float dzv = pok ? rs * (dn * wg[c] - yh * mgy - mg) : 0.f;
+        if (pok) (dz + row)[px] = dzv;
+        const float sw = wave_sum(dn * yh), sb = wave_sum(dn), sz = wave_sum(dzv);
+        if (lane == 0) { pb[c] = sw; pb[C + c] = sb; pb[2 * C + c] = sz; }
+    }
+}
+
+// gw[g][c] = sum_tiles part[g][tile][0][c], gb and gs likewise, fixed order
+__global__ void group_ln_finish_kernel(const float* __restrict__ part, int tiles, int C, long total, float* __restrict__ gw,
+                                       float* __restrict__ gb, float* __restrict__ gs) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long g = i / C;
+        const float* p = part + g * tiles * 3 * C;
+        float a = 0.f, b = 0.f, z = 0.f;
+        for (int t = 0; t < tiles; ++t) { a += p[(long)t * 3 * C + c]; b += p[(long)t * 3 * C + C + c]; z += p[(long)t * 3 * C + 2 * C + c]; }
+        gw[i] = a;
+        gb[i] = b;
+        gs[i] = z;
+    }
+}
+
+// out[b][g][d] = cls[g][d][b] + mean_{t=1..T} patch[g][d][b*LD + t]    (cls [G][D][32], patch [G][D][B*LD]); one wave per (g, d, b)
+__global__ __launch_bounds__(256) void mapper_combine_all_kernel(const float* __restrict__ cls, const float* __restrict__ patch,
+                                                                int B, int G, int D, int LD, int T, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);          // (g*D + d)*B + b
+    if (row >= (long)G * D * B) return;
+    const int b = (int)(row % B);
+    const long gd = row / B;
+    const float* p = patch + gd * ((long)B * LD) + (long)b * LD;
+    float s = 0.f;
+    for (int t = 1 + lane; t <= T; t += 64) s += p[t];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int g = (int)(gd / D), d = (int)(gd % D);
+        out[((long)b * G + g) * D + d] = cls[gd * 32 + b] + s / (float)T;
+    }
+}
+
+// dcls[g][d][b] = go[b][g][d] (0 for b >= B); dpatch[g][d][b*LD + t] = go[b][g][d] / T for 1 <= t <= T, else 0;
+// gsum[g][d] = sum_b go[b][g][d] = the pixel sum of dcls AND of dpatch: the bias gradient of both last Linears
+__global__ void mapper_combine_all_bwd_kernel(const float* __restrict__ go, int B, int G, int D, int LD, int T, float* __restrict__ dcls,
+                                              float* __restrict__ dpatch, float* __restrict__ gsum) {
+    const long total = (long)G * D * B * LD;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % LD);
+        long r = i / LD;
+        const int b = (int)(r % B);
+        const long gd = r / B;
+        const int g = (int)(gd / D), d = (int)(gd % D);
+        dpatch[i] = (t >= 1 && t <= T) ? go[((long)b * G + g) * D + d] / (float)T : 0.f;
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)G * D * 32; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i & 31);
+        const long gd = i >> 5;
+        const int g = (int)(gd / D), d = (int)(gd % D);
+        dcls[i] = b < B ? go[((long)b * G + g) * D + d] : 0.f;
+        if (b == 0) {
+            float t = 0.f;
+            for (int k = 0; k < B; ++k) t += go[((long)k * G + g) * D + d];
+            gsum[gd] = t;
+        }
+    }
+}
+
+// dst[d][b] = src[b*img_stride + d*ch_stride + col] for b < B, 0 for B <= b < 32  (gather_col for any token layout)
+__global__ void gather_col_strided_kernel(const float* __restrict__ src, int B, int D, long img_stride, long ch_stride, int col,
+                                          float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * 32) return;
+    const int d = i >> 5, b = i & 31;
+    dst[i] = b < B ? src[(long)b * img_stride + (long)d * ch_stride + col] : 0.f;
+}
+
 }  // namespace
 
 extern "C" int tdr_leaky_relu_fwd(const float* x, int64_t numel, float slope, float* y, void* stream) {
@@ -284,5 +460,63 @@ extern "C" int tdr_pool_sum(const float* src, int planes, int H, int W, int f, f
     const long total = (long)planes * (H / f) * (W / f);
     hipLaunchKernelGGL(pool_sum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, H, W, f, total, dst);
     TDR_LAUNCH_CHECK("pool_sum");
+    return TDR_OK;
+}
+
+extern "C" int tdr_group_ln_act_fwd(const float* z, const float* w, const float* b, float eps, float slope, int G, int C, int P,
+                                    float* y, float* mu, float* rstd, void* stream) {
+    TDR_REQUIRE(z && w && b && y && mu && rstd && G > 0 && C > 0 && P > 0 && slope > 0.f, "tdr_group_ln_act_fwd: bad argument");
+    TDR_REQUIRE(C <= 16 * 96, "tdr_group_ln_act_fwd: C = %d > 1536 not supported", C);
+    dim3 grid(tdr_cdiv(P, 64), G);
+    hipStream_t st = (hipStream_t)stream;
+#define GLN_FWD(K) hipLaunchKernelGGL(group_ln_act_fwd_kernel<K>, grid, dim3(1024), 0, st, z, w, b, eps, slope, C, P, y, mu, rstd)
+    if (C <= 16 * 16) GLN_FWD(16);
+    else if (C <= 16 * 64) GLN_FWD(64);
+    else if (C <= 16 * 80) GLN_FWD(80);
+    else GLN_FWD(96);
+#undef GLN_FWD
+    TDR_LAUNCH_CHECK("group_ln_act_fwd");
+    return TDR_OK;
+}
+
+extern "C" int64_t tdr_group_ln_ws_floats(int G, int C, int P) { return (int64_t)G * tdr_cdiv(P, 64) * 3 * C; }
+
+extern "C" int tdr_group_ln_act_bwd(const float* dy, const float* y, const float* z, const float* mu, const float* rstd,
+                                    const float* w, float slope, int G, int C, int P, float* dz, float* gw, float* gb, float* gs,
+                                    float* ws, void* stream) {
+    TDR_REQUIRE(dy && y && z && mu && rstd && w && dz && gw && gb && gs && ws && G > 0 && slope > 0.f, "tdr_group_ln_act_bwd: bad argument");
+    const int tiles = tdr_cdiv(P, 64);
+    dim3 grid(tiles, G);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(group_ln_act_bwd_kernel, grid, dim3(1024), 0, st, dy, y, z, mu, rstd, w, slope, C, P, dz, ws);
+    const long total = (long)G * C;
+    hipLaunchKernelGGL(group_ln_finish_kernel, dim3(grid_for(total)), dim3(256), 0, st, ws, tiles, C, total, gw, gb, gs);
+    TDR_LAUNCH_CHECK("group_ln_act_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_mapper_combine_all(const float* cls, const float* patch, int B, int G, int D, int LD, int T, float* out, void* stream) {
+    TDR_REQUIRE(cls && patch && out && B > 0 && B <= 32 && T >= 1 && T < LD, "tdr_mapper_combine_all: bad argument");
+    hipLaunchKernelGGL(mapper_combine_all_kernel, dim3(tdr_cdiv((long)G * D * B, 4)), dim3(256), 0, (hipStream_t)stream, cls, patch, B, G,
+                       D, LD, T, out);
+    TDR_LAUNCH_CHECK("mapper_combine_all");
+    return TDR_OK;
+}
+
+extern "C" int tdr_mapper_combine_all_bwd(const float* go, int B, int G, int D, int LD, int T, float* dcls, float* dpatch, float* gsum,
+                                          void* stream) {
+    TDR_REQUIRE(go && dcls && dpatch && gsum && B > 0 && B <= 32 && T >= 1 && T < LD, "tdr_mapper_combine_all_bwd: bad argument");
+    hipLaunchKernelGGL(mapper_combine_all_bwd_kernel, dim3(grid_for((long)G * D * B * LD)), dim3(256), 0, (hipStream_t)stream, go, B, G, D,
+                       LD, T, dcls, dpatch, gsum);
+    TDR_LAUNCH_CHECK("mapper_combine_all_bwd");
+    return TDR_OK;
+}
+
+extern "C" int tdr_gather_col_strided(const float* src, int B, int D, int64_t img_stride, int64_t ch_stride, int col, float* dst,
+                                      void* stream) {
+    TDR_REQUIRE(src && dst && B > 0 && B <= 32 && col >= 0, "tdr_gather_col_strided: need 1 <= B <= 32");
+    hipLaunchKernelGGL(gather_col_strided_kernel, dim3(tdr_cdiv((long)D * 32, 256)), dim3(256), 0, (hipStream_t)stream, src, B, D,
+                       (long)img_stride, (long)ch_stride, col, dst);
+    TDR_LAUNCH_CHECK("gather_col_strided");
     return TDR_OK;
 }

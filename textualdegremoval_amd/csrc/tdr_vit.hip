@@ -49,8 +49,9 @@ __global__ void unfold_windows_kernel(const float* __restrict__ ref, int C, int 
 // Token tensors are stored with a padded row length LD (a multiple of 32, >= 1+T) so that the 1x1-conv kernels can
 // treat [B][D][LD] as a [LD/32] x 32 image; column 0 is the class token, columns 1..T the patches, the rest padding.
 // x [B][Ci][H][W] -> out [B][Ci*p*p][LD]: row k = c*p*p + ky*p + kx, patch t = ty*cols + tx at column 1+t, zeros elsewhere
+// flat: out [Ci*p*p][B*LD] instead (image b at columns b*LD .. b*LD + LD - 1), the batch-flattened token layout
 __global__ void patchify_kernel(const float* __restrict__ x, int Ci, int H, int W, int p, int cols, int T, int LD, long total,
-                                float* __restrict__ out) {
+                                int B, int flat, float* __restrict__ out) {
     const int K = Ci * p * p;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % LD);
@@ -64,16 +65,17 @@ __global__ void patchify_kernel(const float* __restrict__ x, int Ci, int H, int 
             const int ty = t / cols, tx = t % cols;
             v = x[((b * Ci + c) * H + ty * p + ky) * W + tx * p + kx];
         }
-        out[i] = v;
+        out[flat ? ((long)k * B + b) * LD + col : i] = v;
     }
 }
 
 // in place on tok [B][D][LD]: column 0 = cls + pos[:,0]; columns 1..T += pos; padding columns = 0   (pos is [D][1+T])
+// (flat layout [D][B*LD]: every LD-column group is one image's tokens, the channel is i / (B*LD))
 __global__ void vit_assemble_kernel(float* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ pos,
-                                    int D, int T, int LD, long total) {
+                                    int D, int T, int LD, long total, long ch_span) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % LD);
-        const int d = (int)((i / LD) % D);
+        const int d = (int)((i / ch_span) % D);
         float v = 0.f;
         if (col == 0) v = cls[d] + pos[(long)d * (T + 1)];
         else if (col <= T) v = tok[i] + pos[(long)d * (T + 1) + col];
@@ -89,12 +91,17 @@ __global__ void vit_assemble_kernel(float* __restrict__ tok, const float* __rest
 // round trip, no transposes.  Output columns (queries) are contiguous across lanes: coalesced stores.
 // qkv [B][3C][LD] channel-major: q rows h*HD.., k rows C + h*HD.., v rows 2C + h*HD..;  out [B][C][LD].
 // Separate q / k / v tensors (cross-attention: Tq queries, Tk keys; lse optional = m + log(l) per query, for the backward).
+// Addressing is (batch offset, channel stride): element (b, c, t) of q lives at q + b*q_bs + c*qcs + t.  The per-image layout
+// [B][C][LD] has q_bs = C*LD, qcs = LD; the batch-flattened layout [C][B*LD] of the CLIP encoder (all images' tokens along one
+// pixel axis, so the Linears see B*LD-pixel GEMMs) has q_bs = LD, qcs = B*LD.
 struct AttnArgs {
     const float* q; long q_bs; int LDq, Tq;           // [B][C][LDq]
     const float* k; const float* v; long kv_bs; int LDk, Tk;
     int C; float scale;
-    float* out;                                        // [B][C][LDq]
+    float* out;                                        // element (b, c, t) at out + b*out_bs + c*qcs + t
     float* lse;                                        // [B][heads][LDq] or null
+    long qcs, kcs;                                     // channel strides of q / out and of k / v
+    long out_bs;
 };
 
 template <int HD>
@@ -106,13 +113,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int C = a.C, T = a.Tk, LD = a.LDk, LDq = a.LDq;
     const float scale = a.scale;
     float* out = a.out;
-    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * LDq;
-    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * LD;
-    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * LD;
+    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * a.qcs;
+    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * a.kcs;
+    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * a.kcs;
     const bool qok = q0 + j < a.Tq;
     float qb[HD / 2];                                      // B operand of S^T: Q[q = j][d = 2s + kk] * scale
 #pragma unroll
-    for (int s = 0; s < HD / 2; ++s) qb[s] = qok ? Q[(long)(2 * s + kk) * LDq + q0 + j] * scale : 0.f;
+    for (int s = 0; s < HD / 2; ++s) qb[s] = qok ? Q[(long)(2 * s + kk) * a.qcs + q0 + j] * scale : 0.f;
     f32x16 o[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             const int d = e >> 5, kx = e & 31;
             const bool kok = key0 + kx < T;
             const int kc = kok ? key0 + kx : T - 1;
-            const float kv = Kp[(long)d * LD + kc], vv = Vp[(long)d * LD + kc];
+            const float kv = Kp[(long)d * a.kcs + kc], vv = Vp[(long)d * a.kcs + kc];
             sK[d][kx] = kok ? kv : 0.f;
             sV[d][kx] = kok ? vv : 0.f;
         }
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (d < HD) out[((long)b * C + h * HD + d) * LDq + q0 + j] = qok ? o[dt][r] * inv : 0.f;
+                if (d < HD) out[(long)b * a.out_bs + (long)(h * HD + d) * a.qcs + q0 + j] = qok ? o[dt][r] * inv : 0.f;
             }
         if (a.lse && kk == 0) a.lse[((long)b * gridDim.y + h) * LDq + q0 + j] = qok ? m + __logf(l) : 0.f;
     }
@@ -204,16 +211,16 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
     const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
     const int C = a.C, T = a.Tk, LD = a.LDk, LDq = a.LDq;
     float* out = a.out;
-    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * LDq;
-    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * LD;
-    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * LD;
+    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * a.qcs;
+    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * a.kcs;
+    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * a.kcs;
     const bool qok = q0 + j < a.Tq;
     vh8 qh[KS], ql[KS];                                     // B operand of S^T: Q[q = j][d = 16 s + 8 kk + i] * scale, hi / lo
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float v = qok ? Q[(long)(16 * s + 8 * kk + i) * LDq + q0 + j] * a.scale : 0.f;
+            float v = qok ? Q[(long)(16 * s + 8 * kk + i) * a.qcs + q0 + j] * a.scale : 0.f;
             asm volatile("" : "+v"(v));                     // one fp32 value for head and residual
             const _Float16 hh = (_Float16)v;
             qh[s][i] = hh;
@@ -230,13 +237,13 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
             const bool ok = oc < NOCT && key0 + kx < T;
             const int kc = key0 + kx < T ? key0 + kx : T - 1;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rk[it][i] = ok ? Kp[(long)(8 * (oc < NOCT ? oc : 0) + i) * LD + kc] : 0.f;
+            for (int i = 0; i < 8; ++i) rk[it][i] = ok ? Kp[(long)(8 * (oc < NOCT ? oc : 0) + i) * a.kcs + kc] : 0.f;
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
             const int e = tid + 256 * it, d = e / KT, kx = e % KT;
             const int kc = key0 + kx < T ? key0 + kx : T - 1;
-            const float vv = Vp[(long)d * LD + kc];
+            const float vv = Vp[(long)d * a.kcs + kc];
             rv[it] = key0 + kx < T ? vv : 0.f;
         }
     };
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (d < HD) out[((long)b * C + h * HD + d) * LDq + q0 + j] = qok ? o[dt][r] * inv : 0.f;
+                if (d < HD) out[(long)b * a.out_bs + (long)(h * HD + d) * a.qcs + q0 + j] = qok ? o[dt][r] * inv : 0.f;
             }
         if (a.lse && kk == 0) a.lse[((long)b * gridDim.y + h) * LDq + q0 + j] = qok ? m + __logf(l) : 0.f;
     }
@@ -628,20 +635,21 @@ extern "C" int tdr_unfold_windows(const float* ref, int B, int C, int Hr, int Wr
     return TDR_OK;
 }
 
-extern "C" int tdr_patchify(const float* x, int B, int Ci, int H, int W, int p, int LD, float* out, void* stream) {
+extern "C" int tdr_patchify(const float* x, int B, int Ci, int H, int W, int p, int LD, int flat, float* out, void* stream) {
     TDR_REQUIRE(x && out && H % p == 0 && W % p == 0, "tdr_patchify: H, W must be multiples of the patch size");
     const int cols = W / p, T = (H / p) * cols;
     TDR_REQUIRE(LD >= T + 1, "tdr_patchify: LD %d < 1 + T", LD);
     const long total = (long)B * Ci * p * p * LD;
-    hipLaunchKernelGGL(patchify_kernel, dim3(vgrid(total)), dim3(256), 0, (hipStream_t)stream, x, Ci, H, W, p, cols, T, LD, total, out);
+    hipLaunchKernelGGL(patchify_kernel, dim3(vgrid(total)), dim3(256), 0, (hipStream_t)stream, x, Ci, H, W, p, cols, T, LD, total, B, flat, out);
     TDR_LAUNCH_CHECK("patchify");
     return TDR_OK;
 }
 
-extern "C" int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int D, int T, int LD, void* stream) {
+extern "C" int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int D, int T, int LD, int flat, void* stream) {
     TDR_REQUIRE(tok && cls && pos && LD >= T + 1, "tdr_vit_assemble: bad argument");
     const long total = (long)B * D * LD;
-    hipLaunchKernelGGL(vit_assemble_kernel, dim3(vgrid(total)), dim3(256), 0, (hipStream_t)stream, tok, cls, pos, D, T, LD, total);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(vgrid(total)), dim3(256), 0, (hipStream_t)stream, tok, cls, pos, D, T, LD, total,
+                       flat ? (long)B * LD : (long)LD);
     TDR_LAUNCH_CHECK("vit_assemble");
     return TDR_OK;
 }
@@ -669,14 +677,18 @@ static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st, 
 }
 
 extern "C" int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream) {
-    return tdr_attention_fwd_math(qkv, B, C, heads, T, LD, scale, 0, out, stream);
+    return tdr_attention_fwd_math(qkv, B, C, heads, T, LD, scale, 0, 0, out, stream);
 }
 
 // math 0: exact fp32 MFMA; 2: 2-way fp16 split (operands within the fp16 range: LayerNorm-ed ViT activations)
-extern "C" int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, float* out,
-                                      void* stream) {
+extern "C" int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, int flat,
+                                      float* out, void* stream) {
     TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T && (math == 0 || math == 2), "tdr_attention_fwd: bad argument");
-    AttnArgs a{qkv, 3L * C * LD, LD, T, qkv + (long)C * LD, qkv + 2L * C * LD, 3L * C * LD, LD, T, C, scale, out, nullptr};
+    AttnArgs a{qkv, 3L * C * LD, LD, T, qkv + (long)C * LD, qkv + 2L * C * LD, 3L * C * LD, LD, T, C, scale, out, nullptr, LD, LD, (long)C * LD};
+    if (flat) {      // [3C][B*LD]: image b at column offset b*LD, channel stride B*LD; out [C][B*LD]
+        const long cs = (long)B * LD;
+        a = AttnArgs{qkv, LD, LD, T, qkv + (long)C * cs, qkv + 2L * C * cs, LD, LD, T, C, scale, out, nullptr, cs, cs, LD};
+    }
     return attn_fwd_launch(a, B, heads, (hipStream_t)stream, math);
 }
 
@@ -684,7 +696,7 @@ extern "C" int tdr_cross_attention_fwd(const float* q, const float* k, const flo
                                        int Tk, int LDk, float scale, float* out, float* lse, void* stream) {
     TDR_REQUIRE(q && k && v && out && heads > 0 && C % heads == 0 && LDq >= Tq && LDk >= Tk && Tq > 0 && Tk > 0,
                 "tdr_cross_attention_fwd: bad argument");
-    AttnArgs a{q, (long)C * LDq, LDq, Tq, k, v, (long)C * LDk, LDk, Tk, C, scale, out, lse};
+    AttnArgs a{q, (long)C * LDq, LDq, Tq, k, v, (long)C * LDk, LDk, Tk, C, scale, out, lse, LDq, LDk, (long)C * LDq};
     return attn_fwd_launch(a, B, heads, (hipStream_t)stream);
 }
 

@@ -289,7 +289,11 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     a.gate_off = (long)d->Cin * d->H * d->W;
     a.dout = d->dout; a.dout_ns = d->dout_ns; a.Cout = d->Cout; a.OH = d->OH; a.OW = d->OW;
     a.pad = d->pad; a.tw_log2 = p.tw_log2; a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.tpi = p.tpi; a.tps = p.tps; a.spi = p.spi;
-    a.part = d->ws;
+    // a single partial per output group (per-image Grams / grouped GEMMs with one split, or one image with one split) IS the
+    // result: the kernel writes it straight to g and the fixed-order reduction (here a 131 MB copy for the 20 x 1280 x 1280
+    // weight gradients of a grouped Mapper layer) is skipped
+    const bool direct = !d->db && (d->per_image ? p.spi : d->N * p.spi) * p.WKw == 1;
+    a.part = direct ? d->g : d->ws;
     a.dbpart = d->db ? d->ws + (int64_t)d->N * p.spi * p.WKw * d->Cout * d->Cin * d->KH * d->KH : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool g = d->gate != 0;
@@ -319,7 +323,7 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
         tdr_set_error("tdr_conv_wgrad: unsupported (KH=%d stride=%d gate=%d)", d->KH, d->stride, d->gate);
         return TDR_ERR_UNSUPPORTED;
     }
-    if (rc != TDR_OK) return rc;
+    if (rc != TDR_OK || direct) return rc;
     const long elems = (long)d->Cout * d->Cin * d->KH * d->KH;
     const int groups = d->per_image ? d->N : 1;
     const int per_group = (d->per_image ? p.spi : d->N * p.spi) * p.WKw;

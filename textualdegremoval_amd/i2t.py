@@ -104,6 +104,110 @@ def mapper_bwd(dout, P, num_words, saved):
     return G
 
 
+# ---------------------------------------------------------------------------- the same Mapper as G-way grouped GEMMs
+# 40 chains of small launches (~1 200 per forward + backward) leave the chip mostly idle: a 1280 x 1280 Linear over 4 x 257 tokens
+# is a third of a round of workgroups, a class-token MLP is pure weight-streaming latency.  Grouped, every layer of the 20 patch MLPs
+# (and of the 20 class-token MLPs) is ONE launch: tdr_conv_forward / tdr_conv_wgrad with N = words "images", per-image packed
+# weights (wp_ns) and biases, the shared first-layer input addressed with image stride 0, LayerNorm + LeakyReLU fused and per-word
+# (tdr_group_ln_act_*).  Tokens are batch-flattened: [words, C, B*LD/32, 32].
+KINDS = ('mapping_', 'mapping_patch_')
+
+
+class MapperStacks:
+    """Re-points every parameter of a Mapper into per-layer stacks [words, ...] (p.data becomes a view of the stack, so the
+    optimiser's in-place updates, load_state_dict and state_dict keep working on the same storage) -- the grouped kernels then
+    address word g of a layer as base + g * stride."""
+
+    def __init__(self, mapper):
+        G = self.G = mapper.num_words
+        P = dict(mapper.named_parameters())
+        self.W, self.B, self.LW, self.LB = {}, {}, {}, {}
+        for kind in KINDS:
+            for j in (0, 3, 6, 9):
+                w0 = P[f'{kind}0.{j}.weight']
+                self.W[kind, j] = torch.empty(G, *w0.shape, dtype=torch.float32, device=w0.device)
+                self.B[kind, j] = torch.empty(G, w0.shape[0], dtype=torch.float32, device=w0.device)
+            for j in (1, 4, 7):
+                c = P[f'{kind}0.{j}.weight'].shape[0]
+                self.LW[kind, j] = torch.empty(G, c, dtype=torch.float32, device=w0.device)
+                self.LB[kind, j] = torch.empty(G, c, dtype=torch.float32, device=w0.device)
+            for i in range(G):
+                for j in (0, 3, 6, 9):
+                    self._adopt(P[f'{kind}{i}.{j}.weight'], self.W[kind, j][i])
+                    self._adopt(P[f'{kind}{i}.{j}.bias'], self.B[kind, j][i])
+                for j in (1, 4, 7):
+                    self._adopt(P[f'{kind}{i}.{j}.weight'], self.LW[kind, j][i])
+                    self._adopt(P[f'{kind}{i}.{j}.bias'], self.LB[kind, j][i])
+
+    @staticmethod
+    def _adopt(p, slot):
+        with torch.no_grad():
+            slot.copy_(p.data)
+            p.data = slot
+
+
+def _chain_fwd(x, st, kind):
+    """x [G (stride 0), Din, H, W] -> (out [G, Dout, H, W], saved)"""
+    saved = []
+    for j in (0, 3, 6):
+        wp, mp, per = K.pack_weights_grouped(st.W[kind, j], PACK_FWD)
+        z = K.conv_forward(x, wp, mp, st.W[kind, j].shape[1], 1, wp_ns=per, bias=st.B[kind, j])
+        y, mu, rs = K.group_ln_act_fwd(z, st.LW[kind, j + 1], st.LB[kind, j + 1], LN_EPS, SLOPE)
+        saved.append((x, z, mu, rs, y))
+        x = y
+    wp, mp, per = K.pack_weights_grouped(st.W[kind, 9], PACK_FWD)
+    return K.conv_forward(x, wp, mp, st.W[kind, 9].shape[1], 1, wp_ns=per, bias=st.B[kind, 9]), (saved, x)
+
+
+def _lin_bwd_grouped(dout, x, W, need_dx):
+    """-> (dx or None, dW [G, out, in]); the bias gradient (pixel sums of dout) comes from dout's producer"""
+    G, Cout, Cin = W.shape
+    gw = K.conv_wgrad(x, dout, Cout, Cin, 1, per_image=True).view(G, Cout, Cin)
+    dx = None
+    if need_dx:
+        wp, mp, per = K.pack_weights_grouped(W, PACK_DGRAD_S1)
+        dx = K.conv_forward(dout, wp, mp, Cin, 1, wp_ns=per)
+    return dx, gw
+
+
+def _chain_bwd(d, dsum, st, kind, saved, out):
+    """d: gradient of the chain's output [G, Dout, H, W], dsum [G, Dout] its pixel sums"""
+    layers, x_last = saved
+    out[kind, 9, 'bias'] = dsum
+    d, out[kind, 9, 'weight'] = _lin_bwd_grouped(d, x_last, st.W[kind, 9], True)
+    for j, (x, z, mu, rs, y) in zip((6, 3, 0), reversed(layers)):
+        dz, out[kind, j + 1, 'weight'], out[kind, j + 1, 'bias'], out[kind, j, 'bias'] = \
+            K.group_ln_act_bwd(d, y, z, mu, rs, st.LW[kind, j + 1], SLOPE)
+        d, out[kind, j, 'weight'] = _lin_bwd_grouped(dz, x, st.W[kind, j], j > 0)
+
+
+def mapper_fwd_grouped(tok, B, T, st):
+    """tok: batch-flattened channel-major tokens [1, Din, B*LD/32, 32] (ClipVisionEncoder.encode(..., flat=True));
+    -> ([B, words, Dout], saved)"""
+    if B > 32:
+        raise NotImplementedError('HIP Mapper: batch <= 32 per call (class tokens travel as one 32-pixel row)')
+    G = st.G
+    LD = tok.shape[2] * tok.shape[3] // B
+    cls_in = K.gather_col_flat(tok, B, 0)                                            # embs[:, :1]
+    c, sv_c = _chain_fwd(cls_in.expand(G, -1, -1, -1), st, 'mapping_')
+    p, sv_p = _chain_fwd(tok.expand(G, -1, -1, -1), st, 'mapping_patch_')
+    return K.mapper_combine_all(c, p, B, LD, T), (sv_c, sv_p, B, LD, T)
+
+
+def mapper_bwd_grouped(dout, st, saved):
+    """-> {parameter name: gradient} for every MLP parameter (views of per-layer [words, ...] gradient stacks)"""
+    sv_c, sv_p, B, LD, T = saved
+    dc, dp, dsum = K.mapper_combine_all_bwd(dout.contiguous(), LD, T)
+    stacks = {}
+    _chain_bwd(dc, dsum, st, 'mapping_', sv_c, stacks)
+    _chain_bwd(dp, dsum, st, 'mapping_patch_', sv_p, stacks)
+    G = {}
+    for (kind, j, what), g in stacks.items():
+        for i in range(st.G):
+            G[f'{kind}{i}.{j}.{what}'] = g[i]
+    return G
+
+
 class _MapperFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tok, T, names, num_words, *params):

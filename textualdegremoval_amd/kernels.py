@@ -334,6 +334,7 @@ class PackPlan:
 
     def __init__(self):
         self.entries = {}          # (ptr, shape, mode, math) -> (w, mode, math, PackedWeights)
+        self.grouped = {}          # pack_weights_grouped: stacks of per-word matrices whose packs are views of one buffer
         self.table = None
         self.dirty = True
         self.valid = False
@@ -410,6 +411,38 @@ def pack_weights(w, mode, out=None, math=None):
         pw = PackedWeights(out, FMT_F32) if (out is not None and math == 'f32') else _packed_buffer(w, mode, math)
         _pack_into(w, mode, pw)
     return pw, (M + 31) // 32 * 32, M, Kch, KHe
+
+
+def pack_weights_grouped(W, mode):
+    """W [G, Cout, Cin]: a contiguous stack of G weight matrices (the per-word Linears of the stage-A Mapper).  Returns
+    (PackedWeights over G consecutive packs, Mpad, floats per pack) for a G-way grouped tdr_conv_forward (N = G images,
+    wp_ns = floats per pack).  Inside a PackPlan the G packs are ordinary plan entries (views into one buffer): `run()` re-packs
+    them with the step's one multi-tensor launch."""
+    G, Cout, Cin = W.shape
+    assert W.is_contiguous()
+    plan = _active_plan
+    key = ('grouped', W.data_ptr(), (G, Cout, Cin), mode, MATH, GRAD_SCALED)
+    store = plan.grouped if plan is not None else None
+    e = store.get(key) if store is not None else None
+    if e is None:
+        w4 = [W[g].view(Cout, Cin, 1, 1) for g in range(G)]
+        proto = _packed_buffer(w4[0], mode, MATH)
+        per = proto.buf.numel()
+        big = torch.empty(G * per, dtype=torch.float32, device=W.device)
+        views = [PackedWeights(big[g * per:(g + 1) * per], proto.fmt) for g in range(G)]
+        for g in range(G):
+            _pack_into(w4[g], mode, views[g])
+            if plan is not None:
+                plan.entries[(w4[g].data_ptr(), tuple(w4[g].shape), mode, MATH, GRAD_SCALED)] = (w4[g], mode, MATH, views[g])
+        M = _pack_dims(w4[0], mode)[0]
+        e = (PackedWeights(big, proto.fmt), (M + 31) // 32 * 32, per, w4, views)
+        if plan is not None:
+            plan.dirty = True
+            store[key] = e
+    elif not plan.valid:
+        for w, v in zip(e[3], e[4]):
+            _pack_into(w, mode, v)
+    return e[0], e[1], e[2]
 
 
 def pack_patches(blk, G, PH, PW, pstep, dil, off):
@@ -942,33 +975,40 @@ def token_ld(T):
     return (T + 1 + 31) // 32 * 32
 
 
-def patchify(x, p):
-    """-> [B, Ci*p*p, LD/32, 32] with patch t at flat column 1+t (zeros at column 0 and in the padding)"""
+def patchify(x, p, flat=False):
+    """-> [B, Ci*p*p, LD/32, 32] with patch t at flat column 1+t (zeros at column 0 and in the padding);
+    flat: the batch-flattened layout [1, Ci*p*p, B*LD/32, 32] (image b's tokens at columns b*LD ..)"""
     B, Ci, H, W = x.shape
     assert x.is_contiguous()
     T = (H // p) * (W // p)
     LD = token_ld(T)
-    out = torch.empty(B, Ci * p * p, LD // 32, 32, dtype=torch.float32, device=x.device)
-    check(_lib.load().tdr_patchify(x.data_ptr(), B, Ci, H, W, p, LD, out.data_ptr(), _stream()), 'tdr_patchify')
+    shape = (1, Ci * p * p, B * LD // 32, 32) if flat else (B, Ci * p * p, LD // 32, 32)
+    out = torch.empty(*shape, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_patchify(x.data_ptr(), B, Ci, H, W, p, LD, 1 if flat else 0, out.data_ptr(), _stream()), 'tdr_patchify')
     return out, T
 
 
-def vit_assemble_(tok, cls, pos_cm, T):
-    B, D = tok.shape[0], tok.shape[1]
-    LD = tok.shape[2] * tok.shape[3]
-    check(_lib.load().tdr_vit_assemble(tok.data_ptr(), cls.data_ptr(), pos_cm.data_ptr(), B, D, T, LD, _stream()), 'tdr_vit_assemble')
+def vit_assemble_(tok, cls, pos_cm, T, flat_batch=0):
+    """flat_batch = B for a batch-flattened token tensor [1, D, B*LD/32, 32], 0 for [B, D, LD/32, 32]"""
+    D = tok.shape[1]
+    B = flat_batch or tok.shape[0]
+    LD = tok.shape[2] * tok.shape[3] // (flat_batch or 1)
+    check(_lib.load().tdr_vit_assemble(tok.data_ptr(), cls.data_ptr(), pos_cm.data_ptr(), B, D, T, LD, 1 if flat_batch else 0, _stream()),
+          'tdr_vit_assemble')
     return tok
 
 
-def attention_fwd(qkv, heads, scale, T1):
-    """qkv [B, 3C, LD/32, 32]; attends over the first T1 columns"""
-    B, C3 = qkv.shape[0], qkv.shape[1]
-    Cc, LD = C3 // 3, qkv.shape[2] * qkv.shape[3]
+def attention_fwd(qkv, heads, scale, T1, flat_batch=0):
+    """qkv [B, 3C, LD/32, 32] (or batch-flattened [1, 3C, B*LD/32, 32] with flat_batch = B); attends over the first T1 columns
+    of every image"""
+    B, C3 = (flat_batch or qkv.shape[0]), qkv.shape[1]
+    Cc, LD = C3 // 3, qkv.shape[2] * qkv.shape[3] // (flat_batch or 1)
     assert qkv.is_contiguous()
-    out = torch.empty(B, Cc, qkv.shape[2], qkv.shape[3], dtype=torch.float32, device=qkv.device)
+    out = torch.empty(qkv.shape[0], Cc, qkv.shape[2], qkv.shape[3], dtype=torch.float32, device=qkv.device)
     # the frozen ViTs (no gradient flows through this attention): on the fp16 split whenever the dense contractions are
     math = 2 if (MATH in ('hx2', 'h1') and os.environ.get('TDR_ATTN_F32', '0') != '1') else 0
-    check(_lib.load().tdr_attention_fwd_math(qkv.data_ptr(), B, Cc, heads, T1, LD, float(scale), math, out.data_ptr(), _stream()),
+    check(_lib.load().tdr_attention_fwd_math(qkv.data_ptr(), B, Cc, heads, T1, LD, float(scale), math, 1 if flat_batch else 0, out.data_ptr(),
+                                             _stream()),
           'tdr_attention_fwd')
     return out
 
@@ -1181,6 +1221,64 @@ def cross_attention_bwd(q, k, v, out, dout, lse, heads, scale, Tq, Tk, need_dq=T
                                               lse.data_ptr(), B, Cc, heads, Tq, LDq, Tk, LDk, float(scale), _p(dq),
                                               dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), _stream()), 'tdr_cross_attention_bwd')
     return dq, dk, dv
+
+
+# ---- grouped Mapper glue (csrc/tdr_i2t.hip): tensors [G, C, H, W] with G = words, H*W = the tokens of all images
+def group_ln_act_fwd(z, w, b, eps, slope):
+    """nn.LayerNorm(C, eps) + nn.LeakyReLU(slope) with per-word parameters w, b [G, C] -> (y, mu [G, P], rstd [G, P])"""
+    G, Cc, H, W = z.shape
+    assert z.is_contiguous() and w.shape == (G, Cc) and b.shape == (G, Cc) and w.is_contiguous() and b.is_contiguous()
+    y = torch.empty_like(z)
+    mu = torch.empty(G, H * W, dtype=torch.float32, device=z.device)
+    rs = torch.empty_like(mu)
+    check(_lib.load().tdr_group_ln_act_fwd(z.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps), float(slope), G, Cc, H * W, y.data_ptr(),
+                                           mu.data_ptr(), rs.data_ptr(), _stream()), 'tdr_group_ln_act_fwd')
+    return y, mu, rs
+
+
+def group_ln_act_bwd(dy, y, z, mu, rs, w, slope):
+    """-> (dz [G,C,H,W], gw [G,C], gb [G,C], gs [G,C] = sum over pixels of dz)"""
+    G, Cc, H, W = z.shape
+    assert dy.is_contiguous() and y.is_contiguous() and z.is_contiguous()
+    lib = _lib.load()
+    dz = torch.empty_like(z)
+    gw = torch.empty(G, Cc, dtype=torch.float32, device=z.device)
+    gb, gs = torch.empty_like(gw), torch.empty_like(gw)
+    ws = workspace(lib.tdr_group_ln_ws_floats(G, Cc, H * W), z.device, 'gln')
+    check(lib.tdr_group_ln_act_bwd(dy.data_ptr(), y.data_ptr(), z.data_ptr(), mu.data_ptr(), rs.data_ptr(), w.data_ptr(), float(slope), G, Cc,
+                                   H * W, dz.data_ptr(), gw.data_ptr(), gb.data_ptr(), gs.data_ptr(), ws.data_ptr(), _stream()),
+          'tdr_group_ln_act_bwd')
+    return dz, gw, gb, gs
+
+
+def mapper_combine_all(cls_out, patch_out, B, LD, T):
+    """cls_out [G, D, 1, 32], patch_out [G, D, B*LD/32, 32] -> [B, G, D]"""
+    G, D = patch_out.shape[0], patch_out.shape[1]
+    out = torch.empty(B, G, D, dtype=torch.float32, device=patch_out.device)
+    check(_lib.load().tdr_mapper_combine_all(cls_out.data_ptr(), patch_out.data_ptr(), B, G, D, LD, T, out.data_ptr(), _stream()),
+          'tdr_mapper_combine_all')
+    return out
+
+
+def mapper_combine_all_bwd(go, LD, T):
+    B, G, D = go.shape
+    assert go.is_contiguous()
+    dcls = torch.empty(G, D, 1, 32, dtype=torch.float32, device=go.device)
+    dpatch = torch.empty(G, D, B * LD // 32, 32, dtype=torch.float32, device=go.device)
+    gsum = torch.empty(G, D, dtype=torch.float32, device=go.device)
+    check(_lib.load().tdr_mapper_combine_all_bwd(go.data_ptr(), B, G, D, LD, T, dcls.data_ptr(), dpatch.data_ptr(), gsum.data_ptr(), _stream()),
+          'tdr_mapper_combine_all_bwd')
+    return dcls, dpatch, gsum
+
+
+def gather_col_flat(tok, B, col=0):
+    """batch-flattened tokens [1, D, B*LD/32, 32] -> [1, D, 1, 32]: column `col` of every image as pixel b"""
+    D = tok.shape[1]
+    LD = tok.shape[2] * tok.shape[3] // B
+    assert tok.is_contiguous()
+    out = torch.empty(1, D, 1, 32, dtype=torch.float32, device=tok.device)
+    check(_lib.load().tdr_gather_col_strided(tok.data_ptr(), B, D, LD, B * LD, col, out.data_ptr(), _stream()), 'tdr_gather_col_strided')
+    return out
 
 
 # ---- stage-A train step glue (csrc/tdr_i2t.hip; main_train_i2t_mapping.py:704-760)

@@ -151,6 +151,10 @@ class I2TMappingTrainer:
         self.dist = bool(dist_on)
         self.reducer = GradAllReducer(list(zip(self.names, self.params)), bucket_mb=bucket_mb)
         self._plan = K.PackPlan()
+        # the Mapper as G-way grouped GEMMs over batch-flattened tokens (i2t.mapper_fwd_grouped); TDR_MAPPER_GROUPED=0 keeps the
+        # 2 x num_words chains of small launches on four stream lanes
+        self.grouped = os.environ.get('TDR_MAPPER_GROUPED', '1') == '1'
+        self.stacks = i2t.MapperStacks(self.mapper) if self.grouped else None
         # frozen stand-ins, packed once
         self.vae = _Frozen(S['vae.weight'] * (VAE_SCALE / 64.0))              # average pool = block sum / 64, folded in
         self.text_proj = _Frozen(S['text.proj.weight'], S['text.proj.bias'], want_dgrad=True)
@@ -184,9 +188,12 @@ class I2TMappingTrainer:
             # ---- frozen front: VAE stand-in, forward diffusion, CLIP image encoder (no-grad)
             lat = self.vae(K.pool_sum(b['pixel_values'], 8))
             noisy = K.add_noise(lat, b['noise'], t, S['alphas_cumprod'])
-            tok, T = self.image_encoder.encode(b['pixel_values_clip'], size=self.clip_image_size)
+            tok, T = self.image_encoder.encode(b['pixel_values_clip'], size=self.clip_image_size, flat=self.grouped)
             # ---- Mapper (a29) and the text side: injection (:139-151), stand-in projection, final_layer_norm
-            inj, msaved = i2t.mapper_fwd(tok, T, P, self.num_words)
+            if self.grouped:
+                inj, msaved = i2t.mapper_fwd_grouped(tok, b['pixel_values_clip'].shape[0], T, self.stacks)
+            else:
+                inj, msaved = i2t.mapper_fwd(tok, T, P, self.num_words)
             new = K.text_inject_fwd(ids, S['text.token_embedding'], S['text.position_embedding'], inj, idx)
             z = self.text_proj(new)
             ctx, mu, rs = K.layernorm2d_fwd(z, S['text.final_layer_norm.weight'], S['text.final_layer_norm.bias'], LN_EPS)
@@ -221,7 +228,7 @@ class I2TMappingTrainer:
                 dctx = self._dgrad(dv, wv, res=dctx)
             dz, _, _ = K.layernorm2d_bwd(dctx, z, mu, rs, S['text.final_layer_norm.weight'])
             dinj = K.text_inject_bwd(self.text_proj.dgrad(dz), idx, SEQ, self.num_words)
-            G.update(i2t.mapper_bwd(dinj, P, self.num_words, msaved))
+            G.update(i2t.mapper_bwd_grouped(dinj, self.stacks, msaved) if self.grouped else i2t.mapper_bwd(dinj, P, self.num_words, msaved))
             for kname in self.names:                      # fixed arrival order = registration order
                 sink[kname] = G[kname]
             grads = self.reducer.finish()
