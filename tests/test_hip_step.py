@@ -104,5 +104,7 @@ def test_step_with_dino_window_match(tmp_path):
         model.optimize_parameters(it)
         assert int(model.match_index[0]) == int(o_idx[0]) == 2 * 5 + 1
         assert torch.equal(model.ref_in.cpu(), o_ref_in)
-        assert (model.match_corr.cpu() - o_corr).abs().max().item() < 1e-5
+        # similarities: the matcher's Linears run on ONE fp16 product by default (dino.py; only the index leaves the sub-graph);
+        # tests/test_hip_dino.py pins 1e-5 for the split / exact arithmetic
+        assert (model.match_corr.cpu() - o_corr).abs().max().item() < 5e-3
     assert np.isfinite(model.get_current_log()['l_pix'])

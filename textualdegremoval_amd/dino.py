@@ -8,6 +8,7 @@ Only the parameter pre-processing (bicubic interpolation of the position embeddi
 input size, once per size, as vision_transformers.py:179-207 does it) runs in torch on the host.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -19,7 +20,15 @@ LN_EPS = 1e-6
 
 
 class DinoMatcher:
-    def __init__(self, state_dict, device, patch=14, heads=12, interpolate_offset=0.1):
+    def __init__(self, state_dict, device, patch=14, heads=12, interpolate_offset=0.1, linear_math=None):
+        """linear_math: arithmetic of the frozen Linears (TDR_DINO_MATH overrides; default 'h1' under TDR_MATH=hx2, else
+        kernels.MATH).  'h1' runs them as ONE
+        fp16 MFMA product per operand pair (11-bit operands, fp32 accumulate) instead of the 3 of the 2-way split: nothing but an
+        arg-max over window similarities leaves this sub-graph, so it is admissible exactly as long as that index
+        does not move -- tests/test_hip_dino.py pins it on the reference goldens and on a sweep against the split arithmetic."""
+        self.linear_math = linear_math or os.environ.get('TDR_DINO_MATH') or ('h1' if K.MATH == 'hx2' else None)
+        if self.linear_math not in (None, 'h1', 'hx2', 'bx3', 'f32'):
+            raise ValueError(f'TDR_DINO_MATH / linear_math: {self.linear_math!r}')
         sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
         need = ['cls_token', 'pos_embed', 'patch_embed.proj.weight', 'patch_embed.proj.bias', 'norm.weight', 'norm.bias']
         miss = [k for k in need if k not in sd]
@@ -46,7 +55,7 @@ class DinoMatcher:
     def _pack(self, key, w4):
         prev = K.set_pack_plan(None)                      # persistent buffers, not a per-step plan
         try:
-            wp, mp, *_ = K.pack_weights(w4.to(self.device).contiguous(), PACK_FWD)
+            wp, mp, *_ = K.pack_weights(w4.to(self.device).contiguous(), PACK_FWD, math=self.linear_math)
         finally:
             K.set_pack_plan(prev)
         self.W[key] = (wp, mp, w4.shape[0])
@@ -71,25 +80,31 @@ class DinoMatcher:
         wp, mp, cout = self.W[key]
         return K.conv_forward(x, wp, mp, cout, 1, bias=bias, **kw)
 
-    def tokens(self, x):
+    def tokens(self, x, flat=False):
         """x [B,3,H,W] (multiples of the patch size) -> (final-norm tokens [B, D, LD/32, 32], T): flat column 0 is the
-        class token, columns 1..T the patch tokens, the rest padding (kernels.token_ld)."""
+        class token, columns 1..T the patch tokens, the rest padding (kernels.token_ld).
+        flat=True computes in the batch-flattened layout [1, D, B*LD/32, 32] (every Linear one GEMM over all B*LD tokens: no
+        partly filled pixel tile per image) and returns the same per-image tensor."""
         B, _, H, W = x.shape
         P, D = self.P, self.D
         rows, cols = H // self.patch, W // self.patch
-        xp, T = K.patchify(x.contiguous(), self.patch)
-        t = K.vit_assemble_(self._linear(xp, 'patch', P['patch_embed.proj.bias']), self.cls, self._pos(rows, cols), T)
+        fb = B if flat else 0
+        xp, T = K.patchify(x.contiguous(), self.patch, flat=flat)
+        t = K.vit_assemble_(self._linear(xp, 'patch', P['patch_embed.proj.bias']), self.cls, self._pos(rows, cols), T, flat_batch=fb)
         scale = (D // self.heads) ** -0.5
         for i in range(self.depth):
             p = f'blocks.{i}.'
             h, _, _ = K.layernorm2d_fwd(t, P[p + 'norm1.weight'], P[p + 'norm1.bias'], LN_EPS)
             qkv = self._linear(h, p + 'attn.qkv', P[p + 'attn.qkv.bias'])
-            a = K.attention_fwd(qkv, self.heads, scale, T + 1)
+            a = K.attention_fwd(qkv, self.heads, scale, T + 1, flat_batch=fb)
             t = self._linear(a, p + 'attn.proj', P[p + 'attn.proj.bias'], scale=P[p + 'ls1.gamma'], res=t)
             h, _, _ = K.layernorm2d_fwd(t, P[p + 'norm2.weight'], P[p + 'norm2.bias'], LN_EPS)
             h = self._linear(h, p + 'mlp.fc1', P[p + 'mlp.fc1.bias'], relu=2)
             t = self._linear(h, p + 'mlp.fc2', P[p + 'mlp.fc2.bias'], scale=P[p + 'ls2.gamma'], res=t)
         t, _, _ = K.layernorm2d_fwd(t, P['norm.weight'], P['norm.bias'], LN_EPS)
+        if flat:                                          # [D][B][LD] -> [B][D][LD] (a layout copy of the final tokens only)
+            LD = t.shape[2] * t.shape[3] // B
+            t = t.view(D, B, LD).permute(1, 0, 2).contiguous().view(B, D, LD // 32, 32)
         return t, T
 
     @torch.no_grad()
@@ -105,7 +120,7 @@ class DinoMatcher:
         # one ViT pass over the B images and their B * N windows (the reference runs two, :224-231): every kernel works per image,
         # so the features are the same, and the 4-image pass alone ran its GEMMs / attention at 60 - 75 % of the batched rate
         both = torch.cat([K.resize_bilinear(lq.contiguous(), Hd, Wd), K.resize_bilinear(windows, Hd, Wd)], dim=0)
-        f, T = self.tokens(both)
+        f, T = self.tokens(both, flat=os.environ.get('TDR_DINO_FLAT', '1') == '1')
         fl, fr = f[:B], f[B:]
         corr, index, ref_in = K.token_match(fl, fr, windows, N, T + 1)
         return ref_in, index, corr

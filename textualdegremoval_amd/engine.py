@@ -499,6 +499,62 @@ def net_fwd(P, cfg, inp, ref):
     return out, saved
 
 
+# ---------------------------------------------------------------------------- un-guided NAFNet (reference :305-386)
+def unet_fwd(P, cfg, inp):
+    """`NAFNet.forward`: check_image_size (zero pad to a multiple of 2^len(encoders)) -> intro -> encoders / downs -> middle ->
+    ups (+ skip) / decoders -> ending + inp -> crop.  Same block kernels as the guided network, no reference branch."""
+    n_enc = len(cfg['enc_blk_nums'])
+    N, _, H0, W0 = inp.shape
+    mult = 1 << n_enc
+    Hp, Wp = -(-H0 // mult) * mult, -(-W0 // mult) * mult
+    inp_p = inp.contiguous() if (Hp, Wp) == (H0, W0) else K.pad_crop(inp.contiguous(), Hp, Wp)
+    x = conv_fwd(inp_p, P['intro.weight'], P['intro.bias'], 1, 1)
+    sv_levels, skips = [], []
+    for lvl in range(n_enc):
+        x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl])
+        skips.append(x)
+        sv_levels.append((sv_e, x))
+        x = conv_fwd(x, P[f'downs.{lvl}.weight'], P[f'downs.{lvl}.bias'], 2, 0)
+    x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'])
+    sv_dec = []
+    for lvl in range(len(cfg['dec_blk_nums'])):
+        xin = x
+        x = up_fwd(xin, P[f'ups.{lvl}.0.weight'], skips[-1 - lvl])
+        x, sv_d = naf_seq_fwd(x, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl])
+        sv_dec.append((xin, sv_d))
+    out_p = conv_fwd(x, P['ending.weight'], P['ending.bias'], 1, 1, res=inp_p)
+    out = out_p if (Hp, Wp) == (H0, W0) else K.pad_crop(out_p, H0, W0)
+    return out, ((H0, W0, Hp, Wp), inp_p, sv_levels, sv_m, sv_dec, x)
+
+
+def unet_bwd(dout, P, cfg, saved, G=None):
+    """-> (dinp, G): gradient w.r.t. the input image (the `+ inp` skip and the intro conv) and every parameter"""
+    with deferred_join():
+        (H0, W0, Hp, Wp), inp_p, sv_levels, sv_m, sv_dec, xe = saved
+        n_enc = len(cfg['enc_blk_nums'])
+        G = {} if G is None else G
+        dout = dout.contiguous()
+        if (Hp, Wp) != (H0, W0):
+            dout = K.pad_crop(dout, Hp, Wp)
+        d, G['ending.weight'], G['ending.bias'] = conv_bwd(dout, xe, P['ending.weight'], 1, 1)
+        dskips = [None] * n_enc
+        for lvl in reversed(range(len(cfg['dec_blk_nums']))):
+            xin, sv_d = sv_dec[lvl]
+            d = naf_seq_bwd(d, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl], sv_d, G)
+            dskips[n_enc - 1 - lvl] = d
+            d, G[f'ups.{lvl}.0.weight'] = up_bwd(d, xin, P[f'ups.{lvl}.0.weight'])
+        d = naf_seq_bwd(d, P, 'middle_blks.', cfg['middle_blk_num'], sv_m, G)
+        for lvl in reversed(range(n_enc)):
+            sv_e, x_skip = sv_levels[lvl]
+            d, G[f'downs.{lvl}.weight'], G[f'downs.{lvl}.bias'] = conv_bwd(d, x_skip, P[f'downs.{lvl}.weight'], 2, 0,
+                                                                          add_to_dx=dskips[lvl])
+            d = naf_seq_bwd(d, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl], sv_e, G)
+        dinp, G['intro.weight'], G['intro.bias'] = conv_bwd(d, inp_p, P['intro.weight'], 1, 1, need_dx=True, add_to_dx=dout)
+        if (Hp, Wp) != (H0, W0):
+            dinp = K.pad_crop(dinp, H0, W0)
+        return dinp, G
+
+
 def _pad_into(src, dst_view):
     """dst_view: dense [N,C,Hd,Wd] slice (contiguous along the batch)."""
     N, Cc, Hs, Ws = src.shape

@@ -77,6 +77,24 @@ class _NetFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(G[k] for k in ctx.names)
 
 
+class _UNetFn(torch.autograd.Function):
+    """the un-guided NAFNet as one autograd node (gradient w.r.t. the input image included)"""
+
+    @staticmethod
+    def forward(ctx, inp, names, cfg, *params):
+        require_gpu(inp, 'NAFNet')
+        P = dict(zip(names, [p.detach() for p in params]))
+        out, saved = E.unet_fwd(P, cfg, inp)
+        ctx.names, ctx.P, ctx.cfg, ctx.saved = names, P, cfg, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dinp, G = E.unet_bwd(dout, ctx.P, ctx.cfg, ctx.saved)
+        ctx.saved = None
+        return (dinp, None, None) + tuple(G[k] for k in ctx.names)
+
+
 def make_layer(block, n_layers):
     return nn.Sequential(*[block() for _ in range(n_layers)])
 
@@ -181,6 +199,28 @@ class _NAFBase(nn.Module):
             chan = chan // 2
             self.decoders.append(nn.Sequential(*[NAFBlock(chan) for _ in range(num)]))
         self.padder_size = 2 ** len(self.encoders)
+
+
+class NAFNet(_NAFBase):
+    """the un-guided network of the same file (reference :305-386): same constructor, registration order and forward(inp)"""
+
+    def __init__(self, img_channel=3, width=16, middle_blk_num=1, enc_blk_nums=[], dec_blk_nums=[]):
+        super().__init__()
+        if len(enc_blk_nums) != len(dec_blk_nums):
+            raise ValueError('NAFNet: one decoder level per encoder level (the skips are zipped, reference :362-365)')
+        self._build_unet(img_channel, width, middle_blk_num, enc_blk_nums, dec_blk_nums)
+        self.cfg = dict(img_channel=img_channel, width=width, middle_blk_num=middle_blk_num, enc_blk_nums=list(enc_blk_nums),
+                        dec_blk_nums=list(dec_blk_nums))
+
+    def check_image_size(self, x):
+        from ... import kernels as K
+        _, _, h, w = x.shape
+        m = self.padder_size
+        return K.pad_crop(x.contiguous(), -(-h // m) * m, -(-w // m) * m)
+
+    def forward(self, inp):
+        names, params = _named(self)
+        return _UNetFn.apply(inp, names, self.cfg, *params)
 
 
 class NAFNetRefFusion(_NAFBase):

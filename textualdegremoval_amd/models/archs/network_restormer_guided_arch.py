@@ -227,6 +227,63 @@ class _NetFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(G[k] for k in ctx.names)
 
 
+class _UNetFn(torch.autograd.Function):
+    """the un-guided Restormer as one autograd node"""
+
+    @staticmethod
+    def forward(ctx, inp, names, cfg, *params):
+        P = dict(zip(names, [p.detach() for p in params]))
+        out, saved = R.unet_fwd(P, cfg, inp)
+        ctx.names, ctx.P, ctx.cfg, ctx.saved = names, P, cfg, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        G = R.unet_bwd(dout, ctx.P, ctx.cfg, ctx.saved)
+        ctx.saved = None
+        return (None, None, None) + tuple(G[k] for k in ctx.names)
+
+
+class Restormer(nn.Module):
+    """the un-guided network of the same file (reference :396-501): same constructor, registration order, forward(inp_img)"""
+
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4, heads=[1, 2, 4, 8],
+                 ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias', dual_pixel_task=False):
+        super().__init__()
+        self.patch_embed = OverlapPatchEmbed(inp_channels, dim)
+
+        def blocks(n, c, h):
+            return nn.Sequential(*[TransformerBlock(dim=c, num_heads=h, ffn_expansion_factor=ffn_expansion_factor, bias=bias,
+                                                    LayerNorm_type=LayerNorm_type) for _ in range(n)])
+        self.encoder_level1 = blocks(num_blocks[0], dim, heads[0])
+        self.down1_2 = Downsample(dim)
+        self.encoder_level2 = blocks(num_blocks[1], int(dim * 2 ** 1), heads[1])
+        self.down2_3 = Downsample(int(dim * 2 ** 1))
+        self.encoder_level3 = blocks(num_blocks[2], int(dim * 2 ** 2), heads[2])
+        self.down3_4 = Downsample(int(dim * 2 ** 2))
+        self.latent = blocks(num_blocks[3], int(dim * 2 ** 3), heads[3])
+        self.up4_3 = Upsample(int(dim * 2 ** 3))
+        self.reduce_chan_level3 = nn.Conv2d(int(dim * 2 ** 3), int(dim * 2 ** 2), kernel_size=1, bias=bias)
+        self.decoder_level3 = blocks(num_blocks[2], int(dim * 2 ** 2), heads[2])
+        self.up3_2 = Upsample(int(dim * 2 ** 2))
+        self.reduce_chan_level2 = nn.Conv2d(int(dim * 2 ** 2), int(dim * 2 ** 1), kernel_size=1, bias=bias)
+        self.decoder_level2 = blocks(num_blocks[1], int(dim * 2 ** 1), heads[1])
+        self.up2_1 = Upsample(int(dim * 2 ** 1))
+        self.decoder_level1 = blocks(num_blocks[0], int(dim * 2 ** 1), heads[0])
+        self.refinement = blocks(num_refinement_blocks, int(dim * 2 ** 1), heads[0])
+        self.dual_pixel_task = dual_pixel_task
+        if self.dual_pixel_task:
+            self.skip_conv = nn.Conv2d(dim, int(dim * 2 ** 1), kernel_size=1, bias=bias)
+        self.output = nn.Conv2d(int(dim * 2 ** 1), out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+        self.cfg = dict(inp_channels=inp_channels, out_channels=out_channels, dim=dim, num_blocks=list(num_blocks),
+                        num_refinement_blocks=num_refinement_blocks, heads=list(heads), ffn_expansion_factor=ffn_expansion_factor,
+                        bias=bias, LayerNorm_type=LayerNorm_type, dual_pixel_task=dual_pixel_task)
+
+    def forward(self, inp_img):
+        names, params = _named(self)
+        return _UNetFn.apply(inp_img, names, self.cfg, *params)
+
+
 class RestormerRefFusion(nn.Module):
     engine = R          # image_restoration_ref_model dispatches its fused step through `net.engine`
 
@@ -239,8 +296,6 @@ class RestormerRefFusion(nn.Module):
         if nf != dim:
             raise ValueError('RestormerRefFusion needs nf == dim (the fusion blocks are built for 2*dim*2^l channels, '
                              'reference :563,583,603,623)')
-        if dual_pixel_task:
-            raise NotImplementedError('HIP path: dual_pixel_task=False (no reference YAML enables it)')
         if num_nbr != 1 or psize != 3:
             raise NotImplementedError('HIP path: num_nbr=1, psize=3')
         self.scale, self.num_nbr, self.psize = scale, num_nbr, psize
@@ -277,6 +332,8 @@ class RestormerRefFusion(nn.Module):
         self.decoder_level1 = blocks(num_blocks[0], int(dim * 2 ** 1), heads[0])
         self.refinement = blocks(num_refinement_blocks, int(dim * 2 ** 1), heads[0])
         self.dual_pixel_task = dual_pixel_task
+        if self.dual_pixel_task:           # dual-pixel defocus deblurring (:634-637)
+            self.skip_conv = nn.Conv2d(dim, int(dim * 2 ** 1), kernel_size=1, bias=bias)
         self.output = nn.Conv2d(int(dim * 2 ** 1), out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
         self.cfg = dict(inp_channels=inp_channels, out_channels=out_channels, dim=dim, num_blocks=list(num_blocks),
                         num_refinement_blocks=num_refinement_blocks, heads=list(heads),

@@ -190,8 +190,6 @@ _DOWN = ['down1_2.body.0.weight', 'down2_3.body.0.weight', 'down3_4.body.0.weigh
 
 def net_fwd(P, cfg, inp, ref):
     """inp, ref [N,3,H,W] -> (out [N,3,H,W], saved).  cfg: constructor kwargs of RestormerRefFusion."""
-    if cfg.get('dual_pixel_task'):
-        raise NotImplementedError('HIP path: dual_pixel_task=False (no reference YAML enables it)')
     N = inp.shape[0]
     pyr, (H0, W0, Hp, Wp) = E.pyramids_fwd(P, cfg, inp, ref, PADDER_LOG2, 4)
     inp_p, geo = pyr.inp_p, pyr.geo
@@ -204,6 +202,8 @@ def net_fwd(P, cfg, inp, ref):
         c = dim * 2 ** l
         f, sv_f = seq_fwd(K.concat2(x, warp[l]), P, _FUS[l], nfz[l], hd[l], ln, fusion=True)
         x = K.slice_channels(f, 0, c)                      # `[:, :embed_dim // 2]` (:892,903,914,925)
+        if l == 0:
+            x_l1 = x                                       # `inp_enc_level1`: what skip_conv reads when dual_pixel_task (:958)
         e, sv_e = seq_fwd(x, P, _ENC[l], nb[l], hd[l], ln)
         enc_out.append(e)
         sv_lv.append((sv_f, sv_e))
@@ -217,9 +217,14 @@ def net_fwd(P, cfg, inp, ref):
     cat1 = K.concat2(up_fwd(d2, P['up2_1.body.0.weight']), e1)
     d1, sv_d1 = seq_fwd(cat1, P, 'decoder_level1.', nb[0], hd[0], ln)
     rf, sv_rf = seq_fwd(d1, P, 'refinement.', cfg['num_refinement_blocks'], hd[0], ln)
-    out_p = E.conv_fwd(rf, P['output.weight'], P.get('output.bias'), 1, 1, res=inp_p)
+    if cfg.get('dual_pixel_task'):
+        # dual-pixel defocus deblurring (:955-959): output(refined + skip_conv(inp_enc_level1)), no `+ inp_img`
+        rf = _pw_fwd(x_l1, P, 'skip_conv', res=rf)
+        out_p = E.conv_fwd(rf, P['output.weight'], P.get('output.bias'), 1, 1)
+    else:
+        out_p = E.conv_fwd(rf, P['output.weight'], P.get('output.bias'), 1, 1, res=inp_p)
     out = out_p if (Hp, Wp) == (H0, W0) else K.pad_crop(out_p, H0, W0)
-    saved = (N, (H0, W0, Hp, Wp), geo, pyr, None, None, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2,
+    saved = (N, (H0, W0, Hp, Wp), geo, pyr, x_l1, None, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2,
              sv_d1, rf, sv_rf)
     return out, saved
 
@@ -230,7 +235,7 @@ def net_bwd(dout, P, cfg, saved, G=None):
 
 
 def _net_bwd(dout, P, cfg, saved, G):
-    (N, (H0, W0, Hp, Wp), geo, pyr, _, _, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, rf,
+    (N, (H0, W0, Hp, Wp), geo, pyr, x_l1, _, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, rf,
      sv_rf) = saved
     G = {} if G is None else G
     hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
@@ -243,6 +248,7 @@ def _net_bwd(dout, P, cfg, saved, G):
     d, G['output.weight'], db = E.conv_bwd(dout, rf, P['output.weight'], 1, 1, bias=has_ob)
     if has_ob:
         G['output.bias'] = db
+    dskip_l1 = _pw_bwd(d, x_l1, P, 'skip_conv', G) if cfg.get('dual_pixel_task') else None
     d = seq_bwd(d, P, 'refinement.', cfg['num_refinement_blocks'], hd[0], ln, sv_rf, G)
     d = seq_bwd(d, P, 'decoder_level1.', nb[0], hd[0], ln, sv_d1, G)            # grad of cat[up(d2), e1]
     de1 = d[:, dim:]
@@ -261,6 +267,8 @@ def _net_bwd(dout, P, cfg, saved, G):
         c = dim * 2 ** l
         sv_f, sv_e = sv_lv[l]
         d = seq_bwd(d, P, _ENC[l], nb[l], hd[l], ln, sv_e, G)
+        if l == 0 and dskip_l1 is not None:
+            d = K.add_(d, dskip_l1)
         df = torch.zeros(N, 2 * c, d.shape[2], d.shape[3], dtype=torch.float32, device=d.device)
         K.copy_rows(d, c * d.shape[2] * d.shape[3], df, 2 * c * d.shape[2] * d.shape[3], N, c * d.shape[2] * d.shape[3])
         dcat = seq_bwd(df, P, _FUS[l], nfz[l], hd[l], ln, sv_f, G, fusion=True)
@@ -277,3 +285,80 @@ def _net_bwd(dout, P, cfg, saved, G):
                 G['patch_embed.proj.bias'] = db
     E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
     return G
+
+
+# ---------------------------------------------------------------------------
+# un-guided Restormer.forward (:464-501): the same blocks without the reference branch
+# ---------------------------------------------------------------------------
+def unet_fwd(P, cfg, inp):
+    """inp [N, inp_channels, H, W], H and W multiples of 8 (the reference has no padding here: its PixelUnshuffle raises
+    otherwise) -> (out, saved)"""
+    N, _, H, W = inp.shape
+    if H % 8 or W % 8:
+        raise ValueError(f'Restormer: H, W must be multiples of 8 (three PixelUnshuffle(2) stages, :370-378); got {H}x{W}')
+    hd, ln, nb, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['dim']
+    inp = inp.contiguous()
+    x0 = E.conv_fwd(inp, P['patch_embed.proj.weight'], P.get('patch_embed.proj.bias'), 1, 1)
+    x, sv_lv, enc_out = x0, [], []
+    for l in range(4):
+        e, sv_e = seq_fwd(x, P, _ENC[l], nb[l], hd[l], ln)
+        enc_out.append(e)
+        sv_lv.append(sv_e)
+        if l < 3:
+            x = down_fwd(e, P[_DOWN[l]])
+    e1, e2, e3, lat = enc_out
+    cat3 = K.concat2(up_fwd(lat, P['up4_3.body.0.weight']), e3)
+    d3, sv_d3 = seq_fwd(_pw_fwd(cat3, P, 'reduce_chan_level3'), P, 'decoder_level3.', nb[2], hd[2], ln)
+    cat2 = K.concat2(up_fwd(d3, P['up3_2.body.0.weight']), e2)
+    d2, sv_d2 = seq_fwd(_pw_fwd(cat2, P, 'reduce_chan_level2'), P, 'decoder_level2.', nb[1], hd[1], ln)
+    cat1 = K.concat2(up_fwd(d2, P['up2_1.body.0.weight']), e1)
+    d1, sv_d1 = seq_fwd(cat1, P, 'decoder_level1.', nb[0], hd[0], ln)
+    rf, sv_rf = seq_fwd(d1, P, 'refinement.', cfg['num_refinement_blocks'], hd[0], ln)
+    if cfg.get('dual_pixel_task'):
+        rf = _pw_fwd(x0, P, 'skip_conv', res=rf)
+        out = E.conv_fwd(rf, P['output.weight'], P.get('output.bias'), 1, 1)
+    else:
+        out = E.conv_fwd(rf, P['output.weight'], P.get('output.bias'), 1, 1, res=inp)
+    return out, (inp, x0, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, rf, sv_rf)
+
+
+def unet_bwd(dout, P, cfg, saved, G=None):
+    """-> G (parameter gradients; the input image is data)"""
+    with E.deferred_join():
+        inp, x0, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, rf, sv_rf = saved
+        G = {} if G is None else G
+        hd, ln, nb, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['dim']
+        e1, e2, e3, lat = enc_out
+        dout = dout.contiguous()
+        has_ob = 'output.bias' in P
+        d, G['output.weight'], db = E.conv_bwd(dout, rf, P['output.weight'], 1, 1, bias=has_ob)
+        if has_ob:
+            G['output.bias'] = db
+        dskip0 = _pw_bwd(d, x0, P, 'skip_conv', G) if cfg.get('dual_pixel_task') else None
+        d = seq_bwd(d, P, 'refinement.', cfg['num_refinement_blocks'], hd[0], ln, sv_rf, G)
+        d = seq_bwd(d, P, 'decoder_level1.', nb[0], hd[0], ln, sv_d1, G)
+        de1 = d[:, dim:]
+        d, G['up2_1.body.0.weight'] = up_bwd(K.slice_channels(d, 0, dim), d2, P['up2_1.body.0.weight'])
+        d = seq_bwd(d, P, 'decoder_level2.', nb[1], hd[1], ln, sv_d2, G)
+        d = _pw_bwd(d, cat2, P, 'reduce_chan_level2', G)
+        de2 = d[:, 2 * dim:]
+        d, G['up3_2.body.0.weight'] = up_bwd(K.slice_channels(d, 0, 2 * dim), d3, P['up3_2.body.0.weight'])
+        d = seq_bwd(d, P, 'decoder_level3.', nb[2], hd[2], ln, sv_d3, G)
+        d = _pw_bwd(d, cat3, P, 'reduce_chan_level3', G)
+        de3 = d[:, 4 * dim:]
+        d, G['up4_3.body.0.weight'] = up_bwd(K.slice_channels(d, 0, 4 * dim), lat, P['up4_3.body.0.weight'])
+        dskip = [de1, de2, de3]
+        for l in reversed(range(4)):
+            d = seq_bwd(d, P, _ENC[l], nb[l], hd[l], ln, sv_lv[l], G)
+            if l > 0:
+                d, G[_DOWN[l - 1]] = down_bwd(d, enc_out[l - 1], P[_DOWN[l - 1]])
+                d = K.add_(d, dskip[l - 1])
+            else:
+                if dskip0 is not None:
+                    d = K.add_(d, dskip0)
+                has_pb = 'patch_embed.proj.bias' in P
+                _, G['patch_embed.proj.weight'], db = E.conv_bwd(d, inp, P['patch_embed.proj.weight'], 1, 1,
+                                                                 need_dx=False, bias=has_pb)
+                if has_pb:
+                    G['patch_embed.proj.bias'] = db
+        return G
