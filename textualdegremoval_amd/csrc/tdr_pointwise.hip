@@ -66,6 +66,59 @@ __global__ __launch_bounds__(64 * SLICES) void ln_fwd_kernel(const float* __rest
     }
 }
 
+// wide C over FEW pixels (the ViT / CLIP token LayerNorms: C = 768 .. 1280 over ~1 000 tokens): 64-pixel tiles give a dozen
+// workgroups on a 256-CU chip and each walks C / 16 rows serially (33 us for [1280 x 1152]).  Here a workgroup takes 16 pixels x 64
+// channel slices (64-byte row segments), a thread keeps its C / 64 values in registers: 4x the workgroups, one read of x.
+template <int CPT>
+__global__ __launch_bounds__(1024) void ln_fwd_narrow_kernel(const float* __restrict__ x, long x_ns, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float eps, int center, int C, int HW,
+                                                            float* __restrict__ y, float* __restrict__ mu, float* __restrict__ rstd) {
+    __shared__ float red[16][16];
+    const int p16 = threadIdx.x & 15, slice = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 16 + p16, n = blockIdx.y;
+    const bool pok = px < HW;
+    const float* xn = x + (long)n * x_ns + (pok ? px : HW - 1);
+    float v[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + 64 * i;
+        v[i] = c < C ? xn[(long)c * HW] : 0.f;
+        s += v[i];
+    }
+    auto block_sum = [&](float t) {
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) < 16) red[wave][p16] = t;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][p16];
+        return tot;
+    };
+    const float mean = block_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const float d = (slice + 64 * i < C) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rs = 1.0f / sqrtf(block_sum(q) / (float)C + eps);
+    if (!pok) return;
+    float* yn = y + ((long)n * C) * HW + px;
+    const float mo = center ? mean : 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = slice + 64 * i;
+        if (c < C) yn[(long)c * HW] = (v[i] - mo) * rs * w[c] + (b ? b[c] : 0.f);
+    }
+    if (slice == 0) {
+        mu[(long)n * HW + px] = mean;
+        rstd[(long)n * HW + px] = rs;
+    }
+}
+
 // any C: re-reads x (L2-resident for the small deep maps this serves); 16 channel slices of 64 pixels
 __global__ __launch_bounds__(1024) void ln_fwd_generic_kernel(const float* __restrict__ x, long x_ns,
                                                              const float* __restrict__ w, const float* __restrict__ b,
@@ -781,6 +834,11 @@ extern "C" int tdr_layernorm2d_fwd(const float* x, int64_t x_ns, const float* w,
     else if (C <= 128) LN_FWD(4, 32);
     else if (C <= 256) LN_FWD(8, 32);
     else if (C <= 512) LN_FWD(16, 32);
+    else if (C <= 64 * 24 && (long)grid.x * N < 512) {      // wide rows over few pixels: 16-pixel workgroups (see ln_fwd_narrow_kernel)
+        dim3 g16(tdr_cdiv(HW, 16), N);
+        if (C <= 64 * 12) hipLaunchKernelGGL(ln_fwd_narrow_kernel<12>, g16, dim3(1024), 0, st, x, (long)x_ns, w, b, eps, center, C, HW, y, mu, rstd);
+        else hipLaunchKernelGGL(ln_fwd_narrow_kernel<24>, g16, dim3(1024), 0, st, x, (long)x_ns, w, b, eps, center, C, HW, y, mu, rstd);
+    }
     else hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, dim3(1024), 0, st, x, (long)x_ns, w, b, eps, center, C, HW, y, mu, rstd);
 #undef LN_FWD
     TDR_LAUNCH_CHECK("ln_fwd");

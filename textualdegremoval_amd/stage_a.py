@@ -153,6 +153,7 @@ class I2TMappingTrainer:
         self._plan = K.PackPlan()
         # the Mapper as G-way grouped GEMMs over batch-flattened tokens (i2t.mapper_fwd_grouped); TDR_MAPPER_GROUPED=0 keeps the
         # 2 x num_words chains of small launches on four stream lanes
+        self.grad_scale = os.environ.get('TDR_I2T_GRAD_SCALE', '0') == '1'
         self.grouped = os.environ.get('TDR_MAPPER_GROUPED', '1') == '1'
         self.stacks = i2t.MapperStacks(self.mapper) if self.grouped else None
         # frozen stand-ins, packed once
@@ -182,7 +183,22 @@ class I2TMappingTrainer:
         """forward, MSE, hand-written backward; parameter gradients land in the reducer's arena.  Returns loss [1]."""
         S, P = self.S, {k: p.data for k, p in zip(self.names, self.params)}
         prev_plan = K.set_pack_plan(self._plan)
+        prev_scaled = K.GRAD_SCALED
         try:
+            # Optional loss-scaled backward (TDR_I2T_GRAD_SCALE=1; off by default): under TDR_MATH=hx2 the gradient GEMMs may take the
+            # 2-way fp16 split (3 products instead of the 6 of the 3-way bf16 split) if their operands sit in the fp16 window.
+            # Unlike the restoration step this backward spans ~2^20: dpred = 2 (pred - noise) / numel ~ 2^-14 while dk / dv sum over
+            # 4096 queries and reach ~2^5, so the exact power-of-two scale is S = numel / 256 (2^8 at bs 4): the largest operands
+            # stay below 2^14, the smallest lose part of their residual plane.  Every backward kernel is linear in the gradient, the
+            # gather into the arena multiplies by 1 / S, and the optimiser's device-resident guard skips a step whose gradient norm
+            # is not finite (and halves S).  Measured 29.7 -> 27.9 ms; no range survey guards it here, hence opt-in.
+            numel = b['noise'].numel()
+            gs = 2.0 ** (math.floor(math.log2(numel)) - 8) if (K.fp16_path() and self.grad_scale) else 1.0
+            K.set_grad_scaled(gs != 1.0)
+            guard = self.optimizer.ensure_guard(self.device)
+            if not torch.cuda.is_current_stream_capturing():
+                guard.set_max_scale(gs)
+            self.reducer.guard = guard
             self._plan.run()
             t, idx, ids = b['timesteps'], b['index'], b['input_ids']
             # ---- frozen front: VAE stand-in, forward diffusion, CLIP image encoder (no-grad)
@@ -211,7 +227,7 @@ class I2TMappingTrainer:
                 o = L['o'](a, res=h)                                                          # h + to_out(attention)
                 K.upsample_nearest_add_(pred, L['out'](o), f, accumulate=li > 0)
                 saved.append((q, k, v, a, lse, Tq))
-            loss, dpred = K.pixel_loss(K.LOSS_MSE, pred, b['noise'], 1.0, 0.0)
+            loss, dpred = K.pixel_loss(K.LOSS_MSE, pred, b['noise'], 1.0, 0.0, guard=guard)
             # ---- backward: only what leads to a trained parameter (the UNet side is frozen: no dq, no dh)
             sink = self.reducer.begin(defer_collectives=True)
             G = {}
@@ -233,6 +249,7 @@ class I2TMappingTrainer:
                 sink[kname] = G[kname]
             grads = self.reducer.finish()
         finally:
+            K.set_grad_scaled(prev_scaled)
             K.set_pack_plan(prev_plan)
             self._plan.invalidate()                       # the optimiser is about to change the weights
         if not getattr(self, '_bound', False) or self.reducer.relaid:
