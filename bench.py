@@ -222,21 +222,29 @@ def bench_i2t(a, world, rank, local):
 
 
 def pmc_traffic(prefix):
-    """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/pmc_collect.sh -> profiles/r2/
+    """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/pmc_collect.sh -> profiles/r<N>/
     pmc_traffic.json).  The file records the hash of the kernel source it was collected on: a mismatch means the counters
     describe an older kernel and the figure is reported as stale (null) instead of being passed off as current."""
     import hashlib
-    path = os.path.join(ROOT, 'profiles', 'r2', 'pmc_traffic.json')
     src = os.path.join(ROOT, 'textualdegremoval_amd', 'csrc', 'tdr_conv_bx3.hip')
+    pmc = path = None
+    for rnd in ('r3', 'r2'):                 # newest collection first
+        cand = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')
+        try:
+            with open(cand) as fh:
+                pmc, path = json.load(fh), f'profiles/{rnd}/pmc_traffic.json'
+            break
+        except (OSError, ValueError):
+            continue
     try:
-        with open(path) as fh:
-            pmc = json.load(fh)
         with open(src, 'rb') as fh:
             cur = hashlib.sha256(fh.read()).hexdigest()
-    except (OSError, ValueError):
-        return None, 'no PMC file (profiles/pmc_collect.sh not run this round)'
+    except OSError:
+        cur = None
+    if pmc is None:
+        return None, 'no PMC file (profiles/pmc_collect.sh not run)'
     if pmc.get('meta', {}).get('tdr_conv_bx3_sha256') != cur:
-        return None, 'stale: profiles/r2/pmc_traffic.json was collected on another revision of csrc/tdr_conv_bx3.hip'
+        return None, f'stale: {path} was collected on another revision of csrc/tdr_conv_bx3.hip'
     tot, n = 0.0, 0
     for name, v in pmc['kernels'].items():
         if name.startswith(prefix):
@@ -245,7 +253,7 @@ def pmc_traffic(prefix):
     if not n:
         return None, 'kernel family not in the PMC file'
     return tot / n, ('bytes/launch of the KH=3,S=1 family (FETCH_SIZE + WRITE_SIZE in separate passes, calibrated on copies of '
-                     'known size, profiles/r2/pmc_traffic.json; collected on this revision of the kernel source)')
+                     f'known size, {path}; collected on this revision of the kernel source)')
 
 
 def main():

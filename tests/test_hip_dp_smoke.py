@@ -43,6 +43,21 @@ def test_two_rank_graph_step_runs(wrap):
     assert 'buckets' in r2['config']['grad_exchange'] and r2['guard']['skipped_in_timed_region'] == 0
 
 
+def test_stage_a_step_two_ranks():
+    """C4 (accelerate's DDP over the Mapper, main_train_i2t_mapping.py:662): `bench.py --arch i2t --gpus 2` -- two ranks sharing the GPU
+    over gloo run the captured stage-A step with the gradient exchange of parallel.GradAllReducer between its two graphs"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--arch', 'i2t', '--clip', 'L', '--batch', '1', '--steps', '2',
+           '--warmup', '0', '--backend', 'gloo']
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert r['n_gpus'] == 2 and r['config']['global_batch'] == 2 and r['final_loss'] == r['final_loss']
+    assert r['guard']['skipped_total'] == 0
+
+
 def test_gpus_flag_must_match_the_launched_world():
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')

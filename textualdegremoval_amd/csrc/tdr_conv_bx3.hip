@@ -66,8 +66,15 @@ union Frag {
 //            Reduced precision (2^-11 per operand) -- BASELINE configs[4]'s "fp16 MFMA" arithmetic, selected by TDR_MATH=h1 only.
 enum { SCH_BX3 = 0, SCH_HX2 = 1, SCH_H1 = 2 };
 
+// Occupancy: the high-resolution 3x3 launches (C = 32 level: 32 x 256 tiles, 21 KB of LDS) are latency-bound -- SQ counters show their
+// waves waiting 55 % of the resident time with 3 waves per SIMD, the occupancy 148 VGPRs allow; asking for 4 (5) resident workgroups
+// caps the allocation at 128 (102) registers: 4 fits without spilling (118 VGPRs; same-box A/B 59.0 -> 58.6 ms per cfg2 step), 5 spills
+// 81 registers, the 64 x 256 tiles of the C = 64 level spill 130 at 4, the 128 x 128 tiles of the 1x1 kernel 334.  TDR_CONV_OCC (compile-time -D) selects the request.
+#ifndef TDR_CONV_OCC
+#define TDR_CONV_OCC 4
+#endif
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH, int AD = 0>
-__global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (KH == 3 && S == 1 && WM == 1 && TM == 1 && TN == 2 && AD == 0) ? TDR_CONV_OCC : 2) void conv_bx3_kernel(ConvArgs a) {
     constexpr int NS = SCH == SCH_BX3 ? 3 : (SCH == SCH_HX2 ? 2 : 1);   // operand planes (LDS, fragments)
     constexpr int NSW = SCH == SCH_BX3 ? 3 : 2;                         // planes of the weight pack
     constexpr int NP = SCH == SCH_BX3 ? 6 : (SCH == SCH_HX2 ? 3 : 1);   // matrix products per fp32 product

@@ -301,7 +301,12 @@ class RefGuidedImageCleanModel(BaseModel):
                 st['eager_left'] -= 1
                 return self._eager_step(self.lq, self.gt, self.ref_in)
             st['lq'], st['gt'], st['ref'] = self.lq.clone(), self.gt.clone(), self.ref_in.clone()
+            # what torch.cuda.graph() does on entry: hand the eager steps' cached blocks back, or the graphs' private pool has to
+            # fit NEXT to them (PromptIR-ref 384x384 bs 8: 106 GB live + 180 GB cached = out of memory)
             torch.cuda.synchronize()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             st['ws_refs'] = []                 # scratch buffers the captured kernels address (kernels.workspace_capture)
             split = red.collective and os.environ.get('TDR_GRAPH_BUCKETS', '1') == '1'
             pool = torch.cuda.graph_pool_handle()

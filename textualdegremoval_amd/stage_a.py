@@ -290,7 +290,12 @@ class I2TMappingTrainer:
                 self._eager_left -= 1
                 return self._eager(b)
             g = self._g = {'key': key, 'in': {k: v.clone() for k, v in b.items()}, 'refs': []}
+            # what torch.cuda.graph() does on entry: hand the eager steps' cached blocks back, or the graphs' private pool has to
+            # fit NEXT to them (PromptIR-ref 384x384 bs 8: 106 GB live + 180 GB cached = out of memory)
             torch.cuda.synchronize()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             pool = torch.cuda.graph_pool_handle()
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
