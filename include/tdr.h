@@ -493,6 +493,13 @@ int tdr_mapper_combine_all_bwd(const float* go, int B, int G, int D, int LD, int
                                float* gsum /* [G][D] = sum_b go: the pixel sum of dcls and of dpatch */, void* stream);
 /* tdr_gather_col for any token layout: dst[d][b] = src[b*img_stride + d*ch_stride + col] */
 int tdr_gather_col_strided(const float* src, int B, int D, int64_t img_stride, int64_t ch_stride, int col, float* dst, void* stream);
+/* Split-K for the single-round long-K Linears of the frozen ViTs (1280 -> 1280 and 5120 -> 1280 over ~1 000 tokens: 180 workgroups on
+ * 256 CUs, each walking 20 - 80 K stages).  The K chunks run as the N = S "images" of ONE tdr_conv_forward launch (input viewed as
+ * [S][K/S][P], per-image packed weights wp_ns) into partial sums part [S][C][P]; this finishes them:
+ *   out[c][p] = act((sum_s part[s][c][p] + bias[c]) * scale[c] + res[c][p])   (tdr_conv_forward's STD epilogue order; bias / scale /
+ * res may be NULL; relu codes as TdrConvDesc.relu), fixed summation order. */
+int tdr_splitk_finish(const float* part, int S, int C, int64_t P, const float* bias, const float* scale, const float* res, int relu,
+                      float* out, void* stream);
 /* Stage-A train step glue (main_train_i2t_mapping.py:704-760).
  * inj_forward_text's embedding injection (:139-151) + position embedding, written channel-major [B][D][LD]: the L mapper words
  * inj [B][L][D] replace the placeholder token at position idx[b] of the prompt ids [B][S] (int32), the rest of the prompt moves

@@ -153,3 +153,22 @@ def test_optimizer_param_indices_follow_the_reference_for_unused_tensors():
     assert len(unused) >= 6
     sd = m.optimizer_g.state_dict()
     assert sum(len(g['params']) for g in sd['param_groups']) == len(named)
+
+
+def test_dist_validation_runs_on_local_rank_zero_only(monkeypatch):
+    """reference image_restoration_ref_model.py:319-323: LOCAL_RANK 0 validates, every other rank returns 0."""
+    import bench
+    from textualdegremoval_amd.models import create_model
+    opt = bench.make_opt(8, [1, 1, 1, 1], 64, False)
+    opt['num_gpu'] = 0
+    m = create_model(opt)
+    calls = []
+    monkeypatch.setattr(m, 'nondist_validation', lambda *a: calls.append(a) or 31.5)
+    m.opt['dist'] = True
+    monkeypatch.setenv('LOCAL_RANK', '1')
+    assert m.validation('loader', 10, None, False, True, True) == 0.
+    monkeypatch.setenv('LOCAL_RANK', '0')
+    assert m.validation('loader', 10, None, False, True, True) == 31.5 and len(calls) == 1
+    m.opt['dist'] = False
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert m.validation('loader', 10, None) == 31.5 and len(calls) == 2

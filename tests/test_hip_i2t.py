@@ -275,3 +275,28 @@ def test_grouped_mapper_equals_the_per_word_chains(K):
     p = dict(mp.named_parameters())['mapping_patch_1.3.weight']
     p.data.add_(1.0)
     assert torch.equal(st.W['mapping_patch_', 3][1], p.data)
+
+
+def test_clip_split_k_linears_match_the_single_launch(K):
+    """the narrow-output Linears of the flat-layout encoder run split-K (K chunks as the images of one launch + tdr_splitk_finish):
+    same products, partial sums added in a fixed order -- equal to the single-launch result up to fp32 summation order"""
+    from textualdegremoval_amd.clip_vision import ClipVisionEncoder
+    sd = IO.synth_clip_params(1024, 2048, 2, 14, 56, seed=9)          # cin 1024 / 2048 -> cout 1024: the split-K rule applies
+    x = torch.rand(2, 3, 56, 56, generator=torch.Generator().manual_seed(1)).cuda()
+    prev = ClipVisionEncoder.SPLITK
+    try:
+        ClipVisionEncoder.SPLITK = 4
+        a = ClipVisionEncoder(sd, 'cuda', 16)
+        assert a.W['encoder.layers.0.out'][3] is not None and a.W['encoder.layers.0.mlp.fc2'][3] is not None and a.W['encoder.layers.0.qkv'][3] is None
+        ya, T1 = a.tokens(x, flat=True)
+        ClipVisionEncoder.SPLITK = 1
+        b = ClipVisionEncoder(sd, 'cuda', 16)
+        yb, _ = b.tokens(x, flat=True)
+    finally:
+        ClipVisionEncoder.SPLITK = prev
+    ref = IO.clip_vision_tokens(sd, x.cpu(), 16)
+    scale = ref.abs().max().item()
+    assert maxdiff(ya, yb) < 1e-5 * scale
+    LD = ya.shape[2] * ya.shape[3] // 2
+    tm = ya.reshape(1024, 2, LD)[:, :, :T1 + 1].permute(1, 2, 0)
+    assert maxdiff(tm, ref) < 1e-4 * max(1.0, scale)

@@ -208,8 +208,11 @@ def test_full_size_step_vs_oracle_bs2():
     tr = SA.I2TMappingTrainer(clip_sd, 16, S, clip_act='gelu', num_words=20, mapper=mp, use_hip_graph=False)
     P = {k: v.detach().cpu().clone() for k, v in tr.mapper.state_dict().items()}
     orc = IO.OracleStageATrainer(P, S, clip_sd, 16, 'gelu', SA.LEVELS, 20)
-    tok, Tn = tr.image_encoder.encode(batch['pixel_values_clip'].cuda())
-    emb_hip = cm_to_tm(tok, Tn + 1).cpu()
+    # the very tokens the step's Mapper sees: batch-flattened layout (split-K out-projection / fc2), un-flattened for the oracle
+    tok, Tn = tr.image_encoder.encode(batch['pixel_values_clip'].cuda(), flat=True)
+    B_, D_ = 2, tok.shape[1]
+    LD_ = tok.shape[2] * tok.shape[3] // B_
+    emb_hip = tok.reshape(D_, B_, LD_)[:, :, :Tn + 1].permute(1, 2, 0).contiguous().cpu()
     emb_orc = orc.embed(batch)
     scale = emb_orc.abs().max().item()
     assert maxdiff(emb_hip, emb_orc) < 1e-4 * scale          # tokens reach ~260 (random weights, no post-LayerNorm): relative to that scale

@@ -225,6 +225,7 @@ SIGNATURES = {
     'tdr_mapper_combine_all': (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_mapper_combine_all_bwd': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_gather_col_strided': (i32, [c_fp, i32, i32, i64, i64, i32, c_fp, c_fp]),
+    'tdr_splitk_finish': (i32, [c_fp, i32, i32, i64, c_fp, c_fp, c_fp, i32, c_fp, c_fp]),
     'tdr_text_inject_fwd': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_text_inject_bwd': (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_add_noise': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp]),

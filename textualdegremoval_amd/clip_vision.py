@@ -55,17 +55,36 @@ class ClipVisionEncoder:
                 w = sd[p + name + '.weight']
                 self._pack(p + name, w.reshape(w.shape[0], w.shape[1], 1, 1))
 
+    # Split-K for the narrow-output Linears (attention out-projection, fc2): over the ~1 150 tokens of a 4-image batch they are a
+    # single round of ~180 workgroups walking 20 - 80 serial K stages with cold weights (110 / 165 us per launch for ~10 us of
+    # work).  Their K chunks run as the "images" of ONE launch (input [1, K, .] viewed as [S, K/S, .], per-chunk packs via wp_ns) and
+    # tdr_splitk_finish applies bias / residual / activation to the summed partials (profiles/probe_splitk_1x1.py: 49 -> 33 us and
+    # 165 -> 65 us per launch with warm weights).  Batch-flattened layout only (the image axis is what carries the chunks).
+    SPLITK = int(__import__('os').environ.get('TDR_CLIP_SPLITK', '4'))
+
     def _pack(self, key, w4):
+        cout, cin = w4.shape[0], w4.shape[1]
+        S = self.SPLITK if (self.SPLITK > 1 and cout <= 1536 and cin >= 1024 and cin % (16 * self.SPLITK) == 0) else 1
         prev = K.set_pack_plan(None)                      # persistent buffers, not a per-step plan
         try:
-            wp, mp, *_ = K.pack_weights(w4.to(self.device).contiguous(), PACK_FWD)
+            w4 = w4.to(self.device).contiguous()
+            wp, mp, *_ = K.pack_weights(w4, PACK_FWD)
+            split = None
+            if S > 1:
+                kc = cin // S
+                packs = [K.pack_weights(w4[:, s * kc:(s + 1) * kc].contiguous(), PACK_FWD)[0] for s in range(S)]
+                split = (K.PackedWeights(torch.cat([p.buf for p in packs]), packs[0].fmt), packs[0].buf.numel(), S)
         finally:
             K.set_pack_plan(prev)
-        self.W[key] = (wp, mp, w4.shape[0])
+        self.W[key] = (wp, mp, cout, split)
 
-    def _linear(self, x, key, bias, **kw):
-        wp, mp, cout = self.W[key]
-        return K.conv_forward(x, wp, mp, cout, 1, bias=bias, **kw)
+    def _linear(self, x, key, bias, res=None, relu=0, **kw):
+        wp, mp, cout, split = self.W[key]
+        if split is not None and x.shape[0] == 1 and not kw and x.shape[2] * x.shape[3] % 4 == 0:
+            wps, per, S = split
+            part = K.conv_forward(x.view(S, x.shape[1] // S, x.shape[2], x.shape[3]), wps, mp, cout, 1, wp_ns=per)
+            return K.splitk_finish(part, bias=bias, res=res, relu=relu)
+        return K.conv_forward(x, wp, mp, cout, 1, bias=bias, res=res, relu=relu, **kw)
 
     @torch.no_grad()
     def tokens(self, x, flat=False):

@@ -362,6 +362,32 @@ __global__ void gather_col_strided_kernel(const float* __restrict__ src, int B, 
     dst[i] = b < B ? src[(long)b * img_stride + (long)d * ch_stride + col] : 0.f;
 }
 
+// split-K finish of a 1x1 convolution whose K chunks ran as the "images" of one launch (partial sums part[S][C][P]):
+//   out[c][p] = act( (sum_s part[s][c][p] + bias[c]) * scale[c] + res[c][p] )      -- the STD epilogue order of tdr_conv_forward
+// fixed summation order (s = 0, 1, ...); relu codes as TdrConvDesc.relu (0 none, 1 ReLU, 2 erf-GELU, 3 quick_gelu)
+__global__ void splitk_finish_kernel(const float* __restrict__ part, int S, long CP4, int P4, const float* __restrict__ bias,
+                                     const float* __restrict__ scale, const float* __restrict__ res, int relu, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < CP4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(part)[i];
+        for (int s = 1; s < S; ++s) {
+            const float4 q = reinterpret_cast<const float4*>(part)[(long)s * CP4 + i];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        const int c = (int)(i / P4);
+        if (bias) { const float b = bias[c]; v.x += b; v.y += b; v.z += b; v.w += b; }
+        if (scale) { const float g = scale[c]; v.x *= g; v.y *= g; v.z *= g; v.w *= g; }
+        if (res) { const float4 r = reinterpret_cast<const float4*>(res)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (relu == 1) e[k] = fmaxf(e[k], 0.f);
+            else if (relu == 2) e[k] = 0.5f * e[k] * (1.f + erff(e[k] * 0.70710678118654752f));
+            else if (relu == 3) e[k] = e[k] / (1.f + expf(-1.702f * e[k]));
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+
 }  // namespace
 
 extern "C" int tdr_leaky_relu_fwd(const float* x, int64_t numel, float slope, float* y, void* stream) {
@@ -518,5 +544,15 @@ extern "C" int tdr_gather_col_strided(const float* src, int B, int D, int64_t im
     hipLaunchKernelGGL(gather_col_strided_kernel, dim3(tdr_cdiv((long)D * 32, 256)), dim3(256), 0, (hipStream_t)stream, src, B, D,
                        (long)img_stride, (long)ch_stride, col, dst);
     TDR_LAUNCH_CHECK("gather_col_strided");
+    return TDR_OK;
+}
+
+extern "C" int tdr_splitk_finish(const float* part, int S, int C, int64_t P, const float* bias, const float* scale, const float* res,
+                                 int relu, float* out, void* stream) {
+    TDR_REQUIRE(part && out && S >= 1 && C > 0 && P > 0 && P % 4 == 0, "tdr_splitk_finish: bad argument (P must be a multiple of 4)");
+    const long CP4 = (long)C * P / 4;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid_for(CP4, 4096)), dim3(256), 0, (hipStream_t)stream, part, S, CP4, (int)(P / 4), bias,
+                       scale, res, relu, out);
+    TDR_LAUNCH_CHECK("splitk_finish");
     return TDR_OK;
 }

@@ -1281,6 +1281,16 @@ def gather_col_flat(tok, B, col=0):
     return out
 
 
+def splitk_finish(part, bias=None, scale=None, res=None, relu=0):
+    """part [S, C, H, W] (K-chunk partial sums of a 1x1 convolution) -> [1, C, H, W] = act((sum_s part + bias) * scale + res)"""
+    S, Cc, H, W = part.shape
+    assert part.is_contiguous() and (res is None or (res.is_contiguous() and res.numel() == Cc * H * W))
+    out = torch.empty(1, Cc, H, W, dtype=torch.float32, device=part.device)
+    check(_lib.load().tdr_splitk_finish(part.data_ptr(), S, Cc, H * W, _p(bias), _p(scale), _p(res), int(relu) if not isinstance(relu, bool) else int(relu),
+                                        out.data_ptr(), _stream()), 'tdr_splitk_finish')
+    return out
+
+
 # ---- stage-A train step glue (csrc/tdr_i2t.hip; main_train_i2t_mapping.py:704-760)
 def _i32(t):
     assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
