@@ -64,6 +64,7 @@ class ClipVisionEncoder:
 
     def _pack(self, key, w4):
         cout, cin = w4.shape[0], w4.shape[1]
+        # (the wide Linears -- q/k/v 1280 -> 3840, fc1 -> 5120: 270 - 360 workgroups -- measured flat or slower when split)
         S = self.SPLITK if (self.SPLITK > 1 and cout <= 1536 and cin >= 1024 and cin % (16 * self.SPLITK) == 0) else 1
         prev = K.set_pack_plan(None)                      # persistent buffers, not a per-step plan
         try:
