@@ -437,13 +437,34 @@ int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int 
  * head dim C/heads in {16,32,64} (attention.py:56-71) */
 int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream);
 /* the same with the arithmetic named: math 0 = exact fp32 MFMA (what tdr_attention_fwd runs), 2 = 2-way fp16 split (3 f16 MFMA
- * products per fp32 product, fp32 accumulate and softmax) for the frozen no-grad ViTs -- q, k, v must lie in the fp16 range */
+ * products per fp32 product, fp32 accumulate and softmax) for the frozen no-grad ViTs -- q, k, v must lie in the fp16 range;
+ * 3 = plain fp16 MFMA (one product, reduced precision) for the DINOv2 window matcher only: its sole output is an arg-max */
 int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, int flat,
                            float* out, void* stream);
 /* cosine similarity of flattened patch-token maps (columns 1..T1-1), first arg-max, window gather:
  * fl [B][D][LD], fr [B*N][D][LD], windows [B*N][per] -> corr [B][N], index [B] (int32), ref_in [B][per] (:230-243) */
 int tdr_token_match(const float* fl, const float* fr, const float* windows, int B, int N, int D, int T1, int LD, int64_t per,
                     float* corr, int* index, float* ref_in, void* stream);
+
+/* Token-major fp16 pipeline of the frozen DINOv2 matcher (csrc/tdr_tok16.hip; replaces the per-block calls of
+ * models/dino/vision_transformers.py inside get_ref_in, image_restoration_ref_model.py:215-247, whose only output is an arg-max).
+ * The residual stream is fp32 [P][D] (P = images x padded tokens per image, D contiguous); every GEMM operand is fp16 [P][K],
+ * rounded once by its producer -- the arithmetic of tdr_attention_fwd_math code 3 / the single-product Linears, summation order
+ * aside.  Pointers named *16 are device arrays of IEEE binary16. */
+/* dst[b][c][r] = src[b][r][c] (contiguous fp32 batches): entering / leaving the channel-major layout of tdr_vit_assemble and
+ * tdr_token_match */
+int tdr_transpose_f32(const float* src, int batch, int R, int C, float* dst, void* stream);
+/* nn.LayerNorm(D) over each of the P token rows (D % 4 == 0, D <= 1024); out is fp16 [P][D] if out_f16 else fp32 [P][D] */
+int tdr_tok_layernorm(const float* x, const float* w, const float* b, int64_t P, int D, float eps, int out_f16, void* out,
+                      void* stream);
+/* nn.Linear: acc = x16 [P][K] . w16 [N][K]^T in fp32 (N % 128 == 0, K % 64 == 0); bias may be NULL.
+ * epi 0: y16 [P][N] = acc + bias;  1: y16 = erf-GELU(acc + bias);  2: res [P][N] (fp32, in place) += ls[n] * (acc + bias)
+ * (LayerScale + residual; ls NULL = 1) */
+int tdr_tok16_gemm(const void* x16, const void* w16, const float* bias, int64_t P, int N, int K, int epi, void* y16, float* res,
+                   const float* ls, void* stream);
+/* softmax(q k^T * scale) v per head over the first T rows of each image: qkv16 [B][LD][3C] (q | k | v column blocks, head-major
+ * inside each, head dim 64), out16 [B][LD][C]; rows T..LD-1 of out16 are zero */
+int tdr_tok16_attention(const void* qkv16, int B, int C, int heads, int T, int LD, float scale, void* out16, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Stage-A (image-to-text mapping) glue: scripts/train/main_train_i2t_mapping.py:40-81 (Mapper), :85-98,197-233 (injected

@@ -85,8 +85,46 @@ def test_vit_b14_head_dim_64(matcher):
     assert (t - ref).abs().max().item() < 2e-4
 
 
+def test_tok16_kernels_against_torch():
+    """csrc/tdr_tok16.hip piece by piece against torch on the same fp16-rounded operands (fp32 accumulation on both sides: the bars
+    are summation-order noise, 1e-3 of the output scale, plus half an fp16 ulp where the output is fp16)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()
+    x = r(3, 70, 45)
+    assert torch.equal(K.transpose_f32(x), x.transpose(1, 2).contiguous())
+    P, D = 2 * 160 + 37, 768                                               # a ragged last row tile
+    t, w, b = r(P, D) * 3 + 1, r(D), r(D)
+    ref = torch.nn.functional.layer_norm(t, (D,), w, b, 1e-6)
+    assert (K.tok_layernorm(t, w, b, 1e-6, out_f16=False) - ref).abs().max().item() < 2e-5
+    h16 = K.tok_layernorm(t, w, b, 1e-6)
+    assert h16.dtype == torch.float16 and (h16.float() - ref).abs().max().item() < 1e-5 + 2 ** -11 * ref.abs().max().item()
+    for N, Kd in ((2304, 768), (768, 3072)):
+        x16, w16, bias, ls = (r(P, Kd) * 0.5).half(), (r(N, Kd) * 0.05).half(), r(N), r(N)
+        acc = x16.float() @ w16.float().t() + bias
+        bar = 1e-3 * acc.abs().max().item()
+        y0, y1 = K.tok16_gemm(x16, w16, bias), K.tok16_gemm(x16, w16, bias, epi=1)
+        assert (y0.float() - acc).abs().max().item() < bar + 2 ** -11 * acc.abs().max().item()
+        assert (y1.float() - torch.nn.functional.gelu(acc)).abs().max().item() < bar + 2 ** -11 * acc.abs().max().item()
+        res = r(P, N)
+        want = res + ls * acc
+        got = K.tok16_gemm(x16, w16, bias, epi=2, res=res.clone(), ls=ls)
+        assert (got - want).abs().max().item() < 1e-3 * want.abs().max().item()
+        assert (K.tok16_gemm(x16, w16, None, epi=2, res=res.clone()) - (res + acc - bias)).abs().max().item() < 1e-3 * want.abs().max().item()
+    B, heads, T1, LD = 3, 12, 257 + 64, 352                              # 5 full key tiles + 1 key, a partly filled query block
+    qkv = (r(B * LD, 3 * 768) * 0.7).half()
+    out = K.tok16_attention(qkv, B, heads, 0.125, T1).float().view(B, LD, heads, 64)
+    q, k, v = (qkv.float().view(B, LD, 3, heads, 64)[:, :T1, i].permute(0, 2, 1, 3) for i in range(3))
+    want = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3)
+    assert (out[:, :T1] - want).abs().max().item() < 3e-3 * want.abs().max().item()        # P is rounded to fp16 before P V
+    assert torch.equal(out[:, T1:], torch.zeros_like(out[:, T1:]))
+
+
 def test_single_product_linears_keep_every_match_decision():
-    """DinoMatcher(linear_math='h1'): the frozen Linears on ONE fp16 MFMA product.  The sub-graph's only output is the window index, so
+    """DinoMatcher(linear_math='h1'): the frozen Linears AND the attention (tdr_attention_fwd_math math code 3) on ONE fp16 MFMA product.
+    The sub-graph's only output is the window index, so
     the bar is bit-exact indices: on the reference golden, and -- full ViT-B/14 geometry, structured 128x128 crops against 256x256
     references at several offsets / seeds (25 windows each) -- against the 2-way split arithmetic, with the similarity margin between
     the best and the second-best window reported."""
@@ -97,6 +135,11 @@ def test_single_product_linears_keep_every_match_decision():
     prev = K.MATH
     K.set_math('hx2')
     try:
+        qkv = torch.randn(3, 3 * 128, 9, 32, generator=torch.Generator().manual_seed(5)).cuda()      # head dim 64, 257 of 288 columns
+        a2, a3 = K.attention_fwd(qkv, 2, 0.125, 257), K.attention_fwd(qkv, 2, 0.125, 257, single_product=True)
+        err = (a2 - a3).view(3, 128, -1)[..., :257].abs().max().item()
+        assert 0 < err < 4e-3 * a2.abs().max().item(), err                    # a different (plain fp16) arithmetic, and close
+        assert torch.equal(a3.view(3, 128, -1)[..., 257:], torch.zeros_like(a3.view(3, 128, -1)[..., 257:]))
         sd = D.synth_vit_params(32, 2, 2, seed=11)
         m1 = DinoMatcher(sd, torch.device('cuda'), heads=2, linear_math='h1')
         gold = np.load(os.path.join(GOLDEN, 'dino_vit_e32_d2.npz'))
@@ -107,7 +150,18 @@ def test_single_product_linears_keep_every_match_decision():
         assert (corr.cpu() - o_corr).abs().max().item() < 5e-3
         sdb = random_vit_b14_state_dict(seed=1, depth=12)
         a, b = DinoMatcher(sdb, torch.device('cuda'), linear_math='hx2'), DinoMatcher(sdb, torch.device('cuda'))     # default: 'h1'
-        assert b.linear_math == 'h1'
+        assert b.linear_math == 'h1' and b.tok16 and not a.tok16          # b: the token-major fp16 pipeline (csrc/tdr_tok16.hip)
+        os.environ['TDR_DINO_TOK16'] = '0'
+        try:
+            c = DinoMatcher(sdb, torch.device('cuda'))                       # the same arithmetic on the channel-major engines
+        finally:
+            del os.environ['TDR_DINO_TOK16']
+        xs = images(3, 126, 126, seed=77).cuda()
+        (fb, Tb), (fc, Tc), (fa, _) = b.tokens(xs, flat=True), c.tokens(xs, flat=True), a.tokens(xs, flat=True)
+        assert Tb == Tc and not c.tok16
+        e_bc, e_ca = (fb - fc).view(3, 768, -1)[..., :Tb + 1].abs().max().item(), (fc - fa).view(3, 768, -1)[..., :Tb + 1].abs().max().item()
+        print(f'final-norm tokens: token-major fp16 pipeline vs channel-major h1 {e_bc:.2e}; channel-major h1 vs the 2-way split {e_ca:.2e}')
+        assert e_bc < 2 * e_ca + 1e-4                                        # two orderings of one arithmetic: inside its own rounding noise
         worst_margin, n = 1.0, 0
         for seed in range(4):
             big = images(2, 256, 256, seed=40 + seed)

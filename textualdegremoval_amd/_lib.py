@@ -180,6 +180,10 @@ SIGNATURES = {
     'tdr_attention_fwd_math': (i32, [c_fp, i32, i32, i32, i32, i32, f32, i32, i32, c_fp, c_fp]),
     'tdr_attention_fwd': (i32, [c_fp, i32, i32, i32, i32, i32, f32, c_fp, c_fp]),
     'tdr_token_match': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i64, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_transpose_f32': (i32, [c_fp, i32, i32, i32, c_fp, c_fp]),
+    'tdr_tok_layernorm': (i32, [c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp, c_fp]),
+    'tdr_tok16_gemm': (i32, [c_fp, c_fp, c_fp, i64, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_tok16_attention': (i32, [c_fp, i32, i32, i32, i32, i32, f32, c_fp, c_fp]),
     'tdr_optim_chunk': (i32, []),
     'tdr_multi_copy': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
     'tdr_grad_sumsq': (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp]),

@@ -198,7 +198,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 typedef _Float16 vh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 vh4 __attribute__((ext_vector_type(4)));
 
-template <int HD, int KT>
+// H1 = true: ONE product per operand pair (the hi planes only; lo planes are neither built nor multiplied) -- plain fp16 MFMA with fp32
+// accumulation and softmax, a third of the matrix work.  Reduced precision (2^-11 per operand): only for the DINOv2 window matcher,
+// whose sole output is an arg-max that tests/test_hip_dino.py pins bit-exactly against the split arithmetic (math code 3).
+template <int HD, int KT, bool H1 = false>
 __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
     constexpr int NDT = (HD + 31) / 32, KS = HD / 16, NOCT = HD / 8, NKB = KT / 32;
     constexpr int VP = KT + 8;                              // halves per d row of the V tile
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
                 hi[i] = hh;
                 lo[i] = (_Float16)(v - (float)hh);
             }
-            if (oc < NOCT) { sK[0][oc][kx] = hi; sK[1][oc][kx] = lo; }
+            if (oc < NOCT) { sK[0][oc][kx] = hi; if constexpr (!H1) sK[1][oc][kx] = lo; }
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
             asm volatile("" : "+v"(v));
             const _Float16 hh = (_Float16)v;
             sV[0][d][kx] = hh;
-            sV[1][d][kx] = (_Float16)(v - (float)hh);
+            if constexpr (!H1) sV[1][d][kx] = (_Float16)(v - (float)hh);
         }
     };
     f32x16 o[NDT];
@@ -294,9 +297,11 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const vh8 kh = sK[0][2 * s + kk][kb * 32 + j];
-                const vh8 kl = sK[1][2 * s + kk][kb * 32 + j];
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], st[kb], 0, 0, 0);       // small cross terms first
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], st[kb], 0, 0, 0);
+                if constexpr (!H1) {
+                    const vh8 kl = sK[1][2 * s + kk][kb * 32 + j];
+                    st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], st[kb], 0, 0, 0);       // small cross terms first
+                    st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], st[kb], 0, 0, 0);
+                }
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], st[kb], 0, 0, 0);
             }
 #pragma unroll
@@ -342,13 +347,18 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
 #pragma unroll
             for (int s = 0; s < 2 * NKB; ++s) {
                 const int kb = (s >> 1) * 32 + 16 * (s & 1) + 4 * kk;
-                vh8 vh, vl;
+                vh8 vh;
                 const vh4 a0 = *reinterpret_cast<const vh4*>(&sV[0][d][kb]), a1 = *reinterpret_cast<const vh4*>(&sV[0][d][kb + 8]);
-                const vh4 b0 = *reinterpret_cast<const vh4*>(&sV[1][d][kb]), b1 = *reinterpret_cast<const vh4*>(&sV[1][d][kb + 8]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { vh[i] = a0[i]; vh[4 + i] = a1[i]; vl[i] = b0[i]; vl[4 + i] = b1[i]; }
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[dt], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) { vh[i] = a0[i]; vh[4 + i] = a1[i]; }
+                if constexpr (!H1) {
+                    vh8 vl;
+                    const vh4 b0 = *reinterpret_cast<const vh4*>(&sV[1][d][kb]), b1 = *reinterpret_cast<const vh4*>(&sV[1][d][kb + 8]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { vl[i] = b0[i]; vl[4 + i] = b1[i]; }
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[dt], 0, 0, 0);
+                }
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[dt], 0, 0, 0);
             }
         }
@@ -657,7 +667,14 @@ extern "C" int tdr_vit_assemble(float* tok, const float* cls, const float* pos, 
 static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st, int math = 0) {
     const int hd = a.C / heads;
     dim3 grid(tdr_cdiv(a.LDq, 128), heads, B);
-    if (math == 2 && (hd == 80 || hd == 64 || hd == 32 || hd == 16)) {
+    if (math == 3 && (hd == 64 || hd == 32 || hd == 16)) {          // plain fp16 (DINOv2 matcher only)
+        if (hd == 64) hipLaunchKernelGGL((attn_fwd_hx2_kernel<64, 32, true>), grid, dim3(256), 0, st, a);
+        else if (hd == 32) hipLaunchKernelGGL((attn_fwd_hx2_kernel<32, 32, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_hx2_kernel<16, 32, true>), grid, dim3(256), 0, st, a);
+        TDR_LAUNCH_CHECK("attention_fwd_h1");
+        return TDR_OK;
+    }
+    if ((math == 2 || math == 3) && (hd == 80 || hd == 64 || hd == 32 || hd == 16)) {
         static const int kt = getenv("TDR_ATTN_KT") ? atoi(getenv("TDR_ATTN_KT")) : 32;       // key tile (tuning aid)
         if (hd == 80) hipLaunchKernelGGL((attn_fwd_hx2_kernel<80, 32>), grid, dim3(256), 0, st, a);
         else if (hd == 64 && kt == 64) hipLaunchKernelGGL((attn_fwd_hx2_kernel<64, 64>), grid, dim3(256), 0, st, a);
@@ -680,10 +697,11 @@ extern "C" int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int 
     return tdr_attention_fwd_math(qkv, B, C, heads, T, LD, scale, 0, 0, out, stream);
 }
 
-// math 0: exact fp32 MFMA; 2: 2-way fp16 split (operands within the fp16 range: LayerNorm-ed ViT activations)
+// math 0: exact fp32 MFMA; 2: 2-way fp16 split (operands within the fp16 range: LayerNorm-ed ViT activations);
+// 3: plain fp16, one product (reduced precision: the DINOv2 matcher, whose only output is an arg-max pinned by its tests)
 extern "C" int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, int flat,
                                       float* out, void* stream) {
-    TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T && (math == 0 || math == 2), "tdr_attention_fwd: bad argument");
+    TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T && (math == 0 || math == 2 || math == 3), "tdr_attention_fwd: bad argument");
     AttnArgs a{qkv, 3L * C * LD, LD, T, qkv + (long)C * LD, qkv + 2L * C * LD, 3L * C * LD, LD, T, C, scale, out, nullptr, LD, LD, (long)C * LD};
     if (flat) {      // [3C][B*LD]: image b at column offset b*LD, channel stride B*LD; out [C][B*LD]
         const long cs = (long)B * LD;

@@ -21,14 +21,15 @@ LN_EPS = 1e-6
 
 class DinoMatcher:
     def __init__(self, state_dict, device, patch=14, heads=12, interpolate_offset=0.1, linear_math=None):
-        """linear_math: arithmetic of the frozen Linears (TDR_DINO_MATH overrides; default 'h1' under TDR_MATH=hx2, else
-        kernels.MATH).  'h1' runs them as ONE
+        """linear_math: arithmetic of the frozen Linears and of the attention (TDR_DINO_MATH overrides; default 'h1' under
+        TDR_MATH=hx2, else kernels.MATH).  'h1' runs them as ONE
         fp16 MFMA product per operand pair (11-bit operands, fp32 accumulate) instead of the 3 of the 2-way split: nothing but an
         arg-max over window similarities leaves this sub-graph, so it is admissible exactly as long as that index
         does not move -- tests/test_hip_dino.py pins it on the reference goldens and on a sweep against the split arithmetic."""
         self.linear_math = linear_math or os.environ.get('TDR_DINO_MATH') or ('h1' if K.MATH == 'hx2' else None)
         if self.linear_math not in (None, 'h1', 'hx2', 'bx3', 'f32'):
             raise ValueError(f'TDR_DINO_MATH / linear_math: {self.linear_math!r}')
+        self.tok16 = False          # set below: the token-major fp16 pipeline (csrc/tdr_tok16.hip), the same 'h1' arithmetic
         sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
         need = ['cls_token', 'pos_embed', 'patch_embed.proj.weight', 'patch_embed.proj.bias', 'norm.weight', 'norm.bias']
         miss = [k for k in need if k not in sd]
@@ -51,6 +52,13 @@ class DinoMatcher:
             for name in ('attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2'):
                 w = sd[p + name + '.weight']
                 self._pack(p + name, w.reshape(w.shape[0], w.shape[1], 1, 1))
+        # 'h1' at ViT-B geometry (head dim 64, widths in GEMM tiles): the blocks run token-major with fp16 operands produced once
+        # (TDR_DINO_TOK16=0 keeps them on the channel-major engines)
+        self.tok16 = (self.linear_math == 'h1' and self.D == 64 * heads and self.D % 128 == 0 and self.D <= 1024
+                      and os.environ.get('TDR_DINO_TOK16', '1') == '1')
+        if self.tok16:
+            self.W16 = {k: sd[k].to(device).to(torch.float16).contiguous() for k in sd if k.startswith('blocks.') and k.endswith('.weight')
+                        and k.split('.')[-2] in ('qkv', 'proj', 'fc1', 'fc2')}
 
     def _pack(self, key, w4):
         prev = K.set_pack_plan(None)                      # persistent buffers, not a per-step plan
@@ -92,11 +100,13 @@ class DinoMatcher:
         xp, T = K.patchify(x.contiguous(), self.patch, flat=flat)
         t = K.vit_assemble_(self._linear(xp, 'patch', P['patch_embed.proj.bias']), self.cls, self._pos(rows, cols), T, flat_batch=fb)
         scale = (D // self.heads) ** -0.5
+        if self.tok16 and flat:
+            return self._blocks_tok16(t, B, T, scale), T
         for i in range(self.depth):
             p = f'blocks.{i}.'
             h, _, _ = K.layernorm2d_fwd(t, P[p + 'norm1.weight'], P[p + 'norm1.bias'], LN_EPS)
             qkv = self._linear(h, p + 'attn.qkv', P[p + 'attn.qkv.bias'])
-            a = K.attention_fwd(qkv, self.heads, scale, T + 1, flat_batch=fb)
+            a = K.attention_fwd(qkv, self.heads, scale, T + 1, flat_batch=fb, single_product=self.linear_math == 'h1')
             t = self._linear(a, p + 'attn.proj', P[p + 'attn.proj.bias'], scale=P[p + 'ls1.gamma'], res=t)
             h, _, _ = K.layernorm2d_fwd(t, P[p + 'norm2.weight'], P[p + 'norm2.bias'], LN_EPS)
             h = self._linear(h, p + 'mlp.fc1', P[p + 'mlp.fc1.bias'], relu=2)
@@ -106,6 +116,24 @@ class DinoMatcher:
             LD = t.shape[2] * t.shape[3] // B
             t = t.view(D, B, LD).permute(1, 0, 2).contiguous().view(B, D, LD // 32, 32)
         return t, T
+
+    def _blocks_tok16(self, t, B, T, scale):
+        """the transformer blocks + final norm on csrc/tdr_tok16.hip: t [1, D, B*LD/32, 32] (channel-major, batch-flattened) ->
+        final-norm tokens [B, D, LD/32, 32]"""
+        P, D, W16 = self.P, self.D, self.W16
+        LD = t.shape[2] * t.shape[3] // B
+        x = K.transpose_f32(t.view(1, D, B * LD))[0]                           # residual stream, fp32 [B*LD, D]
+        for i in range(self.depth):
+            p = f'blocks.{i}.'
+            h = K.tok_layernorm(x, P[p + 'norm1.weight'], P[p + 'norm1.bias'], LN_EPS)
+            qkv = K.tok16_gemm(h, W16[p + 'attn.qkv.weight'], P[p + 'attn.qkv.bias'])
+            a = K.tok16_attention(qkv, B, self.heads, scale, T + 1)
+            K.tok16_gemm(a, W16[p + 'attn.proj.weight'], P[p + 'attn.proj.bias'], epi=2, res=x, ls=P[p + 'ls1.gamma'])
+            h = K.tok_layernorm(x, P[p + 'norm2.weight'], P[p + 'norm2.bias'], LN_EPS)
+            h = K.tok16_gemm(h, W16[p + 'mlp.fc1.weight'], P[p + 'mlp.fc1.bias'], epi=1)
+            K.tok16_gemm(h, W16[p + 'mlp.fc2.weight'], P[p + 'mlp.fc2.bias'], epi=2, res=x, ls=P[p + 'ls2.gamma'])
+        f = K.tok_layernorm(x, P['norm.weight'], P['norm.bias'], LN_EPS, out_f16=False)
+        return K.transpose_f32(f.view(B, LD, D)).view(B, D, LD // 32, 32)
 
     @torch.no_grad()
     def match(self, lq, ref):

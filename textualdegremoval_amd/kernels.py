@@ -998,7 +998,7 @@ def vit_assemble_(tok, cls, pos_cm, T, flat_batch=0):
     return tok
 
 
-def attention_fwd(qkv, heads, scale, T1, flat_batch=0):
+def attention_fwd(qkv, heads, scale, T1, flat_batch=0, single_product=False):
     """qkv [B, 3C, LD/32, 32] (or batch-flattened [1, 3C, B*LD/32, 32] with flat_batch = B); attends over the first T1 columns
     of every image"""
     B, C3 = (flat_batch or qkv.shape[0]), qkv.shape[1]
@@ -1007,9 +1007,56 @@ def attention_fwd(qkv, heads, scale, T1, flat_batch=0):
     out = torch.empty(qkv.shape[0], Cc, qkv.shape[2], qkv.shape[3], dtype=torch.float32, device=qkv.device)
     # the frozen ViTs (no gradient flows through this attention): on the fp16 split whenever the dense contractions are
     math = 2 if (MATH in ('hx2', 'h1') and os.environ.get('TDR_ATTN_F32', '0') != '1') else 0
+    if single_product and math == 2 and Cc // heads in (16, 32, 64):
+        math = 3          # plain fp16 products (the DINOv2 matcher: only an arg-max leaves it)
     check(_lib.load().tdr_attention_fwd_math(qkv.data_ptr(), B, Cc, heads, T1, LD, float(scale), math, 1 if flat_batch else 0, out.data_ptr(),
                                              _stream()),
           'tdr_attention_fwd')
+    return out
+
+
+# ---- token-major fp16 pipeline of the frozen DINOv2 matcher (csrc/tdr_tok16.hip) ------------------------------------------
+def transpose_f32(src):
+    """[B, R, C] fp32 -> [B, C, R]"""
+    B, R, Cc = src.shape
+    assert src.is_contiguous() and src.dtype == torch.float32
+    dst = torch.empty(B, Cc, R, dtype=torch.float32, device=src.device)
+    check(_lib.load().tdr_transpose_f32(src.data_ptr(), B, R, Cc, dst.data_ptr(), _stream()), 'tdr_transpose_f32')
+    return dst
+
+
+def tok_layernorm(x, w, b, eps, out_f16=True):
+    """nn.LayerNorm over the rows of x [P, D] (fp32) -> fp16 (a GEMM operand) or fp32 [P, D]"""
+    P, D = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32
+    out = torch.empty(P, D, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
+    check(_lib.load().tdr_tok_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), P, D, float(eps), 1 if out_f16 else 0, out.data_ptr(),
+                                        _stream()), 'tdr_tok_layernorm')
+    return out
+
+
+def tok16_gemm(x16, w16, bias, epi=0, res=None, ls=None):
+    """x16 [P, K] . w16 [N, K]^T (+ bias): epi 0 -> fp16 [P, N]; 1 -> erf-GELU, fp16; 2 -> res [P, N] (fp32) += ls * (. + bias), in place"""
+    P, Kd = x16.shape
+    N = w16.shape[0]
+    assert x16.is_contiguous() and w16.is_contiguous() and x16.dtype == torch.float16 and w16.dtype == torch.float16 and w16.shape[1] == Kd
+    y = None
+    if epi == 2:
+        assert res is not None and res.is_contiguous() and res.dtype == torch.float32 and tuple(res.shape) == (P, N)
+    else:
+        y = torch.empty(P, N, dtype=torch.float16, device=x16.device)
+    check(_lib.load().tdr_tok16_gemm(x16.data_ptr(), w16.data_ptr(), _p(bias), P, N, Kd, int(epi), _p(y), _p(res), _p(ls), _stream()),
+          'tdr_tok16_gemm')
+    return res if epi == 2 else y
+
+
+def tok16_attention(qkv16, B, heads, scale, T1):
+    """qkv16 [B * LD, 3C] fp16 (token-major) -> [B * LD, C] fp16; attends over the first T1 rows of every image"""
+    P, C3 = qkv16.shape
+    assert qkv16.is_contiguous() and qkv16.dtype == torch.float16 and P % B == 0
+    out = torch.empty(P, C3 // 3, dtype=torch.float16, device=qkv16.device)
+    check(_lib.load().tdr_tok16_attention(qkv16.data_ptr(), B, C3 // 3, heads, T1, P // B, float(scale), out.data_ptr(), _stream()),
+          'tdr_tok16_attention')
     return out
 
 
