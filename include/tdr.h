@@ -454,7 +454,8 @@ int tdr_token_match(const float* fl, const float* fr, const float* windows, int 
 /* dst[b][c][r] = src[b][r][c] (contiguous fp32 batches): entering / leaving the channel-major layout of tdr_vit_assemble and
  * tdr_token_match */
 int tdr_transpose_f32(const float* src, int batch, int R, int C, float* dst, void* stream);
-/* nn.LayerNorm(D) over each of the P token rows (D % 4 == 0, D <= 1024); out is fp16 [P][D] if out_f16 else fp32 [P][D] */
+/* nn.LayerNorm(D) over each of the P token rows (D % 4 == 0, D <= 1280); out_f16 0: fp32 [P][D]; 1: fp16 [P][D];
+ * 2: the 2-way split, hi | lo fp16 planes [2][P][D] (hi = fp16(y), lo = fp16(y - hi)) */
 int tdr_tok_layernorm(const float* x, const float* w, const float* b, int64_t P, int D, float eps, int out_f16, void* out,
                       void* stream);
 /* nn.Linear: acc = x16 [P][K] . w16 [N][K]^T in fp32 (N % 128 == 0, K % 64 == 0); bias may be NULL.
@@ -462,6 +463,15 @@ int tdr_tok_layernorm(const float* x, const float* w, const float* b, int64_t P,
  * (LayerScale + residual; ls NULL = 1) */
 int tdr_tok16_gemm(const void* x16, const void* w16, const float* bias, int64_t P, int N, int K, int epi, void* y16, float* res,
                    const float* ls, void* stream);
+/* The same GEMM on 2-way split operands (fp32-faithful: the frozen CLIP encoder of the stage-A trainers,
+ * scripts/train/main_train_i2t_mapping.py:564,726-731, feeds a trained path): x16x2 [2][P][K] and w16x2 [2][N][K] are hi | lo planes,
+ * acc = x_lo w_hi + x_hi w_lo + x_hi w_hi in fp32 (N % 128 == 0, K % 32 == 0, P % 8 == 0); bias may be NULL.
+ * epi 2: out32 [P][N] (in place) += acc + bias;  3: out32 [N][P] = acc + bias (channel-major: the layout of tdr_attention_fwd_math);
+ * epi 4: y16x2 [2][P][N] = split(act(acc + bias)), act 0 none / 2 erf-GELU / 3 quick_gelu (the codes of tdr_conv_forward) */
+int tdr_tok16x2_gemm(const void* x16x2, const void* w16x2, const float* bias, int64_t P, int N, int K, int epi, int act, void* y16x2,
+                     float* out32, void* stream);
+/* fp32 channel-major src [C][P] -> token-major hi | lo planes dst16x2 [2][P][C] */
+int tdr_cm_to_tok16x2(const float* src, int C, int64_t P, void* dst16x2, void* stream);
 /* softmax(q k^T * scale) v per head over the first T rows of each image: qkv16 [B][LD][3C] (q | k | v column blocks, head-major
  * inside each, head dim 64), out16 [B][LD][C]; rows T..LD-1 of out16 are zero */
 int tdr_tok16_attention(const void* qkv16, int B, int C, int heads, int T, int LD, float scale, void* out16, void* stream);

@@ -27,3 +27,17 @@ us = timeit(lambda: K.tok16_attention(qkv, B, 12, 0.125, T1))
 print(f'attention B={B} T={T1}: {us:7.1f} us  {4 * B * 12 * T1 * T1 * 64 / us / 1e6:6.0f} TFLOP/s')
 x = r(P, D); w = r(D); b = r(D)
 print(f'layernorm -> fp16: {timeit(lambda: K.tok_layernorm(x, w, b, 1e-6)):7.1f} us')
+
+# the 2-way split GEMMs of the stage-A CLIP ViT-H/14 encoder (4 images x 288 padded tokens), weights cold (32 distinct layers cycled)
+P, D = 4 * 288, 1280
+L = 8
+for name, N, Kd, epi in (('qkv', 3 * D, D, 3), ('out', D, D, 2), ('fc1', 4 * D, D, 4), ('fc2', D, 4 * D, 2)):
+    x2 = K.split_planes(r(P, Kd))
+    ws = [K.split_planes(r(N, Kd) * 0.03) for _ in range(L)]
+    bias, res = r(N), r(P, N)
+    i = [0]
+    def f():
+        i[0] = (i[0] + 1) % L
+        K.tok16x2_gemm(x2, ws[i[0]], bias, epi=epi, act=2 if epi == 4 else 0, out32=res if epi == 2 else None)
+    us = timeit(f, n=40)
+    print(f'x2 {name:4s} P={P} N={N} K={Kd}: {us:7.1f} us  {2 * P * N * Kd / us / 1e6:6.0f} TFLOP/s (fp32-equivalent)')

@@ -284,6 +284,7 @@ def test_clip_split_k_linears_match_the_single_launch(K):
     sd = IO.synth_clip_params(1024, 2048, 2, 14, 56, seed=9)          # cin 1024 / 2048 -> cout 1024: the split-K rule applies
     x = torch.rand(2, 3, 56, 56, generator=torch.Generator().manual_seed(1)).cuda()
     prev = ClipVisionEncoder.SPLITK
+    os.environ['TDR_CLIP_TOK16'] = '0'                                  # the channel-major engines (the token-major path has its own test)
     try:
         ClipVisionEncoder.SPLITK = 4
         a = ClipVisionEncoder(sd, 'cuda', 16)
@@ -294,9 +295,66 @@ def test_clip_split_k_linears_match_the_single_launch(K):
         yb, _ = b.tokens(x, flat=True)
     finally:
         ClipVisionEncoder.SPLITK = prev
+        del os.environ['TDR_CLIP_TOK16']
     ref = IO.clip_vision_tokens(sd, x.cpu(), 16)
     scale = ref.abs().max().item()
     assert maxdiff(ya, yb) < 1e-5 * scale
     LD = ya.shape[2] * ya.shape[3] // 2
     tm = ya.reshape(1024, 2, LD)[:, :, :T1 + 1].permute(1, 2, 0)
     assert maxdiff(tm, ref) < 1e-4 * max(1.0, scale)
+
+
+def test_tok16x2_kernels_against_torch(K):
+    """csrc/tdr_tok16.hip on 2-way split planes: LayerNorm -> planes, the GEMM with its three epilogues, channel-major -> planes,
+    against fp64 torch on the fp32 values.  fp32-faithful: each operand carries 22 significand bits, so the bar is a few 2^-22 of the
+    accumulated magnitude (sum |x||w|), not fp16 precision."""
+    if K.MATH != 'hx2':
+        pytest.skip('the token-major planes are the hx2 arithmetic')
+    g = torch.Generator().manual_seed(8)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()
+    P, D = 2 * 64 + 24, 1280                                             # a ragged last 64-row tile
+    t, w, b = r(P, D) * 2 + 0.5, r(D), r(D)
+    pl = K.tok_layernorm(t, w, b, 1e-5, planes=True)
+    ref = torch.nn.functional.layer_norm(t.double(), (D,), w.double(), b.double(), 1e-5)
+    assert pl.shape == (2, P, D) and maxdiff(pl[0].double() + pl[1].double(), ref) < 2e-6 * ref.abs().max().item()
+    a = r(96, 72)
+    ap = K.cm_to_tok16x2(a)
+    assert maxdiff(ap[0].double() + ap[1].double(), a.t().double()) < 2 ** -21 * a.abs().max().item()
+    for N, Kd in ((384, 1280), (1280, 160)):
+        x, wt, bias = r(P, Kd), r(N, Kd) * 0.05, r(N)
+        x2, w2 = K.split_planes(x), K.split_planes(wt)
+        acc = x.double() @ wt.double().t() + bias.double()
+        bar = 6 * 2 ** -22 * (x.abs().double() @ wt.abs().double().t()).max().item()
+        assert maxdiff(K.tok16x2_gemm(x2, w2, bias, epi=3), acc.t()) < bar
+        res = r(P, N)
+        assert maxdiff(K.tok16x2_gemm(x2, w2, bias, epi=2, out32=res.clone()), res.double() + acc) < bar + 1e-6
+        for act, f in ((0, lambda v: v), (2, torch.nn.functional.gelu), (3, lambda v: v * torch.sigmoid(1.702 * v))):
+            y = K.tok16x2_gemm(x2, w2, bias, epi=4, act=act)
+            assert maxdiff(y[0].double() + y[1].double(), f(acc)) < 2 * bar + 2 ** -21 * acc.abs().max().item(), act
+        y = K.tok16x2_gemm(x2, w2, None, epi=3)
+        assert maxdiff(y, (acc - bias.double()).t()) < bar
+
+
+@pytest.mark.parametrize('hidden,inter,heads,act', [(1024, 2048, 16, 'quick_gelu'), (1280, 2560, 16, 'gelu')])
+def test_clip_token_major_planes_match_the_channel_major_engines(K, hidden, inter, heads, act):
+    """ClipVisionEncoder.tokens(flat=True) under hx2 at ViT-L / ViT-H widths: blocks on tdr_tok16x2_gemm (operands pre-split into
+    hi | lo fp16 planes, token-major) against the oracle and against the channel-major engines -- one arithmetic, two layouts"""
+    if K.MATH != 'hx2':
+        pytest.skip('the token-major planes are the hx2 arithmetic')
+    from textualdegremoval_amd.clip_vision import ClipVisionEncoder
+    sd = IO.synth_clip_params(hidden, inter, 2, 14, 56, seed=hidden)
+    x = torch.rand(3, 3, 56, 56, generator=torch.Generator().manual_seed(1))
+    os.environ['TDR_CLIP_TOK16'] = '1'                                  # opt-in path (measured neutral on the stage-A step)
+    try:
+        enc = ClipVisionEncoder(sd, 'cuda', heads, act=act)
+    finally:
+        del os.environ['TDR_CLIP_TOK16']
+    assert enc.tok16
+    f, Tn = enc.tokens(x.cuda(), flat=True)
+    c, _ = enc.tokens(x.cuda())                                          # per-image layout: the channel-major engines
+    ref = IO.clip_vision_tokens(sd, x, heads, act=act)
+    scale = ref.abs().max().item()
+    LD = c.shape[2] * c.shape[3]
+    back = f.reshape(hidden, 3, LD).permute(1, 0, 2)[:, :, :Tn + 1]
+    assert maxdiff(back, c.reshape(3, hidden, LD)[:, :, :Tn + 1]) < 2e-5 * scale
+    assert maxdiff(back.permute(0, 2, 1), ref) < 2e-5 * scale

@@ -54,6 +54,23 @@ class ClipVisionEncoder:
             for name in ('mlp.fc1', 'mlp.fc2'):
                 w = sd[p + name + '.weight']
                 self._pack(p + name, w.reshape(w.shape[0], w.shape[1], 1, 1))
+        # Opt-in (TDR_CLIP_TOK16=1): batch-flattened passes under TDR_MATH=hx2 run the blocks token-major on pre-split fp16 planes
+        # (csrc/tdr_tok16.hip, tdr_tok16x2_gemm: the same 2-way split arithmetic, operands split once by their producers and fetched
+        # as 16-byte fragments).  Measured neutral on the stage-A step (ViT-H 25.5 vs 25.0 ms, ViT-L 20.0 vs 20.5 ms, same box): over
+        # ~1 150 token rows both layouts run the Linears at ~140 - 200 fp32-equivalent TFLOP/s, so the channel-major engines with
+        # their split-K narrow Linears stay the default.
+        inter = sd['encoder.layers.0.mlp.fc1.weight'].shape[0]
+        self.tok16 = (K.MATH == 'hx2' and self.D % 128 == 0 and inter % 128 == 0 and self.D <= 1280
+                      and __import__('os').environ.get('TDR_CLIP_TOK16', '0') == '1')
+        if self.tok16:
+            self.W2 = {}
+            for i in range(self.depth):
+                p = f'encoder.layers.{i}.'
+                qkv = torch.cat([sd[p + f'self_attn.{n}_proj.weight'] for n in 'qkv'], dim=0)
+                self.W2[p + 'qkv'] = K.split_planes(qkv.to(device))
+                self.W2[p + 'out'] = K.split_planes(sd[p + 'self_attn.out_proj.weight'].to(device))
+                self.W2[p + 'mlp.fc1'] = K.split_planes(sd[p + 'mlp.fc1.weight'].to(device))
+                self.W2[p + 'mlp.fc2'] = K.split_planes(sd[p + 'mlp.fc2.weight'].to(device))
 
     # Split-K for the narrow-output Linears (attention out-projection, fc2): over the ~1 150 tokens of a 4-image batch they are a
     # single round of ~180 workgroups walking 20 - 80 serial K stages with cold weights (110 / 165 us per launch for ~10 us of
@@ -100,8 +117,10 @@ class ClipVisionEncoder:
             raise ValueError(f'CLIP encoder built for {self.pos.shape[1] - 1} patches, input gives {T} '
                              '(position embeddings are not interpolated, transformers CLIPVisionEmbeddings)')
         t = K.vit_assemble_(self._linear(xp, 'patch', None), self.cls, self.pos, T, flat_batch=fb)
-        t, _, _ = K.layernorm2d_fwd(t, P['pre_layrnorm.weight'], P['pre_layrnorm.bias'], self.eps)
         scale = (self.D // self.heads) ** -0.5
+        if self.tok16 and flat:
+            return self._blocks_tok16(t, B, T, scale), T
+        t, _, _ = K.layernorm2d_fwd(t, P['pre_layrnorm.weight'], P['pre_layrnorm.bias'], self.eps)
         for i in range(self.depth):
             p = f'encoder.layers.{i}.'
             h, _, _ = K.layernorm2d_fwd(t, P[p + 'layer_norm1.weight'], P[p + 'layer_norm1.bias'], self.eps)
@@ -112,6 +131,24 @@ class ClipVisionEncoder:
             h = self._linear(h, p + 'mlp.fc1', P[p + 'mlp.fc1.bias'], relu=self.act)
             t = self._linear(h, p + 'mlp.fc2', P[p + 'mlp.fc2.bias'], res=t)
         return t, T
+
+    def _blocks_tok16(self, t, B, T, scale):
+        """pre-LayerNorm + the encoder layers on csrc/tdr_tok16.hip: t [1, D, B*LD/32, 32] (embeddings, channel-major, batch-flattened)
+        -> last hidden state in the same layout.  Residual stream fp32 token-major [B*LD, D]; GEMM operands travel as hi | lo planes;
+        the attention stays on tdr_attention_fwd_math (channel-major fp32 q/k/v written by the qkv GEMM's epilogue)."""
+        P, D, W2 = self.P, self.D, self.W2
+        Pn = t.shape[2] * t.shape[3]
+        x = K.tok_layernorm(K.transpose_f32(t.view(1, D, Pn))[0], P['pre_layrnorm.weight'], P['pre_layrnorm.bias'], self.eps, out_f16=False)
+        for i in range(self.depth):
+            p = f'encoder.layers.{i}.'
+            h = K.tok_layernorm(x, P[p + 'layer_norm1.weight'], P[p + 'layer_norm1.bias'], self.eps, planes=True)
+            qkv = K.tok16x2_gemm(h, W2[p + 'qkv'], P[p + 'qkv.bias'], epi=3)
+            a = K.attention_fwd(qkv.view(1, 3 * D, Pn // 32, 32), self.heads, scale, T + 1, flat_batch=B)
+            K.tok16x2_gemm(K.cm_to_tok16x2(a.view(D, Pn)), W2[p + 'out'], P[p + 'out.bias'], epi=2, out32=x)
+            h = K.tok_layernorm(x, P[p + 'layer_norm2.weight'], P[p + 'layer_norm2.bias'], self.eps, planes=True)
+            h = K.tok16x2_gemm(h, W2[p + 'mlp.fc1'], P[p + 'mlp.fc1.bias'], epi=4, act=self.act)
+            K.tok16x2_gemm(h, W2[p + 'mlp.fc2'], P[p + 'mlp.fc2.bias'], epi=2, out32=x)
+        return K.transpose_f32(x.view(1, Pn, D)).view(1, D, Pn // 32, 32)
 
     @torch.no_grad()
     def encode(self, image, size=224, flat=False):

@@ -16,6 +16,7 @@
 //                     tiles; K staged as is, V transposed on its way into LDS; softmax in fp32 on exp2 with the scale folded in
 // tok_ln_kernel     : nn.LayerNorm over D of a token row (one wave per token), fp16 or fp32 output
 // transpose kernel  : [R][C] <-> [C][R] fp32 (entering / leaving the channel-major world of the patch embedding and of tdr_token_match)
+#include <utility>
 #include "tdr_common.h"
 #include "tdr_erf.h"
 #include "../../include/tdr.h"
@@ -50,7 +51,7 @@ extern "C" int tdr_transpose_f32(const float* src, int batch, int R, int C, floa
 }
 
 // ---- LayerNorm over the row of a token ---------------------------------------------------------------------------------
-template <bool OUT16>
+template <int OUT>         // 0: fp32 | 1: fp16 | 2: hi | lo fp16 planes (2-way split)
 __global__ __launch_bounds__(256) void tok_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                     int D, long P, float eps, void* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -58,10 +59,10 @@ __global__ __launch_bounds__(256) void tok_ln_kernel(const float* __restrict__ x
     if (tok >= P) return;
     const int n4 = D >> 2;
     const float4* row = reinterpret_cast<const float4*>(x + tok * D);
-    float4 v[4];                                            // D <= 1024
+    float4 v[5];                                            // D <= 1280
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         const int c = lane + 64 * i;
         v[i] = c < n4 ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -69,22 +70,26 @@ __global__ __launch_bounds__(256) void tok_ln_kernel(const float* __restrict__ x
     const float mean = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (lane + 64 * i < n4) {
             const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
             q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
         }
     const float rstd = rsqrtf(wave_sum(q) / D + eps);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         const int c = lane + 64 * i;
         if (c >= n4) continue;
         const float4 g = reinterpret_cast<const float4*>(w)[c], h = reinterpret_cast<const float4*>(b)[c];
         const float y0 = (v[i].x - mean) * rstd * g.x + h.x, y1 = (v[i].y - mean) * rstd * g.y + h.y;
         const float y2 = (v[i].z - mean) * rstd * g.z + h.z, y3 = (v[i].w - mean) * rstd * g.w + h.w;
-        if constexpr (OUT16) {
-            vh4 o = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+        if constexpr (OUT >= 1) {
+            const vh4 o = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
             reinterpret_cast<vh4*>(reinterpret_cast<_Float16*>(out) + tok * D)[c] = o;
+            if constexpr (OUT == 2) {
+                const vh4 l = {(_Float16)(y0 - (float)o[0]), (_Float16)(y1 - (float)o[1]), (_Float16)(y2 - (float)o[2]), (_Float16)(y3 - (float)o[3])};
+                reinterpret_cast<vh4*>(reinterpret_cast<_Float16*>(out) + (P + tok) * D)[c] = l;
+            }
         } else {
             reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + tok * D)[c] = make_float4(y0, y1, y2, y3);
         }
@@ -94,34 +99,72 @@ __global__ __launch_bounds__(256) void tok_ln_kernel(const float* __restrict__ x
 extern "C" int tdr_tok_layernorm(const float* x, const float* w, const float* b, int64_t P, int D, float eps, int out_f16, void* out,
                                  void* stream) {
     TDR_REQUIRE(x && w && b && out && P > 0, "tdr_tok_layernorm: bad argument");
-    TDR_REQUIRE(D % 4 == 0 && D <= 1024, "tdr_tok_layernorm: D must be a multiple of 4, at most 1024 (got %d)", D);
+    TDR_REQUIRE(D % 4 == 0 && D <= 1280, "tdr_tok_layernorm: D must be a multiple of 4, at most 1280 (got %d)", D);
+    TDR_REQUIRE(out_f16 >= 0 && out_f16 <= 2, "tdr_tok_layernorm: output mode %d", out_f16);
     const dim3 grid(tdr_cdiv(P, 4));
-    if (out_f16) hipLaunchKernelGGL(tok_ln_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
-    else hipLaunchKernelGGL(tok_ln_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
+    if (out_f16 == 2) hipLaunchKernelGGL(tok_ln_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
+    else if (out_f16) hipLaunchKernelGGL(tok_ln_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
+    else hipLaunchKernelGGL(tok_ln_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
     TDR_LAUNCH_CHECK("tok_layernorm");
     return TDR_OK;
 }
 
 // ---- fp16 GEMM ---------------------------------------------------------------------------------------------------------
+// Two instances of one kernel:
+//   <BM 128, BK 64, X2 false>  plain fp16 operands (the DINOv2 matcher: 'h1' arithmetic), 27 000 token rows: 128 x 128 tiles
+//   <BM  64, BK 32, X2 true >  2-way split operands (hi / lo fp16 planes; the three products lo*hi + hi*lo + hi*hi per fragment
+//                              pair, fp32-faithful -- the frozen CLIP encoder of the stage-A trainers feeds a trained path):
+//                              ~1 150 token rows, so 64 x 128 tiles (180 - 720 workgroups) and 32-deep stages (61 KB of LDS,
+//                              two workgroups per CU)
 namespace {
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int OS = BK + 8;                 // halves per operand row in LDS: 144 B -> the 16 lanes of a ds_read_b128 pass hit 64 distinct banks
-constexpr int CS = BN + 8;                 // floats per C row in LDS
-constexpr int GEMM_LDS = 2 * (BM + BN) * OS * 2;            // 73 728 B: two stages of both operands; the C tile (69 632 B) reuses it
-static_assert(BM * CS * 4 <= GEMM_LDS, "C tile must fit the operand buffers");
+constexpr int BN = 128;
+
+// N 16-byte registers with compile-time indexing
+template <int N>
+struct RegSet {
+    uint4 head;
+    RegSet<N - 1> tail;
+    template <int I>
+    __device__ __forceinline__ uint4& at() {
+        if constexpr (I == 0) return head;
+        else return tail.template at<I - 1>();
+    }
+};
+template <>
+struct RegSet<0> {};
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 struct TokGemmArgs {
-    const _Float16* x; const _Float16* w; const float* bias; const float* ls;
+    const _Float16* x; const _Float16* w; const float* bias; const float* ls;     // X2: the lo planes follow at x + P*K, w + N*K
     long P; int N, K, nt;
-    _Float16* y; float* res;
+    _Float16* y; float* res;                                                      // y: fp16 [P][N] (X2 + EPI_PLANES: hi | lo); res: fp32
 };
+enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_RES = 2, EPI_CM_F32 = 3, EPI_ACT_PLANES = 4 };
 }  // namespace
 
-template <int EPI>      // 0: y = acc + bias; 1: y = gelu(acc + bias); 2: res += ls * (acc + bias)
-__global__ __launch_bounds__(256, 2) void tok_gemm_kernel(TokGemmArgs a) {
+// EPI_F16: y = acc + bias | EPI_GELU_F16: y = erf-GELU(acc + bias) | EPI_RES: res += ls * (acc + bias)
+// EPI_CM_F32: res[n][P] = acc + bias, fp32 channel-major (the input layout of tdr_attention_fwd_math)
+// EPI_ACT_PLANES: y = split(ACT(acc + bias)) as hi | lo planes; ACT 0 none, 2 erf-GELU, 3 quick_gelu
+template <int EPI, int BM, int BK, bool X2, int ACT, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
+    constexpr int OS = BK + 8;                 // halves per operand row in LDS (144 B / 80 B): ds_read_b128 passes without bank conflicts
+    constexpr int CS = EPI == EPI_CM_F32 ? BN + 5 : BN + 8;                      // floats per C row in LDS
+    constexpr int NP = X2 ? 2 : 1;             // operand planes
+    constexpr int CPR = BK / 8, RPP = 256 / CPR, NA = BM / RPP, NB = BN / RPP;   // 16-byte chunks per row, rows per staging pass
+    constexpr int MI = BM / 64;                // 32-row accumulator tiles per wave (waves 2 x 2, wave tile BM/2 x 64)
+    constexpr int EP = BM * CS * 4 <= 2 * (BM + BN) * OS * 2 * NP ? 1 : 2;       // epilogue passes (the C tile reuses the operand buffers)
+    constexpr int ER = BM / EP;                                                  // token rows per pass
+    static_assert(ER * CS * 4 <= 2 * (BM + BN) * OS * 2 * NP && (EP == 1 || BM == 128), "C tile must fit the operand buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char tok_smem[];
-    _Float16* sA = reinterpret_cast<_Float16*>(tok_smem);        // [2][BM][OS]
-    _Float16* sB = sA + 2 * BM * OS;                             // [2][BN][OS]
+    _Float16* sA = reinterpret_cast<_Float16*>(tok_smem);        // [2 stages][NP][BM][OS]
+    _Float16* sB = sA + 2 * NP * BM * OS;                        // [2 stages][NP][BN][OS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
     // consecutive tiles (same token rows, neighbouring output columns) on ONE XCD: the X rows they share stay in that L2
     int id = blockIdx.x;
@@ -131,143 +174,256 @@ __global__ __launch_bounds__(256, 2) void tok_gemm_kernel(TokGemmArgs a) {
     const long m0 = (long)tm * BM;
     const int n0 = tn * BN, K = a.K;
     const int wm = wave >> 1, wn = wave & 1;
-    const int srow = tid >> 3, sc8 = (tid & 7) * 8;              // staging: rows srow + 32 i, 8 halves at sc8
-    const _Float16* gx[4];
-    const _Float16* gw[4];
+    const int srow = tid / CPR, sc8 = (tid % CPR) * 8;           // staging: rows srow + RPP i, 8 halves at sc8
+    const long xlo = a.P * K, wlo = (long)a.N * K;               // plane strides
+    const _Float16* gx[NA];
+    const _Float16* gw[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long m = m0 + srow + 32 * i;
+    for (int i = 0; i < NA; ++i) {
+        const long m = m0 + srow + RPP * i;
         gx[i] = a.x + (m < a.P ? m : a.P - 1) * K + sc8;
-        gw[i] = a.w + (long)(n0 + srow + 32 * i) * K + sc8;
     }
-    // global -> registers two stages ahead, registers -> LDS one stage ahead: with two waves per SIMD a load has ~2 stages of MFMA
-    // time (> 1000 cycles) to land; one stage ahead left the matrix pipe waiting on L2 every iteration
-    struct Stage { uint4 a0, a1, a2, a3, b0, b1, b2, b3; };            // named members: the sets must stay in registers
+#pragma unroll
+    for (int i = 0; i < NB; ++i) gw[i] = a.w + (long)(n0 + srow + RPP * i) * K + sc8;
+    // the two register sets of the prefetch: named members walked by compile-time indices (as arrays -- local, in a struct, or
+    // handed to a lambda by reference -- the compiler demoted them to scratch memory)
+    constexpr int NR = NP * (NA + NB);
     auto gload = [&](int k0) {
-        Stage g;
-        g.a0 = *reinterpret_cast<const uint4*>(gx[0] + k0); g.b0 = *reinterpret_cast<const uint4*>(gw[0] + k0);
-        g.a1 = *reinterpret_cast<const uint4*>(gx[1] + k0); g.b1 = *reinterpret_cast<const uint4*>(gw[1] + k0);
-        g.a2 = *reinterpret_cast<const uint4*>(gx[2] + k0); g.b2 = *reinterpret_cast<const uint4*>(gw[2] + k0);
-        g.a3 = *reinterpret_cast<const uint4*>(gx[3] + k0); g.b3 = *reinterpret_cast<const uint4*>(gw[3] + k0);
+        RegSet<NR> g;
+        static_for<NR>([&](auto q) {
+            constexpr int Q = decltype(q)::value, pl = Q / (NA + NB), i = Q % (NA + NB);
+            if constexpr (i < NA) g.template at<Q>() = *reinterpret_cast<const uint4*>(gx[i] + pl * xlo + k0);
+            else g.template at<Q>() = *reinterpret_cast<const uint4*>(gw[i - NA] + pl * wlo + k0);
+        });
         return g;
     };
-    auto sstore = [&](const Stage& g, int buf) {
-        _Float16* pa = sA + (buf * BM + srow) * OS + sc8;
-        _Float16* pb = sB + (buf * BN + srow) * OS + sc8;
-        *reinterpret_cast<uint4*>(pa) = g.a0;           *reinterpret_cast<uint4*>(pb) = g.b0;
-        *reinterpret_cast<uint4*>(pa + 32 * OS) = g.a1; *reinterpret_cast<uint4*>(pb + 32 * OS) = g.b1;
-        *reinterpret_cast<uint4*>(pa + 64 * OS) = g.a2; *reinterpret_cast<uint4*>(pb + 64 * OS) = g.b2;
-        *reinterpret_cast<uint4*>(pa + 96 * OS) = g.a3; *reinterpret_cast<uint4*>(pb + 96 * OS) = g.b3;
+    auto sstore = [&](RegSet<NR> g, int buf) {
+        static_for<NR>([&](auto q) {
+            constexpr int Q = decltype(q)::value, pl = Q / (NA + NB), i = Q % (NA + NB);
+            if constexpr (i < NA) *reinterpret_cast<uint4*>(sA + ((buf * NP + pl) * BM + srow + RPP * i) * OS + sc8) = g.template at<Q>();
+            else *reinterpret_cast<uint4*>(sB + ((buf * NP + pl) * BN + srow + RPP * (i - NA)) * OS + sc8) = g.template at<Q>();
+        });
     };
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     auto compute = [&](int buf) {
-        const _Float16* pa = sA + (buf * BM + wm * 64 + j) * OS + kk * 8;
-        const _Float16* pb = sB + (buf * BN + wn * 64 + j) * OS + kk * 8;
+        const _Float16* pa = sA + (buf * NP * BM + wm * (BM / 2) + j) * OS + kk * 8;
+        const _Float16* pb = sB + (buf * NP * BN + wn * 64 + j) * OS + kk * 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            const vh8 fa0 = *reinterpret_cast<const vh8*>(pa + ks * 16), fa1 = *reinterpret_cast<const vh8*>(pa + 32 * OS + ks * 16);
-            const vh8 fb0 = *reinterpret_cast<const vh8*>(pb + ks * 16), fb1 = *reinterpret_cast<const vh8*>(pb + 32 * OS + ks * 16);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb1, acc[1][1], 0, 0, 0);
+            vh8 fa[NP][MI], fb[NP][2];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[pl][mi] = *reinterpret_cast<const vh8*>(pa + (pl * BM + mi * 32) * OS + ks * 16);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) fb[pl][ni] = *reinterpret_cast<const vh8*>(pb + (pl * BN + ni * 32) * OS + ks * 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (X2) {                     // small cross terms first
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][mi], fb[1][ni], acc[mi][ni], 0, 0, 0);
+                    }
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
+                }
         }
     };
     const int nk = K / BK;
     // Every workgroup starts its K loop at a different stage and wraps around: the token rows of a tile lie K * 2 bytes apart
     // (1536 B / 6144 B), so workgroups marching through K in step asked 2 - 8 of an XCD's 16 L2 channels for everything at once
-    // (fc2 ran at 2.2 TB/s of L2 traffic, 141 TFLOP/s).  The loads are unconditional (a wrapped prefetch past the last stage is
-    // simply not used), which also lets the compiler count them: the LDS store of stage s + 1 waits for its own 8 loads only.
+    // (fc2 ran at 2.2 TB/s of L2 traffic, 141 TFLOP/s).  Global loads run two stages ahead of the MFMAs (registers), LDS stores one
+    // stage ahead; the loads are unconditional (a wrapped prefetch past the last stage is simply not used), which lets the compiler
+    // count them: the LDS store of stage s + 1 waits for its own loads only, not for those of stage s + 2.
     int kn = (int)((tm * 5 + tn * 3) % nk) * BK;
     auto next = [&]() { const int k = kn; kn += BK; kn = kn >= K ? kn - K : kn; return k; };
-    Stage g0 = gload(next());
+    RegSet<NR> g0 = gload(next());
     sstore(g0, 0);
-    Stage g1 = gload(next());
+    RegSet<NR> g1 = gload(next());
     // stage s travels in register set s & 1 and lives in LDS buffer s & 1
     for (int kt = 0; kt < nk; kt += 2) {
         __syncthreads();                                    // stage kt is in LDS; every wave is done reading stage kt - 1
         g0 = gload(next());
-        asm volatile("" ::: "memory");                      // the scheduler otherwise sinks these loads below the MFMA block
+        __builtin_amdgcn_sched_barrier(0);                  // the scheduler otherwise sinks these loads below the MFMA block
         compute(0);
         sstore(g1, 1);
         if (kt + 1 >= nk) break;
         __syncthreads();
         g1 = gload(next());
-        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         compute(1);
         sstore(g0, 0);
     }
     // C tile through LDS: accumulator rows are tokens (r & 3) + 8 (r >> 2) + 4 kk, its column is output channel j
-    __syncthreads();
     float* sC = reinterpret_cast<float*>(tok_smem);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int ep = 0; ep < EP; ++ep) {
+        __syncthreads();
+        if (EP == 1 || wm == ep) {
+            const int rbase = EP == 1 ? wm * (BM / 2) : 0;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sC[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CS + wn * 64 + ni * 32 + j] = acc[mi][ni][r];
-    __syncthreads();
-    const int c8 = (tid & 15) * 8, er = tid >> 4;          // 8 consecutive output channels of rows er + 16 i
-    float bias[8], ls[8];
+                for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bias[e] = a.bias ? a.bias[n0 + c8 + e] : 0.f;
-        ls[e] = (EPI == 2 && a.ls) ? a.ls[n0 + c8 + e] : 1.f;
-    }
-#pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
-        const int row = er + 16 * i;
-        const long m = m0 + row;
-        if (m >= a.P) continue;
-        const float4 v0 = *reinterpret_cast<const float4*>(sC + row * CS + c8), v1 = *reinterpret_cast<const float4*>(sC + row * CS + c8 + 4);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] += bias[e];
-            if constexpr (EPI == 1) v[e] = 0.5f * v[e] * (1.0f + erf_1ulp(v[e] * 0.70710678118654752f));
+                    for (int r = 0; r < 16; ++r)
+                        sC[(rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CS + wn * 64 + ni * 32 + j] = acc[mi][ni][r];
         }
-        if constexpr (EPI == 2) {
-            float4* rp = reinterpret_cast<float4*>(a.res + m * a.N + n0 + c8);
-            float4 r0 = rp[0], r1 = rp[1];
-            r0.x += ls[0] * v[0]; r0.y += ls[1] * v[1]; r0.z += ls[2] * v[2]; r0.w += ls[3] * v[3];
-            r1.x += ls[4] * v[4]; r1.y += ls[5] * v[5]; r1.z += ls[6] * v[6]; r1.w += ls[7] * v[7];
-            rp[0] = r0;
-            rp[1] = r1;
-        } else {
-            vh8 o;
+        __syncthreads();
+        const long mb = m0 + ep * ER;
+        if constexpr (EPI == EPI_CM_F32) {
+            // 8 consecutive tokens of one output channel per thread; lanes walk the token groups first: 32-byte pieces of one output
+            // row side by side, LDS reads without bank conflicts (CS = 133)
+            constexpr int TG = ER / 8, CPP = 256 / TG;
+            const int tg = tid % TG, c0 = tid / TG;
+            const long m = mb + 8 * tg;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-            *reinterpret_cast<vh8*>(a.y + m * a.N + n0 + c8) = o;
+            for (int i = 0; i < BN / CPP; ++i) {
+                const int c = c0 + CPP * i;
+                if (m >= a.P) continue;
+                const float bv = a.bias ? a.bias[n0 + c] : 0.f;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sC[(8 * tg + e) * CS + c] + bv;
+                float4* op = reinterpret_cast<float4*>(a.res + (long)(n0 + c) * a.P + m);
+                op[0] = make_float4(v[0], v[1], v[2], v[3]);
+                op[1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        } else {
+            const int c8 = (tid & 15) * 8, er = tid >> 4;          // 8 consecutive output channels of rows er + 16 i
+            float bias[8], ls[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bias[e] = a.bias ? a.bias[n0 + c8 + e] : 0.f;
+                ls[e] = (EPI == EPI_RES && a.ls) ? a.ls[n0 + c8 + e] : 1.f;
+            }
+#pragma unroll
+            for (int i = 0; i < ER / 16; ++i) {
+                const int row = er + 16 * i;
+                const long m = mb + row;
+                if (m >= a.P) continue;
+                const float4 v0 = *reinterpret_cast<const float4*>(sC + row * CS + c8), v1 = *reinterpret_cast<const float4*>(sC + row * CS + c8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] += bias[e];
+                    if constexpr (EPI == EPI_GELU_F16 || (EPI == EPI_ACT_PLANES && ACT == 2)) v[e] = 0.5f * v[e] * (1.0f + erf_1ulp(v[e] * 0.70710678118654752f));
+                    if constexpr (EPI == EPI_ACT_PLANES && ACT == 3) v[e] = v[e] / (1.f + expf(-1.702f * v[e]));
+                }
+                if constexpr (EPI == EPI_RES) {
+                    float4* rp = reinterpret_cast<float4*>(a.res + m * a.N + n0 + c8);
+                    float4 r0 = rp[0], r1 = rp[1];
+                    r0.x += ls[0] * v[0]; r0.y += ls[1] * v[1]; r0.z += ls[2] * v[2]; r0.w += ls[3] * v[3];
+                    r1.x += ls[4] * v[4]; r1.y += ls[5] * v[5]; r1.z += ls[6] * v[6]; r1.w += ls[7] * v[7];
+                    rp[0] = r0;
+                    rp[1] = r1;
+                } else {
+                    vh8 o, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        o[e] = (_Float16)v[e];
+                        lo[e] = (_Float16)(v[e] - (float)o[e]);
+                    }
+                    *reinterpret_cast<vh8*>(a.y + m * a.N + n0 + c8) = o;
+                    if constexpr (EPI == EPI_ACT_PLANES) *reinterpret_cast<vh8*>(a.y + (a.P + m) * a.N + n0 + c8) = lo;
+                }
+            }
         }
     }
 }
 
+namespace {
+template <int EPI, int BM, int BK, bool X2, int ACT, int OCC = 2>
+int launch_tok_gemm(const TokGemmArgs& a, hipStream_t st) {
+    constexpr int lds = 2 * (BM + BN) * (BK + 8) * 2 * (X2 ? 2 : 1);
+    auto kern = tok_gemm_kernel<EPI, BM, BK, X2, ACT, OCC>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tdr_cdiv(a.P, BM) * a.nt), dim3(256), lds, st, a);
+    TDR_LAUNCH_CHECK("tok16_gemm");
+    return TDR_OK;
+}
+}  // namespace
+
 extern "C" int tdr_tok16_gemm(const void* x16, const void* w16, const float* bias, int64_t P, int N, int K, int epi, void* y16,
                               float* res, const float* ls, void* stream) {
     TDR_REQUIRE(x16 && w16 && P > 0 && N > 0 && K > 0, "tdr_tok16_gemm: bad argument");
-    TDR_REQUIRE(N % BN == 0 && K % BK == 0, "tdr_tok16_gemm: N must be a multiple of %d and K of %d (got %d, %d)", BN, BK, N, K);
+    TDR_REQUIRE(N % BN == 0 && K % 64 == 0, "tdr_tok16_gemm: N must be a multiple of %d and K of 64 (got %d, %d)", BN, N, K);
     TDR_REQUIRE(epi == 2 ? res != nullptr : (y16 != nullptr && (epi == 0 || epi == 1)), "tdr_tok16_gemm: epilogue %d lacks its output", epi);
     TokGemmArgs a{(const _Float16*)x16, (const _Float16*)w16, bias, ls, (long)P, N, K, N / BN, (_Float16*)y16, res};
-    const dim3 grid(tdr_cdiv(P, BM) * (N / BN));
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_gemm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_gemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_gemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        attr = true;
-    }
     hipStream_t st = (hipStream_t)stream;
-    if (epi == 0) hipLaunchKernelGGL(tok_gemm_kernel<0>, grid, dim3(256), GEMM_LDS, st, a);
-    else if (epi == 1) hipLaunchKernelGGL(tok_gemm_kernel<1>, grid, dim3(256), GEMM_LDS, st, a);
-    else hipLaunchKernelGGL(tok_gemm_kernel<2>, grid, dim3(256), GEMM_LDS, st, a);
-    TDR_LAUNCH_CHECK("tok16_gemm");
+    if (epi == 0) return launch_tok_gemm<EPI_F16, 128, 64, false, 0>(a, st);
+    if (epi == 1) return launch_tok_gemm<EPI_GELU_F16, 128, 64, false, 0>(a, st);
+    return launch_tok_gemm<EPI_RES, 128, 64, false, 0>(a, st);
+}
+
+extern "C" int tdr_tok16x2_gemm(const void* x16x2, const void* w16x2, const float* bias, int64_t P, int N, int K, int epi, int act,
+                                void* y16x2, float* out32, void* stream) {
+    TDR_REQUIRE(x16x2 && w16x2 && P > 0 && N > 0 && K > 0, "tdr_tok16x2_gemm: bad argument");
+    TDR_REQUIRE(N % BN == 0 && K % 32 == 0 && P % 8 == 0, "tdr_tok16x2_gemm: N %% %d, K %% 32, P %% 8 must be 0 (got %d, %d, %lld)", BN, N, K,
+                (long long)P);
+    TDR_REQUIRE(epi == 4 ? (y16x2 != nullptr && (act == 0 || act == 2 || act == 3)) : ((epi == 2 || epi == 3) && out32 != nullptr),
+                "tdr_tok16x2_gemm: epilogue %d (act %d) lacks its output", epi, act);
+    TokGemmArgs a{(const _Float16*)x16x2, (const _Float16*)w16x2, bias, nullptr, (long)P, N, K, N / BN, (_Float16*)y16x2, out32};
+    hipStream_t st = (hipStream_t)stream;
+    // ~1 150 token rows: (a) the wide Linears (q/k/v, fc1: > 512 tiles of 64 rows) take 128-row tiles -- one round of 270 - 360
+    // workgroups, two per CU (2 x 80 KB of LDS), and 2/3 of the L2 traffic of 64-row tiles, which ran them at 7 TB/s of operand
+    // re-reads; (b) the narrow ones (out-projection, fc2: 180 tiles) are a single partial round whose time is the serial chain of K
+    // stages behind cold weights (~0.7 us per stage at two stages of prefetch): 64-deep stages halve the chain.
+    const bool wide = (long)tdr_cdiv(P, 64) * (N / BN) > 512;
+    const int cfg = wide ? 0 : (K % 64 == 0 ? 1 : 2);
+#define TOK_X2(EPI_, ACT_)                                                               \
+    (cfg == 0 ? launch_tok_gemm<EPI_, 128, 32, true, ACT_>(a, st)                        \
+              : cfg == 1 ? launch_tok_gemm<EPI_, 64, 64, true, ACT_>(a, st) : launch_tok_gemm<EPI_, 64, 32, true, ACT_>(a, st))
+    if (epi == 2) return TOK_X2(EPI_RES, 0);
+    if (epi == 3) return TOK_X2(EPI_CM_F32, 0);
+    if (act == 2) return TOK_X2(EPI_ACT_PLANES, 2);
+    if (act == 3) return TOK_X2(EPI_ACT_PLANES, 3);
+    return TOK_X2(EPI_ACT_PLANES, 0);
+#undef TOK_X2
+}
+
+// ---- 2-way split planes: producers ----------------------------------------------------------------------------------------
+// fp32 channel-major [C][P] (the attention output) -> token-major hi | lo fp16 planes [2][P][C]
+__global__ __launch_bounds__(256) void cm_to_planes_kernel(const float* __restrict__ src, int C, long P, _Float16* __restrict__ dst) {
+    __shared__ float t[32][33];
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i;
+        const long pp = p0 + tx;
+        t[ty + 8 * i][tx] = (c < C && pp < P) ? src[(long)c * P + pp] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long pp = p0 + ty + 8 * i;
+        const int c = c0 + tx;
+        if (pp < P && c < C) {
+            const float v = t[tx][ty + 8 * i];
+            const _Float16 h = (_Float16)v;
+            dst[pp * C + c] = h;
+            dst[(P + pp) * C + c] = (_Float16)(v - (float)h);
+        }
+    }
+}
+
+extern "C" int tdr_cm_to_tok16x2(const float* src, int C, int64_t P, void* dst16x2, void* stream) {
+    TDR_REQUIRE(src && dst16x2 && C > 0 && P > 0, "tdr_cm_to_tok16x2: bad argument");
+    hipLaunchKernelGGL(cm_to_planes_kernel, dim3(tdr_cdiv(P, 32), tdr_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, src, C, (long)P,
+                       (_Float16*)dst16x2);
+    TDR_LAUNCH_CHECK("cm_to_tok16x2");
     return TDR_OK;
 }
 
@@ -305,25 +461,22 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(TokAttnArgs a) {
     }
     // staging: 64 keys x 8 chunks of 8 halves, K and V: two chunks of each per thread
     const int skey = tid >> 3, sc8 = (tid & 7) * 8;
-    uint4 rk[2], rv[2];
+    struct KV { uint4 k0, k1, v0, v1; };                    // (named members, returned by value: arrays went to scratch memory)
     auto gload = [&](int key0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = key0 + skey + 32 * i;
-            const _Float16* p = base + (long)(key < LD ? key : LD - 1) * C3 + a.C + sc8;
-            rk[i] = *reinterpret_cast<const uint4*>(p);
-            rv[i] = *reinterpret_cast<const uint4*>(p + a.C);
-        }
+        KV g;
+        const int ka = key0 + skey, kb = ka + 32;
+        const _Float16* pa = base + (long)(ka < LD ? ka : LD - 1) * C3 + a.C + sc8;
+        const _Float16* pb = base + (long)(kb < LD ? kb : LD - 1) * C3 + a.C + sc8;
+        g.k0 = *reinterpret_cast<const uint4*>(pa); g.v0 = *reinterpret_cast<const uint4*>(pa + a.C);
+        g.k1 = *reinterpret_cast<const uint4*>(pb); g.v1 = *reinterpret_cast<const uint4*>(pb + a.C);
+        return g;
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](KV g, int buf) {
+        *reinterpret_cast<uint4*>(&sK[buf][skey][sc8]) = g.k0;
+        *reinterpret_cast<uint4*>(&sK[buf][skey + 32][sc8]) = g.k1;
+        const vh8 v0 = __builtin_bit_cast(vh8, g.v0), v1 = __builtin_bit_cast(vh8, g.v1);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = skey + 32 * i;
-            *reinterpret_cast<uint4*>(&sK[buf][key][sc8]) = rk[i];
-            const vh8 v = __builtin_bit_cast(vh8, rv[i]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sV[buf][sc8 + e][key] = v[e];
-        }
+        for (int e = 0; e < 8; ++e) { sV[buf][sc8 + e][skey] = v0[e]; sV[buf][sc8 + e][skey + 32] = v1[e]; }
     };
     f32x16 o[2][2];
 #pragma unroll
@@ -334,13 +487,13 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(TokAttnArgs a) {
             for (int r = 0; r < 16; ++r) o[qt][dt][r] = 0.f;
     float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
     const float c = a.c;
-    gload(0);
-    sstore(0);
+    KV g = gload(0);
+    sstore(g, 0);
     const int ntile = (T + KT - 1) / KT;
     for (int t = 0; t < ntile; ++t) {
         const int key0 = t * KT, buf = t & 1;
         __syncthreads();
-        if (t + 1 < ntile) gload(key0 + KT);
+        if (t + 1 < ntile) g = gload(key0 + KT);
         if (active) {
             f32x16 st[2][2];
 #pragma unroll
@@ -403,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(TokAttnArgs a) {
                     o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[1][s], o[1][dt], 0, 0, 0);
                 }
         }
-        if (t + 1 < ntile) sstore(buf ^ 1);
+        if (t + 1 < ntile) sstore(g, buf ^ 1);
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {

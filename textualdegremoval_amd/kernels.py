@@ -1025,13 +1025,49 @@ def transpose_f32(src):
     return dst
 
 
-def tok_layernorm(x, w, b, eps, out_f16=True):
-    """nn.LayerNorm over the rows of x [P, D] (fp32) -> fp16 (a GEMM operand) or fp32 [P, D]"""
+def tok_layernorm(x, w, b, eps, out_f16=True, planes=False):
+    """nn.LayerNorm over the rows of x [P, D] (fp32) -> fp16 (a GEMM operand), fp32 [P, D], or (planes) the 2-way split [2, P, D] fp16"""
     P, D = x.shape
     assert x.is_contiguous() and x.dtype == torch.float32
-    out = torch.empty(P, D, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
-    check(_lib.load().tdr_tok_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), P, D, float(eps), 1 if out_f16 else 0, out.data_ptr(),
-                                        _stream()), 'tdr_tok_layernorm')
+    if planes:
+        out = torch.empty(2, P, D, dtype=torch.float16, device=x.device)
+    else:
+        out = torch.empty(P, D, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
+    check(_lib.load().tdr_tok_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), P, D, float(eps), 2 if planes else (1 if out_f16 else 0),
+                                        out.data_ptr(), _stream()), 'tdr_tok_layernorm')
+    return out
+
+
+def split_planes(w):
+    """host-side 2-way split of a frozen fp32 matrix [N, K] -> hi | lo fp16 planes [2, N, K]"""
+    hi = w.to(torch.float16)
+    return torch.stack([hi, (w - hi.to(torch.float32)).to(torch.float16)]).contiguous()
+
+
+def tok16x2_gemm(x2, w2, bias, epi, act=0, out32=None):
+    """x2 [2, P, K] . w2 [2, N, K]^T on the 2-way split (+ bias): epi 2 -> out32 [P, N] += ., in place; 3 -> fp32 [N, P] (channel-major);
+    4 -> split(act(.)) [2, P, N]"""
+    _, P, Kd = x2.shape
+    N = w2.shape[1]
+    assert x2.is_contiguous() and w2.is_contiguous() and x2.dtype == torch.float16 and w2.dtype == torch.float16 and w2.shape[2] == Kd
+    y = None
+    if epi == 2:
+        assert out32 is not None and out32.is_contiguous() and out32.dtype == torch.float32 and tuple(out32.shape) == (P, N)
+    elif epi == 3:
+        out32 = torch.empty(N, P, dtype=torch.float32, device=x2.device)
+    else:
+        y = torch.empty(2, P, N, dtype=torch.float16, device=x2.device)
+    check(_lib.load().tdr_tok16x2_gemm(x2.data_ptr(), w2.data_ptr(), _p(bias), P, N, Kd, int(epi), int(act), _p(y), _p(out32), _stream()),
+          'tdr_tok16x2_gemm')
+    return y if epi == 4 else out32
+
+
+def cm_to_tok16x2(src):
+    """fp32 channel-major [C, P] -> token-major split planes [2, P, C]"""
+    Cc, P = src.shape
+    assert src.is_contiguous() and src.dtype == torch.float32
+    out = torch.empty(2, P, Cc, dtype=torch.float16, device=src.device)
+    check(_lib.load().tdr_cm_to_tok16x2(src.data_ptr(), Cc, P, out.data_ptr(), _stream()), 'tdr_cm_to_tok16x2')
     return out
 
 
