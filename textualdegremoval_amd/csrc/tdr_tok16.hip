@@ -237,12 +237,11 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
         }
     };
     const int nk = K / BK;
-    // Every workgroup starts its K loop at a different stage and wraps around: the token rows of a tile lie K * 2 bytes apart
-    // (1536 B / 6144 B), so workgroups marching through K in step asked 2 - 8 of an XCD's 16 L2 channels for everything at once
-    // (fc2 ran at 2.2 TB/s of L2 traffic, 141 TFLOP/s).  Global loads run two stages ahead of the MFMAs (registers), LDS stores one
-    // stage ahead; the loads are unconditional (a wrapped prefetch past the last stage is simply not used), which lets the compiler
-    // count them: the LDS store of stage s + 1 waits for its own loads only, not for those of stage s + 2.
-    int kn = (int)((tm * 5 + tn * 3) % nk) * BK;
+    // Global loads run two stages ahead of the MFMAs (registers), LDS stores one stage ahead.  The loads are unconditional (the
+    // prefetch past the last stage wraps around and is simply not used), which lets the compiler count them: the LDS store of stage
+    // s + 1 waits for its own loads only (vmcnt(8)), not for those of stage s + 2.  (With conditional loads it waited for vmcnt(0),
+    // and without the scheduling barriers below it sank the loads under the MFMA block: 141 - 175 TFLOP/s instead of 450 - 580.)
+    int kn = 0;
     auto next = [&]() { const int k = kn; kn += BK; kn = kn >= K ? kn - K : kn; return k; };
     RegSet<NR> g0 = gload(next());
     sstore(g0, 0);
