@@ -10,6 +10,7 @@ bash profiles/rocprof_run.sh gpurun_out/r3m/rocprofv3_kernel_summary_bench.txt 1
 cp /tmp/tdr_prof_cmd.log gpurun_out/r3m/bench_under_rocprof.log
 bash profiles/rocprof_run.sh gpurun_out/r3m/rocprofv3_kernel_summary_steps.txt 27 -- python /root/repo/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-f32-exact --no-roofline --no-matcher-active
 bash profiles/rocprof_run.sh gpurun_out/r3m/rocprofv3_i2t_step_summary.txt 16 -- python /root/repo/bench.py --arch i2t --steps 10 --warmup 2
+bash profiles/rocprof_run.sh gpurun_out/r3m/rocprofv3_dino640_summary.txt 18 -- python /root/repo/bench.py --dino-ref-size 640 --steps 10 --warmup 3 --no-cpu-baseline --no-f32-exact --no-roofline
 python bench.py > gpurun_out/r3m/bench_default.log 2>&1
 python bench.py --arch i2t --steps 10 --warmup 2 > gpurun_out/r3m/bench_i2t_step.log 2>&1
 python bench.py --arch i2t --clip L --steps 10 --warmup 2 > gpurun_out/r3m/bench_i2t_step_vit_l14.log 2>&1
