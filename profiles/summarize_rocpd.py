@@ -21,7 +21,7 @@ def main():
     print(f'total kernel time {tot / 1e6 / steps:.2f} ms/step over {steps:g} steps; {nl / steps:.0f} launches/step')
     print('--- by kernel')
     for name, n, t, avg in c.execute('select name, count(*), sum(end-start), avg(end-start) from kernels where name not like "%spin_kernel%" group by name '
-                                     'order by sum(end-start) desc limit 40'):
+                                     'order by sum(end-start) desc limit 140'):
         print(f'{t / 1e6 / steps:8.2f} ms/step {100 * t / tot:5.1f}%  n/step {n / steps:7.1f}  avg {avg / 1e3:8.1f} us  {short(name)}')
     print('--- by kernel and grid (workgroups x,y,z)')
     q = ('select name, grid_x/workgroup_x, grid_y, grid_z, count(*), sum(end-start), avg(end-start), lds_size, vgpr_count '
