@@ -495,15 +495,15 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(TokAttnArgs a) {
         if (t + 1 < ntile) g = gload(key0 + KT);
         if (active) {
             f32x16 st[2][2];
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st[0][kb][r] = 0.f; st[1][kb][r] = 0.f; }
-#pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const vh8 kf = *reinterpret_cast<const vh8*>(&sK[buf][kb * 32 + j][16 * s + 8 * kk]);
-                    st[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][s], st[0][kb], 0, 0, 0);
-                    st[1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][s], st[1][kb], 0, 0, 0);
+                    // (the first product takes the constant 0 as its C operand: no 64 v_mov per tile to clear the score tiles)
+                    st[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][s], s == 0 ? zero : st[0][kb], 0, 0, 0);
+                    st[1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][s], s == 0 ? zero : st[1][kb], 0, 0, 0);
                 }
             }
             if (key0 + KT > T) {                            // last tile: keys past the sequence
@@ -539,10 +539,13 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(TokAttnArgs a) {
                 sum += __shfl_xor(sum, 32, 64);
                 l[qt] = l[qt] * alpha + sum;
                 m[qt] = mnew;
+                // the running maximum of a query stops moving after a few tiles: the rescale (alpha == 1 exactly) is skipped for the wave
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+                }
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
