@@ -74,7 +74,7 @@ enum { SCH_BX3 = 0, SCH_HX2 = 1, SCH_H1 = 2 };
 #define TDR_CONV_OCC 4
 #endif
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH, int AD = 0>
-__global__ __launch_bounds__(256, (KH == 3 && S == 1 && WM == 1 && TM == 1 && TN == 2 && AD == 0) ? TDR_CONV_OCC : 2) void conv_bx3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (KH == 3 && S == 1 && WM == 1 && TM == 1 && TN == 2 && AD != 9) ? TDR_CONV_OCC : 2) void conv_bx3_kernel(ConvArgs a) {
     constexpr int NS = SCH == SCH_BX3 ? 3 : (SCH == SCH_HX2 ? 2 : 1);   // operand planes (LDS, fragments)
     constexpr int NSW = SCH == SCH_BX3 ? 3 : 2;                         // planes of the weight pack
     constexpr int NP = SCH == SCH_BX3 ? 6 : (SCH == SCH_HX2 ? 3 : 1);   // matrix products per fp32 product
@@ -250,10 +250,21 @@ __global__ __launch_bounds__(256, (KH == 3 && S == 1 && WM == 1 && TM == 1 && TN
             if (g < ngroups) {
                 const int buf = a.single_buf ? 0 : (g & 1);
                 const uint4* sb = smem4 + buf * (2 * NS) * plane;
-                if (PF == 1 && g + 1 < ngroups) load_group(g + 1, 0);
+                // Short rings (0 < AD < 9): the next group's operand loads are issued at tap 9 - AD, i.e. AFTER the last weight-
+                // fragment request this group still consumes -- every fragment wait of the group is then a wait on OLDER loads
+                // (vmcnt counts in order) and the operand loads stay in flight under the remaining AD taps.  Issued at the top of
+                // the group (AD = 0, and AD = 9 where every slot in use was requested a whole group earlier) the first wait on a
+                // fragment requested after them drains them: with AD = 0 that is tap 1, so the high-resolution launches overlapped
+                // their HBM loads with one tap of MFMAs only.
+                constexpr int IGT = (PF == 1 && KH == 3 && AD > 0 && AD < TAPS) ? TAPS - AD : -1;
+                if (PF == 1 && IGT < 0 && g + 1 < ngroups) load_group(g + 1, 0);
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
                     const int tapoff = (tap / KH) * LW + (tap % KH);
+                    if (tap == IGT && g + 1 < ngroups) {
+                        load_group(g + 1, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     // next (group, tap) weight fragments first, THEN the far-ahead operand loads: the wait for
                     // the fragments (in-order vmcnt) then leaves the operand loads in flight.
                     // (the last prefetch of the last group re-reads a valid slot)
@@ -561,6 +572,25 @@ int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
     const int tiles_y = tdr_cdiv(a.OH, TH);
     b.mtiles = tdr_cdiv(a.Cout, BM);
     dim3 grid(b.tiles_x * tiles_y * b.mtiles, 1, N);
+    // Multi-round launches (and the two-m-tile kernels, which spill with 9 slots): a 3-slot ring -- fragments requested three taps
+    // ahead (an L2 round trip is longer than one tap of MFMAs) and the operand prefetch deferred to tap 6 (see the main loop).
+    // Same-box step 59.1 -> 58.4 ms: 32 -> 32 @512^2 216 -> 196 us, 128 -> 128 @128^2 145 -> 129 us, 64 -> 64 @256^2 unchanged
+    // (profiles/r3/tried_and_dropped.txt has the counterpart experiments); TDR_RING3=0 restores the double-buffered fragments.
+    if constexpr (KH == 3 && S == 1 && SCH == SCH_HX2 && EPI == EPI_STD && !GATE) {
+        static const int ring3 = getenv("TDR_RING3") ? atoi(getenv("TDR_RING3")) : 1;
+        static const long ring_blocks3 = getenv("TDR_RING_BLOCKS") ? atol(getenv("TDR_RING_BLOCKS")) : 512;
+        if (ring3 && ((long)grid.x * N > ring_blocks3 || TM != 1)) {
+            auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE, SCH, 3>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, b);
+            TDR_LAUNCH_CHECK("conv_bx3_kernel(ring3)");
+            return TDR_OK;
+        }
+    }
     if constexpr (KH == 3 && S == 1 && TM == 1 && SCH == SCH_HX2 && EPI == EPI_STD) {   // weight-fragment ring: single-round launches
         static const long ring_blocks = getenv("TDR_RING_BLOCKS") ? atol(getenv("TDR_RING_BLOCKS")) : 512;
         if ((long)grid.x * N <= ring_blocks) {
