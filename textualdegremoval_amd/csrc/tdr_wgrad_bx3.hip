@@ -173,12 +173,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
             v0 = *reinterpret_cast<const f32x4*>(src + (ok0 ? ox : 0));
             v1 = *reinterpret_cast<const f32x4*>(src + (ok1 ? ox + 4 : 0));
         }
-        v0 = ok0 ? v0 : z4;
-        v1 = ok1 ? v1 : z4;
-        ldsoff = col * DPITCH + ch * 8;
+        // the out-of-range masks ride in the two top bits of the LDS offset and are applied by d_store: NOTHING here consumes
+        // the loaded values, so a prefetch stays in flight under the MFMAs of the current tile (with the selects here the
+        // compiler waited for every load right behind its issue: vmcnt(7..0) in front of the MFMA block)
+        ldsoff = (col * DPITCH + ch * 8) | (ok0 ? 1 << 30 : 0) | (ok1 ? (int)0x80000000u : 0);
     };
-    auto d_store = [&](int it, const f32x4& v0, const f32x4& v1, int ldsoff, bool live) {
+    auto d_store = [&](int it, const f32x4& r0, const f32x4& r1, int ldsoff_, bool live) {
         if (!live) return;
+        const f32x4 v0 = (ldsoff_ >> 30) & 1 ? r0 : z4, v1 = ((unsigned)ldsoff_ >> 31) ? r1 : z4;
+        const int ldsoff = ldsoff_ & 0x3fffffff;
         dsum[it] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
         u32x4 h, m, l;
         split8v<SCH>(v0, v1, h, m, l);
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         if constexpr (NS >= 2) dst[(BMc * DPITCH) >> 3] = m;
         if constexpr (NS == 3) dst[(2 * BMc * DPITCH) >> 3] = l;
     };
-    auto i_load = [&](int t, int it, f32x4& v0, f32x4& v1, int& ldsoff, bool& live, bool from_raw = false) {
+    auto i_load = [&](int t, int it, f32x4& v0, f32x4& v1, f32x4& g0, f32x4& g1, int& ldsoff, bool& live, bool from_raw = false) {
         int oy0, ox0, ty;
         tile_origin(t, oy0, ox0, ty);
         // 3x3: rows 0,1 of the halo tile are the previous tile's rows R, R+1 unless this is the first tile of the
@@ -215,18 +218,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
             v0 = *reinterpret_cast<const f32x4*>(src + o0);
             v1 = *reinterpret_cast<const f32x4*>(src + o1);
         }
-        if (GATE) {
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(src + o0 + a.gate_off);
-            const f32x4 g1 = *reinterpret_cast<const f32x4*>(src + o1 + a.gate_off);
-            v0 *= g0;
-            v1 *= g1;
+        if (GATE) {                                  // (the gate product is formed by i_store, like the masks)
+            g0 = *reinterpret_cast<const f32x4*>(src + o0 + a.gate_off);
+            g1 = *reinterpret_cast<const f32x4*>(src + o1 + a.gate_off);
         }
-        v0 = ok0 ? v0 : z4;
-        v1 = ok1 ? v1 : z4;
-        ldsoff = cil * IPITCH + slot * CP + c0;
+        ldsoff = (cil * IPITCH + slot * CP + c0) | (ok0 ? 1 << 30 : 0) | (ok1 ? (int)0x80000000u : 0);     // masks applied by i_store (see d_load)
     };
-    auto i_store = [&](const f32x4& v0, const f32x4& v1, int ldsoff, bool live) {
+    auto i_store = [&](const f32x4& r0, const f32x4& r1, const f32x4& g0, const f32x4& g1, int ldsoff_, bool live) {
         if (!live) return;
+        const f32x4 v0 = (ldsoff_ >> 30) & 1 ? (GATE ? r0 * g0 : r0) : z4, v1 = ((unsigned)ldsoff_ >> 31) ? (GATE ? r1 * g1 : r1) : z4;
+        const int ldsoff = ldsoff_ & 0x3fffffff;
         u32x4 h, m, l;
         split8v<SCH>(v0, v1, h, m, l);
         u32x4* dst = reinterpret_cast<u32x4*>(s_i + ldsoff);
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
     };
     // prefetch registers (PRE only): every index below is a compile-time constant after unrolling
     f32x4 pd0[PRE ? NITD : 1], pd1[PRE ? NITD : 1], pi0[PRE ? NITI : 1], pi1[PRE ? NITI : 1];
+    f32x4 pg0[PRE && GATE ? NITI : 1], pg1[PRE && GATE ? NITI : 1];
     int pdo[PRE ? NITD : 1], pio[PRE ? NITI : 1];
     bool pdl[PRE ? NITD : 1], pil[PRE ? NITI : 1];
     auto prefetch = [&](int t) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
 #pragma unroll
             for (int it = 0; it < NITD; ++it) d_load(t, it, pd0[it], pd1[it], pdo[it], pdl[it]);
 #pragma unroll
-            for (int it = 0; it < NITI; ++it) i_load(t, it, pi0[it], pi1[it], pio[it], pil[it]);
+            for (int it = 0; it < NITI; ++it) i_load(t, it, pi0[it], pi1[it], pg0[GATE ? it : 0], pg1[GATE ? it : 0], pio[it], pil[it]);
         }
     };
     auto commit = [&]() {
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
 #pragma unroll
             for (int it = 0; it < NITD; ++it) d_store(it, pd0[it], pd1[it], pdo[it], pdl[it]);
 #pragma unroll
-            for (int it = 0; it < NITI; ++it) i_store(pi0[it], pi1[it], pio[it], pil[it]);
+            for (int it = 0; it < NITI; ++it) i_store(pi0[it], pi1[it], pg0[GATE ? it : 0], pg1[GATE ? it : 0], pio[it], pil[it]);
         }
     };
     auto stage_sync = [&](int t, bool from_raw = false) {   // load + convert + store, item by item
@@ -263,9 +265,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < NITI; ++it) {
-            f32x4 v0, v1; int o; bool live;
-            i_load(t, it, v0, v1, o, live, from_raw);
-            i_store(v0, v1, o, live);
+            f32x4 v0, v1, g0 = z4, g1 = z4; int o; bool live;
+            i_load(t, it, v0, v1, g0, g1, o, live, from_raw);
+            i_store(v0, v1, g0, g1, o, live);
         }
     };
     // a tile whose rows 0,1 are already in the LDS ring (not the first of the block / of a column)
