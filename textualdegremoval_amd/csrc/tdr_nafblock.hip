@@ -84,6 +84,11 @@ __device__ __forceinline__ void gemm_hx2(f32x16 (&acc)[TMW][2], const uint4* __r
                 for (int tn = 0; tn < 2; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g % PF][tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
         if (g + PF < NG) load_a(g % PF, g + PF);
+        // pin the request here: left free, the scheduler sinks each fragment load to just in front of its use (to shorten live
+        // ranges) and the loop degenerates into load -> s_waitcnt vmcnt(0) -> two MFMAs -> load ... (101 vmcnt(0) in naf_tail_bwd<256>).
+        // These kernels sit at the 256-VGPR limit of two waves per SIMD: pinned, PF = 3 - 4 groups spilled more (step +0.6 ms), PF = 2
+        // (12 - 24 MFMAs of cover, about an L2 round trip) spills less than the unpinned code did and is 0.1 ms faster
+        __builtin_amdgcn_sched_barrier(0);
         side(g);
     }
 }
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-    gemm_hx2<1, NG, 4>(acc, a.w3, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [](int) {});
+    gemm_hx2<1, NG, 2>(acc, a.w3, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [](int) {});
 
     float yv[2][16];
     float psum[2] = {0.f, 0.f};
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     {
         float* yp = a.y + (long)n * a.y_ns + p0 + j;
         float* ynp = a.yn + (long)n * a.yn_ns + p0 + j;
-        gemm_hx2<2, NG, 3>(acc4, a.w4, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
+        gemm_hx2<2, NG, 2>(acc4, a.w4, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
             // 64 dword stores (y, yn: 2 sub-tiles x 16 rows each) spread evenly over the NG groups
             constexpr int IPG = 32 / NG;
 #pragma unroll
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-        gemm_hx2<1, NG, 4>(acc, a.w5, a.c_out / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
+        gemm_hx2<1, NG, 2>(acc, a.w5, a.c_out / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
             constexpr int IPG = 64 / NG;                                         // 64 stores spread evenly over the NG groups
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_head_fwd_kernel(HeadFwdArgs a) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
     {
         float* xnp = a.xn + (long)n * a.xn_ns + p0 + j;
-        gemm_hx2<2, NG, 3>(acc, a.w1, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
+        gemm_hx2<2, NG, 2>(acc, a.w1, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
             constexpr int IPG = 32 / NG;
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -608,8 +613,8 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-    if (a.c_out == C) gemm_hx2<1, C / 16, 4>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [](int) {});
-    else gemm_hx2<1, C / 32, 4>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 16, lane, rot, [](int) {});
+    if (a.c_out == C) gemm_hx2<1, C / 16, 2>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [](int) {});
+    else gemm_hx2<1, C / 32, 2>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 16, lane, rot, [](int) {});
     __syncthreads();                                          // every wave is done with the dout planes
 
     // ---- SimpleGate backward; dt4 rows c -> octets [4w, 4w+4), rows C + c -> octets [C/8 + 4w, ...) of the K = 2C operand
@@ -647,10 +652,10 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
     if constexpr (HEAD) {
-        gemm_hx2<1, 2 * C / 16, 4>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [](int) {});
+        gemm_hx2<1, 2 * C / 16, 2>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [](int) {});
     } else {
         float* dp = a.dt4 + (long)n * a.dt4_ns + p0 + j;
-        gemm_hx2<1, 2 * C / 16, 4>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [&](int g) {
+        gemm_hx2<1, 2 * C / 16, 2>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [&](int g) {
             constexpr int IPG = 32 / (2 * C / 16);             // 64 dword stores spread evenly over the groups
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
             float* dyp = a.dy + (long)n * a.dy_ns + p0 + j;
-            gemm_hx2<1, C / 16, 4>(acc, a.w3t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [&](int g) {
+            gemm_hx2<1, C / 16, 2>(acc, a.w3t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [&](int g) {
                 constexpr int IPG = 32 / (C / 16);
 #pragma unroll
                 for (int e = 0; e < IPG; ++e) {
