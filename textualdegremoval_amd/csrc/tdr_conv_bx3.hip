@@ -74,7 +74,7 @@ enum { SCH_BX3 = 0, SCH_HX2 = 1, SCH_H1 = 2 };
 #define TDR_CONV_OCC 4
 #endif
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE, int SCH, int AD = 0>
-__global__ __launch_bounds__(256, (KH == 3 && S == 1 && WM == 1 && TM == 1 && TN == 2 && AD != 9) ? TDR_CONV_OCC : 2) void conv_bx3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (KH == 3 && S == 1 && WM == 1 && TM == 1 && TN == 2 && AD != 9) ? TDR_CONV_OCC : ((KH == 3 && S == 1 && WM == 2 && TM == 1 && TN == 4 && AD == 3) ? 3 : 2)) void conv_bx3_kernel(ConvArgs a) {
     constexpr int NS = SCH == SCH_BX3 ? 3 : (SCH == SCH_HX2 ? 2 : 1);   // operand planes (LDS, fragments)
     constexpr int NSW = SCH == SCH_BX3 ? 3 : 2;                         // planes of the weight pack
     constexpr int NP = SCH == SCH_BX3 ? 6 : (SCH == SCH_HX2 ? 3 : 1);   // matrix products per fp32 product
@@ -663,7 +663,10 @@ int launch_bx_shape(const ConvArgs& a, int N, hipStream_t st) {
             if (force3 == 2) return launch_bx_cfg<KH, S, 2, 1, 4, EPI, GATE>(a, N, st);
             if (force3 == 3) return launch_bx_cfg<KH, S, 2, 1, 2, EPI, GATE>(a, N, st);
             if (force3 == 4) return launch_bx_cfg<KH, S, 2, 2, 2, EPI, GATE>(a, N, st);
-            if (a.Cout > 64 && blocks(128, 256) >= 512) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);  // 128 x 256
+            // 128 x 256 (two m-tiles per wave: 256 VGPRs, the 3-slot ring spills 836 B there) only where it leaves at least two rounds of
+            // workgroups or the 64-row tile would waste rows: 128 -> 128 @128^2 runs 64 x 256 (1024 workgroups, no spills) 5 - 8 % faster
+            const bool tall_ok = blocks(128, 256) >= 1024 || a.Cout % 128 != 0 || a.scheme != SCH_HX2;
+            if (a.Cout > 64 && blocks(128, 256) >= 512 && tall_ok) return launch_bx_cfg<KH, S, 2, 2, 4, EPI, GATE>(a, N, st);  // 128 x 256
         }
         // weight fragments are re-read per 32-pixel column of the wave tile: wide pixel tiles (TN = 4) halve that L2->VGPR
         // stream -- but only with two resident workgroups per CU: one wave per SIMD cannot overlap its own LDS reads and
