@@ -1,4 +1,5 @@
-"""s_memtime timeline of tok_gemm_kernel (build csrc/tdr_tok16.hip with -DTDR_TOK_PROBE into profiles/ab/libtdr_hip_probe.so):
+"""s_memtime timeline of tok_gemm_kernel (apply profiles/probes/tok16_timeline_probe.patch to csrc/tdr_tok16.hip, build that object, link it with the other
+objects of the library into profiles/ab/libtdr_hip_probe.so -- the product source carries no probe code):
 TDR_LIB_PATH=$PWD/profiles/ab/libtdr_hip_probe.so python profiles/probe_tok16_timeline.py
 Stamps of wave 0 of three workgroups: start | prologue done | per even stage: after barrier, after the global-load issue, after the
 MFMA block, after the LDS stores | loop end.  s_memtime ticks at 100 MHz on gfx950 (10 ns)."""
