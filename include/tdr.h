@@ -130,6 +130,38 @@ int tdr_pack_patches(const float* blk, int B, int G, int C, int BH, int BW, int 
                      int off, float* wp, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Pre-split activations ("P16" tensors) and the 3x3 convolution that consumes them (csrc/tdr_conv_p16.hip).
+ * Replaces the 3x3 / stride 1 / pad 1 convolutions of the MASA encoder's ResidualBlocks, forward and data gradient
+ * (network_nafnet_guided_arch.py:44-59,110-143), in the 2-way fp16 split arithmetic.
+ * P16 image of an fp32 [N][C][H][W] tensor, C % 16 == 0: 16-byte slots [N][C/8][plane][H+2][W+2], a slot = 8 consecutive
+ * channels of one pixel as 8 x f16; plane 0 = rn_f16(x), plane 1 = rn_f16(x - plane 0); the 1-pixel border is zero.
+ * tdr_p16_bytes: buffer size.  tdr_p16_from_f32 / tdr_p16_to_f32 convert (to_f32 returns head + residual).
+ * tdr_conv3x3_p16: out = mask( relu( conv(in, W) + bias + res ) ); `in` is a P16 tensor of Cin channels, `wp` an hx2 pack
+ * (tdr_pack_weights_hx2, mode 0 forward / mode 1 data gradient; wp_fmt must be 2); the residual and the ReLU mask (> 0) are read
+ * from fp32 NCHW tensors (res32 / mask32, strides in floats) or from P16 tensors of Cout channels (res16 / mask16: the mask is
+ * the sign of the head plane); the result is written as fp32 NCHW (out32), as a P16 tensor including its zero border (out16),
+ * or both.  Accumulation order = tdr_conv_forward's 2-way fp16 split kernel: bit-identical results on the same operands. */
+typedef struct TdrConvP16Desc {
+    int N, Cin, H, W, Cout;
+    const void* in;
+    const void* wp; int Mpad; int wp_fmt;
+    const float* bias;
+    const float* res32;  int64_t res32_ns;
+    const void*  res16;
+    const float* mask32; int64_t mask32_ns;
+    const void*  mask16;
+    int relu;
+    float* out32; int64_t out32_ns;
+    void*  out16;
+} TdrConvP16Desc;
+int64_t tdr_p16_bytes(int N, int C, int H, int W);
+int tdr_p16_from_f32(const float* src, int64_t src_ns, int N, int C, int H, int W, void* dst, void* stream);
+int tdr_p16_to_f32(const void* src, int N, int C, int H, int W, float* dst, int64_t dst_ns, void* stream);
+int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream);
+/* tuning aid: force tile configuration 1..5 (0 = heuristic) */
+int tdr_conv3x3_p16_force_cfg(int cfg);
+
+/* ---------------------------------------------------------------------------
  * Weight gradient GEMM (K = pixels) on the fp32 matrix cores.
  *   G[g][co][ci][tap] = sum_{n in group g} sum_{oy,ox} dout[n,co,oy,ox] * B[n,ci,oy*s+ky-pad,ox*s+kx-pad]
  * groups = 1 (sum over the batch) or N (per-image, needed by the SCA/beta chain).

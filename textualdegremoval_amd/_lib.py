@@ -40,6 +40,22 @@ class TdrConvDesc(C.Structure):
     ]
 
 
+class TdrConvP16Desc(C.Structure):
+    _fields_ = [
+        ('N', i32), ('Cin', i32), ('H', i32), ('W', i32), ('Cout', i32),
+        ('inp', c_fp),
+        ('wp', c_fp), ('Mpad', i32), ('wp_fmt', i32),
+        ('bias', c_fp),
+        ('res32', c_fp), ('res32_ns', i64),
+        ('res16', c_fp),
+        ('mask32', c_fp), ('mask32_ns', i64),
+        ('mask16', c_fp),
+        ('relu', i32),
+        ('out32', c_fp), ('out32_ns', i64),
+        ('out16', c_fp),
+    ]
+
+
 class TdrPackJob(C.Structure):
     _fields_ = [
         ('w', c_fp), ('wp', c_fp),
@@ -103,6 +119,11 @@ SIGNATURES = {
     'tdr_last_error': (C.c_char_p, []),
     'tdr_conv_forward': (i32, [C.POINTER(TdrConvDesc), c_fp]),
     'tdr_conv_ck': (i32, [i32]),
+    'tdr_p16_bytes': (i64, [i32, i32, i32, i32]),
+    'tdr_p16_from_f32': (i32, [c_fp, i64, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_p16_to_f32': (i32, [c_fp, i32, i32, i32, i32, c_fp, i64, c_fp]),
+    'tdr_conv3x3_p16': (i32, [C.POINTER(TdrConvP16Desc), c_fp]),
+    'tdr_conv3x3_p16_force_cfg': (i32, [i32]),
     'tdr_packed_weight_floats': (i64, [i32, i32, i32]),
     'tdr_pack_weights': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_packed_weight_bytes_bx3': (i64, [i32, i32, i32]),

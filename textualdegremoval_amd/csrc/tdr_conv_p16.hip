@@ -1,0 +1,535 @@
+// 3x3 / stride 1 / pad 1 implicit-GEMM convolution on PRE-SPLIT operands ("P16" tensors), gfx950 only.
+//
+// The fp16-split arithmetic of tdr_conv_bx3.hip (x = h + m, h = rn_f16(x), m = rn_f16(x - h); a*b ~ am*bh + ah*bm + ah*bh on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation) re-did the split in every consumer: dword loads per (lane, channel), ~8 VALU per
+// element, VGPR staging across the MFMA block.  Here the PRODUCER writes the pair once, in the layout the matrix pipe consumes:
+//
+//   P16 tensor of an fp32 [N][C][H][W] activation (C % 16 == 0):  uint4 slots  [N][C/8][plane 2][H+2][W+2]
+//   slot = 8 consecutive channels of ONE pixel as 8 x f16; plane 0 = heads h, plane 1 = residuals m; the one-pixel border is zero
+//   (it IS the convolution's zero padding).  Bytes per element: 4, the same as the fp32 value the pair encodes.
+//
+// With that layout a B fragment (lane = pixel, 8 channels) is one 16-byte slot, a halo-tile row is LW contiguous slots in
+// memory, and BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU): the halo tile of the next
+// 16-channel group in NB pieces spread over the taps of the current group, the packed weight fragments of tap s + LA (the hx2
+// pack of tdr_pack_weights_hx2 is already lane-linear: one 1 KiB piece per (m-tile, plane)) into a ring of LA + 1 slots.
+// The main loop has no global loads the compiler knows of: waits are counted by hand (s_waitcnt vmcnt(N) with N = the pieces
+// issued after the one the next step needs, never 0) in front of one raw s_barrier per (group, tap) step.
+//
+// Accumulation order per output element is the one of conv_bx3_kernel<..., SCH_HX2>: groups of 16 channels ascending, taps
+// ascending, products mh, hm, hh -- results are bit-identical to that kernel on the same operands.
+//
+// Replaces (reference): the 3x3 convolutions of the MASA encoder's ResidualBlocks, forward and data gradient
+// (models/archs/network_nafnet_guided_arch.py:44-59,110-143 and their autograd).
+#include <stdlib.h>
+#include <type_traits>
+#include "tdr_common.h"
+#include "../../include/tdr.h"
+
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct P16Args {
+    const uint4* in; long in_ns;       // P16 input, slots per image
+    int Cin, H, W, Hp, Wp;
+    const uint4* wp; int MT;           // hx2 weight pack [group][tap][m-tile][plane][lane]
+    int Cout;
+    const float* bias;
+    const float* res32; long res32_ns;
+    const uint4* res16; long res16_ns;
+    const float* mask32; long mask32_ns;
+    const uint4* mask16; long mask16_ns;
+    int relu;
+    float* out32; long out32_ns;
+    uint4* out16; long out16_ns;
+    int tiles_x, tiles_y, mtiles;
+};
+
+#define P16_GLDS(gptr, lptr)                                                                          \
+    __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(gptr),          \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// counted wait + workgroup barrier in ONE asm statement: the compiler neither sees the LDS-DMA pieces in its own vmcnt
+// bookkeeping nor may it move LDS accesses across this point ("memory").  lgkmcnt(0): this wave's fragment reads of the step
+// are complete (they were consumed by the MFMAs above) before any wave may overwrite their ring slot.
+template <int N>
+__device__ __forceinline__ void wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// Workgroup = NW = WM x WN waves (4 or 8), tile = BM output channels x TH rows x 32 columns; wave (wm, wn) owns m-tiles wm*TM..
+// and rows wn*TN..  (a 32-pixel sub-tile is one image row segment, so every tap shift of a B fragment is a contiguous run of
+// slots).  PIPE: the fragments of step s + 1 are read from LDS while the MFMAs of step s run (register double buffer), so a
+// wave keeps the matrix pipe busy on its own; the weight ring is then LA + 1 = 4 slots with a run-time slot index.
+template <int TM, int TN, int WM, int WN, bool PIPE, int ABL = 0, bool ILV = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_p16_kernel(P16Args a) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    constexpr int BM = 32 * TM * WM, TH = TN * WN;
+    constexpr int LH = TH + 2, LW = 34, TS = LH * LW;      // halo tile slots per (octet, plane)
+    constexpr int NBW = (4 * TS + NT - 1) / NT;            // halo pieces per wave per group (2 octets x 2 planes)
+    constexpr int BREG = NBW * NT;                         // slots per halo buffer (padded to whole pieces)
+    constexpr int NAI = (BM / 32) * 2;                     // weight pieces per step
+    static_assert(NAI % NW == 0, "every wave issues the same number of weight pieces");
+    constexpr int NAW = NAI / NW;                          // per wave
+    constexpr int LA = PIPE ? 3 : 2;
+    constexpr int R = LA + 1;
+    static_assert(NBW <= (PIPE ? 6 : 7), "halo pieces must be issued early enough to be covered by the wait that publishes them");
+
+    extern __shared__ __attribute__((aligned(1024))) uint4 smem4[];
+    uint4* sB = smem4;                   // [2][BREG]
+    uint4* sA = smem4 + 2 * BREG;        // [R][NAI * 64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int j = lane & 31, kk = lane >> 5;
+    int logical;
+    {   // XCD-aware block order (as conv_bx3_kernel): the m-tiles of one pixel tile run back to back on one XCD
+        const int T = gridDim.x, b = blockIdx.x;
+        const int q = T >> 3, r = T & 7, xcd = b & 7, slot = b >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int mtile = logical % a.mtiles;
+    int pt = logical / a.mtiles;
+    const int tx = pt % a.tiles_x; pt /= a.tiles_x;
+    const int ty = pt % a.tiles_y;
+    const int n = pt / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * 32;
+    const int m0 = mtile * BM;
+    const long PS = (long)a.Hp * a.Wp;
+    const int ngroups = a.Cin >> 4;
+    const int S = ngroups * 9;
+
+    // ---- LDS-DMA sources.  Halo piece k of this wave covers flat slots (k*NW + wave)*64 + lane of [octet][plane][LH][LW]
+    unsigned boff[NBW];
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+        const int f = min((k * NW + wave) * 64 + lane, 4 * TS - 1);
+        const int op = f / TS, s = f - op * TS;
+        const int r = s / LW, c = s - r * LW;
+        const int gy = min(oy0 + r, a.Hp - 1), gx = min(ox0 + c, a.Wp - 1);
+        boff[k] = (unsigned)((op * PS + (long)gy * a.Wp + gx) * 16);
+    }
+    const char* bsrc = reinterpret_cast<const char*>(a.in + (long)n * a.in_ns);     // + g * 64 * PS bytes per group
+    const long bstep = 64 * PS;
+    unsigned aoff[NAW];
+#pragma unroll
+    for (int i = 0; i < NAW; ++i) {
+        const int idx = i * NW + wave;
+        const int mt = min(mtile * (BM / 32) + (idx >> 1), a.MT - 1);
+        aoff[i] = (unsigned)(((mt * 2 + (idx & 1)) * 64 + lane) * 16);
+    }
+    const char* asrc = reinterpret_cast<const char*>(a.wp);
+    const long astep = (long)a.MT * 2048;                                            // bytes per (group, tap)
+
+    // ABL (timing ablations, profiles/probe_conv_p16.py; results are wrong): 1 no LDS-DMA in the loop, 2 no fragment reads in the
+    // loop, 4 no barrier, 8 no MFMAs, 16 no epilogue
+    auto issue_a = [&](int step, int slot) {
+        if ((ABL & 1) && step >= LA) return;
+        const char* base = asrc + (long)min(step, S - 1) * astep;
+#pragma unroll
+        for (int i = 0; i < NAW; ++i) P16_GLDS(base + aoff[i], sA + slot * (NAI * 64) + (i * NW + wave) * 64);
+    };
+    auto issue_b = [&](int g, int buf, int k) {
+        if ((ABL & 1) && g > 0) return;
+        const char* base = bsrc + (long)min(g, ngroups - 1) * bstep;
+        P16_GLDS(base + boff[k], sB + buf * BREG + (k * NW + wave) * 64);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    // ---- prologue: halo tile of group 0, weight pieces of steps 0 .. LA-1
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) issue_b(0, 0, k);
+#pragma unroll
+    for (int d = 0; d < LA; ++d) issue_a(d, d);
+    wait_barrier<0>();
+
+    const uint4* pa0 = sA + (wm * TM * 2) * 64 + lane;
+    const uint4* pb0 = sB + kk * 2 * TS + (wn * TN) * LW + j;
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};   // mh hm hh
+
+    pf16x8 af[TM][2], bf[TN][2];
+    auto read_frags = [&](pf16x8 (&fa)[TM][2], pf16x8 (&fb)[TN][2], int slot, int buf, int tap) {
+        const uint4* pa = pa0 + slot * (NAI * 64);
+        const uint4* pb = pb0 + buf * BREG + (tap / 3) * LW + (tap % 3);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fa[tm][s] = __builtin_bit_cast(pf16x8, pa[(tm * 2 + s) * 64]);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fb[tn][s] = __builtin_bit_cast(pf16x8, pb[s * TS + tn * LW]);
+    };
+    auto mma_step = [&](const pf16x8 (&fa)[TM][2], const pf16x8 (&fb)[TN][2]) {
+        if constexpr (!ILV) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][HA[q]], fb[tn][HB[q]], acc[tm][tn], 0, 0, 0);
+        if constexpr (!ILV) __builtin_amdgcn_s_setprio(0);
+    };
+
+    if constexpr (PIPE) read_frags(af, bf, 0, 0, 0);
+
+    auto step = [&](auto tapc, int g, int buf) {
+        constexpr int tap = decltype(tapc)::value;
+        const int s = g * 9 + tap;
+        issue_a(s + LA, PIPE ? ((s + LA) & 3) : ((tap + LA) % 3));
+        if (tap < NBW) issue_b(g + 1, buf ^ 1, tap);
+        if constexpr (PIPE) {
+            // fragments of step s + 1 (its weight slot and halo buffer were published by the previous barrier)
+            pf16x8 afn[TM][2], bfn[TN][2];
+            constexpr int ntap = (tap + 1) % 9;
+            if (!(ABL & 2)) read_frags(afn, bfn, (s + 1) & 3, tap == 8 ? (buf ^ 1) : buf, ntap);
+            else {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) { afn[tm][0] = af[tm][0]; afn[tm][1] = af[tm][1]; }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) { bfn[tn][0] = bf[tn][0]; bfn[tn][1] = bf[tn][1]; }
+            }
+            if (!(ABL & 8)) mma_step(af, bf);
+            else { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
+            // issue order inside the step: one LDS-DMA piece or one fragment read in the shadow of each MFMA (they belong to later
+            // steps, so nothing below depends on them) instead of a load block in front of an MFMA block -- the waves that share
+            // a SIMD run in phase, so a block of loads is time in which NO wave of the SIMD has an MFMA to issue
+            if constexpr (ILV) {
+                constexpr int NM = TM * TN * 3, ND = (TM + TN) * 2, NV = NAW + (tap < NBW ? 1 : 0);
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+                    if (i < NV) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // VMEM (LDS-DMA piece)
+                    else if (i - NV < ND) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                }
+            }
+            // outstanding afterwards: pieces younger than the weight pieces of step s + 2 (issued at step s - 1)
+            constexpr int nb = (((tap + 8) % 9) < NBW ? 1 : 0) + (tap < NBW ? 1 : 0);
+            if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if constexpr (ABL & 1) wait_barrier<0>();
+            else wait_barrier<NAW + nb>();
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) af[tm][q] = afn[tm][q];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bf[tn][q] = bfn[tn][q];
+        } else {
+            if (!(ABL & 2) || s == 0) read_frags(af, bf, (tap % R), buf, tap);
+            if (!(ABL & 8)) mma_step(af, bf);
+            else { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
+            // pieces issued after the weight pieces of step s + 1 (issued at step s - 1)
+            constexpr int nb = (((tap + 8) % 9) < NBW ? 1 : 0) + (tap < NBW ? 1 : 0);
+            if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if constexpr (ABL & 1) wait_barrier<0>();
+            else wait_barrier<NAW + nb>();
+        }
+    };
+    for (int g = 0; g < ngroups; ++g) {
+        const int buf = g & 1;
+        step(std::integral_constant<int, 0>{}, g, buf); step(std::integral_constant<int, 1>{}, g, buf);
+        step(std::integral_constant<int, 2>{}, g, buf); step(std::integral_constant<int, 3>{}, g, buf);
+        step(std::integral_constant<int, 4>{}, g, buf); step(std::integral_constant<int, 5>{}, g, buf);
+        step(std::integral_constant<int, 6>{}, g, buf); step(std::integral_constant<int, 7>{}, g, buf);
+        step(std::integral_constant<int, 8>{}, g, buf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail pieces have landed: LDS is free
+
+    if constexpr (ABL & 16) {
+        float sum = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[tm][tn][r];
+        if (sum == 1.2345f && a.out32) a.out32[0] = sum;
+        return;
+    }
+    // ---- epilogue (accumulator layout: lane (j, kk) holds pixel j of row tn, channels mb + (r&3) + 8*(r>>2), mb = .. + 4*kk)
+    const long HW = (long)a.H * a.W;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int oy = oy0 + wn * TN + tn, ox = ox0 + j;
+        const bool pvalid = oy < a.H && ox < a.W;
+        const long pix = pvalid ? (long)oy * a.W + ox : 0;
+        const long pslot = pvalid ? (long)(oy + 1) * a.Wp + ox + 1 : 0;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            __builtin_amdgcn_sched_barrier(0);     // one tile at a time: hoisting every tile's operand loads spills
+            const int mt0 = m0 + (wm * TM + tm) * 32;
+            const int mb = mt0 + 4 * kk;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r];
+            if (a.bias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += a.bias[min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+            }
+            if (a.res32) {
+                float tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tv[r] = a.res32[(long)n * a.res32_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HW + pix];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += tv[r];
+            }
+            if (a.res16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);
+                    const char* p = reinterpret_cast<const char*>(a.res16 + (long)n * a.res16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
+                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
+                    const pf16x4 m = *reinterpret_cast<const pf16x4*>(p + PS * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)h[e] + (float)m[e];
+                }
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.mask32) {
+                float tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tv[r] = a.mask32[(long)n * a.mask32_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HW + pix];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = tv[r] > 0.f ? v[r] : 0.f;
+            }
+            if (a.mask16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);
+                    const char* p = reinterpret_cast<const char*>(a.mask16 + (long)n * a.mask16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
+                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = (float)h[e] > 0.f ? v[4 * q + e] : 0.f;
+                }
+            }
+            if (a.out32) {
+                float* op = a.out32 + (long)n * a.out32_ns + pix;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (pvalid && m < a.Cout) op[(long)m * HW] = v[r];
+                }
+            }
+            if (a.out16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!pvalid || mt0 + 8 * q >= a.Cout) continue;
+                    pf16x4 h, m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[4 * q + e];
+                        asm volatile("" : "+v"(x));          // head and residual from the same fp32 value
+                        const _Float16 hh = (_Float16)x;
+                        h[e] = hh;
+                        m[e] = (_Float16)(x - (float)hh);
+                    }
+                    char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * 2 * PS) + kk * 8;
+                    *reinterpret_cast<pf16x4*>(base + pslot * 16) = h;
+                    *reinterpret_cast<pf16x4*>(base + (PS + pslot) * 16) = m;
+                    // the zero border of the output tensor is written by the tiles that touch it
+                    const pf16x4 z = {0, 0, 0, 0};
+                    const bool top = oy == 0, bot = oy == a.H - 1, lef = ox == 0, rig = ox == a.W - 1;
+                    if (top | bot | lef | rig) {
+                        const long Wp = a.Wp;
+                        auto zero_at = [&](long sl) {
+                            *reinterpret_cast<pf16x4*>(base + sl * 16) = z;
+                            *reinterpret_cast<pf16x4*>(base + (PS + sl) * 16) = z;
+                        };
+                        if (top) zero_at(ox + 1);
+                        if (bot) zero_at((long)(a.H + 1) * Wp + ox + 1);
+                        if (lef) zero_at((long)(oy + 1) * Wp);
+                        if (rig) zero_at((long)(oy + 1) * Wp + a.W + 1);
+                        if (top && lef) zero_at(0);
+                        if (top && rig) zero_at(a.W + 1);
+                        if (bot && lef) zero_at((long)(a.H + 1) * Wp);
+                        if (bot && rig) zero_at((long)(a.H + 1) * Wp + a.W + 1);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int WM, int WN, bool PIPE, int ABL = 0, bool ILV = false>
+int launch_p16(const P16Args& a0, int N, hipStream_t st) {
+    constexpr int NW = WM * WN, BM = 32 * TM * WM, TH = TN * WN;
+    constexpr int TS = (TH + 2) * 34, NBW = (4 * TS + 64 * NW - 1) / (64 * NW), BREG = NBW * 64 * NW, NAI = (BM / 32) * 2;
+    constexpr int R = PIPE ? 4 : 3;
+    P16Args a = a0;
+    a.tiles_x = tdr_cdiv(a.W, 32);
+    a.tiles_y = tdr_cdiv(a.H, TH);
+    a.mtiles = tdr_cdiv(a.Cout, BM);
+    const size_t lds = (size_t)(2 * BREG + R * NAI * 64) * 16;
+    dim3 grid((unsigned)((long)a.tiles_x * a.tiles_y * a.mtiles * N));
+    auto kern = conv3x3_p16_kernel<TM, TN, WM, WN, PIPE, ABL, ILV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);
+    TDR_LAUNCH_CHECK("conv3x3_p16_kernel");
+    return TDR_OK;
+}
+
+// ---- fp32 NCHW <-> P16
+__global__ void p16_from_f32_kernel(const float* __restrict__ src, long src_ns, int C, int H, int W, uint4* __restrict__ dst) {
+    const int Hp = H + 2, Wp = W + 2;
+    const long PS = (long)Hp * Wp, HW = (long)H * W;
+    const int G = C >> 3;
+    const long total = (long)G * PS;
+    const int n = blockIdx.y;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int oc = (int)(i / PS);
+        const long s = i - oc * PS;
+        const int y = (int)(s / Wp), x = (int)(s - (long)y * Wp);
+        pf16x8 h, m;
+        const bool in = y >= 1 && y <= H && x >= 1 && x <= W;
+        const float* p = src + (long)n * src_ns + (long)oc * 8 * HW + (in ? (long)(y - 1) * W + x - 1 : 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = in ? p[e * HW] : 0.f;
+            asm volatile("" : "+v"(v));
+            const _Float16 hh = (_Float16)v;
+            h[e] = hh;
+            m[e] = (_Float16)(v - (float)hh);
+        }
+        uint4* o = dst + ((long)n * G + oc) * 2 * PS + s;
+        o[0] = __builtin_bit_cast(uint4, h);
+        o[PS] = __builtin_bit_cast(uint4, m);
+    }
+}
+
+__global__ void p16_to_f32_kernel(const uint4* __restrict__ src, int C, int H, int W, float* __restrict__ dst, long dst_ns) {
+    const int Hp = H + 2, Wp = W + 2;
+    const long PS = (long)Hp * Wp, HW = (long)H * W;
+    const int G = C >> 3;
+    const long total = (long)G * HW;
+    const int n = blockIdx.y;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int oc = (int)(i / HW);
+        const long s = i - oc * HW;
+        const int y = (int)(s / W), x = (int)(s - (long)y * W);
+        const uint4* p = src + ((long)n * G + oc) * 2 * PS + (long)(y + 1) * Wp + x + 1;
+        const pf16x8 h = __builtin_bit_cast(pf16x8, p[0]), m = __builtin_bit_cast(pf16x8, p[PS]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[(long)n * dst_ns + (long)(oc * 8 + e) * HW + s] = (float)h[e] + (float)m[e];
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t tdr_p16_bytes(int N, int C, int H, int W) {
+    return (int64_t)N * (C / 8) * 2 * (H + 2) * (W + 2) * 16;
+}
+
+extern "C" int tdr_p16_from_f32(const float* src, int64_t src_ns, int N, int C, int H, int W, void* dst, void* stream) {
+    TDR_REQUIRE(src && dst && N > 0, "tdr_p16_from_f32: bad argument");
+    TDR_REQUIRE(C % 16 == 0, "tdr_p16_from_f32: C = %d is not a multiple of 16", C);
+    const long total = (long)(C / 8) * (H + 2) * (W + 2);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(p16_from_f32_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, src, (long)src_ns, C, H, W, (uint4*)dst);
+    TDR_LAUNCH_CHECK("p16_from_f32_kernel");
+    return TDR_OK;
+}
+
+extern "C" int tdr_p16_to_f32(const void* src, int N, int C, int H, int W, float* dst, int64_t dst_ns, void* stream) {
+    TDR_REQUIRE(src && dst && N > 0, "tdr_p16_to_f32: bad argument");
+    TDR_REQUIRE(C % 16 == 0, "tdr_p16_to_f32: C = %d is not a multiple of 16", C);
+    const long total = (long)(C / 8) * H * W;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(p16_to_f32_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, C, H, W, dst, (long)dst_ns);
+    TDR_LAUNCH_CHECK("p16_to_f32_kernel");
+    return TDR_OK;
+}
+
+static int g_p16_cfg = getenv("TDR_P16_CFG") ? atoi(getenv("TDR_P16_CFG")) : 0;
+extern "C" int tdr_conv3x3_p16_force_cfg(int cfg) { g_p16_cfg = cfg; return TDR_OK; }
+
+extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
+    TDR_REQUIRE(d && d->in && d->wp && (d->out32 || d->out16), "tdr_conv3x3_p16: null pointer");
+    TDR_REQUIRE(d->Cin % 16 == 0 && d->Cin >= 16, "tdr_conv3x3_p16: Cin = %d is not a multiple of 16", d->Cin);
+    TDR_REQUIRE(!d->out16 || d->Cout % 16 == 0, "tdr_conv3x3_p16: P16 output needs Cout %% 16 == 0 (got %d)", d->Cout);
+    TDR_REQUIRE((!d->res16 && !d->mask16) || d->Cout % 8 == 0, "tdr_conv3x3_p16: P16 residual / mask need Cout %% 8 == 0");
+    TDR_REQUIRE(d->wp_fmt == 2, "tdr_conv3x3_p16: weights must be the 2-way fp16 split pack (wp_fmt 2)");
+    P16Args a;
+    a.in = (const uint4*)d->in; a.in_ns = (long)(d->Cin / 8) * 2 * (d->H + 2) * (d->W + 2);
+    a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Hp = d->H + 2; a.Wp = d->W + 2;
+    a.wp = (const uint4*)d->wp; a.MT = d->Mpad >> 5; a.Cout = d->Cout;
+    a.bias = d->bias;
+    a.res32 = d->res32; a.res32_ns = d->res32_ns;
+    a.res16 = (const uint4*)d->res16; a.res16_ns = (long)(d->Cout / 8) * 2 * (d->H + 2) * (d->W + 2);
+    a.mask32 = d->mask32; a.mask32_ns = d->mask32_ns;
+    a.mask16 = (const uint4*)d->mask16; a.mask16_ns = a.res16_ns;
+    a.relu = d->relu;
+    a.out32 = d->out32; a.out32_ns = d->out32_ns;
+    a.out16 = (uint4*)d->out16; a.out16_ns = a.res16_ns;
+    a.tiles_x = a.tiles_y = a.mtiles = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = d->N;
+    auto blocks = [&](int bm, int th) { return (long)tdr_cdiv(d->Cout, bm) * tdr_cdiv(d->H, th) * tdr_cdiv(d->W, 32) * N; };
+    int cfg = g_p16_cfg;
+    if (cfg == 0) {
+        // largest tile that still gives every CU its two resident workgroups
+        if (d->Cout > 64 && blocks(128, 8) >= 512) cfg = 1;
+        else if (d->Cout > 64 && blocks(128, 4) >= 512) cfg = 2;
+        else if (blocks(64, 8) >= 512) cfg = 3;
+        else cfg = 4;
+    }
+    switch (cfg) {
+        //                       TM TN WM WN PIPE
+        case 1: return launch_p16<4, 2, 1, 4, false>(a, N, st);   // 128 x (8 x 32), 4 waves
+        case 2: return launch_p16<2, 2, 2, 2, false>(a, N, st);   // 128 x (4 x 32)
+        case 3: return launch_p16<2, 2, 1, 4, false>(a, N, st);   //  64 x (8 x 32)
+        case 4: return launch_p16<1, 2, 2, 2, false>(a, N, st);   //  64 x (4 x 32)
+        case 5: return launch_p16<4, 1, 1, 4, false>(a, N, st);   // 128 x (4 x 32), all waves side by side in pixels
+        case 6: return launch_p16<2, 2, 1, 4, true>(a, N, st);    //  64 x (8 x 32), pipelined fragments
+        case 7: return launch_p16<2, 2, 2, 2, true>(a, N, st);    // 128 x (4 x 32), pipelined
+        case 8: return launch_p16<2, 2, 2, 4, false>(a, N, st);   // 128 x (8 x 32), 8 waves
+        case 9: return launch_p16<2, 2, 2, 4, true>(a, N, st);    // 128 x (8 x 32), 8 waves, pipelined
+        case 10: return launch_p16<2, 4, 2, 4, false>(a, N, st);  // 128 x (16 x 32), 8 waves
+        case 11: return launch_p16<2, 4, 2, 4, true>(a, N, st);   // 128 x (16 x 32), 8 waves, pipelined
+        case 12: return launch_p16<2, 2, 4, 2, true>(a, N, st);   // 256 x (4 x 32), 8 waves, pipelined
+        case 13: return launch_p16<4, 2, 1, 4, true>(a, N, st);   // 128 x (8 x 32), 4 waves, pipelined
+        case 16: return launch_p16<2, 2, 1, 4, true, 0, true>(a, N, st);    //  64 x (8 x 32), pipelined + interleaved
+        case 17: return launch_p16<2, 2, 2, 2, true, 0, true>(a, N, st);    // 128 x (4 x 32)
+        case 19: return launch_p16<2, 2, 2, 4, true, 0, true>(a, N, st);    // 128 x (8 x 32), 8 waves
+        case 22: return launch_p16<2, 2, 4, 2, true, 0, true>(a, N, st);    // 256 x (4 x 32), 8 waves
+        case 201: return launch_p16<2, 2, 1, 4, true, 1, true>(a, N, st);
+        case 202: return launch_p16<2, 2, 1, 4, true, 2, true>(a, N, st);
+        case 203: return launch_p16<2, 2, 1, 4, true, 3, true>(a, N, st);
+        case 204: return launch_p16<2, 2, 1, 4, true, 4, true>(a, N, st);
+        case 207: return launch_p16<2, 2, 1, 4, true, 7, true>(a, N, st);
+        case 216: return launch_p16<2, 2, 1, 4, true, 16, true>(a, N, st);
+        case 223: return launch_p16<2, 2, 1, 4, true, 23, true>(a, N, st);
+        case 101: return launch_p16<2, 2, 1, 4, false, 1>(a, N, st);
+        case 102: return launch_p16<2, 2, 1, 4, false, 2>(a, N, st);
+        case 103: return launch_p16<2, 2, 1, 4, false, 3>(a, N, st);
+        case 104: return launch_p16<2, 2, 1, 4, false, 4>(a, N, st);
+        case 107: return launch_p16<2, 2, 1, 4, false, 7>(a, N, st);
+        case 108: return launch_p16<2, 2, 1, 4, false, 8>(a, N, st);
+        case 116: return launch_p16<2, 2, 1, 4, false, 16>(a, N, st);
+        case 123: return launch_p16<2, 2, 1, 4, false, 23>(a, N, st);
+        case 131: return launch_p16<2, 2, 1, 4, false, 31>(a, N, st);
+        default: break;
+    }
+    tdr_set_error("tdr_conv3x3_p16: unknown tile configuration %d", cfg);
+    return TDR_ERR_ARG;
+}

@@ -7,7 +7,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import TdrConvDesc, TdrWgradDesc, check
+from ._lib import TdrConvDesc, TdrConvP16Desc, TdrWgradDesc, check
 
 EPI_STD, EPI_GATEBWD, EPI_PSHUF = 0, 1, 2
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2 = 0, 1, 2, 3
@@ -497,6 +497,74 @@ def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None
         _survey.probe(x, 'grad' if BACKWARD_PHASE else 'fwd')
     check(lib.tdr_conv_forward(C.byref(d), _stream()), 'tdr_conv_forward')
     return out
+
+
+class P16:
+    """A pre-split activation (include/tdr.h, "P16 tensors"): 16-byte slots [N][C/8][plane][H+2][W+2] of 8 x f16, plane 0 the
+    fp16 heads, plane 1 the fp16 residuals, zero border.  `buf` is a flat int32 tensor (4 bytes per element of the fp32 tensor
+    plus the border)."""
+    __slots__ = ('buf', 'N', 'C', 'H', 'W')
+
+    def __init__(self, buf, N, Cc, H, W):
+        self.buf, self.N, self.C, self.H, self.W = buf, N, Cc, H, W
+
+    @staticmethod
+    def empty(N, Cc, H, W, device):
+        assert Cc % 16 == 0, f'P16 tensors need C % 16 == 0 (got {Cc})'
+        n = _lib.load().tdr_p16_bytes(N, Cc, H, W) // 4
+        return P16(torch.empty(n, dtype=torch.int32, device=device), N, Cc, H, W)
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    def to_f32(self):
+        out = torch.empty(self.N, self.C, self.H, self.W, dtype=torch.float32, device=self.buf.device)
+        check(_lib.load().tdr_p16_to_f32(self.buf.data_ptr(), self.N, self.C, self.H, self.W, out.data_ptr(), _dense_nchw(out),
+                                         _stream()), 'tdr_p16_to_f32')
+        return out
+
+
+def p16_supported(Cc):
+    """channel counts the pre-split 3x3 path takes (both operands in the fp16 window: TDR_MATH=hx2)"""
+    return Cc % 16 == 0 and Cc >= 16
+
+
+def p16_from_f32(x, out=None):
+    N, Cc, H, W = x.shape
+    out = out if out is not None else P16.empty(N, Cc, H, W, x.device)
+    if _survey is not None:
+        _survey.probe(x, 'grad' if BACKWARD_PHASE else 'fwd')
+    check(_lib.load().tdr_p16_from_f32(x.data_ptr(), _dense_nchw(x), N, Cc, H, W, out.data_ptr(), _stream()), 'tdr_p16_from_f32')
+    return out
+
+
+def conv3x3_p16(x16, wp, Mpad, Cout, bias=None, res=None, mask=None, relu=False, want32=True, want16=False, out32=None):
+    """3x3 / stride 1 / pad 1 convolution of a P16 tensor (csrc/tdr_conv_p16.hip); `res` / `mask` may be fp32 NCHW tensors or
+    P16 tensors.  Returns (fp32 NCHW result or None, P16 result or None)."""
+    lib = _lib.load()
+    d = TdrConvP16Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout = x16.N, x16.C, x16.H, x16.W, Cout
+    d.inp = x16.data_ptr()
+    d.wp, d.Mpad, d.wp_fmt = wp.data_ptr(), Mpad, getattr(wp, 'fmt', FMT_F32)
+    d.bias = _p(bias)
+    if isinstance(res, P16):
+        d.res16 = res.data_ptr()
+    elif res is not None:
+        d.res32, d.res32_ns = res.data_ptr(), _dense_nchw(res)
+    if isinstance(mask, P16):
+        d.mask16 = mask.data_ptr()
+    elif mask is not None:
+        d.mask32, d.mask32_ns = mask.data_ptr(), _dense_nchw(mask)
+    d.relu = 1 if relu else 0
+    o32 = o16 = None
+    if want32:
+        o32 = out32 if out32 is not None else torch.empty(x16.N, Cout, x16.H, x16.W, dtype=torch.float32, device=x16.buf.device)
+        d.out32, d.out32_ns = o32.data_ptr(), _dense_nchw(o32)
+    if want16:
+        o16 = P16.empty(x16.N, Cout, x16.H, x16.W, x16.buf.device)
+        d.out16 = o16.data_ptr()
+    check(lib.tdr_conv3x3_p16(C.byref(d), _stream()), 'tdr_conv3x3_p16')
+    return o32, o16
 
 
 def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=False, want_db=False, fp16_range=False):
