@@ -158,8 +158,22 @@ int64_t tdr_p16_bytes(int N, int C, int H, int W);
 int tdr_p16_from_f32(const float* src, int64_t src_ns, int N, int C, int H, int W, void* dst, void* stream);
 int tdr_p16_to_f32(const void* src, int N, int C, int H, int W, float* dst, int64_t dst_ns, void* stream);
 int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream);
-/* tuning aid: force tile configuration 1..5 (0 = heuristic) */
+/* tuning aid: force a tile configuration (0 = heuristic) */
 int tdr_conv3x3_p16_force_cfg(int cfg);
+/* Weight (and bias) gradient of the same convolution from P16 operands (csrc/tdr_wgrad_p16.hip):
+ *   g[co][ci][ky][kx] = sum_{n,y,x} dout[n,co,y,x] * in[n,ci,y+ky-1,x+kx-1],   db[co] = sum dout[n,co,y,x]  (optional)
+ * in16: P16 tensor of Cin channels (the convolution's input), dout16: P16 tensor of Cout channels (the output gradient, inside the
+ * fp16 window: loss-scaled backward).  Deterministic: split-K partials in ws are reduced in a fixed order. */
+typedef struct TdrWgradP16Desc {
+    int N, Cin, H, W, Cout;
+    const void* in16;
+    const void* dout16;
+    float* g;
+    float* db;
+    float* ws; int64_t ws_floats;
+} TdrWgradP16Desc;
+int64_t tdr_wgrad3x3_p16_ws_floats(const TdrWgradP16Desc* d);
+int tdr_wgrad3x3_p16(const TdrWgradP16Desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Weight gradient GEMM (K = pixels) on the fp32 matrix cores.

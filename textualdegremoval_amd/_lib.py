@@ -56,6 +56,11 @@ class TdrConvP16Desc(C.Structure):
     ]
 
 
+class TdrWgradP16Desc(C.Structure):
+    _fields_ = [('N', i32), ('Cin', i32), ('H', i32), ('W', i32), ('Cout', i32),
+                ('in16', c_fp), ('dout16', c_fp), ('g', c_fp), ('db', c_fp), ('ws', c_fp), ('ws_floats', i64)]
+
+
 class TdrPackJob(C.Structure):
     _fields_ = [
         ('w', c_fp), ('wp', c_fp),
@@ -124,6 +129,8 @@ SIGNATURES = {
     'tdr_p16_to_f32': (i32, [c_fp, i32, i32, i32, i32, c_fp, i64, c_fp]),
     'tdr_conv3x3_p16': (i32, [C.POINTER(TdrConvP16Desc), c_fp]),
     'tdr_conv3x3_p16_force_cfg': (i32, [i32]),
+    'tdr_wgrad3x3_p16_ws_floats': (i64, [C.POINTER(TdrWgradP16Desc)]),
+    'tdr_wgrad3x3_p16': (i32, [C.POINTER(TdrWgradP16Desc), c_fp]),
     'tdr_packed_weight_floats': (i64, [i32, i32, i32]),
     'tdr_pack_weights': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_packed_weight_bytes_bx3': (i64, [i32, i32, i32]),

@@ -7,7 +7,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import TdrConvDesc, TdrConvP16Desc, TdrWgradDesc, check
+from ._lib import TdrConvDesc, TdrConvP16Desc, TdrWgradDesc, TdrWgradP16Desc, check
 
 EPI_STD, EPI_GATEBWD, EPI_PSHUF = 0, 1, 2
 PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2 = 0, 1, 2, 3
@@ -565,6 +565,23 @@ def conv3x3_p16(x16, wp, Mpad, Cout, bias=None, res=None, mask=None, relu=False,
         d.out16 = o16.data_ptr()
     check(lib.tdr_conv3x3_p16(C.byref(d), _stream()), 'tdr_conv3x3_p16')
     return o32, o16
+
+
+def wgrad3x3_p16(x16, d16, want_db=False):
+    """weight (and bias) gradient of a 3x3 / stride 1 / pad 1 convolution from its P16 input and P16 output gradient
+    (csrc/tdr_wgrad_p16.hip).  Returns g [1, Cout, Cin, 3, 3] (and db [Cout])."""
+    lib = _lib.load()
+    d = TdrWgradP16Desc()
+    d.N, d.Cin, d.H, d.W, d.Cout = x16.N, x16.C, x16.H, x16.W, d16.C
+    d.in16, d.dout16 = x16.data_ptr(), d16.data_ptr()
+    dev = x16.buf.device
+    g = torch.empty(1, d16.C, x16.C, 3, 3, dtype=torch.float32, device=dev)
+    db = torch.empty(d16.C, dtype=torch.float32, device=dev) if want_db else None
+    d.g, d.db = g.data_ptr(), _p(db)
+    ws = workspace(lib.tdr_wgrad3x3_p16_ws_floats(C.byref(d)), dev, 'wgrad')
+    d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+    check(lib.tdr_wgrad3x3_p16(C.byref(d), _stream()), 'tdr_wgrad3x3_p16')
+    return (g, db) if want_db else g
 
 
 def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=False, want_db=False, fp16_range=False):
