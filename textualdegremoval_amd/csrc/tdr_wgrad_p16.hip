@@ -230,10 +230,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_p16_kernel(WgP16Args a) {
     }
 }
 
-// out[e] = sum_s part[s][e] in fixed order; blocks >= nb_main reduce the bias-gradient partials
-__global__ __launch_bounds__(256) void wgrad_p16_reduce_kernel(const float* __restrict__ part, long elems, int nsplit, float* __restrict__ out,
-                                                               int nb_main, const float* __restrict__ part2, long elems2, float* __restrict__ out2) {
-    __shared__ float red[4][64];
+// out[e] = sum_s part[s][e] in fixed order; blocks >= nb_main reduce the bias-gradient partials.  Block = 64 elements x KL
+// partial-lanes, eight partials in flight per thread (as wgrad_reduce_kernel of tdr_wgrad_mfma.hip).
+template <int KL>
+__global__ __launch_bounds__(64 * KL) void wgrad_p16_reduce_kernel(const float* __restrict__ part, long elems, int nsplit, float* __restrict__ out,
+                                                                   int nb_main, const float* __restrict__ part2, long elems2, float* __restrict__ out2) {
+    __shared__ float red[KL][64];
     const int lane = threadIdx.x & 63, kl = threadIdx.x >> 6;
     const bool second = (int)blockIdx.x >= nb_main;
     const float* pbase = second ? part2 : part;
@@ -242,15 +244,20 @@ __global__ __launch_bounds__(256) void wgrad_p16_reduce_kernel(const float* __re
     const long e = ((int)blockIdx.x - (second ? nb_main : 0)) * 64L + lane;
     const float* p = pbase + (e < ne ? e : ne - 1);
     float s0 = 0.f;
-    for (int k = kl; k < nsplit; k += 32) {
+    for (int k = kl; k < nsplit; k += 8 * KL) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = k + u * 4 < nsplit ? p[(long)(k + u * 4) * ne] : 0.f;
+        for (int u = 0; u < 8; ++u) v[u] = k + u * KL < nsplit ? p[(long)(k + u * KL) * ne] : 0.f;
         s0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
     red[kl][lane] = s0;
     __syncthreads();
-    if (kl == 0 && e < ne) o[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (kl == 0 && e < ne) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < KL; ++q) t += red[q][lane];
+        o[e] = t;
+    }
 }
 
 struct WgP16Plan { int cfg, bm, bn, strips, chunks, rc, nsplit; };
@@ -318,8 +325,15 @@ extern "C" int tdr_wgrad3x3_p16(const TdrWgradP16Desc* d, void* stream) {
     if (rc != TDR_OK) return rc;
     const long elems = (long)d->Cout * d->Cin * 9;
     const int nb_main = tdr_cdiv(elems, 64), nb2 = d->db ? tdr_cdiv(d->Cout, 64) : 0;
-    hipLaunchKernelGGL(wgrad_p16_reduce_kernel, dim3(nb_main + nb2), dim3(256), 0, st, d->ws, elems, p.nsplit, d->g, nb_main, a.dbpart,
-                       (long)d->Cout, d->db);
+    if (p.nsplit <= 8)
+        hipLaunchKernelGGL(wgrad_p16_reduce_kernel<1>, dim3(nb_main + nb2), dim3(64), 0, st, d->ws, elems, p.nsplit, d->g, nb_main, a.dbpart,
+                           (long)d->Cout, d->db);
+    else if (p.nsplit <= 64)
+        hipLaunchKernelGGL(wgrad_p16_reduce_kernel<4>, dim3(nb_main + nb2), dim3(256), 0, st, d->ws, elems, p.nsplit, d->g, nb_main, a.dbpart,
+                           (long)d->Cout, d->db);
+    else
+        hipLaunchKernelGGL(wgrad_p16_reduce_kernel<16>, dim3(nb_main + nb2), dim3(1024), 0, st, d->ws, elems, p.nsplit, d->g, nb_main, a.dbpart,
+                           (long)d->Cout, d->db);
     TDR_LAUNCH_CHECK("wgrad_p16_reduce_kernel");
     return TDR_OK;
 }

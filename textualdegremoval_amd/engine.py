@@ -249,6 +249,23 @@ def _enc_counts(ext):
     return [ext[0], ext[1], ext[2], ext[2], ext[2]]
 
 
+# The ResidualBlock convolutions run on PRE-SPLIT activations (kernels.P16, csrc/tdr_conv_p16.hip / tdr_wgrad_p16.hip) when the
+# step's arithmetic is the 2-way fp16 split in both passes (TDR_MATH=hx2 inside a loss-scaled step) and the level's channel
+# count is a multiple of 16: conv1 / conv2 read and write the fp16 pair planes (the same 4 bytes per element as the fp32
+# tensors they replace: `h`, the block inputs and, in the backward pass, `dh` and the gradient stream exist ONLY as pairs),
+# both weight gradients read them through transposed LDS reads, and the ReLU masks are the sign of the head plane.  A level
+# enters the format through one conversion of conv_L's output (forward) and of the incoming feature gradient (backward) and
+# leaves it as fp32 (feats[lvl] for the MASA kernels / the next conv_L, the gradient for conv_L's backward).
+# TDR_P16=0 keeps the fp32 tensors + per-consumer split of rounds 1-3.
+P16_ON = os.environ.get('TDR_P16', '1') == '1'
+# narrower levels (C = 32: one 32-row m-tile, 18 (group, tap) steps) keep the fp32 kernels until the weights-stationary variant exists
+P16_MIN_C = int(os.environ.get('TDR_P16_MIN_C', '64'))
+
+
+def _p16_level(Cc, n_blocks):
+    return P16_ON and n_blocks > 0 and K.MATH == 'hx2' and K.GRAD_SCALED and K.p16_supported(Cc) and Cc >= P16_MIN_C
+
+
 def encoder_fwd(x, P, pre, ext_n_blocks, levels=5):
     """returns ([f1..f_levels], saved).  levels=4: the Restormer-ref file's own 4-level Encoder
     (network_restormer_guided_arch.py:99-133)."""
@@ -260,12 +277,27 @@ def encoder_fwd(x, P, pre, ext_n_blocks, levels=5):
         a = conv_fwd(xin, P[f'{pre}conv_L{k}.weight'], P[f'{pre}conv_L{k}.bias'], 1 if lvl == 0 else 2, 1, relu=True)
         blocks = []
         x = a
-        for i in range(cnt[lvl]):
-            bp = f'{pre}blk_L{k}.{i}.'
-            h = conv_fwd(x, P[bp + 'conv1.weight'], P[bp + 'conv1.bias'], 1, 1, relu=True)
-            o = conv_fwd(h, P[bp + 'conv2.weight'], P[bp + 'conv2.bias'], 1, 1, res=x)
-            blocks.append((x, h))
-            x = o
+        Cc = a.shape[1]
+        if _p16_level(Cc, cnt[lvl]):
+            x16 = K.p16_from_f32(a)
+            for i in range(cnt[lvl]):
+                bp = f'{pre}blk_L{k}.{i}.'
+                wp1, mp1, *_ = K.pack_weights(P[bp + 'conv1.weight'], PACK_FWD)
+                wp2, mp2, *_ = K.pack_weights(P[bp + 'conv2.weight'], PACK_FWD)
+                last = i == cnt[lvl] - 1
+                _, h16 = K.conv3x3_p16(x16, wp1, mp1, Cc, bias=P[bp + 'conv1.bias'], relu=True, want32=False, want16=True)
+                o32, o16 = K.conv3x3_p16(h16, wp2, mp2, Cc, bias=P[bp + 'conv2.bias'], res=a if i == 0 else x16,
+                                         want32=last, want16=not last)
+                blocks.append((x16, h16))
+                x16 = o16
+            x = o32
+        else:
+            for i in range(cnt[lvl]):
+                bp = f'{pre}blk_L{k}.{i}.'
+                h = conv_fwd(x, P[bp + 'conv1.weight'], P[bp + 'conv1.bias'], 1, 1, relu=True)
+                o = conv_fwd(h, P[bp + 'conv2.weight'], P[bp + 'conv2.bias'], 1, 1, res=x)
+                blocks.append((x, h))
+                x = o
         feats.append(x)
         saved.append((xin, a, blocks))
     return feats, saved
@@ -288,22 +320,45 @@ def _encoder_bwd_levels(dfeats, P, pre, cnt, saved, G, dnext):
         d = dnext if dnext is not None else dfeats[lvl]      # dnext already contains dfeats[lvl] (add_to_dx below)
         if d is None:
             continue
-        for i in reversed(range(cnt[lvl])):
-            bp = f'{pre}blk_L{k}.{i}.'
-            x_in, h = blocks[i]
-            w1, w2 = P[bp + 'conv1.weight'], P[bp + 'conv2.weight']
-            Cc = w1.shape[0]
-            with K.on_side(h, d):
-                gw, G[bp + 'conv2.bias'] = K.conv_wgrad(h, d, Cc, Cc, 3, pad=1, want_db=True)
-                G[bp + 'conv2.weight'] = gw.view(Cc, Cc, 3, 3)
-            wp, mp, *_ = K.pack_weights(w2, PACK_DGRAD_S1)
-            dh = K.conv_forward(d, wp, mp, Cc, 3, pad=1, mask=h)
-            with K.on_side(x_in, dh):
-                gw, G[bp + 'conv1.bias'] = K.conv_wgrad(x_in, dh, Cc, Cc, 3, pad=1, want_db=True)
-                G[bp + 'conv1.weight'] = gw.view(Cc, Cc, 3, 3)
-            wp, mp, *_ = K.pack_weights(w1, PACK_DGRAD_S1)
-            # the first block's input is the level's ReLU output `a`: its mask rides on this epilogue (conv + res, then mask)
-            d = K.conv_forward(dh, wp, mp, Cc, 3, pad=1, res=d, mask=a if i == 0 else None)
+        if blocks and isinstance(blocks[0][0], K.P16):
+            d16, d32 = K.p16_from_f32(d), d
+            for i in reversed(range(cnt[lvl])):
+                bp = f'{pre}blk_L{k}.{i}.'
+                x16, h16 = blocks[i]
+                w1, w2 = P[bp + 'conv1.weight'], P[bp + 'conv2.weight']
+                Cc = w1.shape[0]
+                with K.on_side(h16.buf, d16.buf):
+                    gw, G[bp + 'conv2.bias'] = K.wgrad3x3_p16(h16, d16, want_db=True)
+                    G[bp + 'conv2.weight'] = gw.view(Cc, Cc, 3, 3)
+                wp, mp, *_ = K.pack_weights(w2, PACK_DGRAD_S1)
+                _, dh16 = K.conv3x3_p16(d16, wp, mp, Cc, mask=h16, want32=False, want16=True)
+                with K.on_side(x16.buf, dh16.buf):
+                    gw, G[bp + 'conv1.bias'] = K.wgrad3x3_p16(x16, dh16, want_db=True)
+                    G[bp + 'conv1.weight'] = gw.view(Cc, Cc, 3, 3)
+                wp, mp, *_ = K.pack_weights(w1, PACK_DGRAD_S1)
+                # the first block's input is the level's ReLU output `a`: its mask rides on this epilogue (conv + res, then mask);
+                # the gradient leaves the level as fp32 (conv_L's backward), stays a pair otherwise
+                first = i == 0
+                d32, d16 = K.conv3x3_p16(dh16, wp, mp, Cc, res=d32 if d32 is not None else d16, mask=a if first else None,
+                                         want32=first, want16=not first)
+            d = d32
+        else:
+            for i in reversed(range(cnt[lvl])):
+                bp = f'{pre}blk_L{k}.{i}.'
+                x_in, h = blocks[i]
+                w1, w2 = P[bp + 'conv1.weight'], P[bp + 'conv2.weight']
+                Cc = w1.shape[0]
+                with K.on_side(h, d):
+                    gw, G[bp + 'conv2.bias'] = K.conv_wgrad(h, d, Cc, Cc, 3, pad=1, want_db=True)
+                    G[bp + 'conv2.weight'] = gw.view(Cc, Cc, 3, 3)
+                wp, mp, *_ = K.pack_weights(w2, PACK_DGRAD_S1)
+                dh = K.conv_forward(d, wp, mp, Cc, 3, pad=1, mask=h)
+                with K.on_side(x_in, dh):
+                    gw, G[bp + 'conv1.bias'] = K.conv_wgrad(x_in, dh, Cc, Cc, 3, pad=1, want_db=True)
+                    G[bp + 'conv1.weight'] = gw.view(Cc, Cc, 3, 3)
+                wp, mp, *_ = K.pack_weights(w1, PACK_DGRAD_S1)
+                # the first block's input is the level's ReLU output `a`: its mask rides on this epilogue (conv + res, then mask)
+                d = K.conv_forward(dh, wp, mp, Cc, 3, pad=1, res=d, mask=a if i == 0 else None)
         dpre = d if cnt[lvl] > 0 else K.relu_bwd(d, a)
         w = P[f'{pre}conv_L{k}.weight']
         # the feature gradient of the level below joins in the data-gradient epilogue instead of a separate add

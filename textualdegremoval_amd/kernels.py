@@ -564,6 +564,9 @@ def conv3x3_p16(x16, wp, Mpad, Cout, bias=None, res=None, mask=None, relu=False,
         o16 = P16.empty(x16.N, Cout, x16.H, x16.W, x16.buf.device)
         d.out16 = o16.data_ptr()
     check(lib.tdr_conv3x3_p16(C.byref(d), _stream()), 'tdr_conv3x3_p16')
+    if _survey is not None and o16 is not None:
+        # the pair planes are the operands of the next contraction: their fp32 value must sit inside the fp16 window
+        _survey.probe(o32 if o32 is not None else o16.to_f32(), 'grad' if BACKWARD_PHASE else 'fwd')
     return o32, o16
 
 
