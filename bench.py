@@ -143,13 +143,34 @@ def f32_exact_run(args):
         return {'ms_per_step': None, 'note': f'failed: {type(e).__name__}'}
 
 
+def bx3_run(args):
+    """the same workload with EVERY dense contraction on the 3-way bf16 split (TDR_MATH=bx3: 24-bit operand significands over the
+    whole fp32 exponent range, no loss scale, no step guard, fp32 tensors everywhere): the no-asterisk fp32-equivalent number"""
+    try:
+        r = _child_bench(args, ['--steps', '5', '--warmup', '2'], env={'TDR_MATH': 'bx3'})
+        out = {'ms_per_step': r['ms_per_step'], 'value': r['value'], 'unit': r['unit'], 'steps': r['steps'], 'dtype': r['dtype'],
+               'arithmetic': '3-way bf16 split (6 bf16 MFMA products per fp32 product, fp32 accumulate) in both passes, unscaled gradients'}
+        if 'roofline_step' in r:
+            out['roofline_step'] = r['roofline_step']
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {'ms_per_step': None, 'note': f'failed: {type(e).__name__}'}
+
+
 def matcher_active_run(args, ref_size=640):
     """the same step with a reference LARGER than lq (the situation of the shipped YAMLs: 384x384 crops against 512x512
     generated references, image_restoration_ref_model.py:219-247): the frozen DINOv2 ViT-B/14 window matcher runs every step"""
     try:
         r = _child_bench(args, ['--steps', '5', '--warmup', '2', '--dino-ref-size', str(ref_size)])
-        return {'ms_per_step': r['ms_per_step'], 'value': r['value'], 'unit': r['unit'], 'steps': r['steps'],
-                'dino_match': r['config']['dino_match'], 'guard': r.get('guard')}
+        out = {'ms_per_step': r['ms_per_step'], 'value': r['value'], 'unit': r['unit'], 'steps': r['steps'],
+               'dino_match': r['config']['dino_match'] + '; matcher arithmetic = the step\'s fp32-faithful split (default since round 4)',
+               'guard': r.get('guard')}
+        try:      # the opt-in single-product matcher (TDR_DINO_MATH=h1: arg-max pinned on random-init weights only)
+            h = _child_bench(args, ['--steps', '5', '--warmup', '2', '--dino-ref-size', str(ref_size)], env={'TDR_DINO_MATH': 'h1'})
+            out['h1_matcher_opt_in'] = {'ms_per_step': h['ms_per_step'], 'value': h['value']}
+        except Exception:  # noqa: BLE001
+            pass
+        return out
     except Exception as e:  # noqa: BLE001
         return {'ms_per_step': None, 'note': f'failed: {type(e).__name__}'}
 
@@ -221,14 +242,14 @@ def bench_i2t(a, world, rank, local):
     print(json.dumps(line), flush=True)
 
 
-def pmc_traffic(prefix):
-    """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/pmc_collect.sh -> profiles/r<N>/
-    pmc_traffic.json).  The file records the hash of the kernel source it was collected on: a mismatch means the counters
-    describe an older kernel and the figure is reported as stale (null) instead of being passed off as current."""
+def pmc_traffic(prefixes):
+    """HBM bytes per launch of a kernel family (kernel-name prefixes) from the committed PMC passes (profiles/pmc_collect.sh ->
+    profiles/r<N>/pmc_traffic.json).  The file records the hashes of the kernel sources it was collected on: a mismatch means the
+    counters describe older kernels and the figure is reported as stale (null) instead of being passed off as current."""
     import hashlib
-    src = os.path.join(ROOT, 'textualdegremoval_amd', 'csrc', 'tdr_conv_bx3.hip')
+    srcs = {'tdr_conv_bx3_sha256': 'tdr_conv_bx3.hip', 'tdr_conv_p16_sha256': 'tdr_conv_p16.hip'}
     pmc = path = None
-    for rnd in ('r3', 'r2'):                 # newest collection first
+    for rnd in ('r4', 'r3', 'r2'):                 # newest collection first
         cand = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')
         try:
             with open(cand) as fh:
@@ -236,24 +257,39 @@ def pmc_traffic(prefix):
             break
         except (OSError, ValueError):
             continue
-    try:
-        with open(src, 'rb') as fh:
-            cur = hashlib.sha256(fh.read()).hexdigest()
-    except OSError:
-        cur = None
     if pmc is None:
         return None, 'no PMC file (profiles/pmc_collect.sh not run)'
-    if pmc.get('meta', {}).get('tdr_conv_bx3_sha256') != cur:
-        return None, f'stale: {path} was collected on another revision of csrc/tdr_conv_bx3.hip'
+    for key, fn in srcs.items():
+        try:
+            with open(os.path.join(ROOT, 'textualdegremoval_amd', 'csrc', fn), 'rb') as fh:
+                cur = hashlib.sha256(fh.read()).hexdigest()
+        except OSError:
+            cur = None
+        if pmc.get('meta', {}).get(key) != cur:
+            return None, f'stale: {path} was collected on another revision of csrc/{fn}'
     tot, n = 0.0, 0
     for name, v in pmc['kernels'].items():
-        if name.startswith(prefix):
+        if any(name.startswith(p) for p in prefixes):
             tot += (v['read_bytes_per_launch'] + v['write_bytes_per_launch']) * v['launches']
             n += v['launches']
     if not n:
         return None, 'kernel family not in the PMC file'
-    return tot / n, ('bytes/launch of the KH=3,S=1 family (FETCH_SIZE + WRITE_SIZE in separate passes, calibrated on copies of '
-                     f'known size, {path}; collected on this revision of the kernel source)')
+    return tot / n, ('bytes/launch of the 3x3 stride-1 forward + data-gradient family (FETCH_SIZE + WRITE_SIZE in separate passes, calibrated '
+                     f'on copies of known size, {path}; collected on this revision of the kernel sources)')
+
+
+def pmc_step_bytes():
+    """measured HBM bytes of one whole train step from the same PMC collection (sum over every kernel of the step), or None"""
+    for rnd in ('r4', 'r3'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')) as fh:
+                pmc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        tot = pmc.get('meta', {}).get('step_total_bytes')
+        if tot:
+            return float(tot), f'profiles/{rnd}/pmc_traffic.json'
+    return None, None
 
 
 def main():
@@ -388,20 +424,54 @@ def main():
     # (every rank runs the instrumented step -- it contains the gradient all-reduce -- but only rank 0 reports)
     roof, roof_other = None, []
     if not a.no_roofline:
-        recs = []
+        recs = []          # (flop, e0, e1, alg bytes, family key)
         orig = K.conv_forward
+        orig_p16, orig_wg, orig_wg16 = K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16
+
+        def _ev():
+            return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
         def timed(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, **kw):
             if KH == 3 and stride == 1 and dil == 1 and kw.get('wp_ns', 0) == 0:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = _ev()
                 e0.record()
                 out = orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
                 e1.record()
                 recs.append((2.0 * x.shape[0] * Cout * x.shape[1] * 9 * out.shape[2] * out.shape[3], e0, e1,
-                             4.0 * (x.numel() + out.numel()), getattr(wp, 'fmt', 0)))
+                             4.0 * (x.numel() + out.numel()), ('conv', getattr(wp, 'fmt', 0))))
                 return out
             return orig(x, wp, Mpad, Cout, KH, stride=stride, dil=dil, pad=pad, **kw)
-        K.conv_forward = timed
+
+        def timed_p16(x16, wp, Mpad, Cout, **kw):
+            e0, e1 = _ev()
+            e0.record()
+            out = orig_p16(x16, wp, Mpad, Cout, **kw)
+            e1.record()
+            px = x16.N * x16.H * x16.W
+            nout = (1 if kw.get('want32', True) else 0) + (1 if kw.get('want16', False) else 0)
+            recs.append((2.0 * px * Cout * x16.C * 9, e0, e1, 4.0 * px * (x16.C + nout * Cout), ('conv', 'p16')))
+            return out
+
+        def timed_wg(x, dout, Cout, Cin, KH, **kw):
+            if kw.get('per_image') or kw.get('stride', 1) != 1:
+                return orig_wg(x, dout, Cout, Cin, KH, **kw)
+            e0, e1 = _ev()
+            e0.record()
+            out = orig_wg(x, dout, Cout, Cin, KH, **kw)
+            e1.record()
+            recs.append((2.0 * dout.shape[0] * Cout * Cin * KH * KH * dout.shape[2] * dout.shape[3], e0, e1,
+                         4.0 * (dout.shape[0] * Cin * x.shape[2] * x.shape[3] + dout.numel()), ('wgrad', KH)))
+            return out
+
+        def timed_wg16(x16, d16, **kw):
+            e0, e1 = _ev()
+            e0.record()
+            out = orig_wg16(x16, d16, **kw)
+            e1.record()
+            px = x16.N * x16.H * x16.W
+            recs.append((2.0 * px * d16.C * x16.C * 9, e0, e1, 4.0 * px * (x16.C + d16.C), ('wgrad', 'p16')))
+            return out
+        K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16 = timed, timed_p16, timed_wg, timed_wg16
         graph_was = getattr(model, 'use_hip_graph', False)
         model.use_hip_graph = False                       # instrumented step runs eagerly (a replayed graph makes no Python calls)
         try:
@@ -419,34 +489,48 @@ def main():
             step(it)
             torch.cuda.synchronize()
         finally:
-            K.conv_forward = orig
+            K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16 = orig, orig_p16, orig_wg, orig_wg16
             model.use_hip_graph = graph_was
-        # the family splits by operand scheme if a step mixes them (TDR_GRAD_SCALE=0 under hx2: forward launches on the 2-way
-        # fp16 split, data-gradient launches on the 3-way bf16 split); `roofline` is the scheme with the larger total time,
-        # the other goes to roofline_other
-        FAM = {0: ('conv_mfma_kernel<KH=3,S=1> (exact fp32 v_mfma_f32_32x32x2_f32)', PEAK_F32, 'dense fp32 MFMA peak'),
-               1: ('conv_bx3_kernel<KH=3,S=1,SCH_BX3> (3-way bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)',
-                   PEAK_BX3, '2.5 PFLOP/s dense bf16 MFMA / 6 cross products = fp32-equivalent peak of the split scheme'),
-               2: ('conv_bx3_kernel<KH=3,S=1,SCH_HX2> (2-way fp16 split, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)',
-                   PEAK_BF16 / 3.0, '2.5 PFLOP/s dense f16 MFMA / 3 cross products = fp32-equivalent peak of the split scheme')}
-        fams = {}
-        for fmt in sorted({r[4] for r in recs}):
-            rr = [r for r in recs if r[4] == fmt]
+        # `roofline` = the family VERDICT names: every 3x3 / stride-1 forward + data-gradient launch of the step, whichever kernel
+        # runs it (the fp32-tensor kernel conv_bx3_kernel / conv_mfma_kernel and, since round 4, conv3x3_p16_kernel on pre-split
+        # operands), priced against the fp32-equivalent ceiling of the operand scheme that carries most of its time; `by_kernel`
+        # splits it.  `roofline_other`: the weight-gradient families (kernel + its split-K reduction) from the same instrumented step.
+        PEAK_HX2 = PEAK_BF16 / 3.0
+        CONV = {0: ('conv_mfma_kernel<KH=3,S=1> (exact fp32 v_mfma_f32_32x32x2_f32)', PEAK_F32, 'dense fp32 MFMA peak'),
+                1: ('conv_bx3_kernel<KH=3,S=1,SCH_BX3> (3-way bf16 split, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)',
+                    PEAK_BX3, '2.5 PFLOP/s dense bf16 MFMA / 6 cross products = fp32-equivalent peak of the split scheme'),
+                2: ('conv_bx3_kernel<KH=3,S=1,SCH_HX2> (fp32 tensors in, 2-way fp16 split per consumer, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)',
+                    PEAK_HX2, '2.5 PFLOP/s dense f16 MFMA / 3 cross products = fp32-equivalent peak of the split scheme'),
+                'p16': ('conv3x3_p16_kernel (pre-split fp16 pair planes in and out, both operands by LDS-DMA, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)',
+                        PEAK_HX2, '2.5 PFLOP/s dense f16 MFMA / 3 cross products = fp32-equivalent peak of the split scheme')}
+
+        def entry(rr, name, pk, note):
             fl = sum(r[0] for r in rr)
             ms = sum(r[1].elapsed_time(r[2]) for r in rr)
             ach = fl / (ms * 1e-3) / 1e12
-            name, pk, note = FAM[fmt]
-            fams[fmt] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': pk / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (pk / 1e12),
-                         'peak_note': note, 'frac_of_f32_mfma_peak': ach / (PEAK_F32 / 1e12), 'launches': len(rr),
-                         'avg_launch_ms': ms / max(len(rr), 1), 'alg_flop_per_launch': fl / max(len(rr), 1), 'traffic': None,
-                         'alg_bytes_per_launch': sum(r[3] for r in rr) / max(len(rr), 1), '_total_ms': ms}
-        order = sorted(fams, key=lambda f: -fams[f]['_total_ms'])
-        roof = fams[order[0]]
-        roof_other = [fams[f] for f in order[1:]]
-        bx3 = order[0] != 0
-        # HBM bytes per launch of the same kernel family from the PMC passes of this round
-        roof['traffic'], roof['traffic_unit'] = pmc_traffic('conv_bx3_kernel<3, 1,' if bx3 else 'conv_mfma_kernel<3, 1, 1,')
-        for f in fams.values():
+            return {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': pk / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (pk / 1e12),
+                    'peak_note': note, 'frac_of_f32_mfma_peak': ach / (PEAK_F32 / 1e12), 'launches': len(rr),
+                    'avg_launch_ms': ms / max(len(rr), 1), 'alg_flop_per_launch': fl / max(len(rr), 1), 'traffic': None,
+                    'alg_bytes_per_launch': sum(r[3] for r in rr) / max(len(rr), 1), '_total_ms': ms}
+        conv = [r for r in recs if r[4][0] == 'conv']
+        subs = {k: entry([r for r in conv if r[4][1] == k], *CONV[k]) for k in sorted({r[4][1] for r in conv}, key=str)}
+        if subs:
+            lead = max(subs, key=lambda k: subs[k]['_total_ms'])
+            split = [k for k in subs if CONV[k][1] == CONV[lead][1]]          # kernels priced against the same ceiling
+            roof = entry([r for r in conv if r[4][1] in split], ' + '.join(CONV[k][0] for k in split), CONV[lead][1], CONV[lead][2])
+            roof['by_kernel'] = [dict(subs[k]) for k in split]
+            roof_other = [subs[k] for k in subs if k not in split]
+            prefixes = {0: 'conv_mfma_kernel<3, 1, 1,', 1: 'conv_bx3_kernel<3, 1,', 2: 'conv_bx3_kernel<3, 1,', 'p16': 'conv3x3_p16_kernel'}
+            roof['traffic'], roof['traffic_unit'] = pmc_traffic(sorted({prefixes[k] for k in split}))
+        WG = {3: 'wgrad_bx3_kernel<KH=3> + wgrad_reduce_kernel (fp32 tensors in, operand split + v_alignbit fragment assembly per consumer)',
+              1: 'wgrad_bx3_kernel<KH=1> + wgrad_reduce_kernel (1x1 weight gradients of the NAFBlock chains, split-K partials)',
+              'p16': 'wgrad3x3_p16_kernel + wgrad_p16_reduce_kernel (pre-split pair planes, transposed LDS reads, no operand VALU)'}
+        for k in sorted({r[4][1] for r in recs if r[4][0] == 'wgrad'}, key=str):
+            e = entry([r for r in recs if r[4] == ('wgrad', k)], WG.get(k, f'wgrad KH={k}'),
+                      PEAK_HX2 if K.MATH in ('hx2', 'h1') else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32),
+                      'fp32-equivalent ceiling of the step\'s operand scheme; time = kernel + its fixed-order split-K reduction (HIP events around both)')
+            roof_other.append(e)
+        for f in ([roof] if roof else []) + roof_other + (roof.get('by_kernel', []) if roof else []):
             f.pop('_total_ms', None)
 
     if rank == 0:
@@ -459,7 +543,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None,
             # what the number is: tensors, accumulators, optimiser and reductions are fp32 in every mode; `dtype` names how the dense
             # contractions are evaluated on the matrix cores (the only place the modes differ)
-            'dtype': {'hx2': 'f32 (2xfp16-split MFMA: 22-bit operand significands, fp32 accumulate; loss-scaled backward)',
+            'dtype': {'hx2': 'f32 (2xfp16-split MFMA: 22-bit operand significands, fp32 accumulate; loss-scaled backward; the MASA-encoder '
+                             'ResidualBlock activations / gradients are stored as the fp16 pair (head + residual, 4 bytes) instead of fp32)',
                       'bx3': 'f32 (3xbf16-split MFMA: 24-bit operand significands, fp32 accumulate)',
                       'h1': 'f16 (single fp16 MFMA product, fp32 accumulate; reduced precision)',
                       'f32': 'f32 (exact fp32 MFMA)'}[K.MATH],
@@ -476,7 +561,10 @@ def main():
                             'per-product error <= one fp32 rounding, see profiles/r1/bf16x3_probe_mi355x.log; TDR_MATH=f32 selects exact fp32 MFMA',
                      'hx2': 'fp32 tensors; dense contractions as 2-way fp16 split (3 f16 MFMA products per fp32 product, fp32 accumulate), '
                             'the backward pass on gradients scaled by an exact power of two (dpred ~ 2^9, removed when the parameter '
-                            'gradients are gathered); per-image correlations as 3-way bf16 split / exact fp32: measured error of the split '
+                            'gradients are gathered); the 3x3 ResidualBlock convolutions of the MASA encoder (C >= 64) read and write their '
+                            'activations / gradients pre-split (csrc/tdr_conv_p16.hip: the pair IS the stored tensor there, 22-23 significant '
+                            'bits incl. the residual stream; TDR_P16=0 restores fp32 tensors + per-consumer split); '
+                            'per-image correlations as 3-way bf16 split / exact fp32: measured error of the split '
                             'schemes = that of the exact fp32 MFMA chain (profiles/r1/fp16x2_probe_mi355x.log, bf16x3_probe_mi355x.log, '
                             'grad_range_survey_cfg2.log); TDR_MATH=bx3 / f32 select the all-bf16-split / exact fp32 MFMA paths',
                      'h1': 'fp32 tensors; dense contractions on plain fp16 MFMA (operands rounded to one fp16 plane, ONE product, fp32 '
@@ -523,6 +611,12 @@ def main():
             if nprod:      # fp32-equivalent ceiling of the split scheme in use: 2.5 PFLOP/s dense f16 / bf16 MFMA over its products
                 line['roofline_step']['achieved_split_flop_frac'] = CFG2['F_alg'] * per_gpu / (PEAK_BF16 / nprod)
                 line['roofline_step']['split_peak_tflops'] = PEAK_BF16 / nprod / 1e12
+            # what the counters say really moves per step (all kernels, PMC passes of profiles/pmc_collect.sh) against the same clock
+            mb, mpath = pmc_step_bytes()
+            if mb:
+                line['roofline_step']['measured_hbm_bytes'] = mb
+                line['roofline_step']['measured_hbm_frac'] = mb / (dt / a.steps) / PEAK_HBM
+                line['roofline_step']['measured_hbm_source'] = mpath + ' (FETCH_SIZE + WRITE_SIZE over every kernel of an eager step)'
         if roof is not None:
             line['roofline'] = roof
             if roof_other:
@@ -535,6 +629,8 @@ def main():
                                      'alg_bytes_per_image': CFG3['B_alg'], 'alg_flop_per_image': CFG3['F_alg']}
         if not a.no_f32_exact and world == 1 and K.MATH != 'f32':
             line['f32_exact'] = f32_exact_run(a)
+            if K.MATH != 'bx3' and is_cfg2:
+                line['bx3'] = bx3_run(a)
         if not a.no_matcher_active and world == 1 and is_cfg2 and a.dino_ref_size <= a.size:
             line['matcher_active'] = matcher_active_run(a)
         if not a.no_cpu_baseline and world == 1 and a.arch == 'nafnet':

@@ -20,6 +20,9 @@
 extern "C" {
 #endif
 
+/* C-ABI version: bumped with every incompatible change of this header (100 rounds 1-2, 101 round 3, 102 round 4); the
+ * binding (textualdegremoval_amd/_lib.py) refuses a library whose version differs from the one it was written against. */
+#define TDR_ABI_VERSION 102
 int tdr_version(void);
 const char* tdr_last_error(void);
 

@@ -12,7 +12,14 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write 
 cd "$root" && python profiles/pmc_summarize.py /tmp/pmc_fetch /tmp/pmc_write > /tmp/pmc_traffic_raw.json && python - "$out" <<'PY'
 import hashlib, json, sys
 d = json.load(open('/tmp/pmc_traffic_raw.json'))
-d['meta'] = {'tdr_conv_bx3_sha256': hashlib.sha256(open('textualdegremoval_amd/csrc/tdr_conv_bx3.hip', 'rb').read()).hexdigest(),
+sha = lambda fn: hashlib.sha256(open('textualdegremoval_amd/csrc/' + fn, 'rb').read()).hexdigest()
+# whole-step HBM bytes: every kernel of the 3 profiled eager steps except the calibration copies and the fp16-window survey probes
+# (absmax_bits_*: they run in surveyed eager steps only, one step in 1000 of a training run)
+skip = ('rows_kernel', 'rows_scalar_kernel', 'absmax_bits')
+step_total = sum((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) * v['launches'] for k, v in d['kernels'].items()
+                 if not any(s in k for s in skip)) / 3.0
+d['meta'] = {'tdr_conv_bx3_sha256': sha('tdr_conv_bx3.hip'), 'tdr_conv_p16_sha256': sha('tdr_conv_p16.hip'),
+             'step_total_bytes': step_total, 'steps_profiled': 3,
              'workload': 'profiles/pmc_workload.py (BASELINE configs[1], eager steps)', 'collected_by': 'profiles/pmc_collect.sh'}
 json.dump(d, open(sys.argv[1], 'w'), indent=1)
 print('wrote', sys.argv[1], len(d['kernels']), 'kernels')

@@ -22,7 +22,7 @@ def matcher(request):
     prev = K.MATH
     K.set_math(request.param)
     sd = D.synth_vit_params(32, 2, 2, seed=11)
-    yield DinoMatcher(sd, torch.device('cuda'), heads=2, linear_math=request.param), sd      # (the default would be 'h1' under hx2)
+    yield DinoMatcher(sd, torch.device('cuda'), heads=2, linear_math=request.param), sd
     K.set_math(prev)
 
 
@@ -149,11 +149,13 @@ def test_single_product_linears_keep_every_match_decision():
         assert np.array_equal(idx.cpu().numpy(), gold['match_index']) and torch.equal(ref_in.cpu(), o_ref_in)
         assert (corr.cpu() - o_corr).abs().max().item() < 5e-3
         sdb = random_vit_b14_state_dict(seed=1, depth=12)
-        a, b = DinoMatcher(sdb, torch.device('cuda'), linear_math='hx2'), DinoMatcher(sdb, torch.device('cuda'))     # default: 'h1'
+        # the default is the fp32-faithful split (round 4: 'h1' is opt-in -- its arg-max is only pinned on random-init weights)
+        assert DinoMatcher(sdb, torch.device('cuda')).linear_math is None and not DinoMatcher(sdb, torch.device('cuda')).tok16
+        a, b = DinoMatcher(sdb, torch.device('cuda'), linear_math='hx2'), DinoMatcher(sdb, torch.device('cuda'), linear_math='h1')
         assert b.linear_math == 'h1' and b.tok16 and not a.tok16          # b: the token-major fp16 pipeline (csrc/tdr_tok16.hip)
         os.environ['TDR_DINO_TOK16'] = '0'
         try:
-            c = DinoMatcher(sdb, torch.device('cuda'))                       # the same arithmetic on the channel-major engines
+            c = DinoMatcher(sdb, torch.device('cuda'), linear_math='h1')    # the same arithmetic on the channel-major engines
         finally:
             del os.environ['TDR_DINO_TOK16']
         xs = images(3, 126, 126, seed=77).cuda()

@@ -15,6 +15,7 @@ import torch  # noqa: F401  (import order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TDR_LIB_PATH', os.path.join(_HERE, 'libtdr_hip.so'))   # override: profiling probe builds
 
+ABI_VERSION = 102      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
 c_fp = C.c_void_p      # device pointers travel as integers
 i32, i64, f32 = C.c_int, C.c_int64, C.c_float
 
@@ -304,6 +305,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    have = lib.tdr_version()
+    if have != ABI_VERSION:
+        raise TdrError(f'{LIB_PATH} exports C-ABI version {have}, this package binds version {ABI_VERSION}: a stale build would be '
+                       'called with shifted arguments -- rebuild it (python -c "import __graft_entry__ as g; g.build()")')
     _lib = lib
     return lib
 

@@ -21,12 +21,14 @@ LN_EPS = 1e-6
 
 class DinoMatcher:
     def __init__(self, state_dict, device, patch=14, heads=12, interpolate_offset=0.1, linear_math=None):
-        """linear_math: arithmetic of the frozen Linears and of the attention (TDR_DINO_MATH overrides; default 'h1' under
-        TDR_MATH=hx2, else kernels.MATH).  'h1' runs them as ONE
-        fp16 MFMA product per operand pair (11-bit operands, fp32 accumulate) instead of the 3 of the 2-way split: nothing but an
-        arg-max over window similarities leaves this sub-graph, so it is admissible exactly as long as that index
-        does not move -- tests/test_hip_dino.py pins it on the reference goldens and on a sweep against the split arithmetic."""
-        self.linear_math = linear_math or os.environ.get('TDR_DINO_MATH') or ('h1' if K.MATH == 'hx2' else None)
+        """linear_math: arithmetic of the frozen Linears and of the attention (TDR_DINO_MATH overrides; default: kernels.MATH,
+        i.e. the fp32-faithful 2-way fp16 split under TDR_MATH=hx2).  'h1' runs them as ONE fp16 MFMA product per operand pair
+        (11-bit operands, fp32 accumulate; the token-major pipeline of csrc/tdr_tok16.hip) instead of the 3 of the split: nothing
+        but an arg-max over window similarities leaves this sub-graph, so it is admissible exactly as long as that
+        index does not move.  That is pinned on the reference goldens and on a sweep with random-init weights
+        (tests/test_hip_dino.py), NOT for trained DINOv2 weights on overlapping windows, where top-1 / top-2 margins can be
+        smaller than the ~1e-3 feature error -- hence opt-in (TDR_DINO_MATH=h1, 12 - 14 ms per step faster at ref 640^2)."""
+        self.linear_math = linear_math or os.environ.get('TDR_DINO_MATH') or None
         if self.linear_math not in (None, 'h1', 'hx2', 'bx3', 'f32'):
             raise ValueError(f'TDR_DINO_MATH / linear_math: {self.linear_math!r}')
         self.tok16 = False          # set below: the token-major fp16 pipeline (csrc/tdr_tok16.hip), the same 'h1' arithmetic

@@ -120,6 +120,7 @@ class MapperStacks:
 
     def __init__(self, mapper):
         G = self.G = mapper.num_words
+        self._slots = []
         P = dict(mapper.named_parameters())
         self.W, self.B, self.LW, self.LB = {}, {}, {}, {}
         for kind in KINDS:
@@ -139,11 +140,20 @@ class MapperStacks:
                     self._adopt(P[f'{kind}{i}.{j}.weight'], self.LW[kind, j][i])
                     self._adopt(P[f'{kind}{i}.{j}.bias'], self.LB[kind, j][i])
 
-    @staticmethod
-    def _adopt(p, slot):
+    def _adopt(self, p, slot):
         with torch.no_grad():
             slot.copy_(p.data)
             p.data = slot
+        self._slots.append((p, slot))
+
+    def verify(self):
+        """every parameter must still live in its stack slot: mapper.to() / .float() / .cuda() or a wrapper that re-allocates
+        parameters detaches them, and the grouped kernels would go on reading (and the optimiser stop updating) orphaned
+        buffers without any error.  Cheap (host-side pointer compares); called before every grouped forward."""
+        for p, slot in self._slots:
+            if p.data_ptr() != slot.data_ptr():
+                raise RuntimeError('MapperStacks: a Mapper parameter no longer aliases its stack slot (the module was moved or its '
+                                   'parameters were re-allocated after the stacks were built): rebuild with MapperStacks(mapper)')
 
 
 def _chain_fwd(x, st, kind):
@@ -186,6 +196,7 @@ def mapper_fwd_grouped(tok, B, T, st):
     -> ([B, words, Dout], saved)"""
     if B > 32:
         raise NotImplementedError('HIP Mapper: batch <= 32 per call (class tokens travel as one 32-pixel row)')
+    st.verify()
     G = st.G
     LD = tok.shape[2] * tok.shape[3] // B
     cls_in = K.gather_col_flat(tok, B, 0)                                            # embs[:, :1]

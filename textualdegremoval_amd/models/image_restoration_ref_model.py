@@ -335,6 +335,16 @@ class RefGuidedImageCleanModel(BaseModel):
                     cur[0].capture_end()
                 segs.append((cur[0], tail[0]))
                 st['pinned'] = red.pinned_tables      # host blocks the captured table uploads re-read on replay
+                if split:
+                    # every bucket must have been cut into the segment list: one whose parameters did not all receive a gradient in
+                    # the captured step never completes, is never exchanged on replay, and the replicas would silently diverge
+                    seen = {bi for _, bi in segs if bi is not None}
+                    missing = red.uncovered_buckets() or sorted(set(range(len(red.buckets))) - seen)
+                    if missing:
+                        logger.warning(f'captured step: gradient bucket(s) {missing} were not completed by the backward pass '
+                                       '(a parameter without a gradient): falling back to one flat all-reduce of the arena')
+                        split = False
+                        segs = [(g, None) for g, _ in segs]
                 self.optimizer_g.prepare()
                 gB = torch.cuda.CUDAGraph()
                 gB.capture_begin(pool=pool, capture_error_mode='thread_local')

@@ -173,6 +173,9 @@ class GradSink(dict):
         self.reducer._arrive(key, value)
 
 
+CAP_RING = 4          # capture passes whose pinned gather tables stay untouched (GradAllReducer._layout)
+
+
 class GradAllReducer:
     def __init__(self, named_params, bucket_mb=64, process_group=None):
         self.named = list(named_params)                  # [(name, param)] in registration order
@@ -231,9 +234,14 @@ class GradAllReducer:
                     sizes=torch.tensor([sizes[k] for k in ns], dtype=torch.int64).to(device),
                     ct=torch.tensor(ct, dtype=torch.int32).to(device), ci=torch.tensor(ci, dtype=torch.int32).to(device),
                     src=torch.empty(len(ns), dtype=torch.int64, device=device),
-                    # pinned source-pointer tables, allocated here (never inside a stream capture), used alternately
+                    # pinned source-pointer tables, allocated here (never inside a stream capture), used alternately by EAGER steps
                     host=[torch.empty(len(ns), dtype=torch.int64).pin_memory() for _ in range(2)],
-                    done=[None, None], flip=0))
+                    done=[None, None], flip=0,
+                    # tables of CAPTURED gathers: the upload node of a hipGraph re-reads its pinned block at every replay, so that
+                    # block must never be written again while the graph lives -- eager steps keep coming after a capture (the
+                    # fp16-window survey runs one every TDR_RANGE_CHECK_EVERY iterations) and own the two tables above.
+                    # One table per capture pass, a ring of CAP_RING passes (only the newest graphs of a model are replayed).
+                    cap=[torch.empty(len(ns), dtype=torch.int64).pin_memory() for _ in range(CAP_RING)], cap_i=0))
 
     # ---- per step -----------------------------------------------------------
     grad_unscale = 1.0          # 1 / (power-of-two loss scale of the backward pass); applied while gathering
@@ -286,11 +294,15 @@ class GradAllReducer:
         if not all(k in self._pending for k in tb['names']):
             return
         capturing = torch.cuda.is_current_stream_capturing()
-        slot = tb['flip']
-        tb['flip'] ^= 1
-        if tb['done'][slot] is not None and not capturing:
-            tb['done'][slot].synchronize()                # the upload that last read this table (two steps ago) has run
-        host = tb['host'][slot]
+        if capturing:
+            host = tb['cap'][tb['cap_i'] % CAP_RING]      # never touched by eager steps (see _layout)
+            tb['cap_i'] += 1
+        else:
+            slot = tb['flip']
+            tb['flip'] ^= 1
+            if tb['done'][slot] is not None:
+                tb['done'][slot].synchronize()            # the upload that last read this table (two steps ago) has run
+            host = tb['host'][slot]
         host.copy_(torch.tensor([self._pending[k].data_ptr() for k in tb['names']], dtype=torch.int64))
         self.pinned_tables.append(host)
         tb['src'].copy_(host, non_blocking=True)
@@ -300,6 +312,12 @@ class GradAllReducer:
         K.multi_copy(tb['src'], tb['dst'], tb['sizes'], tb['ct'], tb['ci'], tb['n_chunks'], scale=self.grad_unscale,
                      guard=self.guard)
         self._keep = [self._pending.pop(k) for k in tb['names']]   # sources stay referenced until the next gather is enqueued
+
+    def uncovered_buckets(self):
+        """bucket indices whose gather never ran in the step that just ended: a parameter of the bucket received no gradient
+        (`_bucket_left` never reached 0), so neither its gather nor its exchange was enqueued.  The captured step checks this
+        after a capture pass: a bucket missing from the segment list would silently never be all-reduced on replay."""
+        return [bi for bi, left in enumerate(self._bucket_left) if left != 0]
 
     def _launch(self, bi):
         if not self.collective:

@@ -148,8 +148,14 @@ class I2TMappingTrainer:
         self.mlp_names = [k for k in self.names if k.startswith('mapping_')]
         self.optimizer = FusedClipAdamW([{'params': self.params}], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                         max_norm=max_grad_norm, use_grad_clip=True)
+        # dist_on: average the gradients over the ranks of the initialised process group (accelerate's DDP over the Mapper, :662).
+        # True without a process group is an error; False keeps this trainer local even under a launcher.
         self.dist = bool(dist_on)
+        if self.dist and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise RuntimeError('I2TMappingTrainer(dist_on=True): torch.distributed is not initialised')
         self.reducer = GradAllReducer(list(zip(self.names, self.params)), bucket_mb=bucket_mb)
+        if not self.dist and os.environ.get('TDR_FORCE_COLLECTIVES') != '1':
+            self.reducer.collective, self.reducer.comm = False, None
         self._plan = K.PackPlan()
         # the Mapper as G-way grouped GEMMs over batch-flattened tokens (i2t.mapper_fwd_grouped); TDR_MAPPER_GROUPED=0 keeps the
         # 2 x num_words chains of small launches on four stream lanes
