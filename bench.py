@@ -341,7 +341,24 @@ def main():
         if a.backend == 'nccl':
             # the N-GPU line is an RCCL-through-the-C-ABI measurement or it is an error: no silent torch.distributed fallback
             os.environ.setdefault('TDR_COMM', 'rccl')
-        dist.init_process_group(a.backend)
+        import datetime
+        try:
+            dist.init_process_group(a.backend, timeout=datetime.timedelta(seconds=float(os.environ.get('TDR_PG_TIMEOUT', '120'))))
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f'bench.py: rank {rank}/{world}: torch.distributed rendezvous failed ({type(e).__name__}: {e})\n')
+            sys.exit(2)
+    try:
+        return _main_body(a, world, rank, local, enc)
+    except Exception as e:  # noqa: BLE001
+        from textualdegremoval_amd.parallel import DataPlaneUnavailable
+        if isinstance(e, DataPlaneUnavailable):
+            # one line, non-zero exit: the N-GPU line is an RCCL measurement or an error (the bring-up watchdog covers ranks that hang)
+            sys.stderr.write(f'bench.py: rank {rank}/{world}: RCCL data plane unavailable: {e}\n')
+            sys.exit(2)
+        raise
+
+
+def _main_body(a, world, rank, local, enc):
     if a.arch == 'i2t':
         bench_i2t(a, world, rank, local)
         if world > 1:

@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
     shapes = [(3,), (5, 4), (1, 6, 1, 1), (2, 2, 3, 3), (9,), (1,), (300,)]
     params = [(k, torch.nn.Parameter(torch.zeros(s))) for k, s in zip(names, shapes)]
     red = GradAllReducer(params, bucket_mb=0.0001)            # ~26-float buckets -> several buckets
-    full = torch.arange(1, 9, dtype=torch.float32)            # global batch of 8 "samples"
+    full = torch.arange(1, 2 * max(world, 4) + 1, dtype=torch.float32)   # global batch: 2 "samples" per rank (8 on the 2-rank test)
     shard = full[rank::world]                                 # rank-strided sharding (EnlargedSampler style)
     res = []
     for step in range(3):                                     # step 0 learns the arrival order, 1-2 use live buckets
@@ -64,6 +64,56 @@ def test_two_rank_gradient_average_equals_full_batch_gradient():
         assert max(res) < 1e-5, res
         assert nb >= 3, nb
     assert abs(out[0][3] - 1.5) < 1e-6          # rank 0 holds mean(1, 2)
+
+
+def _sampler_worker(rank, world, port, q):
+    """EnlargedSampler on every rank of an 8-rank job: the rank shards are disjoint, cover ratio x the data set exactly once per
+    epoch, and every rank draws the same permutation (seeded by the epoch) -- data/data_sampler.py:1-49 of the reference."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from textualdegremoval_amd.data.data_sampler import EnlargedSampler
+    ds = list(range(37))
+    sm = EnlargedSampler(ds, world, rank, ratio=3)
+    sm.set_epoch(5)
+    mine = list(iter(sm))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    q.put((rank, len(sm), gathered))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_gradient_average_and_sampler_shards():
+    """the first real N-GPU run happens on an 8-GPU node this repository never sees: the reducer's layout / bucket / mean logic and
+    the sampler's sharding are exercised here at world size 8 (gloo, CPU)."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(20) for p in ps]
+    for rank, res, nb, l0 in out:
+        assert max(res) < 1e-4, res           # mean over 8 ranks of values up to ~1e5: fp32 rounding of the sum order
+        assert nb >= 3, nb
+    assert abs(out[0][3] - 4.5) < 1e-6          # rank 0 holds mean(1..8)
+    port = _free_port()
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sampler_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(20) for p in ps]
+    import math
+    per = math.ceil(37 * 3 / world)
+    for rank, n, gathered in out:
+        assert n == per and all(len(g) == per for g in gathered)
+        flat = [i for g in gathered for i in g]
+        assert len(flat) == per * world and all(0 <= i < 37 for i in flat)
+        # total_size = per * world indices drawn from a permutation of ratio x dataset, reduced modulo the dataset size:
+        # every sample appears floor / ceil(total / 37) times
+        cnt = [flat.count(i) for i in range(37)]
+        assert max(cnt) - min(cnt) <= 1, cnt
+        assert gathered == out[0][2]            # every rank saw the same global assignment
 
 
 def test_single_process_reducer_is_identity():

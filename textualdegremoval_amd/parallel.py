@@ -91,7 +91,63 @@ def _agree(flag, group):
     return int(t.item()) == 1
 
 
+class _BringUpWatchdog:
+    """A rank that dies INSIDE the bring-up (ncclCommInitRank, or one of the side-channel collectives around it) leaves its peers
+    blocked in a call that never returns -- the MIN-agreements below only cover failures that come back as errors.  While this
+    context is open a timer thread ends the process with ONE line on stderr and exit code 3 when the bring-up has not finished
+    within TDR_COMM_INIT_TIMEOUT seconds (default 45): every surviving rank does so on its own, so `python bench.py --gpus N`
+    (torch.distributed.run) is down within a minute instead of hanging until torch's 10 - 30 minute collective timeout."""
+
+    def __init__(self, rank, world, what):
+        self.rank, self.world, self.what = rank, world, what
+        self.timeout = float(os.environ.get('TDR_COMM_INIT_TIMEOUT', '45'))
+        self.stage = 'start'
+        self._timer = None
+
+    def _die(self):
+        import sys
+        sys.stderr.write(f'[tdr] rank {self.rank}/{self.world}: {self.what} did not finish within {self.timeout:.0f} s (stuck in: '
+                         f'{self.stage}) -- a peer died or never entered the bring-up; see the other ranks\' stderr '
+                         '(TDR_COMM_INIT_TIMEOUT changes the limit).  Exiting with code 3.\n')
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        if self.timeout > 0:
+            self._timer = threading.Timer(self.timeout, self._die)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
+def _fault(point, rank):
+    """fault injection for the bring-up tests (tests/test_dp_bringup_faults.py): TDR_FAULT=<point>:<rank>[:hang] makes that rank
+    fail (raise) or hang (sleep past the watchdog) at `point` in {unique_id, init}.  Never set in production."""
+    spec = os.environ.get('TDR_FAULT')
+    if not spec:
+        return
+    parts = spec.split(':')
+    if parts[0] == point and int(parts[1]) == rank:
+        if len(parts) > 2 and parts[2] == 'hang':
+            import time
+            time.sleep(3600)
+        raise RuntimeError(f'injected fault at {point} on rank {rank} (TDR_FAULT)')
+
+
 def _resolve_plane(group):
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    with _BringUpWatchdog(dist.get_rank(group), dist.get_world_size(group), 'the RCCL data-plane bring-up (tdr_comm_*)') as wd:
+        return _resolve_plane_watched(group, wd)
+
+
+def _resolve_plane_watched(group, wd):
     mode = os.environ.get('TDR_COMM', 'auto')          # auto | rccl (strict: raise instead of falling back) | torch
     if mode == 'torch' or (mode == 'auto' and dist.get_backend(group) != 'nccl'):
         return None
@@ -109,8 +165,9 @@ def _resolve_plane(group):
     # never leave the ranks in mismatched collectives:
     #   1. all ranks agree that librccl resolves in their process BEFORE anyone touches ncclGetUniqueId / ncclCommInitRank
     from . import _lib
+    wd.stage = 'agreeing that librccl resolves on every rank'
     try:
-        loaded = bool(_lib.load().tdr_comm_available())
+        loaded = bool(_comm_available())
     except Exception:   # noqa: BLE001
         loaded = False
     if not _agree(loaded, group):
@@ -118,8 +175,10 @@ def _resolve_plane(group):
     #   2. rank 0 makes the id; a failure there travels in the broadcast as None (the broadcast itself always happens)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     box, err = [None], None
+    wd.stage = 'broadcast of rank 0\'s ncclUniqueId'
     if rank == 0:
         try:
+            _fault('unique_id', rank)
             box[0] = TdrComm.new_unique_id()
         except Exception as e:   # noqa: BLE001
             err = e
@@ -128,15 +187,23 @@ def _resolve_plane(group):
         return unavailable(f'ncclGetUniqueId failed on rank 0: {err}')
     #   3. all ranks enter ncclCommInitRank together, then agree on the outcome
     comm = None
+    wd.stage = 'ncclCommInitRank'
     try:
+        _fault('init', rank)
         comm = TdrComm(rank, world, box[0])
     except Exception as e:   # noqa: BLE001
         err = e
+    wd.stage = 'agreeing on the outcome of ncclCommInitRank'
     if not _agree(comm is not None, group):
         if comm is not None:
             comm.destroy()
         return unavailable(f'ncclCommInitRank failed on some rank: {err}')
     return comm
+
+
+def _comm_available():
+    from . import _lib
+    return _lib.load().tdr_comm_available()
 
 
 def data_plane(group=None):
