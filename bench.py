@@ -186,8 +186,11 @@ def bench_i2t(a, world, rank, local):
     from textualdegremoval_amd.clip_vision import random_clip_state_dict
     vit = {'H': (1280, 5120, 32, 16, 'gelu', 0.334e12), 'L': (1024, 4096, 24, 16, 'quick_gelu', 0.1626e12)}[a.clip]
     torch.manual_seed(0)
-    tr = SA.I2TMappingTrainer(random_clip_state_dict(vit[0], vit[1], vit[2]), vit[3], SA.stage_a_stub(seed=0), clip_act=vit[4],
-                              num_words=20, lr=1e-4 * a.batch * world, dist_on=world > 1, bucket_mb=a.bucket_mb)
+    # --arch tr: the textual-restoration mapping step (main_train_tr_mapping.py:757-812) -- frozen Mapper, trained CleanMapper (with the
+    # optimiser over the CleanMapper: the script as written updates nothing)
+    cls = SA.TRMappingTrainer if a.arch == 'tr' else SA.I2TMappingTrainer
+    tr = cls(random_clip_state_dict(vit[0], vit[1], vit[2]), vit[3], SA.stage_a_stub(seed=0), clip_act=vit[4],
+             num_words=20, lr=1e-4 * a.batch * world, dist_on=world > 1, bucket_mb=a.bucket_mb)
     batch = {k: v.cuda() for k, v in SA.synthetic_batch(a.batch, size=a.size, seed=rank).items()}
     for _ in range(4 + a.warmup):
         tr.step(batch)
@@ -218,14 +221,16 @@ def bench_i2t(a, world, rank, local):
     # MLPs see one token) + the cross-attention projections / products of the four levels (fwd + the dk / dv side of the backward)
     f_mapper = 3 * 2 * (tokens - 1 + 1) * (n_map / 2)
     ips = world * a.batch * a.steps / dt
-    line = {'metric': f'train images/sec (stage-A I2T mapping, {a.size}x{a.size}, bs={a.batch}/GPU)', 'value': ips, 'unit': 'images/sec',
+    line = {'metric': f'train images/sec (stage-A {"TR" if a.arch == "tr" else "I2T"} mapping, {a.size}x{a.size}, bs={a.batch}/GPU)', 'value': ips, 'unit': 'images/sec',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'hx2': 'f32 (2xfp16-split MFMA forward, 3xbf16-split MFMA backward; fp32 accumulate)', 'bx3': 'f32 (3xbf16-split MFMA)',
                       'f32': 'f32 (exact fp32 MFMA)', 'h1': 'f16 (single fp16 MFMA product)'}[K.MATH],
             'data': 'synthetic',
             'guard': {'skipped_total': int(g.skipped), 'applied_steps': int(g.step)},
-            'config': {'workload': f'BASELINE configs[3]: I2T-mapper training step, CLIP ViT-{a.clip}/14 frozen + Mapper(1280->1024, 20 words) + injected '
+            'config': {'workload': ('textual-restoration mapping step (main_train_tr_mapping.py:757-812): the stage-A pipeline with the Mapper and its to_k / '
+                                    'to_v FROZEN and a CleanMapper(1024->1024, 20 words) trained (optimiser over the CleanMapper: DESIGN R9); ' if a.arch == 'tr' else '') +
+                                   f'BASELINE configs[3]: I2T-mapper training step, CLIP ViT-{a.clip}/14 frozen + Mapper(1280->1024, 20 words) + injected '
                                    f'cross-attention at 4096/1024/256/64 tokens (to_k_global/to_v_global trained), MSE, clip 1.0, AdamW; SD UNet/VAE/text '
                                    f'transformer = fixed random linear stand-in (SURVEY 8d cfg4), {a.size}x{a.size}, bs={a.batch}/GPU',
                        'global_batch': world * a.batch, 'parallelism': f'dp{world}', 'trained_parameters': sum(p.numel() for p in tr.params),
@@ -298,7 +303,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--clip', default='H', choices=['H', 'L'], help='--arch i2t: CLIP ViT-H/14 (SD-2.1, the Mapper input width 1280) or ViT-L/14 geometry')
-    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc', 'i2t'],
+    ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc', 'i2t', 'tr'],
                     help="nafnet: the headline workload (BASELINE configs[1]); restormer: configs[2]'s per-GPU workload "
                          '(Restormer-ref dim 48, 256x256, bs 8) -- a secondary measurement, not the metric line')
     ap.add_argument('--batch', type=int, default=None)
@@ -359,7 +364,7 @@ def main():
 
 
 def _main_body(a, world, rank, local, enc):
-    if a.arch == 'i2t':
+    if a.arch in ('i2t', 'tr'):
         bench_i2t(a, world, rank, local)
         if world > 1:
             dist.barrier()

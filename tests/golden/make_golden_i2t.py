@@ -35,8 +35,8 @@ def sample(t, n=16):
     return f[::step][:n].numpy().copy()
 
 
-def load_reference_defs(names):
-    src = open(REF_SCRIPT).read()
+def load_reference_defs(names, script=None):
+    src = open(script or REF_SCRIPT).read()
     tree = ast.parse(src)
     import types
     from typing import Optional, Tuple, Union
@@ -130,6 +130,29 @@ def mapper_case():
     print('mapper', out.shape, float(out.abs().mean()))
 
 
+def clean_mapper_case():
+    """`CleanMapper` (scripts/train/main_train_tr_mapping.py:84-120), executed from the reference file: forward on the words of a
+    Mapper-shaped input, gradient w.r.t. every parameter and w.r.t. the input words."""
+    ns = load_reference_defs({'CleanMapper'}, script='/root/reference/scripts/train/main_train_tr_mapping.py')
+    din, dout, words, B = 40, 40, 3, 2
+    cm = ns['CleanMapper'](input_dim=din, output_dim=dout, num_words=words)
+    P = IO.synth_clean_mapper_params(din, 1280, dout, words, seed=6)
+    assert sorted(P.keys()) == sorted(cm.state_dict().keys())
+    cm.load_state_dict(P)
+    g = torch.Generator().manual_seed(10)
+    inj = torch.randn(B, words, din, generator=g, requires_grad=True)
+    out = cm(inj)
+    go = torch.randn(out.shape, generator=g)
+    (out * go).sum().backward()
+    names = list(cm.state_dict().keys())                                      # registration order of the reference class
+    sdp = dict(cm.named_parameters())
+    d = dict(inj=inj.detach().numpy(), out=out.detach().numpy(), go=go.numpy(), dinj=inj.grad.numpy(), cfg=np.array([din, dout, words, B]),
+             names=np.array(names), grad_norm=np.array([sdp[k].grad.double().norm().item() for k in names]),
+             grad_sample=np.stack([np.pad(sample(sdp[k].grad, 8), (0, 8 - min(8, sdp[k].grad.numel()))) for k in names]))
+    np.savez_compressed(os.path.join(HERE, 'i2t_clean_mapper.npz'), **d)
+    print('clean mapper', out.shape, float(out.abs().mean()))
+
+
 def cross_attention_case():
     ns = load_reference_defs({'inj_forward_crossattention', 'reshape_heads_to_batch_dim', 'reshape_batch_dim_to_heads'})
 
@@ -220,11 +243,15 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'text_inject':
         text_injection_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'clean_mapper':
+        clean_mapper_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'clip_full':
         clip_full_geometry_cases()
         sys.exit(0)
     clip_cases()
     clip_full_geometry_cases()
     mapper_case()
+    clean_mapper_case()
     cross_attention_case()
     text_injection_case()

@@ -178,6 +178,96 @@ def test_draws_noise_and_timesteps_when_absent(K):
     assert np.isfinite(l)
 
 
+# ---------------------------------------------------------------------------------------------- f4: CleanMapper + the TR-mapping step
+def test_clean_mapper_module_vs_reference_golden(K, golden_dir):
+    """i2t.CleanMapper (same ctor / parameter names as main_train_tr_mapping.py:84-120, grouped kernels) against vectors produced
+    by the reference class itself: output, gradient of the input words, every parameter gradient (norm + samples)."""
+    from textualdegremoval_amd.i2t import CleanMapper
+    g = np.load(os.path.join(golden_dir, 'i2t_clean_mapper.npz'))
+    din, dout, words, B = [int(v) for v in g['cfg']]
+    cm = CleanMapper(din, dout, words)
+    assert [k for k, _ in cm.named_parameters()] == [str(k) for k in g['names']]          # registration order of the reference class
+    cm.load_state_dict(IO.synth_clean_mapper_params(din, 1280, dout, words, seed=6))
+    cm = cm.cuda()
+    inj = torch.from_numpy(g['inj']).cuda().requires_grad_(True)
+    out = cm(inj)
+    assert maxdiff(out, torch.from_numpy(g['out'])) < 1e-4
+    (out * torch.from_numpy(g['go']).cuda()).sum().backward()
+    assert maxdiff(inj.grad, torch.from_numpy(g['dinj'])) < 2e-4 * max(1.0, float(np.abs(g['dinj']).max()))
+    sdp = dict(cm.named_parameters())
+    for k, gn in zip(g['names'], g['grad_norm']):
+        got = sdp[str(k)].grad.double().norm().item()
+        assert abs(got - gn) <= 5e-3 * gn + 1e-7, (str(k), got, gn)
+
+
+def _tr_setup(words=3, seed=0):
+    SA, S, clip_sd, batch, P = _small_setup(words, seed=seed)
+    Pc = IO.synth_clean_mapper_params(1024, 1280, 1024, words, seed=11 + seed)
+    from textualdegremoval_amd.i2t import CleanMapper
+    cm = CleanMapper(1024, 1024, words)
+    cm.load_state_dict(Pc)
+    tr = SA.TRMappingTrainer(clip_sd, 4, S, clean_mapper=cm, clip_act='quick_gelu', num_words=words, levels=SMALL_LEVELS,
+                             use_hip_graph=False, clip_image_size=56)
+    tr.mapper.load_state_dict(dict(P), strict=True)
+    return SA, S, clip_sd, batch, P, Pc, tr
+
+
+class _OracleTRWithSize(IO.OracleTRTrainer):
+    size = 56
+
+    def embed(self, batch):
+        sd, heads, act = self.clip
+        with torch.no_grad():
+            return IO.clip_vision_tokens(sd, F.interpolate(batch['pixel_values_clip'], (self.size, self.size), mode='bilinear'), heads, act)
+
+
+def test_tr_mapping_step_vs_oracle_trainer(K):
+    """the textual-restoration step with the evident intent (AdamW + clip over the CleanMapper): 3 steps against the oracle trainer --
+    loss per step, every CleanMapper gradient of the first step, the CleanMapper after the last step; the frozen Mapper (and the
+    to_k / to_v it carries) must not move."""
+    words = 3
+    SA, S, clip_sd, batch, P, Pc, tr = _tr_setup(words)
+    orc = _OracleTRWithSize(P, Pc, S, clip_sd, 4, 'quick_gelu', SMALL_LEVELS, words)
+    before = {k: p.detach().clone() for k, p in tr.mapper.named_parameters()}
+    for it in range(3):
+        want = orc.step(batch)
+        got = tr.step(batch).item()
+        assert abs(got - want) < 2e-5 * max(1.0, abs(want)), (it, got, want)
+        if it == 0:
+            for k, p in zip(tr.names, tr.params):
+                ref = orc.last_grads[k]
+                assert maxdiff(p.grad, ref) <= 5e-3 * ref.abs().max().item() + 1e-9, k
+            assert abs(tr.optimizer.grad_norm() - orc.last_norm) < 2e-3 * orc.last_norm
+    for k, p in tr.mapper.named_parameters():
+        assert torch.equal(p.detach(), before[k]), k
+    for k, p in zip(tr.names, tr.params):
+        d = (p.data.cpu() - orc.Pc[k].detach()).abs()
+        assert d.max().item() <= 6e-4 and (d > 2e-5).float().mean().item() < 0.01, (k, d.max().item())
+        assert (orc.Pc[k].detach() - Pc[k]).abs().max().item() > 1e-4, k
+
+
+def test_tr_mapping_step_as_written_changes_nothing_and_accumulates(K):
+    """reference defect R9 restated: the script's optimiser / clip / zero_grad run over the frozen Mapper, so as written no
+    parameter changes and the CleanMapper's gradients accumulate from step to step"""
+    words = 3
+    SA, S, clip_sd, batch, P, Pc, tr0 = _tr_setup(words, seed=1)
+    from textualdegremoval_amd.i2t import CleanMapper
+    cm = CleanMapper(1024, 1024, words)
+    cm.load_state_dict(Pc)
+    tr = SA.TRMappingTrainer(clip_sd, 4, S, clean_mapper=cm, as_written=True, clip_act='quick_gelu', num_words=words, levels=SMALL_LEVELS,
+                             use_hip_graph=False, clip_image_size=56)
+    tr.mapper.load_state_dict(dict(P), strict=True)
+    orc = _OracleTRWithSize(P, Pc, S, clip_sd, 4, 'quick_gelu', SMALL_LEVELS, words, as_written=True)
+    for it in range(2):
+        want = orc.step(batch)
+        got = tr.step(batch).item()
+        assert abs(got - want) < 2e-5 * max(1.0, abs(want))
+    for k, p in zip(tr.names, tr.params):
+        assert torch.equal(p.data.cpu(), Pc[k]), k                                  # nothing moved
+        ref = orc.last_grads[k]                                                      # the oracle's accumulated .grad after 2 steps
+        assert maxdiff(tr._accum[k], ref) <= 5e-3 * ref.abs().max().item() + 1e-9, k
+
+
 # ---------------------------------------------------------------------------------------------- configs[3] at its own size
 def _full_setup(B, layers):
     from textualdegremoval_amd import stage_a as SA

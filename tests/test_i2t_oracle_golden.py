@@ -39,6 +39,22 @@ def test_mapper_forward_backward(golden_dir):
     assert np.allclose(gn, g['grad_norm'], rtol=1e-3, atol=1e-6)
 
 
+def test_clean_mapper_forward_backward(golden_dir):
+    """oracle CleanMapper against the reference class (scripts/train/main_train_tr_mapping.py:84-120, executed from the reference
+    file by make_golden_i2t.py::clean_mapper_case): output, gradient w.r.t. the input words, every parameter-gradient norm"""
+    g = load(golden_dir, 'i2t_clean_mapper')
+    din, dout, words, B = [int(v) for v in g['cfg']]
+    P = {k: v.requires_grad_(True) for k, v in IO.synth_clean_mapper_params(din, 1280, dout, words, seed=6).items()}
+    inj = T(g['inj']).requires_grad_(True)
+    out = IO.clean_mapper_forward(P, inj, words)
+    assert np.abs(out.detach().numpy() - g['out']).max() < 2e-5
+    (out * T(g['go'])).sum().backward()
+    assert np.abs(inj.grad.numpy() - g['dinj']).max() < 2e-5 * max(1.0, np.abs(g['dinj']).max())
+    names = [str(k) for k in g['names']]
+    gn = np.array([P[k].grad.double().norm().item() for k in names])
+    assert np.allclose(gn, g['grad_norm'], rtol=1e-3, atol=1e-6)
+
+
 @pytest.mark.parametrize('tag', ['x', 's'])
 def test_injected_cross_attention(golden_dir, tag):
     g = load(golden_dir, 'i2t_xattn')

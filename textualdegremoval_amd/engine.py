@@ -279,18 +279,21 @@ def encoder_fwd(x, P, pre, ext_n_blocks, levels=5):
         x = a
         Cc = a.shape[1]
         if _p16_level(Cc, cnt[lvl]):
-            x16 = K.p16_from_f32(a)
+            # The FORWARD residual stream stays fp32 (conv2 writes the fp32 sum next to its pair image): the pair of x is x rounded
+            # to ~23 bits, and a 1e-7 perturbation of the stream flips a handful of ReLU decisions h > 0 per tensor -- each flip moves
+            # a conv1 gradient element by a whole term (measured 1.8e-4 of the tensor maximum against the fp32-tensor path,
+            # profiles/r4/diag_p16_grads.log).  With the fp32 stream the forward pass is bit-identical to the fp32-tensor kernels.
+            x16, x32 = K.p16_from_f32(a), a
             for i in range(cnt[lvl]):
                 bp = f'{pre}blk_L{k}.{i}.'
                 wp1, mp1, *_ = K.pack_weights(P[bp + 'conv1.weight'], PACK_FWD)
                 wp2, mp2, *_ = K.pack_weights(P[bp + 'conv2.weight'], PACK_FWD)
                 last = i == cnt[lvl] - 1
                 _, h16 = K.conv3x3_p16(x16, wp1, mp1, Cc, bias=P[bp + 'conv1.bias'], relu=True, want32=False, want16=True)
-                o32, o16 = K.conv3x3_p16(h16, wp2, mp2, Cc, bias=P[bp + 'conv2.bias'], res=a if i == 0 else x16,
-                                         want32=last, want16=not last)
+                o32, o16 = K.conv3x3_p16(h16, wp2, mp2, Cc, bias=P[bp + 'conv2.bias'], res=x32, want32=True, want16=not last)
                 blocks.append((x16, h16))
-                x16 = o16
-            x = o32
+                x16, x32 = o16, o32
+            x = x32
         else:
             for i in range(cnt[lvl]):
                 bp = f'{pre}blk_L{k}.{i}.'

@@ -118,12 +118,12 @@ class MapperStacks:
     optimiser's in-place updates, load_state_dict and state_dict keep working on the same storage) -- the grouped kernels then
     address word g of a layer as base + g * stride."""
 
-    def __init__(self, mapper):
+    def __init__(self, mapper, kinds=KINDS):
         G = self.G = mapper.num_words
         self._slots = []
         P = dict(mapper.named_parameters())
         self.W, self.B, self.LW, self.LB = {}, {}, {}, {}
-        for kind in KINDS:
+        for kind in kinds:
             for j in (0, 3, 6, 9):
                 w0 = P[f'{kind}0.{j}.weight']
                 self.W[kind, j] = torch.empty(G, *w0.shape, dtype=torch.float32, device=w0.device)
@@ -180,15 +180,17 @@ def _lin_bwd_grouped(dout, x, W, need_dx):
     return dx, gw
 
 
-def _chain_bwd(d, dsum, st, kind, saved, out):
-    """d: gradient of the chain's output [G, Dout, H, W], dsum [G, Dout] its pixel sums"""
+def _chain_bwd(d, dsum, st, kind, saved, out, need_dx=False):
+    """d: gradient of the chain's output [G, Dout, H, W], dsum [G, Dout] its pixel sums; returns the gradient of the chain's
+    input when `need_dx` (CleanMapper: the Mapper's words), else None"""
     layers, x_last = saved
     out[kind, 9, 'bias'] = dsum
     d, out[kind, 9, 'weight'] = _lin_bwd_grouped(d, x_last, st.W[kind, 9], True)
     for j, (x, z, mu, rs, y) in zip((6, 3, 0), reversed(layers)):
         dz, out[kind, j + 1, 'weight'], out[kind, j + 1, 'bias'], out[kind, j, 'bias'] = \
             K.group_ln_act_bwd(d, y, z, mu, rs, st.LW[kind, j + 1], SLOPE)
-        d, out[kind, j, 'weight'] = _lin_bwd_grouped(dz, x, st.W[kind, j], j > 0)
+        d, out[kind, j, 'weight'] = _lin_bwd_grouped(dz, x, st.W[kind, j], j > 0 or need_dx)
+    return d if need_dx else None
 
 
 def mapper_fwd_grouped(tok, B, T, st):
@@ -217,6 +219,89 @@ def mapper_bwd_grouped(dout, st, saved):
         for i in range(st.G):
             G[f'{kind}{i}.{j}.{what}'] = g[i]
     return G
+
+
+# ---------------------------------------------------------------------------- CleanMapper (main_train_tr_mapping.py:84-120)
+def _words_to_cm(x):
+    """[B, words, D] token-major -> [words, D, 1, 32] channel-major: word g is "image" g, sample b its pixel b (zero beyond B)"""
+    B, G, D = x.shape
+    return K.transpose_pad(x.contiguous().view(1, B, G * D), 32).view(G, D, 1, 32)
+
+
+def _cm_to_words(x, B):
+    """[words, D, 1, 32] -> [B, words, D]"""
+    G, D = x.shape[0], x.shape[1]
+    return K.transpose_pad(x.reshape(1, G * D, 32), G * D)[0, :B].reshape(B, G, D)
+
+
+def clean_mapper_fwd_grouped(inj, st):
+    """inj [B, words, Din] (the Mapper's words) -> ([B, words, Dout], saved): word i through its own MLP `mapping_{i}` -- the
+    class-token chain of the grouped Mapper with a per-word input (every layer ONE grouped launch over the words)."""
+    B = inj.shape[0]
+    if B > 32:
+        raise NotImplementedError('HIP CleanMapper: batch <= 32 per call (the samples of a word travel as one 32-pixel row)')
+    st.verify()
+    out, sv = _chain_fwd(_words_to_cm(inj), st, 'mapping_')
+    return _cm_to_words(out, B), (sv, B)
+
+
+def clean_mapper_bwd_grouped(dout, st, saved, need_dinj=False):
+    """-> ({parameter name: gradient}, d inj [B, words, Din] or None)"""
+    sv, B = saved
+    d = _words_to_cm(dout)
+    G, Dout = d.shape[0], d.shape[1]
+    dsum = K.channel_sum(d.view(1, G * Dout, 1, 32)).view(G, Dout)          # bias gradient of the last Linear (padded pixels are 0)
+    stacks = {}
+    dinj = _chain_bwd(d, dsum, st, 'mapping_', sv, stacks, need_dx=need_dinj)
+    Gd = {}
+    for (kind, j, what), g in stacks.items():
+        for i in range(st.G):
+            Gd[f'{kind}{i}.{j}.{what}'] = g[i]
+    return Gd, (_cm_to_words(dinj, B) if need_dinj else None)
+
+
+class _CleanMapperFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inj, st, names, *params):
+        _require_gpu(inj, 'CleanMapper')
+        out, saved = clean_mapper_fwd_grouped(inj.detach().contiguous(), st)
+        ctx.st, ctx.saved, ctx.names, ctx.need = st, saved, names, inj.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        G, dinj = clean_mapper_bwd_grouped(dout.contiguous(), ctx.st, ctx.saved, need_dinj=ctx.need)
+        ctx.saved = None
+        return (dinj, None, None) + tuple(G[k] for k in ctx.names)
+
+
+class CleanMapper(nn.Module):
+    """`CleanMapper` of scripts/train/main_train_tr_mapping.py:84-120 (same constructor, parameter names and default init): word i
+    of the injected embedding through `mapping_{i}`.  Forward / backward on the grouped kernels (the parameters are re-pointed
+    into per-layer stacks on first use: MapperStacks)."""
+
+    def __init__(self, input_dim: int, output_dim: int, num_words: int):
+        super().__init__()
+        self.num_words = num_words
+        for i in range(self.num_words):
+            setattr(self, f'mapping_{i}', nn.Sequential(nn.Linear(input_dim, 1280), nn.LayerNorm(1280), nn.LeakyReLU(),
+                                                        nn.Linear(1280, 1280), nn.LayerNorm(1280), nn.LeakyReLU(),
+                                                        nn.Linear(1280, 1280), nn.LayerNorm(1280), nn.LeakyReLU(),
+                                                        nn.Linear(1280, output_dim)))
+        self._stacks = None
+
+    def stacks(self):
+        if self._stacks is None:
+            self._stacks = MapperStacks(self, kinds=('mapping_',))
+        return self._stacks
+
+    def forward(self, embs):
+        _require_gpu(embs, 'CleanMapper')
+        names, params = [], []
+        for k, p in self.named_parameters():
+            names.append(k)
+            params.append(p)
+        return _CleanMapperFn.apply(embs, self.stacks(), names, *params)
 
 
 class _MapperFn(torch.autograd.Function):

@@ -143,8 +143,8 @@ class I2TMappingTrainer:
                     lin = nn.Linear(CTX_DIM, dim, bias=False)
                     lin.weight.data = S[f'{name}.to_{kv}.weight'].clone()
                     self.mapper.add_module(f'{name}_to_{kv}', lin.to(self.device))
-        self.names = [k for k, _ in self.mapper.named_parameters()]
-        self.params = [p for _, p in self.mapper.named_parameters()]
+        self.train_kv = True
+        self._trainables()
         self.mlp_names = [k for k in self.names if k.startswith('mapping_')]
         self.optimizer = FusedClipAdamW([{'params': self.params}], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                         max_norm=max_grad_norm, use_grad_clip=True)
@@ -174,6 +174,19 @@ class I2TMappingTrainer:
         self._g = None
         self._eager_left = 2
 
+    def _trainables(self):
+        """the tensors the optimiser owns (registration order): here every parameter of the Mapper, incl. the to_k / to_v it carries"""
+        self.names = [k for k, _ in self.mapper.named_parameters()]
+        self.params = [p for _, p in self.mapper.named_parameters()]
+
+    def _words_fwd(self, tok, T, B, P):
+        if self.grouped:
+            return i2t.mapper_fwd_grouped(tok, B, T, self.stacks)
+        return i2t.mapper_fwd(tok, T, P, self.num_words)
+
+    def _words_bwd(self, dinj, saved, P):
+        return i2t.mapper_bwd_grouped(dinj, self.stacks, saved) if self.grouped else i2t.mapper_bwd(dinj, P, self.num_words, saved)
+
     # ------------------------------------------------------------------ pieces
     @staticmethod
     def _lin(x, w, **kw):
@@ -187,7 +200,7 @@ class I2TMappingTrainer:
 
     def _fwd_bwd(self, b):
         """forward, MSE, hand-written backward; parameter gradients land in the reducer's arena.  Returns loss [1]."""
-        S, P = self.S, {k: p.data for k, p in zip(self.names, self.params)}
+        S, P = self.S, {k: p.data for k, p in self.mapper.named_parameters()}
         prev_plan = K.set_pack_plan(self._plan)
         prev_scaled = K.GRAD_SCALED
         try:
@@ -212,10 +225,7 @@ class I2TMappingTrainer:
             noisy = K.add_noise(lat, b['noise'], t, S['alphas_cumprod'])
             tok, T = self.image_encoder.encode(b['pixel_values_clip'], size=self.clip_image_size, flat=self.grouped)
             # ---- Mapper (a29) and the text side: injection (:139-151), stand-in projection, final_layer_norm
-            if self.grouped:
-                inj, msaved = i2t.mapper_fwd_grouped(tok, b['pixel_values_clip'].shape[0], T, self.stacks)
-            else:
-                inj, msaved = i2t.mapper_fwd(tok, T, P, self.num_words)
+            inj, msaved = self._words_fwd(tok, T, b['pixel_values_clip'].shape[0], P)
             new = K.text_inject_fwd(ids, S['text.token_embedding'], S['text.position_embedding'], inj, idx)
             z = self.text_proj(new)
             ctx, mu, rs = K.layernorm2d_fwd(z, S['text.final_layer_norm.weight'], S['text.final_layer_norm.bias'], LN_EPS)
@@ -244,13 +254,14 @@ class I2TMappingTrainer:
                 da = L['o'].dgrad(do)
                 _, dk, dv = K.cross_attention_bwd(q, k, v, a, da, lse, heads, HEAD_DIM ** -0.5, Tq, SEQ, need_dq=False)
                 wk, wv = P[f'{name}_to_k.weight'], P[f'{name}_to_v.weight']
-                G[f'{name}_to_k.weight'] = K.conv_wgrad(ctx, dk, dim, CTX_DIM, 1).view(dim, CTX_DIM)
-                G[f'{name}_to_v.weight'] = K.conv_wgrad(ctx, dv, dim, CTX_DIM, 1).view(dim, CTX_DIM)
+                if self.train_kv:
+                    G[f'{name}_to_k.weight'] = K.conv_wgrad(ctx, dk, dim, CTX_DIM, 1).view(dim, CTX_DIM)
+                    G[f'{name}_to_v.weight'] = K.conv_wgrad(ctx, dv, dim, CTX_DIM, 1).view(dim, CTX_DIM)
                 dctx = self._dgrad(dk, wk, res=dctx) if dctx is not None else self._dgrad(dk, wk)
                 dctx = self._dgrad(dv, wv, res=dctx)
             dz, _, _ = K.layernorm2d_bwd(dctx, z, mu, rs, S['text.final_layer_norm.weight'])
             dinj = K.text_inject_bwd(self.text_proj.dgrad(dz), idx, SEQ, self.num_words)
-            G.update(i2t.mapper_bwd_grouped(dinj, self.stacks, msaved) if self.grouped else i2t.mapper_bwd(dinj, P, self.num_words, msaved))
+            G.update(self._words_bwd(dinj, msaved, P))
             for kname in self.names:                      # fixed arrival order = registration order
                 sink[kname] = G[kname]
             grads = self.reducer.finish()
@@ -330,3 +341,65 @@ class I2TMappingTrainer:
         self.reducer.allreduce_flat()
         g['B'].replay()
         return g['loss']
+
+
+class TRMappingTrainer(I2TMappingTrainer):
+    """The textual-restoration mapping step (scripts/train/main_train_tr_mapping.py:757-812): the same pipeline as the
+    image-to-text step with the Mapper -- and the `to_k_global` / `to_v_global` it carries -- FROZEN (:668) and a `CleanMapper`
+    (:84-120, i2t.CleanMapper) between the Mapper's words and the placeholder-token injection (:785-786); only the CleanMapper
+    requires gradients (:671).
+
+    Reference defect R9 (recorded in DESIGN.md): the script builds its optimiser over `mapper.parameters()` (:679-685) -- all
+    frozen -- and clips / zeroes the same list (:806-810), so as written a step changes no parameter and the CleanMapper's
+    gradients accumulate.  `as_written=True` restates exactly that (gradients accumulate into `clean_mapper.*.grad`, no update);
+    the default is the evident intent: AdamW (+ clip_grad_norm_ 1.0, zero_grad) over the CleanMapper."""
+
+    def __init__(self, clip_state_dict, clip_heads, stub, clean_mapper=None, as_written=False, **kw):
+        self._clean_arg, self.as_written = clean_mapper, bool(as_written)
+        super().__init__(clip_state_dict, clip_heads, stub, **kw)
+
+    def _trainables(self):
+        cm = self._clean_arg if self._clean_arg is not None else i2t.CleanMapper(CTX_DIM, CTX_DIM, self.num_words)
+        self.clean_mapper = cm.to(self.device)
+        for p in self.mapper.parameters():
+            p.requires_grad_(False)                                   # :668 freeze_params(mapper.parameters())
+        self.train_kv = False
+        self.names = [k for k, _ in self.clean_mapper.named_parameters()]
+        self.params = [p for _, p in self.clean_mapper.named_parameters()]
+        self._accum = None
+
+    def _words_fwd(self, tok, T, B, P):
+        if not self.grouped:
+            raise NotImplementedError('TRMappingTrainer runs the grouped kernels (TDR_MAPPER_GROUPED=1)')
+        inj, _ = i2t.mapper_fwd_grouped(tok, B, T, self.stacks)      # frozen: nothing kept for a backward pass
+        return i2t.clean_mapper_fwd_grouped(inj, self.clean_mapper.stacks())
+
+    def _words_bwd(self, dinj, saved, P):
+        G, _ = i2t.clean_mapper_bwd_grouped(dinj, self.clean_mapper.stacks(), saved)
+        return G
+
+    def _eager(self, b):
+        loss = self._fwd_bwd(b)
+        self.reducer.allreduce_flat()
+        if self.as_written:
+            self._accumulate()
+        else:
+            self.optimizer.step()
+        return loss
+
+    def _accumulate(self):
+        """as written: nothing zeroes the CleanMapper's gradients, nothing updates it"""
+        if self._accum is None:
+            self._accum = {k: p.grad.clone() for k, p in zip(self.names, self.params)}
+        else:
+            for k, p in zip(self.names, self.params):
+                self._accum[k] += p.grad
+
+    def step(self, batch):
+        if self.as_written:
+            if 'noise' not in batch:
+                B, _, H, W = batch['pixel_values'].shape
+                batch = dict(batch, noise=torch.randn(B, 4, H // 8, W // 8, device=self.device),
+                             timesteps=torch.randint(0, 1000, (B,), device=self.device))
+            return self._eager(self._device_batch(batch))
+        return super().step(batch)
