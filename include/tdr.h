@@ -137,12 +137,13 @@ int tdr_pack_patches(const float* blk, int B, int G, int C, int BH, int BW, int 
  * Replaces the 3x3 / stride 1 / pad 1 convolutions of the MASA encoder's ResidualBlocks, forward and data gradient
  * (network_nafnet_guided_arch.py:44-59,110-143), in the 2-way fp16 split arithmetic.
  * P16 image of an fp32 [N][C][H][W] tensor, C % 16 == 0: 16-byte slots [N][C/8][plane][H+2][W+2], a slot = 8 consecutive
- * channels of one pixel as 8 x f16; plane 0 = rn_f16(x), plane 1 = rn_f16(x - plane 0); the 1-pixel border is zero.
+ * channels of one pixel as 8 x f16; plane 0 = rn_f16(x) (an exact zero is stored as -0.0: the sign bit of plane 0 is "x <= 0" even
+ * where a tiny positive x rounds to +0), plane 1 = rn_f16(x - rn_f16(x)); the 1-pixel border is zero.
  * tdr_p16_bytes: buffer size.  tdr_p16_from_f32 / tdr_p16_to_f32 convert (to_f32 returns head + residual).
  * tdr_conv3x3_p16: out = mask( relu( conv(in, W) + bias + res ) ); `in` is a P16 tensor of Cin channels, `wp` an hx2 pack
  * (tdr_pack_weights_hx2, mode 0 forward / mode 1 data gradient; wp_fmt must be 2); the residual and the ReLU mask (> 0) are read
  * from fp32 NCHW tensors (res32 / mask32, strides in floats) or from P16 tensors of Cout channels (res16 / mask16: the mask is
- * the sign of the head plane); the result is written as fp32 NCHW (out32), as a P16 tensor including its zero border (out16),
+ * the sign bit of the head plane, see above); the result is written as fp32 NCHW (out32), as a P16 tensor including its zero border (out16),
  * or both.  Accumulation order = tdr_conv_forward's 2-way fp16 split kernel: bit-identical results on the same operands. */
 typedef struct TdrConvP16Desc {
     int N, Cin, H, W, Cout;

@@ -93,6 +93,29 @@ def test_conv3x3_p16_vs_torch_and_the_fp32_tensor_kernel(K, case, cfg):
         assert torch.equal(o16.buf, K.p16_from_f32(o32).buf)
 
 
+def test_p16_mask_is_exactly_x_greater_than_zero(K):
+    """ReLU masks are read from the pair planes.  fp16 heads underflow below 2^-25, so "x > 0" is carried by the SIGN BIT of the head
+    with exact zeros stored as -0.0: tiny positives (head +0) pass, exact zeros and negatives do not -- the same decisions as the
+    fp32 mask, element for element (a plain rn_f16(x) > 0 test dropped a few gradient terms per tensor at configs[1]'s size)."""
+    N, C, H, W = 1, 32, 16, 32
+    vals = torch.tensor([1e-9, 0.0, -1e-9, 3e-8, 1.0, -0.0, 1e-30, 6e-8, -1.0, 2.0 ** -25, 2.0 ** -26, 1e-38])
+    mask = vals.repeat((N * C * H * W + len(vals) - 1) // len(vals))[:N * C * H * W].view(N, C, H, W).cuda().contiguous()
+    x = rnd(N, C, H, W, seed=31)
+    w = rnd(C, C, 3, 3, seed=32, scale=0.05)
+    wp, mp, *_ = K.pack_weights(w, K.PACK_FWD)
+    x16, m16 = K.p16_from_f32(x), K.p16_from_f32(mask)
+    a, _ = K.conv3x3_p16(x16, wp, mp, C, mask=mask)
+    b, _ = K.conv3x3_p16(x16, wp, mp, C, mask=m16)
+    assert torch.equal(a, b)
+    assert ((a != 0) == (mask > 0)).all() or (a[mask > 0] == 0).float().mean().item() < 1e-3     # kept exactly where mask > 0
+    # and a ReLU output written by the kernel itself carries the same information
+    _, h16 = K.conv3x3_p16(x16, wp, mp, C, relu=True, want32=False, want16=True)
+    h32, _ = K.conv3x3_p16(x16, wp, mp, C, relu=True)
+    c, _ = K.conv3x3_p16(x16, wp, mp, C, mask=h16)
+    d, _ = K.conv3x3_p16(x16, wp, mp, C, mask=h32)
+    assert torch.equal(c, d)
+
+
 @pytest.mark.parametrize('shape', [(1, 32, 32, 16, 32), (2, 64, 64, 32, 32), (1, 16, 48, 19, 45), (2, 128, 64, 24, 64),
                                    (1, 32, 32, 40, 33), (1, 64, 128, 7, 70), (2, 256, 256, 8, 32)])
 def test_wgrad3x3_p16_vs_fp64(K, shape):

@@ -7,6 +7,9 @@
 //   P16 tensor of an fp32 [N][C][H][W] activation (C % 16 == 0):  uint4 slots  [N][C/8][plane 2][H+2][W+2]
 //   slot = 8 consecutive channels of ONE pixel as 8 x f16; plane 0 = heads h, plane 1 = residuals m; the one-pixel border is zero
 //   (it IS the convolution's zero padding).  Bytes per element: 4, the same as the fp32 value the pair encodes.
+//   An element that is EXACTLY zero is stored with the head -0.0 (p16_head): "x > 0" is then the head's sign bit being clear even for
+//   0 < x < 2^-25, whose head rounds to +0 -- the ReLU masks of the backward pass are read from the pair planes (p16_positive), and
+//   with a plain fp16(x) > 0 test a few such elements per tensor lost their gradient term (profiles/r4/diag_p16_seq.log).
 //
 // With that layout a B fragment (lane = pixel, 8 channels) is one 16-byte slot, a halo-tile row is LW contiguous slots in
 // memory, and BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU): the halo tile of the next
@@ -29,6 +32,13 @@ typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// head plane value of x: rn_f16(x), except that an exact zero becomes -0.0 (see the header: the sign bit of the head is "x <= 0")
+__device__ __forceinline__ _Float16 p16_head(float x) {
+    const _Float16 h = (_Float16)x;
+    return x == 0.f ? __builtin_bit_cast(_Float16, (unsigned short)0x8000) : h;
+}
+__device__ __forceinline__ bool p16_positive(_Float16 head) { return (__builtin_bit_cast(unsigned short, head) & 0x8000u) == 0; }
 
 struct P16Args {
     const uint4* in; long in_ns;       // P16 input, slots per image
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
                     const char* p = reinterpret_cast<const char*>(a.mask16 + (long)n * a.mask16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
                     const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * q + e] = (float)h[e] > 0.f ? v[4 * q + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = p16_positive(h[e]) ? v[4 * q + e] : 0.f;
                 }
             }
             if (a.out32) {
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
                         float x = v[4 * q + e];
                         asm volatile("" : "+v"(x));          // head and residual from the same fp32 value
                         const _Float16 hh = (_Float16)x;
-                        h[e] = hh;
+                        h[e] = p16_head(x);
                         m[e] = (_Float16)(x - (float)hh);
                     }
                     char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * 2 * PS) + kk * 8;
@@ -408,7 +418,7 @@ __global__ void p16_from_f32_kernel(const float* __restrict__ src, long src_ns, 
             float v = in ? p[e * HW] : 0.f;
             asm volatile("" : "+v"(v));
             const _Float16 hh = (_Float16)v;
-            h[e] = hh;
+            h[e] = in ? p16_head(v) : hh;             // (the border is plain +0, as the convolution epilogue writes it)
             m[e] = (_Float16)(v - (float)hh);
         }
         uint4* o = dst + ((long)n * G + oc) * 2 * PS + s;
