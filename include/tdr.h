@@ -335,6 +335,18 @@ int64_t tdr_ssim3d_ws_floats(int H, int W);
 int tdr_ssim3d(const float* img1, const float* img2, int H, int W, int C, float max_value, float* ws, float* out,
                void* stream);
 
+/* The Y-channel SSIM in float64 -- metrics/psnr_ssim.py:184-222 (_ssim_cly: cv2.filter2D of float64 images with the 11 x 11 Gaussian
+ * window, BORDER_REPLICATE, [0,255] constants).  img1 / img2 [H][W] float32 (the Y planes); ws: tdr_ssim_y64_ws_doubles(H, W)
+ * doubles; out: 1 double = mean of the SSIM map.  Filtering, the SSIM map and its mean are evaluated in double. */
+int64_t tdr_ssim_y64_ws_doubles(int H, int W);
+int tdr_ssim_y64(const float* img1, const float* img2, int H, int W, double* ws, double* out, void* stream);
+/* TLSC local average pooling -- `AvgPool2d.forward` of models/archs/nafnet_local_arch.py:10-75 (fast_imp = False, auto_pad):
+ * out[p][y][x] = mean of the k1' x k2' box (k' = min(size, k)) whose top-left corner is (clamp(y - (H - hv) / 2, 0, hv - 1),
+ * clamp(x - (W - wv) / 2, 0, wv - 1)), hv = H - k1' + 1, wv = W - k2' + 1: the valid box means replicate-padded back to H x W.
+ * in / out: `planes` dense [H][W] planes; ws: tdr_local_avgpool_ws_floats(planes, H, W, k1) floats. */
+int64_t tdr_local_avgpool_ws_floats(int planes, int H, int W, int k1);
+int tdr_local_avgpool(const float* in, int planes, int H, int W, int k1, int k2, float* ws, float* out, void* stream);
+
 /* ReLU backward: out = act > 0 ? go : 0 (Encoder/ResidualBlock nn.ReLU, :52,132) */
 int tdr_relu_bwd(const float* go, const float* act, int64_t numel, float* out, void* stream);
 

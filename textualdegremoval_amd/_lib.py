@@ -125,6 +125,10 @@ SIGNATURES = {
     'tdr_last_error': (C.c_char_p, []),
     'tdr_conv_forward': (i32, [C.POINTER(TdrConvDesc), c_fp]),
     'tdr_conv_ck': (i32, [i32]),
+    'tdr_ssim_y64_ws_doubles': (i64, [i32, i32]),
+    'tdr_ssim_y64': (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_local_avgpool_ws_floats': (i64, [i32, i32, i32, i32]),
+    'tdr_local_avgpool': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_p16_bytes': (i64, [i32, i32, i32, i32]),
     'tdr_p16_from_f32': (i32, [c_fp, i64, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_p16_to_f32': (i32, [c_fp, i32, i32, i32, i32, c_fp, i64, c_fp]),

@@ -1613,6 +1613,28 @@ def ssim3d(img1, img2, max_value):
 # ---------------------------------------------------------------------------
 # DRSformer-ref pieces (csrc/tdr_mdta.hip: top-k sparse attention; csrc/tdr_dwk.hip: grouped depthwise convs)
 # ---------------------------------------------------------------------------
+def ssim_y64(img1, img2):
+    """float64 SSIM of two [H, W] float32 planes (metrics/psnr_ssim.py:184-222); returns a python float"""
+    lib = _lib.load()
+    H, W = img1.shape
+    assert img1.is_contiguous() and img2.is_contiguous() and img2.shape == img1.shape
+    ws = torch.empty(lib.tdr_ssim_y64_ws_doubles(H, W), dtype=torch.float64, device=img1.device)
+    out = torch.empty(1, dtype=torch.float64, device=img1.device)
+    check(lib.tdr_ssim_y64(img1.data_ptr(), img2.data_ptr(), H, W, ws.data_ptr(), out.data_ptr(), _stream()), 'tdr_ssim_y64')
+    return float(out.item())
+
+
+def local_avgpool(x, k1, k2):
+    """TLSC box mean of x [N, C, H, W] with replicate padding back to H x W (nafnet_local_arch.py:10-75)"""
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    ws = workspace(lib.tdr_local_avgpool_ws_floats(N * Cc, H, W, k1), x.device, 'tlsc')
+    check(lib.tdr_local_avgpool(x.data_ptr(), N * Cc, H, W, k1, k2, ws.data_ptr(), out.data_ptr(), _stream()), 'tdr_local_avgpool')
+    return out
+
+
 def tksa_ks(c):
     """the four top-k sizes of a head with c channels, as the reference computes them (python int() of float expressions,
     network_drsformer_guided_arch.py:293-306)"""

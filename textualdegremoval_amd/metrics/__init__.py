@@ -82,11 +82,14 @@ def calculate_ssim(img1, img2, crop_border, input_order='HWC', test_y_channel=Fa
     if crop_border != 0:
         a = a[crop_border:-crop_border, crop_border:-crop_border, ...]
         b = b[crop_border:-crop_border, crop_border:-crop_border, ...]
-    if test_y_channel:
-        a, b, max_value = to_y_channel(a), to_y_channel(b), 255       # _ssim_cly: constants of the [0,255] range
-    else:
-        max_value = 1 if a.max() <= 1 else 255
     dev = torch.device('cuda', torch.cuda.current_device())
+    if test_y_channel:
+        # _ssim_cly (:184-222): float64 filtering of the Y planes (csrc/tdr_tlsc.hip, ssim_y64_kernel: every field in double)
+        a, b = to_y_channel(a), to_y_channel(b)
+        ya = torch.from_numpy(np.ascontiguousarray(a[..., 0], dtype=np.float32)).to(dev)
+        yb = torch.from_numpy(np.ascontiguousarray(b[..., 0], dtype=np.float32)).to(dev)
+        return K.ssim_y64(ya, yb)
+    max_value = 1 if a.max() <= 1 else 255
     ta = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     tb = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(dev)
     return float(K.ssim3d(ta, tb, max_value).item())
