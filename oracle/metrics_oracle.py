@@ -1,8 +1,10 @@
 """CPU restatement of the reference's SSIM (metrics/psnr_ssim.py) -- TEST INFRASTRUCTURE ONLY: imported by tests/, never by
 the product (textualdegremoval_amd.metrics.calculate_ssim runs csrc/tdr_metrics.hip and has no host fallback).
 
-PARITY UNPINNED: the reference module imports cv2 (absent from this image) and moves its conv3d to .cuda(), so it cannot
-be run here to make golden vectors.  cv2.getGaussianKernel(11, 1.5) is restated from its published definition
+PINNED (round 4) for the Y-channel path: `ssim_cly` is checked against `_ssim_cly` executed from the reference file
+(tests/golden/make_golden_tlsc.py: the two cv2 calls it makes are served by scipy.ndimage.correlate(mode='nearest') and the
+kernel's published formula), tests/test_hip_tlsc.py.  PARITY UNPINNED for `ssim_3d`: the reference moves its conv3d to
+.cuda() and imports cv2 (absent from this image), so that function cannot be run here to make golden vectors.  cv2.getGaussianKernel(11, 1.5) is restated from its published definition
 (G_i = alpha * exp(-(i - (ksize-1)/2)^2 / (2 sigma^2)), sum 1; ksize 11 > 7 so no fixed table applies), and the
 conv3d / filter2D calls are restated with torch / numpy.
 """

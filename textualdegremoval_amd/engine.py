@@ -172,12 +172,43 @@ def naf_bwd(dout, P, saved):
     return dx, G
 
 
-def naf_seq_fwd(x, P, pre, n, c_out_last=None):
+def naf_seq_fwd(x, P, pre, n, c_out_last=None, local=None):
+    """local = (k1, k2): TLSC inference (naf_fwd_local), nothing saved"""
     saved = []
     for i in range(n):
+        if local is not None:
+            x = naf_fwd_local(x, _sub(P, f'{pre}{i}.'), *local)
+            continue
         x, sv = naf_fwd(x, _sub(P, f'{pre}{i}.'), c_out_last if i == n - 1 else None)
         saved.append(sv)
     return x, saved
+
+
+def naf_fwd_local(x, P, k1, k2):
+    """NAFBlock forward with the SCA branch's global average pool replaced by TLSC's local box mean of k1 x k2 pixels
+    (models/archs/nafnet_local_arch.py:10-75, `replace_layers`): the pooled statistic -- and with it the channel attention --
+    becomes a per-pixel map, so `x * sca(x)` (:192) is an element-wise product of two maps, folded into conv3's operand load as
+    the gate product of the concatenation [g ; sca(pool(g))].  Inference only (the reference wraps the network in eval /
+    no_grad, network_nafnet_guided_arch.py:756-768).  Where the box covers the whole map the reference falls back to
+    F.adaptive_avg_pool2d(x, 1) (:43-44): that is the ordinary block."""
+    N, c, H, W = x.shape
+    if k1 >= H and k2 >= W:
+        return naf_fwd(x, P)[0]
+    wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_FWD)
+    xn, _, _ = K.layernorm2d_fwd(x, P['norm1.weight'], P['norm1.bias'], LN_EPS)
+    t1 = K.conv_forward(xn, wp, mp, 2 * c, 1, bias=P['conv1.bias'])
+    g, _ = K.dwsg_fwd(t1, P['conv2.weight'], P['conv2.bias'])
+    cat = torch.empty(N, 2 * c, H, W, dtype=torch.float32, device=x.device)
+    K.copy_rows(g, c * H * W, cat, 2 * c * H * W, N, c * H * W)
+    wp, mp, *_ = K.pack_weights(P['sca.1.weight'], PACK_FWD)
+    K.conv_forward(K.local_avgpool(g, k1, k2), wp, mp, c, 1, bias=P['sca.1.bias'], out=cat[:, c:])
+    wp, mp, *_ = K.pack_weights(P['conv3.weight'], PACK_FWD)
+    y = K.conv_forward(cat, wp, mp, c, 1, gate=True, bias=P['conv3.bias'], scale=P['beta'].view(-1), res=x)
+    yn, _, _ = K.layernorm2d_fwd(y, P['norm2.weight'], P['norm2.bias'], LN_EPS)
+    wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_FWD)
+    t4 = K.conv_forward(yn, wp, mp, 2 * c, 1, bias=P['conv4.bias'])
+    wp, mp, *_ = K.pack_weights(P['conv5.weight'], PACK_FWD)
+    return K.conv_forward(t4, wp, mp, c, 1, gate=True, bias=P['conv5.bias'], scale=P['gamma'].view(-1), res=y)
 
 
 def naf_seq_bwd(dout, P, pre, n, saved, G):
@@ -536,19 +567,19 @@ def net_fwd(P, cfg, inp, ref):
     sv_levels, skips = [], []
     for lvl in range(n_enc):
         x, sv_f = naf_seq_fwd(cats[lvl], P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], c_out_last=chan)
-        x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl])
+        x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl], local=local[lvl] if local else None)
         skips.append(x)
         conv_fwd(x, P[f'downs.{lvl}.weight'], P[f'downs.{lvl}.bias'], 2, 0, out=cats[lvl + 1][:, :2 * chan])
         sv_levels.append((sv_f, sv_e, x))
         chan *= 2
     cat = cats[n_enc]
     x, sv_fm = naf_seq_fwd(cat, P, 'masa_blk_middle.0.', cfg['reffusion_n_blocks'][n_enc], c_out_last=chan)
-    x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'])
+    x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'], local=local[n_enc] if local else None)
     sv_dec = []
     for lvl in range(len(cfg['dec_blk_nums'])):
         xin = x
         x = up_fwd(xin, P[f'ups.{lvl}.0.weight'], skips[-1 - lvl])
-        x, sv_d = naf_seq_fwd(x, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl])
+        x, sv_d = naf_seq_fwd(x, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl], local=local[n_enc - 1 - lvl] if local else None)
         sv_dec.append((xin, sv_d))
     xe = x
     out_p = conv_fwd(xe, P['ending.weight'], P['ending.bias'], 1, 1, res=inp_p)
@@ -558,9 +589,22 @@ def net_fwd(P, cfg, inp, ref):
 
 
 # ---------------------------------------------------------------------------- un-guided NAFNet (reference :305-386)
-def unet_fwd(P, cfg, inp):
+def tlsc_kernel_sizes(cfg, train_size):
+    """pooling kernel of every U-Net level as `Local_Base.convert` fixes it (nafnet_local_arch.py:29-36,99-104, NAFNetLocal :756-768):
+    the first forward runs on rand(train_size) with base_size = int(1.5 x train size), and each AvgPool2d keeps
+    kernel = feature size at that forward * base_size // train size.  Level l sees the zero-padded train image >> l."""
+    _, _, Ht, Wt = train_size
+    n_enc = len(cfg['enc_blk_nums'])
+    mult = 1 << n_enc
+    Hp, Wp = -(-Ht // mult) * mult, -(-Wt // mult) * mult
+    bh, bw = int(Ht * 1.5), int(Wt * 1.5)
+    return [((Hp >> l) * bh // Ht, (Wp >> l) * bw // Wt) for l in range(n_enc + 1)]
+
+
+def unet_fwd(P, cfg, inp, local=None):
     """`NAFNet.forward`: check_image_size (zero pad to a multiple of 2^len(encoders)) -> intro -> encoders / downs -> middle ->
-    ups (+ skip) / decoders -> ending + inp -> crop.  Same block kernels as the guided network, no reference branch."""
+    ups (+ skip) / decoders -> ending + inp -> crop.  Same block kernels as the guided network, no reference branch.
+    local: per-level TLSC pooling kernels (tlsc_kernel_sizes) -- `NAFNetLocal`, inference only (saved state is empty)."""
     n_enc = len(cfg['enc_blk_nums'])
     N, _, H0, W0 = inp.shape
     mult = 1 << n_enc
@@ -569,16 +613,16 @@ def unet_fwd(P, cfg, inp):
     x = conv_fwd(inp_p, P['intro.weight'], P['intro.bias'], 1, 1)
     sv_levels, skips = [], []
     for lvl in range(n_enc):
-        x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl])
+        x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl], local=local[lvl] if local else None)
         skips.append(x)
         sv_levels.append((sv_e, x))
         x = conv_fwd(x, P[f'downs.{lvl}.weight'], P[f'downs.{lvl}.bias'], 2, 0)
-    x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'])
+    x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'], local=local[n_enc] if local else None)
     sv_dec = []
     for lvl in range(len(cfg['dec_blk_nums'])):
         xin = x
         x = up_fwd(xin, P[f'ups.{lvl}.0.weight'], skips[-1 - lvl])
-        x, sv_d = naf_seq_fwd(x, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl])
+        x, sv_d = naf_seq_fwd(x, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl], local=local[n_enc - 1 - lvl] if local else None)
         sv_dec.append((xin, sv_d))
     out_p = conv_fwd(x, P['ending.weight'], P['ending.bias'], 1, 1, res=inp_p)
     out = out_p if (Hp, Wp) == (H0, W0) else K.pad_crop(out_p, H0, W0)

@@ -258,6 +258,31 @@ class NAFNetRefFusion(_NAFBase):
         return _NetFn.apply(inp, ref, names, self.cfg, *params)
 
 
+class NAFNetLocal(NAFNet):
+    """TLSC test-time wrapper of the un-guided NAFNet (reference :756-768 + models/archs/nafnet_local_arch.py:10-104): same
+    constructor (`train_size`, `fast_imp`), same parameters / state dict as NAFNet; every NAFBlock's global average pool becomes a
+    local box mean whose kernel is fixed at construction -- 1.5 x the feature size the network sees at `train_size`
+    (engine.tlsc_kernel_sizes restates what `Local_Base.convert`'s first forward computes; that forward itself only serves to fix
+    the kernels there).  Inference only: the module is put in eval mode and its forward runs without autograd, as in the reference.
+    `fast_imp=True` selects the reference's sub-sampled "non-equivalent but faster" variant (:46-60), not built here."""
+
+    def __init__(self, *args, train_size=(1, 3, 256, 256), fast_imp=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        if fast_imp:
+            raise NotImplementedError('NAFNetLocal(fast_imp=True): the sub-sampled integral-image variant is not built (fast_imp=False '
+                                      'is what every shipped configuration uses)')
+        self.train_size, self.fast_imp = tuple(train_size), fast_imp
+        self.ksizes = E.tlsc_kernel_sizes(self.cfg, self.train_size)
+        self.eval()
+
+    def forward(self, inp):
+        require_gpu(inp, 'NAFNetLocal')
+        names, params = _named(self)
+        with torch.no_grad():
+            out, _ = E.unet_fwd(dict(zip(names, [p.detach() for p in params])), self.cfg, inp.detach(), local=self.ksizes)
+        return out
+
+
 class NAFNetLocal_RefFusion(NAFNetRefFusion):
     """The reference's TLSC test-time wrapper of the guided NAFNet (network_nafnet_guided_arch.py:743-753) cannot be
     constructed there: Local_Base.convert (nafnet_local_arch.py:99-104) runs `self.forward(imgs)` with one argument, and the
