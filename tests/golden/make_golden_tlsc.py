@@ -50,7 +50,7 @@ def naflocal_case(d):
         for k, p in net.named_parameters():
             p.add_(torch.randn(p.shape, generator=g) * 0.1 if p.dim() <= 1 or k.endswith(('beta', 'gamma')) else 0)
     ks = [tuple(m.kernel_size) for m in net.modules() if isinstance(m, sys.modules['models.archs.nafnet_local_arch'].AvgPool2d)]
-    x = torch.rand(1, 3, 78, 70, generator=g)                  # padded to 80 x 72: every level is larger than its pooling kernel
+    x = torch.rand(1, 3, 78, 94, generator=g)                  # padded to 80 x 96 (levels 80x96, 40x48, 20x24: rows of 4-pixel multiples, the depthwise stencil's requirement); every level is larger than its pooling kernel
     with torch.no_grad():
         out = net(x)
     d['nl_x'], d['nl_out'], d['nl_ksizes'] = x.numpy(), out.numpy(), np.array(ks)

@@ -185,11 +185,22 @@ def seq_bwd(d, P, pre, n, heads, ln_type, saved, G, fusion=False):
 
 
 def net_fwd(P, cfg, inp, ref):
+    """ref = None: the UN-GUIDED `DRSformer` of the same file (network_drsformer_guided_arch.py:586-676): no MASA pyramid, no
+    fusion blocks, no padding (its PixelUnshuffle raises on sizes that are not multiples of 8), MEFC sub-networks always."""
     N = inp.shape[0]
-    pyr, (H0, W0, Hp, Wp) = E.pyramids_fwd(P, cfg, inp, ref, PADDER_LOG2, 4)
+    guided = ref is not None
+    if guided:
+        pyr, (H0, W0, Hp, Wp) = E.pyramids_fwd(P, cfg, inp, ref, PADDER_LOG2, 4)
+        warp, sv_masa = E.masa_fwd(pyr.lq_deep, pyr.ref_feats, N, pyr.geo)
+    else:
+        H0, W0 = inp.shape[2:]
+        if H0 % 8 or W0 % 8:
+            raise ValueError(f'DRSformer: H, W must be multiples of 8 (three PixelUnshuffle(2) stages); got {H0}x{W0}')
+        Hp, Wp = H0, W0
+        import types
+        pyr, warp, sv_masa = types.SimpleNamespace(inp_p=inp.contiguous(), geo=None), None, None
     inp_p, geo = pyr.inp_p, pyr.geo
-    warp, sv_masa = E.masa_fwd(pyr.lq_deep, pyr.ref_feats, N, geo)
-    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
+    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg.get('reffusion_n_blocks'), cfg['dim']
     full = bool(cfg.get('mefc'))       # DRSformerRefFusion: MEFC sub-networks + a working level-1 fusion; else the 200L_SPA class
     x = E.conv_fwd(inp_p, P['patch_embed.proj.weight'], P.get('patch_embed.proj.bias'), 1, 1)
     x_embed, sv_m0 = x, None
@@ -199,7 +210,7 @@ def net_fwd(P, cfg, inp, ref):
     for l in range(4):
         c = dim * 2 ** l
         sv_f = None
-        if l > 0 or full:          # R6 (200L_SPA only): the reference discards the level-1 fusion; it is not computed there
+        if guided and (l > 0 or full):   # R6 (200L_SPA only): the reference discards the level-1 fusion; it is not computed there
             f, sv_f = seq_fwd(K.concat2(x, warp[l]), P, R._FUS[l], nfz[l], hd[l], ln, fusion=True)
             x = K.slice_channels(f, 0, c)
         e, sv_e = seq_fwd(x, P, R._ENC[l], nb[l], hd[l], ln)
@@ -232,7 +243,7 @@ def _net_bwd(dout, P, cfg, saved, G):
     (N, (H0, W0, Hp, Wp), geo, pyr, sv_m0, sv_m1, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, d1) = saved
     full = bool(cfg.get('mefc'))
     G = {} if G is None else G
-    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
+    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg.get('reffusion_n_blocks'), cfg['dim']
     e1, e2, e3, lat = enc_out
     inp_p = pyr.inp_p
     dout = dout.contiguous()
@@ -261,7 +272,7 @@ def _net_bwd(dout, P, cfg, saved, G):
         c = dim * 2 ** l
         sv_f, sv_e = sv_lv[l]
         d = seq_bwd(d, P, R._ENC[l], nb[l], hd[l], ln, sv_e, G)
-        if l > 0 or full:
+        if sv_f is not None:
             df = torch.zeros(N, 2 * c, d.shape[2], d.shape[3], dtype=torch.float32, device=d.device)
             K.copy_rows(d, c * d.shape[2] * d.shape[3], df, 2 * c * d.shape[2] * d.shape[3], N, c * d.shape[2] * d.shape[3])
             dcat = seq_bwd(df, P, R._FUS[l], nfz[l], hd[l], ln, sv_f, G, fusion=True)
@@ -273,13 +284,14 @@ def _net_bwd(dout, P, cfg, saved, G):
         else:
             if full:
                 d = mefc_bwd(d, P, 'encoder_level0.', sv_m0, G)
-            else:
+            elif sv_masa is not None:
                 dwarp[0] = torch.zeros(N, c, d.shape[2], d.shape[3], dtype=torch.float32, device=d.device)     # R6: unused warp level
             has_pb = 'patch_embed.proj.bias' in P
             _, G['patch_embed.proj.weight'], db = E.conv_bwd(d, inp_p, P['patch_embed.proj.weight'], 1, 1, need_dx=False, bias=has_pb)
             if has_pb:
                 G['patch_embed.proj.bias'] = db
-    E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
+    if sv_masa is not None:
+        E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
     return G
 
 

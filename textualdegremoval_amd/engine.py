@@ -567,19 +567,19 @@ def net_fwd(P, cfg, inp, ref):
     sv_levels, skips = [], []
     for lvl in range(n_enc):
         x, sv_f = naf_seq_fwd(cats[lvl], P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], c_out_last=chan)
-        x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl], local=local[lvl] if local else None)
+        x, sv_e = naf_seq_fwd(x, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl])
         skips.append(x)
         conv_fwd(x, P[f'downs.{lvl}.weight'], P[f'downs.{lvl}.bias'], 2, 0, out=cats[lvl + 1][:, :2 * chan])
         sv_levels.append((sv_f, sv_e, x))
         chan *= 2
     cat = cats[n_enc]
     x, sv_fm = naf_seq_fwd(cat, P, 'masa_blk_middle.0.', cfg['reffusion_n_blocks'][n_enc], c_out_last=chan)
-    x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'], local=local[n_enc] if local else None)
+    x, sv_m = naf_seq_fwd(x, P, 'middle_blks.', cfg['middle_blk_num'])
     sv_dec = []
     for lvl in range(len(cfg['dec_blk_nums'])):
         xin = x
         x = up_fwd(xin, P[f'ups.{lvl}.0.weight'], skips[-1 - lvl])
-        x, sv_d = naf_seq_fwd(x, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl], local=local[n_enc - 1 - lvl] if local else None)
+        x, sv_d = naf_seq_fwd(x, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl])
         sv_dec.append((xin, sv_d))
     xe = x
     out_p = conv_fwd(xe, P['ending.weight'], P['ending.bias'], 1, 1, res=inp_p)

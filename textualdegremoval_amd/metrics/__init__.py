@@ -49,7 +49,9 @@ def calculate_psnr(img1, img2, crop_border=0, input_order='HWC', test_y_channel=
 
 def bgr2ycbcr_y(img):
     """Y of ITU-R BT.601 YCbCr from a BGR float32 image in [0,1] (utils/matlab_functions.py:207-238, y_only branch)"""
-    return (np.dot(img.astype(np.float32), [24.966, 128.553, 65.481]) + 16.0).astype(np.float32) / np.float32(255.)
+    # np.dot with the python-float coefficients is float64; the reference divides by 255 in float64 and casts afterwards
+    # (_convert_output_type_range, utils/matlab_functions.py:354-361): casting first is off by one float32 ulp in some pixels
+    return ((np.dot(img.astype(np.float32), [24.966, 128.553, 65.481]) + 16.0) / 255.).astype(np.float32)
 
 
 def to_y_channel(img):

@@ -141,6 +141,44 @@ class _NetFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(G[k].view_as(ctx.P[k]) for k in ctx.names)
 
 
+class DRSformer(nn.Module):
+    """the un-guided network of the same file (reference :586-676): same constructor, registration order and `forward(inp_img)`;
+    MEFC sub-networks before the encoder and as the refinement stage; runs on the guided engine without the reference branch."""
+
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], heads=[1, 2, 4, 8],
+                 ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias'):
+        super().__init__()
+        self.patch_embed = OverlapPatchEmbed(inp_channels, dim)
+        self.encoder_level0 = subnet(dim)
+
+        def blocks(n, c, h):
+            return nn.Sequential(*[TransformerBlock(dim=c, num_heads=h, ffn_expansion_factor=ffn_expansion_factor, bias=bias,
+                                                    LayerNorm_type=LayerNorm_type) for _ in range(n)])
+        self.encoder_level1 = blocks(num_blocks[0], dim, heads[0])
+        self.down1_2 = Downsample(dim)
+        self.encoder_level2 = blocks(num_blocks[1], int(dim * 2 ** 1), heads[1])
+        self.down2_3 = Downsample(int(dim * 2 ** 1))
+        self.encoder_level3 = blocks(num_blocks[2], int(dim * 2 ** 2), heads[2])
+        self.down3_4 = Downsample(int(dim * 2 ** 2))
+        self.latent = blocks(num_blocks[3], int(dim * 2 ** 3), heads[3])
+        self.up4_3 = Upsample(int(dim * 2 ** 3))
+        self.reduce_chan_level3 = nn.Conv2d(int(dim * 2 ** 3), int(dim * 2 ** 2), kernel_size=1, bias=bias)
+        self.decoder_level3 = blocks(num_blocks[2], int(dim * 2 ** 2), heads[2])
+        self.up3_2 = Upsample(int(dim * 2 ** 2))
+        self.reduce_chan_level2 = nn.Conv2d(int(dim * 2 ** 2), int(dim * 2 ** 1), kernel_size=1, bias=bias)
+        self.decoder_level2 = blocks(num_blocks[1], int(dim * 2 ** 1), heads[1])
+        self.up2_1 = Upsample(int(dim * 2 ** 1))
+        self.decoder_level1 = blocks(num_blocks[0], int(dim * 2 ** 1), heads[0])
+        self.refinement = subnet(dim=int(dim * 2 ** 1))
+        self.output = nn.Conv2d(int(dim * 2 ** 1), out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+        self.cfg = dict(inp_channels=inp_channels, out_channels=out_channels, dim=dim, num_blocks=list(num_blocks), heads=list(heads),
+                        ffn_expansion_factor=ffn_expansion_factor, bias=bias, LayerNorm_type=LayerNorm_type, mefc=True)
+
+    def forward(self, inp_img):
+        names, params = _named(self)
+        return _NetFn.apply(inp_img, None, names, self.cfg, *params)
+
+
 class DRSformerRefFusion(nn.Module):
     engine = DE
 

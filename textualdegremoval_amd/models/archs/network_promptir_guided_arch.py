@@ -72,6 +72,79 @@ class _NetFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(G[k] for k in ctx.names)
 
 
+class PromptIR(nn.Module):
+    """the un-guided network of the same file (reference :443-590): same constructor, registration order, parameter names and
+    `forward(inp_img, noise_emb=None)`; runs on the guided engine without the reference branch (promptir_engine.net_fwd(ref=None)).
+    Like the guided class it only runs as decoder=True with dim = 48 (R4); `chnl_reduce1-3` / `reduce_noise_channel_1-3` are
+    registered and never used, as in the reference."""
+    unused_parameter_prefixes = ('chnl_reduce1.', 'chnl_reduce2.', 'chnl_reduce3.', 'reduce_noise_channel_1.',
+                                 'reduce_noise_channel_2.', 'reduce_noise_channel_3.')
+
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4,
+                 heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias', decoder=False):
+        super().__init__()
+        if not decoder:
+            raise ValueError('PromptIR(decoder=False): the reference raises in up4_3 on its first forward pass (384-channel latent into '
+                             'Upsample(dim*4), network_promptir_guided_arch.py:497,557); only decoder=True runs')
+        if dim != 48:
+            raise ValueError('PromptIR(decoder=True) needs dim = 48: the prompt widths 64/128/320 and the +192/+224/+512 channel counts '
+                             'are hard-wired in the reference (:463-465, :498-521)')
+        self.patch_embed = OverlapPatchEmbed(inp_channels, dim)
+        self.decoder = decoder
+        self.prompt1 = PromptGenBlock(prompt_dim=64, prompt_len=5, prompt_size=64, lin_dim=96)
+        self.prompt2 = PromptGenBlock(prompt_dim=128, prompt_len=5, prompt_size=32, lin_dim=192)
+        self.prompt3 = PromptGenBlock(prompt_dim=320, prompt_len=5, prompt_size=16, lin_dim=384)
+        self.chnl_reduce1 = nn.Conv2d(64, 64, kernel_size=1, bias=bias)
+        self.chnl_reduce2 = nn.Conv2d(128, 128, kernel_size=1, bias=bias)
+        self.chnl_reduce3 = nn.Conv2d(320, 256, kernel_size=1, bias=bias)
+        self.reduce_noise_channel_1 = nn.Conv2d(dim + 64, dim, kernel_size=1, bias=bias)
+
+        def blocks(n, c, h):
+            return nn.Sequential(*[TransformerBlock(dim=c, num_heads=h, ffn_expansion_factor=ffn_expansion_factor, bias=bias,
+                                                    LayerNorm_type=LayerNorm_type) for _ in range(n)])
+
+        def tblock(c, h):
+            return TransformerBlock(dim=c, num_heads=h, ffn_expansion_factor=ffn_expansion_factor, bias=bias, LayerNorm_type=LayerNorm_type)
+        self.encoder_level1 = blocks(num_blocks[0], dim, heads[0])
+        self.down1_2 = Downsample(dim)
+        self.reduce_noise_channel_2 = nn.Conv2d(int(dim * 2 ** 1) + 128, int(dim * 2 ** 1), kernel_size=1, bias=bias)
+        self.encoder_level2 = blocks(num_blocks[1], int(dim * 2 ** 1), heads[1])
+        self.down2_3 = Downsample(int(dim * 2 ** 1))
+        self.reduce_noise_channel_3 = nn.Conv2d(int(dim * 2 ** 2) + 256, int(dim * 2 ** 2), kernel_size=1, bias=bias)
+        self.encoder_level3 = blocks(num_blocks[2], int(dim * 2 ** 2), heads[2])
+        self.down3_4 = Downsample(int(dim * 2 ** 2))
+        self.latent = blocks(num_blocks[3], int(dim * 2 ** 3), heads[3])
+        self.up4_3 = Upsample(int(dim * 2 ** 2))
+        self.reduce_chan_level3 = nn.Conv2d(int(dim * 2 ** 1) + 192, int(dim * 2 ** 2), kernel_size=1, bias=bias)
+        self.noise_level3 = tblock(int(dim * 2 ** 2) + 512, heads[2])
+        self.reduce_noise_level3 = nn.Conv2d(int(dim * 2 ** 2) + 512, int(dim * 2 ** 2), kernel_size=1, bias=bias)
+        self.decoder_level3 = blocks(num_blocks[2], int(dim * 2 ** 2), heads[2])
+        self.up3_2 = Upsample(int(dim * 2 ** 2))
+        self.reduce_chan_level2 = nn.Conv2d(int(dim * 2 ** 2), int(dim * 2 ** 1), kernel_size=1, bias=bias)
+        self.noise_level2 = tblock(int(dim * 2 ** 1) + 224, heads[2])
+        self.reduce_noise_level2 = nn.Conv2d(int(dim * 2 ** 1) + 224, int(dim * 2 ** 2), kernel_size=1, bias=bias)
+        self.decoder_level2 = blocks(num_blocks[1], int(dim * 2 ** 1), heads[1])
+        self.up2_1 = Upsample(int(dim * 2 ** 1))
+        self.noise_level1 = tblock(int(dim * 2 ** 1) + 64, heads[2])
+        self.reduce_noise_level1 = nn.Conv2d(int(dim * 2 ** 1) + 64, int(dim * 2 ** 1), kernel_size=1, bias=bias)
+        self.decoder_level1 = blocks(num_blocks[0], int(dim * 2 ** 1), heads[0])
+        self.refinement = blocks(num_refinement_blocks, int(dim * 2 ** 1), heads[0])
+        self.output = nn.Conv2d(int(dim * 2 ** 1), out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+        self.cfg = dict(inp_channels=inp_channels, out_channels=out_channels, dim=dim, num_blocks=list(num_blocks),
+                        num_refinement_blocks=num_refinement_blocks, heads=list(heads), ffn_expansion_factor=ffn_expansion_factor,
+                        bias=bias, LayerNorm_type=LayerNorm_type, decoder=decoder)
+        for k, p in self.named_parameters():
+            if k.startswith(self.unused_parameter_prefixes):
+                p.requires_grad_(False)
+
+    def used_named_parameters(self):
+        return [(k, p) for k, p in self.named_parameters() if not k.startswith(self.unused_parameter_prefixes)]
+
+    def forward(self, inp_img, noise_emb=None):
+        names, params = zip(*self.used_named_parameters())
+        return _NetFn.apply(inp_img, None, list(names), self.cfg, *params)
+
+
 class PromptIRRefFusion(nn.Module):
     engine = PE         # image_restoration_ref_model dispatches its fused step through `net.engine`
     # registered by the reference (:647-651, :668, :687) but never used in forward: part of the state dict, no gradient

@@ -72,20 +72,34 @@ def _prompt_stage_bwd(d, P, k, heads, ln, saved, G):
 # whole network  PromptIRRefFusion.forward (:864-1092)
 # ---------------------------------------------------------------------------
 def net_fwd(P, cfg, inp, ref):
-    if not cfg.get('decoder', True) or cfg['dim'] != 48 or cfg['nf'] != 48:
-        raise ValueError('PromptIR-ref exists only as decoder=True, dim = nf = 48 (the reference raises otherwise: defect R4)')
+    """ref = None: the UN-GUIDED `PromptIR` of the same file (:443-590): no MASA pyramid, no fusion blocks, no padding (sizes must
+    be multiples of 8).  Like the guided class it only exists as decoder=True, dim = 48 (with decoder=False its up4_3 receives
+    the 384-channel latent on a 192-channel convolution and the reference raises: R4)."""
+    guided = ref is not None
+    if not cfg.get('decoder', True) or cfg['dim'] != 48 or (guided and cfg['nf'] != 48):
+        raise ValueError('PromptIR(-ref) exists only as decoder=True, dim = nf = 48 (the reference raises otherwise: defect R4)')
     N = inp.shape[0]
-    pyr, (H0, W0, Hp, Wp) = E.pyramids_fwd(P, cfg, inp, ref, PADDER_LOG2, 4)
+    if guided:
+        pyr, (H0, W0, Hp, Wp) = E.pyramids_fwd(P, cfg, inp, ref, PADDER_LOG2, 4)
+        warp, sv_masa = E.masa_fwd(pyr.lq_deep, pyr.ref_feats, N, pyr.geo)
+    else:
+        H0, W0 = inp.shape[2:]
+        if H0 % 8 or W0 % 8:
+            raise ValueError(f'PromptIR: H, W must be multiples of 8 (three PixelUnshuffle(2) stages); got {H0}x{W0}')
+        Hp, Wp = H0, W0
+        import types
+        pyr, warp, sv_masa = types.SimpleNamespace(inp_p=inp.contiguous(), geo=None), None, None
     inp_p, geo = pyr.inp_p, pyr.geo
-    warp, sv_masa = E.masa_fwd(pyr.lq_deep, pyr.ref_feats, N, geo)
-    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
+    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg.get('reffusion_n_blocks'), cfg['dim']
 
     x = E.conv_fwd(inp_p, P['patch_embed.proj.weight'], P.get('patch_embed.proj.bias'), 1, 1)
     sv_lv, enc_out = [], []
     for l in range(4):
         c = dim * 2 ** l
-        f, sv_f = R.seq_fwd(K.concat2(x, warp[l]), P, R._FUS[l], nfz[l], hd[l], ln, fusion=True)
-        x = K.slice_channels(f, 0, c)
+        sv_f = None
+        if guided:
+            f, sv_f = R.seq_fwd(K.concat2(x, warp[l]), P, R._FUS[l], nfz[l], hd[l], ln, fusion=True)
+            x = K.slice_channels(f, 0, c)
         e, sv_e = R.seq_fwd(x, P, R._ENC[l], nb[l], hd[l], ln)
         enc_out.append(e)
         sv_lv.append((sv_f, sv_e))
@@ -119,7 +133,7 @@ def _net_bwd(dout, P, cfg, saved, G):
     (N, (H0, W0, Hp, Wp), geo, pyr, _, _, sv_masa, sv_lv, enc_out, sv_p3, p3, cat3, sv_d3, sv_p2, p2, cat2, sv_d2,
      sv_p1, p1, sv_d1, rf, sv_rf) = saved
     G = {} if G is None else G
-    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
+    hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg.get('reffusion_n_blocks'), cfg['dim']
     inp_p = pyr.inp_p
     dout = dout.contiguous()
     if (Hp, Wp) != (H0, W0):
@@ -149,11 +163,13 @@ def _net_bwd(dout, P, cfg, saved, G):
         c = dim * 2 ** l
         sv_f, sv_e = sv_lv[l]
         d = R.seq_bwd(d, P, R._ENC[l], nb[l], hd[l], ln, sv_e, G)
-        df = torch.zeros(N, 2 * c, d.shape[2], d.shape[3], dtype=torch.float32, device=d.device)
-        K.copy_rows(d, c * d.shape[2] * d.shape[3], df, 2 * c * d.shape[2] * d.shape[3], N, c * d.shape[2] * d.shape[3])
-        dcat = R.seq_bwd(df, P, R._FUS[l], nfz[l], hd[l], ln, sv_f, G, fusion=True)
-        dwarp[l] = dcat[:, c:]
-        dx = K.slice_channels(dcat, 0, c)
+        dx = d
+        if sv_f is not None:
+            df = torch.zeros(N, 2 * c, d.shape[2], d.shape[3], dtype=torch.float32, device=d.device)
+            K.copy_rows(d, c * d.shape[2] * d.shape[3], df, 2 * c * d.shape[2] * d.shape[3], N, c * d.shape[2] * d.shape[3])
+            dcat = R.seq_bwd(df, P, R._FUS[l], nfz[l], hd[l], ln, sv_f, G, fusion=True)
+            dwarp[l] = dcat[:, c:]
+            dx = K.slice_channels(dcat, 0, c)
         if l > 0:
             d, G[R._DOWN[l - 1]] = R.down_bwd(dx, enc_out[l - 1], P[R._DOWN[l - 1]])
             d = K.add_(d, dskip[l - 1])
@@ -163,5 +179,6 @@ def _net_bwd(dout, P, cfg, saved, G):
                                                              bias=has_pb)
             if has_pb:
                 G['patch_embed.proj.bias'] = db
-    E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
+    if sv_masa is not None:
+        E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
     return G
