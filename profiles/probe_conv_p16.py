@@ -77,7 +77,9 @@ def timing(N, Cc, H):
     line = f'3x3 {Cc}->{Cc} @{H} N{N}: old {t_old:7.1f} us | p16_from_f32 {t_cvt:6.1f} us |'
     flop = 2.0 * N * Cc * Cc * 9 * H * H
     for cfg in CFGS:
-        if cfg not in (3, 4, 6) and cfg < 100 and Cc < 64:
+        if cfg not in (3, 4, 6, 30, 31, 32, 33, 34, 35, 36, 130, 131, 132) and Cc < 64:
+            continue
+        if cfg in (30, 31, 32, 33, 34, 35, 36, 130, 131, 132) and Cc > 32:
             continue
         lib.tdr_conv3x3_p16_force_cfg(cfg)
         for tag, kw in (('f32', dict(want32=True, want16=False)), ('p16', dict(want32=False, want16=True))):
@@ -101,6 +103,8 @@ if what in ('check', 'all'):
         allok &= check(1, 16, 16, 8, 8, cfg, mask_kind='p16', bias=False)
         allok &= check(1, 128, 128, 64, 64, cfg, res_kind='f32', mask_kind='f32')
         allok &= check(1, 32, 24, 33, 31, cfg)
+        allok &= check(2, 32, 32, 40, 70, cfg, res_kind='p16', mask_kind='p16', relu=True)
+        allok &= check(3, 16, 32, 17, 96, cfg, res_kind='f32')
     print('ALL OK' if allok else 'SOME FAILED', flush=True)
 if what in ('time', 'all'):
     timing(8, 32, 512)

@@ -24,6 +24,7 @@
 // Replaces (reference): the 3x3 convolutions of the MASA encoder's ResidualBlocks, forward and data gradient
 // (models/archs/network_nafnet_guided_arch.py:44-59,110-143 and their autograd).
 #include <stdlib.h>
+#include <stdint.h>
 #include <type_traits>
 #include "tdr_common.h"
 #include "../../include/tdr.h"
@@ -66,6 +67,224 @@ struct P16Args {
 template <int N>
 __device__ __forceinline__ void wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// ---- epilogue shared by the kernels of this file (accumulator layout: lane (j, kk) holds pixel j of row tn, channels
+// mb + (r&3) + 8*(r>>2), mb = .. + 4*kk): bias, residual (fp32 tensor or pair planes), ReLU, mask (fp32 tensor or the sign bit of
+// the head plane), then the fp32 NCHW store and / or the pair-plane store incl. the zero border of the output tensor.
+template <int TM, int TN>
+__device__ __forceinline__ void p16_epilogue(const P16Args& a, f32x16 (&acc)[TM][TN], int n, int m0, int wm, int wn, int oy0, int ox0, int j, int kk) {
+    const long PS = (long)a.Hp * a.Wp;
+    const long HW = (long)a.H * a.W;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int oy = oy0 + wn * TN + tn, ox = ox0 + j;
+        const bool pvalid = oy < a.H && ox < a.W;
+        const long pix = pvalid ? (long)oy * a.W + ox : 0;
+        const long pslot = pvalid ? (long)(oy + 1) * a.Wp + ox + 1 : 0;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            __builtin_amdgcn_sched_barrier(0);     // one tile at a time: hoisting every tile's operand loads spills
+            const int mt0 = m0 + (wm * TM + tm) * 32;
+            const int mb = mt0 + 4 * kk;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r];
+            if (a.bias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += a.bias[min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+            }
+            if (a.res32) {
+                float tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tv[r] = a.res32[(long)n * a.res32_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HW + pix];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += tv[r];
+            }
+            if (a.res16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);
+                    const char* p = reinterpret_cast<const char*>(a.res16 + (long)n * a.res16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
+                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
+                    const pf16x4 m = *reinterpret_cast<const pf16x4*>(p + PS * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)h[e] + (float)m[e];
+                }
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.mask32) {
+                float tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tv[r] = a.mask32[(long)n * a.mask32_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HW + pix];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = tv[r] > 0.f ? v[r] : 0.f;
+            }
+            if (a.mask16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);
+                    const char* p = reinterpret_cast<const char*>(a.mask16 + (long)n * a.mask16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
+                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = p16_positive(h[e]) ? v[4 * q + e] : 0.f;
+                }
+            }
+            if (a.out32) {
+                float* op = a.out32 + (long)n * a.out32_ns + pix;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (pvalid && m < a.Cout) op[(long)m * HW] = v[r];
+                }
+            }
+            if (a.out16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!pvalid || mt0 + 8 * q >= a.Cout) continue;
+                    pf16x4 h, m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[4 * q + e];
+                        asm volatile("" : "+v"(x));          // head and residual from the same fp32 value
+                        const _Float16 hh = (_Float16)x;
+                        h[e] = p16_head(x);
+                        m[e] = (_Float16)(x - (float)hh);
+                    }
+                    char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * 2 * PS) + kk * 8;
+                    *reinterpret_cast<pf16x4*>(base + pslot * 16) = h;
+                    *reinterpret_cast<pf16x4*>(base + (PS + pslot) * 16) = m;
+                    // the zero border of the output tensor is written by the tiles that touch it
+                    const pf16x4 z = {0, 0, 0, 0};
+                    const bool top = oy == 0, bot = oy == a.H - 1, lef = ox == 0, rig = ox == a.W - 1;
+                    if (top | bot | lef | rig) {
+                        const long Wp = a.Wp;
+                        auto zero_at = [&](long sl) {
+                            *reinterpret_cast<pf16x4*>(base + sl * 16) = z;
+                            *reinterpret_cast<pf16x4*>(base + (PS + sl) * 16) = z;
+                        };
+                        if (top) zero_at(ox + 1);
+                        if (bot) zero_at((long)(a.H + 1) * Wp + ox + 1);
+                        if (lef) zero_at((long)(oy + 1) * Wp);
+                        if (rig) zero_at((long)(oy + 1) * Wp + a.W + 1);
+                        if (top && lef) zero_at(0);
+                        if (top && rig) zero_at(a.W + 1);
+                        if (bot && lef) zero_at((long)(a.H + 1) * Wp);
+                        if (bot && rig) zero_at((long)(a.H + 1) * Wp + a.W + 1);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the same epilogue one half-octet at a time (a handful of live registers): for the thin-level kernels, which keep the weight
+// fragments of all steps resident; 5 - 10 % slower on the main kernel (less memory-level parallelism), hence separate
+template <int TM, int TN>
+__device__ __forceinline__ void p16_epilogue_lean(const P16Args& a, f32x16 (&acc)[TM][TN], int n, int m0, int wm, int wn, int oy0, int ox0, int j, int kk) {
+    const long PS = (long)a.Hp * a.Wp;
+    const long HW = (long)a.H * a.W;
+    // One half-octet (the 4 consecutive channels mt0 + 8q + 4kk .. of this lane) at a time, fenced from the next: a handful of live
+    // registers.  Hoisting the operand loads of a whole 32 x 32 tile (or of every tile) spilled hundreds of bytes per lane in the
+    // kernels that keep large accumulator / weight sets resident.
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int oy = oy0 + wn * TN + tn, ox = ox0 + j;
+        const bool pvalid = oy < a.H && ox < a.W;
+        const long pix = pvalid ? (long)oy * a.W + ox : 0;
+        const long pslot = pvalid ? (long)(oy + 1) * a.Wp + ox + 1 : 0;
+        const bool top = oy == 0, bot = oy == a.H - 1, lef = ox == 0, rig = ox == a.W - 1;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int mt0 = m0 + (wm * TM + tm) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int c0 = mt0 + 8 * q + 4 * kk;                          // first of the lane's 4 channels
+                const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);        // its octet (pair-plane operands)
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[tm][tn][4 * q + e];
+                if (a.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += a.bias[min(c0 + e, a.Cout - 1)];
+                }
+                if (a.res32) {
+                    float tv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tv[e] = a.res32[(long)n * a.res32_ns + (long)min(c0 + e, a.Cout - 1) * HW + pix];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += tv[e];
+                }
+                if (a.res16) {
+                    const char* p = reinterpret_cast<const char*>(a.res16 + (long)n * a.res16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
+                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
+                    const pf16x4 m = *reinterpret_cast<const pf16x4*>(p + PS * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)h[e] + (float)m[e];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.mask32) {
+                    float tv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tv[e] = a.mask32[(long)n * a.mask32_ns + (long)min(c0 + e, a.Cout - 1) * HW + pix];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tv[e] > 0.f ? v[e] : 0.f;
+                }
+                if (a.mask16) {
+                    const char* p = reinterpret_cast<const char*>(a.mask16 + (long)n * a.mask16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
+                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = p16_positive(h[e]) ? v[e] : 0.f;
+                }
+                if (a.out32) {
+                    float* op = a.out32 + (long)n * a.out32_ns + pix;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (pvalid && c0 + e < a.Cout) op[(long)(c0 + e) * HW] = v[e];
+                }
+                if (a.out16 && pvalid && mt0 + 8 * q < a.Cout) {
+                    pf16x4 h, m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e];
+                        asm volatile("" : "+v"(x));          // head and residual from the same fp32 value
+                        const _Float16 hh = (_Float16)x;
+                        h[e] = p16_head(x);
+                        m[e] = (_Float16)(x - (float)hh);
+                    }
+                    char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * 2 * PS) + kk * 8;
+                    *reinterpret_cast<pf16x4*>(base + pslot * 16) = h;
+                    *reinterpret_cast<pf16x4*>(base + (PS + pslot) * 16) = m;
+                    // the zero border of the output tensor is written by the tiles that touch it
+                    if (top | bot | lef | rig) {
+                        const pf16x4 z = {0, 0, 0, 0};
+                        const long Wp = a.Wp;
+                        auto zero_at = [&](long sl) {
+                            *reinterpret_cast<pf16x4*>(base + sl * 16) = z;
+                            *reinterpret_cast<pf16x4*>(base + (PS + sl) * 16) = z;
+                        };
+                        if (top) zero_at(ox + 1);
+                        if (bot) zero_at((long)(a.H + 1) * Wp + ox + 1);
+                        if (lef) zero_at((long)(oy + 1) * Wp);
+                        if (rig) zero_at((long)(oy + 1) * Wp + a.W + 1);
+                        if (top && lef) zero_at(0);
+                        if (top && rig) zero_at(a.W + 1);
+                        if (bot && lef) zero_at((long)(a.H + 1) * Wp);
+                        if (bot && rig) zero_at((long)(a.H + 1) * Wp + a.W + 1);
+                    }
+                }
+            }
+        }
+    }
 }
 
 // Workgroup = NW = WM x WN waves (4 or 8), tile = BM output channels x TH rows x 32 columns; wave (wm, wn) owns m-tiles wm*TM..
@@ -268,113 +487,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
         if (sum == 1.2345f && a.out32) a.out32[0] = sum;
         return;
     }
-    // ---- epilogue (accumulator layout: lane (j, kk) holds pixel j of row tn, channels mb + (r&3) + 8*(r>>2), mb = .. + 4*kk)
-    const long HW = (long)a.H * a.W;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int oy = oy0 + wn * TN + tn, ox = ox0 + j;
-        const bool pvalid = oy < a.H && ox < a.W;
-        const long pix = pvalid ? (long)oy * a.W + ox : 0;
-        const long pslot = pvalid ? (long)(oy + 1) * a.Wp + ox + 1 : 0;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            __builtin_amdgcn_sched_barrier(0);     // one tile at a time: hoisting every tile's operand loads spills
-            const int mt0 = m0 + (wm * TM + tm) * 32;
-            const int mb = mt0 + 4 * kk;
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r];
-            if (a.bias) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += a.bias[min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
-            }
-            if (a.res32) {
-                float tv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    tv[r] = a.res32[(long)n * a.res32_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HW + pix];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += tv[r];
-            }
-            if (a.res16) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);
-                    const char* p = reinterpret_cast<const char*>(a.res16 + (long)n * a.res16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
-                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
-                    const pf16x4 m = *reinterpret_cast<const pf16x4*>(p + PS * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)h[e] + (float)m[e];
-                }
-            }
-            if (a.relu) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (a.mask32) {
-                float tv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    tv[r] = a.mask32[(long)n * a.mask32_ns + (long)min(mb + (r & 3) + 8 * (r >> 2), a.Cout - 1) * HW + pix];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = tv[r] > 0.f ? v[r] : 0.f;
-            }
-            if (a.mask16) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);
-                    const char* p = reinterpret_cast<const char*>(a.mask16 + (long)n * a.mask16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
-                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * q + e] = p16_positive(h[e]) ? v[4 * q + e] : 0.f;
-                }
-            }
-            if (a.out32) {
-                float* op = a.out32 + (long)n * a.out32_ns + pix;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (pvalid && m < a.Cout) op[(long)m * HW] = v[r];
-                }
-            }
-            if (a.out16) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (!pvalid || mt0 + 8 * q >= a.Cout) continue;
-                    pf16x4 h, m;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = v[4 * q + e];
-                        asm volatile("" : "+v"(x));          // head and residual from the same fp32 value
-                        const _Float16 hh = (_Float16)x;
-                        h[e] = p16_head(x);
-                        m[e] = (_Float16)(x - (float)hh);
-                    }
-                    char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * 2 * PS) + kk * 8;
-                    *reinterpret_cast<pf16x4*>(base + pslot * 16) = h;
-                    *reinterpret_cast<pf16x4*>(base + (PS + pslot) * 16) = m;
-                    // the zero border of the output tensor is written by the tiles that touch it
-                    const pf16x4 z = {0, 0, 0, 0};
-                    const bool top = oy == 0, bot = oy == a.H - 1, lef = ox == 0, rig = ox == a.W - 1;
-                    if (top | bot | lef | rig) {
-                        const long Wp = a.Wp;
-                        auto zero_at = [&](long sl) {
-                            *reinterpret_cast<pf16x4*>(base + sl * 16) = z;
-                            *reinterpret_cast<pf16x4*>(base + (PS + sl) * 16) = z;
-                        };
-                        if (top) zero_at(ox + 1);
-                        if (bot) zero_at((long)(a.H + 1) * Wp + ox + 1);
-                        if (lef) zero_at((long)(oy + 1) * Wp);
-                        if (rig) zero_at((long)(oy + 1) * Wp + a.W + 1);
-                        if (top && lef) zero_at(0);
-                        if (top && rig) zero_at(a.W + 1);
-                        if (bot && lef) zero_at((long)(a.H + 1) * Wp);
-                        if (bot && rig) zero_at((long)(a.H + 1) * Wp + a.W + 1);
-                    }
-                }
-            }
-        }
-    }
+    p16_epilogue<TM, TN>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
 }
 
 template <int TM, int TN, int WM, int WN, bool PIPE, int ABL = 0, bool ILV = false>
@@ -396,6 +509,258 @@ int launch_p16(const P16Args& a0, int N, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);
     TDR_LAUNCH_CHECK("conv3x3_p16_kernel");
+    return TDR_OK;
+}
+
+// ---- thin levels (Cin <= 32, Cout <= 32: the C = 32 level of the MASA encoder at full resolution: 18 (group, tap) steps, one m-tile).
+// The whole weight pack (<= 36 KiB) is loaded into LDS ONCE per workgroup; workgroups are persistent and walk pixel tiles of
+// TH x 32 outputs; the halo tile of ALL channels of a pixel tile (2 groups x 4 planes) is loaded in one go, so a tile is
+// [barrier, LDS-DMA of the next halo tile issued, epilogue stores of the previous tile, wait, barrier, 18 barrier-free steps].
+// The launch is HBM-bound (4 B in + 4 B out per element and 0.3 kflop per byte): what matters is that the stream never stops --
+// two workgroups per CU alternate between their load and MFMA phases.
+template <int TN, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_p16_thin_kernel(P16Args a, int ntiles) {
+    constexpr int TH = 4 * TN, LH = TH + 2, LW = 34, TS = LH * LW;
+    constexpr int NBW = (4 * TS + 255) / 256, BREG = 4 * TS;            // exact: the last piece is exec-masked, no padding
+    constexpr int MAXG = 2;
+    extern __shared__ __attribute__((aligned(1024))) uint4 smem4[];
+    uint4* sB = smem4;                         // [MAXG][BREG]
+    uint4* sA = smem4 + MAXG * BREG;           // [ngroups * 9][2 planes][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kk = lane >> 5;
+    const long PS = (long)a.Hp * a.Wp;
+    const int ngroups = a.Cin >> 4, S = ngroups * 9;
+    // weights: S steps x 2 pieces (m-tile 0 of every (group, tap)); pieces i = wave, wave + 4, ..
+    for (int i = wave; i < 2 * S; i += 4) {
+        const char* src = reinterpret_cast<const char*>(a.wp) + ((long)(i >> 1) * a.MT * 2 + (i & 1)) * 1024 + lane * 16;
+        P16_GLDS(src, sA + i * 64);
+    }
+    // halo pieces: tile-independent decomposition of the flat slot index
+    int prc[NBW];
+    unsigned plin[NBW];
+    bool pok[NBW];
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+        const int f0 = (k * 4 + wave) * 64 + lane;
+        pok[k] = f0 < 4 * TS;
+        const int f = min(f0, 4 * TS - 1);
+        const int op = f / TS, sl = f - op * TS;
+        const int r = sl / LW, c = sl - r * LW;
+        prc[k] = (r << 8) | c;
+        plin[k] = (unsigned)(op * PS * 16);
+    }
+    const uint4* pa0 = sA + lane;
+    const uint4* pb0 = sB + kk * 2 * TS + (wave * TN) * LW + j;
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+    const int tiles_xy = a.tiles_x * a.tiles_y;
+
+    auto issue_tile = [&](int t) {
+        const int n = t / tiles_xy, r0 = t - n * tiles_xy;
+        const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
+        const char* base = reinterpret_cast<const char*>(a.in + (long)n * a.in_ns);
+#pragma unroll
+        for (int k = 0; k < NBW; ++k) {
+            const int gy = min(ty * TH + (prc[k] >> 8), a.Hp - 1), gx = min(tx * 32 + (prc[k] & 255), a.Wp - 1);
+            const unsigned off = plin[k] + (unsigned)((gy * a.Wp + gx) * 16);
+            if (pok[k])                          // lanes past the tile write nothing (LDS-DMA honours EXEC)
+                for (int g = 0; g < ngroups; ++g) P16_GLDS(base + (long)g * 64 * PS + off, sB + g * BREG + (k * 4 + wave) * 64);
+        }
+    };
+
+    f32x16 acc[1][TN];
+    int tprev = -1;
+    int t = blockIdx.x;
+    if (t < ntiles) issue_tile(t);
+    for (; t < ntiles; t += gridDim.x) {
+        // this tile's halo (and, first time, the weights) have landed; the stores of tile t - 2 strides are long done
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tprev >= 0 && !(ABL & 16)) {      // the previous tile's stores go out now and drain under this tile's MFMAs
+            const int n = tprev / tiles_xy, r0 = tprev - n * tiles_xy;
+            const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
+            p16_epilogue_lean<1, TN>(a, acc, n, 0, 0, wave, ty * TH, tx * 32, j, kk);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
+        for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const uint4* pa = pa0 + (g * 9 + tap) * 128;
+                const uint4* pb = pb0 + g * BREG + (tap / 3) * LW + (tap % 3);
+                pf16x8 af[2], bf[TN][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) af[s2] = __builtin_bit_cast(pf16x8, pa[s2 * 64]);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) bf[tn][s2] = __builtin_bit_cast(pf16x8, pb[s2 * TS + tn * LW]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[HA[q]], bf[tn][HB[q]], acc[0][tn], 0, 0, 0);
+            }
+        }
+        // every wave is done reading the halo tile: the next tile's pieces go out
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int tnext = t + gridDim.x;
+        if (tnext < ntiles && !(ABL & 1)) issue_tile(tnext);
+        tprev = t;
+    }
+    if (tprev >= 0) {
+        const int n = tprev / tiles_xy, r0 = tprev - n * tiles_xy;
+        const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
+        p16_epilogue_lean<1, TN>(a, acc, n, 0, 0, wave, ty * TH, tx * 32, j, kk);
+    }
+}
+
+template <int TN, int ABL = 0>
+int launch_p16_thin(const P16Args& a0, int N, hipStream_t st) {
+    constexpr int TH = 4 * TN, TS = (TH + 2) * 34, BREG = 4 * TS;
+    P16Args a = a0;
+    a.tiles_x = tdr_cdiv(a.W, 32);
+    a.tiles_y = tdr_cdiv(a.H, TH);
+    a.mtiles = 1;
+    const int ngroups = a.Cin >> 4;
+    const long ntiles = (long)a.tiles_x * a.tiles_y * N;
+    const size_t lds = (size_t)(2 * BREG + ngroups * 9 * 128) * 16;
+    static const int wgs = getenv("TDR_P16_THIN_WGS") ? atoi(getenv("TDR_P16_THIN_WGS")) : 512;      // 2 resident workgroups x 256 CUs
+    const int grid = (int)(ntiles < wgs ? ntiles : wgs);
+    auto kern = conv3x3_p16_thin_kernel<TN, ABL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, (int)ntiles);
+    TDR_LAUNCH_CHECK("conv3x3_p16_thin_kernel");
+    return TDR_OK;
+}
+
+// ---- thin levels, second structure: ONE 8-wave workgroup per CU, the weight fragments of all (group, tap) steps in REGISTERS (one
+// m-tile: 18 x 2 fragments = 144 VGPRs, loaded once per workgroup -- the fragment reads of the weights were half of the LDS traffic
+// of an LDS-read-bound loop), the whole-K halo tile double buffered in LDS.  Per tile: [stores of tile t-1] -> [LDS-DMA of tile
+// t+1 into the other buffer] -> [18 barrier-free steps on tile t] -> wait + barrier: loads and stores are both issued a whole
+// compute phase before anything waits for them.  LDS-DMA by inline asm (hipcc would put vmcnt(0) in front of the fragment reads).
+__device__ __forceinline__ void p16_glds_asm(const char* src, const uint4* dst) {
+    const unsigned l = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(l) : "memory");
+}
+
+template <int TN, int ABL = 0>
+__global__ __launch_bounds__(512) void conv3x3_p16_thin8_kernel(P16Args a, int ntiles) {
+    constexpr int TH = 8 * TN, LH = TH + 2, LW = 34, TS = LH * LW;
+    constexpr int NBW = (4 * TS + 511) / 512, BREG = 4 * TS;
+    extern __shared__ __attribute__((aligned(1024))) uint4 smem4[];      // [2 buffers][2 groups][BREG]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kk = lane >> 5;
+    const long PS = (long)a.Hp * a.Wp;
+    const int ngroups = a.Cin >> 4;
+    pf16x8 aw[18][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 18; ++s2) {
+        const int sc = min(s2, ngroups * 9 - 1);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            aw[s2][pl] = __builtin_bit_cast(pf16x8, a.wp[((long)sc * a.MT * 2 + pl) * 64 + lane]);
+    }
+    int prc[NBW];
+    unsigned plin[NBW];
+    bool pok[NBW];
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+        const int f0 = (k * 8 + wave) * 64 + lane;
+        pok[k] = f0 < 4 * TS;
+        const int f = min(f0, 4 * TS - 1);
+        const int op = f / TS, sl = f - op * TS;
+        const int r = sl / LW, c = sl - r * LW;
+        prc[k] = (r << 8) | c;
+        plin[k] = (unsigned)(op * PS * 16);
+    }
+    const uint4* pb0 = smem4 + kk * 2 * TS + (wave * TN) * LW + j;
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+    const int tiles_xy = a.tiles_x * a.tiles_y;
+
+    auto issue_tile = [&](int t, int buf) {
+        const int n = t / tiles_xy, r0 = t - n * tiles_xy;
+        const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
+        const char* base = reinterpret_cast<const char*>(a.in + (long)n * a.in_ns);
+#pragma unroll
+        for (int k = 0; k < NBW; ++k) {
+            const int gy = min(ty * TH + (prc[k] >> 8), a.Hp - 1), gx = min(tx * 32 + (prc[k] & 255), a.Wp - 1);
+            const unsigned off = plin[k] + (unsigned)((gy * a.Wp + gx) * 16);
+            if (pok[k])
+                for (int g = 0; g < ngroups; ++g)
+                    p16_glds_asm(base + (long)g * 64 * PS + off, smem4 + (buf * 2 + g) * BREG + (k * 8 + wave) * 64);
+        }
+    };
+    auto tile_epilogue = [&](int t, f32x16 (&acc)[1][TN]) {
+        const int n = t / tiles_xy, r0 = t - n * tiles_xy;
+        const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
+        p16_epilogue_lean<1, TN>(a, acc, n, 0, 0, wave, ty * TH, tx * 32, j, kk);
+    };
+
+    f32x16 acc[1][TN];
+    int tprev = -1, it = 0;
+    int t = blockIdx.x;
+    if (t < ntiles) issue_tile(t, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (; t < ntiles; t += gridDim.x, ++it) {
+        const int buf = it & 1;
+        if (tprev >= 0 && !(ABL & 16)) tile_epilogue(tprev, acc);
+        const int tnext = t + gridDim.x;
+        if (tnext < ntiles && !(ABL & 1)) issue_tile(tnext, buf ^ 1);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (g < ngroups) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const uint4* pb = pb0 + (buf * 2 + g) * BREG + (tap / 3) * LW + (tap % 3);
+                    pf16x8 bf[TN][2];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) bf[tn][s2] = __builtin_bit_cast(pf16x8, pb[s2 * TS + tn * LW]);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[g * 9 + tap][HA[q]], bf[tn][HB[q]], acc[0][tn], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        tprev = t;
+    }
+    if (tprev >= 0) tile_epilogue(tprev, acc);
+}
+
+template <int TN, int ABL = 0>
+int launch_p16_thin8(const P16Args& a0, int N, hipStream_t st) {
+    constexpr int TH = 8 * TN, TS = (TH + 2) * 34, BREG = 4 * TS;
+    P16Args a = a0;
+    a.tiles_x = tdr_cdiv(a.W, 32);
+    a.tiles_y = tdr_cdiv(a.H, TH);
+    a.mtiles = 1;
+    const long ntiles = (long)a.tiles_x * a.tiles_y * N;
+    const size_t lds = (size_t)(4 * BREG) * 16;
+    static const int wgs = getenv("TDR_P16_THIN8_WGS") ? atoi(getenv("TDR_P16_THIN8_WGS")) : 256;      // one resident workgroup per CU
+    const int grid = (int)(ntiles < wgs ? ntiles : wgs);
+    auto kern = conv3x3_p16_thin8_kernel<TN, ABL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, (int)ntiles);
+    TDR_LAUNCH_CHECK("conv3x3_p16_thin8_kernel");
     return TDR_OK;
 }
 
@@ -496,6 +861,18 @@ extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
     const int N = d->N;
     auto blocks = [&](int bm, int th) { return (long)tdr_cdiv(d->Cout, bm) * tdr_cdiv(d->H, th) * tdr_cdiv(d->W, 32) * N; };
     int cfg = g_p16_cfg;
+    if (cfg >= 32 && cfg <= 36 && d->Cin <= 32 && d->Cout <= 32)
+        return cfg == 32 ? launch_p16_thin8<1>(a, N, st) : (cfg == 33 ? launch_p16_thin8<2>(a, N, st) : (cfg == 34 ? launch_p16_thin8<1, 1>(a, N, st) :
+               (cfg == 35 ? launch_p16_thin8<1, 16>(a, N, st) : launch_p16_thin8<1, 17>(a, N, st))));
+    if (cfg >= 130 && cfg <= 132 && d->Cin <= 32 && d->Cout <= 32)      // timing ablations of the thin kernel (wrong results)
+        return cfg == 130 ? launch_p16_thin<2, 1>(a, N, st) : (cfg == 131 ? launch_p16_thin<2, 16>(a, N, st) : launch_p16_thin<2, 17>(a, N, st));
+    if ((cfg == 0 || cfg == 30 || cfg == 31) && d->Cin <= 32 && d->Cout <= 32) {
+        // thin level: weights-stationary persistent kernel (TN = 2: 8 x 32 pixel tiles; cfg 31: 4 x 32).  Measured at 32 -> 32 @512^2, N = 8
+        // (profiles/r4/probe_p16_thin*.log): 182 - 195 us against 208 - 212 us of the fp32-tensor kernel and a ~125 us HBM floor (624 MB);
+        // the 8-wave / weights-in-registers structure (cfg 32 / 33) hides the loads (108 us without its epilogue) but not yet the stores.
+        return cfg == 31 ? launch_p16_thin<1>(a, N, st) : launch_p16_thin<2>(a, N, st);
+    }
+    if (cfg >= 30 && cfg <= 36) cfg = 0;          // forced thin configuration on a shape it does not take
     if (cfg == 0) {
         // profiles/r4/probe_p16_v3.log (N = 8, C = 64 .. 512 at 256^2 .. 32^2): the 64 x (8 x 32) tile with pipelined fragments and
         // LDS-DMA / fragment reads interleaved with the MFMAs is the best or within 2 % of the best at every level
