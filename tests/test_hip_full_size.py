@@ -55,6 +55,23 @@ def psnr(a, b):
     return 10.0 * math.log10(1.0 / max(mse, 1e-20))
 
 
+
+def _worst_gradient_gap(G, fwd, P, gt, dtype):
+    """autograd through the oracle in `dtype`; worst |G - g| / max|g| over the parameter tensors"""
+    Pr = {k: v.clone().to(dtype).requires_grad_(True) for k, v in P.items()}
+    rl = O.l1_loss(fwd(Pr), gt.to(dtype))
+    rl.backward()
+    worst, worst_k = 0.0, None
+    for k, p in Pr.items():
+        if p.grad is None or k not in G:
+            continue
+        g = p.grad.double()
+        r = (G[k].double().reshape(g.shape) - g).abs().max().item() / max(g.abs().max().item(), 1e-300)
+        if r > worst:
+            worst, worst_k = r, k
+    return rl.item(), worst, worst_k
+
+
 def test_full_size_forward_against_oracle(world, monkeypatch):
     """The MASA matcher is an arg-max over cosine similarities (4 x 16 coarse matches over 1024 positions, 4096 fine matches
     over 676): at this size a few near-ties can resolve differently between the oracle's torch-CPU correlation and the
@@ -134,19 +151,19 @@ def test_full_size_gradients_against_oracle(world, monkeypatch):
 
     monkeypatch.setattr(O, 'coarse_search', cs)
     monkeypatch.setattr(O, 'fine_search', fs)
-    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    rl = O.l1_loss(O.nafnet_ref_forward(Pr, cfg, lq, ref), gt)
-    rl.backward()
-    assert abs(loss.item() - rl.item()) < 1e-6
-    worst, worst_k = 0.0, None
-    for k, p in Pr.items():
-        if p.grad is None:
-            continue
-        r = (G[k].reshape(p.grad.shape) - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
-        if r > worst:
-            worst, worst_k = r, k
-    _log(f'full-size gradients vs oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
-    assert worst < 2e-3, (worst, worst_k)
+    # The gradient reference is the oracle evaluated in FLOAT64.  Rounds 1-3 compared against its fp32 autograd under a 2e-3 bound
+    # because a few bias gradients sat at 5e-4..8e-4; profiles/diag_bias_grad.py (profiles/r4/diag_bias_grad.log) shows that gap is
+    # the fp32 ORACLE's own summation error (decoders.3.0.conv5.bias: oracle32 vs oracle64 6.4e-4, HIP vs oracle64 5e-7).  What
+    # remains against float64 are ReLU decisions of the MASA encoder on pre-activations within a few ulp of zero (3.4e-4 at
+    # masa_enc.blk_L4.2.conv1.weight here; the exact-fp32 MFMA path shows 2.2e-4 on another block for the same reason).
+    rl64, worst, worst_k = _worst_gradient_gap(G, lambda Pr: O.nafnet_ref_forward(Pr, cfg, lq.double(), ref.double()), P, gt, torch.float64)
+    assert abs(loss.item() - rl64) < 1e-6
+    _log(f'full-size gradients vs float64 oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
+    assert worst < 5e-4, (worst, worst_k)
+    rl32, w32, w32_k = _worst_gradient_gap(G, lambda Pr: O.nafnet_ref_forward(Pr, cfg, lq, ref), P, gt, torch.float32)
+    assert abs(loss.item() - rl32) < 1e-6
+    _log(f'full-size gradients vs fp32 oracle autograd (the oracle rounding included): worst {w32:.2e} at {w32_k}')
+    assert w32 < 2e-3, (w32, w32_k)
 
 
 @pytest.mark.timeout(1500)
@@ -210,7 +227,9 @@ def test_full_size_batch4_against_oracle(world, monkeypatch):
         if r > worst:
             worst, worst_k = r, k
     _log(f'bs=4 full-size gradients vs oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
-    assert worst < 2e-3, (worst, worst_k)
+    # fp32 oracle here (a float64 pass of 4 x 512x512 would double the minutes this test takes): the bound carries the oracle's own
+    # fp32 summation error on bias gradients, 6.4e-4 on the single-pair case where both references are evaluated
+    assert worst < 1e-3, (worst, worst_k)
 
 
 def test_full_size_batch_permutation_is_bit_exact(world):
@@ -370,19 +389,15 @@ def test_restormer_full_size_gradients_against_oracle(rworld, monkeypatch):
 
     monkeypatch.setattr(O, 'coarse_search', cs)
     monkeypatch.setattr(O, 'fine_search', fs)
-    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    rl = O.l1_loss(RO.restormer_ref_forward(Pr, cfg, lq, ref), gt)
-    rl.backward()
-    assert abs(loss.item() - rl.item()) < 1e-6
-    worst, worst_k = 0.0, None
-    for k, p in Pr.items():
-        if p.grad is None or k not in G:
-            continue
-        r = (G[k].reshape(p.grad.shape) - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
-        if r > worst:
-            worst, worst_k = r, k
-    _log(f'restormer full-size gradients vs oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
-    assert worst < 2e-3, (worst, worst_k)
+    # float64 oracle as the gradient reference (see test_full_size_gradients_against_oracle)
+    rl64, worst, worst_k = _worst_gradient_gap(G, lambda Pr: RO.restormer_ref_forward(Pr, cfg, lq.double(), ref.double()), P, gt, torch.float64)
+    assert abs(loss.item() - rl64) < 1e-6
+    _log(f'restormer full-size gradients vs float64 oracle autograd: worst relative (to the tensor max) {worst:.2e} at {worst_k}')
+    assert worst < 5e-4, (worst, worst_k)
+    rl32, w32, w32_k = _worst_gradient_gap(G, lambda Pr: RO.restormer_ref_forward(Pr, cfg, lq, ref), P, gt, torch.float32)
+    assert abs(loss.item() - rl32) < 1e-6
+    _log(f'restormer full-size gradients vs fp32 oracle autograd (the oracle rounding included): worst {w32:.2e} at {w32_k}')
+    assert w32 < 2e-3, (w32, w32_k)
 
 
 @pytest.mark.timeout(1500)
