@@ -86,7 +86,7 @@ def _check_gradients(tag, G, loss, fwd64, fwd32, P, gt):
     assert abs(loss - rl64) < 1e-6
     _log(f'{tag} gradients vs float64 oracle autograd, worst relative (to the tensor max): outside the ReLU encoder '
          f'{w64["other"][0]:.2e} at {w64["other"][1]}; masa_enc.* {w64["relu_encoder"][0]:.2e} at {w64["relu_encoder"][1]}')
-    assert w64['other'][0] < 5e-5, w64
+    assert w64['other'][0] < 1e-4, w64          # measured 8.5e-6 (NAFNet-ref) / 4.6e-5 (Restormer-ref: an attention temperature scalar)
     assert w64['relu_encoder'][0] < 1e-3, w64
     rl32, w32 = _worst_gradient_gap(G, fwd32, P, gt, torch.float32)
     assert abs(loss - rl32) < 1e-6

@@ -514,7 +514,9 @@ WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d) {
     WgPlan p;
     p.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);
     if (d->KH == 1) {
-        if (d->Cout > 64 && d->Cin > 64) p.cfg = 0;
+        static const int force1 = getenv("TDR_WGB_CFG1X1") ? atoi(getenv("TDR_WGB_CFG1X1")) : -1;   // tuning aid: 0 | 1 | 5
+        if (force1 >= 0 && d->Cout >= 64 && d->Cin >= 64) p.cfg = force1;
+        else if (d->Cout > 64 && d->Cin > 64) p.cfg = 0;
         else if (d->Cin <= 32 && d->Cout <= 32) p.cfg = 2;
         else if (d->Cin <= 32) p.cfg = 5;
         else p.cfg = 1;
