@@ -463,10 +463,18 @@ def test_restormer_configs4_shapes_512_batch2(rworld, monkeypatch):
     d = (out - exact).abs()
     flips = (saved[6][7] != saved_x[6][7]).sum().item() + (saved[6][4] != saved_x[6][4]).sum().item()
     _log(f'restormer 512x512 bs 2: fp16 split vs exact fp32: max {d.max().item():.2e} mean {d.mean().item():.2e}, {flips} of 8320 match decisions differ')
-    if flips == 0:
-        assert d.max().item() < 1e-4
-    else:       # a near-tie of the hard-attention arg-max resolved the other way (1e-7 feature differences): a patch of pixels moves
-        assert flips <= 4 and d.mean().item() < 1e-6 and (d > 1e-4).float().mean().item() < 2e-3
+    # per image: where every match decision agrees the north-star bound holds as is; a near-tie of the hard-attention arg-max resolved
+    # the other way (1e-7 feature differences) moves one patch of pixels of THAT image -- bounded in count, area and magnitude
+    nb = out.shape[0]
+    per_img = (saved[6][7] != saved_x[6][7]).reshape(nb, -1).sum(1) + (saved[6][4] != saved_x[6][4]).reshape(nb, -1).sum(1)
+    assert flips <= 4
+    for i in range(nb):
+        di = d[i]
+        if per_img[i].item() == 0:
+            assert di.max().item() < 1e-4, (i, di.max().item())
+        else:
+            assert di.max().item() < 5e-3 and di.mean().item() < 2e-6 and (di > 1e-4).float().mean().item() < 4e-3, \
+                (i, di.max().item(), di.mean().item())
     assert abs(psnr(out.clamp(0, 1), gtc) - psnr(exact.clamp(0, 1), gtc)) < 1e-3
     del exact, outp, saved_x
     Sg = 2.0 ** math.floor(math.log2(512.0 * 2 * 3 * S512 * S512))
