@@ -496,6 +496,8 @@ def _main_body(a, world, rank, local, enc):
         K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16 = timed, timed_p16, timed_wg, timed_wg16
         graph_was = getattr(model, 'use_hip_graph', False)
         model.use_hip_graph = False                       # instrumented step runs eagerly (a replayed graph makes no Python calls)
+        from textualdegremoval_amd import engine as _E
+        defer_was, _E.DEFER_WGRAD = _E.DEFER_WGRAD, False    # one stream: an event pair around a launch times THAT launch, not a co-running pair
         try:
             # The eager host loop issues launches more slowly than the GPU retires them; an event pair around a launch
             # would then also time the idle gap before it.  Park the GPU on a calibrated spin kernel so that the whole
@@ -513,6 +515,7 @@ def _main_body(a, world, rank, local, enc):
         finally:
             K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16 = orig, orig_p16, orig_wg, orig_wg16
             model.use_hip_graph = graph_was
+            _E.DEFER_WGRAD = defer_was
         # `roofline` = the family VERDICT names: every 3x3 / stride-1 forward + data-gradient launch of the step, whichever kernel
         # runs it (the fp32-tensor kernel conv_bx3_kernel / conv_mfma_kernel and, since round 4, conv3x3_p16_kernel on pre-split
         # operands), priced against the fp32-equivalent ceiling of the operand scheme that carries most of its time; `by_kernel`
@@ -614,6 +617,9 @@ def _main_body(a, world, rank, local, enc):
                        'collectives': ('none (1 GPU)' if world == 1 else
                                        ('tdr_comm_* (RCCL through the C ABI)' if comm is not None else f'torch.distributed ({a.backend})')),
                        'ranks_seen': ranks_seen,
+                       'streams': ('2: the leaf 1x1 weight gradients of the NAFBlocks run deferred on a second HIP stream beside the MASA-encoder '
+                                   'backward (engine.DEFER_WGRAD; the roofline leg times its launches on one stream)'
+                                   if a.arch == 'nafnet' and world == 1 and os.environ.get('TDR_DEFER_WGRAD', '1') == '1' else '1'),
                        'grad_exchange': ('none' if world == 1 else
                                          (f'{len(red.buckets)} buckets of <= 64 MiB, each all-reduced on the comm stream between the segments of '
                                           f'the captured backward ({red.bucket_launches} bucket exchanges issued so far)'

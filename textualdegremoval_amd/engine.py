@@ -56,6 +56,42 @@ def maybe_join():
         K.side_join()
 
 
+# Leaf weight gradients of the NAFBlocks (conv1 / conv4 / conv5: nothing downstream in the backward reads them) can be DEFERRED to the
+# end of the main backward chain and run on a second HIP stream next to the MASA-encoder backward (kernels.lane): at bs 4 the 1x1 weight
+# gradients of the deep levels are L2 / HBM-bound launches of 512 small workgroups, the encoder's 3x3 data / weight gradients are matrix-
+# bound launches of 256 - 2048 large ones -- complementary resources, where the NAFBlock chain itself (135 KB of LDS per workgroup) leaves
+# no room for a second kernel.  The operands stay referenced until the join (288 GB of HBM: ~10 GB of gradient operands kept alive).
+# Only without a gradient exchange: with collectives the buckets are cut in arrival order inside the backward (parallel.GradAllReducer).
+DEFER_WGRAD = os.environ.get('TDR_DEFER_WGRAD', '1') == '1'
+_late = None            # [(prefix, closure -> {name: grad})] while a whole-network backward collects deferred leaves
+_late_pre = ''
+
+
+def _leaf(keep, fn, G):
+    """run a parameter-gradient leaf now (optionally on the side stream), or queue it for the deferred pass"""
+    if _late is not None:
+        _late.append((_late_pre, fn, keep))
+        return
+    with K.on_side(*keep):
+        G.update(fn())
+
+
+def run_late_leaves(G, main_chain):
+    """deferred leaves on lane 0, `main_chain()` on the current stream, join, then hand the gradients to the collector in order"""
+    global _late
+    late, _late = _late, None
+    if not late:
+        main_chain()
+        return
+    with K.lane(0):
+        results = [(pre, fn()) for pre, fn, _ in late]
+    main_chain()
+    K.lanes_join()
+    for pre, g in results:
+        _put(G, pre, g)
+    late.clear()          # (operands referenced until here: the allocator cannot recycle them under a running lane kernel)
+
+
 # ---------------------------------------------------------------------------
 # NAFBlock / NAFResFuseBlock   models/archs/network_nafnet_guided_arch.py:178-302
 # ---------------------------------------------------------------------------
@@ -103,21 +139,23 @@ def naf_bwd(dout, P, saved):
     dev = x.device
     G = {}
     beta, gamma = P['beta'].view(-1), P['gamma'].view(-1)
-    # ---- conv5 / gamma chain (parameter gradients only: side stream, off the data-gradient chain)
-    if c_out != c:
-        fw = torch.zeros(c, c, 1, 1, dtype=torch.float32, device=dev)
-        fb = torch.zeros(c, dtype=torch.float32, device=dev)
-        fg = torch.zeros(1, c, 1, 1, dtype=torch.float32, device=dev)
-    with K.on_side(t4, dout):
+    # ---- conv5 / gamma chain (parameter gradients only: a leaf off the data-gradient chain)
+    def leaf5():
+        g = {}
         G5, S5 = K.side_keep(*K.conv_wgrad(t4, dout, c_out, c, 1, gate=True, want_db=True))
         dw5, db5, dgam = K.side_keep(*K.scaled_conv_param_grads(G5.view(c_out, c), S5, P['conv5.weight'], P['conv5.bias'], gamma))
         if c_out == c:
-            G['conv5.weight'], G['conv5.bias'], G['gamma'] = dw5.view(c, c, 1, 1), db5, dgam.view(1, c, 1, 1)
+            g['conv5.weight'], g['conv5.bias'], g['gamma'] = dw5.view(c, c, 1, 1), db5, dgam.view(1, c, 1, 1)
         else:
+            fw = torch.zeros(c, c, 1, 1, dtype=torch.float32, device=dev)
+            fb = torch.zeros(c, dtype=torch.float32, device=dev)
+            fg = torch.zeros(1, c, 1, 1, dtype=torch.float32, device=dev)
             K.copy_rows(dw5, 0, fw, 0, 1, c_out * c)
             K.copy_rows(db5, 0, fb, 0, 1, c_out)
             K.copy_rows(dgam, 0, fg, 0, 1, c_out)
-            G['conv5.weight'], G['conv5.bias'], G['gamma'] = fw, fb, fg
+            g['conv5.weight'], g['conv5.bias'], g['gamma'] = fw, fb, fg
+        return g
+    _leaf((t4, dout), leaf5, G)
     fused = FUSE_TAIL and K.naf_tail_supported(c, H * W, c_out) and dout.is_contiguous() and \
         _dgrad_is_hx2()
     if fused:
@@ -133,9 +171,10 @@ def naf_bwd(dout, P, saved):
         wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
         dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
     # ---- conv4
-    with K.on_side(yn, dt4):
-        g4, G['conv4.bias'] = K.conv_wgrad(yn, dt4, 2 * c, c, 1, want_db=True)
-        G['conv4.weight'] = g4.view(2 * c, c, 1, 1)
+    def leaf4():
+        g4, b4 = K.conv_wgrad(yn, dt4, 2 * c, c, 1, want_db=True)
+        return {'conv4.weight': g4.view(2 * c, c, 1, 1), 'conv4.bias': b4}
+    _leaf((yn, dt4), leaf4, G)
     if not fused:
         wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)
         dyn = K.conv_forward(dt4, wp, mp, c, 1)
@@ -157,9 +196,10 @@ def naf_bwd(dout, P, saved):
         dg = K.conv_forward(dy, wp, mp, c, 1, kscale=beta, scale=s, bias2=dpooled, bias2_mul=1.0 / (H * W))
         dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'])
     # ---- conv1
-    with K.on_side(xn, dt1):
-        g1, G['conv1.bias'] = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)
-        G['conv1.weight'] = g1.view(2 * c, c, 1, 1)
+    def leaf1():
+        g1, b1 = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)
+        return {'conv1.weight': g1.view(2 * c, c, 1, 1), 'conv1.bias': b1}
+    _leaf((xn, dt1), leaf1, G)
     if FUSE_TAIL and K.naf_tail_supported(c, H * W) and _dgrad_is_hx2() and x.is_contiguous() and dy.is_contiguous():
         # conv1 dgrad -> norm1 bwd (+ dy) in one launch
         w1t = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)[0]
@@ -212,7 +252,9 @@ def naf_fwd_local(x, P, k1, k2):
 
 
 def naf_seq_bwd(dout, P, pre, n, saved, G):
+    global _late_pre
     for i in reversed(range(n)):
+        _late_pre = f'{pre}{i}.'
         dout, g = naf_bwd(dout, _sub(P, f'{pre}{i}.'), saved[i])
         _put(G, f'{pre}{i}.', g)
     return dout
@@ -677,9 +719,21 @@ def net_bwd(dout, P, cfg, saved, G=None):
 
 
 def _net_bwd(dout, P, cfg, saved, G):
+    global _late
     N, (H0, W0, Hp, Wp), geo, pyr, _, _, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe = saved
     n_enc = len(cfg['enc_blk_nums'])
     G = {} if G is None else G
+    if DEFER_WGRAD and not K.SIDE_WGRAD and not getattr(getattr(G, 'reducer', None), 'collective', False):
+        _late = []
+    try:
+        return _net_bwd_body(dout, P, cfg, saved, G)
+    finally:
+        _late = None
+
+
+def _net_bwd_body(dout, P, cfg, saved, G):
+    N, (H0, W0, Hp, Wp), geo, pyr, _, _, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe = saved
+    n_enc = len(cfg['enc_blk_nums'])
     inp_p = pyr.inp_p
     dout = dout.contiguous()
     if (Hp, Wp) != (H0, W0):
@@ -710,5 +764,5 @@ def _net_bwd(dout, P, cfg, saved, G):
         d = dcat[:, :chan]                             # batch-strided view: every consumer takes an image stride
     # intro conv: input image needs no gradient
     _, G['intro.weight'], G['intro.bias'] = conv_bwd(d, inp_p, P['intro.weight'], 1, 1, need_dx=False)
-    pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
+    run_late_leaves(G, lambda: pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G))
     return G
