@@ -547,6 +547,11 @@ def _main_body(a, world, rank, local, enc):
             roof_other = [subs[k] for k in subs if k not in split]
             prefixes = {0: 'conv_mfma_kernel<3, 1, 1,', 1: 'conv_bx3_kernel<3, 1,', 2: 'conv_bx3_kernel<3, 1,', 'p16': 'conv3x3_p16_kernel'}
             roof['traffic'], roof['traffic_unit'] = pmc_traffic(sorted({prefixes[k] for k in split}))
+            for k, sub in zip(split, roof['by_kernel']):
+                sub['traffic'] = pmc_traffic([prefixes[k]])[0]
+            for k in subs:
+                if k not in split:
+                    subs[k]['traffic'] = pmc_traffic([prefixes[k]])[0]
         WG = {3: 'wgrad_bx3_kernel<KH=3> + wgrad_reduce_kernel (fp32 tensors in, operand split + v_alignbit fragment assembly per consumer)',
               1: 'wgrad_bx3_kernel<KH=1> + wgrad_reduce_kernel (1x1 weight gradients of the NAFBlock chains, split-K partials)',
               'p16': 'wgrad3x3_p16_kernel + wgrad_p16_reduce_kernel (pre-split pair planes, transposed LDS reads, no operand VALU)'}
@@ -554,6 +559,12 @@ def _main_body(a, world, rank, local, enc):
             e = entry([r for r in recs if r[4] == ('wgrad', k)], WG.get(k, f'wgrad KH={k}'),
                       PEAK_HX2 if K.MATH in ('hx2', 'h1') else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32),
                       'fp32-equivalent ceiling of the step\'s operand scheme; time = kernel + its fixed-order split-K reduction (HIP events around both)')
+            # measured bytes per launch: the kernel's own traffic plus its split-K reduction's (one reduction per weight-gradient launch)
+            wpre = {3: ('wgrad_bx3_kernel<3,', 'wgrad_reduce_kernel'), 1: ('wgrad_bx3_kernel<1,', 'wgrad_reduce_kernel'),
+                    'p16': ('wgrad3x3_p16_kernel', 'wgrad_p16_reduce_kernel')}.get(k)
+            if wpre:
+                t_k, t_r = pmc_traffic([wpre[0]])[0], pmc_traffic([wpre[1]])[0]
+                e['traffic'] = None if t_k is None else t_k + (t_r or 0.0)
             roof_other.append(e)
         for f in ([roof] if roof else []) + roof_other + (roof.get('by_kernel', []) if roof else []):
             f.pop('_total_ms', None)
