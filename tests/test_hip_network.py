@@ -214,6 +214,38 @@ def test_side_stream_weight_gradients_match(E):
             assert torch.equal(res[0][k], res[1][k]), k
 
 
+def test_deferred_leaf_weight_gradients_match(E):
+    """engine.DEFER_WGRAD (default without a gradient exchange): the conv1 / conv4 / conv5 weight gradients of every NAFBlock are queued
+    and run on a second stream beside the MASA-encoder backward -- same kernels on the same operands, so every tensor outside the
+    MASA encoder (atomics in the transfer backward) is bit-identical to the single-stream backward; the set of keys is the same and
+    the deferred operands were still alive (a recycled buffer would show up as a wrong gradient)."""
+    from textualdegremoval_amd import kernels as K
+    cfg = O.default_cfg(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
+    P = cuda_params(O.synth_params(cfg, seed=2))
+    lq, gt, ref = O.synth_pair(2, 128, 128, seed=12)
+    res = []
+    for defer in (False, True, True):
+        prev, E.DEFER_WGRAD = E.DEFER_WGRAD, defer
+        try:
+            out, saved = E.net_fwd(P, cfg, lq.cuda(), ref.cuda())
+            loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0)
+            junk = [torch.full((1 << 20,), float('nan'), device='cuda') for _ in range(4)]      # churn the allocator around the backward
+            G = E.net_bwd(dpred, P, cfg, saved)
+            del junk
+            torch.cuda.synchronize()
+            res.append({k: v.clone() for k, v in G.items()})
+        finally:
+            E.DEFER_WGRAD = prev
+    assert E._late is None
+    for other in res[1:]:
+        assert set(res[0]) == set(other)
+        for k in res[0]:
+            if k.startswith('masa_enc.'):
+                assert maxdiff(res[0][k], other[k]) <= 1e-5 * max(1e-6, res[0][k].abs().max().item()), k
+            else:
+                assert torch.equal(res[0][k], other[k]), k
+
+
 @pytest.mark.parametrize('name', ['net_w8_256_b2_clear', 'net_w8_128_wrap', 'net_w8_256_ref384'])
 def test_deterministic_mode_is_bit_reproducible_and_matches_golden(E, name):
     """TDR_DETERMINISTIC=1 (kernels.DETERMINISTIC): the MASA transfer backward accumulates in 64-bit fixed point -- the only
