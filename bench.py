@@ -642,9 +642,9 @@ def _main_body(a, world, rank, local, enc):
                        'collectives': ('none (1 GPU)' if world == 1 else
                                        ('tdr_comm_* (RCCL through the C ABI)' if comm is not None else f'torch.distributed ({a.backend})')),
                        'ranks_seen': ranks_seen,
-                       'streams': ('2: the leaf 1x1 weight gradients of the NAFBlocks run deferred on a second HIP stream beside the MASA-encoder '
+                       'streams': ('2: the leaf 1x1 weight gradients of the blocks run deferred on a second HIP stream beside the MASA-encoder '
                                    'backward (engine.DEFER_WGRAD; the roofline leg times its launches on one stream)'
-                                   if a.arch == 'nafnet' and world == 1 and os.environ.get('TDR_DEFER_WGRAD', '1') == '1' else '1'),
+                                   if a.arch in ('nafnet', 'restormer') and world == 1 and os.environ.get('TDR_DEFER_WGRAD', '1') == '1' else '1'),
                        'grad_exchange': ('none' if world == 1 else
                                          (f'{len(red.buckets)} buckets of <= 64 MiB, each all-reduced on the comm stream between the segments of '
                                           f'the captured backward ({red.bucket_launches} bucket exchanges issued so far)'

@@ -73,7 +73,30 @@ def _leaf(keep, fn, G):
         _late.append((_late_pre, fn, keep))
         return
     with K.on_side(*keep):
-        G.update(fn())
+        for k, v in fn().items():
+            G[k] = v                    # (item by item: a GradSink collector acts on __setitem__)
+
+
+class late_leaves:
+    """`with late_leaves(G):` around a whole-network backward: leaves are queued (when allowed) until run_late_leaves()"""
+
+    def __init__(self, G):
+        self.on = DEFER_WGRAD and not K.SIDE_WGRAD and not getattr(getattr(G, 'reducer', None), 'collective', False)
+
+    def __enter__(self):
+        global _late
+        _late = [] if self.on else None
+        return self
+
+    def __exit__(self, *exc):
+        global _late
+        _late = None
+        return False
+
+
+def set_late_prefix(pre):
+    global _late_pre
+    _late_pre = pre
 
 
 def run_late_leaves(G, main_chain):
@@ -257,6 +280,7 @@ def naf_seq_bwd(dout, P, pre, n, saved, G):
         _late_pre = f'{pre}{i}.'
         dout, g = naf_bwd(dout, _sub(P, f'{pre}{i}.'), saved[i])
         _put(G, f'{pre}{i}.', g)
+    _late_pre = ''
     return dout
 
 
@@ -719,16 +743,9 @@ def net_bwd(dout, P, cfg, saved, G=None):
 
 
 def _net_bwd(dout, P, cfg, saved, G):
-    global _late
-    N, (H0, W0, Hp, Wp), geo, pyr, _, _, sv_masa, warp, sv_levels, sv_fm, sv_m, sv_dec, xe = saved
-    n_enc = len(cfg['enc_blk_nums'])
     G = {} if G is None else G
-    if DEFER_WGRAD and not K.SIDE_WGRAD and not getattr(getattr(G, 'reducer', None), 'collective', False):
-        _late = []
-    try:
+    with late_leaves(G):
         return _net_bwd_body(dout, P, cfg, saved, G)
-    finally:
-        _late = None
 
 
 def _net_bwd_body(dout, P, cfg, saved, G):

@@ -54,12 +54,12 @@ def _pw_bwd(dout, x, P, name, G):
     w = P[name + '.weight']
     Cout, Cin = w.shape[0], w.shape[1]
     has_b = (name + '.bias') in P
-    with K.on_side(x, dout):          # parameter gradient: side stream, off the data-gradient chain
+    def leaf():                        # parameter gradient: a leaf off the data-gradient chain (engine._leaf: deferred or side stream)
         r = K.conv_wgrad(x, dout, Cout, Cin, 1, want_db=has_b)
         if has_b:
-            G[name + '.weight'], G[name + '.bias'] = r[0].view(Cout, Cin, 1, 1), r[1]
-        else:
-            G[name + '.weight'] = r.view(Cout, Cin, 1, 1)
+            return {name + '.weight': r[0].view(Cout, Cin, 1, 1), name + '.bias': r[1]}
+        return {name + '.weight': r.view(Cout, Cin, 1, 1)}
+    E._leaf((x, dout), leaf, G)
     wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_S1)
     return K.conv_forward(dout, wp, mp, Cin, 1)
 
@@ -153,8 +153,10 @@ def seq_fwd(x, P, pre, n, heads, ln_type, fusion=False):
 
 def seq_bwd(d, P, pre, n, heads, ln_type, saved, G, fusion=False):
     for i in reversed(range(n)):
+        E.set_late_prefix(f'{pre}{i}.')
         d, g = (fblock_bwd if fusion else tblock_bwd)(d, E._sub(P, f'{pre}{i}.'), heads, ln_type, saved[i])
         E._put(G, f'{pre}{i}.', g)
+    E.set_late_prefix('')              # (top-level leaves -- reduce_chan_level*, skip_conv -- carry full names)
     return d
 
 
@@ -230,14 +232,14 @@ def net_fwd(P, cfg, inp, ref):
 
 
 def net_bwd(dout, P, cfg, saved, G=None):
-    with E.deferred_join():
+    G = {} if G is None else G
+    with E.deferred_join(), E.late_leaves(G):
         return _net_bwd(dout, P, cfg, saved, G)
 
 
 def _net_bwd(dout, P, cfg, saved, G):
     (N, (H0, W0, Hp, Wp), geo, pyr, x_l1, _, sv_masa, sv_lv, enc_out, cat3, d3, sv_d3, cat2, d2, sv_d2, sv_d1, rf,
      sv_rf) = saved
-    G = {} if G is None else G
     hd, ln, nb, nfz, dim = cfg['heads'], cfg['LayerNorm_type'], cfg['num_blocks'], cfg['reffusion_n_blocks'], cfg['dim']
     e1, e2, e3, lat = enc_out
     inp_p = pyr.inp_p
@@ -283,7 +285,7 @@ def _net_bwd(dout, P, cfg, saved, G):
                                                              bias=has_pb)
             if has_pb:
                 G['patch_embed.proj.bias'] = db
-    E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
+    E.run_late_leaves(G, lambda: E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G))
     return G
 
 
