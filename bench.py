@@ -644,7 +644,7 @@ def _main_body(a, world, rank, local, enc):
                        'ranks_seen': ranks_seen,
                        'streams': ('2: the leaf 1x1 weight gradients of the blocks run deferred on a second HIP stream beside the MASA-encoder '
                                    'backward (engine.DEFER_WGRAD; the roofline leg times its launches on one stream)'
-                                   if a.arch in ('nafnet', 'restormer') and world == 1 and os.environ.get('TDR_DEFER_WGRAD', '1') == '1' else '1'),
+                                   if a.arch in ('nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc') and world == 1 and os.environ.get('TDR_DEFER_WGRAD', '1') == '1' else '1'),
                        'grad_exchange': ('none' if world == 1 else
                                          (f'{len(red.buckets)} buckets of <= 64 MiB, each all-reduced on the comm stream between the segments of '
                                           f'the captured backward ({red.bucket_launches} bucket exchanges issued so far)'

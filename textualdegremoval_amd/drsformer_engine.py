@@ -179,8 +179,10 @@ def seq_fwd(x, P, pre, n, heads, ln_type, fusion=False):
 
 def seq_bwd(d, P, pre, n, heads, ln_type, saved, G, fusion=False):
     for i in reversed(range(n)):
+        E.set_late_prefix(f'{pre}{i}.')
         d, g = (fblock_bwd if fusion else tblock_bwd)(d, E._sub(P, f'{pre}{i}.'), heads, ln_type, saved[i])
         E._put(G, f'{pre}{i}.', g)
+    E.set_late_prefix('')
     return d
 
 
@@ -235,7 +237,8 @@ def net_fwd(P, cfg, inp, ref):
 
 
 def net_bwd(dout, P, cfg, saved, G=None):
-    with E.deferred_join():
+    G = {} if G is None else G
+    with E.deferred_join(), E.late_leaves(G):       # (leaf 1x1 weight gradients: engine.DEFER_WGRAD)
         return _net_bwd(dout, P, cfg, saved, G)
 
 
@@ -290,8 +293,7 @@ def _net_bwd(dout, P, cfg, saved, G):
             _, G['patch_embed.proj.weight'], db = E.conv_bwd(d, inp_p, P['patch_embed.proj.weight'], 1, 1, need_dx=False, bias=has_pb)
             if has_pb:
                 G['patch_embed.proj.bias'] = db
-    if sv_masa is not None:
-        E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
+    E.run_late_leaves(G, (lambda: E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)) if sv_masa is not None else (lambda: None))
     return G
 
 

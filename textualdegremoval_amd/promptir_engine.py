@@ -61,7 +61,9 @@ def _prompt_stage_fwd(x, P, k, heads, ln):
 def _prompt_stage_bwd(d, P, k, heads, ln, saved, G):
     c, sv_p, sv_t, t = saved
     d = R._pw_bwd(d, t, P, f'reduce_noise_level{k}', G)
+    E.set_late_prefix(f'noise_level{k}.')
     dcat, g = R.tblock_bwd(d, E._sub(P, f'noise_level{k}.'), heads, ln, sv_t)
+    E.set_late_prefix('')
     E._put(G, f'noise_level{k}.', g)
     dx = K.slice_channels(dcat, 0, c)
     demb, inv = prompt_bwd(K.slice_channels(dcat, c, dcat.shape[1]), P, f'prompt{k}.', sv_p, G)
@@ -125,7 +127,8 @@ def net_fwd(P, cfg, inp, ref):
 
 
 def net_bwd(dout, P, cfg, saved, G=None):
-    with E.deferred_join():
+    G = {} if G is None else G
+    with E.deferred_join(), E.late_leaves(G):       # (leaf 1x1 weight gradients: engine.DEFER_WGRAD)
         return _net_bwd(dout, P, cfg, saved, G)
 
 
@@ -179,6 +182,5 @@ def _net_bwd(dout, P, cfg, saved, G):
                                                              bias=has_pb)
             if has_pb:
                 G['patch_embed.proj.bias'] = db
-    if sv_masa is not None:
-        E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)
+    E.run_late_leaves(G, (lambda: E.pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G)) if sv_masa is not None else (lambda: None))
     return G
