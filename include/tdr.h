@@ -667,7 +667,10 @@ int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream);
  *   dt4 = SimpleGate'(W5^T (dout * gamma); t4);  dyn = W4^T dt4;  dy = LayerNorm2d'(dyn; y, mu, rs, lnw) + dout
  * plus the LayerNorm parameter gradients gw = sum dyn * yhat, gb = sum dyn (per-workgroup partials in ws, reduced in a
  * fixed order).  dt4 is an output because conv4's weight gradient (tdr_conv_wgrad) reads it.
- * w5t / w4t: tdr_pack_weights_hx2(mode DGRAD_S1) of conv5 / conv4.  ws: tdr_naf_tail_bwd_ws_floats(N, C, HW) floats. */
+ * w5t / w4t: tdr_pack_weights_hx2(mode DGRAD_S1) of conv5 / conv4.  ws: tdr_naf_tail_bwd_ws_floats(N, C, HW) floats.
+ * gw = gb = NULL (tail and head backward alike): the per-workgroup partials [N * HW / 64][2][C] are left at the start of ws and the
+ * caller finishes them later with tdr_pair_sum_partials(ws, N * HW / 64, C, gw, gb, ws + N * HW / 64 * 2 * C) -- the LayerNorm
+ * parameter gradients are leaves, so a trainer may run that reduction off the data-gradient chain. */
 typedef struct TdrNafTailBwdDesc {
     int N, C, HW, w_fmt;
     int c_out;                               /* channels of dout (C or C / 2; 0 = C) */

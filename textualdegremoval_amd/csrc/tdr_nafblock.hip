@@ -831,9 +831,9 @@ extern "C" int64_t tdr_naf_tail_bwd_ws_floats(int N, int C, int HW) {
 }
 
 extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
-    TDR_REQUIRE(d && d->dout && d->gamma && d->t4 && d->y && d->mu && d->rs && d->lnw && d->w5t && d->w4t && d->dt4 && d->dy && d->gw &&
-                    d->gb && d->ws,
+    TDR_REQUIRE(d && d->dout && d->gamma && d->t4 && d->y && d->mu && d->rs && d->lnw && d->w5t && d->w4t && d->dt4 && d->dy && d->ws,
                 "tdr_naf_tail_bwd: null pointer");
+    TDR_REQUIRE((d->gw != nullptr) == (d->gb != nullptr), "tdr_naf_tail_bwd: gw and gb are given together or not at all");
     TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_bwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
     TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_tail_bwd: weights must be packed with tdr_pack_weights_hx2 (mode DGRAD_S1)");
     TDR_REQUIRE(d->dout_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->dout) & 15) == 0, "tdr_naf_tail_bwd: dout must be 16-byte aligned");
@@ -853,12 +853,13 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
     else if (d->C == 64) NAF_DISPATCH_C(64, (naf_tail_bwd_kernel<64, false>), lds, a, d, stream);
     else NAF_DISPATCH_C(32, (naf_tail_bwd_kernel<32, false>), lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_tail_bwd_kernel");
+    if (!d->gw) return TDR_OK;            // the caller finishes the LayerNorm parameter gradients itself (tdr_pair_sum_partials on ws)
     return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, d->ws + (long)d->N * (d->HW / NPX) * 2 * d->C, stream);
 }
 
 extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
-    TDR_REQUIRE(d && d->dt1 && d->x && d->mu && d->rs && d->lnw && d->w1t && d->res && d->dx && d->gw && d->gb && d->ws,
-                "tdr_naf_head_bwd: null pointer");
+    TDR_REQUIRE(d && d->dt1 && d->x && d->mu && d->rs && d->lnw && d->w1t && d->res && d->dx && d->ws, "tdr_naf_head_bwd: null pointer");
+    TDR_REQUIRE((d->gw != nullptr) == (d->gb != nullptr), "tdr_naf_head_bwd: gw and gb are given together or not at all");
     TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_head_bwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
     TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_head_bwd: weights must be packed with tdr_pack_weights_hx2 (mode DGRAD_S1)");
     TDR_REQUIRE(d->dt1_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->dt1) & 15) == 0, "tdr_naf_head_bwd: dt1 must be 16-byte aligned");
@@ -875,5 +876,6 @@ extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
     else if (d->C == 64) NAF_DISPATCH_C(64, (naf_tail_bwd_kernel<64, true>), lds, a, d, stream);
     else NAF_DISPATCH_C(32, (naf_tail_bwd_kernel<32, true>), lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_head_bwd_kernel");
+    if (!d->gw) return TDR_OK;
     return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, d->ws + (long)d->N * (d->HW / NPX) * 2 * d->C, stream);
 }

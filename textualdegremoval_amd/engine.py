@@ -63,6 +63,7 @@ def maybe_join():
 # no room for a second kernel.  The operands stay referenced until the join (288 GB of HBM: ~10 GB of gradient operands kept alive).
 # Only without a gradient exchange: with collectives the buckets are cut in arrival order inside the backward (parallel.GradAllReducer).
 DEFER_WGRAD = os.environ.get('TDR_DEFER_WGRAD', '1') == '1'
+DEFER_LN_FINISH = os.environ.get('TDR_DEFER_LN_FINISH', '1') == '1'     # also the reductions of the LayerNorm-gradient partials
 _late = None            # [(prefix, closure -> {name: grad})] while a whole-network backward collects deferred leaves
 _late_pre = ''
 
@@ -162,6 +163,7 @@ def naf_bwd(dout, P, saved):
     dev = x.device
     G = {}
     beta, gamma = P['beta'].view(-1), P['gamma'].view(-1)
+    late = _late is not None and DEFER_LN_FINISH
     # ---- conv5 / gamma chain (parameter gradients only: a leaf off the data-gradient chain)
     def leaf5():
         g = {}
@@ -186,10 +188,14 @@ def naf_bwd(dout, P, saved):
         w5t, w4t = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)[0], K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)[0]
         if FUSE_CONV3_DGRAD:
             w3t = K.pack_weights(P['conv3.weight'], PACK_DGRAD_S1)[0]
-            dy, dt4, G['norm2.weight'], G['norm2.bias'], dgp = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t,
-                                                                              w4t, w3tp=w3t, beta=beta, sca=s.contiguous())
+            dy, dt4, gw2, gb2, dgp = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t, w4t, w3tp=w3t, beta=beta,
+                                                    sca=s.contiguous(), defer_finish=late)
         else:
-            dy, dt4, G['norm2.weight'], G['norm2.bias'] = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t, w4t)
+            dy, dt4, gw2, gb2 = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t, w4t, defer_finish=late)
+        if late:        # the reduction of the per-workgroup LayerNorm-gradient partials is a leaf too (gw2: closure over its private buffer)
+            _leaf((), lambda: dict(zip(('norm2.weight', 'norm2.bias'), gw2())), G)
+        else:
+            G['norm2.weight'], G['norm2.bias'] = gw2, gb2
     else:
         wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
         dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
@@ -226,7 +232,11 @@ def naf_bwd(dout, P, saved):
     if FUSE_TAIL and K.naf_tail_supported(c, H * W) and _dgrad_is_hx2() and x.is_contiguous() and dy.is_contiguous():
         # conv1 dgrad -> norm1 bwd (+ dy) in one launch
         w1t = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)[0]
-        dx, G['norm1.weight'], G['norm1.bias'] = K.naf_head_bwd(dt1, x, mu1, rs1, P['norm1.weight'], w1t, dy)
+        dx, gw1, gb1 = K.naf_head_bwd(dt1, x, mu1, rs1, P['norm1.weight'], w1t, dy, defer_finish=late)
+        if late:
+            _leaf((), lambda: dict(zip(('norm1.weight', 'norm1.bias'), gw1())), G)
+        else:
+            G['norm1.weight'], G['norm1.bias'] = gw1, gb1
     else:
         wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)
         dxn = K.conv_forward(dt1, wp, mp, c, 1)

@@ -713,19 +713,37 @@ def naf_tail_fwd(g, s, x, w3p, b3, beta, lnw, lnb, eps, w4p, b4, w5p, b5, gamma,
     return out, y, mu, rs, yn, t4
 
 
-def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp, w3tp=None, beta=None, sca=None):
+def _ln_partials_finish(ws, nparts, Cc):
+    """closure that reduces the per-workgroup LayerNorm-gradient partials a fused NAFBlock backward left in its PRIVATE `ws`"""
+    def fin():
+        gw = torch.empty(Cc, dtype=torch.float32, device=ws.device)
+        gb = torch.empty_like(gw)
+        check(_lib.load().tdr_pair_sum_partials(ws.data_ptr(), nparts, Cc, gw.data_ptr(), gb.data_ptr(),
+                                                ws.data_ptr() + 4 * nparts * 2 * Cc, _stream()), 'tdr_pair_sum_partials')
+        return gw, gb
+    return fin
+
+
+def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp, w3tp=None, beta=None, sca=None, defer_finish=False):
     """fused conv5 dgrad -> SimpleGate bwd -> conv4 dgrad -> norm2 bwd (+ skip) (csrc/tdr_nafblock.hip).
     Returns (dy, dt4, gw2, gb2[, dgp]); with w3tp / beta / sca the conv3 data gradient dgp = sca * W3^T (beta * dy) comes out
-    of the same launch (without the pooled-gradient term: dwsg_bwd(dg_bias=...) adds it)."""
+    of the same launch (without the pooled-gradient term: dwsg_bwd(dg_bias=...) adds it).
+    defer_finish: gw2 is a closure -> (gw2, gb2) and gb2 is None -- the reduction of the per-workgroup partials (a leaf) is left to
+    the caller, the partials live in a buffer of their own."""
     lib = _lib.load()
     N, Cc, H, W = y.shape
     dev = y.device
     assert dout.is_contiguous()
     dt4 = torch.empty(N, 2 * Cc, H, W, dtype=torch.float32, device=dev)
     dy = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
-    gw = torch.empty(Cc, dtype=torch.float32, device=dev)
-    gb = torch.empty_like(gw)
-    ws = workspace(lib.tdr_naf_tail_bwd_ws_floats(N, Cc, H * W), dev, 'naftail')
+    nws = lib.tdr_naf_tail_bwd_ws_floats(N, Cc, H * W)
+    if defer_finish:
+        gw = gb = None
+        ws = torch.empty(int(nws), dtype=torch.float32, device=dev)
+    else:
+        gw = torch.empty(Cc, dtype=torch.float32, device=dev)
+        gb = torch.empty_like(gw)
+        ws = workspace(nws, dev, 'naftail')
     d = _lib.TdrNafTailBwdDesc()
     d.N, d.C, d.HW, d.c_out = N, Cc, H * W, dout.shape[1]
     assert w5tp.fmt == w4tp.fmt
@@ -734,7 +752,7 @@ def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp, w3tp=None, beta=No
     d.t4, d.t4_ns, d.y, d.y_ns = t4.data_ptr(), _dense_nchw(t4), y.data_ptr(), _dense_nchw(y)
     d.mu, d.rs, d.lnw, d.w5t, d.w4t = mu.data_ptr(), rs.data_ptr(), lnw.data_ptr(), w5tp.data_ptr(), w4tp.data_ptr()
     d.dt4, d.dt4_ns, d.dy, d.dy_ns = dt4.data_ptr(), _dense_nchw(dt4), dy.data_ptr(), _dense_nchw(dy)
-    d.gw, d.gb, d.ws = gw.data_ptr(), gb.data_ptr(), ws.data_ptr()
+    d.gw, d.gb, d.ws = _p(gw), _p(gb), ws.data_ptr()
     dgp = None
     if w3tp is not None:
         assert w3tp.fmt == w4tp.fmt and sca.is_contiguous()
@@ -747,6 +765,8 @@ def naf_tail_bwd(dout, gamma, t4, y, mu, rs, lnw, w5tp, w4tp, w3tp=None, beta=No
         _survey.probe(dt4, 'grad')            # the K = 2C operand formed inside the kernel
         if dgp is not None:
             _survey.probe(dy, 'grad')         # (times beta: the K = C operand of the conv3 stage)
+    if defer_finish:
+        gw = _ln_partials_finish(ws, N * (H * W // 64), Cc)
     return (dy, dt4, gw, gb) if dgp is None else (dy, dt4, gw, gb, dgp)
 
 
@@ -770,25 +790,32 @@ def naf_head_fwd(x, lnw, lnb, eps, w1p, b1):
     return xn, mu, rs, t1
 
 
-def naf_head_bwd(dt1, x, mu, rs, lnw, w1tp, res):
-    """fused conv1 dgrad -> norm1 bwd (+ skip gradient `res`).  Returns (dx, gw1, gb1)."""
+def naf_head_bwd(dt1, x, mu, rs, lnw, w1tp, res, defer_finish=False):
+    """fused conv1 dgrad -> norm1 bwd (+ skip gradient `res`).  Returns (dx, gw1, gb1); defer_finish as in naf_tail_bwd."""
     lib = _lib.load()
     N, Cc, H, W = x.shape
     dev = x.device
     assert dt1.is_contiguous()
     dx = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
-    gw = torch.empty(Cc, dtype=torch.float32, device=dev)
-    gb = torch.empty_like(gw)
-    ws = workspace(lib.tdr_naf_tail_bwd_ws_floats(N, Cc, H * W), dev, 'naftail')
+    nws = lib.tdr_naf_tail_bwd_ws_floats(N, Cc, H * W)
+    if defer_finish:
+        gw = gb = None
+        ws = torch.empty(int(nws), dtype=torch.float32, device=dev)
+    else:
+        gw = torch.empty(Cc, dtype=torch.float32, device=dev)
+        gb = torch.empty_like(gw)
+        ws = workspace(nws, dev, 'naftail')
     d = _lib.TdrNafHeadBwdDesc()
     d.N, d.C, d.HW, d.w_fmt = N, Cc, H * W, w1tp.fmt
     d.dt1, d.dt1_ns, d.x, d.x_ns = dt1.data_ptr(), _dense_nchw(dt1), x.data_ptr(), _dense_nchw(x)
     d.mu, d.rs, d.lnw, d.w1t = mu.data_ptr(), rs.data_ptr(), lnw.data_ptr(), w1tp.data_ptr()
     d.res, d.res_ns, d.dx, d.dx_ns = res.data_ptr(), _dense_nchw(res), dx.data_ptr(), _dense_nchw(dx)
-    d.gw, d.gb, d.ws = gw.data_ptr(), gb.data_ptr(), ws.data_ptr()
+    d.gw, d.gb, d.ws = _p(gw), _p(gb), ws.data_ptr()
     if _survey is not None:
         _survey.probe(dt1, 'grad')
     check(lib.tdr_naf_head_bwd(C.byref(d), _stream()), 'tdr_naf_head_bwd')
+    if defer_finish:
+        gw = _ln_partials_finish(ws, N * (H * W // 64), Cc)
     return dx, gw, gb
 
 
