@@ -22,7 +22,7 @@ extern "C" {
 
 /* C-ABI version: bumped with every incompatible change of this header (100 rounds 1-2, 101 round 3, 102 round 4); the
  * binding (textualdegremoval_amd/_lib.py) refuses a library whose version differs from the one it was written against. */
-#define TDR_ABI_VERSION 102
+#define TDR_ABI_VERSION 103
 int tdr_version(void);
 const char* tdr_last_error(void);
 
@@ -231,6 +231,11 @@ int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b
  * which the reference's autograd adds through the adaptive-average-pool backward, :192-196) */
 int tdr_dwsg_bwd_biased(const float* dg, const float* dg_bias, float dg_bias_mul, const float* t, const float* w, const float* b,
                         int N, int C, int H, int W, float* dt, float* dw, float* db, float* ws, void* stream);
+/* dw = db = NULL in the two calls above (allowed when tdr_dwsg_bwd_parts_supported(W): the one-pass backward): the per-workgroup
+ * partials of the parameter gradients stay at the start of ws and the caller finishes them later -- they are leaves of the backward
+ * pass -- with tdr_dw_param_finish on the same (N, C, H, W).  (ABI 103) */
+int tdr_dwsg_bwd_parts_supported(int W);
+int tdr_dw_param_finish(const float* ws, int N, int C, int H, int W, float* dw /*[2C,9]*/, float* db /*[2C]*/, void* stream);
 
 /* ---- Restormer-ref depthwise stencils (models/archs/network_restormer_guided_arch.py); b / db may be NULL (bias=False).
  * GDFN gate (:236-239): t [N,2C,H,W] -> g [N,C,H,W] = gelu(dw(t)[:C]) * dw(t)[C:]  (erf GELU) */

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (import order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TDR_LIB_PATH', os.path.join(_HERE, 'libtdr_hip.so'))   # override: profiling probe builds
 
-ABI_VERSION = 102      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
+ABI_VERSION = 103      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
 c_fp = C.c_void_p      # device pointers travel as integers
 i32, i64, f32 = C.c_int, C.c_int64, C.c_float
 
@@ -153,6 +153,8 @@ SIGNATURES = {
     'tdr_dwsg_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwsg_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwsg_bwd_biased': (i32, [c_fp, c_fp, f32, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_dwsg_bwd_parts_supported': (i32, [i32]),
+    'tdr_dw_param_finish': (i32, [c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_dwgelu_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_dwgelu_bwd': (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'tdr_dwconv_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, c_fp]),

@@ -527,7 +527,8 @@ int dw_bwd_fused(const float* t, const float* dg, const float* dg_bias, float dg
     DwArgs a{t, dg, w, b, dt, ws, C, H, W, q.tprw_log2, q.rpt, q.ncb, 1.0f, nullptr, nullptr, dg_bias, dg_bias_mul, act,
              {0, dg_ns, act_ns}, nullptr, 0, dgB, dg_ns, actB, act_ns};
     hipLaunchKernelGGL((dwsg_bwd_fused_kernel<GATE>), dim3(q.nb, C, N), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, st, ws, N, C, q.nb, dw, db, GATE == GATE_SUM ? 1 : 0);
+    if (dw)        // dw = NULL: the partials stay in ws, the caller finishes them (tdr_dw_param_finish)
+        hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, st, ws, N, C, q.nb, dw, db, GATE == GATE_SUM ? 1 : 0);
     return 0;
 }
 
@@ -558,6 +559,16 @@ extern "C" int tdr_dwsg_fwd(const float* t, const float* w, const float* b, int 
     return TDR_OK;
 }
 
+extern "C" int tdr_dwsg_bwd_parts_supported(int W) { return (W <= 1024 && !dw_two_pass()) ? 1 : 0; }
+
+extern "C" int tdr_dw_param_finish(const float* ws, int N, int C, int H, int W, float* dw, float* db, void* stream) {
+    TDR_REQUIRE(ws && dw && db && N > 0 && C > 0, "tdr_dw_param_finish: bad argument");
+    const DwGeom q = dw_geom_fused(H, W);
+    hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, (hipStream_t)stream, const_cast<float*>(ws), N, C, q.nb, dw, db, 0);
+    TDR_LAUNCH_CHECK("dw_param_finish_kernel");
+    return TDR_OK;
+}
+
 extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, const float* b, int N, int C, int H, int W,
                             float* dt, float* dw, float* db, float* ws, void* stream) {
     return tdr_dwsg_bwd_biased(dg, nullptr, 0.f, t, w, b, N, C, H, W, dt, dw, db, ws, stream);
@@ -566,7 +577,9 @@ extern "C" int tdr_dwsg_bwd(const float* dg, const float* t, const float* w, con
 extern "C" int tdr_dwsg_bwd_biased(const float* dg, const float* dg_bias, float dg_bias_mul, const float* t, const float* w,
                                    const float* b, int N, int C, int H, int W, float* dt, float* dw, float* db, float* ws,
                                    void* stream) {
-    TDR_REQUIRE(dg && t && w && b && dt && dw && db && ws, "tdr_dwsg_bwd: null pointer");
+    TDR_REQUIRE(dg && t && w && b && dt && ws, "tdr_dwsg_bwd: null pointer");
+    TDR_REQUIRE((dw != nullptr) == (db != nullptr), "tdr_dwsg_bwd: dw and db are given together or not at all");
+    TDR_REQUIRE(dw || tdr_dwsg_bwd_parts_supported(W), "tdr_dwsg_bwd: dw = db = NULL (partials left to the caller) needs the one-pass backward");
     TDR_REQUIRE(W % 4 == 0, "tdr_dwsg_bwd: W must be a multiple of 4 (got %d)", W);
     hipStream_t st = (hipStream_t)stream;
     if (W <= 1024 && !dw_two_pass()) {

@@ -218,12 +218,16 @@ def naf_bwd(dout, P, saved):
     # ---- depthwise + SimpleGate
     if fused and FUSE_CONV3_DGRAD:
         # conv3's data gradient already left the tail kernel; its pooled-gradient term joins as a per-plane constant
-        dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dgp, t1, P['conv2.weight'], P['conv2.bias'], dg_bias=dpooled,
-                                                             dg_bias_mul=1.0 / (H * W))
+        dt1, gdw, gdb = K.dwsg_bwd(dgp, t1, P['conv2.weight'], P['conv2.bias'], dg_bias=dpooled, dg_bias_mul=1.0 / (H * W),
+                                   defer_finish=late)
     else:
         wp, mp, *_ = K.pack_weights(P['conv3.weight'], PACK_DGRAD_S1)
         dg = K.conv_forward(dy, wp, mp, c, 1, kscale=beta, scale=s, bias2=dpooled, bias2_mul=1.0 / (H * W))
-        dt1, G['conv2.weight'], G['conv2.bias'] = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'])
+        dt1, gdw, gdb = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'], defer_finish=late)
+    if callable(gdw):       # the finish of the depthwise parameter gradients: one more leaf
+        _leaf((), lambda: dict(zip(('conv2.weight', 'conv2.bias'), gdw())), G)
+    else:
+        G['conv2.weight'], G['conv2.bias'] = gdw, gdb
     # ---- conv1
     def leaf1():
         g1, b1 = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)

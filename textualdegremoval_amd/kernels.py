@@ -660,17 +660,31 @@ def dwsg_fwd(t, w, b):
     return g, pooled
 
 
-def dwsg_bwd(dg, t, w, b, dg_bias=None, dg_bias_mul=1.0):
+def dwsg_bwd(dg, t, w, b, dg_bias=None, dg_bias_mul=1.0, defer_finish=False):
     """dg_bias [N, C]: per-plane constant added to dg (times dg_bias_mul) as it is read -- the pooled gradient of the SCA
-    branch when the conv3 data gradient comes out of the fused tail kernel without it."""
+    branch when the conv3 data gradient comes out of the fused tail kernel without it.
+    defer_finish (one-pass backward only; otherwise ignored): returns (dt, fin, None), fin() -> (dw, db) reduces the per-workgroup
+    partials of the parameter gradients, which then live in a buffer of their own."""
     lib = _lib.load()
     N, C2, H, W = t.shape
     Cc = C2 // 2
     assert dg.is_contiguous() and t.is_contiguous()
     dt = torch.empty_like(t)
-    dw = torch.empty(C2, 1, 3, 3, dtype=torch.float32, device=t.device)
-    db = torch.empty(C2, dtype=torch.float32, device=t.device)
-    ws = workspace(lib.tdr_dwsg_ws_floats(N, Cc, H, W), t.device)
+    dev = t.device
+    if defer_finish and lib.tdr_dwsg_bwd_parts_supported(W):
+        ws = torch.empty(int(lib.tdr_dwsg_ws_floats(N, Cc, H, W)), dtype=torch.float32, device=dev)
+        check(lib.tdr_dwsg_bwd_biased(dg.data_ptr(), _p(dg_bias), float(dg_bias_mul), t.data_ptr(), w.data_ptr(), b.data_ptr(), N, Cc,
+                                      H, W, dt.data_ptr(), 0, 0, ws.data_ptr(), _stream()), 'tdr_dwsg_bwd')
+
+        def fin():
+            dw = torch.empty(C2, 1, 3, 3, dtype=torch.float32, device=dev)
+            db = torch.empty(C2, dtype=torch.float32, device=dev)
+            check(lib.tdr_dw_param_finish(ws.data_ptr(), N, Cc, H, W, dw.data_ptr(), db.data_ptr(), _stream()), 'tdr_dw_param_finish')
+            return dw, db
+        return dt, fin, None
+    dw = torch.empty(C2, 1, 3, 3, dtype=torch.float32, device=dev)
+    db = torch.empty(C2, dtype=torch.float32, device=dev)
+    ws = workspace(lib.tdr_dwsg_ws_floats(N, Cc, H, W), dev)
     check(lib.tdr_dwsg_bwd_biased(dg.data_ptr(), _p(dg_bias), float(dg_bias_mul), t.data_ptr(), w.data_ptr(), b.data_ptr(), N, Cc,
                                   H, W, dt.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream()), 'tdr_dwsg_bwd')
     return dt, dw, db
