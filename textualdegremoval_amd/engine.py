@@ -308,15 +308,30 @@ def conv_fwd(x, w, b, stride, pad, res=None, relu=False, out=None):
     return out
 
 
-def conv_bwd(dout, x, w, stride, pad, need_dx=True, add_to_dx=None, bias=True):
-    """returns (dx or None, dw, db); db is None for a bias-free conv (bias=False)."""
+def conv_bwd(dout, x, w, stride, pad, need_dx=True, add_to_dx=None, bias=True, into=None):
+    """returns (dx or None, dw, db); db is None for a bias-free conv (bias=False).
+    into = (G, weight name, bias name or None): the parameter gradients go to the collector instead -- as a leaf (_leaf: deferred to
+    the second stream when a whole-network backward collects leaves) -- and (dx, None, None) is returned."""
     Cout, Cin, KH, _ = w.shape
-    with K.on_side(x, dout):
+
+    def leaf():
         if bias:
-            dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad, want_db=True)
+            gw, gb = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad, want_db=True)
         else:
-            dw, db = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad), None
-    dw = dw.view(Cout, Cin, KH, KH)
+            gw, gb = K.conv_wgrad(x, dout, Cout, Cin, KH, stride=stride, pad=pad), None
+        return gw.view(Cout, Cin, KH, KH), gb
+    dw = db = None
+    if into is not None:
+        Gc, wname, bname = into
+        set_late_prefix('')
+
+        def leaf_named():
+            gw, gb = leaf()
+            return {wname: gw} if (gb is None or bname is None) else {wname: gw, bname: gb}
+        _leaf((x, dout), leaf_named, Gc)
+    else:
+        with K.on_side(x, dout):
+            dw, db = leaf()
     dx = None
     if need_dx:
         N, _, OH, OW = dout.shape
@@ -342,11 +357,17 @@ def up_fwd(x, w, skip):
     return K.conv_forward(x, wp, mp, C2, 1, epi=EPI_PSHUF, res=skip)
 
 
-def up_bwd(dout, x, w):
+def up_bwd(dout, x, w, into=None):
+    """into = (G, weight name): as in conv_bwd"""
     C2, Cc = w.shape[0], w.shape[1]
     dT = K.pixel_unshuffle2(dout)
-    with K.on_side(x, dT):
-        dw = K.conv_wgrad(x, dT, C2, Cc, 1).view(C2, Cc, 1, 1)
+    dw = None
+    if into is not None:
+        set_late_prefix('')
+        _leaf((x, dT), lambda: {into[1]: K.conv_wgrad(x, dT, C2, Cc, 1).view(C2, Cc, 1, 1)}, into[0])
+    else:
+        with K.on_side(x, dT):
+            dw = K.conv_wgrad(x, dT, C2, Cc, 1).view(C2, Cc, 1, 1)
     wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_S1)
     dx = K.conv_forward(dT, wp, mp, Cc, 1)
     maybe_join()
@@ -718,7 +739,7 @@ def unet_bwd(dout, P, cfg, saved, G=None):
         dout = dout.contiguous()
         if (Hp, Wp) != (H0, W0):
             dout = K.pad_crop(dout, Hp, Wp)
-        d, G['ending.weight'], G['ending.bias'] = conv_bwd(dout, xe, P['ending.weight'], 1, 1)
+        d, _, _ = conv_bwd(dout, xe, P['ending.weight'], 1, 1, into=(G, 'ending.weight', 'ending.bias'))
         dskips = [None] * n_enc
         for lvl in reversed(range(len(cfg['dec_blk_nums']))):
             xin, sv_d = sv_dec[lvl]
@@ -776,7 +797,7 @@ def _net_bwd_body(dout, P, cfg, saved, G):
         xin, sv_d = sv_dec[lvl]
         d = naf_seq_bwd(d, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl], sv_d, G)
         dskips[n_enc - 1 - lvl] = d                    # gradient of `x + enc_skip` w.r.t. the skip
-        d, G[f'ups.{lvl}.0.weight'] = up_bwd(d, xin, P[f'ups.{lvl}.0.weight'])
+        d, _ = up_bwd(d, xin, P[f'ups.{lvl}.0.weight'], into=(G, f'ups.{lvl}.0.weight'))
     d = naf_seq_bwd(d, P, 'middle_blks.', cfg['middle_blk_num'], sv_m, G)
     dcat = naf_seq_bwd(d, P, 'masa_blk_middle.0.', cfg['reffusion_n_blocks'][n_enc], sv_fm, G)
     dwarp = [None] * 5
@@ -786,14 +807,14 @@ def _net_bwd_body(dout, P, cfg, saved, G):
     for lvl in reversed(range(n_enc)):
         sv_f, sv_e, x_skip = sv_levels[lvl]
         # downs: gradient into the skip tensor, accumulated with the decoder-side skip gradient
-        d, G[f'downs.{lvl}.weight'], G[f'downs.{lvl}.bias'] = conv_bwd(d, x_skip, P[f'downs.{lvl}.weight'], 2, 0,
-                                                                      add_to_dx=dskips[lvl])
+        d, _, _ = conv_bwd(d, x_skip, P[f'downs.{lvl}.weight'], 2, 0, add_to_dx=dskips[lvl],
+                           into=(G, f'downs.{lvl}.weight', f'downs.{lvl}.bias'))
         d = naf_seq_bwd(d, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl], sv_e, G)
         dcat = naf_seq_bwd(d, P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], sv_f, G)
         chan = dcat.shape[1] // 2
         dwarp[lvl] = dcat[:, chan:]
         d = dcat[:, :chan]                             # batch-strided view: every consumer takes an image stride
     # intro conv: input image needs no gradient
-    _, G['intro.weight'], G['intro.bias'] = conv_bwd(d, inp_p, P['intro.weight'], 1, 1, need_dx=False)
+    conv_bwd(d, inp_p, P['intro.weight'], 1, 1, need_dx=False, into=(G, 'intro.weight', 'intro.bias'))
     run_late_leaves(G, lambda: pyramids_bwd(dwarp, pyr, P, cfg, sv_masa, G))
     return G
