@@ -655,6 +655,7 @@ def _main_body(a, world, rank, local, enc):
                                       f'DINOv2 ViT-B/14 window match every step, ref {a.dino_ref_size}x{a.dino_ref_size} '
                                       f'({((a.dino_ref_size - a.size) // max(a.size // 4, 1) + 1) ** 2} windows/image, random-init ViT)')},
             'final_loss': loss,
+            'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9,     # of 288 GB (saved activations + deferred gradient operands + arena)
         }
         if is_cfg2:
             nprod = {'hx2': 3.0, 'bx3': 6.0, 'h1': 1.0}.get(K.MATH)
