@@ -300,8 +300,8 @@ def pmc_step_bytes():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--clip', default='H', choices=['H', 'L'], help='--arch i2t: CLIP ViT-H/14 (SD-2.1, the Mapper input width 1280) or ViT-L/14 geometry')
     ap.add_argument('--arch', default='nafnet', choices=['nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc', 'i2t', 'tr'],
                     help="nafnet: the headline workload (BASELINE configs[1]); restormer: configs[2]'s per-GPU workload "
