@@ -60,7 +60,7 @@ def maybe_join():
 # end of the main backward chain and run on a second HIP stream next to the MASA-encoder backward (kernels.lane): at bs 4 the 1x1 weight
 # gradients of the deep levels are L2 / HBM-bound launches of 512 small workgroups, the encoder's 3x3 data / weight gradients are matrix-
 # bound launches of 256 - 2048 large ones -- complementary resources, where the NAFBlock chain itself (135 KB of LDS per workgroup) leaves
-# no room for a second kernel.  The operands stay referenced until the join (288 GB of HBM: ~10 GB of gradient operands kept alive).
+# no room for a second kernel.  The operands stay referenced until the join (288 GB of HBM: ~14 GB of gradient operands kept alive).
 # Only without a gradient exchange: with collectives the buckets are cut in arrival order inside the backward (parallel.GradAllReducer).
 DEFER_WGRAD = os.environ.get('TDR_DEFER_WGRAD', '1') == '1'
 DEFER_LN_FINISH = os.environ.get('TDR_DEFER_LN_FINISH', '1') == '1'     # also the reductions of the LayerNorm-gradient partials
