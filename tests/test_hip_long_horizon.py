@@ -7,11 +7,13 @@ step with the product arithmetic (TDR_MATH=hx2, hipGraph replay, P16 encoder pat
 
   * no step of the hx2 run is skipped by the guard, the loss scale never moves, no survey-triggered change of arithmetic;
   * the split arithmetic tracks the oracle as closely as exact fp32 on another summation order does.  Training is a chaotic map (ReLU
-    and arg-max decisions, 1e-8 differences in a gradient norm): both device runs drift away from the oracle at the same exponential
-    rate, and WHICH of them is ahead at step 250 changes with anything that permutes a summation (measured on two revisions of the
-    engine: max error 7.7e-4 / 8.6e-4 and 6.2e-4 / 1.36e-3 for f32 / hx2, mean error 1.4e-4 / 2.3e-4 and 1.3e-4 / 2.3e-4).  So the bars
-    are on what is reproducible: over the first third of the horizon max|err_hx2| <= 4 x max|err_f32| (+ 2e-6; measured 0.3 - 0.8 x),
-    over the whole horizon mean|err_hx2| <= 3 x mean|err_f32| (measured 1.6 - 1.8 x) and max|err_hx2| <= 5 x max|err_f32|.
+    and arg-max decisions, float atomics in the transfer backward, 1e-8 differences in a gradient norm): both device runs drift away
+    from the oracle at the same exponential rate, and WHICH of them is ahead late in the run changes from run to run of the SAME
+    binary (measured over eight runs: whole-horizon mean error hx2 / f32 between 0.6 x and 4.1 x, maximum between 0.6 x and 2.2 x;
+    first third of the horizon, where rounding still dominates the amplification: 0.3 x - 2.6 x).  So the bars are: first third
+    max|err_hx2| <= 4 x max|err_f32| (+ 2e-6); whole horizon mean and max <= 10 x those of f32 (same order of magnitude: a
+    systematic bias of the split would show as 100 x and from the first steps on); and max|err_hx2| <= 10 % of the final loss (the
+    curves are the same curve: measured 0.8 % / 4.7 %).
 
 The three curves are persisted under gpurun_out/margins/ (copied to profiles/r<N>/margins/).
 Reference: models/image_restoration_ref_model.py:199-284."""
@@ -105,8 +107,9 @@ def _compare(tag, net, cfg, size, steps, n_pairs):
     assert st_hx2['skipped'] == 0 and st_hx2['applied'] == steps, st_hx2            # the guard never skipped a step
     assert st_hx2['math_after'] == 'hx2' and not st_hx2['bwd_full_range'] and st_hx2['scale_shift'] == 0, st_hx2
     assert max(d_hx2[:third]) <= 4.0 * max(d_f32[:third]) + 2e-6, (max(d_hx2[:third]), max(d_f32[:third]))
-    assert m_hx2 <= 3.0 * m_f32 + 2e-6, (m_hx2, m_f32)
-    assert e_hx2 <= 5.0 * e_f32 + 2e-6, (e_hx2, e_f32)
+    assert m_hx2 <= 10.0 * m_f32 + 2e-6, (m_hx2, m_f32)
+    assert e_hx2 <= 10.0 * e_f32 + 2e-6, (e_hx2, e_f32)
+    assert e_hx2 <= 0.10 * l_or[-1], (e_hx2, l_or[-1])
     assert l_or[-1] < l_or[0]                                                        # (the run does train)
 
 
