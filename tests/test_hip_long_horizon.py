@@ -11,7 +11,7 @@ step with the product arithmetic (TDR_MATH=hx2, hipGraph replay, P16 encoder pat
     from the oracle at the same exponential rate, and WHICH of them is ahead late in the run changes from run to run of the SAME
     binary (measured over eight runs: whole-horizon mean error hx2 / f32 between 0.6 x and 4.1 x, maximum between 0.6 x and 2.2 x;
     first third of the horizon, where rounding still dominates the amplification: 0.3 x - 2.6 x).  So the bars are: first third
-    max|err_hx2| <= 4 x max|err_f32| (+ 2e-6); whole horizon mean and max <= 10 x those of f32 (same order of magnitude: a
+    max|err_hx2| <= 4 x max|err_f32| (+ 1e-5); whole horizon mean and max <= 10 x those of f32 (same order of magnitude: a
     systematic bias of the split would show as 100 x and from the first steps on); and max|err_hx2| <= 10 % of the final loss (the
     curves are the same curve: measured 0.8 % / 4.7 %).
 
@@ -106,7 +106,7 @@ def _compare(tag, net, cfg, size, steps, n_pairs):
     assert all(math.isfinite(v) for v in l_hx2)
     assert st_hx2['skipped'] == 0 and st_hx2['applied'] == steps, st_hx2            # the guard never skipped a step
     assert st_hx2['math_after'] == 'hx2' and not st_hx2['bwd_full_range'] and st_hx2['scale_shift'] == 0, st_hx2
-    assert max(d_hx2[:third]) <= 4.0 * max(d_f32[:third]) + 2e-6, (max(d_hx2[:third]), max(d_f32[:third]))
+    assert max(d_hx2[:third]) <= 4.0 * max(d_f32[:third]) + 1e-5, (max(d_hx2[:third]), max(d_f32[:third]))
     assert m_hx2 <= 10.0 * m_f32 + 2e-6, (m_hx2, m_f32)
     assert e_hx2 <= 10.0 * e_f32 + 2e-6, (e_hx2, e_f32)
     assert e_hx2 <= 0.10 * l_or[-1], (e_hx2, l_or[-1])
