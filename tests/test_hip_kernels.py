@@ -205,7 +205,11 @@ def test_conv_data_gradient(K, KH, st, pd, Cin, Cout, H, W):
     (3, 64, 128, 16, 16, 1, 1, 0), (2, 256, 512, 8, 8, 1, 1, 0), (1, 8, 16, 8, 8, 1, 1, 0),
     (2, 32, 32, 64, 64, 3, 1, 1), (2, 64, 64, 32, 32, 3, 1, 1), (1, 3, 32, 64, 64, 3, 1, 1),
     (2, 32, 3, 32, 32, 3, 1, 1), (1, 128, 128, 8, 8, 3, 1, 1), (2, 16, 32, 32, 32, 3, 2, 1),
-    (2, 16, 32, 32, 32, 2, 2, 0), (1, 8, 8, 13, 17, 3, 1, 1)])
+    (2, 16, 32, 32, 32, 2, 2, 0), (1, 8, 8, 13, 17, 3, 1, 1),
+    # 3x3 stride 2 (csrc/tdr_wgrad_s2.hip under hx2): Cin <= 32 / > 32 variants, several 32-column strips, blocks that start
+    # mid-column and cross a column (OH = 20: 8 tiles per block), ragged channel blocks and a ragged last strip (OW = 40)
+    (2, 32, 64, 128, 128, 3, 2, 1), (1, 64, 128, 64, 64, 3, 2, 1), (2, 128, 256, 32, 32, 3, 2, 1),
+    (1, 72, 80, 40, 80, 3, 2, 1), (3, 8, 16, 64, 64, 3, 2, 1), (1, 40, 24, 16, 24, 3, 2, 1)])
 def test_conv_wgrad(K, N, Cin, Cout, H, W, KH, st, pd):
     x = rnd(N, Cin, H, W, seed=1)
     w = torch.zeros(Cout, Cin, KH, KH, requires_grad=True)
@@ -215,6 +219,24 @@ def test_conv_wgrad(K, N, Cin, Cout, H, W, KH, st, pd):
     # under 'hx2' the O(1) operands are declared fp16-range, so the 2-way fp16 split variant of the kernel is the one tested
     g = K.conv_wgrad(dev(x), dev(go), Cout, Cin, KH, stride=st, pad=pd, fp16_range=True)
     assert rel(g.view_as(ref), ref) < 2e-5
+
+
+def test_conv_wgrad_stride2_bias_and_per_image(K):
+    """bias gradient riding on the stride-2 weight gradient, and the per-image groups (reference conv_L2 .. conv_L5,
+    models/archs/network_nafnet_guided_arch.py:122-128)"""
+    N, Cin, Cout, H, W = 3, 48, 96, 48, 64
+    x = rnd(N, Cin, H, W, seed=3); go = rnd(N, Cout, H // 2, W // 2, seed=4)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    ref = torch.autograd.grad(F.conv2d(x, w, stride=2, padding=1), w, go)[0]
+    g, db = K.conv_wgrad(dev(x), dev(go), Cout, Cin, 3, stride=2, pad=1, want_db=True, fp16_range=True)
+    assert rel(g.view_as(ref), ref) < 2e-5
+    assert rel(db, go.sum(dim=(0, 2, 3))) < 2e-5
+    gi = K.conv_wgrad(dev(x), dev(go), Cout, Cin, 3, stride=2, pad=1, per_image=True, fp16_range=True)
+    assert rel(gi.sum(0).view_as(ref), ref) < 2e-5
+    for n in range(N):
+        w1 = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+        r1 = torch.autograd.grad(F.conv2d(x[n:n + 1], w1, stride=2, padding=1), w1, go[n:n + 1])[0]
+        assert rel(gi[n].view_as(r1), r1) < 2e-5
 
 
 def test_conv_wgrad_gate_and_per_image(K):

@@ -19,3 +19,8 @@ struct WgPlan { int tw_log2, tiles_x, tiles_y, tpi, tps, spi, cfg, WKw, BMc, BNc
 bool tdr_wgrad_bx3_supported(const TdrWgradDesc* d);
 WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d);
 int tdr_wgrad_bx3_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st);
+
+// tdr_wgrad_s2.hip (3x3 stride 2 on the 2-way fp16 split)
+bool tdr_wgrad_s2_supported(const TdrWgradDesc* d);
+WgPlan tdr_wgrad_s2_plan(const TdrWgradDesc* d);
+int tdr_wgrad_s2_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st);

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64 * KL) void wgrad_reduce_kernel(const float* __re
 //      3 = waves 1x1x4 tile 1x1 (32x32)
 WgPlan make_plan(const TdrWgradDesc* d) {
     if (d->math >= 1 && tdr_wgrad_bx3_supported(d)) return tdr_wgrad_bx3_plan(d);
+    if (tdr_wgrad_s2_supported(d)) return tdr_wgrad_s2_plan(d);
     WgPlan p;
     p.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);
     const int TW = 1 << p.tw_log2, TH = 64 >> p.tw_log2;
@@ -306,11 +307,13 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     const int key = d->KH * 10 + d->stride;
     a.scheme = d->math == 3 ? 2 : (d->math == 2 ? 1 : 0);   // 3: plain fp16 (TDR_MATH=h1)
     static const bool dbg = getenv("TDR_WG_DEBUG") != nullptr;   // which shapes miss the split kernel
-    if (dbg && !(d->math >= 1 && tdr_wgrad_bx3_supported(d)))
+    if (dbg && !(d->math >= 1 && tdr_wgrad_bx3_supported(d)) && !tdr_wgrad_s2_supported(d))
         fprintf(stderr, "[tdr] exact wgrad: math %d N %d %d->%d @%dx%d k%d s%d pad %d gate %d per_image %d in_ns %ld dout_ns %ld\n", d->math,
                 d->N, d->Cin, d->Cout, d->H, d->W, d->KH, d->stride, d->pad, d->gate, d->per_image, (long)d->in_ns, (long)d->dout_ns);
     if (d->math >= 1 && tdr_wgrad_bx3_supported(d)) {
         rc = tdr_wgrad_bx3_launch(a, p, d, st);
+    } else if (tdr_wgrad_s2_supported(d)) {
+        rc = tdr_wgrad_s2_launch(a, p, d, st);
     } else if (key == 11) {
         switch (p.cfg) {
             case 0: rc = g ? launch_wg<1, 1, 2, 2, 1, 2, 2, true>(a, p, d->N, st) : launch_wg<1, 1, 2, 2, 1, 2, 2, false>(a, p, d->N, st); break;

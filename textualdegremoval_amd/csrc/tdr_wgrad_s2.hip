@@ -1,0 +1,314 @@
+// Weight gradient of the 3x3 STRIDE-2 convolutions (pad 1, H = 2 OH, W = 2 OW) on the 2-way fp16 split -- the four level
+// transitions conv_L2 .. conv_L5 of the MASA encoder (reference models/archs/network_nafnet_guided_arch.py:122-128), which
+// were the last dense weight gradients of the step on the exact-fp32 kernel (tdr_wgrad_mfma.hip: 4 launches, 1.4 ms).
+//
+//   G[co][ci][ky][kx] = sum_{n,oy,ox} dout[n][co][oy][ox] * in[n][ci][2 oy + ky - 1][2 ox + kx - 1]
+//
+// MFMA view as in tdr_wgrad_bx3.hip: A[i = co][k = output pixel] (dout), B[k][j = ci] (input, per tap), 32x32x16 f16, three
+// products per fp32 product (mh, hm, hh), fp32 accumulate.  What stride 2 changes is the B operand: 8 consecutive output
+// pixels of a tap are 8 input columns two apart.  The staging therefore DE-INTERLEAVES every input row by column parity
+// while it splits it:
+//     E[e] = in[2 (ox0 + e)]         (kx = 1)
+//     O[o] = in[2 (ox0 + o) + 1]     (kx = 2 reads O[ox], kx = 0 reads O[ox - 1])
+// so the kx = 1 / 2 fragments are aligned 16-byte LDS reads and kx = 0 is the kx = 2 piece shifted by one element
+// (v_alignbit with the dword in front of it).  A tile is one output row x 32 columns (two k-steps); a block walks DOWN a
+// 32-column strip, so of the three input rows of a tile only two are new: the LDS tile is a ring of five input rows --
+// the two rows of tile t+1 are converted and written while tile t is on the matrix pipe (they never alias the three rows
+// tile t reads), one barrier per tile; the global loads of tile t+2 are in flight in registers meanwhile.
+//
+// Workgroup = 2 (co halves) x WN (ci halves) x 3 (ky) waves: a wave owns one 32 x 32 (co, ci) tile of ONE kernel row (three
+// accumulators, 48 VGPRs) -- 12 waves per CU instead of the 4 x 144-register waves of the stride-1 kernel, so the
+// conversion VALU of some waves runs under the MFMAs of the others.  Split-K partials go to the workspace in the layout of
+// the other weight-gradient kernels ([split][co][ci][tap]) and are reduced in a fixed order by tdr_conv_wgrad.
+#include "tdr_common.h"
+#include "tdr_wgrad_common.h"
+#include "../../include/tdr.h"
+#include <stdlib.h>
+
+typedef _Float16 s2f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 s2f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned s2u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned s2u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int S2_BM = 64;        // co rows per block
+constexpr int S2_C = 32;         // output columns per tile
+constexpr int S2_PL = 40;        // elements per parity plane of one input row: idx 8 + e, e in [-4, 32)
+constexpr int S2_RP = 2 * S2_PL; // one input row: E plane | O plane
+constexpr int S2_SLOTS = 5;      // ring of input rows
+constexpr int S2_IP = 408;       // channel pitch (elements): 5 * 80 = 400 -> 51 x 16 bytes (odd)
+constexpr int S2_DP = 40;        // dout row pitch (elements): 5 x 16 bytes
+
+// x -> (h, m), h = rn_f16(x), m = rn_f16(x - h); the value is pinned first (tdr_wgrad_bx3.hip split8v)
+template <bool H1>
+__device__ __forceinline__ void s2_split4(float x0, float x1, float x2, float x3, s2u32x2& h, s2u32x2& m) {
+    s2f16x4 hv, mv;
+    float x[4] = {x0, x1, x2, x3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = x[i];
+        asm volatile("" : "+v"(v));
+        const _Float16 hh = (_Float16)v;
+        hv[i] = hh;
+        mv[i] = H1 ? hh : (_Float16)(v - (float)hh);
+    }
+    h = __builtin_bit_cast(s2u32x2, hv);
+    m = __builtin_bit_cast(s2u32x2, mv);
+}
+
+template <int WN, bool H1>
+__global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
+    constexpr int NT = 384 * WN;
+    constexpr int NS = H1 ? 1 : 2;
+    constexpr int BN = 32 * WN;
+    constexpr int NITI = (BN * 27 + NT - 1) / NT;          // input items per thread, non-steady tile (3 rows x 9 chunks per channel)
+    constexpr int DBUF = NS * S2_BM * S2_DP;               // elements of one dout buffer
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* s_d = reinterpret_cast<_Float16*>(smem_raw);                 // [2][NS][BM][DP]
+    _Float16* s_i = s_d + 2 * DBUF;                                        // [NS][BN][IP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kyw = wave % 3, wn = (wave / 3) % WN, wm = wave / (3 * WN);
+    const int j = lane & 31, kg = lane >> 5;
+
+    const int split = blockIdx.x;
+    const int n = split / a.spi;
+    const int t_begin = (split % a.spi) * a.tps;
+    const int t_end = min(t_begin + a.tps, a.tpi);
+    const int co0 = blockIdx.y * S2_BM, ci0 = blockIdx.z * BN;
+    const long HWin = (long)a.H * a.W, HWo = (long)a.OH * a.OW;
+    const float* in_n = a.in + (long)n * a.in_ns;
+    const float* do_n = a.dout + (long)n * a.dout_ns;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    // tiles in column-major order: t -> (tx, ty = output row)
+    auto tile_ty = [&](int t) { return t - (t / a.tiles_y) * a.tiles_y; };
+
+    // ---- dout: item = (co row, 8-pixel chunk), threads 0..255
+    const int dcol = (tid >> 2) & 63, dch = tid & 3;
+    const bool dthread = tid < 256;
+    float dsum = 0.f;
+    auto d_load = [&](int t, f32x4& v0, f32x4& v1, int& msk) {
+        const int tx = t / a.tiles_y, oy = t - tx * a.tiles_y;
+        const int ox = tx * S2_C + dch * 8;
+        const int co = min(co0 + dcol, a.Cout - 1);
+        const bool rok = co0 + dcol < a.Cout;
+        const float* src = do_n + (long)co * HWo + (long)oy * a.OW;
+        const bool ok0 = rok && ox < a.OW, ok1 = rok && ox + 4 < a.OW;
+        v0 = *reinterpret_cast<const f32x4*>(src + (ok0 ? ox : 0));
+        v1 = *reinterpret_cast<const f32x4*>(src + (ok1 ? ox + 4 : 0));
+        msk = (ok0 ? 1 : 0) | (ok1 ? 2 : 0);
+    };
+    auto d_store = [&](int buf, const f32x4& r0, const f32x4& r1, int msk) {
+        const f32x4 v0 = (msk & 1) ? r0 : z4, v1 = (msk & 2) ? r1 : z4;
+        dsum += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+        s2u32x2 h0, m0, h1, m1;
+        s2_split4<H1>(v0[0], v0[1], v0[2], v0[3], h0, m0);
+        s2_split4<H1>(v1[0], v1[1], v1[2], v1[3], h1, m1);
+        _Float16* dst = s_d + buf * DBUF + dcol * S2_DP + dch * 8;
+        *reinterpret_cast<s2u32x4*>(dst) = (s2u32x4){h0[0], h0[1], h1[0], h1[1]};
+        if constexpr (!H1) *reinterpret_cast<s2u32x4*>(dst + S2_BM * S2_DP) = (s2u32x4){m0[0], m0[1], m1[0], m1[1]};
+    };
+
+    // ---- input: item = (ci row, input row r of the tile's three, 8-column chunk q of nine); chunk q holds input columns
+    // 2 ox0 - 8 + 8 q .. + 7, i.e. plane elements e = o = -4 + 4 q .. + 3 (LDS idx 4 + 4 q ..)
+    auto i_load = [&](int t, bool steady, int it, f32x4& v0, f32x4& v1, int& ldsoff) {
+        const int tx = t / a.tiles_y, oy = t - tx * a.tiles_y;
+        const int lr0 = steady ? 1 : 0;
+        const int per = steady ? 18 : 27;
+        const int nitems = BN * per;
+        if (NT * it >= nitems) { ldsoff = 0; return; }      // (block-uniform) no item of this round is live
+        const int id = tid + NT * it;
+        const bool live = id < nitems;
+        const int idc = min(id, nitems - 1);
+        const int cil = steady ? idc / 18 : idc / 27;
+        const int rem = idc - cil * per;
+        const int r = lr0 + rem / 9, q = rem % 9;
+        const int gy = 2 * oy - 1 + r;
+        const int gx0 = 2 * tx * S2_C - 8 + 8 * q;
+        const int slot = (gy + S2_SLOTS) % S2_SLOTS;
+        const int ci = min(ci0 + cil, a.Cin - 1);
+        const bool rok = gy >= 0 && gy < a.H && ci0 + cil < a.Cin;
+        const float* src = in_n + (long)ci * HWin + (long)min(max(gy, 0), a.H - 1) * a.W;
+        const bool ok0 = rok && gx0 >= 0 && gx0 < a.W, ok1 = rok && gx0 + 4 >= 0 && gx0 + 4 < a.W;
+        v0 = *reinterpret_cast<const f32x4*>(src + (ok0 ? gx0 : 0));
+        v1 = *reinterpret_cast<const f32x4*>(src + (ok1 ? gx0 + 4 : 0));
+        // masks and liveness ride in the top bits of the offset: nothing here consumes the loaded values
+        ldsoff = (cil * S2_IP + slot * S2_RP + 4 + 4 * q) | (ok0 ? 1 << 28 : 0) | (ok1 ? 1 << 29 : 0) | (live ? 1 << 30 : 0);
+    };
+    auto i_store = [&](const f32x4& r0, const f32x4& r1, int ldsoff_) {
+        if (!((ldsoff_ >> 30) & 1)) return;
+        const f32x4 v0 = (ldsoff_ >> 28) & 1 ? r0 : z4, v1 = (ldsoff_ >> 29) & 1 ? r1 : z4;
+        const int off = ldsoff_ & 0x0fffffff;
+        s2u32x2 eh, em, oh, om;
+        s2_split4<H1>(v0[0], v0[2], v1[0], v1[2], eh, em);
+        s2_split4<H1>(v0[1], v0[3], v1[1], v1[3], oh, om);
+        *reinterpret_cast<s2u32x2*>(s_i + off) = eh;
+        *reinterpret_cast<s2u32x2*>(s_i + off + S2_PL) = oh;
+        if constexpr (!H1) {
+            *reinterpret_cast<s2u32x2*>(s_i + BN * S2_IP + off) = em;
+            *reinterpret_cast<s2u32x2*>(s_i + BN * S2_IP + off + S2_PL) = om;
+        }
+    };
+
+    // prefetch registers of one tile
+    f32x4 pd0 = z4, pd1 = z4, pi0[NITI], pi1[NITI];
+    int pdm = 0, pio[NITI];
+    auto prefetch = [&](int t, bool steady) {
+        if (dthread) d_load(t, pd0, pd1, pdm);
+#pragma unroll
+        for (int it = 0; it < NITI; ++it) i_load(t, steady, it, pi0[it], pi1[it], pio[it]);
+    };
+    auto commit = [&](int buf) {
+        if (dthread) d_store(buf, pd0, pd1, pdm);
+#pragma unroll
+        for (int it = 0; it < NITI; ++it) i_store(pi0[it], pi1[it], pio[it]);
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kx][r] = 0.f;
+
+    auto mma = [](const s2u32x4& x, const s2u32x4& y, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s2f16x8, x), __builtin_bit_cast(s2f16x8, y), c, 0, 0, 0);
+    };
+    auto mfma_tile = [&](int t, int buf) {
+        const int oy = tile_ty(t);
+        const int slot = (2 * oy - 1 + kyw + S2_SLOTS) % S2_SLOTS;
+        const _Float16* sd = s_d + buf * DBUF + (wm * 32 + j) * S2_DP;
+        const _Float16* si = s_i + (wn * 32 + j) * S2_IP + slot * S2_RP;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int u = 2 * q + kg;                       // this lane half's 8-pixel chunk
+            s2u32x4 af[NS], bf[3][NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                af[s] = *reinterpret_cast<const s2u32x4*>(sd + s * S2_BM * S2_DP + 8 * u);
+                const _Float16* b = si + s * BN * S2_IP;
+                const s2u32x4 E = *reinterpret_cast<const s2u32x4*>(b + 8 + 8 * u);
+                const s2u32x4 O = *reinterpret_cast<const s2u32x4*>(b + S2_PL + 8 + 8 * u);
+                const unsigned pv = *reinterpret_cast<const unsigned*>(b + S2_PL + 8 * u + 6);   // O[8u - 2], O[8u - 1]
+                bf[1][s] = E;
+                bf[2][s] = O;
+                bf[0][s] = (s2u32x4){__builtin_amdgcn_alignbit(O[0], pv, 16), __builtin_amdgcn_alignbit(O[1], O[0], 16),
+                                     __builtin_amdgcn_alignbit(O[2], O[1], 16), __builtin_amdgcn_alignbit(O[3], O[2], 16)};
+            }
+            if constexpr (H1) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[kx] = mma(af[0], bf[kx][0], acc[kx]);
+            } else {
+                // small cross terms first: m x h, h x m, h x h
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[kx] = mma(af[NS - 1], bf[kx][0], acc[kx]);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[kx] = mma(af[0], bf[kx][NS - 1], acc[kx]);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[kx] = mma(af[0], bf[kx][0], acc[kx]);
+            }
+        }
+    };
+
+    if (t_begin < t_end) {
+        prefetch(t_begin, false);                          // first tile of the block: all three rows, synchronously
+        commit(0);
+        __syncthreads();
+        if (t_begin + 1 < t_end) prefetch(t_begin + 1, tile_ty(t_begin + 1) != 0);
+        for (int t = t_begin; t < t_end; ++t) {
+            const int b = (t - t_begin) & 1;
+            const bool has_next = t + 1 < t_end;
+            const bool next_steady = has_next && tile_ty(t + 1) != 0;
+            if (next_steady) {
+                commit(b ^ 1);                             // rows 2 oy + 2, 2 oy + 3: not among the three rows tile t reads
+                if (t + 2 < t_end) prefetch(t + 2, tile_ty(t + 2) != 0);
+            }
+            mfma_tile(t, b);
+            __syncthreads();
+            if (has_next && !next_steady) {                // first tile of a column: its rows alias the ring -- after the barrier
+                commit(b ^ 1);
+                __syncthreads();
+                if (t + 2 < t_end) prefetch(t + 2, tile_ty(t + 2) != 0);
+            }
+        }
+    }
+
+    // ---- bias gradient partial: fixed-order in-block reduction of the per-thread dout sums
+    if (a.dbpart && blockIdx.z == 0) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);
+        if (dthread) red[tid] = dsum;
+        __syncthreads();
+        if (tid < S2_BM && co0 + tid < a.Cout)
+            a.dbpart[(long)split * a.Cout + co0 + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
+    }
+    // partial[split][co][ci][tap]
+    float* part = a.part + (long)split * a.Cout * a.Cin * 9;
+    const int ci = ci0 + wn * 32 + j;
+    if (ci < a.Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) part[((long)co * a.Cin + ci) * 9 + kyw * 3 + kx] = acc[kx][r];
+        }
+    }
+}
+
+template <int WN, bool H1>
+int launch_s2(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
+    constexpr int NS = H1 ? 1 : 2, BN = 32 * WN;
+    const size_t lds = (size_t)(2 * NS * S2_BM * S2_DP + NS * BN * S2_IP) * 2;
+    dim3 grid(N * p.spi, tdr_cdiv(a.Cout, S2_BM), tdr_cdiv(a.Cin, BN));
+    auto kern = wgrad3x3s2_kernel<WN, H1>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(384 * WN), lds, st, a);
+    TDR_LAUNCH_CHECK("wgrad3x3s2_kernel");
+    return TDR_OK;
+}
+
+}  // namespace
+
+bool tdr_wgrad_s2_supported(const TdrWgradDesc* d) {
+    static const bool off = getenv("TDR_WG_S2") && atoi(getenv("TDR_WG_S2")) == 0;   // A/B aid: 0 = exact-fp32 kernel as before
+    if (off || d->math < 2 || d->gate) return false;
+    if (d->KH != 3 || d->stride != 2 || d->pad != 1) return false;
+    if (d->H != 2 * d->OH || d->W != 2 * d->OW || d->OW < 8 || d->OW % 4 != 0) return false;
+    return d->in_ns % 4 == 0 && d->dout_ns % 4 == 0;
+}
+
+WgPlan tdr_wgrad_s2_plan(const TdrWgradDesc* d) {
+    WgPlan p;
+    p.tw_log2 = 5;
+    p.cfg = d->Cin <= 32 ? 0 : 1;
+    p.BMc = S2_BM; p.BNc = d->Cin <= 32 ? 32 : 64;
+    p.WKw = 1;
+    p.tiles_x = tdr_cdiv(d->OW, S2_C);
+    p.tiles_y = d->OH;
+    p.tpi = p.tiles_x * p.tiles_y;
+    const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
+    // one round of blocks: one 12-wave workgroup (125 KB of LDS) per CU, or two of the 6-wave workgroups of the Cin <= 32 variant (73 KB)
+    static const long want_env = getenv("TDR_WG_S2_WANT") ? atol(getenv("TDR_WG_S2_WANT")) : 0;
+    const long want_total = want_env > 0 ? want_env : (p.BNc == 32 ? 512 : 256);
+    long want = want_total / out_tiles;
+    if (want < 1) want = 1;
+    long spi = (want + d->N - 1) / d->N;
+    if (spi > p.tpi / 8) spi = p.tpi / 8;             // at least 8 tiles (one output row each) per block
+    if (spi < 1) spi = 1;
+    p.tps = tdr_cdiv(p.tpi, spi);
+    p.spi = tdr_cdiv(p.tpi, p.tps);
+    return p;
+}
+
+int tdr_wgrad_s2_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st) {
+    const bool h1 = a.scheme == 2;
+    if (p.cfg == 0) return h1 ? launch_s2<1, true>(a, p, d->N, st) : launch_s2<1, false>(a, p, d->N, st);
+    return h1 ? launch_s2<2, true>(a, p, d->N, st) : launch_s2<2, false>(a, p, d->N, st);
+}
