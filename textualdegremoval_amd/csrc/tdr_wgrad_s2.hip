@@ -40,21 +40,31 @@ constexpr int S2_SLOTS = 5;      // ring of input rows
 constexpr int S2_IP = 408;       // channel pitch (elements): 5 * 80 = 400 -> 51 x 16 bytes (odd)
 constexpr int S2_DP = 40;        // dout row pitch (elements): 5 x 16 bytes
 
-// x -> (h, m), h = rn_f16(x), m = rn_f16(x - h); the value is pinned first (tdr_wgrad_bx3.hip split8v)
+// x -> (h, m), h = rn_f16(x), m = rn_f16(x - h).  h by v_cvt_pk_f16_f32; the residual straight from the packed head with
+// v_fma_mixlo / mixhi_f16 (f16 source x -1 + fp32 source, one rounding of an exact difference): 1.5 VALU per value
+// instead of the 3.5 of convert-back / subtract / convert.  Both halves are formed from the SAME fp32 register.
+typedef float s2f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 s2f16x2 __attribute__((ext_vector_type(2)));
+template <bool H1>
+__device__ __forceinline__ void s2_split2(float x0, float x1, unsigned& h, unsigned& m) {
+    asm volatile("" : "+v"(x0), "+v"(x1));
+    const s2f32x2 xv = {x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, s2f16x2));
+    if constexpr (H1) {
+        m = h;
+    } else {
+        const float neg1 = -1.0f;
+        asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(m) : "v"(h), "v"(neg1), "v"(x0));
+        asm volatile("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(h), "v"(neg1), "v"(x1));
+    }
+}
 template <bool H1>
 __device__ __forceinline__ void s2_split4(float x0, float x1, float x2, float x3, s2u32x2& h, s2u32x2& m) {
-    s2f16x4 hv, mv;
-    float x[4] = {x0, x1, x2, x3};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v = x[i];
-        asm volatile("" : "+v"(v));
-        const _Float16 hh = (_Float16)v;
-        hv[i] = hh;
-        mv[i] = H1 ? hh : (_Float16)(v - (float)hh);
-    }
-    h = __builtin_bit_cast(s2u32x2, hv);
-    m = __builtin_bit_cast(s2u32x2, mv);
+    unsigned h0, m0, h1, m1;
+    s2_split2<H1>(x0, x1, h0, m0);
+    s2_split2<H1>(x2, x3, h1, m1);
+    h = (s2u32x2){h0, h1};
+    m = (s2u32x2){m0, m1};
 }
 
 template <int WN, bool H1>
@@ -82,6 +92,14 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
     const float* in_n = a.in + (long)n * a.in_ns;
     const float* do_n = a.dout + (long)n * a.dout_ns;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // raw buffer descriptors of the image's two operands: a masked piece (outside the image, channel beyond the layer) is a load
+    // at an offset beyond num_records, which returns zeros -- no select on the 16 loaded values, 32-bit offsets
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, (int)(a.Cin * HWin * 4), 0x00020000);
+    const auto rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(do_n), 0, (int)(a.Cout * HWo * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    auto bload = [](decltype(rs_in) rs, unsigned off) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    };
 
     // tiles in column-major order: t -> (tx, ty = output row)
     auto tile_ty = [&](int t) { return t - (t / a.tiles_y) * a.tiles_y; };
@@ -90,19 +108,15 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
     const int dcol = (tid >> 2) & 63, dch = tid & 3;
     const bool dthread = tid < 256;
     float dsum = 0.f;
-    auto d_load = [&](int t, f32x4& v0, f32x4& v1, int& msk) {
+    auto d_load = [&](int t, f32x4& v0, f32x4& v1) {
         const int tx = t / a.tiles_y, oy = t - tx * a.tiles_y;
         const int ox = tx * S2_C + dch * 8;
-        const int co = min(co0 + dcol, a.Cout - 1);
         const bool rok = co0 + dcol < a.Cout;
-        const float* src = do_n + (long)co * HWo + (long)oy * a.OW;
-        const bool ok0 = rok && ox < a.OW, ok1 = rok && ox + 4 < a.OW;
-        v0 = *reinterpret_cast<const f32x4*>(src + (ok0 ? ox : 0));
-        v1 = *reinterpret_cast<const f32x4*>(src + (ok1 ? ox + 4 : 0));
-        msk = (ok0 ? 1 : 0) | (ok1 ? 2 : 0);
+        const unsigned base = (unsigned)(((co0 + dcol) * (int)HWo + oy * a.OW + ox) * 4);
+        v0 = bload(rs_do, rok && ox < a.OW ? base : OOB);
+        v1 = bload(rs_do, rok && ox + 4 < a.OW ? base + 16 : OOB);
     };
-    auto d_store = [&](int buf, const f32x4& r0, const f32x4& r1, int msk) {
-        const f32x4 v0 = (msk & 1) ? r0 : z4, v1 = (msk & 2) ? r1 : z4;
+    auto d_store = [&](int buf, const f32x4& v0, const f32x4& v1) {
         dsum += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
         s2u32x2 h0, m0, h1, m1;
         s2_split4<H1>(v0[0], v0[1], v0[2], v0[3], h0, m0);
@@ -129,18 +143,15 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
         const int gy = 2 * oy - 1 + r;
         const int gx0 = 2 * tx * S2_C - 8 + 8 * q;
         const int slot = (gy + S2_SLOTS) % S2_SLOTS;
-        const int ci = min(ci0 + cil, a.Cin - 1);
         const bool rok = gy >= 0 && gy < a.H && ci0 + cil < a.Cin;
-        const float* src = in_n + (long)ci * HWin + (long)min(max(gy, 0), a.H - 1) * a.W;
-        const bool ok0 = rok && gx0 >= 0 && gx0 < a.W, ok1 = rok && gx0 + 4 >= 0 && gx0 + 4 < a.W;
-        v0 = *reinterpret_cast<const f32x4*>(src + (ok0 ? gx0 : 0));
-        v1 = *reinterpret_cast<const f32x4*>(src + (ok1 ? gx0 + 4 : 0));
-        // masks and liveness ride in the top bits of the offset: nothing here consumes the loaded values
-        ldsoff = (cil * S2_IP + slot * S2_RP + 4 + 4 * q) | (ok0 ? 1 << 28 : 0) | (ok1 ? 1 << 29 : 0) | (live ? 1 << 30 : 0);
+        const unsigned base = (unsigned)(((ci0 + cil) * (int)HWin + gy * a.W + gx0) * 4);
+        v0 = bload(rs_in, rok && gx0 >= 0 && gx0 < a.W ? base : OOB);
+        v1 = bload(rs_in, rok && gx0 + 4 >= 0 && gx0 + 4 < a.W ? base + 16 : OOB);
+        // liveness rides in a top bit of the offset: nothing here consumes the loaded values
+        ldsoff = (cil * S2_IP + slot * S2_RP + 4 + 4 * q) | (live ? 1 << 30 : 0);
     };
-    auto i_store = [&](const f32x4& r0, const f32x4& r1, int ldsoff_) {
+    auto i_store = [&](const f32x4& v0, const f32x4& v1, int ldsoff_) {
         if (!((ldsoff_ >> 30) & 1)) return;
-        const f32x4 v0 = (ldsoff_ >> 28) & 1 ? r0 : z4, v1 = (ldsoff_ >> 29) & 1 ? r1 : z4;
         const int off = ldsoff_ & 0x0fffffff;
         s2u32x2 eh, em, oh, om;
         s2_split4<H1>(v0[0], v0[2], v1[0], v1[2], eh, em);
@@ -155,14 +166,20 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
 
     // prefetch registers of one tile
     f32x4 pd0 = z4, pd1 = z4, pi0[NITI], pi1[NITI];
-    int pdm = 0, pio[NITI];
+    int pio[NITI];
     auto prefetch = [&](int t, bool steady) {
-        if (dthread) d_load(t, pd0, pd1, pdm);
+#if defined(S2_ABL) && S2_ABL == 3
+        return;
+#endif
+        if (dthread) d_load(t, pd0, pd1);
 #pragma unroll
         for (int it = 0; it < NITI; ++it) i_load(t, steady, it, pi0[it], pi1[it], pio[it]);
     };
     auto commit = [&](int buf) {
-        if (dthread) d_store(buf, pd0, pd1, pdm);
+#if defined(S2_ABL) && S2_ABL == 2
+        return;
+#endif
+        if (dthread) d_store(buf, pd0, pd1);
 #pragma unroll
         for (int it = 0; it < NITI; ++it) i_store(pi0[it], pi1[it], pio[it]);
     };
@@ -177,6 +194,9 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s2f16x8, x), __builtin_bit_cast(s2f16x8, y), c, 0, 0, 0);
     };
     auto mfma_tile = [&](int t, int buf) {
+#if defined(S2_ABL) && S2_ABL == 1
+        return;
+#endif
         const int oy = tile_ty(t);
         const int slot = (2 * oy - 1 + kyw + S2_SLOTS) % S2_SLOTS;
         const _Float16* sd = s_d + buf * DBUF + (wm * 32 + j) * S2_DP;
@@ -281,6 +301,7 @@ bool tdr_wgrad_s2_supported(const TdrWgradDesc* d) {
     if (off || d->math < 2 || d->gate) return false;
     if (d->KH != 3 || d->stride != 2 || d->pad != 1) return false;
     if (d->H != 2 * d->OH || d->W != 2 * d->OW || d->OW < 8 || d->OW % 4 != 0) return false;
+    if ((long)d->Cin * d->H * d->W >= (1L << 29) || (long)d->Cout * d->OH * d->OW >= (1L << 29)) return false;   // 32-bit buffer offsets
     return d->in_ns % 4 == 0 && d->dout_ns % 4 == 0;
 }
 
