@@ -62,3 +62,19 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// 2-way fp16 split of two fp32 values: h = rn_f16(x) packed by v_cvt_pk_f16_f32, m = rn_f16(x - h) straight from the packed heads
+// with v_fma_mixlo / mixhi_f16 (f16 source x -1 + fp32 source: x - h is exact in fp32, so the one rounding of the mix instruction
+// IS rn_f16(x - h)) -- 1.5 VALU per value where convert / convert back / subtract / convert costs 3.5 - 4, same bits.  The values
+// are pinned in VGPRs first: head and residual must start from the SAME fp32 value (a product left free may be rounded from its
+// exact form for one and from the rounded one for the other, tdr_nafblock.hip).
+typedef float tdr_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 tdr_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tdr_split2_f16(float x0, float x1, unsigned& h, unsigned& m) {
+    asm volatile("" : "+v"(x0), "+v"(x1));
+    const tdr_f32x2 xv = {x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, tdr_f16x2));
+    const float neg1 = -1.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(m) : "v"(h), "v"(neg1), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(h), "v"(neg1), "v"(x1));
+}

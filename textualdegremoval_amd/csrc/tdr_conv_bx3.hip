@@ -165,26 +165,35 @@ __global__ __launch_bounds__(256, (KH == 3 && S == 1 && WM == 1 && TM == 1 && TN
         for (int it = 0; it < NIT; ++it) {
             Frag h, m, l;
             const bool ok = (okmask >> it) & 1u;
+            float vv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float v = rin[set][it][i];
                 if (GATE) v *= rin2[set][it][i];
                 v *= rks[set][i];
-                v = (ok && cbase + i < a.Cin) ? v : 0.f;
-                // pin the (gated / scaled) operand in a VGPR: the splits below must all start from the SAME fp32 value -- left
-                // free, the compiler may round the head from the exact product and the residual from the rounded one, and at
-                // an fp16 / bf16 tie the pair is then off by a whole ulp of the head (tdr_nafblock.hip, split_hm)
-                asm volatile("" : "+v"(v));
-                if constexpr (SCH == SCH_H1) {
-                    h.hv[i] = (_Float16)v;
-                } else if constexpr (SCH == SCH_HX2) {
-                    const _Float16 hh = (_Float16)v;
-                    h.hv[i] = hh;
-                    m.hv[i] = (_Float16)(v - (float)hh);
-                } else {
-                    __bf16 hh, mm, ll;
-                    split3(v, hh, mm, ll);
-                    h.v[i] = hh; m.v[i] = mm; l.v[i] = ll;
+                vv[i] = (ok && cbase + i < a.Cin) ? v : 0.f;
+            }
+            if constexpr (SCH == SCH_HX2) {
+                // head and residual must start from the SAME fp32 value (tdr_split2_f16 pins the gated / scaled operand in a VGPR:
+                // left free, the compiler may round the head from the exact product and the residual from the rounded one, and at
+                // an fp16 tie the pair is then off by a whole ulp of the head -- tdr_nafblock.hip, split_hm)
+                unsigned hd[4], md[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tdr_split2_f16(vv[2 * i], vv[2 * i + 1], hd[i], md[i]);
+                h.u = make_uint4(hd[0], hd[1], hd[2], hd[3]);
+                m.u = make_uint4(md[0], md[1], md[2], md[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = vv[i];
+                    asm volatile("" : "+v"(v));            // pin: every split plane from the same fp32 value
+                    if constexpr (SCH == SCH_H1) {
+                        h.hv[i] = (_Float16)v;
+                    } else {
+                        __bf16 hh, mm, ll;
+                        split3(v, hh, mm, ll);
+                        h.v[i] = hh; m.v[i] = mm; l.v[i] = ll;
+                    }
                 }
             }
             if ((inplane >> it) & 1u) {
@@ -404,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             Frag h, m;
+            float vv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float4 q4 = rin[set][i];
@@ -412,11 +422,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_hx2_kernel(ConvArgs a) {
                     const float4 g4 = rin2[set][i];
                     v *= px == 0 ? g4.x : (px == 1 ? g4.y : (px == 2 ? g4.z : g4.w));
                 }
-                v *= rks[set][i];
-                asm volatile("" : "+v"(v));        // one fp32 value for head and residual (see conv_bx3_kernel)
-                const _Float16 hh = (_Float16)v;
-                h.hv[i] = hh;
-                if constexpr (NS == 2) m.hv[i] = (_Float16)(v - (float)hh);
+                vv[i] = v * rks[set][i];
+            }
+            if constexpr (NS == 2) {
+                unsigned hd[4], md[4];                    // one fp32 value for head and residual (see conv_bx3_kernel)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tdr_split2_f16(vv[2 * i], vv[2 * i + 1], hd[i], md[i]);
+                h.u = make_uint4(hd[0], hd[1], hd[2], hd[3]);
+                m.u = make_uint4(md[0], md[1], md[2], md[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h.hv[i] = (_Float16)vv[i];
             }
             sb[wslot[px]] = h.u;
             if constexpr (NS == 2) sb[OCT * NPX + wslot[px]] = m.u;

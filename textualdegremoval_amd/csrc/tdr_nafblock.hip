@@ -99,17 +99,13 @@ __device__ __forceinline__ void tile_to_planes(const float (&v)[16], uint4* sB, 
     char* base = reinterpret_cast<char*>(sB);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        f16x4 h, m;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 hh, mm;
-            split_hm(v[4 * q + e], hh, mm);
-            h[e] = hh;
-            m[e] = mm;
-        }
+        unsigned h0, h1, m0, m1;
+        tdr_split2_f16(v[4 * q], v[4 * q + 1], h0, m0);
+        tdr_split2_f16(v[4 * q + 2], v[4 * q + 3], h1, m1);
+        const uint2 h = make_uint2(h0, h1), m = make_uint2(m0, m1);
         const long slot = (long)(oct0 + q) * NPX + swz(pix);
-        *reinterpret_cast<f16x4*>(base + slot * 16 + 8 * kk) = h;
-        *reinterpret_cast<f16x4*>(base + ((long)noct * NPX + slot) * 16 + 8 * kk) = m;
+        *reinterpret_cast<uint2*>(base + slot * 16 + 8 * kk) = h;
+        *reinterpret_cast<uint2*>(base + ((long)noct * NPX + slot) * 16 + 8 * kk) = m;
     }
 }
 
@@ -185,13 +181,11 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             HFrag h, m;
+            unsigned hd[4], md[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                _Float16 hh, mm;
-                split_hm((px == 0 ? v[i].x : (px == 1 ? v[i].y : (px == 2 ? v[i].z : v[i].w))) * sc[i], hh, mm);
-                h.hv[i] = hh;
-                m.hv[i] = mm;
-            }
+            for (int i = 0; i < 4; ++i) tdr_split2_f16((px == 0 ? v[2 * i].x : (px == 1 ? v[2 * i].y : (px == 2 ? v[2 * i].z : v[2 * i].w))) * sc[2 * i], (px == 0 ? v[2 * i + 1].x : (px == 1 ? v[2 * i + 1].y : (px == 2 ? v[2 * i + 1].z : v[2 * i + 1].w))) * sc[2 * i + 1], hd[i], md[i]);
+            h.u = make_uint4(hd[0], hd[1], hd[2], hd[3]);
+            m.u = make_uint4(md[0], md[1], md[2], md[3]);
             const int slot = oct * NPX + swz(4 * q + px);
             sB[slot] = h.u;
             sB[NOCT * NPX + slot] = m.u;
@@ -554,13 +548,11 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 HFrag h, m;
+                unsigned hd[4], md[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    _Float16 hh, mm;
-                    split_hm(px == 0 ? v[i].x : (px == 1 ? v[i].y : (px == 2 ? v[i].z : v[i].w)), hh, mm);
-                    h.hv[i] = hh;
-                    m.hv[i] = mm;
-                }
+                for (int i = 0; i < 4; ++i) tdr_split2_f16(px == 0 ? v[2 * i].x : (px == 1 ? v[2 * i].y : (px == 2 ? v[2 * i].z : v[2 * i].w)), px == 0 ? v[2 * i + 1].x : (px == 1 ? v[2 * i + 1].y : (px == 2 ? v[2 * i + 1].z : v[2 * i + 1].w)), hd[i], md[i]);
+                h.u = make_uint4(hd[0], hd[1], hd[2], hd[3]);
+                m.u = make_uint4(md[0], md[1], md[2], md[3]);
                 const int slot = oct * NPX + swz(4 * q + px);
                 sB[slot] = h.u;
                 sB[(2 * C / 8) * NPX + slot] = m.u;
@@ -594,13 +586,11 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             HFrag h, m;
+            unsigned hd[4], md[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                _Float16 hh, mm;
-                split_hm((px == 0 ? v[i].x : (px == 1 ? v[i].y : (px == 2 ? v[i].z : v[i].w))) * sc[i], hh, mm);
-                h.hv[i] = hh;
-                m.hv[i] = mm;
-            }
+            for (int i = 0; i < 4; ++i) tdr_split2_f16((px == 0 ? v[2 * i].x : (px == 1 ? v[2 * i].y : (px == 2 ? v[2 * i].z : v[2 * i].w))) * sc[2 * i], (px == 0 ? v[2 * i + 1].x : (px == 1 ? v[2 * i + 1].y : (px == 2 ? v[2 * i + 1].z : v[2 * i + 1].w))) * sc[2 * i + 1], hd[i], md[i]);
+            h.u = make_uint4(hd[0], hd[1], hd[2], hd[3]);
+            m.u = make_uint4(md[0], md[1], md[2], md[3]);
             const int slot = oct * NPX + swz(4 * q + px);
             sB[slot] = h.u;
             sB[NOCT * NPX + slot] = m.u;

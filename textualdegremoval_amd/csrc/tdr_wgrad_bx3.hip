@@ -64,17 +64,14 @@ __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h
         m = h;
         l = h;
     } else if constexpr (SCH == WSCH_HX2) {
-        wf16x8 hv, mv;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float x = i < 4 ? a[i & 3] : b[i & 3];
-            asm volatile("" : "+v"(x));          // head and residual from the same fp32 value (gated operands are products)
-            const _Float16 hh = (_Float16)x;
-            hv[i] = hh;
-            mv[i] = (_Float16)(x - (float)hh);
-        }
-        h = __builtin_bit_cast(u32x4, hv);
-        m = __builtin_bit_cast(u32x4, mv);
+        // head and residual from the same fp32 value (gated operands are products): tdr_split2_f16 pins its inputs
+        unsigned h0, h1, h2, h3, m0, m1, m2, m3;
+        tdr_split2_f16(a[0], a[1], h0, m0);
+        tdr_split2_f16(a[2], a[3], h1, m1);
+        tdr_split2_f16(b[0], b[1], h2, m2);
+        tdr_split2_f16(b[2], b[3], h3, m3);
+        h = (u32x4){h0, h1, h2, h3};
+        m = (u32x4){m0, m1, m2, m3};
         l = m;
     } else {
         bf16x8 hv, mv, lv;

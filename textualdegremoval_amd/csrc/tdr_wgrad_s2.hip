@@ -40,23 +40,11 @@ constexpr int S2_SLOTS = 5;      // ring of input rows
 constexpr int S2_IP = 408;       // channel pitch (elements): 5 * 80 = 400 -> 51 x 16 bytes (odd)
 constexpr int S2_DP = 40;        // dout row pitch (elements): 5 x 16 bytes
 
-// x -> (h, m), h = rn_f16(x), m = rn_f16(x - h).  h by v_cvt_pk_f16_f32; the residual straight from the packed head with
-// v_fma_mixlo / mixhi_f16 (f16 source x -1 + fp32 source, one rounding of an exact difference): 1.5 VALU per value
-// instead of the 3.5 of convert-back / subtract / convert.  Both halves are formed from the SAME fp32 register.
-typedef float s2f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 s2f16x2 __attribute__((ext_vector_type(2)));
+// x -> (h, m) pairs (tdr_common.h: tdr_split2_f16)
 template <bool H1>
 __device__ __forceinline__ void s2_split2(float x0, float x1, unsigned& h, unsigned& m) {
-    asm volatile("" : "+v"(x0), "+v"(x1));
-    const s2f32x2 xv = {x0, x1};
-    h = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, s2f16x2));
-    if constexpr (H1) {
-        m = h;
-    } else {
-        const float neg1 = -1.0f;
-        asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(m) : "v"(h), "v"(neg1), "v"(x0));
-        asm volatile("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(h), "v"(neg1), "v"(x1));
-    }
+    tdr_split2_f16(x0, x1, h, m);
+    if constexpr (H1) m = h;
 }
 template <bool H1>
 __device__ __forceinline__ void s2_split4(float x0, float x1, float x2, float x3, s2u32x2& h, s2u32x2& m) {
