@@ -40,6 +40,16 @@ __device__ __forceinline__ _Float16 p16_head(float x) {
     return x == 0.f ? __builtin_bit_cast(_Float16, (unsigned short)0x8000) : h;
 }
 __device__ __forceinline__ bool p16_positive(_Float16 head) { return (__builtin_bit_cast(unsigned short, head) & 0x8000u) == 0; }
+// four fp32 values -> their head (p16_head) and residual slots halves: tdr_split2_f16 pairs + the sign bit of exact zeros
+__device__ __forceinline__ void p16_split4(float x0, float x1, float x2, float x3, uint2& h, uint2& m) {
+    unsigned h0, h1, m0, m1;
+    tdr_split2_f16(x0, x1, h0, m0);
+    tdr_split2_f16(x2, x3, h1, m1);
+    h0 |= (x0 == 0.f ? 0x8000u : 0u) | (x1 == 0.f ? 0x80000000u : 0u);     // +-0 -> -0.0
+    h1 |= (x2 == 0.f ? 0x8000u : 0u) | (x3 == 0.f ? 0x80000000u : 0u);
+    h = make_uint2(h0, h1);
+    m = make_uint2(m0, m1);
+}
 
 struct P16Args {
     const uint4* in; long in_ns;       // P16 input, slots per image
@@ -147,18 +157,11 @@ __device__ __forceinline__ void p16_epilogue(const P16Args& a, f32x16 (&acc)[TM]
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (!pvalid || mt0 + 8 * q >= a.Cout) continue;
-                    pf16x4 h, m;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = v[4 * q + e];
-                        asm volatile("" : "+v"(x));          // head and residual from the same fp32 value
-                        const _Float16 hh = (_Float16)x;
-                        h[e] = p16_head(x);
-                        m[e] = (_Float16)(x - (float)hh);
-                    }
+                    uint2 h, m;                                  // head and residual from the same fp32 value (tdr_split2_f16)
+                    p16_split4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], h, m);
                     char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * 2 * PS) + kk * 8;
-                    *reinterpret_cast<pf16x4*>(base + pslot * 16) = h;
-                    *reinterpret_cast<pf16x4*>(base + (PS + pslot) * 16) = m;
+                    *reinterpret_cast<uint2*>(base + pslot * 16) = h;
+                    *reinterpret_cast<uint2*>(base + (PS + pslot) * 16) = m;
                     // the zero border of the output tensor is written by the tiles that touch it
                     const pf16x4 z = {0, 0, 0, 0};
                     const bool top = oy == 0, bot = oy == a.H - 1, lef = ox == 0, rig = ox == a.W - 1;
@@ -252,18 +255,11 @@ __device__ __forceinline__ void p16_epilogue_lean(const P16Args& a, f32x16 (&acc
                         if (pvalid && c0 + e < a.Cout) op[(long)(c0 + e) * HW] = v[e];
                 }
                 if (a.out16 && pvalid && mt0 + 8 * q < a.Cout) {
-                    pf16x4 h, m;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = v[e];
-                        asm volatile("" : "+v"(x));          // head and residual from the same fp32 value
-                        const _Float16 hh = (_Float16)x;
-                        h[e] = p16_head(x);
-                        m[e] = (_Float16)(x - (float)hh);
-                    }
+                    uint2 h, m;                                  // head and residual from the same fp32 value (tdr_split2_f16)
+                    p16_split4(v[0], v[1], v[2], v[3], h, m);
                     char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * 2 * PS) + kk * 8;
-                    *reinterpret_cast<pf16x4*>(base + pslot * 16) = h;
-                    *reinterpret_cast<pf16x4*>(base + (PS + pslot) * 16) = m;
+                    *reinterpret_cast<uint2*>(base + pslot * 16) = h;
+                    *reinterpret_cast<uint2*>(base + (PS + pslot) * 16) = m;
                     // the zero border of the output tensor is written by the tiles that touch it
                     if (top | bot | lef | rig) {
                         const pf16x4 z = {0, 0, 0, 0};
