@@ -16,16 +16,16 @@ K.set_math('hx2')
 torch.manual_seed(0)
 
 
-def t(name, N, Cin, Cout, H):
+def t(name, N, Cin, Cout, H, KH=3):
     xs = [torch.randn(N, Cin, H, H, device='cuda') for _ in range(2)]
     ds = [torch.randn(N, Cout, H // 2, H // 2, device='cuda') for _ in range(2)]
-    f = lambda i: K.conv_wgrad(xs[i & 1], ds[i & 1], Cout, Cin, 3, stride=2, pad=1, want_db=True, fp16_range=True)
+    f = lambda i: K.conv_wgrad(xs[i & 1], ds[i & 1], Cout, Cin, KH, stride=2, pad=(KH - 1) // 2, want_db=True, fp16_range=True)
     for i in range(3): f(i)
     torch.cuda.synchronize()
     g, db = f(0)
-    w = torch.zeros(Cout, Cin, 3, 3, device='cuda', dtype=torch.float64, requires_grad=True)
-    y = torch.nn.functional.conv2d(xs[0][:2].double(), w, stride=2, padding=1)
-    g2, _ = K.conv_wgrad(xs[0][:2].contiguous(), ds[0][:2].contiguous(), Cout, Cin, 3, stride=2, pad=1, want_db=True, fp16_range=True)
+    w = torch.zeros(Cout, Cin, KH, KH, device='cuda', dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(xs[0][:2].double(), w, stride=2, padding=(KH - 1) // 2)
+    g2, _ = K.conv_wgrad(xs[0][:2].contiguous(), ds[0][:2].contiguous(), Cout, Cin, KH, stride=2, pad=(KH - 1) // 2, want_db=True, fp16_range=True)
     ref = torch.autograd.grad(y, w, ds[0][:2].double())[0]
     err = ((g2.view_as(ref).double() - ref).abs().max() / ref.abs().max()).item()
     dbe = ((db.double() - ds[0].double().sum(dim=(0, 2, 3))).abs().max() / ds[0].double().sum(dim=(0, 2, 3)).abs().max()).item()
@@ -47,3 +47,7 @@ t('3x3 s2 32->64 @512 N8', 8, 32, 64, 512)
 t('3x3 s2 64->128 @256 N8', 8, 64, 128, 256)
 t('3x3 s2 128->256 @128 N8', 8, 128, 256, 128)
 t('3x3 s2 256->512 @64 N8', 8, 256, 512, 64)
+t('2x2 s2 32->64 @512 N4', 4, 32, 64, 512, 2)
+t('2x2 s2 64->128 @256 N4', 4, 64, 128, 256, 2)
+t('2x2 s2 128->256 @128 N4', 4, 128, 256, 128, 2)
+t('2x2 s2 256->512 @64 N4', 4, 256, 512, 64, 2)

@@ -209,7 +209,9 @@ def test_conv_data_gradient(K, KH, st, pd, Cin, Cout, H, W):
     # 3x3 stride 2 (csrc/tdr_wgrad_s2.hip under hx2): Cin <= 32 / > 32 variants, several 32-column strips, blocks that start
     # mid-column and cross a column (OH = 20: 8 tiles per block), ragged channel blocks and a ragged last strip (OW = 40)
     (2, 32, 64, 128, 128, 3, 2, 1), (1, 64, 128, 64, 64, 3, 2, 1), (2, 128, 256, 32, 32, 3, 2, 1),
-    (1, 72, 80, 40, 80, 3, 2, 1), (3, 8, 16, 64, 64, 3, 2, 1), (1, 40, 24, 16, 24, 3, 2, 1)])
+    (1, 72, 80, 40, 80, 3, 2, 1), (3, 8, 16, 64, 64, 3, 2, 1), (1, 40, 24, 16, 24, 3, 2, 1),
+    # 2x2 stride 2 (the `downs`), same kernel family
+    (2, 32, 64, 128, 128, 2, 2, 0), (1, 64, 128, 64, 64, 2, 2, 0), (1, 72, 80, 40, 80, 2, 2, 0), (2, 128, 256, 32, 32, 2, 2, 0)])
 def test_conv_wgrad(K, N, Cin, Cout, H, W, KH, st, pd):
     x = rnd(N, Cin, H, W, seed=1)
     w = torch.zeros(Cout, Cin, KH, KH, requires_grad=True)

@@ -1,6 +1,7 @@
-// Weight gradient of the 3x3 STRIDE-2 convolutions (pad 1, H = 2 OH, W = 2 OW) on the 2-way fp16 split -- the four level
-// transitions conv_L2 .. conv_L5 of the MASA encoder (reference models/archs/network_nafnet_guided_arch.py:122-128), which
-// were the last dense weight gradients of the step on the exact-fp32 kernel (tdr_wgrad_mfma.hip: 4 launches, 1.4 ms).
+// Weight gradient of the STRIDE-2 convolutions (H = 2 OH, W = 2 OW) on the 2-way fp16 split: 3x3 pad 1 -- the four level
+// transitions conv_L2 .. conv_L5 of the MASA encoder (reference models/archs/network_nafnet_guided_arch.py:122-128) -- and
+// 2x2 pad 0 -- the `downs` of the U-Net (:434-437).  They were the last dense weight gradients of the step on the exact-fp32
+// kernel (tdr_wgrad_mfma.hip: 4 + 4 launches, 1.4 + 0.35 ms).  Described for 3x3; the 2x2 variant has no halo and no shifted tap.
 //
 //   G[co][ci][ky][kx] = sum_{n,oy,ox} dout[n][co][oy][ox] * in[n][ci][2 oy + ky - 1][2 ox + kx - 1]
 //
@@ -36,8 +37,10 @@ constexpr int S2_BM = 64;        // co rows per block
 constexpr int S2_C = 32;         // output columns per tile
 constexpr int S2_PL = 40;        // elements per parity plane of one input row: idx 8 + e, e in [-4, 32)
 constexpr int S2_RP = 2 * S2_PL; // one input row: E plane | O plane
-constexpr int S2_SLOTS = 5;      // ring of input rows
-constexpr int S2_IP = 408;       // channel pitch (elements): 5 * 80 = 400 -> 51 x 16 bytes (odd)
+// ring of input rows: 5 (3x3: rows 2 oy - 1 .. 2 oy + 3 live at once) / 4 (2x2: 2 oy .. 2 oy + 3); channel pitch (elements) = slots * 80
+// rounded up to an odd number of 16-byte pieces: 408 = 51 x 8 / 328 = 41 x 8
+constexpr int s2_slots(int KH) { return KH == 3 ? 5 : 4; }
+constexpr int s2_ip(int KH) { return KH == 3 ? 408 : 328; }
 constexpr int S2_DP = 40;        // dout row pitch (elements): 5 x 16 bytes
 
 // x -> (h, m) pairs (tdr_common.h: tdr_split2_f16)
@@ -55,12 +58,16 @@ __device__ __forceinline__ void s2_split4(float x0, float x1, float x2, float x3
     m = (s2u32x2){m0, m1};
 }
 
-template <int WN, bool H1>
-__global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
-    constexpr int NT = 384 * WN;
+// KH = 3 (pad 1) or 2 (pad 0: the 2x2 stride-2 `downs` of the U-Net, :434-437 -- rows 2 oy, 2 oy + 1, columns 2 ox (E) / 2 ox + 1 (O), no halo)
+template <int KH, int WN, bool H1>
+__global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
+    constexpr int NT = 128 * KH * WN;
+    constexpr int PAD = KH == 3 ? 1 : 0;
+    constexpr int NCH = KH == 3 ? 9 : 8;                   // 8-column chunks per staged input row
+    constexpr int S2_SLOTS = s2_slots(KH), S2_IP = s2_ip(KH);
     constexpr int NS = H1 ? 1 : 2;
     constexpr int BN = 32 * WN;
-    constexpr int NITI = (BN * 27 + NT - 1) / NT;          // input items per thread, non-steady tile (3 rows x 9 chunks per channel)
+    constexpr int NITI = (BN * KH * NCH + NT - 1) / NT;    // input items per thread, non-steady tile (KH rows x NCH chunks per channel)
     constexpr int DBUF = NS * S2_BM * S2_DP;               // elements of one dout buffer
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
     _Float16* s_i = s_d + 2 * DBUF;                                        // [NS][BN][IP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kyw = wave % 3, wn = (wave / 3) % WN, wm = wave / (3 * WN);
+    const int kyw = wave % KH, wn = (wave / KH) % WN, wm = wave / (KH * WN);
     const int j = lane & 31, kg = lane >> 5;
 
     const int split = blockIdx.x;
@@ -118,25 +125,25 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
     // 2 ox0 - 8 + 8 q .. + 7, i.e. plane elements e = o = -4 + 4 q .. + 3 (LDS idx 4 + 4 q ..)
     auto i_load = [&](int t, bool steady, int it, f32x4& v0, f32x4& v1, int& ldsoff) {
         const int tx = t / a.tiles_y, oy = t - tx * a.tiles_y;
-        const int lr0 = steady ? 1 : 0;
-        const int per = steady ? 18 : 27;
+        const int lr0 = (KH == 3 && steady) ? 1 : 0;       // 3x3: row 2 oy - 1 of a steady tile is the previous tile's row 2 oy + 1
+        const int per = (KH - lr0) * NCH;
         const int nitems = BN * per;
         if (NT * it >= nitems) { ldsoff = 0; return; }      // (block-uniform) no item of this round is live
         const int id = tid + NT * it;
         const bool live = id < nitems;
         const int idc = min(id, nitems - 1);
-        const int cil = steady ? idc / 18 : idc / 27;
+        const int cil = lr0 ? idc / ((KH - 1) * NCH) : idc / (KH * NCH);
         const int rem = idc - cil * per;
-        const int r = lr0 + rem / 9, q = rem % 9;
-        const int gy = 2 * oy - 1 + r;
-        const int gx0 = 2 * tx * S2_C - 8 + 8 * q;
+        const int r = lr0 + rem / NCH, q = rem % NCH;
+        const int gy = 2 * oy - PAD + r;
+        const int gx0 = 2 * tx * S2_C - (KH == 3 ? 8 : 0) + 8 * q;
         const int slot = (gy + S2_SLOTS) % S2_SLOTS;
         const bool rok = gy >= 0 && gy < a.H && ci0 + cil < a.Cin;
         const unsigned base = (unsigned)(((ci0 + cil) * (int)HWin + gy * a.W + gx0) * 4);
         v0 = bload(rs_in, rok && gx0 >= 0 && gx0 < a.W ? base : OOB);
         v1 = bload(rs_in, rok && gx0 + 4 >= 0 && gx0 + 4 < a.W ? base + 16 : OOB);
         // liveness rides in a top bit of the offset: nothing here consumes the loaded values
-        ldsoff = (cil * S2_IP + slot * S2_RP + 4 + 4 * q) | (live ? 1 << 30 : 0);
+        ldsoff = (cil * S2_IP + slot * S2_RP + (KH == 3 ? 4 : 8) + 4 * q) | (live ? 1 << 30 : 0);
     };
     auto i_store = [&](const f32x4& v0, const f32x4& v1, int ldsoff_) {
         if (!((ldsoff_ >> 30) & 1)) return;
@@ -172,9 +179,9 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
         for (int it = 0; it < NITI; ++it) i_store(pi0[it], pi1[it], pio[it]);
     };
 
-    f32x16 acc[3];
+    f32x16 acc[KH];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int kx = 0; kx < KH; ++kx)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[kx][r] = 0.f;
 
@@ -186,36 +193,41 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
         return;
 #endif
         const int oy = tile_ty(t);
-        const int slot = (2 * oy - 1 + kyw + S2_SLOTS) % S2_SLOTS;
+        const int slot = (2 * oy - PAD + kyw + S2_SLOTS) % S2_SLOTS;
         const _Float16* sd = s_d + buf * DBUF + (wm * 32 + j) * S2_DP;
         const _Float16* si = s_i + (wn * 32 + j) * S2_IP + slot * S2_RP;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int u = 2 * q + kg;                       // this lane half's 8-pixel chunk
-            s2u32x4 af[NS], bf[3][NS];
+            s2u32x4 af[NS], bf[KH][NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 af[s] = *reinterpret_cast<const s2u32x4*>(sd + s * S2_BM * S2_DP + 8 * u);
                 const _Float16* b = si + s * BN * S2_IP;
                 const s2u32x4 E = *reinterpret_cast<const s2u32x4*>(b + 8 + 8 * u);
                 const s2u32x4 O = *reinterpret_cast<const s2u32x4*>(b + S2_PL + 8 + 8 * u);
-                const unsigned pv = *reinterpret_cast<const unsigned*>(b + S2_PL + 8 * u + 6);   // O[8u - 2], O[8u - 1]
-                bf[1][s] = E;
-                bf[2][s] = O;
-                bf[0][s] = (s2u32x4){__builtin_amdgcn_alignbit(O[0], pv, 16), __builtin_amdgcn_alignbit(O[1], O[0], 16),
-                                     __builtin_amdgcn_alignbit(O[2], O[1], 16), __builtin_amdgcn_alignbit(O[3], O[2], 16)};
+                if constexpr (KH == 3) {
+                    const unsigned pv = *reinterpret_cast<const unsigned*>(b + S2_PL + 8 * u + 6);   // O[8u - 2], O[8u - 1]
+                    bf[1][s] = E;
+                    bf[2][s] = O;
+                    bf[0][s] = (s2u32x4){__builtin_amdgcn_alignbit(O[0], pv, 16), __builtin_amdgcn_alignbit(O[1], O[0], 16),
+                                         __builtin_amdgcn_alignbit(O[2], O[1], 16), __builtin_amdgcn_alignbit(O[3], O[2], 16)};
+                } else {
+                    bf[0][s] = E;                           // kx = 0: column 2 ox; kx = 1: column 2 ox + 1
+                    bf[1][s] = O;
+                }
             }
             if constexpr (H1) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[kx] = mma(af[0], bf[kx][0], acc[kx]);
+                for (int kx = 0; kx < KH; ++kx) acc[kx] = mma(af[0], bf[kx][0], acc[kx]);
             } else {
                 // small cross terms first: m x h, h x m, h x h
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[kx] = mma(af[NS - 1], bf[kx][0], acc[kx]);
+                for (int kx = 0; kx < KH; ++kx) acc[kx] = mma(af[NS - 1], bf[kx][0], acc[kx]);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[kx] = mma(af[0], bf[kx][NS - 1], acc[kx]);
+                for (int kx = 0; kx < KH; ++kx) acc[kx] = mma(af[0], bf[kx][NS - 1], acc[kx]);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[kx] = mma(af[0], bf[kx][0], acc[kx]);
+                for (int kx = 0; kx < KH; ++kx) acc[kx] = mma(af[0], bf[kx][0], acc[kx]);
             }
         }
     };
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
             a.dbpart[(long)split * a.Cout + co0 + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
     }
     // partial[split][co][ci][tap]
-    float* part = a.part + (long)split * a.Cout * a.Cin * 9;
+    float* part = a.part + (long)split * a.Cout * a.Cin * (KH * KH);
     const int ci = ci0 + wn * 32 + j;
     if (ci < a.Cin) {
 #pragma unroll
@@ -261,24 +273,24 @@ __global__ __launch_bounds__(384 * WN) void wgrad3x3s2_kernel(WgArgs a) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             if (co >= a.Cout) continue;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) part[((long)co * a.Cin + ci) * 9 + kyw * 3 + kx] = acc[kx][r];
+            for (int kx = 0; kx < KH; ++kx) part[((long)co * a.Cin + ci) * (KH * KH) + kyw * KH + kx] = acc[kx][r];
         }
     }
 }
 
-template <int WN, bool H1>
+template <int KH, int WN, bool H1>
 int launch_s2(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
     constexpr int NS = H1 ? 1 : 2, BN = 32 * WN;
-    const size_t lds = (size_t)(2 * NS * S2_BM * S2_DP + NS * BN * S2_IP) * 2;
+    const size_t lds = (size_t)(2 * NS * S2_BM * S2_DP + NS * BN * s2_ip(KH)) * 2;
     dim3 grid(N * p.spi, tdr_cdiv(a.Cout, S2_BM), tdr_cdiv(a.Cin, BN));
-    auto kern = wgrad3x3s2_kernel<WN, H1>;
+    auto kern = wgrad_s2_kernel<KH, WN, H1>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(384 * WN), lds, st, a);
-    TDR_LAUNCH_CHECK("wgrad3x3s2_kernel");
+    hipLaunchKernelGGL(kern, grid, dim3(128 * KH * WN), lds, st, a);
+    TDR_LAUNCH_CHECK("wgrad_s2_kernel");
     return TDR_OK;
 }
 
@@ -287,7 +299,7 @@ int launch_s2(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
 bool tdr_wgrad_s2_supported(const TdrWgradDesc* d) {
     static const bool off = getenv("TDR_WG_S2") && atoi(getenv("TDR_WG_S2")) == 0;   // A/B aid: 0 = exact-fp32 kernel as before
     if (off || d->math < 2 || d->gate) return false;
-    if (d->KH != 3 || d->stride != 2 || d->pad != 1) return false;
+    if (d->stride != 2 || !((d->KH == 3 && d->pad == 1) || (d->KH == 2 && d->pad == 0))) return false;
     if (d->H != 2 * d->OH || d->W != 2 * d->OW || d->OW < 8 || d->OW % 4 != 0) return false;
     if ((long)d->Cin * d->H * d->W >= (1L << 29) || (long)d->Cout * d->OH * d->OW >= (1L << 29)) return false;   // 32-bit buffer offsets
     return d->in_ns % 4 == 0 && d->dout_ns % 4 == 0;
@@ -318,6 +330,10 @@ WgPlan tdr_wgrad_s2_plan(const TdrWgradDesc* d) {
 
 int tdr_wgrad_s2_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st) {
     const bool h1 = a.scheme == 2;
-    if (p.cfg == 0) return h1 ? launch_s2<1, true>(a, p, d->N, st) : launch_s2<1, false>(a, p, d->N, st);
-    return h1 ? launch_s2<2, true>(a, p, d->N, st) : launch_s2<2, false>(a, p, d->N, st);
+    if (d->KH == 3) {
+        if (p.cfg == 0) return h1 ? launch_s2<3, 1, true>(a, p, d->N, st) : launch_s2<3, 1, false>(a, p, d->N, st);
+        return h1 ? launch_s2<3, 2, true>(a, p, d->N, st) : launch_s2<3, 2, false>(a, p, d->N, st);
+    }
+    if (p.cfg == 0) return h1 ? launch_s2<2, 1, true>(a, p, d->N, st) : launch_s2<2, 1, false>(a, p, d->N, st);
+    return h1 ? launch_s2<2, 2, true>(a, p, d->N, st) : launch_s2<2, 2, false>(a, p, d->N, st);
 }
