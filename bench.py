@@ -475,14 +475,15 @@ def _main_body(a, world, rank, local, enc):
             return out
 
         def timed_wg(x, dout, Cout, Cin, KH, **kw):
-            if kw.get('per_image') or kw.get('stride', 1) != 1:
+            if kw.get('per_image'):
                 return orig_wg(x, dout, Cout, Cin, KH, **kw)
             e0, e1 = _ev()
             e0.record()
             out = orig_wg(x, dout, Cout, Cin, KH, **kw)
             e1.record()
             recs.append((2.0 * dout.shape[0] * Cout * Cin * KH * KH * dout.shape[2] * dout.shape[3], e0, e1,
-                         4.0 * (dout.shape[0] * Cin * x.shape[2] * x.shape[3] + dout.numel()), ('wgrad', KH)))
+                         4.0 * (dout.shape[0] * Cin * x.shape[2] * x.shape[3] + dout.numel()),
+                         ('wgrad', KH if kw.get('stride', 1) == 1 else 's2')))
             return out
 
         def timed_wg16(x16, d16, **kw):
@@ -568,14 +569,15 @@ def _main_body(a, world, rank, local, enc):
             roof_other = [subs[k] for k in subs if k != lead]
         WG = {3: 'wgrad_bx3_kernel<KH=3> + wgrad_reduce_kernel (fp32 tensors in, operand split + v_alignbit fragment assembly per consumer)',
               1: 'wgrad_bx3_kernel<KH=1> + wgrad_reduce_kernel (1x1 weight gradients of the NAFBlock chains, split-K partials)',
-              'p16': 'wgrad3x3_p16_kernel + wgrad_p16_reduce_kernel (pre-split pair planes, transposed LDS reads, no operand VALU)'}
+              'p16': 'wgrad3x3_p16_kernel + wgrad_p16_reduce_kernel (pre-split pair planes, transposed LDS reads, no operand VALU)',
+              's2': 'wgrad_s2_kernel + wgrad_reduce_kernel (3x3 / 2x2 stride-2 level transitions: parity-de-interleaved LDS planes, 12 / 8-wave workgroups)'}
         for k in sorted({r[4][1] for r in recs if r[4][0] == 'wgrad'}, key=str):
             e = entry([r for r in recs if r[4] == ('wgrad', k)], WG.get(k, f'wgrad KH={k}'),
                       PEAK_HX2 if K.MATH in ('hx2', 'h1') else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32),
                       'fp32-equivalent ceiling of the step\'s operand scheme; time = kernel + its fixed-order split-K reduction (HIP events around both)')
             # measured bytes per launch: the kernel's own traffic plus its split-K reduction's (one reduction per weight-gradient launch)
             wpre = {3: ('wgrad_bx3_kernel<3,', 'wgrad_reduce_kernel'), 1: ('wgrad_bx3_kernel<1,', 'wgrad_reduce_kernel'),
-                    'p16': ('wgrad3x3_p16_kernel', 'wgrad_p16_reduce_kernel')}.get(k)
+                    'p16': ('wgrad3x3_p16_kernel', 'wgrad_p16_reduce_kernel'), 's2': ('wgrad_s2_kernel', 'wgrad_reduce_kernel')}.get(k)
             if wpre:
                 t_k, t_r = pmc_traffic([wpre[0]])[0], pmc_traffic([wpre[1]])[0]
                 e['traffic'] = None if t_k is None else t_k + (t_r or 0.0)
