@@ -210,6 +210,8 @@ def test_conv_data_gradient(K, KH, st, pd, Cin, Cout, H, W):
     # mid-column and cross a column (OH = 20: 8 tiles per block), ragged channel blocks and a ragged last strip (OW = 40)
     (2, 32, 64, 128, 128, 3, 2, 1), (1, 64, 128, 64, 64, 3, 2, 1), (2, 128, 256, 32, 32, 3, 2, 1),
     (1, 72, 80, 40, 80, 3, 2, 1), (3, 8, 16, 64, 64, 3, 2, 1), (1, 40, 24, 16, 24, 3, 2, 1),
+    # wide 1x1 layers: ragged channel tiles, pixel counts that do not divide into the blocks' tiles, three images
+    (2, 256, 512, 64, 64, 1, 1, 0), (1, 96, 72, 40, 40, 1, 1, 0), (3, 64, 64, 40, 40, 1, 1, 0), (2, 192, 64, 32, 40, 1, 1, 0),
     # 2x2 stride 2 (the `downs`), same kernel family
     (2, 32, 64, 128, 128, 2, 2, 0), (1, 64, 128, 64, 64, 2, 2, 0), (1, 72, 80, 40, 80, 2, 2, 0), (2, 128, 256, 32, 32, 2, 2, 0)])
 def test_conv_wgrad(K, N, Cin, Cout, H, W, KH, st, pd):
@@ -239,6 +241,24 @@ def test_conv_wgrad_stride2_bias_and_per_image(K):
         w1 = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
         r1 = torch.autograd.grad(F.conv2d(x[n:n + 1], w1, stride=2, padding=1), w1, go[n:n + 1])[0]
         assert rel(gi[n].view_as(r1), r1) < 2e-5
+
+
+def test_conv_wgrad_wide_gate_bias_and_per_image(K):
+    """SimpleGate operand, fused bias gradient and per-image groups on the wide 1x1 weight-gradient kernel (conv3 / conv5 of a
+    NAFBlock, reference models/archs/network_nafnet_guided_arch.py:226-238)"""
+    N, C, H, W = 3, 96, 32, 40
+    t4 = rnd(N, 2 * C, H, W, seed=5); go = rnd(N, 80, H, W, seed=6)
+    g2 = t4[:, :C] * t4[:, C:]
+    ref = torch.einsum('nohw,nihw->noi', go, g2)
+    g = K.conv_wgrad(dev(t4), dev(go), 80, C, 1, gate=True, per_image=True, fp16_range=True)
+    assert rel(g.view(N, 80, C), ref) < 2e-5
+    gs, db = K.conv_wgrad(dev(t4), dev(go), 80, C, 1, gate=True, want_db=True, fp16_range=True)
+    assert rel(gs.view(80, C), ref.sum(0)) < 2e-5
+    assert rel(db, go.sum(dim=(0, 2, 3))) < 2e-5
+    x = rnd(N, C, H, W, seed=7)
+    g3, db3 = K.conv_wgrad(dev(x), dev(go), 80, C, 1, want_db=True, fp16_range=True)
+    assert rel(g3.view(80, C), torch.einsum('nohw,nihw->oi', go, x)) < 2e-5
+    assert rel(db3, go.sum(dim=(0, 2, 3))) < 2e-5
 
 
 def test_conv_wgrad_gate_and_per_image(K):
