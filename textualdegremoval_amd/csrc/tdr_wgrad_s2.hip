@@ -97,17 +97,17 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
     };
 
     // tiles in column-major order: t -> (tx, ty = output row)
-    auto tile_ty = [&](int t) { return t - (t / a.tiles_y) * a.tiles_y; };
 
     // ---- dout: item = (co row, 8-pixel chunk), threads 0..255
     const int dcol = (tid >> 2) & 63, dch = tid & 3;
     const bool dthread = tid < 256;
     float dsum = 0.f;
-    auto d_load = [&](int t, f32x4& v0, f32x4& v1) {
-        const int tx = t / a.tiles_y, oy = t - tx * a.tiles_y;
+    const bool d_rok = co0 + dcol < a.Cout;
+    const unsigned d_base = (unsigned)(((co0 + dcol) * (int)HWo + dch * 8) * 4);      // per-thread part of the dout offset
+    auto d_load = [&](int tx, int oy, f32x4& v0, f32x4& v1) {
         const int ox = tx * S2_C + dch * 8;
-        const bool rok = co0 + dcol < a.Cout;
-        const unsigned base = (unsigned)(((co0 + dcol) * (int)HWo + oy * a.OW + ox) * 4);
+        const bool rok = d_rok;
+        const unsigned base = d_base + (unsigned)((oy * a.OW + tx * S2_C) * 4);
         v0 = bload(rs_do, rok && ox < a.OW ? base : OOB);
         v1 = bload(rs_do, rok && ox + 4 < a.OW ? base + 16 : OOB);
     };
@@ -123,8 +123,7 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
 
     // ---- input: item = (ci row, input row r of the tile's three, 8-column chunk q of nine); chunk q holds input columns
     // 2 ox0 - 8 + 8 q .. + 7, i.e. plane elements e = o = -4 + 4 q .. + 3 (LDS idx 4 + 4 q ..)
-    auto i_load = [&](int t, bool steady, int it, f32x4& v0, f32x4& v1, int& ldsoff) {
-        const int tx = t / a.tiles_y, oy = t - tx * a.tiles_y;
+    auto i_load = [&](int tx, int oy, bool steady, int it, f32x4& v0, f32x4& v1, int& ldsoff) {
         const int lr0 = (KH == 3 && steady) ? 1 : 0;       // 3x3: row 2 oy - 1 of a steady tile is the previous tile's row 2 oy + 1
         const int per = (KH - lr0) * NCH;
         const int nitems = BN * per;
@@ -159,16 +158,69 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
         }
     };
 
+    // ---- steady tiles (every tile but the first of a block / of a column strip): which (channel, row, chunk) a thread stages does not
+    // change from tile to tile, only the row index does -- the item descriptors are computed once per column strip and a steady load is
+    // a handful of VALU (the generic path above re-derives everything per item: ~100 instructions, more than the split itself)
+    constexpr int LR0S = KH == 3 ? 1 : 0;
+    constexpr int PERS = (KH - LR0S) * NCH;                // items per channel of a steady tile (two new rows)
+    constexpr int NITS = (BN * PERS + NT - 1) / NT;
+    unsigned sd_gofs[NITS];
+    int sd_lds[NITS], sd_fl[NITS];                          // flags: 1 = first half inside, 2 = second half inside, 4 = live, 8 = second row
+    auto make_desc = [&](int tx) {
+#pragma unroll
+        for (int it = 0; it < NITS; ++it) {
+            const int id = tid + NT * it;
+            const bool live = id < BN * PERS;
+            const int idc = min(id, BN * PERS - 1);
+            const int cil = idc / PERS, rem = idc - cil * PERS;
+            const int r2 = rem / NCH, q = rem - r2 * NCH;
+            const int gx0 = 2 * tx * S2_C - (KH == 3 ? 8 : 0) + 8 * q;
+            const bool chok = ci0 + cil < a.Cin;
+            sd_gofs[it] = (unsigned)(((ci0 + cil) * (int)HWin + gx0) * 4);
+            sd_lds[it] = cil * S2_IP + (KH == 3 ? 4 : 8) + 4 * q;
+            sd_fl[it] = ((chok && gx0 >= 0 && gx0 < a.W) ? 1 : 0) | ((chok && gx0 + 4 >= 0 && gx0 + 4 < a.W) ? 2 : 0) | (live ? 4 : 0) | (r2 ? 8 : 0);
+        }
+    };
+    auto i_load_steady = [&](int oy, int it, f32x4& v0, f32x4& v1, int& ldsoff) {
+        if (NT * it >= BN * PERS) { ldsoff = 0; return; }
+        const int gyA = 2 * oy - PAD + LR0S;                // the two new rows gyA, gyA + 1 (>= 0 in a steady tile); uniform
+        const int slotA = (gyA + S2_SLOTS) % S2_SLOTS, slotB = (gyA + 1 + S2_SLOTS) % S2_SLOTS;
+        const unsigned rowA = (unsigned)(gyA * a.W * 4), rowB = rowA + (unsigned)(a.W * 4);
+        const bool okA = gyA < a.H, okB = gyA + 1 < a.H;
+        const int fl = sd_fl[it];
+        const bool second = (fl & 8) != 0;
+        const bool rok = second ? okB : okA;
+        const unsigned base = sd_gofs[it] + (second ? rowB : rowA);
+        v0 = bload(rs_in, (rok && (fl & 1)) ? base : OOB);
+        v1 = bload(rs_in, (rok && (fl & 2)) ? base + 16 : OOB);
+        ldsoff = (sd_lds[it] + (second ? slotB : slotA) * S2_RP) | ((fl & 4) ? 1 << 30 : 0);
+    };
+
     // prefetch registers of one tile
     f32x4 pd0 = z4, pd1 = z4, pi0[NITI], pi1[NITI];
     int pio[NITI];
-    auto prefetch = [&](int t, bool steady) {
+    auto prefetch = [&](int tx, int oy) {                  // steady <=> not the first tile of a column strip (callers stage the block's first tile by prefetch0)
 #if defined(S2_ABL) && S2_ABL == 3
         return;
 #endif
-        if (dthread) d_load(t, pd0, pd1);
+        if (dthread) d_load(tx, oy, pd0, pd1);
+        if (oy != 0) {
 #pragma unroll
-        for (int it = 0; it < NITI; ++it) i_load(t, steady, it, pi0[it], pi1[it], pio[it]);
+            for (int it = 0; it < NITI; ++it) {
+                if (it < NITS) i_load_steady(oy, it, pi0[it], pi1[it], pio[it]);
+                else pio[it] = 0;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NITI; ++it) i_load(tx, oy, false, it, pi0[it], pi1[it], pio[it]);
+            make_desc(tx);                                  // a new column strip: descriptors of its steady tiles
+        }
+    };
+    auto prefetch0 = [&](int tx, int oy) {                 // first tile of the block: all rows, wherever in the strip it is
+        if (dthread) d_load(tx, oy, pd0, pd1);
+#pragma unroll
+        for (int it = 0; it < NITI; ++it) i_load(tx, oy, false, it, pi0[it], pi1[it], pio[it]);
+        make_desc(tx);
     };
     auto commit = [&](int buf) {
 #if defined(S2_ABL) && S2_ABL == 2
@@ -188,11 +240,10 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
     auto mma = [](const s2u32x4& x, const s2u32x4& y, const f32x16& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s2f16x8, x), __builtin_bit_cast(s2f16x8, y), c, 0, 0, 0);
     };
-    auto mfma_tile = [&](int t, int buf) {
+    auto mfma_tile = [&](int oy, int buf) {
 #if defined(S2_ABL) && S2_ABL == 1
         return;
 #endif
-        const int oy = tile_ty(t);
         const int slot = (2 * oy - PAD + kyw + S2_SLOTS) % S2_SLOTS;
         const _Float16* sd = s_d + buf * DBUF + (wm * 32 + j) * S2_DP;
         const _Float16* si = s_i + (wn * 32 + j) * S2_IP + slot * S2_RP;
@@ -233,25 +284,31 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
     };
 
     if (t_begin < t_end) {
-        prefetch(t_begin, false);                          // first tile of the block: all three rows, synchronously
+        // (tx, ty) of tiles t, t + 1, t + 2, advanced incrementally (column-major order)
+        auto adv = [&](int& tx, int& ty) { if (++ty == a.tiles_y) { ty = 0; ++tx; } };
+        int tx0 = t_begin / a.tiles_y, ty0 = t_begin - tx0 * a.tiles_y;
+        int tx1 = tx0, ty1 = ty0; adv(tx1, ty1);
+        int tx2 = tx1, ty2 = ty1; adv(tx2, ty2);
+        prefetch0(tx0, ty0);                               // first tile of the block: all three rows, synchronously
         commit(0);
         __syncthreads();
-        if (t_begin + 1 < t_end) prefetch(t_begin + 1, tile_ty(t_begin + 1) != 0);
+        if (t_begin + 1 < t_end) prefetch(tx1, ty1);
         for (int t = t_begin; t < t_end; ++t) {
             const int b = (t - t_begin) & 1;
             const bool has_next = t + 1 < t_end;
-            const bool next_steady = has_next && tile_ty(t + 1) != 0;
+            const bool next_steady = has_next && ty1 != 0;
             if (next_steady) {
                 commit(b ^ 1);                             // rows 2 oy + 2, 2 oy + 3: not among the three rows tile t reads
-                if (t + 2 < t_end) prefetch(t + 2, tile_ty(t + 2) != 0);
+                if (t + 2 < t_end) prefetch(tx2, ty2);
             }
-            mfma_tile(t, b);
+            mfma_tile(ty0, b);
             __syncthreads();
             if (has_next && !next_steady) {                // first tile of a column: its rows alias the ring -- after the barrier
                 commit(b ^ 1);
                 __syncthreads();
-                if (t + 2 < t_end) prefetch(t + 2, tile_ty(t + 2) != 0);
+                if (t + 2 < t_end) prefetch(tx2, ty2);
             }
+            tx0 = tx1; ty0 = ty1; tx1 = tx2; ty1 = ty2; adv(tx2, ty2);
         }
     }
 
