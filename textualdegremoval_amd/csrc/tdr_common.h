@@ -70,8 +70,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact form for one and from the rounded one for the other, tdr_nafblock.hip).
 typedef float tdr_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 tdr_f16x2 __attribute__((ext_vector_type(2)));
+// PIN = false only for values that come straight from a load (nothing the compiler could fold into the conversion): the pin costs register copies
+template <bool PIN = true>
 __device__ __forceinline__ void tdr_split2_f16(float x0, float x1, unsigned& h, unsigned& m) {
-    asm volatile("" : "+v"(x0), "+v"(x1));
+    if constexpr (PIN) asm volatile("" : "+v"(x0), "+v"(x1));
     const tdr_f32x2 xv = {x0, x1};
     h = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, tdr_f16x2));
     const float neg1 = -1.0f;

@@ -54,7 +54,8 @@ constexpr int wb_max_nch(int KH, int P) {
                    : P / 8;
 }
 
-template <int SCH>
+// PIN: the operand is a product (gated input) -- see tdr_split2_f16
+template <int SCH, bool PIN = true>
 __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h, u32x4& m, u32x4& l) {
     if constexpr (SCH == WSCH_H1) {
         wf16x8 hv;
@@ -66,10 +67,10 @@ __device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& h
     } else if constexpr (SCH == WSCH_HX2) {
         // head and residual from the same fp32 value (gated operands are products): tdr_split2_f16 pins its inputs
         unsigned h0, h1, h2, h3, m0, m1, m2, m3;
-        tdr_split2_f16(a[0], a[1], h0, m0);
-        tdr_split2_f16(a[2], a[3], h1, m1);
-        tdr_split2_f16(b[0], b[1], h2, m2);
-        tdr_split2_f16(b[2], b[3], h3, m3);
+        tdr_split2_f16<PIN>(a[0], a[1], h0, m0);
+        tdr_split2_f16<PIN>(a[2], a[3], h1, m1);
+        tdr_split2_f16<PIN>(b[0], b[1], h2, m2);
+        tdr_split2_f16<PIN>(b[2], b[3], h3, m3);
         h = (u32x4){h0, h1, h2, h3};
         m = (u32x4){m0, m1, m2, m3};
         l = m;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         const int ldsoff = ldsoff_ & 0x3fffffff;
         dsum[it] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
         u32x4 h, m, l;
-        split8v<SCH>(v0, v1, h, m, l);
+        split8v<SCH, false>(v0, v1, h, m, l);          // dout: straight from the load
         u32x4* dst = reinterpret_cast<u32x4*>(s_d + ldsoff);
         dst[0] = h;
         if constexpr (NS >= 2) dst[(BMc * DPITCH) >> 3] = m;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bx3_kernel(WgArgs a) {
         const f32x4 v0 = (ldsoff_ >> 30) & 1 ? (GATE ? r0 * g0 : r0) : z4, v1 = ((unsigned)ldsoff_ >> 31) ? (GATE ? r1 * g1 : r1) : z4;
         const int ldsoff = ldsoff_ & 0x3fffffff;
         u32x4 h, m, l;
-        split8v<SCH>(v0, v1, h, m, l);
+        split8v<SCH, GATE>(v0, v1, h, m, l);           // gated input = a product: pinned
         u32x4* dst = reinterpret_cast<u32x4*>(s_i + ldsoff);
         dst[0] = h;
         if constexpr (NS >= 2) dst[(BNc * IPITCH) >> 3] = m;

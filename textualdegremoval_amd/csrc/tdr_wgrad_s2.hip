@@ -46,7 +46,7 @@ constexpr int S2_DP = 40;        // dout row pitch (elements): 5 x 16 bytes
 // x -> (h, m) pairs (tdr_common.h: tdr_split2_f16)
 template <bool H1>
 __device__ __forceinline__ void s2_split2(float x0, float x1, unsigned& h, unsigned& m) {
-    tdr_split2_f16(x0, x1, h, m);
+    tdr_split2_f16<false>(x0, x1, h, m);          // operands straight from buffer loads: no pin needed
     if constexpr (H1) m = h;
 }
 template <bool H1>
