@@ -196,7 +196,9 @@ typedef struct TdrWgradDesc {
     int math;          /* 0: exact fp32 MFMA; 1: 3-way bf16 split on the bf16 MFMA pipe where supported
                           (stride 1, 1x1 / 3x3), exact fp32 otherwise; 2: 2-way fp16 split (3 products) on the same
                           kernels -- both operands must lie in the fp16 range (activations; gradients of a loss-scaled
-                          backward pass, see tdr_l1_loss); 3: plain fp16 (one product), same range requirement, reduced precision */
+                          backward pass, see tdr_l1_loss); 3: plain fp16 (one product), same range requirement, reduced precision.
+                          With math >= 2 the stride-2 cases (3x3 pad 1, 2x2 pad 0, H = 2 OH, W = 2 OW) run on the split as well
+                          (csrc/tdr_wgrad_s2.hip) instead of falling through to the exact kernel */
 } TdrWgradDesc;
 int64_t tdr_wgrad_ws_floats(const TdrWgradDesc* d);
 int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream);
