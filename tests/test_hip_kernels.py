@@ -199,6 +199,35 @@ def test_conv_data_gradient(K, KH, st, pd, Cin, Cout, H, W):
     assert rel(db, go.sum(dim=(0, 2, 3))) < 2e-5
 
 
+# ------------------------------------------------------------------ multi-tensor weight packing
+def test_pack_multi_equals_single(K):
+    """the one-launch multi-tensor pack of a step (forward layout: one thread per lane of a fragment row, all taps, 16-byte loads) writes
+    the same bytes as the per-weight pack kernels, for every layout the engine asks for -- incl. ragged channel counts, Cin < 8 and a
+    weight that is a 4-byte-aligned view of a larger buffer"""
+    shapes = [(512, 256, 1), (64, 64, 3), (32, 3, 3), (24, 20, 3), (64, 32, 2), (40, 72, 1), (128, 128, 3), (3, 32, 3)]
+    ws = [dev(rnd(co, ci, kh, kh, seed=10 + i)) for i, (co, ci, kh) in enumerate(shapes)]
+    flat = dev(rnd(1 + 48 * 40 * 9, seed=99))
+    ws.append(flat[1:].view(48, 40, 3, 3))                         # data_ptr only 4-byte aligned
+    modes = {1: [K.PACK_FWD, K.PACK_DGRAD_S1], 3: [K.PACK_FWD, K.PACK_DGRAD_S1], 2: [K.PACK_FWD, K.PACK_DGRAD_2X2S2]}
+    singles = [(w, m, K.pack_weights(w, m)[0]) for w in ws for m in modes[w.shape[2]]]
+    plan = K.PackPlan()
+    prev = K.set_pack_plan(plan)
+    try:
+        for w, m, _ in singles:
+            K.pack_weights(w, m)                                   # records (and packs on the spot)
+        for e in plan.entries.values():
+            e[3].buf.fill_(float('nan'))
+        plan.invalidate()
+        plan.run()                                                 # the multi-tensor launch
+        torch.cuda.synchronize()
+        for w, m, ref in singles:
+            got = K.pack_weights(w, m)[0]
+            assert got.fmt == ref.fmt
+            assert torch.equal(got.buf.view(torch.int32), ref.buf.view(torch.int32)), (tuple(w.shape), m)
+    finally:
+        K.set_pack_plan(prev)
+
+
 # ------------------------------------------------------------------ wgrad
 @pytest.mark.parametrize('N,Cin,Cout,H,W,KH,st,pd', [
     (2, 128, 128, 32, 32, 1, 1, 0), (2, 32, 64, 64, 64, 1, 1, 0), (2, 32, 32, 48, 64, 1, 1, 0),

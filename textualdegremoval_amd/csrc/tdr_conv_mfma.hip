@@ -357,6 +357,12 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const TdrPackJob* __res
         reinterpret_cast<float*>(jb.wp)[i] = tdr_pack_f32_elem(jb.w, jb.Cin, jb.KH, jb.mode, jb.CK, jb.M, jb.Kch, jb.KHe, jb.Mx, i);
     else if (jb.fmt == 1)
         tdr_pack_bx3_frag(jb.w, jb.Cin, jb.KH, jb.mode, jb.M, jb.Kch, jb.KHe, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
+    else if (jb.mode == 0 && jb.KHe == 1)            // forward layout: one thread per (group, m-tile, lane), all taps (tdr_pack_job_init sizes `total`)
+        tdr_pack_hx2_fwd_alltaps<1>(jb.w, jb.Cin, jb.M, jb.Kch, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
+    else if (jb.mode == 0 && jb.KHe == 2)
+        tdr_pack_hx2_fwd_alltaps<4>(jb.w, jb.Cin, jb.M, jb.Kch, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
+    else if (jb.mode == 0 && jb.KHe == 3)
+        tdr_pack_hx2_fwd_alltaps<9>(jb.w, jb.Cin, jb.M, jb.Kch, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
     else
         tdr_pack_hx2_frag(jb.w, jb.Cin, jb.KH, jb.mode, jb.M, jb.Kch, jb.KHe, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
 }
@@ -380,6 +386,8 @@ extern "C" int tdr_pack_job_init(TdrPackJob* job, const float* w, int Cout, int 
         job->CK = 16;
         job->Mx = (M + 31) / 32;
         job->total = (long)((Kch + 15) / 16) * KHe * KHe * job->Mx * 64;
+        // hx2 forward layout: one thread makes the fragments of all taps (tdr_pack_hx2_fwd_alltaps)
+        if (fmt == 2 && mode == 0 && KHe >= 1 && KHe <= 3) job->total = (long)((Kch + 15) / 16) * job->Mx * 64;
     }
     job->first_block = 0;
     return TDR_OK;

@@ -88,3 +88,42 @@ __device__ __forceinline__ void tdr_pack_hx2_frag(const float* __restrict__ w, i
     o[0] = __builtin_bit_cast(uint4, h);
     o[64] = __builtin_bit_cast(uint4, mm);
 }
+
+// Forward-layout (mode 0) hx2 pack with ONE thread per (group, m-tile, lane) producing the fragments of ALL taps: the 8 channels x taps weights
+// a lane needs are contiguous in w[m][c][tap] (8 * taps floats), so they arrive as 16-byte loads of which every byte is used, where one thread
+// per (fragment, tap) gathers 8 scalars 4 * taps bytes apart -- 64 different cache lines per load instruction, the texture-address path being
+// the bound (pack_multi_kernel: 0.36 ms per step of the headline network at 0.6 TB/s).  Same bits as tdr_pack_hx2_frag.
+// i = (grp * MT + mt) * 64 + lane
+template <int TAPS>
+__device__ __forceinline__ void tdr_pack_hx2_fwd_alltaps(const float* __restrict__ w, int Cin, int M, int Kch, int MT, long i,
+                                                         uint4* __restrict__ wp) {
+    const int lane = (int)(i & 63);
+    const long r = i >> 6;
+    const int mt = (int)(r % MT);
+    const int grp = (int)(r / MT);
+    const int m = mt * 32 + (lane & 31);
+    const int c0 = grp * 16 + 8 * (lane >> 5);
+    float v[8 * TAPS];
+    const long base = ((long)m * Cin + c0) * TAPS;
+    if (m < M && c0 + 8 <= Kch && ((reinterpret_cast<uintptr_t>(w + base) & 15) == 0)) {
+#pragma unroll
+        for (int q = 0; q < 2 * TAPS; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(w + base + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) v[e * TAPS + t] = (m < M && c0 + e < Kch) ? w[base + e * TAPS + t] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        unsigned h[4], mm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tdr_split2_f16<false>(v[(2 * e) * TAPS + t], v[(2 * e + 1) * TAPS + t], h[e], mm[e]);
+        uint4* o = wp + ((((long)grp * TAPS + t) * MT + mt) * 2) * 64 + lane;
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[64] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+    }
+}
