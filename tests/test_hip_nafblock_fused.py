@@ -31,11 +31,19 @@ def block_params(c, seed):
     return P
 
 
+@pytest.fixture(params=['hx2', 'bx3'])
+def math_mode(request):
+    """both arithmetics of the fused chains: fp16 pair planes (hx2) and bf16 triple planes (bx3: 24-bit operands, fp32 range)"""
+    from textualdegremoval_amd import kernels as K
+    prev = K.MATH
+    K.set_math(request.param)
+    yield request.param
+    K.set_math(prev)
+
+
 @pytest.mark.parametrize('c,N,H,W', [(256, 2, 16, 16), (256, 1, 8, 24), (256, 4, 64, 64), (128, 2, 32, 32), (64, 1, 64, 32), (32, 2, 32, 64)])
-def test_fused_tail_matches_oracle_and_unfused(c, N, H, W):
+def test_fused_tail_matches_oracle_and_unfused(c, N, H, W, math_mode):
     from textualdegremoval_amd import engine as E, kernels as K
-    if K.MATH != 'hx2':
-        pytest.skip('fused blocks run on the fp16-split path')
     P = block_params(c, seed=11)
     Pc = {k: v.cuda() for k, v in P.items()}
     x = rnd(N, c, H, W, seed=5)
@@ -44,9 +52,9 @@ def test_fused_tail_matches_oracle_and_unfused(c, N, H, W):
     for fuse in (True, False):
         prev, E.FUSE_TAIL = E.FUSE_TAIL, fuse
         prev_head, E.FUSE_HEAD = E.FUSE_HEAD, fuse
-        # the fused backward chain runs on the fp16-split data-gradient weights of a loss-scaled backward pass
-        # (kernels.GRAD_SCALED); dout is O(1) here, i.e. already inside the fp16 window
-        prev_scaled = K.set_grad_scaled(True)
+        # hx2: the fused backward chain runs on the fp16-split data-gradient weights of a loss-scaled backward pass
+        # (kernels.GRAD_SCALED); dout is O(1) here, i.e. already inside the fp16 window.  bx3: unscaled, any range.
+        prev_scaled = K.set_grad_scaled(math_mode == 'hx2')
         try:
             out, saved = E.naf_fwd(x.cuda(), Pc)
             dout = rnd(N, c, H, W, seed=6).cuda()
@@ -81,11 +89,9 @@ def test_fused_tail_matches_oracle_and_unfused(c, N, H, W):
 
 
 @pytest.mark.parametrize('c,N,H,W', [(256, 2, 16, 16), (64, 1, 32, 32)])
-def test_fused_fusion_block_with_sliced_output(c, N, H, W):
+def test_fused_fusion_block_with_sliced_output(c, N, H, W, math_mode):
     """the last fusion block of a level keeps `[:, :chan]` of its output (reference :719,727): c_out = c / 2 rows of conv5"""
     from textualdegremoval_amd import engine as E, kernels as K
-    if K.MATH != 'hx2':
-        pytest.skip('fused blocks run on the fp16-split path')
     co = c // 2
     P = block_params(c, seed=21)
     Pc = {k: v.cuda() for k, v in P.items()}
@@ -95,7 +101,7 @@ def test_fused_fusion_block_with_sliced_output(c, N, H, W):
     for fuse in (True, False):
         prev, E.FUSE_TAIL = E.FUSE_TAIL, fuse
         prev_head, E.FUSE_HEAD = E.FUSE_HEAD, fuse
-        prev_scaled = K.set_grad_scaled(True)
+        prev_scaled = K.set_grad_scaled(math_mode == 'hx2')
         try:
             out, saved = E.naf_fwd(x.cuda(), Pc, c_out=co)
             dx, G = E.naf_bwd(dout.cuda(), Pc, saved)
@@ -119,3 +125,31 @@ def test_fused_fusion_block_with_sliced_output(c, N, H, W):
     for k in P:
         ref = Pr['b.' + k].grad
         assert (fG[k].view_as(ref) - ref).abs().max().item() < 2e-3 * max(ref.abs().max().item(), 1e-6), k
+
+
+@pytest.mark.parametrize('c,H,W', [(256, 16, 16), (64, 32, 32)])
+def test_fused_bx3_backward_keeps_fp32_range(c, H, W):
+    """TDR_MATH=bx3 is the reference-arithmetic path: unscaled gradients of the size a real step sees (dpred ~ 1e-7: far below the
+    fp16 window) go through the fused backward chain without a loss scale and agree with the oracle as well as O(1) gradients do"""
+    from textualdegremoval_amd import engine as E, kernels as K
+    prev = K.MATH
+    K.set_math('bx3')
+    try:
+        P = block_params(c, seed=31)
+        Pc = {k: v.cuda() for k, v in P.items()}
+        x = rnd(1, c, H, W, seed=9)
+        dout = rnd(1, c, H, W, seed=10) * 2.0 ** -24
+        assert K.naf_tail_supported(c, H * W) and not K.GRAD_SCALED
+        out, saved = E.naf_fwd(x.cuda(), Pc)
+        dx, G = E.naf_bwd(dout.cuda(), Pc, saved)
+        torch.cuda.synchronize()
+    finally:
+        K.set_math(prev)
+    Pr = {('b.' + k): v.clone().double().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().double().requires_grad_(True)
+    ro = O.naf_block(xr, Pr, 'b.')
+    ro.backward(dout.double())
+    assert (dx.cpu().double() - xr.grad).abs().max().item() < 2e-5 * xr.grad.abs().max().item()
+    for k in P:
+        ref = Pr['b.' + k].grad
+        assert (G[k].cpu().double().view_as(ref) - ref).abs().max().item() < 1e-4 * max(ref.abs().max().item(), 1e-30), k

@@ -80,3 +80,20 @@ __device__ __forceinline__ void tdr_split2_f16(float x0, float x1, unsigned& h, 
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(m) : "v"(h), "v"(neg1), "v"(x0));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(h), "v"(neg1), "v"(x1));
 }
+
+// 3-way bf16 split of two fp32 values: h = rn_bf16(x), m = rn_bf16(x - h), l = rn_bf16(x - h - m), packed pairwise (x0 in the low
+// half).  The same bits as the scalar split3 of tdr_conv_bx3.hip / tdr_pack.h (round-to-nearest-even conversions, exact fp32
+// subtractions): v_cvt_pk_bf16_f32 packs a plane, a shift / mask gives the plane back as fp32 -- 11 VALU per pair.  x = h + m + l
+// carries 24+ significant bits for any fp32 exponent (no fp16 window, no pre-scale).
+typedef __bf16 tdr_bf16x2 __attribute__((ext_vector_type(2)));
+template <bool PIN = true>
+__device__ __forceinline__ void tdr_split3_bf16(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    if constexpr (PIN) asm volatile("" : "+v"(x0), "+v"(x1));
+    const tdr_f32x2 xv = {x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, tdr_bf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const tdr_f32x2 rv = {r0, r1};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, tdr_bf16x2));
+    const tdr_f32x2 sv = {r0 - __builtin_bit_cast(float, m << 16), r1 - __builtin_bit_cast(float, m & 0xffff0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(sv, tdr_bf16x2));
+}

@@ -25,10 +25,29 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 nbf16x8 __attribute__((ext_vector_type(8)));
 union HFrag {
     uint4 u;
     f16x8 hv;
+    nbf16x8 bv;
 };
+
+// Operand split schemes of the fused chains (the same two as tdr_conv_bx3.hip, same packed weights):
+//   SCH_HX2  x = h + m, fp16 each, 3 products (mh hm hh)              -- operands inside the fp16 window (TDR_MATH=hx2)
+//   SCH_BX3  x = h + m + l, bf16 each, 6 products (lh hl mm mh hm hh) -- 24-bit operands, fp32 range, no loss scale (TDR_MATH=bx3)
+// The intermediates of a chain live in LDS as NS planes of 16-byte slots; with three planes the K = 2C operand of the backward
+// kernels (192 KiB at C = 256) is staged one K half at a time (KHALF).
+enum { SCH_BX3 = 0, SCH_HX2 = 1 };
+template <int SCH> struct SchT {
+    static constexpr int NS = SCH == SCH_BX3 ? 3 : 2;
+    static constexpr int NP = SCH == SCH_BX3 ? 6 : 3;
+};
+// two fp32 values -> their NS packed split planes (both planes of a value start from the same pinned fp32 value)
+template <int SCH>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&p)[SchT<SCH>::NS]) {
+    if constexpr (SCH == SCH_HX2) tdr_split2_f16(x0, x1, p[0], p[1]);
+    else tdr_split3_bf16(x0, x1, p[0], p[1], p[2]);
+}
 
 constexpr int NPX = 64;                       // pixels per workgroup
 __device__ __forceinline__ int swz(int slot) { return slot ^ ((slot >> 4) & 3); }
@@ -47,42 +66,48 @@ __device__ __forceinline__ void split_hm(float x, _Float16& h, _Float16& m) {
 // acc[tm][tn] += W[mt_of(tm)] (K = 16 * NG channels) x B(LDS planes).  PF groups of A fragments in flight.
 // side(g) is called once per 16-channel group, between the MFMAs: the caller's global stores of the PREVIOUS phase's
 // tiles ride there, a few per group, so the store stream drains under the matrix work instead of in front of it.
-template <int TMW, int NG, int PF, typename MtOf, typename Side>
-__device__ __forceinline__ void gemm_hx2(f32x16 (&acc)[TMW][2], const uint4* __restrict__ wp, int MT, MtOf mt_of, const uint4* sB,
-                                         int noct, int lane, int rot, Side side) {
+template <int SCH, int TMW, int NG, int PF, typename MtOf, typename Side>
+__device__ __forceinline__ void gemm_split(f32x16 (&acc)[TMW][2], const uint4* __restrict__ wp, int MT, MtOf mt_of, const uint4* sB,
+                                           int noct, int lane, int rot, Side side) {
+    constexpr int NS = SchT<SCH>::NS, NP = SchT<SCH>::NP;
     // rot: every workgroup walks the K groups from a different starting group.  All workgroups of the launch stream the
     // SAME weight fragments; started together they would ask the same few L2 lines at the same moment.
     static_assert((NG & (NG - 1)) == 0, "NG must be a power of two");
     const int j = lane & 31, kk = lane >> 5;
     const uint4* wl = wp + lane;
-    HFrag af[PF][TMW][2];
+    HFrag af[PF][TMW][NS];
     auto load_a = [&](int slot, int g) {
         const int gr = (g + rot) & (NG - 1);
 #pragma unroll
         for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) af[slot][tm][s].u = wl[((long)gr * MT + mt_of(tm)) * 128 + s * 64];
+            for (int s = 0; s < NS; ++s) af[slot][tm][s].u = wl[((long)gr * MT + mt_of(tm)) * (NS * 64) + s * 64];
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_a(p, p < NG ? p : NG - 1);
     const int b0 = swz(j), b1 = swz(32 + j);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        HFrag bf[2][2];
+        HFrag bf[2][NS];
         const uint4* sg = sB + (2 * ((g + rot) & (NG - 1)) + kk) * NPX;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
             bf[0][s].u = sg[s * noct * NPX + b0];
             bf[1][s].u = sg[s * noct * NPX + b1];
         }
-        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};       // m*h, h*m, h*h
+        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};                          // hx2: m*h, h*m, h*h
+        constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};        // bx3: lh hl mm mh hm hh (small cross terms first)
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
             for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g % PF][tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
+                for (int tn = 0; tn < 2; ++tn) {
+                    if constexpr (SCH == SCH_HX2)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g % PF][tm][HA[q]].hv, bf[tn][HB[q]].hv, acc[tm][tn], 0, 0, 0);
+                    else
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g % PF][tm][SA[q]].bv, bf[tn][SB[q]].bv, acc[tm][tn], 0, 0, 0);
+                }
         if (g + PF < NG) load_a(g % PF, g + PF);
         // pin the request here: left free, the scheduler sinks each fragment load to just in front of its use (to shorten live
         // ranges) and the loop degenerates into load -> s_waitcnt vmcnt(0) -> two MFMAs -> load ... (101 vmcnt(0) in naf_tail_bwd<256>).
@@ -94,18 +119,41 @@ __device__ __forceinline__ void gemm_hx2(f32x16 (&acc)[TMW][2], const uint4* __r
 }
 
 // fp32 values of one accumulator tile (channel rows of octet-halves) -> the two f16 planes of the LDS B operand
+template <int SCH>
 __device__ __forceinline__ void tile_to_planes(const float (&v)[16], uint4* sB, int noct, int oct0, int pix, int kk) {
     // rows r = 4q..4q+3 are elements 4kk..4kk+3 of octet oct0 + q
+    constexpr int NS = SchT<SCH>::NS;
     char* base = reinterpret_cast<char*>(sB);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        unsigned h0, h1, m0, m1;
-        tdr_split2_f16(v[4 * q], v[4 * q + 1], h0, m0);
-        tdr_split2_f16(v[4 * q + 2], v[4 * q + 3], h1, m1);
-        const uint2 h = make_uint2(h0, h1), m = make_uint2(m0, m1);
+        unsigned p0[NS], p1[NS];
+        split_pair<SCH>(v[4 * q], v[4 * q + 1], p0);
+        split_pair<SCH>(v[4 * q + 2], v[4 * q + 3], p1);
         const long slot = (long)(oct0 + q) * NPX + swz(pix);
-        *reinterpret_cast<uint2*>(base + slot * 16 + 8 * kk) = h;
-        *reinterpret_cast<uint2*>(base + ((long)noct * NPX + slot) * 16 + 8 * kk) = m;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            *reinterpret_cast<uint2*>(base + ((long)s * noct * NPX + slot) * 16 + 8 * kk) = make_uint2(p0[s], p1[s]);
+    }
+}
+
+// 8 channels x 4 adjacent pixels of fp32 (one float4 per channel, optionally times a per-channel scale) -> the NS planes of octet
+// `oct`, pixels 4q .. 4q + 3 of the LDS B operand
+template <int SCH, bool SCALE>
+__device__ __forceinline__ void stage_octet(const float4 (&v)[8], const float (&sc)[8], uint4* sB, int noct, int oct, int q) {
+    constexpr int NS = SchT<SCH>::NS;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+        unsigned pl[4][NS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float e0 = px == 0 ? v[2 * i].x : (px == 1 ? v[2 * i].y : (px == 2 ? v[2 * i].z : v[2 * i].w));
+            float e1 = px == 0 ? v[2 * i + 1].x : (px == 1 ? v[2 * i + 1].y : (px == 2 ? v[2 * i + 1].z : v[2 * i + 1].w));
+            if constexpr (SCALE) { e0 *= sc[2 * i]; e1 *= sc[2 * i + 1]; }
+            split_pair<SCH>(e0, e1, pl[i]);
+        }
+        const int slot = oct * NPX + swz(4 * q + px);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sB[s * noct * NPX + slot] = make_uint4(pl[0][s], pl[1][s], pl[2][s], pl[3][s]);
     }
 }
 
@@ -137,15 +185,16 @@ struct TailArgs {
 // 2C threads = C/32 waves (C = 256: 8 waves, two per SIMD): wave w owns the 32 channels [32w, 32w + 32) of the C-row GEMMs and, in conv4,
 // also their SimpleGate partners [C + 32w, C + 32w + 32).  While one wave of a SIMD waits on LDS / L2 / the store
 // queue its partner's MFMAs run.
-template <int C>
+template <int C, int SCH>
 __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     static_assert(C == 256 || C == 128 || C == 64 || C == 32, "C / 32 waves x 32 channel rows");
+    constexpr int NS = SchT<SCH>::NS;
     constexpr int NOCT = C / 8;               // octets of the K = C operands
     constexpr int NG = C / 16;
     constexpr int NW = C / 32;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-    uint4* sB = smem4;                                        // 2 planes x NOCT x 64 px x 16 B = 64 KiB
-    float* red = reinterpret_cast<float*>(smem4 + 2 * NOCT * NPX);   // [2][8 waves][64 px]
+    uint4* sB = smem4;                                        // NS planes x NOCT x 64 px x 16 B = 64 / 96 KiB at C = 256
+    float* red = reinterpret_cast<float*>(smem4 + NS * NOCT * NPX);   // [2][8 waves][64 px]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kk = lane >> 5;
@@ -178,18 +227,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
             v[i] = *reinterpret_cast<const float4*>(gp + (long)(8 * oct + i) * HW);
             sc[i] = sp[8 * oct + i];
         }
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            HFrag h, m;
-            unsigned hd[4], md[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tdr_split2_f16((px == 0 ? v[2 * i].x : (px == 1 ? v[2 * i].y : (px == 2 ? v[2 * i].z : v[2 * i].w))) * sc[2 * i], (px == 0 ? v[2 * i + 1].x : (px == 1 ? v[2 * i + 1].y : (px == 2 ? v[2 * i + 1].z : v[2 * i + 1].w))) * sc[2 * i + 1], hd[i], md[i]);
-            h.u = make_uint4(hd[0], hd[1], hd[2], hd[3]);
-            m.u = make_uint4(md[0], md[1], md[2], md[3]);
-            const int slot = oct * NPX + swz(4 * q + px);
-            sB[slot] = h.u;
-            sB[NOCT * NPX + slot] = m.u;
-        }
+        stage_octet<SCH, true>(v, sc, sB, NOCT, oct, q);
     }
     // per-row vectors of this lane's 16 channel rows
     float b3v[16], bev[16];
@@ -206,7 +244,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-    gemm_hx2<1, NG, 2>(acc, a.w3, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [](int) {});
+    gemm_split<SCH, 1, NG, 2>(acc, a.w3, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [](int) {});
 
     float yv[2][16];
     float psum[2] = {0.f, 0.f};
@@ -268,7 +306,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         for (int tn = 0; tn < 2; ++tn) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ynv[tn][r] = (yv[tn][r] - mean[tn]) * rstd[tn] * lw[r] + lb[r];
-            tile_to_planes(ynv[tn], sB, NOCT, 4 * wave, 32 * tn + j, kk);
+            tile_to_planes<SCH>(ynv[tn], sB, NOCT, 4 * wave, 32 * tn + j, kk);
         }
     }
     __syncthreads();
@@ -284,7 +322,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     {
         float* yp = a.y + (long)n * a.y_ns + p0 + j;
         float* ynp = a.yn + (long)n * a.yn_ns + p0 + j;
-        gemm_hx2<2, NG, 2>(acc4, a.w4, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
+        gemm_split<SCH, 2, NG, 2>(acc4, a.w4, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
             // 64 dword stores (y, yn: 2 sub-tiles x 16 rows each) spread evenly over the NG groups
             constexpr int IPG = 32 / NG;
 #pragma unroll
@@ -312,7 +350,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc4[0][tn][r] * acc4[1][tn][r];      // SimpleGate (:170-175)
-        tile_to_planes(v, sB, NOCT, 4 * wave, 32 * tn + j, kk);
+        tile_to_planes<SCH>(v, sB, NOCT, 4 * wave, 32 * tn + j, kk);
     }
     float b5v[16], gav[16];
 #pragma unroll
@@ -330,7 +368,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-        gemm_hx2<1, NG, 2>(acc, a.w5, a.c_out / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
+        gemm_split<SCH, 1, NG, 2>(acc, a.w5, a.c_out / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
             constexpr int IPG = 64 / NG;                                         // 64 stores spread evenly over the NG groups
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -371,12 +409,12 @@ struct HeadFwdArgs {
     int HW;
 };
 
-template <int C>
+template <int C, int SCH>
 __global__ __launch_bounds__(2 * C, 2) void naf_head_fwd_kernel(HeadFwdArgs a) {
-    constexpr int NOCT = C / 8, NG = C / 16, NW = C / 32;
+    constexpr int NOCT = C / 8, NG = C / 16, NW = C / 32, NS = SchT<SCH>::NS;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     uint4* sB = smem4;
-    float* red = reinterpret_cast<float*>(smem4 + 2 * NOCT * NPX);   // [2][NW][64 px]
+    float* red = reinterpret_cast<float*>(smem4 + NS * NOCT * NPX);   // [2][NW][64 px]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kk = lane >> 5;
     const int n = blockIdx.y;
@@ -442,7 +480,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_head_fwd_kernel(HeadFwdArgs a) {
         for (int tn = 0; tn < 2; ++tn) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) xnv[tn][r] = (xv[tn][r] - mean[tn]) * rstd[tn] * lw[r] + lb[r];
-            tile_to_planes(xnv[tn], sB, NOCT, 4 * wave, 32 * tn + j, kk);
+            tile_to_planes<SCH>(xnv[tn], sB, NOCT, 4 * wave, 32 * tn + j, kk);
         }
     }
     __syncthreads();
@@ -457,7 +495,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_head_fwd_kernel(HeadFwdArgs a) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
     {
         float* xnp = a.xn + (long)n * a.xn_ns + p0 + j;
-        gemm_hx2<2, NG, 2>(acc, a.w1, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
+        gemm_split<SCH, 2, NG, 2>(acc, a.w1, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
             constexpr int IPG = 32 / NG;
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -516,13 +554,17 @@ __device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 l
 // HEAD = true is the first half of the block instead (:216-225 backward): dxn = W1^T dt1 (conv1 data gradient, K = 2C,
 // `dout` = dt1 [N, 2C, HW], `w4t` = conv1's DGRAD_S1 fragments) followed by norm1's backward + the y-branch gradient in
 // `res`: the same K = 2C GEMM + LayerNorm epilogue without the conv5 / SimpleGate front.
-template <int C, bool HEAD>
+template <int C, bool HEAD, int SCH>
 __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     static_assert(C == 256 || C == 128 || C == 64 || C == 32, "C / 32 waves x 32 channel rows");
     constexpr int NW = C / 32;
+    constexpr int NS = SchT<SCH>::NS;
+    // three planes: the K = 2C operand (conv4 / conv1 data gradient) goes through LDS one K half (C channels) at a time
+    constexpr bool KHALF = SCH == SCH_BX3;
+    constexpr int KOCT = KHALF ? C / 8 : 2 * C / 8;           // octets of the largest operand resident at once
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-    uint4* sB = smem4;                                        // up to 2 planes x (2C/8) octets x 64 px x 16 B = 128 KiB
-    float* red = reinterpret_cast<float*>(smem4 + 2 * (2 * C / 8) * NPX);   // [2][8 waves][64 px]
+    uint4* sB = smem4;                                        // NS planes x KOCT octets x 64 px x 16 B: 128 KiB (hx2) / 96 KiB (bx3) at C = 256
+    float* red = reinterpret_cast<float*>(smem4 + NS * KOCT * NPX);   // [2][8 waves][64 px]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kk = lane >> 5;
@@ -532,9 +574,11 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     const int m0 = 32 * wave;
     const int rot = (int)(blockIdx.x * 5);   // (not a function of the image index: batch-permutation equivariance stays bit-exact)
     auto off = [&](int r, int tn) { return (long)(m0 + row_of(r, kk)) * HW + 32 * tn; };
+    const float one8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 
     f32x16 acc[1][2];
     float da[HEAD ? 1 : 2][16], db[HEAD ? 1 : 2][16];
+    float4 vh[(HEAD && KHALF) ? 8 : 1];                       // HEAD + KHALF: the second K half of dt1, requested before the first GEMM
     if constexpr (HEAD) {
         // ---- stage B = dt1 (K = 2C): thread (oct, q) owns pixels 4q..4q+3 of octets oct and oct + C/8
         const int q = tid & 15, oct0 = tid >> 4;
@@ -545,17 +589,14 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
             float4 v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(gp + (long)(8 * oct + i) * HW);
+            if constexpr (KHALF) {
+                if (pass == 0) stage_octet<SCH, false>(v, one8, sB, KOCT, oct0, q);
+                else {
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                HFrag h, m;
-                unsigned hd[4], md[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) tdr_split2_f16(px == 0 ? v[2 * i].x : (px == 1 ? v[2 * i].y : (px == 2 ? v[2 * i].z : v[2 * i].w)), px == 0 ? v[2 * i + 1].x : (px == 1 ? v[2 * i + 1].y : (px == 2 ? v[2 * i + 1].z : v[2 * i + 1].w)), hd[i], md[i]);
-                h.u = make_uint4(hd[0], hd[1], hd[2], hd[3]);
-                m.u = make_uint4(md[0], md[1], md[2], md[3]);
-                const int slot = oct * NPX + swz(4 * q + px);
-                sB[slot] = h.u;
-                sB[(2 * C / 8) * NPX + slot] = m.u;
+                    for (int i = 0; i < 8; ++i) vh[i] = v[i];
+                }
+            } else {
+                stage_octet<SCH, false>(v, one8, sB, KOCT, oct, q);
             }
         }
     } else {
@@ -583,18 +624,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
             v[i] = *reinterpret_cast<const float4*>(gp + (long)(8 * oct + i) * HW);
             sc[i] = a.gamma[8 * oct + i];
         }
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            HFrag h, m;
-            unsigned hd[4], md[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tdr_split2_f16((px == 0 ? v[2 * i].x : (px == 1 ? v[2 * i].y : (px == 2 ? v[2 * i].z : v[2 * i].w))) * sc[2 * i], (px == 0 ? v[2 * i + 1].x : (px == 1 ? v[2 * i + 1].y : (px == 2 ? v[2 * i + 1].z : v[2 * i + 1].w))) * sc[2 * i + 1], hd[i], md[i]);
-            h.u = make_uint4(hd[0], hd[1], hd[2], hd[3]);
-            m.u = make_uint4(md[0], md[1], md[2], md[3]);
-            const int slot = oct * NPX + swz(4 * q + px);
-            sB[slot] = h.u;
-            sB[NOCT * NPX + slot] = m.u;
-        }
+        stage_octet<SCH, true>(v, sc, sB, NOCT, oct, q);
     }
     __syncthreads();
 
@@ -603,8 +633,8 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-    if (a.c_out == C) gemm_hx2<1, C / 16, 2>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [](int) {});
-    else gemm_hx2<1, C / 32, 2>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 16, lane, rot, [](int) {});
+    if (a.c_out == C) gemm_split<SCH, 1, C / 16, 2>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [](int) {});
+    else gemm_split<SCH, 1, C / 32, 2>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 16, lane, rot, [](int) {});
     __syncthreads();                                          // every wave is done with the dout planes
 
     // ---- SimpleGate backward; dt4 rows c -> octets [4w, 4w+4), rows C + c -> octets [C/8 + 4w, ...) of the K = 2C operand
@@ -615,14 +645,15 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
             da[tn][r] = acc[0][tn][r] * tb[tn][r];
             db[tn][r] = acc[0][tn][r] * ta[tn][r];
         }
-        tile_to_planes(da[tn], sB, 2 * C / 8, 4 * wave, 32 * tn + j, kk);
-        tile_to_planes(db[tn], sB, 2 * C / 8, C / 8 + 4 * wave, 32 * tn + j, kk);
+        tile_to_planes<SCH>(da[tn], sB, KOCT, 4 * wave, 32 * tn + j, kk);
+        if constexpr (!KHALF) tile_to_planes<SCH>(db[tn], sB, KOCT, C / 8 + 4 * wave, 32 * tn + j, kk);
     }
     }   // !HEAD
-    // LayerNorm operands of this wave's rows
+    // LayerNorm operands of this wave's rows (requested ahead of the GEMM that produces their partner; with three planes and the
+    // gate tiles still live that is 48 registers too many -- 406 spilled -- so there they are requested between the two K halves)
     float yh[2][16], lw[16];
     float mean_[2], rstd_[2];
-    {
+    auto load_ln_operands = [&]() {
         const float* yp = a.y + (long)n * a.y_ns + p0 + j;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
@@ -633,7 +664,9 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) lw[r] = a.lnw[m0 + row_of(r, kk)];
-    }
+    };
+    constexpr bool LN_LATE = KHALF && !HEAD;
+    if constexpr (!LN_LATE) load_ln_operands();
     __syncthreads();
 
     // ---- conv4 data gradient: dyn rows [32w, 32w + 32), K = 2C ; the dt4 tile leaves for HBM under its MFMAs
@@ -641,11 +674,51 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
-    if constexpr (HEAD) {
-        gemm_hx2<1, 2 * C / 16, 2>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [](int) {});
+    if constexpr (KHALF) {
+        // K half 0 (channels [0, C)) sits in LDS; then the planes are overwritten with K half 1 (channels [C, 2C)) and the
+        // accumulation continues with the second half of the packed fragments ([group][m-tile][plane][lane]: group C/16 onwards)
+        const uint4* w_hi = a.w4t + (long)(C / 16) * (C / 32) * (NS * 64);
+        if constexpr (HEAD) {
+            gemm_split<SCH, 1, C / 16, 2>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, KOCT, lane, rot, [](int) {});
+            __syncthreads();
+            stage_octet<SCH, false>(vh, one8, sB, KOCT, tid >> 4, tid & 15);
+            __syncthreads();
+            gemm_split<SCH, 1, C / 16, 2>(acc, w_hi, C / 32, [&](int) { return wave; }, sB, KOCT, lane, rot, [](int) {});
+        } else {
+            // a real two-trip loop (one body, `da` holds the tile of the current half): unrolled, the register allocator kept the
+            // LDS / fragment addresses of the first half alive for the second and spilled 350 registers at C = 256
+            float* dp = a.dt4 + (long)n * a.dt4_ns + p0 + j;
+            const uint4* wk = a.w4t;
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                if (half) {
+                    __syncthreads();
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) tile_to_planes<SCH>(da[tn], sB, KOCT, 4 * wave, 32 * tn + j, kk);
+                    load_ln_operands();
+                    __syncthreads();
+                }
+                gemm_split<SCH, 1, C / 16, 2>(acc, wk, C / 32, [&](int) { return wave; }, sB, KOCT, lane, rot, [&](int g) {
+                    constexpr int IPG = 32 / (C / 16);             // the 32 dword stores of this half's tile spread evenly over the groups
+#pragma unroll
+                    for (int e = 0; e < IPG; ++e) {
+                        const int idx = g * IPG + e, tn = idx >> 4, r = idx & 15;
+                        dp[off(r, tn)] = da[tn][r];
+                    }
+                });
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) da[tn][r] = db[tn][r];
+                dp += (long)C * HW;
+                wk = w_hi;
+            }
+        }
+    } else if constexpr (HEAD) {
+        gemm_split<SCH, 1, 2 * C / 16, 2>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [](int) {});
     } else {
         float* dp = a.dt4 + (long)n * a.dt4_ns + p0 + j;
-        gemm_hx2<1, 2 * C / 16, 2>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [&](int g) {
+        gemm_split<SCH, 1, 2 * C / 16, 2>(acc, a.w4t, C / 32, [&](int) { return wave; }, sB, 2 * C / 8, lane, rot, [&](int g) {
             constexpr int IPG = 32 / (2 * C / 16);             // 64 dword stores spread evenly over the groups
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -730,7 +803,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = gv[tn][r] * be[r];
-                tile_to_planes(v, sB, C / 8, 4 * wave, 32 * tn + j, kk);
+                tile_to_planes<SCH>(v, sB, C / 8, 4 * wave, 32 * tn + j, kk);
             }
             __syncthreads();
 #pragma unroll
@@ -738,7 +811,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
             float* dyp = a.dy + (long)n * a.dy_ns + p0 + j;
-            gemm_hx2<1, C / 16, 2>(acc, a.w3t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [&](int g) {
+            gemm_split<SCH, 1, C / 16, 2>(acc, a.w3t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [&](int g) {
                 constexpr int IPG = 32 / (C / 16);
 #pragma unroll
                 for (int e = 0; e < IPG; ++e) {
@@ -773,12 +846,29 @@ extern "C" int tdr_naf_tail_supported(int C, int HW) { return ((C == 256 || C ==
         hipLaunchKernelGGL(kern, dim3((d_)->HW / NPX, (d_)->N), dim3(2 * C_), lds_, (hipStream_t)stream_, a_);                    \
     } while (0)
 
+// channel count x split scheme (`bx` in scope: the weight packs are the 3-way bf16 split); MID: template arguments between C and SCH
+#define NAF_COMMA ,
+#define NAF_DISPATCH_CS(KERN, MID, lds_, a_, d_, stream_)                                                            \
+    do {                                                                                                             \
+        if (bx) {                                                                                                    \
+            if ((d_)->C == 256) NAF_DISPATCH_C(256, (KERN<256 MID, SCH_BX3>), lds_, a_, d_, stream_);                \
+            else if ((d_)->C == 128) NAF_DISPATCH_C(128, (KERN<128 MID, SCH_BX3>), lds_, a_, d_, stream_);           \
+            else if ((d_)->C == 64) NAF_DISPATCH_C(64, (KERN<64 MID, SCH_BX3>), lds_, a_, d_, stream_);              \
+            else NAF_DISPATCH_C(32, (KERN<32 MID, SCH_BX3>), lds_, a_, d_, stream_);                                 \
+        } else {                                                                                                     \
+            if ((d_)->C == 256) NAF_DISPATCH_C(256, (KERN<256 MID, SCH_HX2>), lds_, a_, d_, stream_);                \
+            else if ((d_)->C == 128) NAF_DISPATCH_C(128, (KERN<128 MID, SCH_HX2>), lds_, a_, d_, stream_);           \
+            else if ((d_)->C == 64) NAF_DISPATCH_C(64, (KERN<64 MID, SCH_HX2>), lds_, a_, d_, stream_);              \
+            else NAF_DISPATCH_C(32, (KERN<32 MID, SCH_HX2>), lds_, a_, d_, stream_);                                 \
+        }                                                                                                            \
+    } while (0)
+
 extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
     TDR_REQUIRE(d && d->g && d->sca && d->x && d->w3 && d->w4 && d->w5 && d->b3 && d->beta && d->lnw && d->lnb && d->b4 && d->b5 &&
                     d->gamma && d->y && d->mu && d->rs && d->yn && d->t4 && d->out,
                 "tdr_naf_tail_fwd: null pointer");
     TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_fwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
-    TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_tail_fwd: weights must be packed with tdr_pack_weights_hx2 (mode FWD)");
+    TDR_REQUIRE(d->w_fmt == 2 || d->w_fmt == 1, "tdr_naf_tail_fwd: weights must be packed with tdr_pack_weights_hx2 / _bx3 (mode FWD)");
     TDR_REQUIRE(d->HW % 4 == 0 && d->g_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->g) & 15) == 0, "tdr_naf_tail_fwd: g must be 16-byte aligned");
     TailArgs a;
     a.g = d->g; a.g_ns = d->g_ns; a.sca = d->sca; a.x = d->x; a.x_ns = d->x_ns;
@@ -789,11 +879,9 @@ extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
     a.out = d->out; a.out_ns = d->out_ns; a.HW = d->HW;
     a.c_out = d->c_out > 0 ? d->c_out : d->C;
     TDR_REQUIRE(a.c_out == d->C || (a.c_out * 2 == d->C && a.c_out % 32 == 0), "tdr_naf_tail_fwd: c_out must be C or C / 2 (a multiple of 32)");
-    const size_t lds = (size_t)2 * (d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
-    if (d->C == 256) NAF_DISPATCH_C(256, naf_tail_fwd_kernel<256>, lds, a, d, stream);
-    else if (d->C == 128) NAF_DISPATCH_C(128, naf_tail_fwd_kernel<128>, lds, a, d, stream);
-    else if (d->C == 64) NAF_DISPATCH_C(64, naf_tail_fwd_kernel<64>, lds, a, d, stream);
-    else NAF_DISPATCH_C(32, naf_tail_fwd_kernel<32>, lds, a, d, stream);
+    const bool bx = d->w_fmt == 1;
+    const size_t lds = (size_t)(bx ? 3 : 2) * (d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    NAF_DISPATCH_CS(naf_tail_fwd_kernel, , lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_tail_fwd_kernel");
     return TDR_OK;
 }
@@ -801,16 +889,14 @@ extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
 extern "C" int tdr_naf_head_fwd(const TdrNafHeadFwdDesc* d, void* stream) {
     TDR_REQUIRE(d && d->x && d->lnw && d->lnb && d->w1 && d->b1 && d->mu && d->rs && d->xn && d->t1, "tdr_naf_head_fwd: null pointer");
     TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_head_fwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
-    TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_head_fwd: weights must be packed with tdr_pack_weights_hx2 (mode FWD)");
+    TDR_REQUIRE(d->w_fmt == 2 || d->w_fmt == 1, "tdr_naf_head_fwd: weights must be packed with tdr_pack_weights_hx2 / _bx3 (mode FWD)");
     HeadFwdArgs a;
     a.x = d->x; a.x_ns = d->x_ns; a.lnw = d->lnw; a.lnb = d->lnb; a.eps = d->eps;
     a.w1 = reinterpret_cast<const uint4*>(d->w1); a.b1 = d->b1;
     a.mu = d->mu; a.rs = d->rs; a.xn = d->xn; a.xn_ns = d->xn_ns; a.t1 = d->t1; a.t1_ns = d->t1_ns; a.HW = d->HW;
-    const size_t lds = (size_t)2 * (d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
-    if (d->C == 256) NAF_DISPATCH_C(256, naf_head_fwd_kernel<256>, lds, a, d, stream);
-    else if (d->C == 128) NAF_DISPATCH_C(128, naf_head_fwd_kernel<128>, lds, a, d, stream);
-    else if (d->C == 64) NAF_DISPATCH_C(64, naf_head_fwd_kernel<64>, lds, a, d, stream);
-    else NAF_DISPATCH_C(32, naf_head_fwd_kernel<32>, lds, a, d, stream);
+    const bool bx = d->w_fmt == 1;
+    const size_t lds = (size_t)(bx ? 3 : 2) * (d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    NAF_DISPATCH_CS(naf_head_fwd_kernel, , lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_head_fwd_kernel");
     return TDR_OK;
 }
@@ -825,7 +911,7 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
                 "tdr_naf_tail_bwd: null pointer");
     TDR_REQUIRE((d->gw != nullptr) == (d->gb != nullptr), "tdr_naf_tail_bwd: gw and gb are given together or not at all");
     TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_tail_bwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
-    TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_tail_bwd: weights must be packed with tdr_pack_weights_hx2 (mode DGRAD_S1)");
+    TDR_REQUIRE(d->w_fmt == 2 || d->w_fmt == 1, "tdr_naf_tail_bwd: weights must be packed with tdr_pack_weights_hx2 / _bx3 (mode DGRAD_S1)");
     TDR_REQUIRE(d->dout_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->dout) & 15) == 0, "tdr_naf_tail_bwd: dout must be 16-byte aligned");
     TailBwdArgs a;
     a.dout = d->dout; a.dout_ns = d->dout_ns; a.gamma = d->gamma; a.t4 = d->t4; a.t4_ns = d->t4_ns; a.y = d->y; a.y_ns = d->y_ns;
@@ -837,11 +923,9 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
     TDR_REQUIRE(a.c_out == d->C || (a.c_out * 2 == d->C && a.c_out % 32 == 0), "tdr_naf_tail_bwd: c_out must be C or C / 2 (a multiple of 32)");
     a.w3t = reinterpret_cast<const uint4*>(d->w3t); a.beta = d->beta; a.sca = d->sca; a.dgp = d->dgp; a.dgp_ns = d->dgp_ns;
     TDR_REQUIRE(!d->w3t || (d->beta && d->sca && d->dgp), "tdr_naf_tail_bwd: the conv3 stage needs beta, sca and dgp");
-    const size_t lds = (size_t)2 * (2 * d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
-    if (d->C == 256) NAF_DISPATCH_C(256, (naf_tail_bwd_kernel<256, false>), lds, a, d, stream);
-    else if (d->C == 128) NAF_DISPATCH_C(128, (naf_tail_bwd_kernel<128, false>), lds, a, d, stream);
-    else if (d->C == 64) NAF_DISPATCH_C(64, (naf_tail_bwd_kernel<64, false>), lds, a, d, stream);
-    else NAF_DISPATCH_C(32, (naf_tail_bwd_kernel<32, false>), lds, a, d, stream);
+    const bool bx = d->w_fmt == 1;       // three planes: one K half (C / 8 octets) resident at a time
+    const size_t lds = (size_t)(bx ? 3 * (d->C / 8) : 2 * (2 * d->C / 8)) * NPX * 16 + 16 * NPX * sizeof(float);
+    NAF_DISPATCH_CS(naf_tail_bwd_kernel, NAF_COMMA false, lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_tail_bwd_kernel");
     if (!d->gw) return TDR_OK;            // the caller finishes the LayerNorm parameter gradients itself (tdr_pair_sum_partials on ws)
     return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, d->ws + (long)d->N * (d->HW / NPX) * 2 * d->C, stream);
@@ -851,7 +935,7 @@ extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
     TDR_REQUIRE(d && d->dt1 && d->x && d->mu && d->rs && d->lnw && d->w1t && d->res && d->dx && d->ws, "tdr_naf_head_bwd: null pointer");
     TDR_REQUIRE((d->gw != nullptr) == (d->gb != nullptr), "tdr_naf_head_bwd: gw and gb are given together or not at all");
     TDR_REQUIRE(tdr_naf_tail_supported(d->C, d->HW), "tdr_naf_head_bwd: needs C in {32, 64, 128, 256} and HW %% 64 == 0 (got C=%d HW=%d)", d->C, d->HW);
-    TDR_REQUIRE(d->w_fmt == 2, "tdr_naf_head_bwd: weights must be packed with tdr_pack_weights_hx2 (mode DGRAD_S1)");
+    TDR_REQUIRE(d->w_fmt == 2 || d->w_fmt == 1, "tdr_naf_head_bwd: weights must be packed with tdr_pack_weights_hx2 / _bx3 (mode DGRAD_S1)");
     TDR_REQUIRE(d->dt1_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(d->dt1) & 15) == 0, "tdr_naf_head_bwd: dt1 must be 16-byte aligned");
     TailBwdArgs a;
     a.dout = d->dt1; a.dout_ns = d->dt1_ns; a.gamma = nullptr; a.t4 = nullptr; a.t4_ns = 0; a.y = d->x; a.y_ns = d->x_ns;
@@ -860,11 +944,9 @@ extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
     a.dt4 = nullptr; a.dt4_ns = 0; a.res = d->res; a.res_ns = d->res_ns; a.dy = d->dx; a.dy_ns = d->dx_ns; a.part = d->ws; a.HW = d->HW;
     a.c_out = d->C;
     a.w3t = nullptr; a.beta = nullptr; a.sca = nullptr; a.dgp = nullptr; a.dgp_ns = 0;
-    const size_t lds = (size_t)2 * (2 * d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
-    if (d->C == 256) NAF_DISPATCH_C(256, (naf_tail_bwd_kernel<256, true>), lds, a, d, stream);
-    else if (d->C == 128) NAF_DISPATCH_C(128, (naf_tail_bwd_kernel<128, true>), lds, a, d, stream);
-    else if (d->C == 64) NAF_DISPATCH_C(64, (naf_tail_bwd_kernel<64, true>), lds, a, d, stream);
-    else NAF_DISPATCH_C(32, (naf_tail_bwd_kernel<32, true>), lds, a, d, stream);
+    const bool bx = d->w_fmt == 1;
+    const size_t lds = (size_t)(bx ? 3 * (d->C / 8) : 2 * (2 * d->C / 8)) * NPX * 16 + 16 * NPX * sizeof(float);
+    NAF_DISPATCH_CS(naf_tail_bwd_kernel, NAF_COMMA true, lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_head_bwd_kernel");
     if (!d->gw) return TDR_OK;
     return tdr_pair_sum_partials(d->ws, d->N * (d->HW / NPX), d->C, d->gw, d->gb, d->ws + (long)d->N * (d->HW / NPX) * 2 * d->C, stream);

@@ -125,7 +125,7 @@ def naf_fwd(x, P, c_out=None):
     N, c, H, W = x.shape
     c_out = c if c_out is None else c_out
     wp, mp, *_ = K.pack_weights(P['conv1.weight'], PACK_FWD)
-    if FUSE_HEAD and K.naf_tail_supported(c, H * W) and wp.fmt == K.FMT_HX2:
+    if FUSE_HEAD and K.naf_tail_supported(c, H * W) and wp.fmt in (K.FMT_HX2, K.FMT_BX3):
         # norm1 -> conv1 in one launch (the workgroup that owns 64 pixels x all channels reduces the statistics itself)
         xn, mu1, rs1, t1 = K.naf_head_fwd(x, P['norm1.weight'], P['norm1.bias'], LN_EPS, wp, P['conv1.bias'])
     else:
@@ -157,6 +157,12 @@ def _dgrad_is_hx2():
     return K.MATH == 'hx2' and K.GRAD_SCALED
 
 
+def _dgrad_fused_ok():
+    """the fused backward chains take the fp16-pair packs of a loss-scaled hx2 backward or the bf16-triple packs of TDR_MATH=bx3
+    (unscaled gradients, fp32 range); an hx2 backward outside a scaled step and the other modes run the per-op launches"""
+    return _dgrad_is_hx2() or K.MATH == 'bx3'
+
+
 def naf_bwd(dout, P, saved):
     x, xn, mu1, rs1, t1, g, pooled, s, y, yn, mu2, rs2, t4, c_out = saved
     N, c, H, W = x.shape
@@ -182,7 +188,7 @@ def naf_bwd(dout, P, saved):
         return g
     _leaf((t4, dout), leaf5, G)
     fused = FUSE_TAIL and K.naf_tail_supported(c, H * W, c_out) and dout.is_contiguous() and \
-        _dgrad_is_hx2()
+        _dgrad_fused_ok()
     if fused:
         # conv5 dgrad -> SimpleGate bwd -> conv4 dgrad -> norm2 bwd (+ skip) in one launch
         w5t, w4t = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)[0], K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)[0]
@@ -233,7 +239,7 @@ def naf_bwd(dout, P, saved):
         g1, b1 = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)
         return {'conv1.weight': g1.view(2 * c, c, 1, 1), 'conv1.bias': b1}
     _leaf((xn, dt1), leaf1, G)
-    if FUSE_TAIL and K.naf_tail_supported(c, H * W) and _dgrad_is_hx2() and x.is_contiguous() and dy.is_contiguous():
+    if FUSE_TAIL and K.naf_tail_supported(c, H * W) and _dgrad_fused_ok() and x.is_contiguous() and dy.is_contiguous():
         # conv1 dgrad -> norm1 bwd (+ dy) in one launch
         w1t = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)[0]
         dx, gw1, gb1 = K.naf_head_bwd(dt1, x, mu1, rs1, P['norm1.weight'], w1t, dy, defer_finish=late)

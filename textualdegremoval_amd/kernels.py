@@ -692,7 +692,8 @@ def dwsg_bwd(dg, t, w, b, dg_bias=None, dg_bias_mul=1.0, defer_finish=False):
 
 def naf_tail_supported(c, hw, c_out=None):
     ok_out = c_out is None or c_out == c or (2 * c_out == c and c_out % 32 == 0)
-    return ok_out and MATH == 'hx2' and bool(_lib.load().tdr_naf_tail_supported(int(c), int(hw)))
+    # 'hx2': fp16 pair planes in LDS (loss-scaled backward); 'bx3': bf16 triple planes, fp32 range (csrc/tdr_nafblock.hip, SchT)
+    return ok_out and MATH in ('hx2', 'bx3') and bool(_lib.load().tdr_naf_tail_supported(int(c), int(hw)))
 
 
 def naf_tail_fwd(g, s, x, w3p, b3, beta, lnw, lnb, eps, w4p, b4, w5p, b5, gamma, c_out=None):
