@@ -647,6 +647,16 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
         }
         tile_to_planes<SCH>(da[tn], sB, KOCT, 4 * wave, 32 * tn + j, kk);
         if constexpr (!KHALF) tile_to_planes<SCH>(db[tn], sB, KOCT, C / 8 + 4 * wave, 32 * tn + j, kk);
+        if constexpr (KHALF) {
+            // three planes: the dt4 tile leaves for HBM right here instead of riding inside the K = 2C GEMM -- only the second half's
+            // 32 values stay in registers across the first half's MFMAs (spill reloads behind queued stores wait for every store)
+            float* dp = a.dt4 + (long)n * a.dt4_ns + p0 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dp[off(r, tn)] = da[tn][r];
+                dp[(long)C * HW + off(r, tn)] = db[tn][r];
+            }
+        }
     }
     }   // !HEAD
     // LayerNorm operands of this wave's rows (requested ahead of the GEMM that produces their partner; with three planes and the
@@ -685,32 +695,19 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
             __syncthreads();
             gemm_split<SCH, 1, C / 16, 2>(acc, w_hi, C / 32, [&](int) { return wave; }, sB, KOCT, lane, rot, [](int) {});
         } else {
-            // a real two-trip loop (one body, `da` holds the tile of the current half): unrolled, the register allocator kept the
-            // LDS / fragment addresses of the first half alive for the second and spilled 350 registers at C = 256
-            float* dp = a.dt4 + (long)n * a.dt4_ns + p0 + j;
+            // a real two-trip loop (one GEMM body): unrolled, the register allocator kept the LDS / fragment addresses of the first
+            // half alive for the second and spilled 350 registers at C = 256
             const uint4* wk = a.w4t;
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
                 if (half) {
                     __syncthreads();
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) tile_to_planes<SCH>(da[tn], sB, KOCT, 4 * wave, 32 * tn + j, kk);
+                    for (int tn = 0; tn < 2; ++tn) tile_to_planes<SCH>(db[tn], sB, KOCT, 4 * wave, 32 * tn + j, kk);
                     load_ln_operands();
                     __syncthreads();
                 }
-                gemm_split<SCH, 1, C / 16, 2>(acc, wk, C / 32, [&](int) { return wave; }, sB, KOCT, lane, rot, [&](int g) {
-                    constexpr int IPG = 32 / (C / 16);             // the 32 dword stores of this half's tile spread evenly over the groups
-#pragma unroll
-                    for (int e = 0; e < IPG; ++e) {
-                        const int idx = g * IPG + e, tn = idx >> 4, r = idx & 15;
-                        dp[off(r, tn)] = da[tn][r];
-                    }
-                });
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) da[tn][r] = db[tn][r];
-                dp += (long)C * HW;
+                gemm_split<SCH, 1, C / 16, 2>(acc, wk, C / 32, [&](int) { return wave; }, sB, KOCT, lane, rot, [](int) {});
                 wk = w_hi;
             }
         }
