@@ -22,7 +22,7 @@ extern "C" {
 
 /* C-ABI version: bumped with every incompatible change of this header (100 rounds 1-2, 101 round 3, 102 round 4); the
  * binding (textualdegremoval_amd/_lib.py) refuses a library whose version differs from the one it was written against. */
-#define TDR_ABI_VERSION 103
+#define TDR_ABI_VERSION 104
 int tdr_version(void);
 const char* tdr_last_error(void);
 
@@ -140,6 +140,11 @@ int tdr_pack_patches(const float* blk, int B, int G, int C, int BH, int BW, int 
  * channels of one pixel as 8 x f16; plane 0 = rn_f16(x) (an exact zero is stored as -0.0: the sign bit of plane 0 is "x <= 0" even
  * where a tiny positive x rounds to +0), plane 1 = rn_f16(x - rn_f16(x)); the 1-pixel border is zero.
  * tdr_p16_bytes: buffer size.  tdr_p16_from_f32 / tdr_p16_to_f32 convert (to_f32 returns head + residual).
+ * Plane formats (ABI 104).  fmt 2: two fp16 planes (above; TDR_MATH=hx2, operands inside the fp16 window).  fmt 1: THREE bf16 planes
+ * h = rn_bf16(x), m = rn_bf16(x - h), l = rn_bf16(x - h - m), 6 bytes per element: 8 + 8 + 8 significand bits on fp32's exponent, so
+ * h + m + l == x exactly for every normal fp32 x -- the tensor IS the fp32 tensor (no window, no loss scale; TDR_MATH=bx3: the
+ * reference's arithmetic, models/image_restoration_ref_model.py:268-279), products lh hl mm mh hm hh on v_mfma_f32_32x32x16_bf16.
+ * tdr_conv3x3_p16 / tdr_wgrad3x3_p16 take the format from wp_fmt / fmt; every plane tensor of a call has that format.
  * tdr_conv3x3_p16: out = mask( relu( conv(in, W) + bias + res ) ); `in` is a P16 tensor of Cin channels, `wp` an hx2 pack
  * (tdr_pack_weights_hx2, mode 0 forward / mode 1 data gradient; wp_fmt must be 2); the residual and the ReLU mask (> 0) are read
  * from fp32 NCHW tensors (res32 / mask32, strides in floats) or from P16 tensors of Cout channels (res16 / mask16: the mask is
@@ -161,6 +166,10 @@ typedef struct TdrConvP16Desc {
 int64_t tdr_p16_bytes(int N, int C, int H, int W);
 int tdr_p16_from_f32(const float* src, int64_t src_ns, int N, int C, int H, int W, void* dst, void* stream);
 int tdr_p16_to_f32(const void* src, int N, int C, int H, int W, float* dst, int64_t dst_ns, void* stream);
+/* the same for either plane format (fmt 1: bf16 triple, 2: fp16 pair; the three above are fmt 2) */
+int64_t tdr_p16_bytes_fmt(int N, int C, int H, int W, int fmt);
+int tdr_p16_from_f32_fmt(const float* src, int64_t src_ns, int N, int C, int H, int W, void* dst, int fmt, void* stream);
+int tdr_p16_to_f32_fmt(const void* src, int N, int C, int H, int W, float* dst, int64_t dst_ns, int fmt, void* stream);
 int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream);
 /* tuning aid: force a tile configuration (0 = heuristic) */
 int tdr_conv3x3_p16_force_cfg(int cfg);
@@ -175,6 +184,7 @@ typedef struct TdrWgradP16Desc {
     float* g;
     float* db;
     float* ws; int64_t ws_floats;
+    int fmt;                     /* plane format of in16 and dout16: 2 fp16 pair (0 is read as 2), 1 bf16 triple */
 } TdrWgradP16Desc;
 int64_t tdr_wgrad3x3_p16_ws_floats(const TdrWgradP16Desc* d);
 int tdr_wgrad3x3_p16(const TdrWgradP16Desc* d, void* stream);

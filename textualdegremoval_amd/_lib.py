@@ -15,7 +15,7 @@ import torch  # noqa: F401  (import order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TDR_LIB_PATH', os.path.join(_HERE, 'libtdr_hip.so'))   # override: profiling probe builds
 
-ABI_VERSION = 103      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
+ABI_VERSION = 104      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
 c_fp = C.c_void_p      # device pointers travel as integers
 i32, i64, f32 = C.c_int, C.c_int64, C.c_float
 
@@ -59,7 +59,7 @@ class TdrConvP16Desc(C.Structure):
 
 class TdrWgradP16Desc(C.Structure):
     _fields_ = [('N', i32), ('Cin', i32), ('H', i32), ('W', i32), ('Cout', i32),
-                ('in16', c_fp), ('dout16', c_fp), ('g', c_fp), ('db', c_fp), ('ws', c_fp), ('ws_floats', i64)]
+                ('in16', c_fp), ('dout16', c_fp), ('g', c_fp), ('db', c_fp), ('ws', c_fp), ('ws_floats', i64), ('fmt', i32)]
 
 
 class TdrPackJob(C.Structure):
@@ -130,6 +130,9 @@ SIGNATURES = {
     'tdr_local_avgpool_ws_floats': (i64, [i32, i32, i32, i32]),
     'tdr_local_avgpool': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_p16_bytes': (i64, [i32, i32, i32, i32]),
+    'tdr_p16_bytes_fmt': (i64, [i32, i32, i32, i32, i32]),
+    'tdr_p16_from_f32_fmt': (i32, [c_fp, i64, i32, i32, i32, i32, c_fp, i32, c_fp]),
+    'tdr_p16_to_f32_fmt': (i32, [c_fp, i32, i32, i32, i32, c_fp, i64, i32, c_fp]),
     'tdr_p16_from_f32': (i32, [c_fp, i64, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_p16_to_f32': (i32, [c_fp, i32, i32, i32, i32, c_fp, i64, c_fp]),
     'tdr_conv3x3_p16': (i32, [C.POINTER(TdrConvP16Desc), c_fp]),

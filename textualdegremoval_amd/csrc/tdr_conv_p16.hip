@@ -31,8 +31,21 @@
 
 typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// Two plane formats share the slot layout [N][C/8][plane NS][H+2][W+2] (16-byte slots of 8 channels of one pixel):
+//   PF_PAIR (wp_fmt 2): NS = 2 fp16 planes (h, m), products mh hm hh -- the fp16-window format described above (TDR_MATH=hx2);
+//   PF_TRI  (wp_fmt 1): NS = 3 bf16 planes (h, m, l), products lh hl mm mh hm hh (v_mfma_f32_32x32x16_bf16) -- the reference-
+//            arithmetic format (TDR_MATH=bx3).  h = rn_bf16(x), m = rn_bf16(x - h), l = rn_bf16(x - h - m): 8 + 8 + 8 significand
+//            bits with fp32's exponent, so for every normal fp32 x the three planes hold x EXACTLY (h + m + l == x): a triple-plane
+//            tensor is the fp32 tensor at 6 bytes per element, no window, no loss scale, and the forward residual stream can
+//            live in it.  Same sign convention for exact zeros (head -0.0).  Results are bit-identical to
+//            conv_bx3_kernel<..., SCH_BX3> on the fp32 tensors (same products, same accumulation order).
+enum { PF_TRI = 1, PF_PAIR = 2 };
+template <int PF> struct PlaneFmt { static constexpr int NS = PF == PF_TRI ? 3 : 2; };
 
 // head plane value of x: rn_f16(x), except that an exact zero becomes -0.0 (see the header: the sign bit of the head is "x <= 0")
 __device__ __forceinline__ _Float16 p16_head(float x) {
@@ -49,6 +62,30 @@ __device__ __forceinline__ void p16_split4(float x0, float x1, float x2, float x
     h1 |= (x2 == 0.f ? 0x8000u : 0u) | (x3 == 0.f ? 0x80000000u : 0u);
     h = make_uint2(h0, h1);
     m = make_uint2(m0, m1);
+}
+
+// the triple-plane counterpart: tdr_split3_bf16 pairs + the sign bit of exact zeros
+__device__ __forceinline__ void p24_split4(float x0, float x1, float x2, float x3, uint2& h, uint2& m, uint2& l) {
+    unsigned h0, h1, m0, m1, l0, l1;
+    tdr_split3_bf16(x0, x1, h0, m0, l0);
+    tdr_split3_bf16(x2, x3, h1, m1, l1);
+    h0 |= (x0 == 0.f ? 0x8000u : 0u) | (x1 == 0.f ? 0x80000000u : 0u);     // +-0 -> -0.0
+    h1 |= (x2 == 0.f ? 0x8000u : 0u) | (x3 == 0.f ? 0x80000000u : 0u);
+    h = make_uint2(h0, h1);
+    m = make_uint2(m0, m1);
+    l = make_uint2(l0, l1);
+}
+// four packed 16-bit plane elements (a uint2) -> fp32
+template <int PF>
+__device__ __forceinline__ void plane4_to_f32(uint2 v, float (&o)[4]) {
+    if constexpr (PF == PF_TRI) {
+        o[0] = __builtin_bit_cast(float, v.x << 16); o[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+        o[2] = __builtin_bit_cast(float, v.y << 16); o[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+    } else {
+        const pf16x4 h = __builtin_bit_cast(pf16x4, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (float)h[e];
+    }
 }
 
 struct P16Args {
@@ -82,8 +119,9 @@ __device__ __forceinline__ void wait_barrier() {
 // ---- epilogue shared by the kernels of this file (accumulator layout: lane (j, kk) holds pixel j of row tn, channels
 // mb + (r&3) + 8*(r>>2), mb = .. + 4*kk): bias, residual (fp32 tensor or pair planes), ReLU, mask (fp32 tensor or the sign bit of
 // the head plane), then the fp32 NCHW store and / or the pair-plane store incl. the zero border of the output tensor.
-template <int TM, int TN>
+template <int TM, int TN, int PF = PF_PAIR>
 __device__ __forceinline__ void p16_epilogue(const P16Args& a, f32x16 (&acc)[TM][TN], int n, int m0, int wm, int wn, int oy0, int ox0, int j, int kk) {
+    constexpr int NS = PlaneFmt<PF>::NS;
     const long PS = (long)a.Hp * a.Wp;
     const long HW = (long)a.H * a.W;
 #pragma unroll
@@ -116,11 +154,19 @@ __device__ __forceinline__ void p16_epilogue(const P16Args& a, f32x16 (&acc)[TM]
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);
-                    const char* p = reinterpret_cast<const char*>(a.res16 + (long)n * a.res16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
-                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
-                    const pf16x4 m = *reinterpret_cast<const pf16x4*>(p + PS * 16);
+                    const char* p = reinterpret_cast<const char*>(a.res16 + (long)n * a.res16_ns + (long)oc * NS * PS + pslot) + kk * 8;
+                    float h[4], m[4];
+                    plane4_to_f32<PF>(*reinterpret_cast<const uint2*>(p), h);
+                    plane4_to_f32<PF>(*reinterpret_cast<const uint2*>(p + PS * 16), m);
+                    if constexpr (PF == PF_TRI) {
+                        float l[4];
+                        plane4_to_f32<PF>(*reinterpret_cast<const uint2*>(p + 2 * PS * 16), l);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)h[e] + (float)m[e];
+                        for (int e = 0; e < 4; ++e) v[4 * q + e] += (h[e] + m[e]) + l[e];      // the planes' sum is the stored fp32 value, exactly
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q + e] += h[e] + m[e];
+                    }
                 }
             }
             if (a.relu) {
@@ -139,8 +185,8 @@ __device__ __forceinline__ void p16_epilogue(const P16Args& a, f32x16 (&acc)[TM]
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int oc = min((mt0 >> 3) + q, (a.Cout >> 3) - 1);
-                    const char* p = reinterpret_cast<const char*>(a.mask16 + (long)n * a.mask16_ns + (long)oc * 2 * PS + pslot) + kk * 8;
-                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);
+                    const char* p = reinterpret_cast<const char*>(a.mask16 + (long)n * a.mask16_ns + (long)oc * NS * PS + pslot) + kk * 8;
+                    const pf16x4 h = *reinterpret_cast<const pf16x4*>(p);         // (sign bits only: the same test for both formats)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * q + e] = p16_positive(h[e]) ? v[4 * q + e] : 0.f;
                 }
@@ -157,19 +203,20 @@ __device__ __forceinline__ void p16_epilogue(const P16Args& a, f32x16 (&acc)[TM]
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (!pvalid || mt0 + 8 * q >= a.Cout) continue;
-                    uint2 h, m;                                  // head and residual from the same fp32 value (tdr_split2_f16)
-                    p16_split4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], h, m);
-                    char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * 2 * PS) + kk * 8;
-                    *reinterpret_cast<uint2*>(base + pslot * 16) = h;
-                    *reinterpret_cast<uint2*>(base + (PS + pslot) * 16) = m;
+                    uint2 pl[NS];                                // every plane from the same fp32 value (tdr_split2_f16 / tdr_split3_bf16)
+                    if constexpr (PF == PF_TRI) p24_split4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], pl[0], pl[1], pl[2]);
+                    else p16_split4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], pl[0], pl[1]);
+                    char* base = reinterpret_cast<char*>(a.out16 + (long)n * a.out16_ns + (long)((mt0 >> 3) + q) * NS * PS) + kk * 8;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(base + (s * PS + pslot) * 16) = pl[s];
                     // the zero border of the output tensor is written by the tiles that touch it
                     const pf16x4 z = {0, 0, 0, 0};
                     const bool top = oy == 0, bot = oy == a.H - 1, lef = ox == 0, rig = ox == a.W - 1;
                     if (top | bot | lef | rig) {
                         const long Wp = a.Wp;
                         auto zero_at = [&](long sl) {
-                            *reinterpret_cast<pf16x4*>(base + sl * 16) = z;
-                            *reinterpret_cast<pf16x4*>(base + (PS + sl) * 16) = z;
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) *reinterpret_cast<pf16x4*>(base + (s * PS + sl) * 16) = z;
                         };
                         if (top) zero_at(ox + 1);
                         if (bot) zero_at((long)(a.H + 1) * Wp + ox + 1);
@@ -287,20 +334,25 @@ __device__ __forceinline__ void p16_epilogue_lean(const P16Args& a, f32x16 (&acc
 // and rows wn*TN..  (a 32-pixel sub-tile is one image row segment, so every tap shift of a B fragment is a contiguous run of
 // slots).  PIPE: the fragments of step s + 1 are read from LDS while the MFMAs of step s run (register double buffer), so a
 // wave keeps the matrix pipe busy on its own; the weight ring is then LA + 1 = 4 slots with a run-time slot index.
-template <int TM, int TN, int WM, int WN, bool PIPE, int ABL = 0, bool ILV = false>
+// PF: plane format of the input / weight pack (PF_PAIR: 2 fp16 planes, 3 products; PF_TRI: 3 bf16 planes, 6 products).
+template <int TM, int TN, int WM, int WN, bool PIPE, int ABL = 0, bool ILV = false, int PF = PF_PAIR>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_p16_kernel(P16Args a) {
+    constexpr int NS = PlaneFmt<PF>::NS;
+    constexpr int NPR = PF == PF_TRI ? 6 : 3;              // matrix products per fp32 product
     constexpr int NW = WM * WN, NT = 64 * NW;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     constexpr int BM = 32 * TM * WM, TH = TN * WN;
     constexpr int LH = TH + 2, LW = 34, TS = LH * LW;      // halo tile slots per (octet, plane)
-    constexpr int NBW = (4 * TS + NT - 1) / NT;            // halo pieces per wave per group (2 octets x 2 planes)
+    constexpr int NBW = (2 * NS * TS + NT - 1) / NT;       // halo pieces per wave per group (2 octets x NS planes)
     constexpr int BREG = NBW * NT;                         // slots per halo buffer (padded to whole pieces)
-    constexpr int NAI = (BM / 32) * 2;                     // weight pieces per step
-    static_assert(NAI % NW == 0, "every wave issues the same number of weight pieces");
-    constexpr int NAW = NAI / NW;                          // per wave
+    constexpr int NAI = (BM / 32) * NS;                    // weight pieces per step
+    constexpr int NAW = (NAI + NW - 1) / NW;               // per wave (the first NAI % NW waves issue one more than the others)
+    constexpr int NAX = NAI % NW;                          // 0: every wave issues NAW pieces
     constexpr int LA = PIPE ? 3 : 2;
     constexpr int R = LA + 1;
-    static_assert(NBW <= (PIPE ? 6 : 7), "halo pieces must be issued early enough to be covered by the wait that publishes them");
+    // halo pieces must be issued early enough to be covered by the wait that publishes them: taps 0 .. NTB-1, HPT pieces per tap
+    constexpr int NTB = PIPE ? 6 : 7;
+    constexpr int HPT = (NBW + NTB - 1) / NTB;
 
     extern __shared__ __attribute__((aligned(1024))) uint4 smem4[];
     uint4* sB = smem4;                   // [2][BREG]
@@ -330,23 +382,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
     unsigned boff[NBW];
 #pragma unroll
     for (int k = 0; k < NBW; ++k) {
-        const int f = min((k * NW + wave) * 64 + lane, 4 * TS - 1);
+        const int f = min((k * NW + wave) * 64 + lane, 2 * NS * TS - 1);
         const int op = f / TS, s = f - op * TS;
         const int r = s / LW, c = s - r * LW;
         const int gy = min(oy0 + r, a.Hp - 1), gx = min(ox0 + c, a.Wp - 1);
         boff[k] = (unsigned)((op * PS + (long)gy * a.Wp + gx) * 16);
     }
-    const char* bsrc = reinterpret_cast<const char*>(a.in + (long)n * a.in_ns);     // + g * 64 * PS bytes per group
-    const long bstep = 64 * PS;
+    const char* bsrc = reinterpret_cast<const char*>(a.in + (long)n * a.in_ns);     // + g * 2 * NS * 16 * PS bytes per group
+    const long bstep = 2 * NS * 16 * PS;
     unsigned aoff[NAW];
 #pragma unroll
     for (int i = 0; i < NAW; ++i) {
-        const int idx = i * NW + wave;
-        const int mt = min(mtile * (BM / 32) + (idx >> 1), a.MT - 1);
-        aoff[i] = (unsigned)(((mt * 2 + (idx & 1)) * 64 + lane) * 16);
+        const int idx = min(i * NW + wave, NAI - 1);
+        const int mt = min(mtile * (BM / 32) + (idx / NS), a.MT - 1);
+        aoff[i] = (unsigned)(((mt * NS + (idx % NS)) * 64 + lane) * 16);
     }
     const char* asrc = reinterpret_cast<const char*>(a.wp);
-    const long astep = (long)a.MT * 2048;                                            // bytes per (group, tap)
+    const long astep = (long)a.MT * (NS * 1024);                                     // bytes per (group, tap)
+    const bool a_extra = NAX == 0 || wave < NAX;                                     // this wave issues NAW (else NAW - 1) weight pieces per step
 
     // ABL (timing ablations, profiles/probe_conv_p16.py; results are wrong): 1 no LDS-DMA in the loop, 2 no fragment reads in the
     // loop, 4 no barrier, 8 no MFMAs, 16 no epilogue
@@ -354,7 +407,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
         if ((ABL & 1) && step >= LA) return;
         const char* base = asrc + (long)min(step, S - 1) * astep;
 #pragma unroll
-        for (int i = 0; i < NAW; ++i) P16_GLDS(base + aoff[i], sA + slot * (NAI * 64) + (i * NW + wave) * 64);
+        for (int i = 0; i < NAW; ++i)
+            if (NAX == 0 || i < NAW - 1 || a_extra) P16_GLDS(base + aoff[i], sA + slot * (NAI * 64) + (i * NW + wave) * 64);
     };
     auto issue_b = [&](int g, int buf, int k) {
         if ((ABL & 1) && g > 0) return;
@@ -377,52 +431,75 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
     for (int d = 0; d < LA; ++d) issue_a(d, d);
     wait_barrier<0>();
 
-    const uint4* pa0 = sA + (wm * TM * 2) * 64 + lane;
-    const uint4* pb0 = sB + kk * 2 * TS + (wn * TN) * LW + j;
-    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};   // mh hm hh
+    const uint4* pa0 = sA + (wm * TM * NS) * 64 + lane;
+    const uint4* pb0 = sB + kk * NS * TS + (wn * TN) * LW + j;
+    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};                          // pair: mh hm hh
+    constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};        // triple: lh hl mm mh hm hh (small cross terms first)
 
-    pf16x8 af[TM][2], bf[TN][2];
-    auto read_frags = [&](pf16x8 (&fa)[TM][2], pf16x8 (&fb)[TN][2], int slot, int buf, int tap) {
+    pu32x4 af[TM][NS], bf[TN][NS];
+    auto read_frags = [&](pu32x4 (&fa)[TM][NS], pu32x4 (&fb)[TN][NS], int slot, int buf, int tap) {
         const uint4* pa = pa0 + slot * (NAI * 64);
         const uint4* pb = pb0 + buf * BREG + (tap / 3) * LW + (tap % 3);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) fa[tm][s] = __builtin_bit_cast(pf16x8, pa[(tm * 2 + s) * 64]);
+            for (int s = 0; s < NS; ++s) fa[tm][s] = __builtin_bit_cast(pu32x4, pa[(tm * NS + s) * 64]);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) fb[tn][s] = __builtin_bit_cast(pf16x8, pb[s * TS + tn * LW]);
+            for (int s = 0; s < NS; ++s) fb[tn][s] = __builtin_bit_cast(pu32x4, pb[s * TS + tn * LW]);
     };
-    auto mma_step = [&](const pf16x8 (&fa)[TM][2], const pf16x8 (&fb)[TN][2]) {
+    auto mma_step = [&](const pu32x4 (&fa)[TM][NS], const pu32x4 (&fb)[TN][NS]) {
         if constexpr (!ILV) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < NPR; ++q)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][HA[q]], fb[tn][HB[q]], acc[tm][tn], 0, 0, 0);
+                for (int tn = 0; tn < TN; ++tn) {
+                    if constexpr (PF == PF_TRI)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, fa[tm][SA[q]]), __builtin_bit_cast(pbf16x8, fb[tn][SB[q]]), acc[tm][tn], 0, 0, 0);
+                    else
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, fa[tm][HA[q]]), __builtin_bit_cast(pf16x8, fb[tn][HB[q]]), acc[tm][tn], 0, 0, 0);
+                }
         if constexpr (!ILV) __builtin_amdgcn_s_setprio(0);
     };
 
     if constexpr (PIPE) read_frags(af, bf, 0, 0, 0);
 
+    // counted wait: pieces this wave issued after the ones the next step needs (own weight pieces of this step + the halo pieces
+    // of this tap and the previous one) stay in flight
+    auto step_wait = [&](auto nbc) {
+        constexpr int nb = decltype(nbc)::value;
+        if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if constexpr (ABL & 1) wait_barrier<0>();
+        else if constexpr (NAX == 0) wait_barrier<NAW + nb>();
+        else { if (a_extra) wait_barrier<NAW + nb>(); else wait_barrier<NAW - 1 + nb>(); }
+    };
+
     auto step = [&](auto tapc, int g, int buf) {
         constexpr int tap = decltype(tapc)::value;
+        constexpr int hb_now = (tap * HPT < NBW) ? ((NBW - tap * HPT) < HPT ? (NBW - tap * HPT) : HPT) : 0;       // halo pieces issued at this tap
+        constexpr int ptap = (tap + 8) % 9;
+        constexpr int hb_prev = (ptap * HPT < NBW) ? ((NBW - ptap * HPT) < HPT ? (NBW - ptap * HPT) : HPT) : 0;   // .. at the previous step
         const int s = g * 9 + tap;
         issue_a(s + LA, PIPE ? ((s + LA) & 3) : ((tap + LA) % 3));
-        if (tap < NBW) issue_b(g + 1, buf ^ 1, tap);
+#pragma unroll
+        for (int h = 0; h < hb_now; ++h) issue_b(g + 1, buf ^ 1, tap * HPT + h);
         if constexpr (PIPE) {
             // fragments of step s + 1 (its weight slot and halo buffer were published by the previous barrier)
-            pf16x8 afn[TM][2], bfn[TN][2];
+            pu32x4 afn[TM][NS], bfn[TN][NS];
             constexpr int ntap = (tap + 1) % 9;
             if (!(ABL & 2)) read_frags(afn, bfn, (s + 1) & 3, tap == 8 ? (buf ^ 1) : buf, ntap);
             else {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) { afn[tm][0] = af[tm][0]; afn[tm][1] = af[tm][1]; }
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) { bfn[tn][0] = bf[tn][0]; bfn[tn][1] = bf[tn][1]; }
+                    for (int q = 0; q < NS; ++q) afn[tm][q] = af[tm][q];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) bfn[tn][q] = bf[tn][q];
             }
             if (!(ABL & 8)) mma_step(af, bf);
             else { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
@@ -430,7 +507,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
             // steps, so nothing below depends on them) instead of a load block in front of an MFMA block -- the waves that share
             // a SIMD run in phase, so a block of loads is time in which NO wave of the SIMD has an MFMA to issue
             if constexpr (ILV) {
-                constexpr int NM = TM * TN * 3, ND = (TM + TN) * 2, NV = NAW + (tap < NBW ? 1 : 0);
+                constexpr int NM = TM * TN * NPR, ND = (TM + TN) * NS, NV = NAW + hb_now;
 #pragma unroll
                 for (int i = 0; i < NM; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
@@ -439,27 +516,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
                 }
             }
             // outstanding afterwards: pieces younger than the weight pieces of step s + 2 (issued at step s - 1)
-            constexpr int nb = (((tap + 8) % 9) < NBW ? 1 : 0) + (tap < NBW ? 1 : 0);
-            if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else if constexpr (ABL & 1) wait_barrier<0>();
-            else wait_barrier<NAW + nb>();
+            step_wait(std::integral_constant<int, hb_prev + hb_now>{});
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) af[tm][q] = afn[tm][q];
+                for (int q = 0; q < NS; ++q) af[tm][q] = afn[tm][q];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) bf[tn][q] = bfn[tn][q];
+                for (int q = 0; q < NS; ++q) bf[tn][q] = bfn[tn][q];
         } else {
             if (!(ABL & 2) || s == 0) read_frags(af, bf, (tap % R), buf, tap);
             if (!(ABL & 8)) mma_step(af, bf);
             else { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
             // pieces issued after the weight pieces of step s + 1 (issued at step s - 1)
-            constexpr int nb = (((tap + 8) % 9) < NBW ? 1 : 0) + (tap < NBW ? 1 : 0);
-            if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else if constexpr (ABL & 1) wait_barrier<0>();
-            else wait_barrier<NAW + nb>();
+            step_wait(std::integral_constant<int, hb_prev + hb_now>{});
         }
     };
     for (int g = 0; g < ngroups; ++g) {
@@ -483,21 +554,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv3x3_
         if (sum == 1.2345f && a.out32) a.out32[0] = sum;
         return;
     }
-    p16_epilogue<TM, TN>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
+    p16_epilogue<TM, TN, PF>(a, acc, n, m0, wm, wn, oy0, ox0, j, kk);
 }
 
-template <int TM, int TN, int WM, int WN, bool PIPE, int ABL = 0, bool ILV = false>
+template <int TM, int TN, int WM, int WN, bool PIPE, int ABL = 0, bool ILV = false, int PF = PF_PAIR>
 int launch_p16(const P16Args& a0, int N, hipStream_t st) {
+    constexpr int NS = PlaneFmt<PF>::NS;
     constexpr int NW = WM * WN, BM = 32 * TM * WM, TH = TN * WN;
-    constexpr int TS = (TH + 2) * 34, NBW = (4 * TS + 64 * NW - 1) / (64 * NW), BREG = NBW * 64 * NW, NAI = (BM / 32) * 2;
+    constexpr int TS = (TH + 2) * 34, NBW = (2 * NS * TS + 64 * NW - 1) / (64 * NW), BREG = NBW * 64 * NW, NAI = (BM / 32) * NS;
     constexpr int R = PIPE ? 4 : 3;
     P16Args a = a0;
     a.tiles_x = tdr_cdiv(a.W, 32);
     a.tiles_y = tdr_cdiv(a.H, TH);
     a.mtiles = tdr_cdiv(a.Cout, BM);
     const size_t lds = (size_t)(2 * BREG + R * NAI * 64) * 16;
+    static_assert((size_t)(2 * BREG + R * NAI * 64) * 16 <= 160 * 1024, "tile configuration does not fit the 160 KiB of LDS");
     dim3 grid((unsigned)((long)a.tiles_x * a.tiles_y * a.mtiles * N));
-    auto kern = conv3x3_p16_kernel<TM, TN, WM, WN, PIPE, ABL, ILV>;
+    auto kern = conv3x3_p16_kernel<TM, TN, WM, WN, PIPE, ABL, ILV, PF>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -760,8 +833,10 @@ int launch_p16_thin8(const P16Args& a0, int N, hipStream_t st) {
     return TDR_OK;
 }
 
-// ---- fp32 NCHW <-> P16
+// ---- fp32 NCHW <-> plane tensors
+template <int PF>
 __global__ void p16_from_f32_kernel(const float* __restrict__ src, long src_ns, int C, int H, int W, uint4* __restrict__ dst) {
+    constexpr int NS = PlaneFmt<PF>::NS;
     const int Hp = H + 2, Wp = W + 2;
     const long PS = (long)Hp * Wp, HW = (long)H * W;
     const int G = C >> 3;
@@ -771,24 +846,39 @@ __global__ void p16_from_f32_kernel(const float* __restrict__ src, long src_ns, 
         const int oc = (int)(i / PS);
         const long s = i - oc * PS;
         const int y = (int)(s / Wp), x = (int)(s - (long)y * Wp);
-        pf16x8 h, m;
         const bool in = y >= 1 && y <= H && x >= 1 && x <= W;
         const float* p = src + (long)n * src_ns + (long)oc * 8 * HW + (in ? (long)(y - 1) * W + x - 1 : 0);
+        uint4* o = dst + ((long)n * G + oc) * NS * PS + s;
+        if constexpr (PF == PF_TRI) {
+            float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = in ? p[e * HW] : 0.f;
-            asm volatile("" : "+v"(v));
-            const _Float16 hh = (_Float16)v;
-            h[e] = in ? p16_head(v) : hh;             // (the border is plain +0, as the convolution epilogue writes it)
-            m[e] = (_Float16)(v - (float)hh);
+            for (int e = 0; e < 8; ++e) v[e] = in ? p[e * HW] : 0.f;
+            uint2 h0, m0, l0, h1, m1, l1;
+            p24_split4(v[0], v[1], v[2], v[3], h0, m0, l0);
+            p24_split4(v[4], v[5], v[6], v[7], h1, m1, l1);
+            if (!in) { h0 = make_uint2(0, 0); h1 = h0; }          // (the border is plain +0, as the convolution epilogue writes it)
+            o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            o[PS] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+            o[2 * PS] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else {
+            pf16x8 h, m;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = in ? p[e * HW] : 0.f;
+                asm volatile("" : "+v"(v));
+                const _Float16 hh = (_Float16)v;
+                h[e] = in ? p16_head(v) : hh;             // (the border is plain +0, as the convolution epilogue writes it)
+                m[e] = (_Float16)(v - (float)hh);
+            }
+            o[0] = __builtin_bit_cast(uint4, h);
+            o[PS] = __builtin_bit_cast(uint4, m);
         }
-        uint4* o = dst + ((long)n * G + oc) * 2 * PS + s;
-        o[0] = __builtin_bit_cast(uint4, h);
-        o[PS] = __builtin_bit_cast(uint4, m);
     }
 }
 
+template <int PF>
 __global__ void p16_to_f32_kernel(const uint4* __restrict__ src, int C, int H, int W, float* __restrict__ dst, long dst_ns) {
+    constexpr int NS = PlaneFmt<PF>::NS;
     const int Hp = H + 2, Wp = W + 2;
     const long PS = (long)Hp * Wp, HW = (long)H * W;
     const int G = C >> 3;
@@ -798,55 +888,89 @@ __global__ void p16_to_f32_kernel(const uint4* __restrict__ src, int C, int H, i
         const int oc = (int)(i / HW);
         const long s = i - oc * HW;
         const int y = (int)(s / W), x = (int)(s - (long)y * W);
-        const uint4* p = src + ((long)n * G + oc) * 2 * PS + (long)(y + 1) * Wp + x + 1;
-        const pf16x8 h = __builtin_bit_cast(pf16x8, p[0]), m = __builtin_bit_cast(pf16x8, p[PS]);
+        const uint4* p = src + ((long)n * G + oc) * NS * PS + (long)(y + 1) * Wp + x + 1;
+        float* o = dst + (long)n * dst_ns + (long)(oc * 8) * HW + s;
+        if constexpr (PF == PF_TRI) {
+            const uint4 h = p[0], m = p[PS], l = p[2 * PS];
+            const unsigned hh[4] = {h.x, h.y, h.z, h.w}, mm[4] = {m.x, m.y, m.z, m.w}, ll[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dst[(long)n * dst_ns + (long)(oc * 8 + e) * HW + s] = (float)h[e] + (float)m[e];
+            for (int e = 0; e < 4; ++e) {
+                o[(long)(2 * e) * HW] = (__builtin_bit_cast(float, hh[e] << 16) + __builtin_bit_cast(float, mm[e] << 16)) + __builtin_bit_cast(float, ll[e] << 16);
+                o[(long)(2 * e + 1) * HW] = (__builtin_bit_cast(float, hh[e] & 0xffff0000u) + __builtin_bit_cast(float, mm[e] & 0xffff0000u)) +
+                                            __builtin_bit_cast(float, ll[e] & 0xffff0000u);
+            }
+        } else {
+            const pf16x8 h = __builtin_bit_cast(pf16x8, p[0]), m = __builtin_bit_cast(pf16x8, p[PS]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[(long)e * HW] = (float)h[e] + (float)m[e];
+        }
     }
 }
 
 }  // namespace
 
-extern "C" int64_t tdr_p16_bytes(int N, int C, int H, int W) {
-    return (int64_t)N * (C / 8) * 2 * (H + 2) * (W + 2) * 16;
+extern "C" int64_t tdr_p16_bytes_fmt(int N, int C, int H, int W, int fmt) {
+    return (int64_t)N * (C / 8) * (fmt == PF_TRI ? 3 : 2) * (H + 2) * (W + 2) * 16;
 }
+extern "C" int64_t tdr_p16_bytes(int N, int C, int H, int W) { return tdr_p16_bytes_fmt(N, C, H, W, PF_PAIR); }
 
-extern "C" int tdr_p16_from_f32(const float* src, int64_t src_ns, int N, int C, int H, int W, void* dst, void* stream) {
+extern "C" int tdr_p16_from_f32_fmt(const float* src, int64_t src_ns, int N, int C, int H, int W, void* dst, int fmt, void* stream) {
     TDR_REQUIRE(src && dst && N > 0, "tdr_p16_from_f32: bad argument");
     TDR_REQUIRE(C % 16 == 0, "tdr_p16_from_f32: C = %d is not a multiple of 16", C);
+    TDR_REQUIRE(fmt == PF_TRI || fmt == PF_PAIR, "tdr_p16_from_f32: plane format %d (1: bf16 triple, 2: fp16 pair)", fmt);
     const long total = (long)(C / 8) * (H + 2) * (W + 2);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(p16_from_f32_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, src, (long)src_ns, C, H, W, (uint4*)dst);
+    if (fmt == PF_TRI) hipLaunchKernelGGL(p16_from_f32_kernel<PF_TRI>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, src, (long)src_ns, C, H, W, (uint4*)dst);
+    else hipLaunchKernelGGL(p16_from_f32_kernel<PF_PAIR>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, src, (long)src_ns, C, H, W, (uint4*)dst);
     TDR_LAUNCH_CHECK("p16_from_f32_kernel");
     return TDR_OK;
 }
+extern "C" int tdr_p16_from_f32(const float* src, int64_t src_ns, int N, int C, int H, int W, void* dst, void* stream) {
+    return tdr_p16_from_f32_fmt(src, src_ns, N, C, H, W, dst, PF_PAIR, stream);
+}
 
-extern "C" int tdr_p16_to_f32(const void* src, int N, int C, int H, int W, float* dst, int64_t dst_ns, void* stream) {
+extern "C" int tdr_p16_to_f32_fmt(const void* src, int N, int C, int H, int W, float* dst, int64_t dst_ns, int fmt, void* stream) {
     TDR_REQUIRE(src && dst && N > 0, "tdr_p16_to_f32: bad argument");
     TDR_REQUIRE(C % 16 == 0, "tdr_p16_to_f32: C = %d is not a multiple of 16", C);
+    TDR_REQUIRE(fmt == PF_TRI || fmt == PF_PAIR, "tdr_p16_to_f32: plane format %d (1: bf16 triple, 2: fp16 pair)", fmt);
     const long total = (long)(C / 8) * H * W;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(p16_to_f32_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, C, H, W, dst, (long)dst_ns);
+    if (fmt == PF_TRI) hipLaunchKernelGGL(p16_to_f32_kernel<PF_TRI>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, C, H, W, dst, (long)dst_ns);
+    else hipLaunchKernelGGL(p16_to_f32_kernel<PF_PAIR>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, C, H, W, dst, (long)dst_ns);
     TDR_LAUNCH_CHECK("p16_to_f32_kernel");
     return TDR_OK;
 }
+extern "C" int tdr_p16_to_f32(const void* src, int N, int C, int H, int W, float* dst, int64_t dst_ns, void* stream) {
+    return tdr_p16_to_f32_fmt(src, N, C, H, W, dst, dst_ns, PF_PAIR, stream);
+}
 
-static int g_p16_cfg = getenv("TDR_P16_CFG") ? atoi(getenv("TDR_P16_CFG")) : 0;
-extern "C" int tdr_conv3x3_p16_force_cfg(int cfg) { g_p16_cfg = cfg; return TDR_OK; }
+static int p16_env_cfg() {
+    const int c = getenv("TDR_P16_CFG") ? atoi(getenv("TDR_P16_CFG")) : 0;
+    return (c >= 100 && c < 300 && !getenv("TDR_PROBES")) ? 0 : c;
+}
+static int g_p16_cfg = p16_env_cfg();
+extern "C" int tdr_conv3x3_p16_force_cfg(int cfg) {
+    // 100 .. 299 are timing ablations that compute WRONG results (profiles/probe_conv_p16.py): never reachable from a product process
+    static const bool probes = getenv("TDR_PROBES") != nullptr;
+    TDR_REQUIRE(probes || cfg < 100 || cfg >= 300, "tdr_conv3x3_p16_force_cfg: configuration %d is a timing ablation (set TDR_PROBES=1)", cfg);
+    g_p16_cfg = cfg;
+    return TDR_OK;
+}
 
 extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
     TDR_REQUIRE(d && d->in && d->wp && (d->out32 || d->out16), "tdr_conv3x3_p16: null pointer");
     TDR_REQUIRE(d->Cin % 16 == 0 && d->Cin >= 16, "tdr_conv3x3_p16: Cin = %d is not a multiple of 16", d->Cin);
     TDR_REQUIRE(!d->out16 || d->Cout % 16 == 0, "tdr_conv3x3_p16: P16 output needs Cout %% 16 == 0 (got %d)", d->Cout);
     TDR_REQUIRE((!d->res16 && !d->mask16) || d->Cout % 8 == 0, "tdr_conv3x3_p16: P16 residual / mask need Cout %% 8 == 0");
-    TDR_REQUIRE(d->wp_fmt == 2, "tdr_conv3x3_p16: weights must be the 2-way fp16 split pack (wp_fmt 2)");
+    TDR_REQUIRE(d->wp_fmt == 2 || d->wp_fmt == 1, "tdr_conv3x3_p16: weights must be the 2-way fp16 split pack (wp_fmt 2, pair planes) or the 3-way bf16 split pack (wp_fmt 1, triple planes)");
+    const int NSd = d->wp_fmt == 1 ? 3 : 2;       // planes of every plane tensor of this call
     P16Args a;
-    a.in = (const uint4*)d->in; a.in_ns = (long)(d->Cin / 8) * 2 * (d->H + 2) * (d->W + 2);
+    a.in = (const uint4*)d->in; a.in_ns = (long)(d->Cin / 8) * NSd * (d->H + 2) * (d->W + 2);
     a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Hp = d->H + 2; a.Wp = d->W + 2;
     a.wp = (const uint4*)d->wp; a.MT = d->Mpad >> 5; a.Cout = d->Cout;
     a.bias = d->bias;
     a.res32 = d->res32; a.res32_ns = d->res32_ns;
-    a.res16 = (const uint4*)d->res16; a.res16_ns = (long)(d->Cout / 8) * 2 * (d->H + 2) * (d->W + 2);
+    a.res16 = (const uint4*)d->res16; a.res16_ns = (long)(d->Cout / 8) * NSd * (d->H + 2) * (d->W + 2);
     a.mask32 = d->mask32; a.mask32_ns = d->mask32_ns;
     a.mask16 = (const uint4*)d->mask16; a.mask16_ns = a.res16_ns;
     a.relu = d->relu;
@@ -857,6 +981,28 @@ extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
     const int N = d->N;
     auto blocks = [&](int bm, int th) { return (long)tdr_cdiv(d->Cout, bm) * tdr_cdiv(d->H, th) * tdr_cdiv(d->W, 32) * N; };
     int cfg = g_p16_cfg;
+    if (d->wp_fmt == 1) {
+        // triple planes (TDR_MATH=bx3).  Tile configurations (forced ones: 301 ..): see profiles/r5/probe_p24*.log
+        constexpr int T = PF_TRI;
+        if (cfg < 300) cfg = 0;
+        if (cfg == 0) cfg = 301;
+        switch (cfg) {
+            //                         TM TN WM WN PIPE ABL ILV
+            case 301: return launch_p16<2, 2, 1, 4, true, 0, true, T>(a, N, st);     //  64 x (8 x 32), 4 waves (89 KiB: one workgroup per CU)
+            case 302: return launch_p16<2, 2, 2, 4, true, 0, true, T>(a, N, st);     // 128 x (8 x 32), 8 waves
+            case 303: return launch_p16<1, 2, 2, 2, true, 0, true, T>(a, N, st);     //  64 x (4 x 32), 4 waves (two workgroups per CU)
+            case 304: return launch_p16<2, 2, 2, 2, true, 0, true, T>(a, N, st);     // 128 x (4 x 32), 4 waves
+            case 306: return launch_p16<2, 2, 4, 2, true, 0, true, T>(a, N, st);     // 256 x (4 x 32), 8 waves
+            case 307: return launch_p16<2, 1, 2, 4, true, 0, true, T>(a, N, st);     // 128 x (4 x 32), 8 waves
+            case 311: return launch_p16<2, 2, 1, 4, true, 0, false, T>(a, N, st);    // 301 without the interleaved issue order
+            case 312: return launch_p16<2, 2, 2, 4, true, 0, false, T>(a, N, st);
+            case 321: return launch_p16<2, 2, 1, 4, false, 0, false, T>(a, N, st);   // 301 without pipelined fragments
+            default: break;
+        }
+        tdr_set_error("tdr_conv3x3_p16: unknown triple-plane tile configuration %d", cfg);
+        return TDR_ERR_ARG;
+    }
+    if (cfg >= 300) cfg = 0;
     if (cfg >= 32 && cfg <= 36 && d->Cin <= 32 && d->Cout <= 32)
         return cfg == 32 ? launch_p16_thin8<1>(a, N, st) : (cfg == 33 ? launch_p16_thin8<2>(a, N, st) : (cfg == 34 ? launch_p16_thin8<1, 1>(a, N, st) :
                (cfg == 35 ? launch_p16_thin8<1, 16>(a, N, st) : launch_p16_thin8<1, 17>(a, N, st))));

@@ -24,6 +24,7 @@
 #include "../../include/tdr.h"
 
 typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef short ws16x4 __attribute__((ext_vector_type(4)));
 typedef short ws16x8 __attribute__((ext_vector_type(8)));
 
@@ -40,23 +41,31 @@ struct WgP16Args {
     __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(gptr),          \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-__device__ __forceinline__ wf16x8 tr_frag(const char* p, int off0, int off1) {
+__device__ __forceinline__ ws16x8 tr_frag(const char* p, int off0, int off1) {
     const ws16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)(p + off0));
     const ws16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)(p + off1));
     const ws16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    return __builtin_bit_cast(wf16x8, v);
+    return v;
+}
+// one matrix product of two 16-bit fragments: fp16 (pair planes) or bf16 (triple planes)
+template <int NS>
+__device__ __forceinline__ f32x16 wg_mfma(ws16x8 x, ws16x8 y, f32x16 c) {
+    if constexpr (NS == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, x), __builtin_bit_cast(wbf16x8, y), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, x), __builtin_bit_cast(wf16x8, y), c, 0, 0, 0);
 }
 
 // WM x WN x WK = 4 waves; wave (wm, wn) owns the 32 co x 32 ci tile pair, WK waves share it and split the k-steps of a step.
-template <int WM, int WN, int WK>
+// NS: planes of the operand tensors (2: fp16 pair, products mh hm hh; 3: bf16 triple, products lh hl mm mh hm hh -- the plane
+// formats of tdr_conv_p16.hip).
+template <int WM, int WN, int WK, int NS = 2>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_p16_kernel(WgP16Args a) {
     static_assert(WM * WN * WK == 4, "4 waves");
     constexpr int RS = WK == 4 ? 2 : 1;                  // rows per step (2 k-steps of 16 pixels per row)
     static_assert(2 * RS % WK == 0, "k-steps of a step split evenly over the K waves");
     constexpr int BMo = 32 * WM, BNi = 32 * WN, NOo = BMo / 8, NOi = BNi / 8;
     constexpr int XS = 2 * RS + 2, DS = 2 * RS;          // ring slots (rows)
-    constexpr int XR = ((NOi * 2 * 34 + 63) / 64) * 64;  // slots per input row (padded to whole pieces)
-    constexpr int DR = NOo * 2 * 32;                     // slots per gradient row
+    constexpr int XR = ((NOi * NS * 34 + 63) / 64) * 64; // slots per input row (padded to whole pieces)
+    constexpr int DR = NOo * NS * 32;                    // slots per gradient row
     constexpr int XP = XR / 64, DP = DR / 64;            // pieces per row
 
     extern __shared__ __attribute__((aligned(1024))) uint4 smem4[];
@@ -83,19 +92,19 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_p16_kernel(WgP16Args a) {
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
         // input row piece: columns beyond the padded row are clamped to the right border (zero)
-        const int f = min((wave + 4 * i) * 64 + lane, NOi * 2 * 34 - 1);
+        const int f = min((wave + 4 * i) * 64 + lane, NOi * NS * 34 - 1);
         const int op = f / 34, c = f - op * 34;
-        const int oc = min((ci0 >> 3) + (op >> 1), Gi - 1);
-        xoff[i] = ((((long)n * Gi + oc) * 2 + (op & 1)) * PS + min(x0 + c, a.Wp - 1)) * 16;
+        const int oc = min((ci0 >> 3) + (op / NS), Gi - 1);
+        xoff[i] = ((((long)n * Gi + oc) * NS + (op % NS)) * PS + min(x0 + c, a.Wp - 1)) * 16;
     }
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
         // gradient row piece: pixels outside the image must contribute ZERO: they are read from the (0, 0) border slot
         const int f = (wave + 4 * i) * 64 + lane;
         const int op = f >> 5, c = f & 31;
-        const int oc = min((co0 >> 3) + (op >> 1), Go - 1);
+        const int oc = min((co0 >> 3) + (op / NS), Go - 1);
         dcol[i] = x0 + c < a.W;
-        doff[i] = ((((long)n * Go + oc) * 2 + (op & 1)) * PS) * 16;
+        doff[i] = ((((long)n * Go + oc) * NS + (op % NS)) * PS) * 16;
     }
     const char* xbase = reinterpret_cast<const char*>(a.in);
     const char* dbase = reinterpret_cast<const char*>(a.dout);
@@ -131,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_p16_kernel(WgP16Args a) {
     const int nn = lane & 15, g16 = lane >> 4;
     const int jpx = nn >> 2, q = nn & 3, chalf = g16 & 1, kk = g16 >> 1;
     const int oct = chalf * 2 + (q >> 1);
-    const int a_lane = ((wm * 4 + oct) * 2 * 32 + 8 * kk + jpx) * 16 + (q & 1) * 8;      // + plane*32*16 + (16*ks + 4*r)*16
-    const int b_lane = ((wn * 4 + oct) * 2 * 34 + 8 * kk + jpx) * 16 + (q & 1) * 8;      // + plane*34*16 + (16*ks + 4*r + kx)*16
+    const int a_lane = ((wm * 4 + oct) * NS * 32 + 8 * kk + jpx) * 16 + (q & 1) * 8;     // + plane*32*16 + (16*ks + 4*r)*16
+    const int b_lane = ((wn * 4 + oct) * NS * 34 + 8 * kk + jpx) * 16 + (q & 1) * 8;     // + plane*34*16 + (16*ks + 4*r + kx)*16
 
     f32x16 acc[9];
 #pragma unroll
@@ -143,9 +152,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_p16_kernel(WgP16Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
     const bool want_db = a.dbpart != nullptr && blockIdx.z == 0 && wn == 0;      // wave-uniform
-    wf16x8 ones;
+    ws16x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.f;
+    for (int e = 0; e < 8; ++e) ones[e] = NS == 3 ? (short)0x3f80 : (short)0x3c00;      // 1.0 as bf16 / fp16
 
     // ---- prologue: halo rows y0, y0+1 (+ the first step's new rows) and the first step's gradient rows
     issue_x_row(y0); issue_x_row(y0 + 1);
@@ -163,26 +172,29 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_p16_kernel(WgP16Args a) {
             const int yr = y + (ku >> 1), ks = ku & 1;
             if (yr < y1) {
                 const char* pd = reinterpret_cast<const char*>(sD + (yr % DS) * DR) + a_lane + ks * 256;
-                const wf16x8 ah = tr_frag(pd, 0, 64), am = tr_frag(pd, 32 * 16, 32 * 16 + 64);
+                ws16x8 ap[NS];                       // gradient planes h, m (, l)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) ap[s] = tr_frag(pd, s * 32 * 16, s * 32 * 16 + 64);
                 if (want_db) {
-                    accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, ones, accb, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ones, accb, 0, 0, 0);
+#pragma unroll
+                    for (int s = NS - 1; s >= 0; --s) accb = wg_mfma<NS>(ap[s], ones, accb);
                 }
+                // small cross terms first, the dominant h*h last
+                constexpr int NPR = NS == 3 ? 6 : 3;
+                constexpr int PA[6] = {NS == 3 ? 2 : 1, 0, NS == 3 ? 1 : 0, 1, 0, 0};      // pair: mh hm hh ; triple: lh hl mm mh hm hh
+                constexpr int PB[6] = {0, NS == 3 ? 2 : 1, NS == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const char* px = reinterpret_cast<const char*>(sX + ((yr + ky) % XS) * XR) + b_lane + ks * 256;
-                    wf16x8 bh[3], bm[3];
+                    ws16x8 bp[NS][3];
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        bh[kx] = tr_frag(px, kx * 16, kx * 16 + 64);
-                        bm[kx] = tr_frag(px, 34 * 16 + kx * 16, 34 * 16 + kx * 16 + 64);
-                    }
+                    for (int s = 0; s < NS; ++s)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+                        for (int kx = 0; kx < 3; ++kx) bp[s][kx] = tr_frag(px, s * 34 * 16 + kx * 16, s * 34 * 16 + kx * 16 + 64);
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm[kx], acc[ky * 3 + kx], 0, 0, 0);
+                    for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[kx], acc[ky * 3 + kx], 0, 0, 0);
+                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = wg_mfma<NS>(ap[PA[pr]], bp[PB[pr]][kx], acc[ky * 3 + kx]);
                 }
             }
         }
@@ -283,14 +295,14 @@ WgP16Plan wgp_plan(const TdrWgradP16Desc* d) {
     return p;
 }
 
-template <int WM, int WN, int WK>
+template <int WM, int WN, int WK, int NS>
 int launch_wgp(const WgP16Args& a, const WgP16Plan& p, const TdrWgradP16Desc* d, hipStream_t st) {
     constexpr int RS = WK == 4 ? 2 : 1, NOo = 4 * WM, NOi = 4 * WN;
-    constexpr int XR = ((NOi * 2 * 34 + 63) / 64) * 64, DR = NOo * 2 * 32;
+    constexpr int XR = ((NOi * NS * 34 + 63) / 64) * 64, DR = NOo * NS * 32;
     size_t lds = (size_t)((2 * RS + 2) * XR + 2 * RS * DR) * 16;
     if (WK > 1 && lds < 10 * 16 * 64 * 4) lds = 10 * 16 * 64 * 4;
     dim3 grid(p.nsplit, tdr_cdiv(d->Cout, 32 * WM), tdr_cdiv(d->Cin, 32 * WN));
-    auto kern = wgrad3x3_p16_kernel<WM, WN, WK>;
+    auto kern = wgrad3x3_p16_kernel<WM, WN, WK, NS>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -321,7 +333,10 @@ extern "C" int tdr_wgrad3x3_p16(const TdrWgradP16Desc* d, void* stream) {
     a.part = d->ws;
     a.dbpart = d->db ? d->ws + (int64_t)p.nsplit * d->Cout * d->Cin * 9 : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = p.cfg == 1 ? launch_wgp<1, 1, 4>(a, p, d, st) : launch_wgp<2, 2, 1>(a, p, d, st);
+    TDR_REQUIRE(d->fmt == 0 || d->fmt == 1 || d->fmt == 2, "tdr_wgrad3x3_p16: plane format %d (1: bf16 triple, 2: fp16 pair)", d->fmt);
+    int rc;
+    if (d->fmt == 1) rc = p.cfg == 1 ? launch_wgp<1, 1, 4, 3>(a, p, d, st) : launch_wgp<2, 2, 1, 3>(a, p, d, st);
+    else rc = p.cfg == 1 ? launch_wgp<1, 1, 4, 2>(a, p, d, st) : launch_wgp<2, 2, 1, 2>(a, p, d, st);
     if (rc != TDR_OK) return rc;
     const long elems = (long)d->Cout * d->Cin * 9;
     const int nb_main = tdr_cdiv(elems, 64), nb2 = d->db ? tdr_cdiv(d->Cout, 64) : 0;

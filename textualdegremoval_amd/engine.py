@@ -401,7 +401,8 @@ P16_MIN_C = int(os.environ.get('TDR_P16_MIN_C', '64'))
 
 
 def _p16_level(Cc, n_blocks):
-    return P16_ON and n_blocks > 0 and K.MATH == 'hx2' and K.GRAD_SCALED and K.p16_supported(Cc) and Cc >= P16_MIN_C
+    """plane tensors at this level: fp16 pairs inside a loss-scaled hx2 step, bf16 triples under TDR_MATH=bx3 (kernels.plane_fmt)"""
+    return P16_ON and n_blocks > 0 and K.plane_fmt() is not None and K.p16_supported(Cc) and Cc >= P16_MIN_C
 
 
 def encoder_fwd(x, P, pre, ext_n_blocks, levels=5):
@@ -421,14 +422,19 @@ def encoder_fwd(x, P, pre, ext_n_blocks, levels=5):
             # to ~23 bits, and a 1e-7 perturbation of the stream flips a handful of ReLU decisions h > 0 per tensor -- each flip moves
             # a conv1 gradient element by a whole term (measured 1.8e-4 of the tensor maximum against the fp32-tensor path,
             # profiles/r4/diag_p16_grads.log).  With the fp32 stream the forward pass is bit-identical to the fp32-tensor kernels.
-            x16, x32 = K.p16_from_f32(a), a
+            # bf16 TRIPLE planes (TDR_MATH=bx3) hold every fp32 value exactly (h + m + l == x): there the residual stream itself
+            # lives in the planes and only the level's output is also written as fp32 -- bit-identical to the fp32-tensor kernels.
+            fmt = K.plane_fmt()
+            tri = fmt == K.FMT_BX3
+            x16, x32 = K.p16_from_f32(a, fmt=fmt), a
             for i in range(cnt[lvl]):
                 bp = f'{pre}blk_L{k}.{i}.'
                 wp1, mp1, *_ = K.pack_weights(P[bp + 'conv1.weight'], PACK_FWD)
                 wp2, mp2, *_ = K.pack_weights(P[bp + 'conv2.weight'], PACK_FWD)
                 last = i == cnt[lvl] - 1
                 _, h16 = K.conv3x3_p16(x16, wp1, mp1, Cc, bias=P[bp + 'conv1.bias'], relu=True, want32=False, want16=True)
-                o32, o16 = K.conv3x3_p16(h16, wp2, mp2, Cc, bias=P[bp + 'conv2.bias'], res=x32, want32=True, want16=not last)
+                o32, o16 = K.conv3x3_p16(h16, wp2, mp2, Cc, bias=P[bp + 'conv2.bias'], res=x16 if tri else x32,
+                                         want32=last or not tri, want16=not last)
                 blocks.append((x16, h16))
                 x16, x32 = o16, o32
             x = x32
@@ -462,7 +468,7 @@ def _encoder_bwd_levels(dfeats, P, pre, cnt, saved, G, dnext):
         if d is None:
             continue
         if blocks and isinstance(blocks[0][0], K.P16):
-            d16, d32 = K.p16_from_f32(d), d
+            d16, d32 = K.p16_from_f32(d, fmt=blocks[0][0].fmt), d
             for i in reversed(range(cnt[lvl])):
                 bp = f'{pre}blk_L{k}.{i}.'
                 x16, h16 = blocks[i]

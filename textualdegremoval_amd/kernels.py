@@ -500,41 +500,52 @@ def conv_forward(x, wp, Mpad, Cout, KH, stride=1, dil=1, pad=0, OH=None, OW=None
 
 
 class P16:
-    """A pre-split activation (include/tdr.h, "P16 tensors"): 16-byte slots [N][C/8][plane][H+2][W+2] of 8 x f16, plane 0 the
-    fp16 heads, plane 1 the fp16 residuals, zero border.  `buf` is a flat int32 tensor (4 bytes per element of the fp32 tensor
-    plus the border)."""
-    __slots__ = ('buf', 'N', 'C', 'H', 'W')
+    """A pre-split activation (include/tdr.h, "plane tensors"): 16-byte slots [N][C/8][plane][H+2][W+2] of 8 x 16-bit elements, zero
+    border.  fmt FMT_HX2: two fp16 planes (heads, residuals) -- 4 bytes per element, operands inside the fp16 window (TDR_MATH=hx2);
+    fmt FMT_BX3: three bf16 planes (h, m, l) -- 6 bytes per element, h + m + l IS the fp32 value (any exponent; TDR_MATH=bx3).
+    `buf` is a flat int32 tensor."""
+    __slots__ = ('buf', 'N', 'C', 'H', 'W', 'fmt')
 
-    def __init__(self, buf, N, Cc, H, W):
-        self.buf, self.N, self.C, self.H, self.W = buf, N, Cc, H, W
+    def __init__(self, buf, N, Cc, H, W, fmt=FMT_HX2):
+        self.buf, self.N, self.C, self.H, self.W, self.fmt = buf, N, Cc, H, W, fmt
 
     @staticmethod
-    def empty(N, Cc, H, W, device):
-        assert Cc % 16 == 0, f'P16 tensors need C % 16 == 0 (got {Cc})'
-        n = _lib.load().tdr_p16_bytes(N, Cc, H, W) // 4
-        return P16(torch.empty(n, dtype=torch.int32, device=device), N, Cc, H, W)
+    def empty(N, Cc, H, W, device, fmt=FMT_HX2):
+        assert Cc % 16 == 0, f'plane tensors need C % 16 == 0 (got {Cc})'
+        assert fmt in (FMT_HX2, FMT_BX3)
+        n = _lib.load().tdr_p16_bytes_fmt(N, Cc, H, W, fmt) // 4
+        return P16(torch.empty(n, dtype=torch.int32, device=device), N, Cc, H, W, fmt)
 
     def data_ptr(self):
         return self.buf.data_ptr()
 
     def to_f32(self):
         out = torch.empty(self.N, self.C, self.H, self.W, dtype=torch.float32, device=self.buf.device)
-        check(_lib.load().tdr_p16_to_f32(self.buf.data_ptr(), self.N, self.C, self.H, self.W, out.data_ptr(), _dense_nchw(out),
-                                         _stream()), 'tdr_p16_to_f32')
+        check(_lib.load().tdr_p16_to_f32_fmt(self.buf.data_ptr(), self.N, self.C, self.H, self.W, out.data_ptr(), _dense_nchw(out),
+                                             self.fmt, _stream()), 'tdr_p16_to_f32')
         return out
 
 
 def p16_supported(Cc):
-    """channel counts the pre-split 3x3 path takes (both operands in the fp16 window: TDR_MATH=hx2)"""
+    """channel counts the pre-split 3x3 path takes"""
     return Cc % 16 == 0 and Cc >= 16
 
 
-def p16_from_f32(x, out=None):
+def plane_fmt():
+    """plane format of the step's arithmetic: fp16 pairs inside a loss-scaled hx2 step, bf16 triples under bx3, else None"""
+    if MATH == 'hx2' and GRAD_SCALED:
+        return FMT_HX2
+    if MATH == 'bx3':
+        return FMT_BX3
+    return None
+
+
+def p16_from_f32(x, out=None, fmt=FMT_HX2):
     N, Cc, H, W = x.shape
-    out = out if out is not None else P16.empty(N, Cc, H, W, x.device)
-    if _survey is not None:
+    out = out if out is not None else P16.empty(N, Cc, H, W, x.device, fmt)
+    if _survey is not None and out.fmt == FMT_HX2:
         _survey.probe(x, 'grad' if BACKWARD_PHASE else 'fwd')
-    check(_lib.load().tdr_p16_from_f32(x.data_ptr(), _dense_nchw(x), N, Cc, H, W, out.data_ptr(), _stream()), 'tdr_p16_from_f32')
+    check(_lib.load().tdr_p16_from_f32_fmt(x.data_ptr(), _dense_nchw(x), N, Cc, H, W, out.data_ptr(), out.fmt, _stream()), 'tdr_p16_from_f32')
     return out
 
 
@@ -546,6 +557,8 @@ def conv3x3_p16(x16, wp, Mpad, Cout, bias=None, res=None, mask=None, relu=False,
     d.N, d.Cin, d.H, d.W, d.Cout = x16.N, x16.C, x16.H, x16.W, Cout
     d.inp = x16.data_ptr()
     d.wp, d.Mpad, d.wp_fmt = wp.data_ptr(), Mpad, getattr(wp, 'fmt', FMT_F32)
+    assert d.wp_fmt == x16.fmt, f'weight pack format {d.wp_fmt} does not match the plane format {x16.fmt} of the input'
+    assert all(t.fmt == x16.fmt for t in (res, mask) if isinstance(t, P16))
     d.bias = _p(bias)
     if isinstance(res, P16):
         d.res16 = res.data_ptr()
@@ -561,10 +574,10 @@ def conv3x3_p16(x16, wp, Mpad, Cout, bias=None, res=None, mask=None, relu=False,
         o32 = out32 if out32 is not None else torch.empty(x16.N, Cout, x16.H, x16.W, dtype=torch.float32, device=x16.buf.device)
         d.out32, d.out32_ns = o32.data_ptr(), _dense_nchw(o32)
     if want16:
-        o16 = P16.empty(x16.N, Cout, x16.H, x16.W, x16.buf.device)
+        o16 = P16.empty(x16.N, Cout, x16.H, x16.W, x16.buf.device, x16.fmt)
         d.out16 = o16.data_ptr()
     check(lib.tdr_conv3x3_p16(C.byref(d), _stream()), 'tdr_conv3x3_p16')
-    if _survey is not None and o16 is not None:
+    if _survey is not None and o16 is not None and o16.fmt == FMT_HX2:
         # the pair planes are the operands of the next contraction: their fp32 value must sit inside the fp16 window
         _survey.probe(o32 if o32 is not None else o16.to_f32(), 'grad' if BACKWARD_PHASE else 'fwd')
     return o32, o16
@@ -577,6 +590,8 @@ def wgrad3x3_p16(x16, d16, want_db=False):
     d = TdrWgradP16Desc()
     d.N, d.Cin, d.H, d.W, d.Cout = x16.N, x16.C, x16.H, x16.W, d16.C
     d.in16, d.dout16 = x16.data_ptr(), d16.data_ptr()
+    assert x16.fmt == d16.fmt
+    d.fmt = x16.fmt
     dev = x16.buf.device
     g = torch.empty(1, d16.C, x16.C, 3, 3, dtype=torch.float32, device=dev)
     db = torch.empty(d16.C, dtype=torch.float32, device=dev) if want_db else None
