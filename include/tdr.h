@@ -31,7 +31,9 @@ const char* tdr_last_error(void);
  * gradients by inv_scale -- both exact).  tdr_grad_sumsq_guarded sets `finite` from the global gradient norm: a
  * non-finite norm (an operand left the fp16 range, or the forward pass overflowed) makes tdr_adamw_step_guarded a
  * no-op for that step, halves `scale` and counts the step in `skipped`; after `growth_interval` finite steps the scale
- * doubles again up to max_scale.  `step` is AdamW's t (applied steps only) and bc1/bc2_sqrt its bias corrections.
+ * doubles again up to max_scale.  growth_interval < 0 switches the verdict OFF: every step is applied (finite = 1) and the scale never
+ * moves -- the modes without a loss scale (TDR_MATH=bx3 / f32: the reference's arithmetic) use the struct only as the device-resident
+ * step counter.  `step` is AdamW's t (applied steps only) and bc1/bc2_sqrt its bias corrections.
  * Everything lives in device memory so the whole step replays from captured hipGraphs with step-invariant launch
  * arguments; the reference has no counterpart (it runs torch fp32, image_restoration_ref_model.py:276-279). */
 typedef struct TdrStepGuard {

@@ -22,3 +22,14 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def hx2_mode():
+    """the opt-in fast arithmetic (TDR_MATH=hx2: fp16 pair planes, loss-scaled backward, step guard, range survey) for the tests of
+    exactly that machinery; the library default is the reference's arithmetic (bx3)"""
+    from textualdegremoval_amd import kernels as K
+    prev = K.MATH
+    K.set_math('hx2')
+    yield K
+    K.set_math(prev)

@@ -40,7 +40,8 @@ def test_two_rank_graph_step_runs(wrap):
     assert r2['n_gpus'] == 2 and r2['config']['ranks_seen'] == 2
     assert r2['value'] > 0 and r2['final_loss'] == r2['final_loss']      # finite
     assert r2['config']['global_batch'] == 2
-    assert 'buckets' in r2['config']['grad_exchange'] and r2['guard']['skipped_in_timed_region'] == 0
+    assert 'buckets' in r2['config']['grad_exchange']
+    assert r2['guard'] is None or r2['guard']['skipped_in_timed_region'] == 0       # (None: the default arithmetic has no step verdict)
 
 
 def test_stage_a_step_two_ranks():

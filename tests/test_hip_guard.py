@@ -68,6 +68,23 @@ def test_non_finite_norm_skips_the_step_and_halves_the_scale():
     assert int(opt.state_dict()['state'][0]['step']) == 3
 
 
+def test_without_a_loss_scale_there_is_no_verdict():
+    """TDR_MATH=bx3 / f32 (the reference's arithmetic): the struct only counts steps -- a non-finite norm does NOT skip the step
+    (torch's clip_grad_norm_ + AdamW.step() apply it too, image_restoration_ref_model.py:276-279) and the scale never moves"""
+    ref, opt_ref, gp, opt = _pair()
+    _set_grads(ref, gp, 0)
+    opt.prepare()
+    opt.guard.set_never_skip(True)
+    assert opt.guard.never_skip
+    _set_grads(ref, gp, 0, poison=float('inf'))
+    opt.step()
+    g = opt.guard.read()
+    assert (g.skipped, g.step, g.finite) == (0, 1, 1) and g.scale == 1.0
+    assert any(not torch.isfinite(p.detach()).all() for p in gp)         # the poisoned update went through
+    opt.guard.set_never_skip(False)
+    assert opt.guard.read().growth_interval == 1000
+
+
 def test_scale_grows_back_after_the_growth_interval():
     ref, opt_ref, gp, opt = _pair()
     _set_grads(ref, gp, 0)
@@ -122,7 +139,7 @@ def test_model_ema_kernel_matches_torch():
 
 
 @pytest.mark.parametrize('graph', ['1', '0'])
-def test_overflowing_backward_is_skipped_then_recovers(monkeypatch, graph):
+def test_overflowing_backward_is_skipped_then_recovers(monkeypatch, graph, hx2_mode):
     """A loss scale 2^22 above the surveyed one pushes gradient operands of the fp16-split backward pass out of the
     fp16 range: those steps must leave the weights untouched and halve the scale until the backward pass fits again,
     in the captured-graph step as well as the eager one; the loss stays finite throughout."""
@@ -130,8 +147,7 @@ def test_overflowing_backward_is_skipped_then_recovers(monkeypatch, graph):
     from oracle import nafnet_ref_oracle as O
     from textualdegremoval_amd import kernels as K
     from textualdegremoval_amd.models import create_model
-    if K.MATH != 'hx2':
-        pytest.skip('the loss-scaled backward pass exists only under TDR_MATH=hx2')
+    assert K.MATH == 'hx2'          # (the loss-scaled backward pass exists only there)
     monkeypatch.setenv('TDR_GRAPH', graph)
     model = create_model(make_opt())
     lq, gt, ref = O.synth_pair(1, 128, 128, seed=7)

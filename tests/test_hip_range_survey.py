@@ -17,8 +17,7 @@ def _model(monkeypatch, every='1'):
     from test_hip_step import make_opt
     from textualdegremoval_amd import kernels as K
     from textualdegremoval_amd.models import create_model
-    if K.MATH != 'hx2':
-        pytest.skip('the survey guards the fp16-split arithmetic')
+    assert K.MATH == 'hx2'          # (the survey guards the fp16-split arithmetic: `hx2_mode`)
     monkeypatch.setenv('TDR_RANGE_CHECK_EVERY', every)
     model = create_model(make_opt())
     cfg = O.default_cfg(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
@@ -32,7 +31,7 @@ def _step(model, it, data):
     model.optimize_parameters(it)
 
 
-def test_survey_reports_the_window_and_leaves_a_healthy_step_alone(monkeypatch):
+def test_survey_reports_the_window_and_leaves_a_healthy_step_alone(monkeypatch, hx2_mode):
     model, K = _model(monkeypatch)
     lq, gt, ref = O.synth_pair(1, 128, 128, seed=1234 + 3)
     _step(model, 1, {'lq': lq, 'gt': gt, 'ref': ref})
@@ -46,7 +45,7 @@ def test_survey_reports_the_window_and_leaves_a_healthy_step_alone(monkeypatch):
     assert g.step == 1 and g.skipped == 0
 
 
-def test_tiny_gradients_move_the_loss_scale_back_into_the_window(monkeypatch):
+def test_tiny_gradients_move_the_loss_scale_back_into_the_window(monkeypatch, hx2_mode):
     """gradient operands 2^-40 below where the surveyed scale puts them: the first survey raises the loss scale by the
     measured deficit, the second one finds the window restored; the trajectory stays on the reference's"""
     model, K = _model(monkeypatch)
@@ -76,7 +75,7 @@ def test_tiny_gradients_move_the_loss_scale_back_into_the_window(monkeypatch):
     assert abs(model.get_current_log()['l_pix'] - ref_model.get_current_log()['l_pix']) < 1e-6
 
 
-def test_forward_overflow_switches_off_the_fp16_split_and_protects_the_weights(monkeypatch):
+def test_forward_overflow_switches_off_the_fp16_split_and_protects_the_weights(monkeypatch, hx2_mode):
     """inputs scaled to 1e6: the first convolutions see operands beyond 65504.  The survey step must not move the weights
     (step guard: non-finite norm), must take the run off the fp16 split, and the next step must be finite."""
     model, K = _model(monkeypatch)
@@ -99,7 +98,7 @@ def test_forward_overflow_switches_off_the_fp16_split_and_protects_the_weights(m
         K.set_math('hx2')
 
 
-def test_unhandled_non_finite_loss_is_loud(monkeypatch):
+def test_unhandled_non_finite_loss_is_loud(monkeypatch, hx2_mode):
     """with the survey disabled the same overflow must surface as an exception when the log is read"""
     model, K = _model(monkeypatch)
     monkeypatch.setenv('TDR_RANGE_CHECK', '0')

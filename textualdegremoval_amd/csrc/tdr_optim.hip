@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void sumsq_finish_guard_kernel(const double* _
     if (threadIdx.x == 0) {
         const double tot = red[0];
         out[0] = tot;
-        const bool ok = isfinite(tot);
+        // growth_interval < 0: no verdict -- the step is applied whatever the norm is, as torch's clip_grad_norm_ + AdamW.step()
+        // do (image_restoration_ref_model.py:276-279): the arithmetic modes without a loss scale (TDR_MATH=bx3 / f32) have no guard
+        const bool ok = g->growth_interval < 0 || isfinite(tot);
         g->finite = ok ? 1 : 0;
         if (ok) {
             const int t = ++g->step;

@@ -251,6 +251,9 @@ class RefGuidedImageCleanModel(BaseModel):
             K.set_grad_scaled(gs != 1.0)
             guard = self.optimizer_g.ensure_guard(lq.device)
             if not torch.cuda.is_current_stream_capturing():
+                # without a loss scale (TDR_MATH=bx3 / f32, or the surveyed fall-back) there is no skip verdict either: the step is
+                # applied whatever the norm, as the reference does (:276-279); the struct only counts steps on the device
+                guard.set_never_skip(gs == 1.0)
                 guard.set_max_scale(gs)        # (host read; the capture pass reuses the value of the eager warm-up steps)
             self.grad_reducer.guard = guard
             self._pack_plan.run()              # all weights, all layouts, one launch (no-op on the recording step)

@@ -45,6 +45,20 @@ class StepGuard:
         import numpy as np
         self.buf.copy_(torch.from_numpy(np.frombuffer(bytes(g), dtype=np.int32).copy()))
 
+    def set_never_skip(self, on):
+        """on: no finite-norm verdict -- every step is applied, as the reference's clip_grad_norm_ + AdamW.step() (the modes without
+        a loss scale); the struct is then only the device-resident step counter.  Host write only when the setting changes."""
+        if self.growth_interval > 0:
+            self._growth_on = self.growth_interval
+        want = -1 if on else getattr(self, '_growth_on', 1000)
+        if want != self.growth_interval:
+            self.growth_interval = want
+            self.write()
+
+    @property
+    def never_skip(self):
+        return self.growth_interval < 0
+
     def set_max_scale(self, s):
         """(re)start from the scale `s` when the caller's upper bound changes (first step, new input shape)"""
         if self.read().max_scale != float(s):
