@@ -1,4 +1,5 @@
-// Weight gradient of the STRIDE-2 convolutions (H = 2 OH, W = 2 OW) on the 2-way fp16 split: 3x3 pad 1 -- the four level
+// Weight gradient of the STRIDE-2 convolutions (H = 2 OH, W = 2 OW) on the split-operand matrix cores (3-way bf16: the default
+// arithmetic, round 5; 2-way fp16: the fast mode it was written for in round 4): 3x3 pad 1 -- the four level
 // transitions conv_L2 .. conv_L5 of the MASA encoder (reference models/archs/network_nafnet_guided_arch.py:122-128) -- and
 // 2x2 pad 0 -- the `downs` of the U-Net (:434-437).  They were the last dense weight gradients of the step on the exact-fp32
 // kernel (tdr_wgrad_mfma.hip: 4 + 4 launches, 1.4 + 0.35 ms).  Described for 3x3; the 2x2 variant has no halo and no shifted tap.
@@ -27,6 +28,7 @@
 #include <stdlib.h>
 
 typedef _Float16 s2f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 s2bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 s2f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned s2u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned s2u32x2 __attribute__((ext_vector_type(2)));
@@ -43,29 +45,36 @@ constexpr int s2_slots(int KH) { return KH == 3 ? 5 : 4; }
 constexpr int s2_ip(int KH) { return KH == 3 ? 408 : 328; }
 constexpr int S2_DP = 40;        // dout row pitch (elements): 5 x 16 bytes
 
-// x -> (h, m) pairs (tdr_common.h: tdr_split2_f16)
-template <bool H1>
-__device__ __forceinline__ void s2_split2(float x0, float x1, unsigned& h, unsigned& m) {
-    tdr_split2_f16<false>(x0, x1, h, m);          // operands straight from buffer loads: no pin needed
-    if constexpr (H1) m = h;
-}
-template <bool H1>
-__device__ __forceinline__ void s2_split4(float x0, float x1, float x2, float x3, s2u32x2& h, s2u32x2& m) {
-    unsigned h0, m0, h1, m1;
-    s2_split2<H1>(x0, x1, h0, m0);
-    s2_split2<H1>(x2, x3, h1, m1);
-    h = (s2u32x2){h0, h1};
-    m = (s2u32x2){m0, m1};
+// Operand schemes (WgArgs.scheme): S2_BX3 = 0: x = h + m + l, bf16 each, 6 products (24-bit operands, fp32 range: TDR_MATH=bx3, the
+// default arithmetic); S2_HX2 = 1: x = h + m, fp16 each, 3 products (fp16 window: loss-scaled backward); S2_H1 = 2: one fp16 plane.
+enum { S2_BX3 = 0, S2_HX2 = 1, S2_H1 = 2 };
+constexpr int s2_ns(int SCH) { return SCH == S2_BX3 ? 3 : (SCH == S2_HX2 ? 2 : 1); }
+// four fp32 values -> their NS packed planes (tdr_common.h: tdr_split2_f16 / tdr_split3_bf16; operands straight from buffer loads: no pin)
+template <int SCH>
+__device__ __forceinline__ void s2_split4(float x0, float x1, float x2, float x3, s2u32x2 (&p)[s2_ns(SCH)]) {
+    if constexpr (SCH == S2_BX3) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        tdr_split3_bf16<false>(x0, x1, h0, m0, l0);
+        tdr_split3_bf16<false>(x2, x3, h1, m1, l1);
+        p[0] = (s2u32x2){h0, h1}; p[1] = (s2u32x2){m0, m1}; p[2] = (s2u32x2){l0, l1};
+    } else {
+        unsigned h0, m0, h1, m1;
+        tdr_split2_f16<false>(x0, x1, h0, m0);
+        tdr_split2_f16<false>(x2, x3, h1, m1);
+        p[0] = (s2u32x2){h0, h1};
+        if constexpr (SCH == S2_HX2) p[1] = (s2u32x2){m0, m1};
+    }
 }
 
 // KH = 3 (pad 1) or 2 (pad 0: the 2x2 stride-2 `downs` of the U-Net, :434-437 -- rows 2 oy, 2 oy + 1, columns 2 ox (E) / 2 ox + 1 (O), no halo)
-template <int KH, int WN, bool H1>
+template <int KH, int WN, int SCH>
 __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
+    constexpr bool H1 = SCH == S2_H1;
     constexpr int NT = 128 * KH * WN;
     constexpr int PAD = KH == 3 ? 1 : 0;
     constexpr int NCH = KH == 3 ? 9 : 8;                   // 8-column chunks per staged input row
     constexpr int S2_SLOTS = s2_slots(KH), S2_IP = s2_ip(KH);
-    constexpr int NS = H1 ? 1 : 2;
+    constexpr int NS = s2_ns(SCH);
     constexpr int BN = 32 * WN;
     constexpr int NITI = (BN * KH * NCH + NT - 1) / NT;    // input items per thread, non-steady tile (KH rows x NCH chunks per channel)
     constexpr int DBUF = NS * S2_BM * S2_DP;               // elements of one dout buffer
@@ -113,12 +122,12 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
     };
     auto d_store = [&](int buf, const f32x4& v0, const f32x4& v1) {
         dsum += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
-        s2u32x2 h0, m0, h1, m1;
-        s2_split4<H1>(v0[0], v0[1], v0[2], v0[3], h0, m0);
-        s2_split4<H1>(v1[0], v1[1], v1[2], v1[3], h1, m1);
+        s2u32x2 p0[NS], p1[NS];
+        s2_split4<SCH>(v0[0], v0[1], v0[2], v0[3], p0);
+        s2_split4<SCH>(v1[0], v1[1], v1[2], v1[3], p1);
         _Float16* dst = s_d + buf * DBUF + dcol * S2_DP + dch * 8;
-        *reinterpret_cast<s2u32x4*>(dst) = (s2u32x4){h0[0], h0[1], h1[0], h1[1]};
-        if constexpr (!H1) *reinterpret_cast<s2u32x4*>(dst + S2_BM * S2_DP) = (s2u32x4){m0[0], m0[1], m1[0], m1[1]};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<s2u32x4*>(dst + s * S2_BM * S2_DP) = (s2u32x4){p0[s][0], p0[s][1], p1[s][0], p1[s][1]};
     };
 
     // ---- input: item = (ci row, input row r of the tile's three, 8-column chunk q of nine); chunk q holds input columns
@@ -147,14 +156,13 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
     auto i_store = [&](const f32x4& v0, const f32x4& v1, int ldsoff_) {
         if (!((ldsoff_ >> 30) & 1)) return;
         const int off = ldsoff_ & 0x0fffffff;
-        s2u32x2 eh, em, oh, om;
-        s2_split4<H1>(v0[0], v0[2], v1[0], v1[2], eh, em);
-        s2_split4<H1>(v0[1], v0[3], v1[1], v1[3], oh, om);
-        *reinterpret_cast<s2u32x2*>(s_i + off) = eh;
-        *reinterpret_cast<s2u32x2*>(s_i + off + S2_PL) = oh;
-        if constexpr (!H1) {
-            *reinterpret_cast<s2u32x2*>(s_i + BN * S2_IP + off) = em;
-            *reinterpret_cast<s2u32x2*>(s_i + BN * S2_IP + off + S2_PL) = om;
+        s2u32x2 pe[NS], po[NS];
+        s2_split4<SCH>(v0[0], v0[2], v1[0], v1[2], pe);
+        s2_split4<SCH>(v0[1], v0[3], v1[1], v1[3], po);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            *reinterpret_cast<s2u32x2*>(s_i + s * BN * S2_IP + off) = pe[s];
+            *reinterpret_cast<s2u32x2*>(s_i + s * BN * S2_IP + off + S2_PL) = po[s];
         }
     };
 
@@ -238,7 +246,10 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
         for (int r = 0; r < 16; ++r) acc[kx][r] = 0.f;
 
     auto mma = [](const s2u32x4& x, const s2u32x4& y, const f32x16& c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s2f16x8, x), __builtin_bit_cast(s2f16x8, y), c, 0, 0, 0);
+        if constexpr (SCH == S2_BX3)
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s2bf16x8, x), __builtin_bit_cast(s2bf16x8, y), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s2f16x8, x), __builtin_bit_cast(s2f16x8, y), c, 0, 0, 0);
     };
     auto mfma_tile = [&](int oy, int buf) {
 #if defined(S2_ABL) && S2_ABL == 1
@@ -271,6 +282,13 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
             if constexpr (H1) {
 #pragma unroll
                 for (int kx = 0; kx < KH; ++kx) acc[kx] = mma(af[0], bf[kx][0], acc[kx]);
+            } else if constexpr (SCH == S2_BX3) {
+                // lh hl mm mh hm hh (small cross terms first), as every 3-way bf16 kernel of the library
+                constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int kx = 0; kx < KH; ++kx) acc[kx] = mma(af[SA[pr]], bf[kx][SB[pr]], acc[kx]);
             } else {
                 // small cross terms first: m x h, h x m, h x h
 #pragma unroll
@@ -335,12 +353,13 @@ __global__ __launch_bounds__(128 * KH * WN) void wgrad_s2_kernel(WgArgs a) {
     }
 }
 
-template <int KH, int WN, bool H1>
+template <int KH, int WN, int SCH>
 int launch_s2(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
-    constexpr int NS = H1 ? 1 : 2, BN = 32 * WN;
+    constexpr int NS = s2_ns(SCH), BN = 32 * WN;
+    static_assert((size_t)(2 * NS * S2_BM * S2_DP + NS * BN * s2_ip(KH)) * 2 <= 160 * 1024, "LDS");
     const size_t lds = (size_t)(2 * NS * S2_BM * S2_DP + NS * BN * s2_ip(KH)) * 2;
     dim3 grid(N * p.spi, tdr_cdiv(a.Cout, S2_BM), tdr_cdiv(a.Cin, BN));
-    auto kern = wgrad_s2_kernel<KH, WN, H1>;
+    auto kern = wgrad_s2_kernel<KH, WN, SCH>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -355,7 +374,7 @@ int launch_s2(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
 
 bool tdr_wgrad_s2_supported(const TdrWgradDesc* d) {
     static const bool off = getenv("TDR_WG_S2") && atoi(getenv("TDR_WG_S2")) == 0;   // A/B aid: 0 = exact-fp32 kernel as before
-    if (off || d->math < 2 || d->gate) return false;
+    if (off || d->math < 1 || d->gate) return false;
     if (d->stride != 2 || !((d->KH == 3 && d->pad == 1) || (d->KH == 2 && d->pad == 0))) return false;
     if (d->H != 2 * d->OH || d->W != 2 * d->OW || d->OW < 8 || d->OW % 4 != 0) return false;
     if ((long)d->Cin * d->H * d->W >= (1L << 29) || (long)d->Cout * d->OH * d->OW >= (1L << 29)) return false;   // 32-bit buffer offsets
@@ -365,8 +384,9 @@ bool tdr_wgrad_s2_supported(const TdrWgradDesc* d) {
 WgPlan tdr_wgrad_s2_plan(const TdrWgradDesc* d) {
     WgPlan p;
     p.tw_log2 = 5;
-    p.cfg = d->Cin <= 32 ? 0 : 1;
-    p.BMc = S2_BM; p.BNc = d->Cin <= 32 ? 32 : 64;
+    // three bf16 planes (math 1): the 64-channel input ring would need 187 KB of LDS -- 32 input channels per block there (109 KB)
+    p.cfg = (d->Cin <= 32 || d->math == 1) ? 0 : 1;
+    p.BMc = S2_BM; p.BNc = p.cfg == 0 ? 32 : 64;
     p.WKw = 1;
     p.tiles_x = tdr_cdiv(d->OW, S2_C);
     p.tiles_y = d->OH;
@@ -374,7 +394,7 @@ WgPlan tdr_wgrad_s2_plan(const TdrWgradDesc* d) {
     const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
     // one round of blocks: one 12-wave workgroup (125 KB of LDS) per CU, or two of the 6-wave workgroups of the Cin <= 32 variant (73 KB)
     static const long want_env = getenv("TDR_WG_S2_WANT") ? atol(getenv("TDR_WG_S2_WANT")) : 0;
-    const long want_total = want_env > 0 ? want_env : (p.BNc == 32 ? 512 : 256);
+    const long want_total = want_env > 0 ? want_env : ((p.BNc == 32 && d->math != 1) ? 512 : 256);     // (three planes: 94 - 109 KB, one workgroup per CU)
     long want = want_total / out_tiles;
     if (want < 1) want = 1;
     long spi = (want + d->N - 1) / d->N;
@@ -387,10 +407,12 @@ WgPlan tdr_wgrad_s2_plan(const TdrWgradDesc* d) {
 
 int tdr_wgrad_s2_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st) {
     const bool h1 = a.scheme == 2;
+    if (a.scheme == 0)      // 3-way bf16 split: always the 32-input-channel blocks (tdr_wgrad_s2_plan)
+        return d->KH == 3 ? launch_s2<3, 1, S2_BX3>(a, p, d->N, st) : launch_s2<2, 1, S2_BX3>(a, p, d->N, st);
     if (d->KH == 3) {
-        if (p.cfg == 0) return h1 ? launch_s2<3, 1, true>(a, p, d->N, st) : launch_s2<3, 1, false>(a, p, d->N, st);
-        return h1 ? launch_s2<3, 2, true>(a, p, d->N, st) : launch_s2<3, 2, false>(a, p, d->N, st);
+        if (p.cfg == 0) return h1 ? launch_s2<3, 1, S2_H1>(a, p, d->N, st) : launch_s2<3, 1, S2_HX2>(a, p, d->N, st);
+        return h1 ? launch_s2<3, 2, S2_H1>(a, p, d->N, st) : launch_s2<3, 2, S2_HX2>(a, p, d->N, st);
     }
-    if (p.cfg == 0) return h1 ? launch_s2<2, 1, true>(a, p, d->N, st) : launch_s2<2, 1, false>(a, p, d->N, st);
-    return h1 ? launch_s2<2, 2, true>(a, p, d->N, st) : launch_s2<2, 2, false>(a, p, d->N, st);
+    if (p.cfg == 0) return h1 ? launch_s2<2, 1, S2_H1>(a, p, d->N, st) : launch_s2<2, 1, S2_HX2>(a, p, d->N, st);
+    return h1 ? launch_s2<2, 2, S2_H1>(a, p, d->N, st) : launch_s2<2, 2, S2_HX2>(a, p, d->N, st);
 }
