@@ -37,17 +37,33 @@ def _need_gpu():
         pytest.skip('needs a GPU')
 
 
-@pytest.fixture(scope='module')
-def world():
+# Both arithmetics of the product: 'bx3' -- the library default and the bench headline: 3-way bf16 split, 24-bit operands, fp32 range,
+# UNSCALED gradients, bf16 triple planes in the MASA encoder -- and 'hx2', the opt-in fast mode (2-way fp16 split, loss-scaled backward,
+# fp16 pair planes).  Every test below runs once per mode.
+MODES = ['bx3', 'hx2']
+
+
+def _bwd_scale(K, numel_factor):
+    """(loss scale, GRAD_SCALED) of a backward pass in the current arithmetic: bx3 runs on the raw gradients"""
+    if K.MATH == 'hx2':
+        return 2.0 ** math.floor(math.log2(512.0 * numel_factor)), True
+    return 1.0, False
+
+
+@pytest.fixture(scope='module', params=MODES)
+def world(request):
     _need_gpu()
     from textualdegremoval_amd import engine as E, kernels as K
     cfg = O.default_cfg(width=32, nf=32, enc_blk_nums=[1, 1, 1, 28], ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2])
     P = O.synth_params(cfg, seed=3)
     Pc = {k: v.cuda() for k, v in P.items()}
     prev = K.MATH
-    K.set_math('hx2')
+    K.set_math(request.param)
     yield E, K, cfg, P, Pc
     K.set_math(prev)
+
+
+_BS4_ORACLE = {}
 
 
 def psnr(a, b):
@@ -151,8 +167,8 @@ def test_full_size_gradients_against_oracle(world, monkeypatch):
     through the oracle, the oracle following the HIP match decisions as above (the selected cosine stays differentiable)."""
     E, K, cfg, P, Pc = world
     lq, gt, ref = O.synth_pair(1, SIZE, SIZE, seed=81)
-    S = 2.0 ** math.floor(math.log2(512.0 * 3 * SIZE * SIZE))
-    prev = K.set_grad_scaled(True)
+    S, scaled = _bwd_scale(K, 3 * SIZE * SIZE)
+    prev = K.set_grad_scaled(scaled)
     try:
         out, saved = E.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
         loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0, grad_scale=S)
@@ -187,8 +203,8 @@ def test_full_size_batch4_against_oracle(world, monkeypatch):
     E, K, cfg, P, Pc = world
     B = 4
     lq, gt, ref = O.synth_pair(B, SIZE, SIZE, seed=83)
-    S = 2.0 ** math.floor(math.log2(512.0 * B * 3 * SIZE * SIZE))
-    prev = K.set_grad_scaled(True)
+    S, scaled = _bwd_scale(K, B * 3 * SIZE * SIZE)
+    prev = K.set_grad_scaled(scaled)
     try:
         out, saved = E.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
         loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0, grad_scale=S)
@@ -218,11 +234,16 @@ def test_full_size_batch4_against_oracle(world, monkeypatch):
 
     monkeypatch.setattr(O, 'coarse_search', cs)
     monkeypatch.setattr(O, 'fine_search', fs)
-    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    ro = O.nafnet_ref_forward(Pr, cfg, lq, ref)
-    rl = O.l1_loss(ro, gt)
-    rl.backward()
-    _log('bs=4 match decisions (mismatches, total, largest oracle score gap at a mismatch):', seen)
+    # the oracle pass (minutes on the host cores) is shared by the two arithmetic modes when it follows the same match decisions
+    key = (hip_index.numpy().tobytes(), hip_index_all.numpy().tobytes())
+    if _BS4_ORACLE.get('key') != key:
+        Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        ro = O.nafnet_ref_forward(Pr, cfg, lq, ref)
+        rl = O.l1_loss(ro, gt)
+        rl.backward()
+        _BS4_ORACLE.update(key=key, Pr=Pr, ro=ro.detach(), rl=rl.detach(), seen=dict(seen))
+    Pr, ro, rl, seen = _BS4_ORACLE['Pr'], _BS4_ORACLE['ro'], _BS4_ORACLE['rl'], _BS4_ORACLE['seen']
+    _log(f'[{K.MATH}] bs=4 match decisions (mismatches, total, largest oracle score gap at a mismatch):', seen)
     assert seen['coarse'][0] <= 4 and seen['coarse'][2] < 1e-5, seen
     assert seen['fine'][0] <= 32 and seen['fine'][2] < 1e-5, seen
     o = out.cpu()
@@ -260,10 +281,12 @@ def test_full_size_split_arithmetic_against_exact_fp32(world):
     lq, ref, gtc = lq.cuda(), ref.cuda(), gt.cuda()
     out, _ = E.net_fwd(Pc, cfg, lq, ref)
     K.set_math('f32')
+    mode = K.MATH
+    K.set_math('f32')
     try:
         exact, _ = E.net_fwd(Pc, cfg, lq, ref)
     finally:
-        K.set_math('hx2')
+        K.set_math(mode)
     assert (out - exact).abs().max().item() < 1e-4
     assert abs(psnr(out.clamp(0, 1), gtc) - psnr(exact.clamp(0, 1), gtc)) < 1e-3
 
@@ -280,8 +303,29 @@ def _grads(E, K, cfg, Pc, lq, ref, gt, lw, gs):
     return loss.item(), G
 
 
+def test_full_size_unscaled_backward_is_linear_in_the_loss_weight(world):
+    """bx3 (default arithmetic): no loss scale exists; every backward kernel is linear and a power of two commutes with the 3-way bf16
+    split bit for bit, so 2x the loss weight is 2x every gradient -- exactly, except behind transfer_bwd's float atomics"""
+    E, K, cfg, P, Pc = world
+    if K.MATH != 'bx3':
+        pytest.skip('the unscaled backward pass is the bx3 arithmetic')
+    lq, gt, ref = O.synth_pair(4, SIZE, SIZE, seed=80)
+    lq, ref, gt = lq.cuda(), ref.cuda(), gt.cuda()
+    l1, G1 = _grads(E, K, cfg, Pc, lq, ref, gt, 1.0, 1.0)
+    l2, G2 = _grads(E, K, cfg, Pc, lq, ref, gt, 2.0, 1.0)
+    assert l2 == 2.0 * l1
+    for k, g1 in G1.items():
+        assert torch.isfinite(g1).all(), k
+        if k.startswith('masa_enc.'):
+            assert (G2[k] - 2.0 * g1).abs().max().item() <= 1e-5 * 2.0 * max(g1.abs().max().item(), 1e-30), k
+        else:
+            assert torch.equal(G2[k], 2.0 * g1), k
+
+
 def test_full_size_loss_scaled_backward(world):
     E, K, cfg, P, Pc = world
+    if K.MATH != 'hx2':
+        pytest.skip('the loss-scaled backward pass is the hx2 arithmetic')
     lq, gt, ref = O.synth_pair(4, SIZE, SIZE, seed=80)
     lq, ref, gt = lq.cuda(), ref.cuda(), gt.cuda()
     S = 2.0 ** math.floor(math.log2(512.0 * lq.shape[0] * 3 * SIZE * SIZE))
@@ -304,8 +348,8 @@ def test_full_size_loss_scaled_backward(world):
 
 
 # ------------------------------------------------------------------ Restormer-ref at configs[2]'s per-GPU shapes (dim 48, 256x256)
-@pytest.fixture(scope='module')
-def rworld():
+@pytest.fixture(scope='module', params=MODES)
+def rworld(request):
     _need_gpu()
     from oracle import restormer_ref_oracle as RO
     from textualdegremoval_amd import kernels as K, restormer_engine as R
@@ -314,7 +358,7 @@ def rworld():
     P = RO.synth_params(cfg, seed=5)
     Pc = {k: v.cuda() for k, v in P.items()}
     prev = K.MATH
-    K.set_math('hx2')
+    K.set_math(request.param)
     yield R, RO, K, cfg, P, Pc
     K.set_math(prev)
 
@@ -366,11 +410,12 @@ def test_restormer_full_size_properties(rworld):
     perm = [5, 2, 7, 0, 3, 6, 1, 4]
     outp, _ = R.net_fwd(Pc, cfg, lq[perm].contiguous(), ref[perm].contiguous())
     assert torch.equal(outp, out[perm])
+    mode = K.MATH
     K.set_math('f32')
     try:
         exact, _ = R.net_fwd(Pc, cfg, lq, ref)
     finally:
-        K.set_math('hx2')
+        K.set_math(mode)
     assert (out - exact).abs().max().item() < 1e-4
     assert abs(psnr(out.clamp(0, 1), gtc) - psnr(exact.clamp(0, 1), gtc)) < 1e-3
 
@@ -378,8 +423,8 @@ def test_restormer_full_size_properties(rworld):
 def test_restormer_full_size_gradients_against_oracle(rworld, monkeypatch):
     R, RO, K, cfg, P, Pc = rworld
     lq, gt, ref = O.synth_pair(1, 256, 256, seed=93)
-    S = 2.0 ** math.floor(math.log2(512.0 * 3 * 256 * 256))
-    prev = K.set_grad_scaled(True)
+    S, scaled = _bwd_scale(K, 3 * 256 * 256)
+    prev = K.set_grad_scaled(scaled)
     try:
         out, saved = R.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
         loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0, grad_scale=S)
@@ -455,11 +500,12 @@ def test_restormer_configs4_shapes_512_batch2(rworld, monkeypatch):
     out, saved = R.net_fwd(Pc, cfg, lq, ref)
     outp, _ = R.net_fwd(Pc, cfg, lq[[1, 0]].contiguous(), ref[[1, 0]].contiguous())
     assert torch.equal(outp, out[[1, 0]])
+    mode = K.MATH
     K.set_math('f32')
     try:
         exact, saved_x = R.net_fwd(Pc, cfg, lq, ref)
     finally:
-        K.set_math('hx2')
+        K.set_math(mode)
     d = (out - exact).abs()
     flips = (saved[6][7] != saved_x[6][7]).sum().item() + (saved[6][4] != saved_x[6][4]).sum().item()
     _log(f'restormer 512x512 bs 2: fp16 split vs exact fp32: max {d.max().item():.2e} mean {d.mean().item():.2e}, {flips} of 8320 match decisions differ')
@@ -477,6 +523,8 @@ def test_restormer_configs4_shapes_512_batch2(rworld, monkeypatch):
                 (i, di.max().item(), di.mean().item())
     assert abs(psnr(out.clamp(0, 1), gtc) - psnr(exact.clamp(0, 1), gtc)) < 1e-3
     del exact, outp, saved_x
+    if K.MATH != 'hx2':
+        return                 # (the scaled-vs-unscaled comparison below is about the fast mode's loss scale)
     Sg = 2.0 ** math.floor(math.log2(512.0 * 2 * 3 * S512 * S512))
     grads = []
     for gs in (1.0, Sg):

@@ -946,13 +946,13 @@ extern "C" int tdr_p16_to_f32(const void* src, int N, int C, int H, int W, float
 
 static int p16_env_cfg() {
     const int c = getenv("TDR_P16_CFG") ? atoi(getenv("TDR_P16_CFG")) : 0;
-    return (c >= 100 && c < 300 && !getenv("TDR_PROBES")) ? 0 : c;
+    return (((c >= 100 && c < 300) || c >= 400) && !getenv("TDR_PROBES")) ? 0 : c;
 }
 static int g_p16_cfg = p16_env_cfg();
 extern "C" int tdr_conv3x3_p16_force_cfg(int cfg) {
     // 100 .. 299 are timing ablations that compute WRONG results (profiles/probe_conv_p16.py): never reachable from a product process
     static const bool probes = getenv("TDR_PROBES") != nullptr;
-    TDR_REQUIRE(probes || cfg < 100 || cfg >= 300, "tdr_conv3x3_p16_force_cfg: configuration %d is a timing ablation (set TDR_PROBES=1)", cfg);
+    TDR_REQUIRE(probes || cfg < 100 || (cfg >= 300 && cfg < 400), "tdr_conv3x3_p16_force_cfg: configuration %d is a timing ablation (set TDR_PROBES=1)", cfg);
     g_p16_cfg = cfg;
     return TDR_OK;
 }
@@ -985,7 +985,16 @@ extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
         // triple planes (TDR_MATH=bx3).  Tile configurations (forced ones: 301 ..): see profiles/r5/probe_p24*.log
         constexpr int T = PF_TRI;
         if (cfg < 300) cfg = 0;
-        if (cfg == 0) cfg = 301;
+        if (cfg == 0) {
+            // profiles/r5/probe_p24_v1.log / probe_p24_abl.log (N = 8, C = 64 .. 512 at 256^2 .. 32^2): the pure MFMA stream of a launch is
+            // 126 - 140 us (232 GFLOP of products at the sustained ~1.75 PFLOP/s), LDS-DMA issue adds 13 - 24, fragment reads 6 - 11, the
+            // epilogue 10 - 54 (it is HBM-write-bound at C = 64 and nothing overlaps it with one workgroup per CU).  Per level the best:
+            // C <= 64: 64 x (4 x 32) with two workgroups per CU (220 vs 238 us); 128 x (8 x 32) on 8 waves where that still fills the
+            // chip (176 / 160 vs 191 / 170 us at C = 128 / 256); else 64 x (8 x 32) (C = 512 @ 32^2: 160 us, 256 workgroups)
+            if (d->Cout <= 64) cfg = 303;
+            else if (d->Cout % 128 == 0 && blocks(128, 8) >= 256) cfg = 302;
+            else cfg = 301;
+        }
         switch (cfg) {
             //                         TM TN WM WN PIPE ABL ILV
             case 301: return launch_p16<2, 2, 1, 4, true, 0, true, T>(a, N, st);     //  64 x (8 x 32), 4 waves (89 KiB: one workgroup per CU)
@@ -997,6 +1006,20 @@ extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
             case 311: return launch_p16<2, 2, 1, 4, true, 0, false, T>(a, N, st);    // 301 without the interleaved issue order
             case 312: return launch_p16<2, 2, 2, 4, true, 0, false, T>(a, N, st);
             case 321: return launch_p16<2, 2, 1, 4, false, 0, false, T>(a, N, st);   // 301 without pipelined fragments
+            // timing ablations of 301 / 302 (wrong results; TDR_PROBES only): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no barrier, 8 no MFMAs, 16 no epilogue
+            case 401: return launch_p16<2, 2, 1, 4, true, 1, true, T>(a, N, st);
+            case 402: return launch_p16<2, 2, 1, 4, true, 2, true, T>(a, N, st);
+            case 403: return launch_p16<2, 2, 1, 4, true, 3, true, T>(a, N, st);
+            case 404: return launch_p16<2, 2, 1, 4, true, 4, true, T>(a, N, st);
+            case 407: return launch_p16<2, 2, 1, 4, true, 7, true, T>(a, N, st);
+            case 408: return launch_p16<2, 2, 1, 4, true, 8, true, T>(a, N, st);
+            case 416: return launch_p16<2, 2, 1, 4, true, 16, true, T>(a, N, st);
+            case 423: return launch_p16<2, 2, 1, 4, true, 23, true, T>(a, N, st);
+            case 431: return launch_p16<2, 2, 1, 4, true, 31, true, T>(a, N, st);
+            case 501: return launch_p16<2, 2, 2, 4, true, 1, true, T>(a, N, st);
+            case 507: return launch_p16<2, 2, 2, 4, true, 7, true, T>(a, N, st);
+            case 516: return launch_p16<2, 2, 2, 4, true, 16, true, T>(a, N, st);
+            case 523: return launch_p16<2, 2, 2, 4, true, 23, true, T>(a, N, st);
             default: break;
         }
         tdr_set_error("tdr_conv3x3_p16: unknown triple-plane tile configuration %d", cfg);

@@ -68,9 +68,23 @@ _late = None            # [(prefix, closure -> {name: grad})] while a whole-netw
 _late_pre = ''
 
 
+# RULE for queued leaves: a leaf reads its operands (`keep`, and whatever its closure names) when run_late_leaves() runs it -- after
+# the whole main backward chain.  Nothing may write those tensors in place (K.add_ and friends) or rebind the closure's names between
+# queueing and the run; every operand must be listed in `keep`.  TDR_DEBUG_LEAVES=1 checks the tensors' version counters at run time.
+DEBUG_LEAVES = os.environ.get('TDR_DEBUG_LEAVES', '0') == '1'
+
+
 def _leaf(keep, fn, G):
     """run a parameter-gradient leaf now (optionally on the side stream), or queue it for the deferred pass"""
     if _late is not None:
+        if DEBUG_LEAVES:
+            stamp = [(t, t._version) for t in keep if torch.is_tensor(t)]
+            inner = fn
+
+            def fn():
+                for t, v in stamp:
+                    assert t._version == v, 'a queued weight-gradient operand was modified in place before its deferred leaf ran'
+                return inner()
         _late.append((_late_pre, fn, keep))
         return
     with K.on_side(*keep):

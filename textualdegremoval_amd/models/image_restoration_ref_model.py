@@ -344,10 +344,13 @@ class RefGuidedImageCleanModel(BaseModel):
                     seen = {bi for _, bi in segs if bi is not None}
                     missing = red.uncovered_buckets() or sorted(set(range(len(red.buckets))) - seen)
                     if missing:
-                        logger.warning(f'captured step: gradient bucket(s) {missing} were not completed by the backward pass '
-                                       '(a parameter without a gradient): falling back to one flat all-reduce of the arena')
-                        split = False
-                        segs = [(g, None) for g, _ in segs]
+                        # An incomplete bucket was never GATHERED either: its arena slice still holds whatever an earlier step left there,
+                        # and a flat all-reduce of the arena would hand those stale numbers to AdamW on every replay (consistent across
+                        # ranks, and wrong).  No silent fallback: a trainable parameter that receives no gradient is a configuration error.
+                        names = [n for bi in missing for n in red.buckets[bi][2] if n not in getattr(red, '_pending', {})]
+                        raise RuntimeError(f'captured step: gradient bucket(s) {missing} were not completed by the backward pass -- '
+                                           f'no gradient arrived for {names[:8]}{" ..." if len(names) > 8 else ""}; freeze those parameters '
+                                           '(requires_grad=False) or run with TDR_GRAPH_BUCKETS=0 / TDR_GRAPH=0')
                 self.optimizer_g.prepare()
                 gB = torch.cuda.CUDAGraph()
                 gB.capture_begin(pool=pool, capture_error_mode='thread_local')

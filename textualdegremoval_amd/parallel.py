@@ -95,12 +95,14 @@ class _BringUpWatchdog:
     """A rank that dies INSIDE the bring-up (ncclCommInitRank, or one of the side-channel collectives around it) leaves its peers
     blocked in a call that never returns -- the MIN-agreements below only cover failures that come back as errors.  While this
     context is open a timer thread ends the process with ONE line on stderr and exit code 3 when the bring-up has not finished
-    within TDR_COMM_INIT_TIMEOUT seconds (default 45): every surviving rank does so on its own, so `python bench.py --gpus N`
+    within TDR_COMM_INIT_TIMEOUT seconds (default 180 + 8 per rank): every surviving rank does so on its own, so `python bench.py --gpus N`
     (torch.distributed.run) is down within a minute instead of hanging until torch's 10 - 30 minute collective timeout."""
 
     def __init__(self, rank, world, what):
         self.rank, self.world, self.what = rank, world, what
-        self.timeout = float(os.environ.get('TDR_COMM_INIT_TIMEOUT', '45'))
+        # default: minutes, growing with the job -- ncclCommInitRank on many ranks (topology detection, a slow fabric or file system)
+        # legitimately takes far longer than a two-rank bring-up, and the exit below is hard (no cleanup)
+        self.timeout = float(os.environ.get('TDR_COMM_INIT_TIMEOUT', str(180 + 8 * int(world))))
         self.stage = 'start'
         self._timer = None
 
@@ -126,10 +128,13 @@ class _BringUpWatchdog:
         return False
 
 
+_FAULT_SPEC = os.environ.get('TDR_FAULT')      # read once at import: the production path pays one `is None` per bring-up
+
+
 def _fault(point, rank):
     """fault injection for the bring-up tests (tests/test_dp_bringup_faults.py): TDR_FAULT=<point>:<rank>[:hang] makes that rank
     fail (raise) or hang (sleep past the watchdog) at `point` in {unique_id, init}.  Never set in production."""
-    spec = os.environ.get('TDR_FAULT')
+    spec = _FAULT_SPEC
     if not spec:
         return
     parts = spec.split(':')
@@ -244,13 +249,15 @@ CAP_RING = 4          # capture passes whose pinned gather tables stay untouched
 
 
 class GradAllReducer:
-    def __init__(self, named_params, bucket_mb=64, process_group=None):
+    def __init__(self, named_params, bucket_mb=64, process_group=None, local_only=False):
+        """local_only: this trainer keeps its gradients to itself even under a launcher -- decided BEFORE the RCCL bring-up, so no
+        communicator is created (and none of its side-channel collectives is issued) for a reducer that will never exchange"""
         self.named = list(named_params)                  # [(name, param)] in registration order
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         # single-rank process groups normally skip the collectives; TDR_FORCE_COLLECTIVES=1 issues them anyway (a 1-GPU box
         # then exercises the RCCL calls, the comm stream and their interplay with hipGraph capture -- tests/test_hip_dp_smoke.py)
-        self.collective = self.world > 1 or (os.environ.get('TDR_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized())
+        self.collective = (not local_only) and (self.world > 1 or (os.environ.get('TDR_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized()))
         self.comm = data_plane(process_group) if self.collective else None      # RCCL through the C ABI (tdr_comm_*)
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.order = None                                # arrival order (fixed after the first step)

@@ -124,7 +124,7 @@ class I2TMappingTrainer:
     1e-2, eps 1e-8, constant schedule, clip_grad_norm_ 1.0."""
 
     def __init__(self, clip_state_dict, clip_heads, stub, clip_act='gelu', num_words=20, lr=1e-4, betas=(0.9, 0.999),
-                 weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0, device='cuda', levels=LEVELS, mapper=None, dist_on=False,
+                 weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0, device='cuda', levels=LEVELS, mapper=None, dist_on=None,
                  bucket_mb=64, use_hip_graph=None, clip_image_size=224):
         if not torch.cuda.is_available():
             raise RuntimeError('I2TMappingTrainer: the HIP path needs an MI355X; there is no CPU fallback')
@@ -149,13 +149,22 @@ class I2TMappingTrainer:
         self.optimizer = FusedClipAdamW([{'params': self.params}], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                         max_norm=max_grad_norm, use_grad_clip=True)
         # dist_on: average the gradients over the ranks of the initialised process group (accelerate's DDP over the Mapper, :662).
-        # True without a process group is an error; False keeps this trainer local even under a launcher.
+        # None (default): exactly when a process group of more than one rank exists -- as accelerate does; True without a process
+        # group is an error; False keeps this trainer local even under a launcher, and says so once (unsynchronised replicas are
+        # almost never what a torchrun launch wants).  Decided BEFORE the reducer exists: a local trainer never brings RCCL up.
+        pg_up = torch.distributed.is_available() and torch.distributed.is_initialized()
+        pg_world = torch.distributed.get_world_size() if pg_up else 1
+        if dist_on is None:
+            dist_on = pg_world > 1
         self.dist = bool(dist_on)
-        if self.dist and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        if self.dist and not pg_up:
             raise RuntimeError('I2TMappingTrainer(dist_on=True): torch.distributed is not initialised')
-        self.reducer = GradAllReducer(list(zip(self.names, self.params)), bucket_mb=bucket_mb)
-        if not self.dist and os.environ.get('TDR_FORCE_COLLECTIVES') != '1':
-            self.reducer.collective, self.reducer.comm = False, None
+        if not self.dist and pg_world > 1:
+            import warnings
+            warnings.warn(f'I2TMappingTrainer(dist_on=False) inside a process group of {pg_world} ranks: gradients are NOT averaged, '
+                          'every rank trains its own replica', RuntimeWarning, stacklevel=2)
+        self.reducer = GradAllReducer(list(zip(self.names, self.params)), bucket_mb=bucket_mb,
+                                      local_only=not self.dist and os.environ.get('TDR_FORCE_COLLECTIVES') != '1')
         self._plan = K.PackPlan()
         # the Mapper as G-way grouped GEMMs over batch-flattened tokens (i2t.mapper_fwd_grouped); TDR_MAPPER_GROUPED=0 keeps the
         # 2 x num_words chains of small launches on four stream lanes
