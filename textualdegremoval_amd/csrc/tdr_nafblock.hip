@@ -192,6 +192,9 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     constexpr int NOCT = C / 8;               // octets of the K = C operands
     constexpr int NG = C / 16;
     constexpr int NW = C / 32;
+    // three planes at the 256-register limit: tiles that only wait for their side stores inside the next GEMM get spilled, and a spill
+    // reload behind queued global stores waits for every one of them (vmcnt is in order) -- there the saved tensors leave right away
+    constexpr bool EARLY_STORES = SCH == SCH_BX3 && C >= 64;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     uint4* sB = smem4;                                        // NS planes x NOCT x 64 px x 16 B = 64 / 96 KiB at C = 256
     float* red = reinterpret_cast<float*>(smem4 + NS * NOCT * NPX);   // [2][8 waves][64 px]
@@ -307,6 +310,15 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ynv[tn][r] = (yv[tn][r] - mean[tn]) * rstd[tn] * lw[r] + lb[r];
             tile_to_planes<SCH>(ynv[tn], sB, NOCT, 4 * wave, 32 * tn + j, kk);
+            if constexpr (EARLY_STORES) {
+                float* yp = a.y + (long)n * a.y_ns + p0 + j;
+                float* ynp = a.yn + (long)n * a.yn_ns + p0 + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    yp[off(r, tn)] = yv[tn][r];
+                    ynp[off(r, tn)] = ynv[tn][r];
+                }
+            }
         }
     }
     __syncthreads();
@@ -324,6 +336,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         float* ynp = a.yn + (long)n * a.yn_ns + p0 + j;
         gemm_split<SCH, 2, NG, 2>(acc4, a.w4, 2 * C / 32, [&](int tm) { return tm * (C / 32) + wave; }, sB, NOCT, lane, rot, [&](int g) {
             // 64 dword stores (y, yn: 2 sub-tiles x 16 rows each) spread evenly over the NG groups
+            if constexpr (EARLY_STORES) return;
             constexpr int IPG = 32 / NG;
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -363,12 +376,21 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     // ---- conv5: out = (W5 gate + b5) * gamma + y ; the t4 tile leaves for HBM under its MFMAs.  Only the first c_out rows
     // exist (fusion blocks keep `[:, :chan]`): the waves above them just store their t4 tiles.
     float* tp = a.t4 + (long)n * a.t4_ns + p0 + j;
+    if constexpr (EARLY_STORES) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tp[(long)tm * C * HW + off(r, tn)] = acc4[tm][tn][r];
+    }
     if (m0 < a.c_out) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
         gemm_split<SCH, 1, NG, 2>(acc, a.w5, a.c_out / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [&](int g) {
+            if constexpr (EARLY_STORES) return;
             constexpr int IPG = 64 / NG;                                         // 64 stores spread evenly over the NG groups
 #pragma unroll
             for (int e = 0; e < IPG; ++e) {
@@ -381,7 +403,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) op[off(r, tn)] = (acc[0][tn][r] + b5v[r]) * gav[r] + yv[tn][r];
-    } else {
+    } else if constexpr (!EARLY_STORES) {
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
