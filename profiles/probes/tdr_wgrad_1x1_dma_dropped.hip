@@ -1,0 +1,283 @@
+// Weight gradient of the 1x1 convolutions (the NAFBlock chains: conv1 / conv3 / conv4 / conv5, ups; reference
+// models/archs/network_nafnet_guided_arch.py:183-205,216-238 and their autograd) with a DECOUPLED operand stream, gfx950.
+//
+//   G[co][ci] = sum_{n, pixel} dout[n][co][pixel] * x[n][ci][pixel]            (GATE: x[ci] * x[Cin + ci], SimpleGate input of conv5)
+//
+// Both operands are fp32 [C][HW] rows with the contraction index (the pixel) contiguous, so an MFMA fragment (lane = channel row,
+// 8 consecutive k) is 32 contiguous bytes of one row.  The round 1-4 kernel (wgrad_bx3_kernel<KH = 1>, tdr_wgrad_bx3.hip) staged a
+// 32-pixel tile as [barrier, split every value into planes + write them to LDS, barrier, 48 MFMAs per wave] with the next tile's
+// loads held in registers: the two phases never overlap inside a workgroup and a tile took ~5 us against 0.8 us of matrix work
+// (45 us per 512 x 256 @ 64^2 launch, the largest family of the step).  Here:
+//   * the RAW fp32 rows of a 32-pixel stage (BM + BN rows x 128 B) go to an LDS ring by LDS-DMA (global_load_lds_dwordx4: no VGPRs,
+//     no VALU, issued a whole stage ahead, waited for with a counted vmcnt) -- coalesced 128-byte row segments, the 16-byte
+//     chunks of a row XOR-permuted by (row >> 1) & 7 on the GLOBAL side so that the lane-linear LDS image is conflict-free for
+//   * the fragment reads: each wave reads its own raw fragments (2 x ds_read_b128 per fragment), splits them IN REGISTERS
+//     (3 x bf16: 44 VALU per fragment, or 2 x fp16) and feeds the MFMAs directly -- no plane writes, one barrier per stage, and
+//     the split VALU of a wave runs in the shadow of its own / its SIMD partner's MFMAs.
+// Same products, same partial layout ([split][co][ci]) and the same fixed-order reduction as the other weight-gradient kernels
+// (tdr_wgrad_mfma.hip reduces; deterministic).  The bias gradient rides along as per-lane sums of the dout fragments.
+#include "tdr_common.h"
+#include "tdr_wgrad_common.h"
+#include "../../include/tdr.h"
+#include <stdlib.h>
+
+typedef __bf16 g1bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 g1f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned g1u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+enum { G1_BX3 = 0, G1_HX2 = 1 };      // WgArgs.scheme: 3-way bf16 split (6 products) / 2-way fp16 split (3 products)
+
+constexpr int G1_PX = 32;             // pixels per stage (two k-steps of 16)
+
+// one fragment: 8 consecutive fp32 values of a row -> NS packed 16-bit planes
+template <int SCH>
+__device__ __forceinline__ void g1_split8(const f32x4& a, const f32x4& b, g1u32x4 (&p)[SCH == G1_BX3 ? 3 : 2]) {
+    if constexpr (SCH == G1_BX3) {
+        unsigned h[4], m[4], l[4];
+        tdr_split3_bf16<false>(a[0], a[1], h[0], m[0], l[0]);
+        tdr_split3_bf16<false>(a[2], a[3], h[1], m[1], l[1]);
+        tdr_split3_bf16<false>(b[0], b[1], h[2], m[2], l[2]);
+        tdr_split3_bf16<false>(b[2], b[3], h[3], m[3], l[3]);
+        p[0] = (g1u32x4){h[0], h[1], h[2], h[3]};
+        p[1] = (g1u32x4){m[0], m[1], m[2], m[3]};
+        p[2] = (g1u32x4){l[0], l[1], l[2], l[3]};
+    } else {
+        unsigned h[4], m[4];
+        tdr_split2_f16<false>(a[0], a[1], h[0], m[0]);
+        tdr_split2_f16<false>(a[2], a[3], h[1], m[1]);
+        tdr_split2_f16<false>(b[0], b[1], h[2], m[2]);
+        tdr_split2_f16<false>(b[2], b[3], h[3], m[3]);
+        p[0] = (g1u32x4){h[0], h[1], h[2], h[3]};
+        p[1] = (g1u32x4){m[0], m[1], m[2], m[3]};
+    }
+}
+
+// LDS-DMA by inline asm: hipcc's own bookkeeping would put s_waitcnt vmcnt(0) in front of every LDS read that follows a builtin
+// LDS-DMA; issued this way the pieces are waited for by the counted vmcnt in front of the stage barrier only
+__device__ __forceinline__ void g1_glds(const char* src, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_byte_addr) : "memory");
+}
+
+// Workgroup = 2 x 2 waves, wave (wm, wn) owns TMW x TNW 32 x 32 tiles: BM = 64 TMW output channels x BN = 64 TNW input channels.
+// RING stages of raw rows in LDS: stage s lives in slot s % RING.
+template <int TMW, int TNW, bool GATE, int SCH, int RING>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(WgArgs a) {
+    constexpr int NS = SCH == G1_BX3 ? 3 : 2, NP = SCH == G1_BX3 ? 6 : 3;
+    constexpr int BM = 64 * TMW, BN = 64 * TNW, NB = GATE ? 2 : 1;
+    constexpr int ROWS = BM + NB * BN;                 // raw rows per stage: dout rows | input rows | (gate partners)
+    constexpr int STAGE = ROWS * 128;                  // bytes
+    constexpr int PIECES = ROWS / 8;                   // 1 KiB LDS-DMA instructions per stage (8 rows x 128 B each)
+    static_assert(PIECES % 4 == 0, "every wave issues the same number of pieces");
+    constexpr int PPW = PIECES / 4;
+    static_assert(RING == 2 || RING == 3, "ring of 2 or 3 stages");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int j = lane & 31, kg = lane >> 5;
+
+    const int split = blockIdx.x;
+    const int n = split / a.spi;
+    const int s_begin = (split % a.spi) * a.tps;                // stages (32 pixels each) of this block: [s_begin, s_end)
+    const int s_end = min(s_begin + a.tps, a.tpi);
+    const int nst = s_end - s_begin;
+    const int co0 = blockIdx.y * BM, ci0 = blockIdx.z * BN;
+    const long HW = (long)a.OH * a.OW;
+    const float* in_n = a.in + (long)n * a.in_ns;
+    const float* do_n = a.dout + (long)n * a.dout_ns;
+
+    // ---- LDS-DMA sources of this thread: piece q = i * 4 + wave covers stage rows 8q .. 8q + 7; lane -> (row 8q + lane / 8,
+    // LDS chunk position lane % 8), which holds GLOBAL chunk (position ^ ((row >> 1) & 7)) of that row's 32 pixels
+    const char* src[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int row = 8 * (i * 4 + wave) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const float* base;
+        if (row < BM) base = do_n + (long)min(co0 + row, a.Cout - 1) * HW;
+        else if (row < BM + BN) base = in_n + (long)min(ci0 + row - BM, a.Cin - 1) * HW;
+        else base = in_n + (long)min(ci0 + row - BM - BN, a.Cin - 1) * HW + a.gate_off;
+        src[i] = reinterpret_cast<const char*>(base + (long)s_begin * G1_PX + 4 * c);
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    auto issue = [&](int s) {                                   // stage s (relative to s_begin) -> slot s % RING
+        const unsigned dst = lds0 + (unsigned)((s % RING) * STAGE) + (unsigned)(wave * 1024);
+        const long adv = (long)s * (G1_PX * 4);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) g1_glds(src[i] + adv, __builtin_amdgcn_readfirstlane(dst + i * 4096));
+    };
+
+    // ---- fragment addresses inside a stage: row r, pixels 16 u + 8 kg .. + 7 = chunks 4u + 2kg, 4u + 2kg + 1
+    int a_off[TMW], b_off[TNW], a_sw[TMW], b_sw[TNW];
+#pragma unroll
+    for (int x = 0; x < TMW; ++x) {
+        const int r = (wm * TMW + x) * 32 + j;
+        a_off[x] = r * 128; a_sw[x] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int y = 0; y < TNW; ++y) {
+        const int r = BM + (wn * TNW + y) * 32 + j;
+        b_off[y] = r * 128; b_sw[y] = (r >> 1) & 7;
+    }
+
+    f32x16 acc[TMW][TNW];
+#pragma unroll
+    for (int x = 0; x < TMW; ++x)
+#pragma unroll
+        for (int y = 0; y < TNW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    float dsum[TMW];
+#pragma unroll
+    for (int x = 0; x < TMW; ++x) dsum[x] = 0.f;
+    const bool want_db = a.dbpart != nullptr && blockIdx.z == 0 && wn == 0;      // wave-uniform
+
+    constexpr int SA[6] = {SCH == G1_HX2 ? 1 : 2, 0, SCH == G1_HX2 ? 0 : 1, 1, 0, 0};      // hx2: mh hm hh ; bx3: lh hl mm mh hm hh
+    constexpr int SB[6] = {0, SCH == G1_HX2 ? 1 : 2, SCH == G1_HX2 ? 0 : 1, 0, 1, 0};
+    auto mma = [](const g1u32x4& x, const g1u32x4& y, const f32x16& c) {
+        if constexpr (SCH == G1_BX3)
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g1bf16x8, x), __builtin_bit_cast(g1bf16x8, y), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(g1f16x8, x), __builtin_bit_cast(g1f16x8, y), c, 0, 0, 0);
+    };
+
+    // ---- prologue: RING - 1 stages in flight
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s)
+        if (s < nst) issue(s);
+
+    for (int s = 0; s < nst; ++s) {
+        // stage s has landed (this wave's pieces: everything but the youngest RING - 2 stages), then every wave's (barrier); the
+        // barrier also says every wave is done reading stage s - 1, whose slot the next issue overwrites
+        if (RING == 3 && s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + RING - 1 < nst) issue(s + RING - 1);
+        const unsigned char* st = smem_raw + (s % RING) * STAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c0 = 4 * u + 2 * kg;
+            g1u32x4 af[TMW][NS], bf[TNW][NS];
+#pragma unroll
+            for (int x = 0; x < TMW; ++x) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + a_off[x] + ((c0 ^ a_sw[x]) << 4));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + a_off[x] + (((c0 + 1) ^ a_sw[x]) << 4));
+                if (want_db) dsum[x] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+                g1_split8<SCH>(v0, v1, af[x]);
+            }
+#pragma unroll
+            for (int y = 0; y < TNW; ++y) {
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(st + b_off[y] + ((c0 ^ b_sw[y]) << 4));
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(st + b_off[y] + (((c0 + 1) ^ b_sw[y]) << 4));
+                if constexpr (GATE) {
+                    // the gate partner row sits BN rows further: same (row >> 1) & 7 (BN is a multiple of 16), same chunk positions
+                    v0 *= *reinterpret_cast<const f32x4*>(st + b_off[y] + BN * 128 + ((c0 ^ b_sw[y]) << 4));
+                    v1 *= *reinterpret_cast<const f32x4*>(st + b_off[y] + BN * 128 + (((c0 + 1) ^ b_sw[y]) << 4));
+                    asm volatile("" : "+v"(v0), "+v"(v1));          // every plane from the same rounded product
+                }
+                g1_split8<SCH>(v0, v1, bf[y]);
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int x = 0; x < TMW; ++x)
+#pragma unroll
+                    for (int y = 0; y < TNW; ++y) acc[x][y] = mma(af[x][SA[p]], bf[y][SB[p]], acc[x][y]);
+        }
+    }
+
+    // ---- bias gradient partial: row j of tile x = the two lane halves' sums (fixed order)
+    if (want_db) {
+#pragma unroll
+        for (int x = 0; x < TMW; ++x) {
+            const float t = dsum[x] + __shfl_xor(dsum[x], 32, 64);
+            const int co = co0 + (wm * TMW + x) * 32 + j;
+            if (kg == 0 && co < a.Cout) a.dbpart[(long)split * a.Cout + co] = t;
+        }
+    }
+    // ---- partial[split][co][ci]
+    float* part = a.part + (long)split * a.Cout * a.Cin;
+#pragma unroll
+    for (int x = 0; x < TMW; ++x)
+#pragma unroll
+        for (int y = 0; y < TNW; ++y) {
+            const int ci = ci0 + (wn * TNW + y) * 32 + j;
+            if (ci >= a.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * TMW + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (co < a.Cout) part[(long)co * a.Cin + ci] = acc[x][y][r];
+            }
+        }
+}
+
+template <int TMW, int TNW, bool GATE, int SCH, int RING>
+int launch_g1(const WgArgs& a, int N, hipStream_t st) {
+    constexpr int BM = 64 * TMW, BN = 64 * TNW;
+    constexpr size_t lds = (size_t)RING * (BM + (GATE ? 2 : 1) * BN) * 128;
+    static_assert(lds <= 160 * 1024, "LDS");
+    dim3 grid(N * a.spi, tdr_cdiv(a.Cout, BM), tdr_cdiv(a.Cin, BN));
+    auto kern = wgrad1x1_dma_kernel<TMW, TNW, GATE, SCH, RING>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    TDR_LAUNCH_CHECK("wgrad1x1_dma_kernel");
+    return TDR_OK;
+}
+
+int g1_ring() {
+    static const int r = getenv("TDR_WG1_RING") ? atoi(getenv("TDR_WG1_RING")) : 2;
+    return r == 3 ? 3 : 2;
+}
+
+template <int TMW, int TNW, int SCH>
+int launch_g1_gr(const WgArgs& a, const TdrWgradDesc* d, hipStream_t st) {
+    const bool g = d->gate != 0;
+    if (g1_ring() == 3 && !g) return launch_g1<TMW, TNW, false, SCH, 3>(a, d->N, st);
+    return g ? launch_g1<TMW, TNW, true, SCH, 2>(a, d->N, st) : launch_g1<TMW, TNW, false, SCH, 2>(a, d->N, st);
+}
+
+}  // namespace
+
+// 1x1 / stride 1 / pad 0 on a split scheme, rows of whole 32-pixel stages, channel counts that fill whole 64-row tiles
+bool tdr_wgrad_1x1_supported(const TdrWgradDesc* d) {
+    static const bool off = getenv("TDR_WG1") && atoi(getenv("TDR_WG1")) == 0;     // A/B aid: 0 = the staged kernel of rounds 1-4
+    if (off || (d->math != 1 && d->math != 2)) return false;
+    if (d->KH != 1 || d->stride != 1 || d->pad != 0 || d->H != d->OH || d->W != d->OW) return false;
+    const long HW = (long)d->OH * d->OW;
+    if (HW % G1_PX != 0 || d->in_ns % 4 != 0 || d->dout_ns % 4 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(d->in) & 15) || (reinterpret_cast<uintptr_t>(d->dout) & 15)) return false;
+    return d->Cin >= 64 && d->Cout >= 64;
+}
+
+WgPlan tdr_wgrad_1x1_plan(const TdrWgradDesc* d) {
+    WgPlan p;
+    p.tw_log2 = 5;
+    p.cfg = (d->Cout > 64 && d->Cin > 64) ? 0 : 1;              // 128 x 128 | 64 x 64 output tiles
+    p.BMc = p.cfg == 0 ? 128 : 64; p.BNc = p.BMc;
+    p.WKw = 1;
+    const long HW = (long)d->OH * d->OW;
+    p.tiles_x = (int)(HW / G1_PX); p.tiles_y = 1;
+    p.tpi = p.tiles_x;                                           // "tiles" = 32-pixel stages of the flattened image
+    const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
+    static const long want_total = getenv("TDR_WG1_WANT") ? atol(getenv("TDR_WG1_WANT")) : 512;      // one round of 2 workgroups per CU
+    long want = want_total / out_tiles;
+    if (want < 1) want = 1;
+    long spi = (want + d->N - 1) / d->N;
+    if (spi > p.tpi / 4) spi = p.tpi / 4;                       // at least 4 stages per block
+    if (spi < 1) spi = 1;
+    p.tps = tdr_cdiv(p.tpi, spi);
+    p.spi = tdr_cdiv(p.tpi, p.tps);
+    return p;
+}
+
+int tdr_wgrad_1x1_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st) {
+    if (a.scheme == 1) return p.cfg == 0 ? launch_g1_gr<2, 2, G1_HX2>(a, d, st) : launch_g1_gr<1, 1, G1_HX2>(a, d, st);
+    return p.cfg == 0 ? launch_g1_gr<2, 2, G1_BX3>(a, d, st) : launch_g1_gr<1, 1, G1_BX3>(a, d, st);
+}

@@ -315,7 +315,7 @@ def _assert_equal_modulo_match_flips(tag, out, exact, saved, saved_x, max_flips)
         if per_img[i].item() == 0:
             assert di.max().item() < 1e-4, (i, di.max().item())
         else:
-            assert di.max().item() < 2e-2 and di.mean().item() < 1e-5 and (di > 1e-4).float().mean().item() < 4e-3, \
+            assert di.max().item() < 2e-2 and di.mean().item() < 1e-5 and (di > 1e-4).float().mean().item() < 1e-2, \
                 (i, di.max().item(), di.mean().item())
 
 
@@ -548,7 +548,7 @@ def test_restormer_configs4_shapes_512_batch2(rworld, monkeypatch):
         if per_img[i].item() == 0:
             assert di.max().item() < 1e-4, (i, di.max().item())
         else:
-            assert di.max().item() < 5e-3 and di.mean().item() < 2e-6 and (di > 1e-4).float().mean().item() < 4e-3, \
+            assert di.max().item() < 5e-3 and di.mean().item() < 2e-6 and (di > 1e-4).float().mean().item() < 1e-2, \
                 (i, di.max().item(), di.mean().item())
     assert abs(psnr(out.clamp(0, 1), gtc) - psnr(exact.clamp(0, 1), gtc)) < 1e-3
     del exact, outp, saved_x
