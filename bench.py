@@ -428,6 +428,7 @@ def _main_body(a, world, rank, local, enc):
         step(it)
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if world > 1:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -443,6 +444,43 @@ def _main_body(a, world, rank, local, enc):
             sys.exit('bench.py: backend nccl but the RCCL data plane (tdr_comm_*) is not in use -- refusing to report an N-GPU line')
     else:
         ranks_seen = 1
+
+    # ---- N > 1: what the first real multi-GPU run needs to diagnose itself (it runs on a node this repo's builder never touches):
+    # per-rank view of the job, the gradient exchange timed with HIP events on the comm stream, and cross-rank agreement checks
+    scale_diag = None
+    if world > 1:
+        import hashlib
+        import socket
+        red.timing = []
+        for _ in range(3):                                # instrumented steps (outside the timed region)
+            it += 1
+            step(it)
+        barrier()
+        tsum = red.comm_timing_summary() if hasattr(red, 'comm_timing_summary') else {}
+        red.timing = None
+        flat = getattr(red, 'flat', None)
+        gsum = float(flat.double().sum().item()) if flat is not None else None
+        gabs = float(flat.double().abs().sum().item()) if flat is not None else None
+        ghash = hashlib.sha1(flat.cpu().numpy().tobytes()).hexdigest()[:16] if flat is not None else None
+        psum = float(sum(p.detach().double().sum().item() for p in model.net_g.parameters()))
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        mine = {'rank': rank, 'local_rank': local, 'host': socket.gethostname(), 'device': torch.cuda.current_device(),
+                'gpu': props.name, 'ranks_seen': int(ranks_seen), 'buckets': len(getattr(red, 'buckets', [])),
+                'arena_MB': (flat.numel() * 4 / 1e6) if flat is not None else None,
+                'ms_per_step_local': dt_local / a.steps * 1e3, 'exchange': tsum,
+                'grad_sum_after_allreduce': gsum, 'grad_abs_sum_after_allreduce': gabs, 'grad_sha1_16': ghash, 'param_sum': psum,
+                'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            scale_diag = {'per_rank': allr,
+                          'gradients_identical_across_ranks': len({r['grad_sha1_16'] for r in allr}) == 1,
+                          'parameters_identical_across_ranks': len({r['param_sum'] for r in allr}) == 1,
+                          'all_ranks_see_world': all(r['ranks_seen'] == world for r in allr),
+                          'slowest_rank_ms_per_step': max(r['ms_per_step_local'] for r in allr),
+                          'fastest_rank_ms_per_step': min(r['ms_per_step_local'] for r in allr),
+                          'note': 'exchange.*: HIP events on the comm stream around every bucket all-reduce of 3 extra steps; compute_stream_waited_ms '
+                                  'is what the optimiser graph had to wait for after the last backward segment (the exposed part)'}
 
     # ---- roofline of the dominant kernel family (3x3 stride-1 implicit GEMM on the fp32 matrix
     # cores: masa_enc forward + data-gradient launches), measured with HIP events on the launch stream
@@ -699,6 +737,8 @@ def _main_body(a, world, rank, local, enc):
                 line['roofline_step']['measured_hbm_bytes'] = mb
                 line['roofline_step']['measured_hbm_frac'] = mb / (dt / a.steps) / PEAK_HBM
                 line['roofline_step']['measured_hbm_source'] = mpath + ' (FETCH_SIZE + WRITE_SIZE over every kernel of an eager step)'
+        if scale_diag is not None:
+            line['scale_diagnostics'] = scale_diag
         if roof is not None:
             line['roofline'] = roof
             if roof_other:

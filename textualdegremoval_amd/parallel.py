@@ -413,18 +413,51 @@ class GradAllReducer:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             self.bucket_launches += 1
             if self.comm is not None:
+                tm = self.timing
+                if tm is not None:                       # bench.py --gpus N: HIP events on the COMM stream around this exchange
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._comm_stream)
                 self.comm.allreduce(buf, average=True, stream=self._comm_stream.cuda_stream)
+                if tm is not None:
+                    e1.record(self._comm_stream)
+                    tm.append(('bucket', bi, (e - s) * 4, e0, e1))
                 return
             avg = dist.ReduceOp.AVG if dist.get_backend(self.pg) == 'nccl' else dist.ReduceOp.SUM
             with torch.cuda.stream(self._comm_stream):
+                tm = self.timing
+                if tm is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._comm_stream)
                 self._works.append(dist.all_reduce(buf, op=avg, group=self.pg, async_op=True))
                 if avg != dist.ReduceOp.AVG:
                     self._works[-1].wait()
                     buf.div_(self.world)
+                if tm is not None:
+                    e1.record(self._comm_stream)
+                    tm.append(('bucket', bi, (e - s) * 4, e0, e1))
         else:
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     bucket_launches = 0          # per-bucket exchanges issued so far (bench.py / tests: the overlapped path really ran)
+    timing = None                # a list while bench.py instruments the exchange (launch_bucket / wait_buckets append event pairs)
+
+    def comm_timing_summary(self):
+        """after a device synchronize: what the instrumented steps' gradient exchange cost on the comm stream and how much of it the
+        compute stream had to WAIT for (the rest ran under the backward pass).  -> dict (times in ms, summed over the instrumented steps)"""
+        tm = self.timing or []
+        buckets = [(bi, nbytes, e0.elapsed_time(e1)) for kind, bi, nbytes, e0, e1 in tm if kind == 'bucket']
+        waits = [e0.elapsed_time(e1) for kind, _, _, e0, e1 in tm if kind == 'wait']
+        busy = sum(t for _, _, t in buckets)
+        exposed = sum(waits)
+        per_bucket = {}
+        for bi, nbytes, t in buckets:
+            d = per_bucket.setdefault(bi, {'bytes': nbytes, 'ms': []})
+            d['ms'].append(t)
+        return {'exchanges': len(buckets), 'comm_stream_busy_ms': busy, 'compute_stream_waited_ms': exposed,
+                'fraction_hidden_under_backward': (1.0 - exposed / busy) if busy > 0 else None,
+                'per_bucket': [{'bucket': bi, 'bytes': d['bytes'], 'mean_ms': sum(d['ms']) / len(d['ms']),
+                                'GBps': d['bytes'] / (sum(d['ms']) / len(d['ms']) * 1e-3) / 1e9 if sum(d['ms']) > 0 else None}
+                               for bi, d in sorted(per_bucket.items())]}
 
     def wait_buckets(self):
         """the current stream waits for every bucket exchange launched since the last wait"""
@@ -432,7 +465,14 @@ class GradAllReducer:
             w.wait()
         self._works = []
         if self._comm_stream is not None and self.flat is not None and self.flat.is_cuda:
+            tm = self.timing
+            if tm is not None:                           # how long the compute stream sits in this wait: the exposed part of the exchange
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             torch.cuda.current_stream().wait_stream(self._comm_stream)
+            if tm is not None:
+                e1.record()
+                tm.append(('wait', -1, 0, e0, e1))
 
     def _arrive(self, key, g):
         self._arrived.append((key, g))
