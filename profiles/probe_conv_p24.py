@@ -52,5 +52,6 @@ def level(N, Cc, H):
     print(line, flush=True)
 
 
-for Cc, H in ((64, 256), (128, 128), (256, 64), (512, 32)):
-    level(8, Cc, H)
+if __name__ == '__main__':
+    for Cc, H in ((64, 256), (128, 128), (256, 64), (512, 32)):
+        level(8, Cc, H)
