@@ -991,7 +991,8 @@ extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
             // epilogue 10 - 54 (it is HBM-write-bound at C = 64 and nothing overlaps it with one workgroup per CU).  Per level the best:
             // C <= 64: 64 x (4 x 32) with two workgroups per CU (220 vs 238 us); 128 x (8 x 32) on 8 waves where that still fills the
             // chip (176 / 160 vs 191 / 170 us at C = 128 / 256); else 64 x (8 x 32) (C = 512 @ 32^2: 160 us, 256 workgroups)
-            if (d->Cout <= 64) cfg = 303;
+            if (d->Cout <= 32) cfg = 308;
+            else if (d->Cout <= 64) cfg = 303;
             else if (d->Cout % 128 == 0 && blocks(128, 8) >= 256) cfg = 302;
             else cfg = 301;
         }
@@ -1003,6 +1004,8 @@ extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
             case 304: return launch_p16<2, 2, 2, 2, true, 0, true, T>(a, N, st);     // 128 x (4 x 32), 4 waves
             case 306: return launch_p16<2, 2, 4, 2, true, 0, true, T>(a, N, st);     // 256 x (4 x 32), 8 waves
             case 307: return launch_p16<2, 1, 2, 4, true, 0, true, T>(a, N, st);     // 128 x (4 x 32), 8 waves
+            case 308: return launch_p16<1, 2, 1, 4, true, 0, true, T>(a, N, st);     //  32 x (8 x 32), 4 waves (the C = 32 level)
+            case 309: return launch_p16<1, 1, 1, 4, true, 0, true, T>(a, N, st);     //  32 x (4 x 32), 4 waves
             case 311: return launch_p16<2, 2, 1, 4, true, 0, false, T>(a, N, st);    // 301 without the interleaved issue order
             case 312: return launch_p16<2, 2, 2, 4, true, 0, false, T>(a, N, st);
             case 321: return launch_p16<2, 2, 1, 4, false, 0, false, T>(a, N, st);   // 301 without pipelined fragments
