@@ -3,11 +3,11 @@
 mkdir -p gpurun_out/r5
 run() { tag=$1; shift; env "$@" python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-exact --no-roofline --no-matcher-active 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],2))"; }
 ( run base A=1
-  run p16_min32 TDR_P16_MIN_C=32
-  run wg_want256 TDR_WG_WANT=256
-  run wg_want768 TDR_WG_WANT=768
-  run wgp_want256 TDR_WGP_WANT=256
-  run wgp_want1024 TDR_WGP_WANT=1024
-  run nodefer TDR_DEFER_WGRAD=0
-  run noln_defer TDR_DEFER_LN_FINISH=0
+  run old_defaults TDR_P16_MIN_C=64 TDR_WG_WANT=512
+  run dwf_rpt8 TDR_DWF_RPT=8
+  run dwf_rpt4 TDR_DWF_RPT=4
+  run wg_want128 TDR_WG_WANT=128
+  run wgp_want384 TDR_WGP_WANT=384
+  run s2_want128 TDR_WG_S2_WANT=128
+  run s2_want512 TDR_WG_S2_WANT=512
   run base2 A=1 ) | tee gpurun_out/r5/sweep_$1.log

@@ -533,7 +533,9 @@ WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d) {
     const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
     // split-K so that ONE round of blocks fills the chip (2 resident workgroups x 256 CUs): 768 (1.5 rounds) leaves a
     // half-empty tail round on every launch -- 94.7 vs 90.4 ms per cfg2 step; TDR_WG_WANT overrides (tuning aid)
-    static const long want_total = getenv("TDR_WG_WANT") ? atol(getenv("TDR_WG_WANT")) : 512;
+    // (3-way bf16 split, round 5: 256 -- a block's matrix phase is twice as long there, half the split-K partials win: 68.8 -> 68.2 ms same box)
+    static const long want_env = getenv("TDR_WG_WANT") ? atol(getenv("TDR_WG_WANT")) : 0;
+    const long want_total = want_env > 0 ? want_env : (d->math == 1 ? 256 : 512);
     long want = want_total / out_tiles;
     if (want < 1) want = 1;
     long spi = (want + d->N - 1) / d->N;              // splits per image

@@ -411,12 +411,16 @@ def _enc_counts(ext):
 # TDR_P16=0 keeps the fp32 tensors + per-consumer split of rounds 1-3.
 P16_ON = os.environ.get('TDR_P16', '1') == '1'
 # narrower levels (C = 32: one 32-row m-tile, 18 (group, tap) steps) keep the fp32 kernels until the weights-stationary variant exists
-P16_MIN_C = int(os.environ.get('TDR_P16_MIN_C', '64'))
+# (bf16 triple planes, TDR_MATH=bx3: the C = 32 level too -- its convolution is a wash at 6 bytes per element (292 vs 283 us per launch), its
+# weight gradient is not (232 vs 273 us): -0.5 ms per step, same-box A/B profiles/r5/sweep_a.log)
+P16_MIN_C = int(os.environ['TDR_P16_MIN_C']) if 'TDR_P16_MIN_C' in os.environ else None
 
 
 def _p16_level(Cc, n_blocks):
     """plane tensors at this level: fp16 pairs inside a loss-scaled hx2 step, bf16 triples under TDR_MATH=bx3 (kernels.plane_fmt)"""
-    return P16_ON and n_blocks > 0 and K.plane_fmt() is not None and K.p16_supported(Cc) and Cc >= P16_MIN_C
+    fmt = K.plane_fmt()
+    min_c = P16_MIN_C if P16_MIN_C is not None else (32 if fmt == K.FMT_BX3 else 64)
+    return P16_ON and n_blocks > 0 and fmt is not None and K.p16_supported(Cc) and Cc >= min_c
 
 
 def encoder_fwd(x, P, pre, ext_n_blocks, levels=5):
