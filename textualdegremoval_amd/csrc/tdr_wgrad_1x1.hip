@@ -6,8 +6,9 @@
 // Both operands are fp32 [C][HW] rows with the contraction index (the pixel) contiguous, so an MFMA fragment (lane = channel row,
 // 8 consecutive k) is 32 contiguous bytes of one row.  The round 1-4 kernel (wgrad_bx3_kernel<KH = 1>, tdr_wgrad_bx3.hip) staged a
 // 32-pixel tile as [barrier, split every value into planes + write them to LDS, barrier, 48 MFMAs per wave] with the next tile's
-// loads held in registers: the two phases never overlap inside a workgroup and a tile took ~5 us against 0.8 us of matrix work
-// (45 us per 512 x 256 @ 64^2 launch, the largest family of the step).  Here:
+// loads held in registers.  Measured (profiles/r5/probe_wgrad1x1_v*.log, sweep_c.log): this kernel 43.9 - 46 us against 47.5 - 51 us per
+// 512 x 256 @ 64^2 launch, -0.4 ms per step -- a modest gain: both designs stay at ~37 % matrix-pipe utilisation (an in-order wave
+// runs its split VALU and its MFMAs back to back; profiles/r5/tried_and_dropped.txt has the variants).  Here:
 //   * the RAW fp32 rows of a 32-pixel stage (BM + BN rows x 128 B) go to an LDS ring by LDS-DMA (global_load_lds_dwordx4: no VGPRs,
 //     no VALU, issued a whole stage ahead, waited for with a counted vmcnt) -- coalesced 128-byte row segments, the 16-byte
 //     chunks of a row XOR-permuted by (row >> 1) & 7 on the GLOBAL side so that the lane-linear LDS image is conflict-free for
@@ -157,36 +158,54 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(WgArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (s + RING - 1 < nst) issue(s + RING - 1);
         const unsigned char* st = smem_raw + (s % RING) * STAGE;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        // software pipeline inside the stage: the raw fragments of k-step 1 are read and split WHILE the MFMAs of k-step 0 run (one
+        // MFMA, then a handful of the split's VALU: an in-order wave otherwise spends split + MFMA time back to back)
+        g1u32x4 af[2][TMW][NS], bf[2][TNW][NS];
+        auto frags = [&](int u, g1u32x4 (&fa)[TMW][NS], g1u32x4 (&fb)[TNW][NS]) {
             const int c0 = 4 * u + 2 * kg;
-            g1u32x4 af[TMW][NS], bf[TNW][NS];
 #pragma unroll
             for (int x = 0; x < TMW; ++x) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + a_off[x] + ((c0 ^ a_sw[x]) << 4));
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + a_off[x] + (((c0 + 1) ^ a_sw[x]) << 4));
                 if (want_db) dsum[x] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
-                g1_split8<SCH>(v0, v1, af[x]);
+                g1_split8<SCH>(v0, v1, fa[x]);
             }
 #pragma unroll
             for (int y = 0; y < TNW; ++y) {
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(st + b_off[y] + ((c0 ^ b_sw[y]) << 4));
                 f32x4 v1 = *reinterpret_cast<const f32x4*>(st + b_off[y] + (((c0 + 1) ^ b_sw[y]) << 4));
                 if constexpr (GATE) {
-                    // the gate partner row sits BN rows further: same (row >> 1) & 7 (BN is a multiple of 16), same chunk positions
                     v0 *= *reinterpret_cast<const f32x4*>(st + b_off[y] + BN * 128 + ((c0 ^ b_sw[y]) << 4));
                     v1 *= *reinterpret_cast<const f32x4*>(st + b_off[y] + BN * 128 + (((c0 + 1) ^ b_sw[y]) << 4));
                     asm volatile("" : "+v"(v0), "+v"(v1));          // every plane from the same rounded product
                 }
-                g1_split8<SCH>(v0, v1, bf[y]);
+                g1_split8<SCH>(v0, v1, fb[y]);
             }
+        };
+        auto mmas = [&](const g1u32x4 (&fa)[TMW][NS], const g1u32x4 (&fb)[TNW][NS]) {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int x = 0; x < TMW; ++x)
 #pragma unroll
-                    for (int y = 0; y < TNW; ++y) acc[x][y] = mma(af[x][SA[p]], bf[y][SB[p]], acc[x][y]);
+                    for (int y = 0; y < TNW; ++y) acc[x][y] = mma(fa[x][SA[p]], fb[y][SB[p]], acc[x][y]);
+        };
+        frags(0, af[0], bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(1, af[1], bf[1]);
+        mmas(af[0], bf[0]);
+        {
+            constexpr int NM = NP * TMW * TNW;
+            constexpr int VPM = ((TMW + TNW) * (SCH == G1_BX3 ? 44 : 12) + (GATE ? 8 * TNW : 0) + 8 * TMW + NM - 1) / NM + 1;   // VALU per MFMA slot
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                if (i == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TMW + TNW) * (GATE ? 2 : 1), 0);      // the raw fragment reads first
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(af[1], bf[1]);
     }
 
     // ---- bias gradient partial: row j of tile x = the two lane halves' sums (fixed order)
@@ -266,7 +285,9 @@ WgPlan tdr_wgrad_1x1_plan(const TdrWgradDesc* d) {
     p.tiles_x = (int)(HW / G1_PX); p.tiles_y = 1;
     p.tpi = p.tiles_x;                                           // "tiles" = 32-pixel stages of the flattened image
     const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
-    static const long want_total = getenv("TDR_WG1_WANT") ? atol(getenv("TDR_WG1_WANT")) : 512;      // one round of 2 workgroups per CU
+    // bx3: 256 blocks (one per CU; half the split-K partials: 68.66 -> 68.24 ms per step same box, profiles/r5/sweep_c.log); hx2: one round of 2 per CU
+    static const long want_env = getenv("TDR_WG1_WANT") ? atol(getenv("TDR_WG1_WANT")) : 0;
+    const long want_total = want_env > 0 ? want_env : (d->math == 1 ? 256 : 512);
     long want = want_total / out_tiles;
     if (want < 1) want = 1;
     long spi = (want + d->N - 1) / d->N;

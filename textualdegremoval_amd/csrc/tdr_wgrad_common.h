@@ -24,3 +24,8 @@ int tdr_wgrad_bx3_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d
 bool tdr_wgrad_s2_supported(const TdrWgradDesc* d);
 WgPlan tdr_wgrad_s2_plan(const TdrWgradDesc* d);
 int tdr_wgrad_s2_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st);
+
+// tdr_wgrad_1x1.hip (1x1 on the split schemes: LDS-DMA ring of raw rows, operands split in registers)
+bool tdr_wgrad_1x1_supported(const TdrWgradDesc* d);
+WgPlan tdr_wgrad_1x1_plan(const TdrWgradDesc* d);
+int tdr_wgrad_1x1_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st);

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(64 * KL) void wgrad_reduce_kernel(const float* __re
 // cfg: 0 = waves 2x2x1 tile 2x2 (128x128) | 1 = waves 1x1x4 tile 2x1 (64x32) | 2 = 2x2x1 tile 1x1 (64x64)
 //      3 = waves 1x1x4 tile 1x1 (32x32)
 WgPlan make_plan(const TdrWgradDesc* d) {
+    if (tdr_wgrad_1x1_supported(d)) return tdr_wgrad_1x1_plan(d);
     if (d->math >= 1 && tdr_wgrad_bx3_supported(d)) return tdr_wgrad_bx3_plan(d);
     if (tdr_wgrad_s2_supported(d)) return tdr_wgrad_s2_plan(d);
     WgPlan p;
@@ -310,7 +311,9 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     if (dbg && !(d->math >= 1 && tdr_wgrad_bx3_supported(d)) && !tdr_wgrad_s2_supported(d))
         fprintf(stderr, "[tdr] exact wgrad: math %d N %d %d->%d @%dx%d k%d s%d pad %d gate %d per_image %d in_ns %ld dout_ns %ld\n", d->math,
                 d->N, d->Cin, d->Cout, d->H, d->W, d->KH, d->stride, d->pad, d->gate, d->per_image, (long)d->in_ns, (long)d->dout_ns);
-    if (d->math >= 1 && tdr_wgrad_bx3_supported(d)) {
+    if (tdr_wgrad_1x1_supported(d)) {
+        rc = tdr_wgrad_1x1_launch(a, p, d, st);
+    } else if (d->math >= 1 && tdr_wgrad_bx3_supported(d)) {
         rc = tdr_wgrad_bx3_launch(a, p, d, st);
     } else if (tdr_wgrad_s2_supported(d)) {
         rc = tdr_wgrad_s2_launch(a, p, d, st);
