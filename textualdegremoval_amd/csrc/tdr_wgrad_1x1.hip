@@ -250,6 +250,232 @@ int launch_g1(const WgArgs& a, int N, hipStream_t st) {
     return TDR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// SPLIT-ONCE kernel (round 5, second design): the DMA kernel above splits every operand value in every wave that multiplies it
+// (2 x 2 waves: each value twice, 7.3 VALU per MFMA -- measured VALU-pipe-bound: 2.45 us per (workgroup, 32-pixel stage) at any
+// occupancy and any contraction length, profiles/r5/probe_wgrad1x1_longk.log).  Here a workgroup of 8 waves splits each value of a
+// stage ONCE: thread t loads 4 pixels (one dwordx4; 8 lanes = one 128-byte row segment) of rows t/8 + 64 i, splits them in
+// registers and writes the bf16 (fp16) planes of the NEXT stage into the other LDS buffer while the MFMAs of the current stage run:
+// 22 split VALU + 3 ds_write_b64 per load, 88 VALU per 24 MFMAs of a wave.  The 8 waves are 2 k-groups x (2 x 2) 64 x 64
+// quadrants of the 128 x 128 output tile: wave (kq, wm, wn) multiplies k-step kq (16 pixels) of every stage, the two k-groups are
+// summed through LDS in a fixed order at the end (in-block K split: the partial volume of a 256-block launch, two waves per SIMD).
+// Plane image of a k-step: [plane][row][16 pixels] bf16 = 32-byte rows, the two 16-byte chunks of a row swapped on rows with
+// bit 3 set so that the four 16-lane groups of a ds_read_b128 (lanes {0-3, 12-15, 20-27}, ..) touch 64 distinct banks; the second
+// k-step's image sits 64 bytes off a multiple of 128 so that the 16 lanes of a ds_write_b64 group (2 rows x 8 pieces) do too.
+template <bool GATE, int SCH>
+__global__ __launch_bounds__(512) void wgrad1x1_sp_kernel(WgArgs a) {
+    constexpr int NS = SCH == G1_BX3 ? 3 : 2, NP = SCH == G1_BX3 ? 6 : 3;
+    constexpr int ROWS = 256;                          // 128 dout rows | 128 input rows
+    constexpr int PLANE = ROWS * 32;                   // bytes of one plane of one k-step
+    constexpr int KSTR = NS * PLANE + 64;              // k-step image stride
+    constexpr int BUF = 2 * KSTR;                      // one stage
+    constexpr int NL = GATE ? 6 : 4;                   // dwordx4 loads per thread and stage
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int j = lane & 31, kg = lane >> 5;
+
+    const int split = blockIdx.x;
+    const int n = split / a.spi;
+    const int s_begin = (split % a.spi) * a.tps;
+    const int s_end = min(s_begin + a.tps, a.tpi);
+    const int nst = s_end - s_begin;
+    const int co0 = blockIdx.y * 128, ci0 = blockIdx.z * 128;
+    const long HW = (long)a.OH * a.OW;
+    const float* in_n = a.in + (long)n * a.in_ns;
+    const float* do_n = a.dout + (long)n * a.dout_ns;
+
+    // ---- loader role: piece lp (4 pixels) of rows lr + 64 i
+    const int lp = tid & 7, lr = tid >> 3;
+    const float* src[NL];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = lr + 64 * i;
+        const float* base = i < 2 ? do_n + (long)min(co0 + row, a.Cout - 1) * HW : in_n + (long)min(ci0 + row - 128, a.Cin - 1) * HW;
+        src[i] = base + (long)s_begin * G1_PX + 4 * lp;
+    }
+    if constexpr (GATE) { src[4] = src[2] + a.gate_off; src[5] = src[3] + a.gate_off; }
+    const int w_off = (lp >> 2) * KSTR + lr * 32 + ((((lp >> 1) & 1) ^ ((lr >> 3) & 1)) << 4) + (lp & 1) * 8;     // + i * 64 * 32 + plane * PLANE
+
+    // ---- multiplier role
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        a_off[x] = kq * KSTR + (wm * 64 + x * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
+        b_off[x] = kq * KSTR + (128 + wn * 64 + x * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    float dsum[2] = {0.f, 0.f};
+    const bool want_db = a.dbpart != nullptr && blockIdx.z == 0;      // workgroup-uniform
+
+    constexpr int SA[6] = {SCH == G1_HX2 ? 1 : 2, 0, SCH == G1_HX2 ? 0 : 1, 1, 0, 0};      // hx2: mh hm hh ; bx3: lh hl mm mh hm hh
+    constexpr int SB[6] = {0, SCH == G1_HX2 ? 1 : 2, SCH == G1_HX2 ? 0 : 1, 0, 1, 0};
+    auto mma = [](const g1u32x4& x, const g1u32x4& y, const f32x16& c) {
+        if constexpr (SCH == G1_BX3)
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g1bf16x8, x), __builtin_bit_cast(g1bf16x8, y), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(g1f16x8, x), __builtin_bit_cast(g1f16x8, y), c, 0, 0, 0);
+    };
+
+    auto load = [&](int s, f32x4 (&r)[NL]) {
+        const long adv = (long)min(s, nst - 1) * G1_PX;       // past the end: a harmless re-read (keeps the loop branch-free)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) r[i] = *reinterpret_cast<const f32x4*>(src[i] + adv);
+    };
+    auto split_store = [&](f32x4 (&r)[NL], int wr, bool live) {
+        unsigned char* dst = smem_raw + wr + w_off;
+        // stages past the end are split like the others (branch-free pipeline) with their dout planes zeroed: they add nothing
+        const float zf = live ? 1.f : 0.f, lf = want_db ? zf : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = r[i];
+            if (i < 2) {
+                v *= zf;
+                dsum[i] = __builtin_fmaf(lf, (v[0] + v[1]) + (v[2] + v[3]), dsum[i]);
+            }
+            else if constexpr (GATE) {
+                v *= r[i + 2];
+                asm volatile("" : "+v"(v));                  // every plane from the same rounded product
+            }
+            unsigned p0[NS], p1[NS];
+            if constexpr (SCH == G1_BX3) {
+                tdr_split3_bf16<false>(v[0], v[1], p0[0], p0[1], p0[2]);
+                tdr_split3_bf16<false>(v[2], v[3], p1[0], p1[1], p1[2]);
+            } else {
+                tdr_split2_f16<false>(v[0], v[1], p0[0], p0[1]);
+                tdr_split2_f16<false>(v[2], v[3], p1[0], p1[1]);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(dst + i * (64 * 32) + s * PLANE) = make_uint2(p0[s], p1[s]);
+        }
+    };
+    auto read_frags = [&](int rd, g1u32x4 (&fa)[2][NS], g1u32x4 (&fb)[2][NS]) {
+        const unsigned char* st = smem_raw + rd;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                fa[x][s] = *reinterpret_cast<const g1u32x4*>(st + a_off[x] + s * PLANE);
+                fb[x][s] = *reinterpret_cast<const g1u32x4*>(st + b_off[x] + s * PLANE);
+            }
+    };
+    auto mmas = [&](const g1u32x4 (&fa)[2][NS], const g1u32x4 (&fb)[2][NS]) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = mma(fa[x][SA[p]], fb[y][SB[p]], acc[x][y]);
+    };
+    // the split of stage s + 1 rides in the shadow of the MFMAs of stage s: per MFMA a handful of VALU, a plane store every other one
+    auto interleave = [&]() {
+        constexpr int NM = NP * 4;
+        constexpr int VPM = (4 * (SCH == G1_BX3 ? 22 : 6) + (GATE ? 8 : 0) + 16 + NM - 1) / NM + 1;
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NS, 0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    };
+
+    // ---- two stage images in LDS: iteration s multiplies stage s, splits stage s + 1 (raw since iteration s - 1 / s - 2) into the
+    // other image and issues the loads of stage s + DIST
+    f32x4 raw0[NL], raw1[NL];
+    g1u32x4 fa[2][NS], fb[2][NS];
+    load(0, raw0);
+    load(1, raw1);
+    split_store(raw0, 0, true);
+    __syncthreads();
+    for (int s = 0; s < nst; s += 2) {           // (an odd count runs one extra, zeroed stage)
+        load(s + 2, raw0);
+        read_frags(0, fa, fb);
+        mmas(fa, fb);
+        split_store(raw1, BUF, s + 1 < nst);
+        interleave();
+        __syncthreads();
+        load(s + 3, raw1);
+        read_frags(BUF, fa, fb);
+        mmas(fa, fb);
+        split_store(raw0, 0, s + 2 < nst);
+        interleave();
+        __syncthreads();
+    }
+
+    // ---- bias gradient partial: the 8 pieces of a row live in 8 consecutive lanes (fixed-order butterfly)
+    if (want_db) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float t = dsum[i];
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            const int co = co0 + lr + 64 * i;
+            if (lp == 0 && co < a.Cout) a.dbpart[(long)split * a.Cout + co] = t;
+        }
+    }
+    // ---- k-group 1 hands its sums to k-group 0 through LDS (the stage buffers are free: the loop ended on a barrier)
+    float* red = reinterpret_cast<float*>(smem_raw);            // [quadrant][64 values][64 lanes] = 64 KiB (the stage images are dead)
+    const int wq = wave & 3;
+    if (kq == 1) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wq * 4 + x * 2 + y) * 16 + r) * 64 + lane] = acc[x][y][r];
+    }
+    __syncthreads();
+    if (kq == 1) return;
+    float* part = a.part + (long)split * a.Cout * a.Cin;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int ci = ci0 + (wn * 2 + y) * 32 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[x][y][r] + red[((wq * 4 + x * 2 + y) * 16 + r) * 64 + lane];
+                const int co = co0 + (wm * 2 + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (co < a.Cout && ci < a.Cin) part[(long)co * a.Cin + ci] = v;
+            }
+        }
+}
+
+template <bool GATE, int SCH>
+int launch_sp(const WgArgs& a, int N, hipStream_t st) {
+    constexpr int NS = SCH == G1_BX3 ? 3 : 2;
+    constexpr size_t lds0 = (size_t)2 * 2 * (NS * 256 * 32 + 64);
+    constexpr size_t lds = lds0 < 65536 ? 65536 : lds0;
+    dim3 grid(N * a.spi, tdr_cdiv(a.Cout, 128), tdr_cdiv(a.Cin, 128));
+    auto kern = wgrad1x1_sp_kernel<GATE, SCH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+    TDR_LAUNCH_CHECK("wgrad1x1_sp_kernel");
+    return TDR_OK;
+}
+
+bool g1_sp() {
+    // Opt-in (TDR_WG1_SP=1).  Standalone it is the faster kernel (256 -> 512 @ 64^2, N = 4: 35 vs 45 us per launch incl. the reduction;
+    // 1.54 vs 1.93 us per stage, fixed cost 10 vs 14 us: profiles/r5/probe_wgrad1x1_fixed.log), and on one stream the step gains 0.4 ms
+    // (70.5 vs 70.9 ms).  But the default step runs the deferred leaves NEXT TO the MASA-encoder backward, and there a 512-thread /
+    // 96 KiB workgroup shares a CU with nothing: the overlap that is worth 2.6 ms with the 256-thread / 64 KiB LDS-DMA kernel shrinks
+    // to 1.1 ms (68.3 -> 69.4 ms same box, profiles/r5/sweep_e.log).
+    static const bool on = getenv("TDR_WG1_SP") && atoi(getenv("TDR_WG1_SP")) == 1;
+    return on;
+}
+
 int g1_ring() {
     static const int r = getenv("TDR_WG1_RING") ? atoi(getenv("TDR_WG1_RING")) : 2;
     return r == 3 ? 3 : 2;
@@ -299,6 +525,11 @@ WgPlan tdr_wgrad_1x1_plan(const TdrWgradDesc* d) {
 }
 
 int tdr_wgrad_1x1_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st) {
+    if (p.cfg == 0 && g1_sp()) {
+        const bool g = d->gate != 0;
+        if (a.scheme == 1) return g ? launch_sp<true, G1_HX2>(a, d->N, st) : launch_sp<false, G1_HX2>(a, d->N, st);
+        return g ? launch_sp<true, G1_BX3>(a, d->N, st) : launch_sp<false, G1_BX3>(a, d->N, st);
+    }
     if (a.scheme == 1) return p.cfg == 0 ? launch_g1_gr<2, 2, G1_HX2>(a, d, st) : launch_g1_gr<1, 1, G1_HX2>(a, d, st);
     return p.cfg == 0 ? launch_g1_gr<2, 2, G1_BX3>(a, d, st) : launch_g1_gr<1, 1, G1_BX3>(a, d, st);
 }

@@ -64,6 +64,7 @@ def maybe_join():
 # Only without a gradient exchange: with collectives the buckets are cut in arrival order inside the backward (parallel.GradAllReducer).
 DEFER_WGRAD = os.environ.get('TDR_DEFER_WGRAD', '1') == '1'
 DEFER_LN_FINISH = os.environ.get('TDR_DEFER_LN_FINISH', '1') == '1'     # also the reductions of the LayerNorm-gradient partials
+LEAF_LANES = int(os.environ.get('TDR_LEAF_LANES', '1'))                 # HIP streams the deferred leaves are spread over
 _late = None            # [(prefix, closure -> {name: grad})] while a whole-network backward collects deferred leaves
 _late_pre = ''
 
@@ -121,8 +122,15 @@ def run_late_leaves(G, main_chain):
     if not late:
         main_chain()
         return
-    with K.lane(0):
-        results = [(pre, fn()) for pre, fn, _ in late]
+    if LEAF_LANES <= 1:
+        with K.lane(0):
+            results = [(pre, fn()) for pre, fn, _ in late]
+    else:
+        # independent leaves round-robin over a few streams: the ramp / tail / split-K reduction of one overlaps the main loop of the next
+        results = []
+        for i, (pre, fn, _) in enumerate(late):
+            with K.lane(i % LEAF_LANES):
+                results.append((pre, fn()))
     main_chain()
     K.lanes_join()
     for pre, g in results:
