@@ -263,32 +263,35 @@ int launch_g1(const WgArgs& a, int N, hipStream_t st) {
 // Plane image of a k-step: [plane][row][16 pixels] bf16 = 32-byte rows, the two 16-byte chunks of a row swapped on rows with
 // bit 3 set so that the four 16-lane groups of a ds_read_b128 (lanes {0-3, 12-15, 20-27}, ..) touch 64 distinct banks; the second
 // k-step's image sits 64 bytes off a multiple of 128 so that the 16 lanes of a ds_write_b64 group (2 rows x 8 pieces) do too.
-template <bool GATE, int SCH>
-__global__ __launch_bounds__(512) void wgrad1x1_sp_kernel(WgArgs a) {
+// KQ = 1: the same pipeline on 4 waves and 16-pixel stages (no in-block K split): the footprint of the LDS-DMA kernel (256 threads, 49 KiB),
+// for launches that should share a CU with the kernels of another stream.
+template <bool GATE, int SCH, int KQ>
+__global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
     constexpr int NS = SCH == G1_BX3 ? 3 : 2, NP = SCH == G1_BX3 ? 6 : 3;
     constexpr int ROWS = 256;                          // 128 dout rows | 128 input rows
     constexpr int PLANE = ROWS * 32;                   // bytes of one plane of one k-step
     constexpr int KSTR = NS * PLANE + 64;              // k-step image stride
-    constexpr int BUF = 2 * KSTR;                      // one stage
+    constexpr int BUF = KQ * KSTR;                     // one stage
+    constexpr int PXS = 16 * KQ;                       // pixels per stage
     constexpr int NL = GATE ? 6 : 4;                   // dwordx4 loads per thread and stage
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kq = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int kq = KQ == 2 ? wave >> 2 : 0, wm = (wave >> 1) & 1, wn = wave & 1;
     const int j = lane & 31, kg = lane >> 5;
 
     const int split = blockIdx.x;
     const int n = split / a.spi;
-    const int s_begin = (split % a.spi) * a.tps;
+    const int s_begin = (split % a.spi) * a.tps;                // (the plan counts 32-pixel stages)
     const int s_end = min(s_begin + a.tps, a.tpi);
-    const int nst = s_end - s_begin;
+    const int nst = (s_end - s_begin) * (2 / KQ);
     const int co0 = blockIdx.y * 128, ci0 = blockIdx.z * 128;
     const long HW = (long)a.OH * a.OW;
     const float* in_n = a.in + (long)n * a.in_ns;
     const float* do_n = a.dout + (long)n * a.dout_ns;
 
     // ---- loader role: piece lp (4 pixels) of rows lr + 64 i
-    const int lp = tid & 7, lr = tid >> 3;
+    const int lp = tid & (4 * KQ - 1), lr = tid >> (KQ == 2 ? 3 : 2);
     const float* src[NL];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(512) void wgrad1x1_sp_kernel(WgArgs a) {
     };
 
     auto load = [&](int s, f32x4 (&r)[NL]) {
-        const long adv = (long)min(s, nst - 1) * G1_PX;       // past the end: a harmless re-read (keeps the loop branch-free)
+        const long adv = (long)min(s, nst - 1) * PXS;       // past the end: a harmless re-read (keeps the loop branch-free)
 #pragma unroll
         for (int i = 0; i < NL; ++i) r[i] = *reinterpret_cast<const f32x4*>(src[i] + adv);
     };
@@ -416,7 +419,8 @@ __global__ __launch_bounds__(512) void wgrad1x1_sp_kernel(WgArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float t = dsum[i];
-            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64);
+            if constexpr (KQ == 2) t += __shfl_xor(t, 4, 64);
             const int co = co0 + lr + 64 * i;
             if (lp == 0 && co < a.Cout) a.dbpart[(long)split * a.Cout + co] = t;
         }
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(512) void wgrad1x1_sp_kernel(WgArgs a) {
     // ---- k-group 1 hands its sums to k-group 0 through LDS (the stage buffers are free: the loop ended on a barrier)
     float* red = reinterpret_cast<float*>(smem_raw);            // [quadrant][64 values][64 lanes] = 64 KiB (the stage images are dead)
     const int wq = wave & 3;
-    if (kq == 1) {
+    if (KQ == 2 && kq == 1) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -432,8 +436,10 @@ __global__ __launch_bounds__(512) void wgrad1x1_sp_kernel(WgArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) red[((wq * 4 + x * 2 + y) * 16 + r) * 64 + lane] = acc[x][y][r];
     }
-    __syncthreads();
-    if (kq == 1) return;
+    if constexpr (KQ == 2) {
+        __syncthreads();
+        if (kq == 1) return;
+    }
     float* part = a.part + (long)split * a.Cout * a.Cin;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -442,38 +448,40 @@ __global__ __launch_bounds__(512) void wgrad1x1_sp_kernel(WgArgs a) {
             const int ci = ci0 + (wn * 2 + y) * 32 + j;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[x][y][r] + red[((wq * 4 + x * 2 + y) * 16 + r) * 64 + lane];
+                const float v = KQ == 2 ? acc[x][y][r] + red[((wq * 4 + x * 2 + y) * 16 + r) * 64 + lane] : acc[x][y][r];
                 const int co = co0 + (wm * 2 + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (co < a.Cout && ci < a.Cin) part[(long)co * a.Cin + ci] = v;
             }
         }
 }
 
-template <bool GATE, int SCH>
+template <bool GATE, int SCH, int KQ>
 int launch_sp(const WgArgs& a, int N, hipStream_t st) {
     constexpr int NS = SCH == G1_BX3 ? 3 : 2;
-    constexpr size_t lds0 = (size_t)2 * 2 * (NS * 256 * 32 + 64);
-    constexpr size_t lds = lds0 < 65536 ? 65536 : lds0;
+    constexpr size_t lds0 = (size_t)2 * KQ * (NS * 256 * 32 + 64);
+    constexpr size_t lds = (KQ == 2 && lds0 < 65536) ? 65536 : lds0;
     dim3 grid(N * a.spi, tdr_cdiv(a.Cout, 128), tdr_cdiv(a.Cin, 128));
-    auto kern = wgrad1x1_sp_kernel<GATE, SCH>;
+    auto kern = wgrad1x1_sp_kernel<GATE, SCH, KQ>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256 * KQ), lds, st, a);
     TDR_LAUNCH_CHECK("wgrad1x1_sp_kernel");
     return TDR_OK;
 }
 
-bool g1_sp() {
-    // Opt-in (TDR_WG1_SP=1).  Standalone it is the faster kernel (256 -> 512 @ 64^2, N = 4: 35 vs 45 us per launch incl. the reduction;
-    // 1.54 vs 1.93 us per stage, fixed cost 10 vs 14 us: profiles/r5/probe_wgrad1x1_fixed.log), and on one stream the step gains 0.4 ms
-    // (70.5 vs 70.9 ms).  But the default step runs the deferred leaves NEXT TO the MASA-encoder backward, and there a 512-thread /
-    // 96 KiB workgroup shares a CU with nothing: the overlap that is worth 2.6 ms with the 256-thread / 64 KiB LDS-DMA kernel shrinks
-    // to 1.1 ms (68.3 -> 69.4 ms same box, profiles/r5/sweep_e.log).
-    static const bool on = getenv("TDR_WG1_SP") && atoi(getenv("TDR_WG1_SP")) == 1;
-    return on;
+int g1_sp() {
+    // TDR_WG1_SP: 0 = the LDS-DMA kernel, 1 = 8 waves with the in-block K split, 2 (default) = 4 waves.
+    // Standalone the 8-wave form is the fastest (256 -> 512 @ 64^2, N = 4, time per launch incl. the reduction: 36.7 us; 4 waves 41.6;
+    // LDS-DMA 44.3 -- 1.54 vs 1.93 us per stage, fixed cost 10 vs 14 us: profiles/r5/probe_wgrad1x1_fixed.log), and on one stream the
+    // step gains 0.4 ms with it (70.5 vs 70.9 ms).  But the default step runs the deferred leaves NEXT TO the MASA-encoder backward, and
+    // there a 512-thread / 96 KiB workgroup shares a CU with nothing: the overlap that is worth 2.6 ms with a 256-thread / 64 KiB
+    // kernel shrinks to 1.1 ms (68.3 -> 69.4 ms same box, profiles/r5/sweep_e.log).  The 4-wave form keeps the footprint of the
+    // LDS-DMA kernel (256 threads, 49 KiB) and its overlap: 67.63 -> 67.31 ms (sweep_g.log).
+    static const int v = getenv("TDR_WG1_SP") ? atoi(getenv("TDR_WG1_SP")) : 2;
+    return v;
 }
 
 int g1_ring() {
@@ -525,10 +533,15 @@ WgPlan tdr_wgrad_1x1_plan(const TdrWgradDesc* d) {
 }
 
 int tdr_wgrad_1x1_launch(const WgArgs& a, const WgPlan& p, const TdrWgradDesc* d, hipStream_t st) {
-    if (p.cfg == 0 && g1_sp()) {
+    if (p.cfg == 0 && g1_sp() == 1) {
         const bool g = d->gate != 0;
-        if (a.scheme == 1) return g ? launch_sp<true, G1_HX2>(a, d->N, st) : launch_sp<false, G1_HX2>(a, d->N, st);
-        return g ? launch_sp<true, G1_BX3>(a, d->N, st) : launch_sp<false, G1_BX3>(a, d->N, st);
+        if (a.scheme == 1) return g ? launch_sp<true, G1_HX2, 2>(a, d->N, st) : launch_sp<false, G1_HX2, 2>(a, d->N, st);
+        return g ? launch_sp<true, G1_BX3, 2>(a, d->N, st) : launch_sp<false, G1_BX3, 2>(a, d->N, st);
+    }
+    if (p.cfg == 0 && g1_sp() == 2) {
+        const bool g = d->gate != 0;
+        if (a.scheme == 1) return g ? launch_sp<true, G1_HX2, 1>(a, d->N, st) : launch_sp<false, G1_HX2, 1>(a, d->N, st);
+        return g ? launch_sp<true, G1_BX3, 1>(a, d->N, st) : launch_sp<false, G1_BX3, 1>(a, d->N, st);
     }
     if (a.scheme == 1) return p.cfg == 0 ? launch_g1_gr<2, 2, G1_HX2>(a, d, st) : launch_g1_gr<1, 1, G1_HX2>(a, d, st);
     return p.cfg == 0 ? launch_g1_gr<2, 2, G1_BX3>(a, d, st) : launch_g1_gr<1, 1, G1_BX3>(a, d, st);
