@@ -257,7 +257,7 @@ def pmc_traffic(prefixes):
     import hashlib
     srcs = {'tdr_conv_bx3_sha256': 'tdr_conv_bx3.hip', 'tdr_conv_p16_sha256': 'tdr_conv_p16.hip'}
     pmc = path = None
-    for rnd in ('r4', 'r3', 'r2'):                 # newest collection first
+    for rnd in ('r5', 'r4', 'r3', 'r2'):           # newest collection first
         cand = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')
         try:
             with open(cand) as fh:
@@ -288,7 +288,7 @@ def pmc_traffic(prefixes):
 
 def pmc_step_bytes():
     """measured HBM bytes of one whole train step from the same PMC collection (sum over every kernel of the step), or None"""
-    for rnd in ('r4', 'r3'):
+    for rnd in ('r5', 'r4', 'r3'):
         try:
             with open(os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')) as fh:
                 pmc = json.load(fh)
@@ -621,7 +621,8 @@ def _main_body(a, world, rank, local, enc):
             roof['event_pair_overhead_ms'] = ev_overhead_ms
             roof_other = [subs[k] for k in subs if k != lead]
         WG = {3: 'wgrad_bx3_kernel<KH=3> + wgrad_reduce_kernel (fp32 tensors in, operand split + v_alignbit fragment assembly per consumer)',
-              1: 'wgrad_bx3_kernel<KH=1> + wgrad_reduce_kernel (1x1 weight gradients of the NAFBlock chains, split-K partials)',
+              1: 'wgrad1x1_sp_kernel<KQ=1> (128 x 128 tiles: every operand value split once per workgroup, bf16 planes shared through LDS) / '
+                 'wgrad1x1_dma_kernel<1,1> (64 x 64 tiles) + wgrad_reduce_kernel (1x1 weight gradients of the NAFBlock chains, split-K partials)',
               'p16': 'wgrad3x3_p16_kernel + wgrad_p16_reduce_kernel (pre-split pair planes, transposed LDS reads, no operand VALU)',
               'p24': 'wgrad3x3_p16_kernel<NS=3> + wgrad_p16_reduce_kernel (pre-split bf16 triple planes, transposed LDS reads, no operand VALU)',
               's2': 'wgrad_s2_kernel + wgrad_reduce_kernel (3x3 / 2x2 stride-2 level transitions: parity-de-interleaved LDS planes, 12 / 8-wave workgroups)'}
@@ -630,7 +631,7 @@ def _main_body(a, world, rank, local, enc):
                       PEAK_HX2 if K.MATH in ('hx2', 'h1') else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32),
                       'fp32-equivalent ceiling of the step\'s operand scheme; time = kernel + its fixed-order split-K reduction (HIP events around both)')
             # measured bytes per launch: the kernel's own traffic plus its split-K reduction's (one reduction per weight-gradient launch)
-            wpre = {3: ('wgrad_bx3_kernel<3,', 'wgrad_reduce_kernel'), 1: ('wgrad_bx3_kernel<1,', 'wgrad_reduce_kernel'),
+            wpre = {3: ('wgrad_bx3_kernel<3,', 'wgrad_reduce_kernel'), 1: ('wgrad1x1_', 'wgrad_reduce_kernel'),
                     'p16': ('wgrad3x3_p16_kernel', 'wgrad_p16_reduce_kernel'), 'p24': ('wgrad3x3_p16_kernel', 'wgrad_p16_reduce_kernel'),
                     's2': ('wgrad_s2_kernel', 'wgrad_reduce_kernel')}.get(k)
             if wpre:

@@ -10,10 +10,13 @@ step with the product arithmetic (TDR_MATH=hx2, hipGraph replay, P16 encoder pat
     and arg-max decisions, float atomics in the transfer backward, 1e-8 differences in a gradient norm): both device runs drift away
     from the oracle at the same exponential rate, and WHICH of them is ahead late in the run changes from run to run of the SAME
     binary (measured over eight runs: whole-horizon mean error hx2 / f32 between 0.6 x and 4.1 x, maximum between 0.6 x and 2.2 x;
-    first third of the horizon, where rounding still dominates the amplification: 0.3 x - 2.6 x).  So the bars are: first third
-    max|err_hx2| <= 4 x max|err_f32| (+ 1e-5); whole horizon mean and max <= 10 x those of f32 (same order of magnitude: a
-    systematic bias of the split would show as 100 x and from the first steps on); and max|err_hx2| <= 10 % of the final loss (the
-    curves are the same curve: measured 0.8 % / 4.7 %).
+    first third of the horizon, where rounding still dominates the amplification: 0.3 x - 2.6 x).  Round 5 MEASURES that chaos
+    floor instead of allowing for it: the exact-fp32 trajectory is run twice (the runs differ only in the commit order of
+    transfer_bwd's float atomics) and the bars are 3 x max(error of exact fp32 against the oracle, distance of the two exact runs) for
+    the first third, the whole-horizon mean and the whole-horizon maximum (rounds 3-4: 4 x / 10 x / 10 x of the f32 error alone);
+    and max|err| <= 10 % of the final loss (the curves are the same curve: measured 0.8 % / 4.7 %).
+  * a 1100-step run of the small network crosses the range-survey boundary of the fast mode (TDR_RANGE_CHECK_EVERY = 1000 steps: one
+    eager survey step inside a replayed run) with no skipped step and no change of scale or arithmetic.
 
 The three curves are persisted under gpurun_out/margins/ (copied to profiles/r<N>/margins/).
 Reference: models/image_restoration_ref_model.py:199-284."""
@@ -32,26 +35,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PERIODS, RW, EM = [200, 400], [1, 1], [3e-4, 1e-6]
 
 
-def _opt(net):
+def _opt(net, periods=None):
     return {
         'model_type': 'RefGuidedImageCleanModel', 'num_gpu': 1, 'dist': False, 'is_train': True,
         'network_g': dict(type='NAFNetRefFusion', **net),
         'path': {},
         'train': {'optim_g': {'type': 'AdamW', 'lr': 2e-4, 'ref_lr': 1e-4, 'weight_decay': 1e-4, 'betas': [0.9, 0.999]},
-                  'scheduler': {'type': 'CosineAnnealingRestartCyclicLR', 'periods': PERIODS, 'restart_weights': RW, 'eta_mins': EM},
+                  'scheduler': {'type': 'CosineAnnealingRestartCyclicLR', 'periods': periods or PERIODS, 'restart_weights': RW, 'eta_mins': EM},
                   'pixel_opt': {'type': 'L1Loss', 'loss_weight': 1, 'reduction': 'mean'},
-                  'use_grad_clip': True, 'total_iter': 600, 'warmup_iter': -1},
+                  'use_grad_clip': True, 'total_iter': sum(periods or PERIODS), 'warmup_iter': -1},
         'logger': {'check_freq': 10 ** 9}, 'val': {}, 'scale': 1,
     }
 
 
-def _hip_run(mode, net, cfg, seed, data, steps):
+def _hip_run(mode, net, cfg, seed, data, steps, periods=None):
     from textualdegremoval_amd import kernels as K
     from textualdegremoval_amd.models import create_model
     prev = K.MATH
     K.set_math(mode)
     try:
-        model = create_model(_opt(net))
+        model = create_model(_opt(net, periods))
         model.net_g.load_state_dict(O.synth_params(cfg, seed=seed), strict=True)
         losses = []
         for it in range(1, steps + 1):
@@ -90,9 +93,24 @@ def _compare(tag, net, cfg, size, steps, n_pairs):
     d_f32 = [abs(a - b) for a, b in zip(l_f32, l_or)]
     e_f32, m_f32 = max(d_f32), sum(d_f32) / steps
     third = max(steps // 3, 1)
+    # The CHAOS FLOOR, measured: the same exact-fp32 binary run a second time.  Nothing differs but the order in which the float
+    # atomics of transfer_bwd commit (1e-8-sized gradient differences in step 1); what the two curves are apart at the end is what
+    # the training map's own amplification does to a last-bit perturbation over this horizon -- no arithmetic can track the oracle
+    # more closely than that.
+    l_f32b, _ = _hip_run('f32', net, cfg, 3, data, steps)
+    d_fl = [abs(a - b) for a, b in zip(l_f32, l_f32b)]
+    d_f32b = [abs(a - b) for a, b in zip(l_f32b, l_or)]
+    fl_max, fl_mean, fl_third = max(d_fl), sum(d_fl) / steps, max(d_fl[:third])
     rec = {'steps': steps, 'network': net, 'size': size, 'pairs_cycled': n_pairs, 'loss_oracle': l_or, 'loss_f32': l_f32,
+           'loss_f32_second_run': l_f32b, 'chaos_floor_max': fl_max, 'chaos_floor_mean': fl_mean, 'chaos_floor_first_third': fl_third,
            'max_abs_err_f32_vs_oracle': e_f32, 'mean_abs_err_f32_vs_oracle': m_f32, 'first_third_max_err_f32': max(d_f32[:third]),
            'state_f32': st_f32}
+    print(f'{tag}: chaos floor (exact fp32 against itself, float-atomic order only): max {fl_max:.3e} mean {fl_mean:.3e} first third {fl_third:.3e}; '
+          f'exact fp32 against the oracle: max {e_f32:.3e} mean {m_f32:.3e}')
+    # bars: 3 x the largest of three realisations of the same distance (either exact-fp32 run against the oracle, the two against each other)
+    b_third = 3.0 * max(max(d_f32[:third]), max(d_f32b[:third]), fl_third) + 1e-5
+    b_mean = 3.0 * max(m_f32, sum(d_f32b) / steps, fl_mean) + 2e-6
+    b_max = 3.0 * max(e_f32, max(d_f32b), fl_max) + 2e-6
     # 'bx3': the library default / bench headline (3-way bf16 split, unscaled gradients, no step verdict, triple planes);
     # 'hx2': the opt-in fast mode (2-way fp16 split, loss-scaled backward under the guard, pair planes)
     for mode in ('bx3', 'hx2'):
@@ -108,9 +126,9 @@ def _compare(tag, net, cfg, size, steps, n_pairs):
         assert st['math_after'] == mode and not st['bwd_full_range'] and st['scale_shift'] == 0, st
         if mode == 'bx3':
             assert st['scale_log2'] == 0.0, st                              # no loss scale in the default arithmetic
-        assert max(d_m[:third]) <= 4.0 * max(d_f32[:third]) + 1e-5, (mode, max(d_m[:third]), max(d_f32[:third]))
-        assert m_m <= 10.0 * m_f32 + 2e-6, (mode, m_m, m_f32)
-        assert e_m <= 10.0 * e_f32 + 2e-6, (mode, e_m, e_f32)
+        assert max(d_m[:third]) <= b_third, (mode, max(d_m[:third]), b_third)
+        assert m_m <= b_mean, (mode, m_m, b_mean)
+        assert e_m <= b_max, (mode, e_m, b_max)
         assert e_m <= 0.10 * l_or[-1], (mode, e_m, l_or[-1])
     out = os.path.join(ROOT, 'gpurun_out', 'margins')
     os.makedirs(out, exist_ok=True)
@@ -132,3 +150,40 @@ def test_50_steps_w32_256():
                reffusion_n_blocks=[2, 2, 2, 2, 2])
     cfg = O.default_cfg(width=32, nf=32, enc_blk_nums=[1, 1, 1, 28], ext_n_blocks=[4, 4, 4, 4], reffusion_n_blocks=[2, 2, 2, 2, 2])
     _compare('w32_256', net, cfg, 256, 50, 4)
+
+
+def test_1100_steps_w8_128_cross_the_range_survey():
+    """hx2 (the opt-in fast mode) runs a range survey every 1000 steps: an eager step that measures every fp16-split operand and may
+    move the loss scale or switch a pass to the 3-way bf16 split, after which the graphs are re-captured.  1100 steps of the small
+    network cross that boundary once: no step skipped, scale and arithmetic unchanged, the loss curve continuous across the survey
+    step and equal in kind to the default arithmetic's (bx3, which has no scale, guard or survey) over the same 1100 steps."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    net = dict(width=8, nf=8, enc_blk_nums=[1, 1, 1, 1], dec_blk_nums=[1, 1, 1, 1], middle_blk_num=1, ext_n_blocks=[1, 1, 1, 1],
+               reffusion_n_blocks=[1, 1, 1, 1, 1])
+    cfg = O.default_cfg(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
+    data = [O.synth_pair(1, 128, 128, seed=4000 + i) for i in range(8)]
+    steps = 1100
+    l_h, st = _hip_run('hx2', net, cfg, 3, data, steps, periods=[400, 800])
+    l_b, st_b = _hip_run('bx3', net, cfg, 3, data, steps, periods=[400, 800])
+    assert all(math.isfinite(v) for v in l_h) and all(math.isfinite(v) for v in l_b)
+    assert st['skipped'] == 0 and st['applied'] == steps, st
+    assert st['math_after'] == 'hx2' and not st['bwd_full_range'] and st['scale_shift'] == 0, st
+    assert st_b['skipped'] == 0 and st_b['applied'] == steps and st_b['scale_log2'] == 0.0, st_b
+    # continuity across the survey step (iteration 1000 +- 8: the 8 pairs cycle, so compare like with like one cycle apart)
+    around = [abs(l_h[i] - l_h[i - 8]) for i in range(992, 1016)]
+    before = [abs(l_h[i] - l_h[i - 8]) for i in range(900, 992)]
+    d = [abs(a - b) for a, b in zip(l_h, l_b)]
+    print(f'w8_128 1100 steps: loss {l_h[0]:.5f} -> {l_h[-1]:.5f} (hx2) / {l_b[-1]:.5f} (bx3); max |hx2 - bx3| {max(d):.3e} '
+          f'(steps 990..1010: {max(d[990:1010]):.3e}); cycle-to-cycle change around the survey {max(around):.3e}, before it {max(before):.3e}; '
+          f'state {st}')
+    assert max(around) <= 3.0 * max(before) + 1e-5, (max(around), max(before))
+    # two realisations of a chaotic map 1100 steps apart from their common start: the same curve, not the same numbers
+    rel = max(x / b for x, b in zip(d, l_b))
+    tail_h, tail_b = sum(l_h[-100:]) / 100, sum(l_b[-100:]) / 100
+    print(f'   largest |hx2 - bx3| / loss at a step {rel:.3f}; mean loss of the last 100 steps {tail_h:.5f} / {tail_b:.5f}')
+    assert rel <= 0.25 and abs(tail_h - tail_b) <= 0.05 * tail_b, (rel, tail_h, tail_b)
+    out = os.path.join(ROOT, 'gpurun_out', 'margins')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'long_horizon_w8_128_1100.json'), 'w') as fh:
+        json.dump({'steps': steps, 'loss_hx2': l_h, 'loss_bx3': l_b, 'state_hx2': st, 'state_bx3': st_b}, fh)
