@@ -215,6 +215,20 @@ typedef struct TdrWgradDesc {
 int64_t tdr_wgrad_ws_floats(const TdrWgradDesc* d);
 int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream);
 
+/* Grouped 1x1 weight gradients (round 5): the leaf weight gradients of a whole level of NAFBlocks -- autograd's dW / db of conv1, conv4,
+ * conv5 of every block, models/archs/network_nafnet_guided_arch.py:183-205,216-238 -- have the same shape and nothing downstream in
+ * the backward pass reads them, so they run as ONE launch + ONE fixed-order reduction after the data-gradient chain (deterministic).
+ * `d` carries the common shape (N, Cin, Cout, H = OH, W = OW, KH = 1, in_ns, dout_ns, gate, math 1 or 2); its pointers are ignored.
+ * `table`: TdrWg1GroupEntry[nprob] in DEVICE memory; entry p: the operands, the problem's own workspace of
+ * tdr_wgrad1x1_group_ws_floats(d, nprob) floats (`part`; `dbpart` = part + bpp * Cout * Cin with bpp = (ws_floats / (Cout * (Cin + 1))),
+ * or NULL for no bias gradient) and the outputs g [Cout][Cin], db [Cout] or NULL. */
+typedef struct TdrWg1GroupEntry {
+    const float* in; const float* dout; float* part; float* dbpart; float* g; float* db;
+} TdrWg1GroupEntry;
+int tdr_wgrad1x1_group_supported(const TdrWgradDesc* d);
+int64_t tdr_wgrad1x1_group_ws_floats(const TdrWgradDesc* d, int nprob);
+int tdr_wgrad1x1_group(const TdrWgradDesc* d, int nprob, const void* table, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Streaming (HBM-bound) kernels.
  * ------------------------------------------------------------------------- */

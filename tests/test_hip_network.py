@@ -198,7 +198,8 @@ def test_side_stream_weight_gradients_match(E):
     res = []
     for side in (False, True):
         prev, K.SIDE_WGRAD = K.SIDE_WGRAD, side
-        try:
+        grp, E.GROUP_LEAVES = E.GROUP_LEAVES, False      # (same kernels on the same operands: the grouped launch of the deferred leaves
+        try:                                              #  cuts the pixel sums differently, tests/test_hip_wgrad1x1_group.py)
             out, saved = E.net_fwd(P, cfg, lq.cuda(), ref.cuda())
             loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0)
             G = E.net_bwd(dpred, P, cfg, saved)
@@ -206,6 +207,7 @@ def test_side_stream_weight_gradients_match(E):
             res.append({k: v.clone() for k, v in G.items()})
         finally:
             K.SIDE_WGRAD = prev
+            E.GROUP_LEAVES = grp
     assert set(res[0]) == set(res[1])
     for k in res[0]:
         if k.startswith('masa_enc.'):
@@ -226,6 +228,7 @@ def test_deferred_leaf_weight_gradients_match(E):
     res = []
     for defer in (False, True, True):
         prev, E.DEFER_WGRAD = E.DEFER_WGRAD, defer
+        grp, E.GROUP_LEAVES = E.GROUP_LEAVES, False      # (per-leaf launches: the grouped form is compared in tests/test_hip_wgrad1x1_group.py)
         try:
             out, saved = E.net_fwd(P, cfg, lq.cuda(), ref.cuda())
             loss, dpred = K.l1_loss(out.contiguous(), gt.cuda(), 1.0)
@@ -236,6 +239,7 @@ def test_deferred_leaf_weight_gradients_match(E):
             res.append({k: v.clone() for k, v in G.items()})
         finally:
             E.DEFER_WGRAD = prev
+            E.GROUP_LEAVES = grp
     assert E._late is None
     for other in res[1:]:
         assert set(res[0]) == set(other)

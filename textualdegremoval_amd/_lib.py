@@ -148,6 +148,9 @@ SIGNATURES = {
     'tdr_pack_patches': (i32, [c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_wgrad_ws_floats': (i64, [C.POINTER(TdrWgradDesc)]),
     'tdr_conv_wgrad': (i32, [C.POINTER(TdrWgradDesc), c_fp]),
+    'tdr_wgrad1x1_group_supported': (i32, [C.POINTER(TdrWgradDesc)]),
+    'tdr_wgrad1x1_group_ws_floats': (i64, [C.POINTER(TdrWgradDesc), i32]),
+    'tdr_wgrad1x1_group': (i32, [C.POINTER(TdrWgradDesc), i32, c_fp, c_fp]),
     'tdr_layernorm2d_fwd': (i32, [c_fp, i64, c_fp, c_fp, f32, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_ln_ws_floats': (i64, [i32, i32, i32]),
     'tdr_layernorm2d_bwd': (i32, [c_fp, c_fp, i64, c_fp, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp,

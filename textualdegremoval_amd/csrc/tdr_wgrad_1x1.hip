@@ -265,27 +265,46 @@ int launch_g1(const WgArgs& a, int N, hipStream_t st) {
 // k-step's image sits 64 bytes off a multiple of 128 so that the 16 lanes of a ds_write_b64 group (2 rows x 8 pieces) do too.
 // KQ = 1: the same pipeline on 4 waves and 16-pixel stages (no in-block K split): the footprint of the LDS-DMA kernel (256 threads, 49 KiB),
 // for launches that should share a CU with the kernels of another stream.
-template <bool GATE, int SCH, int KQ>
+// GRP: one launch over many problems of ONE shape (tdr_wgrad1x1_group): blockIdx.x = problem * grp_bpp + split, the problem's operand /
+// partial pointers come from a table in device memory.
+// TNW: 32-column tiles per wave along the input channels: 2 = 128 x 128 output tiles, 1 = 128 x 64 (layers with 64 input channels: the
+// 64 x 64-tile LDS-DMA form splits every value in the wave that multiplies it -- 14.7 VALU per MFMA, 0.07 of the matrix ceiling there).
+template <bool GATE, int SCH, int KQ, bool GRP = false, int TNW = 2>
 __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
+    constexpr int BN = 64 * TNW, NI = 2 + TNW;        // input-channel rows of the tile; 64-row groups a thread loads from
     constexpr int NS = SCH == G1_BX3 ? 3 : 2, NP = SCH == G1_BX3 ? 6 : 3;
-    constexpr int ROWS = 256;                          // 128 dout rows | 128 input rows
+    constexpr int ROWS = 128 + BN;                     // 128 dout rows | BN input rows
     constexpr int PLANE = ROWS * 32;                   // bytes of one plane of one k-step
     constexpr int KSTR = NS * PLANE + 64;              // k-step image stride
     constexpr int BUF = KQ * KSTR;                     // one stage
     constexpr int PXS = 16 * KQ;                       // pixels per stage
-    constexpr int NL = GATE ? 6 : 4;                   // dwordx4 loads per thread and stage
+    constexpr int NL = GATE ? NI + TNW : NI;           // dwordx4 loads per thread and stage
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = KQ == 2 ? wave >> 2 : 0, wm = (wave >> 1) & 1, wn = wave & 1;
     const int j = lane & 31, kg = lane >> 5;
 
-    const int split = blockIdx.x;
+    // GRP: 1-D grid in chunks of 8 T blocks (T = output tiles of a problem): block r of a chunk is tile r / 8 of pair r % 8 -- the
+    // hardware deals consecutive workgroups round-robin to the 8 XCDs, so the T tiles of one (problem, image, split) pair land on ONE
+    // XCD at about the same time and share its L2 (each operand row is needed by Cout / 128 or Cin / 128 of them); in (pair, tile)
+    // order they ran on different XCDs at different times and every tile fetched its rows from HBM (2.7 x the bytes).
+    int prob = 0, split = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if constexpr (GRP) {
+        const int T = a.tiles_x * a.tiles_y;
+        const int chunk = (int)blockIdx.x / (8 * T), r = (int)blockIdx.x - chunk * (8 * T);
+        const int pair = chunk * 8 + (r & 7), tile = r >> 3;
+        if (pair >= a.grp_pairs) return;
+        prob = pair / a.grp_bpp; split = pair - prob * a.grp_bpp;
+        by = tile % a.tiles_x; bz = tile / a.tiles_x;
+        const TdrWg1GroupEntry e = static_cast<const TdrWg1GroupEntry*>(a.grp_tab)[prob];
+        a.in = e.in; a.dout = e.dout; a.part = e.part; a.dbpart = e.dbpart;
+    }
     const int n = split / a.spi;
     const int s_begin = (split % a.spi) * a.tps;                // (the plan counts 32-pixel stages)
     const int s_end = min(s_begin + a.tps, a.tpi);
     const int nst = (s_end - s_begin) * (2 / KQ);
-    const int co0 = blockIdx.y * 128, ci0 = blockIdx.z * 128;
+    const int co0 = by * 128, ci0 = bz * BN;
     const long HW = (long)a.OH * a.OW;
     const float* in_n = a.in + (long)n * a.in_ns;
     const float* do_n = a.dout + (long)n * a.dout_ns;
@@ -294,30 +313,32 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
     const int lp = tid & (4 * KQ - 1), lr = tid >> (KQ == 2 ? 3 : 2);
     const float* src[NL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int row = lr + 64 * i;
         const float* base = i < 2 ? do_n + (long)min(co0 + row, a.Cout - 1) * HW : in_n + (long)min(ci0 + row - 128, a.Cin - 1) * HW;
         src[i] = base + (long)s_begin * G1_PX + 4 * lp;
     }
-    if constexpr (GATE) { src[4] = src[2] + a.gate_off; src[5] = src[3] + a.gate_off; }
+    if constexpr (GATE) {
+#pragma unroll
+        for (int i = 2; i < NI; ++i) src[i + TNW] = src[i] + a.gate_off;
+    }
     const int w_off = (lp >> 2) * KSTR + lr * 32 + ((((lp >> 1) & 1) ^ ((lr >> 3) & 1)) << 4) + (lp & 1) * 8;     // + i * 64 * 32 + plane * PLANE
 
     // ---- multiplier role
-    int a_off[2], b_off[2];
+    int a_off[2], b_off[TNW];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        a_off[x] = kq * KSTR + (wm * 64 + x * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
-        b_off[x] = kq * KSTR + (128 + wn * 64 + x * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
-    }
-    f32x16 acc[2][2];
+    for (int x = 0; x < 2; ++x) a_off[x] = kq * KSTR + (wm * 64 + x * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
+#pragma unroll
+    for (int y = 0; y < TNW; ++y) b_off[y] = kq * KSTR + (128 + (wn * TNW + y) * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
+    f32x16 acc[2][TNW];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
+        for (int y = 0; y < TNW; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
     float dsum[2] = {0.f, 0.f};
-    const bool want_db = a.dbpart != nullptr && blockIdx.z == 0;      // workgroup-uniform
+    const bool want_db = a.dbpart != nullptr && bz == 0;      // workgroup-uniform
 
     constexpr int SA[6] = {SCH == G1_HX2 ? 1 : 2, 0, SCH == G1_HX2 ? 0 : 1, 1, 0, 0};      // hx2: mh hm hh ; bx3: lh hl mm mh hm hh
     constexpr int SB[6] = {0, SCH == G1_HX2 ? 1 : 2, SCH == G1_HX2 ? 0 : 1, 0, 1, 0};
@@ -338,14 +359,14 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
         // stages past the end are split like the others (branch-free pipeline) with their dout planes zeroed: they add nothing
         const float zf = live ? 1.f : 0.f, lf = want_db ? zf : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             f32x4 v = r[i];
             if (i < 2) {
                 v *= zf;
                 dsum[i] = __builtin_fmaf(lf, (v[0] + v[1]) + (v[2] + v[3]), dsum[i]);
             }
             else if constexpr (GATE) {
-                v *= r[i + 2];
+                v *= r[i + TNW];
                 asm volatile("" : "+v"(v));                  // every plane from the same rounded product
             }
             unsigned p0[NS], p1[NS];
@@ -360,29 +381,29 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
             for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(dst + i * (64 * 32) + s * PLANE) = make_uint2(p0[s], p1[s]);
         }
     };
-    auto read_frags = [&](int rd, g1u32x4 (&fa)[2][NS], g1u32x4 (&fb)[2][NS]) {
+    auto read_frags = [&](int rd, g1u32x4 (&fa)[2][NS], g1u32x4 (&fb)[TNW][NS]) {
         const unsigned char* st = smem_raw + rd;
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                fa[x][s] = *reinterpret_cast<const g1u32x4*>(st + a_off[x] + s * PLANE);
-                fb[x][s] = *reinterpret_cast<const g1u32x4*>(st + b_off[x] + s * PLANE);
-            }
+            for (int x = 0; x < 2; ++x) fa[x][s] = *reinterpret_cast<const g1u32x4*>(st + a_off[x] + s * PLANE);
+#pragma unroll
+            for (int y = 0; y < TNW; ++y) fb[y][s] = *reinterpret_cast<const g1u32x4*>(st + b_off[y] + s * PLANE);
+        }
     };
-    auto mmas = [&](const g1u32x4 (&fa)[2][NS], const g1u32x4 (&fb)[2][NS]) {
+    auto mmas = [&](const g1u32x4 (&fa)[2][NS], const g1u32x4 (&fb)[TNW][NS]) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = mma(fa[x][SA[p]], fb[y][SB[p]], acc[x][y]);
+                for (int y = 0; y < TNW; ++y) acc[x][y] = mma(fa[x][SA[p]], fb[y][SB[p]], acc[x][y]);
     };
     // the split of stage s + 1 rides in the shadow of the MFMAs of stage s: per MFMA a handful of VALU, a plane store every other one
     auto interleave = [&]() {
-        constexpr int NM = NP * 4;
-        constexpr int VPM = (4 * (SCH == G1_BX3 ? 22 : 6) + (GATE ? 8 : 0) + 16 + NM - 1) / NM + 1;
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NS, 0);
+        constexpr int NM = NP * 2 * TNW;
+        constexpr int VPM = (NI * (SCH == G1_BX3 ? 22 : 6) + (GATE ? 4 * TNW : 0) + 16 + NM - 1) / NM + 1;
+        __builtin_amdgcn_sched_group_barrier(0x100, (2 + TNW) * NS, 0);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
     // ---- two stage images in LDS: iteration s multiplies stage s, splits stage s + 1 (raw since iteration s - 1 / s - 2) into the
     // other image and issues the loads of stage s + DIST
     f32x4 raw0[NL], raw1[NL];
-    g1u32x4 fa[2][NS], fb[2][NS];
+    g1u32x4 fa[2][NS], fb[TNW][NS];
     load(0, raw0);
     load(1, raw1);
     split_store(raw0, 0, true);
@@ -432,7 +453,7 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
+            for (int y = 0; y < TNW; ++y)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) red[((wq * 4 + x * 2 + y) * 16 + r) * 64 + lane] = acc[x][y][r];
     }
@@ -444,8 +465,8 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int ci = ci0 + (wn * 2 + y) * 32 + j;
+        for (int y = 0; y < TNW; ++y) {
+            const int ci = ci0 + (wn * TNW + y) * 32 + j;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = KQ == 2 ? acc[x][y][r] + red[((wq * 4 + x * 2 + y) * 16 + r) * 64 + lane] : acc[x][y][r];
@@ -496,6 +517,107 @@ int launch_g1_gr(const WgArgs& a, const TdrWgradDesc* d, hipStream_t st) {
     return g ? launch_g1<TMW, TNW, true, SCH, 2>(a, d->N, st) : launch_g1<TMW, TNW, false, SCH, 2>(a, d->N, st);
 }
 
+// ---- grouped launch: the deferred leaf weight gradients of a whole level (same N, Cin, Cout, HW, gate) in ONE launch + ONE reduction.
+// A per-problem launch is 256 workgroups x 16 stages: a third of its time is ramp, prologue, partial write and the reduction launch
+// (profiles/r5/probe_wgrad1x1_fixed.log: 10 - 14 us fixed next to 16 x 1.5 - 1.9 us), and one workgroup per CU leaves every stall
+// uncovered.  Grouped, a workgroup takes a whole image of one tile (>= 32 stages, 1 / 8 of the partial volume), thousands of
+// workgroups keep 2 - 3 resident per CU, and the fixed-order reduction of all problems is one launch.
+template <int KL>
+__global__ __launch_bounds__(256) void wgrad1x1_grp_reduce_kernel(const TdrWg1GroupEntry* __restrict__ tab, long elems, int nsplit, int Cout, int nb_main) {
+    const TdrWg1GroupEntry e = tab[blockIdx.y];
+    const bool second = (int)blockIdx.x >= nb_main;
+    const long ne = second ? Cout : elems;
+    const float* p = second ? e.dbpart : e.part;
+    float* o = second ? e.db : e.g;
+    const long i = ((int)blockIdx.x - (second ? nb_main : 0)) * 256L + threadIdx.x;
+    if (i >= ne || o == nullptr) return;
+    float s0 = 0.f;
+    for (int k = 0; k < nsplit; k += 8) {            // fixed order, eight partials in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k + u < nsplit ? p[(long)(k + u) * ne + i] : 0.f;
+        s0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    o[i] = s0;
+}
+
+struct G1GroupPlan { int spi, tps, tpi, bpp; };
+
+G1GroupPlan g1_group_plan(const TdrWgradDesc* d, int nprob) {
+    G1GroupPlan p;
+    const long HW = (long)d->OH * d->OW;
+    p.tpi = (int)(HW / G1_PX);
+    const long tiles = (long)tdr_cdiv(d->Cout, 128) * tdr_cdiv(d->Cin, d->Cin > 64 ? 128 : 64);
+    // one image per workgroup unless that leaves the chip short of workgroups (few problems / few tiles): then split the images,
+    // never below 8 stages per workgroup
+    long spi = 1;
+    while ((long)nprob * d->N * spi * tiles < 1024 && p.tpi / (spi * 2) >= 8) spi *= 2;
+    p.tps = tdr_cdiv(p.tpi, spi);
+    p.spi = tdr_cdiv(p.tpi, p.tps);
+    p.bpp = d->N * p.spi;
+    return p;
+}
+
+template <bool GATE, int SCH, int TNW>
+int launch_grp(const WgArgs& a, int nprob, hipStream_t st) {
+    constexpr int NS = SCH == G1_BX3 ? 3 : 2;
+    constexpr size_t lds = (size_t)2 * (NS * (128 + 64 * TNW) * 32 + 64);
+    const int T = a.tiles_x * a.tiles_y;
+    dim3 grid((unsigned)tdr_cdiv(a.grp_pairs, 8) * 8 * T);
+    hipLaunchKernelGGL((wgrad1x1_sp_kernel<GATE, SCH, 1, true, TNW>), grid, dim3(256), lds, st, a);
+    TDR_LAUNCH_CHECK("wgrad1x1_sp_kernel<grouped>");
+    return TDR_OK;
+}
+
+}  // namespace
+
+extern "C" int tdr_wgrad1x1_group_supported(const TdrWgradDesc* d) {
+    if (!d || (d->math != 1 && d->math != 2) || d->per_image) return 0;
+    if (d->KH != 1 || d->stride != 1 || d->pad != 0 || d->H != d->OH || d->W != d->OW) return 0;
+    const long HW = (long)d->OH * d->OW;
+    if (HW % G1_PX != 0 || d->in_ns % 4 != 0 || d->dout_ns % 4 != 0) return 0;
+    return d->Cin >= 64 && d->Cout > 64;          // (Cin = 64: 128 x 64 output tiles)
+}
+
+// floats of workspace PER PROBLEM: [bpp][Cout][Cin] partials, then [bpp][Cout] bias-gradient partials
+extern "C" int64_t tdr_wgrad1x1_group_ws_floats(const TdrWgradDesc* d, int nprob) {
+    const G1GroupPlan p = g1_group_plan(d, nprob);
+    return (int64_t)p.bpp * d->Cout * d->Cin + (int64_t)p.bpp * d->Cout;
+}
+
+// d: the common shape (N, Cin, Cout, OH, OW, in_ns, dout_ns, gate, math); its pointers are ignored.  table: TdrWg1GroupEntry[nprob] in
+// DEVICE memory (in, dout, part = the problem's workspace, dbpart = part + bpp * Cout * Cin or NULL, g, db or NULL).
+extern "C" int tdr_wgrad1x1_group(const TdrWgradDesc* d, int nprob, const void* table, void* stream) {
+    TDR_REQUIRE(d && table && nprob > 0, "tdr_wgrad1x1_group: null argument");
+    TDR_REQUIRE(tdr_wgrad1x1_group_supported(d), "tdr_wgrad1x1_group: shape not supported (1x1, whole 32-pixel stages, channels > 64, split arithmetic)");
+    const G1GroupPlan p = g1_group_plan(d, nprob);
+    WgArgs a;
+    a.in = nullptr; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
+    a.gate_off = (long)d->Cin * d->H * d->W;
+    a.dout = nullptr; a.dout_ns = d->dout_ns; a.Cout = d->Cout; a.OH = d->OH; a.OW = d->OW;
+    const bool wide = d->Cin > 64;
+    a.pad = 0; a.tw_log2 = 5; a.tiles_x = tdr_cdiv(d->Cout, 128); a.tiles_y = tdr_cdiv(d->Cin, wide ? 128 : 64);      // (grouped: the output tile grid)
+    a.tpi = p.tpi; a.tps = p.tps; a.spi = p.spi;
+    a.part = nullptr; a.dbpart = nullptr;
+    a.scheme = d->math == 2 ? 1 : 0;
+    a.grp_tab = table; a.grp_bpp = p.bpp; a.grp_pairs = nprob * p.bpp;
+    hipStream_t st = (hipStream_t)stream;
+    const bool g = d->gate != 0;
+    int rc;
+    if (a.scheme == 1) rc = g ? (wide ? launch_grp<true, G1_HX2, 2>(a, nprob, st) : launch_grp<true, G1_HX2, 1>(a, nprob, st))
+                              : (wide ? launch_grp<false, G1_HX2, 2>(a, nprob, st) : launch_grp<false, G1_HX2, 1>(a, nprob, st));
+    else rc = g ? (wide ? launch_grp<true, G1_BX3, 2>(a, nprob, st) : launch_grp<true, G1_BX3, 1>(a, nprob, st))
+                : (wide ? launch_grp<false, G1_BX3, 2>(a, nprob, st) : launch_grp<false, G1_BX3, 1>(a, nprob, st));
+    if (rc != TDR_OK) return rc;
+    const long elems = (long)d->Cout * d->Cin;
+    const int nb_main = tdr_cdiv(elems, 256), nb2 = tdr_cdiv(d->Cout, 256);
+    hipLaunchKernelGGL(wgrad1x1_grp_reduce_kernel<1>, dim3(nb_main + nb2, nprob), dim3(256), 0, st, static_cast<const TdrWg1GroupEntry*>(table), elems,
+                       p.bpp, d->Cout, nb_main);
+    TDR_LAUNCH_CHECK("wgrad1x1_grp_reduce_kernel");
+    return TDR_OK;
+}
+
+namespace {
 }  // namespace
 
 // 1x1 / stride 1 / pad 0 on a split scheme, rows of whole 32-pixel stages, channel counts that fill whole 64-row tiles

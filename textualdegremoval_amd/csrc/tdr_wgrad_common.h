@@ -11,6 +11,9 @@ struct WgArgs {
     float* part;
     float* dbpart;      // optional [nsplit][Cout]: per-split sums of dout rows (bias gradient), ci-tile 0 only
     int scheme;         // split-kernel operand scheme: 0 = 3-way bf16, 1 = 2-way fp16 (TdrWgradDesc.math == 2)
+    const void* grp_tab; // grouped launch (tdr_wgrad1x1_group): TdrWg1GroupEntry[] in device memory, in / dout / part / dbpart per problem
+    int grp_bpp;        // ... (image, split) pairs per problem (= N * spi); 0: a single problem, pointers above
+    int grp_pairs;      // ... nprob * grp_bpp; the grid is 1-D: 64-block chunks = 8 pairs (one per XCD) x the output tiles of a pair
 };
 
 struct WgPlan { int tw_log2, tiles_x, tiles_y, tpi, tps, spi, cfg, WKw, BMc, BNc; };

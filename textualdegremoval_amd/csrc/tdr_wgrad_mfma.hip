@@ -295,6 +295,7 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     a.in = d->in; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
     a.gate_off = (long)d->Cin * d->H * d->W;
     a.dout = d->dout; a.dout_ns = d->dout_ns; a.Cout = d->Cout; a.OH = d->OH; a.OW = d->OW;
+    a.grp_tab = nullptr; a.grp_bpp = 0; a.grp_pairs = 0;
     a.pad = d->pad; a.tw_log2 = p.tw_log2; a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.tpi = p.tpi; a.tps = p.tps; a.spi = p.spi;
     // a single partial per output group (per-image Grams / grouped GEMMs with one split, or one image with one split) IS the
     // result: the kernel writes it straight to g and the fixed-order reduction (here a 131 MB copy for the 20 x 1280 x 1280

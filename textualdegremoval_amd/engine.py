@@ -65,6 +65,9 @@ def maybe_join():
 DEFER_WGRAD = os.environ.get('TDR_DEFER_WGRAD', '1') == '1'
 DEFER_LN_FINISH = os.environ.get('TDR_DEFER_LN_FINISH', '1') == '1'     # also the reductions of the LayerNorm-gradient partials
 LEAF_LANES = int(os.environ.get('TDR_LEAF_LANES', '1'))                 # HIP streams the deferred leaves are spread over
+# deferred 1x1 leaf weight gradients of one shape (a level's conv1 / conv4, its conv5) share ONE launch + ONE reduction
+# (kernels.wgrad1x1_group, csrc/tdr_wgrad_1x1.hip): no per-launch ramp / prologue / partial write / reduction launch, 1 / 8 of the partials
+GROUP_LEAVES = os.environ.get('TDR_GROUP_LEAVES', '1') == '1' 
 _late = None            # [(prefix, closure -> {name: grad})] while a whole-network backward collects deferred leaves
 _late_pre = ''
 
@@ -91,6 +94,18 @@ def _leaf(keep, fn, G):
     with K.on_side(*keep):
         for k, v in fn().items():
             G[k] = v                    # (item by item: a GradSink collector acts on __setitem__)
+
+
+def _leaf_wgrad1x1(keep, req, post, G):
+    """a leaf whose work is ONE 1x1 weight gradient with bias gradient -- req = (x, dout, Cout, Cin, gate) -- followed by `post(g, db)
+    -> {name: grad}`: queued for the grouped launch when leaves are being collected and the shape qualifies, an ordinary leaf otherwise"""
+    x, dout, Cout, Cin, gate = req
+    if _late is not None and GROUP_LEAVES:
+        key = K.wgrad1x1_group_key(x, dout, Cout, Cin, gate)
+        if key is not None:
+            _late.append((_late_pre, ('grp', key, req, post), keep))
+            return
+    _leaf(keep, lambda: post(*K.side_keep(*K.conv_wgrad(x, dout, Cout, Cin, 1, gate=gate, want_db=True))), G)
 
 
 class late_leaves:
@@ -124,8 +139,17 @@ def run_late_leaves(G, main_chain):
         return
     if LEAF_LANES <= 1:
         with K.lane(0):
-            results = [(pre, fn()) for pre, fn, _ in late]
+            groups, outs = {}, {}
+            for i, (pre, fn, _) in enumerate(late):
+                if isinstance(fn, tuple):
+                    groups.setdefault(fn[1], []).append(i)
+            for seq, (key, idxs) in enumerate(groups.items()):     # one launch + one reduction per shape
+                for i, r in zip(idxs, K.wgrad1x1_group([late[i][1][2] for i in idxs], seq=seq)):
+                    outs[i] = r
+            results = [(pre, fn[3](*outs[i]) if isinstance(fn, tuple) else fn()) for i, (pre, fn, _) in enumerate(late)]
     else:
+        late = [(pre, (lambda f=fn: f[3](*K.conv_wgrad(f[2][0], f[2][1], f[2][2], f[2][3], 1, gate=f[2][4], want_db=True)))
+                 if isinstance(fn, tuple) else fn, keep) for pre, fn, keep in late]
         # independent leaves round-robin over a few streams: the ramp / tail / split-K reduction of one overlaps the main loop of the next
         results = []
         for i, (pre, fn, _) in enumerate(late):
@@ -193,9 +217,8 @@ def naf_bwd(dout, P, saved):
     beta, gamma = P['beta'].view(-1), P['gamma'].view(-1)
     late = _late is not None and DEFER_LN_FINISH
     # ---- conv5 / gamma chain (parameter gradients only: a leaf off the data-gradient chain)
-    def leaf5():
+    def post5(G5, S5):
         g = {}
-        G5, S5 = K.side_keep(*K.conv_wgrad(t4, dout, c_out, c, 1, gate=True, want_db=True))
         dw5, db5, dgam = K.side_keep(*K.scaled_conv_param_grads(G5.view(c_out, c), S5, P['conv5.weight'], P['conv5.bias'], gamma))
         if c_out == c:
             g['conv5.weight'], g['conv5.bias'], g['gamma'] = dw5.view(c, c, 1, 1), db5, dgam.view(1, c, 1, 1)
@@ -208,7 +231,7 @@ def naf_bwd(dout, P, saved):
             K.copy_rows(dgam, 0, fg, 0, 1, c_out)
             g['conv5.weight'], g['conv5.bias'], g['gamma'] = fw, fb, fg
         return g
-    _leaf((t4, dout), leaf5, G)
+    _leaf_wgrad1x1((t4, dout), (t4, dout, c_out, c, True), post5, G)
     fused = FUSE_TAIL and K.naf_tail_supported(c, H * W, c_out) and dout.is_contiguous() and \
         _dgrad_fused_ok()
     if fused:
@@ -228,10 +251,8 @@ def naf_bwd(dout, P, saved):
         wp, mp, *_ = K.pack_weights(P['conv5.weight'][:c_out], PACK_DGRAD_S1)
         dt4 = K.conv_forward(dout, wp, mp, c, 1, epi=EPI_GATEBWD, kscale=gamma, aux=t4)
     # ---- conv4
-    def leaf4():
-        g4, b4 = K.conv_wgrad(yn, dt4, 2 * c, c, 1, want_db=True)
-        return {'conv4.weight': g4.view(2 * c, c, 1, 1), 'conv4.bias': b4}
-    _leaf((yn, dt4), leaf4, G)
+    _leaf_wgrad1x1((yn, dt4), (yn, dt4, 2 * c, c, False),
+                   lambda g4, b4: {'conv4.weight': g4.view(2 * c, c, 1, 1), 'conv4.bias': b4}, G)
     if not fused:
         wp, mp, *_ = K.pack_weights(P['conv4.weight'], PACK_DGRAD_S1)
         dyn = K.conv_forward(dt4, wp, mp, c, 1)
@@ -257,10 +278,8 @@ def naf_bwd(dout, P, saved):
     else:
         G['conv2.weight'], G['conv2.bias'] = gdw, gdb
     # ---- conv1
-    def leaf1():
-        g1, b1 = K.conv_wgrad(xn, dt1, 2 * c, c, 1, want_db=True)
-        return {'conv1.weight': g1.view(2 * c, c, 1, 1), 'conv1.bias': b1}
-    _leaf((xn, dt1), leaf1, G)
+    _leaf_wgrad1x1((xn, dt1), (xn, dt1, 2 * c, c, False),
+                   lambda g1, b1: {'conv1.weight': g1.view(2 * c, c, 1, 1), 'conv1.bias': b1}, G)
     if FUSE_TAIL and K.naf_tail_supported(c, H * W) and _dgrad_fused_ok() and x.is_contiguous() and dy.is_contiguous():
         # conv1 dgrad -> norm1 bwd (+ dy) in one launch
         w1t = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)[0]

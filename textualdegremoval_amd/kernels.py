@@ -637,6 +637,93 @@ def conv_wgrad(x, dout, Cout, Cin, KH, stride=1, pad=0, gate=False, per_image=Fa
     return (g, db) if want_db else g
 
 
+def _wgrad1x1_desc(x, dout, Cout, Cin, gate):
+    N, _, H, W = x.shape
+    d = TdrWgradDesc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.OH, d.OW = N, Cin, H, W, Cout, H, W
+    d.KH, d.stride, d.pad = 1, 1, 0
+    d.in_ns, d.gate, d.dout_ns = _dense_nchw(x), 1 if gate else 0, _dense_nchw(dout)
+    d.per_image = 0
+    if fp16_path() and GRAD_SCALED and WGRAD_1X1_BX3:
+        d.math = 2 if MATH == 'hx2' else 3
+    else:
+        d.math = 1 if (MATH != 'f32' and WGRAD_1X1_BX3) else 0
+    return d
+
+
+def wgrad1x1_group_key(x, dout, Cout, Cin, gate):
+    """hashable shape signature under which 1x1 weight-gradient requests can share one grouped launch, or None if this one cannot
+    (csrc/tdr_wgrad_1x1.hip, tdr_wgrad1x1_group: same N, channels, image size, strides, gate; 16-byte aligned dense operands)"""
+    if x.dim() != 4 or dout.dim() != 4 or x.shape[2:] != dout.shape[2:] or x.data_ptr() % 16 or dout.data_ptr() % 16:
+        return None
+    d = _wgrad1x1_desc(x, dout, Cout, Cin, gate)
+    if not _lib.load().tdr_wgrad1x1_group_supported(C.byref(d)):
+        return None
+    return (d.N, Cin, Cout, d.H, d.W, int(d.in_ns), int(d.dout_ns), int(d.gate), int(d.math))
+
+
+# Pinned pointer tables of the grouped launches, per call site (`seq` = index of the group within a backward pass) and size.  Allocated
+# in EAGER steps only (never inside a stream capture; every shape runs eagerly before it is captured).  The upload node of a hipGraph
+# re-reads its pinned block at every replay, so a block handed to a capture is never written again: captures take theirs from a ring of
+# GRP_CAP_RING blocks (only the newest graphs of a model are replayed), eager steps alternate between two blocks of their own.
+GRP_CAP_RING = 4
+_grp_pool = {}
+
+
+def _grp_table(seq, nrows, capturing):
+    key = (seq, nrows)
+    ent = _grp_pool.get(key)
+    if ent is None:
+        if capturing:
+            raise RuntimeError('kernels.wgrad1x1_group: this backward pass is being captured before it ever ran eagerly (no pinned table for '
+                               f'group {seq}); run one eager step of the shape first or set TDR_GROUP_LEAVES=0')
+        ent = _grp_pool[key] = dict(eager=[torch.empty(nrows, dtype=torch.int64).pin_memory() for _ in range(2)], ev=[None, None], flip=0,
+                                    cap=[torch.empty(nrows, dtype=torch.int64).pin_memory() for _ in range(GRP_CAP_RING)], cap_i=0)
+    if capturing:
+        host = ent['cap'][ent['cap_i'] % GRP_CAP_RING]
+        ent['cap_i'] += 1
+        return host, None
+    slot = ent['flip']
+    ent['flip'] ^= 1
+    if ent['ev'][slot] is not None:
+        ent['ev'][slot].synchronize()          # the upload that last read this block (two eager steps ago) has run
+    return ent['eager'][slot], (ent, slot)
+
+
+def wgrad1x1_group(reqs, seq=0, want_db=True):
+    """reqs: [(x, dout, Cout, Cin, gate)] of ONE wgrad1x1_group_key.  One launch + one fixed-order reduction for all of them.
+    Returns [(g [1, Cout, Cin, 1, 1], db [Cout] or None)] in request order."""
+    lib = _lib.load()
+    x0, d0, Cout, Cin, gate = reqs[0]
+    dev = x0.device
+    n = len(reqs)
+    d = _wgrad1x1_desc(x0, d0, Cout, Cin, gate)
+    per = int(lib.tdr_wgrad1x1_group_ws_floats(C.byref(d), n))
+    bpp = per // (Cout * (Cin + 1))
+    ws = workspace(per * n, dev, 'wgrad_group')
+    g = torch.empty(n, Cout, Cin, dtype=torch.float32, device=dev)
+    db = torch.empty(n, Cout, dtype=torch.float32, device=dev) if want_db else None
+    rows = []
+    for i, (x, do, *_r) in enumerate(reqs):
+        part = ws.data_ptr() + 4 * per * i
+        rows += [x.data_ptr(), do.data_ptr(), part, part + 4 * bpp * Cout * Cin if want_db else 0, g.data_ptr() + 4 * Cout * Cin * i,
+                 db.data_ptr() + 4 * Cout * i if want_db else 0]
+    capturing = torch.cuda.is_current_stream_capturing()
+    host, eager_slot = _grp_table(seq, len(rows), capturing)
+    host.copy_(torch.tensor(rows, dtype=torch.int64))
+    tab = torch.empty(len(rows), dtype=torch.int64, device=dev)
+    tab.copy_(host, non_blocking=True)
+    if eager_slot is not None:
+        ent, slot = eager_slot
+        ent['ev'][slot] = torch.cuda.Event()
+        ent['ev'][slot].record()
+    if _survey is not None and d.math >= 2:
+        for (_x, do, *_r) in reqs:
+            _survey.probe(do, 'grad')
+    check(lib.tdr_wgrad1x1_group(C.byref(d), n, tab.data_ptr(), _stream()), 'tdr_wgrad1x1_group')
+    return [(g[i].view(1, Cout, Cin, 1, 1), db[i] if want_db else None) for i in range(n)]
+
+
 def layernorm2d_fwd(x, w, b, eps, center=True):
     """center=False (b None): BiasFree_LayerNorm, y = x * rstd * w."""
     lib = _lib.load()
