@@ -550,8 +550,9 @@ G1GroupPlan g1_group_plan(const TdrWgradDesc* d, int nprob) {
     const long tiles = (long)tdr_cdiv(d->Cout, 128) * tdr_cdiv(d->Cin, d->Cin > 64 ? 128 : 64);
     // one image per workgroup unless that leaves the chip short of workgroups (few problems / few tiles): then split the images,
     // never below 8 stages per workgroup
+    static const long want = getenv("TDR_WG1_GRP_WANT") ? atol(getenv("TDR_WG1_GRP_WANT")) : 512;      // (256 / 512 / 1024 / 2048: 67.06 / 67.12 / 67.33 / 67.39 ms per step, profiles/r5/sweep_k.log)
     long spi = 1;
-    while ((long)nprob * d->N * spi * tiles < 1024 && p.tpi / (spi * 2) >= 8) spi *= 2;
+    while ((long)nprob * d->N * spi * tiles < want && p.tpi / (spi * 2) >= 8) spi *= 2;
     p.tps = tdr_cdiv(p.tpi, spi);
     p.spi = tdr_cdiv(p.tpi, p.tps);
     p.bpp = d->N * p.spi;

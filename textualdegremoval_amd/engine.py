@@ -96,16 +96,21 @@ def _leaf(keep, fn, G):
             G[k] = v                    # (item by item: a GradSink collector acts on __setitem__)
 
 
-def _leaf_wgrad1x1(keep, req, post, G):
-    """a leaf whose work is ONE 1x1 weight gradient with bias gradient -- req = (x, dout, Cout, Cin, gate) -- followed by `post(g, db)
-    -> {name: grad}`: queued for the grouped launch when leaves are being collected and the shape qualifies, an ordinary leaf otherwise"""
+def _leaf_wgrad1x1(keep, req, post, G, want_db=True):
+    """a leaf whose work is ONE 1x1 weight gradient (with the bias gradient unless want_db=False) -- req = (x, dout, Cout, Cin, gate) --
+    followed by `post(g, db) -> {name: grad}` (db None without a bias): queued for the grouped launch when leaves are being collected and
+    the shape qualifies, an ordinary leaf otherwise"""
     x, dout, Cout, Cin, gate = req
     if _late is not None and GROUP_LEAVES:
         key = K.wgrad1x1_group_key(x, dout, Cout, Cin, gate)
         if key is not None:
-            _late.append((_late_pre, ('grp', key, req, post), keep))
+            _late.append((_late_pre, ('grp', key + (want_db,), req + (want_db,), post), keep))
             return
-    _leaf(keep, lambda: post(*K.side_keep(*K.conv_wgrad(x, dout, Cout, Cin, 1, gate=gate, want_db=True))), G)
+
+    def run():
+        r = K.conv_wgrad(x, dout, Cout, Cin, 1, gate=gate, want_db=want_db)
+        return post(*K.side_keep(*r)) if want_db else post(K.side_keep(r), None)
+    _leaf(keep, run, G)
 
 
 class late_leaves:
@@ -144,12 +149,14 @@ def run_late_leaves(G, main_chain):
                 if isinstance(fn, tuple):
                     groups.setdefault(fn[1], []).append(i)
             for seq, (key, idxs) in enumerate(groups.items()):     # one launch + one reduction per shape
-                for i, r in zip(idxs, K.wgrad1x1_group([late[i][1][2] for i in idxs], seq=seq)):
+                for i, r in zip(idxs, K.wgrad1x1_group([late[i][1][2][:5] for i in idxs], seq=seq, want_db=key[-1])):
                     outs[i] = r
             results = [(pre, fn[3](*outs[i]) if isinstance(fn, tuple) else fn()) for i, (pre, fn, _) in enumerate(late)]
     else:
-        late = [(pre, (lambda f=fn: f[3](*K.conv_wgrad(f[2][0], f[2][1], f[2][2], f[2][3], 1, gate=f[2][4], want_db=True)))
-                 if isinstance(fn, tuple) else fn, keep) for pre, fn, keep in late]
+        def _single(f):
+            r = K.conv_wgrad(f[2][0], f[2][1], f[2][2], f[2][3], 1, gate=f[2][4], want_db=f[2][5])
+            return f[3](*r) if f[2][5] else f[3](r, None)
+        late = [(pre, (lambda f=fn: _single(f)) if isinstance(fn, tuple) else fn, keep) for pre, fn, keep in late]
         # independent leaves round-robin over a few streams: the ramp / tail / split-K reduction of one overlaps the main loop of the next
         results = []
         for i, (pre, fn, _) in enumerate(late):

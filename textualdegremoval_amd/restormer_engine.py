@@ -54,12 +54,10 @@ def _pw_bwd(dout, x, P, name, G):
     w = P[name + '.weight']
     Cout, Cin = w.shape[0], w.shape[1]
     has_b = (name + '.bias') in P
-    def leaf():                        # parameter gradient: a leaf off the data-gradient chain (engine._leaf: deferred or side stream)
-        r = K.conv_wgrad(x, dout, Cout, Cin, 1, want_db=has_b)
-        if has_b:
-            return {name + '.weight': r[0].view(Cout, Cin, 1, 1), name + '.bias': r[1]}
-        return {name + '.weight': r.view(Cout, Cin, 1, 1)}
-    E._leaf((x, dout), leaf, G)
+    # parameter gradient: a leaf off the data-gradient chain (engine._leaf_wgrad1x1: deferred, leaves of one shape in one grouped launch)
+    def post(g, db):
+        return {name + '.weight': g.view(Cout, Cin, 1, 1), name + '.bias': db} if has_b else {name + '.weight': g.view(Cout, Cin, 1, 1)}
+    E._leaf_wgrad1x1((x, dout), (x, dout, Cout, Cin, False), post, G, want_db=has_b)
     wp, mp, *_ = K.pack_weights(w, PACK_DGRAD_S1)
     return K.conv_forward(dout, wp, mp, Cin, 1)
 
