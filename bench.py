@@ -489,7 +489,7 @@ def _main_body(a, world, rank, local, enc):
     if not a.no_roofline:
         recs = []          # (flop, e0, e1, alg bytes, family key)
         orig = K.conv_forward
-        orig_p16, orig_wg, orig_wg16 = K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16
+        orig_p16, orig_wg, orig_wg16, orig_grp = K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16, K.wgrad1x1_group
 
         def _ev():
             return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -512,6 +512,7 @@ def _main_body(a, world, rank, local, enc):
             e1.record()
             px = x16.N * x16.H * x16.W
             nout = (1 if kw.get('want32', True) else 0) + (1 if kw.get('want16', False) else 0)
+            # (algorithmic bytes = the fp32 tensors of SURVEY 8d: 4 B per element; triple planes move 6)
             recs.append((2.0 * px * Cout * x16.C * 9, e0, e1, 4.0 * px * (x16.C + nout * Cout), ('conv', 'p24' if x16.fmt == K.FMT_BX3 else 'p16')))
             return out
 
@@ -535,15 +536,36 @@ def _main_body(a, world, rank, local, enc):
             px = x16.N * x16.H * x16.W
             recs.append((2.0 * px * d16.C * x16.C * 9, e0, e1, 4.0 * px * (x16.C + d16.C), ('wgrad', 'p24' if x16.fmt == K.FMT_BX3 else 'p16')))
             return out
-        K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16 = timed, timed_p16, timed_wg, timed_wg16
+
+        def timed_grp(reqs, seq=0, want_db=True):
+            e0, e1 = _ev()
+            e0.record()
+            out = orig_grp(reqs, seq=seq, want_db=want_db)
+            e1.record()
+            fl = by = 0.0
+            for (x, dout, Cout, Cin, _gate) in reqs:
+                px = dout.shape[0] * dout.shape[2] * dout.shape[3]
+                fl += 2.0 * px * Cout * Cin
+                by += 4.0 * (x.numel() + dout.numel())
+            recs.append((fl, e0, e1, by, ('wgrad', 'g1'), len(reqs)))
+            return out
+        K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16, K.wgrad1x1_group = timed, timed_p16, timed_wg, timed_wg16, timed_grp
         graph_was = getattr(model, 'use_hip_graph', False)
         model.use_hip_graph = False                       # instrumented step runs eagerly (a replayed graph makes no Python calls)
         from textualdegremoval_amd import engine as _E
-        defer_was, _E.DEFER_WGRAD = _E.DEFER_WGRAD, False    # one stream: an event pair around a launch times THAT launch, not a co-running pair
+        # one stream: an event pair around a launch times THAT launch, not a co-running pair -- the deferred leaves (incl. the grouped 1x1
+        # weight gradients) run on the current stream in front of the MASA-encoder backward instead of beside it
+        serial_was, _E.SERIAL_LEAVES = _E.SERIAL_LEAVES, True
         try:
             # The eager host loop issues launches more slowly than the GPU retires them; an event pair around a launch
             # would then also time the idle gap before it.  Park the GPU on a calibrated spin kernel so that the whole
             # step is queued before it starts executing: the event pairs then bracket back-to-back device work.
+            # one un-timed eager step in the same configuration first: buffers this configuration allocates for the first time (the
+            # workspace of the grouped weight gradients on the current stream) must not meet a parked GPU -- hipMalloc waits for it
+            it += 1
+            step(it)
+            recs.clear()
+            torch.cuda.synchronize()
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
             torch.cuda._sleep(20_000_000)
@@ -552,7 +574,11 @@ def _main_body(a, world, rank, local, enc):
             per_cycle_ms = max(c0.elapsed_time(c1), 1e-3) / 20_000_000
             torch.cuda._sleep(int(min(1500.0, 12 * (dt / a.steps * 1e3)) / per_cycle_ms))
             it += 1
+            _t_host = time.time()
             step(it)
+            _t_host = time.time() - _t_host
+            if os.environ.get('TDR_BENCH_DEBUG'):
+                sys.stderr.write(f'bench.py: instrumented eager step issued in {_t_host * 1e3:.0f} ms of host time\n')
             # what an event pair costs by itself on this queue (two marker packets back to back, nothing between them): subtracted
             # from every pair below, so that avg_launch_ms is the kernel's duration as rocprofv3 --kernel-trace reports it
             empties = []
@@ -564,9 +590,9 @@ def _main_body(a, world, rank, local, enc):
             torch.cuda.synchronize()
             ev_overhead_ms = sorted(e0.elapsed_time(e1) for e0, e1 in empties)[len(empties) // 2]
         finally:
-            K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16 = orig, orig_p16, orig_wg, orig_wg16
+            K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16, K.wgrad1x1_group = orig, orig_p16, orig_wg, orig_wg16, orig_grp
             model.use_hip_graph = graph_was
-            _E.DEFER_WGRAD = defer_was
+            _E.SERIAL_LEAVES = serial_was
         # The 3x3 / stride-1 forward + data-gradient launches of the step are run by two kernels since round 4 (conv3x3_p16_kernel on
         # pre-split operands for C >= 64, the fp32-tensor kernel conv_bx3_kernel / conv_mfma_kernel for the C = 32 level): `roofline` is
         # the one with most device time, `roofline.family_3x3_s1` the all-launch aggregate (+ `by_kernel`), `roofline_other` the second
@@ -625,7 +651,10 @@ def _main_body(a, world, rank, local, enc):
                  'wgrad1x1_dma_kernel<1,1> (64 x 64 tiles) + wgrad_reduce_kernel (1x1 weight gradients of the NAFBlock chains, split-K partials)',
               'p16': 'wgrad3x3_p16_kernel + wgrad_p16_reduce_kernel (pre-split pair planes, transposed LDS reads, no operand VALU)',
               'p24': 'wgrad3x3_p16_kernel<NS=3> + wgrad_p16_reduce_kernel (pre-split bf16 triple planes, transposed LDS reads, no operand VALU)',
-              's2': 'wgrad_s2_kernel + wgrad_reduce_kernel (3x3 / 2x2 stride-2 level transitions: parity-de-interleaved LDS planes, 12 / 8-wave workgroups)'}
+              's2': 'wgrad_s2_kernel + wgrad_reduce_kernel (3x3 / 2x2 stride-2 level transitions: parity-de-interleaved LDS planes, 12 / 8-wave workgroups)',
+              'g1': 'wgrad1x1_sp_kernel<GRP> + wgrad1x1_grp_reduce_kernel (tdr_wgrad1x1_group: the deferred 1x1 leaf weight gradients of one shape -- e.g. the '
+                    '58 conv1 / conv4 problems of the C = 256 level -- in ONE launch + ONE fixed-order reduction; `launches` = grouped launches, '
+                    '`problems` = weight gradients they carry)'}
         for k in sorted({r[4][1] for r in recs if r[4][0] == 'wgrad'}, key=str):
             e = entry([r for r in recs if r[4] == ('wgrad', k)], WG.get(k, f'wgrad KH={k}'),
                       PEAK_HX2 if K.MATH in ('hx2', 'h1') else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32),
@@ -633,10 +662,12 @@ def _main_body(a, world, rank, local, enc):
             # measured bytes per launch: the kernel's own traffic plus its split-K reduction's (one reduction per weight-gradient launch)
             wpre = {3: ('wgrad_bx3_kernel<3,', 'wgrad_reduce_kernel'), 1: ('wgrad1x1_', 'wgrad_reduce_kernel'),
                     'p16': ('wgrad3x3_p16_kernel', 'wgrad_p16_reduce_kernel'), 'p24': ('wgrad3x3_p16_kernel', 'wgrad_p16_reduce_kernel'),
-                    's2': ('wgrad_s2_kernel', 'wgrad_reduce_kernel')}.get(k)
+                    's2': ('wgrad_s2_kernel', 'wgrad_reduce_kernel'), 'g1': ('wgrad1x1_sp_kernel<false, 0, 1, true', 'wgrad1x1_grp_reduce_kernel')}.get(k)
             if wpre:
                 t_k, t_r = pmc_traffic([wpre[0]])[0], pmc_traffic([wpre[1]])[0]
                 e['traffic'] = None if t_k is None else t_k + (t_r or 0.0)
+            if k == 'g1':
+                e['problems'] = sum(r[5] for r in recs if r[4] == ('wgrad', 'g1'))
             roof_other.append(e)
         for f in ([roof] if roof else []) + roof_other:
             f.pop('_total_ms', None)

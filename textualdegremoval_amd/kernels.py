@@ -201,15 +201,17 @@ _lane_active = False
 
 
 class lane:
-    def __init__(self, i):
-        self.i = i
+    def __init__(self, i, sync=False):
+        """sync: the lane waits for everything issued so far on the current stream at EVERY entry (not only the first since the last
+        lanes_join): for work whose operands were produced after the lane's first use"""
+        self.i, self.sync = i, sync
 
     def __enter__(self):
         global _lane_active
         while len(_lane_streams) <= self.i:
             _lane_streams.append(torch.cuda.Stream())
         st = _lane_streams[self.i]
-        if self.i not in _lane_dirty:
+        if self.i not in _lane_dirty or self.sync:
             st.wait_stream(torch.cuda.current_stream())
             _lane_dirty[self.i] = st
         self.ctx = torch.cuda.stream(st)
