@@ -29,6 +29,7 @@ vals = {
     'KTOT': m.group(1), 'NLAUNCH': m.group(2),
     'WG1_MS': f"{tot('wgrad1x1_', 'wgrad_reduce_kernel'):.1f}", 'CONV_MS': f"{tot('conv3x3_p16_kernel'):.1f}",
     'WG3_MS': f"{tot('wgrad3x3_p16_kernel', 'wgrad_p16_reduce_kernel'):.1f}",
+    'WG1_VERDICT': 'met' if tot('wgrad1x1_', 'wgrad_reduce_kernel') <= 5.0 else 'not met',
     'FAST_MS': f"{b['fast_mode']['ms_per_step']:.1f}",
     'RESTORMER': f"{line('bench_restormer_cfg3.log')['ms_per_step']:.1f}", 'RESTORMER5': f"{line('bench_restormer_cfg5.log')['ms_per_step']:.1f}",
     'PROMPTIR': f"{line('bench_promptir_384_bs8.log')['ms_per_step']:.0f}", 'DRS': f"{line('bench_drsformer_256_bs8.log')['ms_per_step']:.0f}",
