@@ -670,10 +670,18 @@ def wgrad1x1_group_key(x, dout, Cout, Cin, gate):
 # GRP_CAP_RING blocks (only the newest graphs of a model are replayed), eager steps alternate between two blocks of their own.
 GRP_CAP_RING = 4
 _grp_pool = {}
+_grp_owner = 0
+
+
+def set_group_owner(token):
+    """the pinned-table rings of the grouped launches are per owner (a model passes id(self) at the start of its step): two models of
+    one process that replay their own captured graphs never share a ring"""
+    global _grp_owner
+    _grp_owner = token
 
 
 def _grp_table(seq, nrows, capturing):
-    key = (seq, nrows)
+    key = (_grp_owner, seq, nrows)
     ent = _grp_pool.get(key)
     if ent is None:
         if capturing:

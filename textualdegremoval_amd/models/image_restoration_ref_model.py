@@ -157,6 +157,7 @@ class RefGuidedImageCleanModel(BaseModel):
             self.use_hip_graph = os.environ.get('TDR_GRAPH', '1') == '1'
             self._gstate = None
         self.optimizer_g.use_grad_clip = bool(self.opt['train']['use_grad_clip'])
+        K.set_group_owner(id(self))            # pinned pointer tables of the grouped leaf weight gradients: one ring per model
         if self._survey_due(current_iter):
             loss = self._surveyed_step(current_iter)
         elif self.use_hip_graph:
