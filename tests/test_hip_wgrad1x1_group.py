@@ -27,7 +27,9 @@ def K():
     (1, 3, 160, 136, 8, 20, False),       # a single problem
     (4, 2, 128, 128, 24, 12, True),
     (6, 2, 64, 128, 32, 32, False),       # 64 input channels: 128 x 64 output tiles
-    (3, 4, 64, 192, 16, 24, True)])
+    (3, 4, 64, 192, 16, 24, True),
+    (2, 2, 288, 320, 16, 16, False),      # 256 x 256 output tiles, ragged in both directions
+    (2, 2, 256, 256, 16, 8, True)])
 def test_group_vs_fp64_and_single_launches(K, nprob, N, Cin, Cout, H, W, gate):
     torch.manual_seed(nprob * 7 + Cin)
     reqs = []

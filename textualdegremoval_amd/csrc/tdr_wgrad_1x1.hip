@@ -269,11 +269,15 @@ int launch_g1(const WgArgs& a, int N, hipStream_t st) {
 // partial pointers come from a table in device memory.
 // TNW: 32-column tiles per wave along the input channels: 2 = 128 x 128 output tiles, 1 = 128 x 64 (layers with 64 input channels: the
 // 64 x 64-tile LDS-DMA form splits every value in the wave that multiplies it -- 14.7 VALU per MFMA, 0.07 of the matrix ceiling there).
-template <bool GATE, int SCH, int KQ, bool GRP = false, int TNW = 2>
+// TMW: 32-row tiles per wave along the output channels: 2 = 128-row tiles; 4 = 256 rows (with TNW = 4: 256 x 256 output tiles, 16 accumulators
+// per wave in AGPRs, one wave per SIMD): every operand value is split by half as many workgroups and fetched half as often -- the grouped
+// launch measured 2.2 x its algorithmic HBM bytes on 128 x 128 tiles (the tiles of a pair do not stay in step inside an XCD).
+template <bool GATE, int SCH, int KQ, bool GRP = false, int TNW = 2, int TMW = 2>
 __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
-    constexpr int BN = 64 * TNW, NI = 2 + TNW;        // input-channel rows of the tile; 64-row groups a thread loads from
+    static_assert(KQ == 1 || TMW == 2, "the in-block K split is built for 128-row tiles");
+    constexpr int BM = 64 * TMW, BN = 64 * TNW, NI = TMW + TNW;        // rows of the tile; 64-row groups a thread loads from
     constexpr int NS = SCH == G1_BX3 ? 3 : 2, NP = SCH == G1_BX3 ? 6 : 3;
-    constexpr int ROWS = 128 + BN;                     // 128 dout rows | BN input rows
+    constexpr int ROWS = BM + BN;                      // BM dout rows | BN input rows
     constexpr int PLANE = ROWS * 32;                   // bytes of one plane of one k-step
     constexpr int KSTR = NS * PLANE + 64;              // k-step image stride
     constexpr int BUF = KQ * KSTR;                     // one stage
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
     const int s_begin = (split % a.spi) * a.tps;                // (the plan counts 32-pixel stages)
     const int s_end = min(s_begin + a.tps, a.tpi);
     const int nst = (s_end - s_begin) * (2 / KQ);
-    const int co0 = by * 128, ci0 = bz * BN;
+    const int co0 = by * BM, ci0 = bz * BN;
     const long HW = (long)a.OH * a.OW;
     const float* in_n = a.in + (long)n * a.in_ns;
     const float* do_n = a.dout + (long)n * a.dout_ns;
@@ -315,29 +319,31 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = lr + 64 * i;
-        const float* base = i < 2 ? do_n + (long)min(co0 + row, a.Cout - 1) * HW : in_n + (long)min(ci0 + row - 128, a.Cin - 1) * HW;
+        const float* base = i < TMW ? do_n + (long)min(co0 + row, a.Cout - 1) * HW : in_n + (long)min(ci0 + row - BM, a.Cin - 1) * HW;
         src[i] = base + (long)s_begin * G1_PX + 4 * lp;
     }
     if constexpr (GATE) {
 #pragma unroll
-        for (int i = 2; i < NI; ++i) src[i + TNW] = src[i] + a.gate_off;
+        for (int i = TMW; i < NI; ++i) src[i + TNW] = src[i] + a.gate_off;
     }
     const int w_off = (lp >> 2) * KSTR + lr * 32 + ((((lp >> 1) & 1) ^ ((lr >> 3) & 1)) << 4) + (lp & 1) * 8;     // + i * 64 * 32 + plane * PLANE
 
     // ---- multiplier role
-    int a_off[2], b_off[TNW];
+    int a_off[TMW], b_off[TNW];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) a_off[x] = kq * KSTR + (wm * 64 + x * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
+    for (int x = 0; x < TMW; ++x) a_off[x] = kq * KSTR + ((wm * TMW + x) * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
 #pragma unroll
-    for (int y = 0; y < TNW; ++y) b_off[y] = kq * KSTR + (128 + (wn * TNW + y) * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
-    f32x16 acc[2][TNW];
+    for (int y = 0; y < TNW; ++y) b_off[y] = kq * KSTR + (BM + (wn * TNW + y) * 32 + j) * 32 + ((kg ^ ((j >> 3) & 1)) << 4);
+    f32x16 acc[TMW][TNW];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < TMW; ++x)
 #pragma unroll
         for (int y = 0; y < TNW; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-    float dsum[2] = {0.f, 0.f};
+    float dsum[TMW];
+#pragma unroll
+    for (int x = 0; x < TMW; ++x) dsum[x] = 0.f;
     const bool want_db = a.dbpart != nullptr && bz == 0;      // workgroup-uniform
 
     constexpr int SA[6] = {SCH == G1_HX2 ? 1 : 2, 0, SCH == G1_HX2 ? 0 : 1, 1, 0, 0};      // hx2: mh hm hh ; bx3: lh hl mm mh hm hh
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             f32x4 v = r[i];
-            if (i < 2) {
+            if (i < TMW) {
                 v *= zf;
                 dsum[i] = __builtin_fmaf(lf, (v[0] + v[1]) + (v[2] + v[3]), dsum[i]);
             }
@@ -381,29 +387,29 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
             for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(dst + i * (64 * 32) + s * PLANE) = make_uint2(p0[s], p1[s]);
         }
     };
-    auto read_frags = [&](int rd, g1u32x4 (&fa)[2][NS], g1u32x4 (&fb)[TNW][NS]) {
+    auto read_frags = [&](int rd, g1u32x4 (&fa)[TMW][NS], g1u32x4 (&fb)[TNW][NS]) {
         const unsigned char* st = smem_raw + rd;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
 #pragma unroll
-            for (int x = 0; x < 2; ++x) fa[x][s] = *reinterpret_cast<const g1u32x4*>(st + a_off[x] + s * PLANE);
+            for (int x = 0; x < TMW; ++x) fa[x][s] = *reinterpret_cast<const g1u32x4*>(st + a_off[x] + s * PLANE);
 #pragma unroll
             for (int y = 0; y < TNW; ++y) fb[y][s] = *reinterpret_cast<const g1u32x4*>(st + b_off[y] + s * PLANE);
         }
     };
-    auto mmas = [&](const g1u32x4 (&fa)[2][NS], const g1u32x4 (&fb)[TNW][NS]) {
+    auto mmas = [&](const g1u32x4 (&fa)[TMW][NS], const g1u32x4 (&fb)[TNW][NS]) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < TMW; ++x)
 #pragma unroll
                 for (int y = 0; y < TNW; ++y) acc[x][y] = mma(fa[x][SA[p]], fb[y][SB[p]], acc[x][y]);
     };
     // the split of stage s + 1 rides in the shadow of the MFMAs of stage s: per MFMA a handful of VALU, a plane store every other one
     auto interleave = [&]() {
-        constexpr int NM = NP * 2 * TNW;
+        constexpr int NM = NP * TMW * TNW;
         constexpr int VPM = (NI * (SCH == G1_BX3 ? 22 : 6) + (GATE ? 4 * TNW : 0) + 16 + NM - 1) / NM + 1;
-        __builtin_amdgcn_sched_group_barrier(0x100, (2 + TNW) * NS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (TMW + TNW) * NS, 0);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
     // ---- two stage images in LDS: iteration s multiplies stage s, splits stage s + 1 (raw since iteration s - 1 / s - 2) into the
     // other image and issues the loads of stage s + DIST
     f32x4 raw0[NL], raw1[NL];
-    g1u32x4 fa[2][NS], fb[TNW][NS];
+    g1u32x4 fa[TMW][NS], fb[TNW][NS];
     load(0, raw0);
     load(1, raw1);
     split_store(raw0, 0, true);
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
     // ---- bias gradient partial: the 8 pieces of a row live in 8 consecutive lanes (fixed-order butterfly)
     if (want_db) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TMW; ++i) {
             float t = dsum[i];
             t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64);
             if constexpr (KQ == 2) t += __shfl_xor(t, 4, 64);
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
     const int wq = wave & 3;
     if (KQ == 2 && kq == 1) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < TMW; ++x)
 #pragma unroll
             for (int y = 0; y < TNW; ++y)
 #pragma unroll
@@ -463,14 +469,14 @@ __global__ __launch_bounds__(256 * KQ) void wgrad1x1_sp_kernel(WgArgs a) {
     }
     float* part = a.part + (long)split * a.Cout * a.Cin;
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < TMW; ++x)
 #pragma unroll
         for (int y = 0; y < TNW; ++y) {
             const int ci = ci0 + (wn * TNW + y) * 32 + j;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = KQ == 2 ? acc[x][y][r] + red[((wq * 4 + x * 2 + y) * 16 + r) * 64 + lane] : acc[x][y][r];
-                const int co = co0 + (wm * 2 + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int co = co0 + (wm * TMW + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (co < a.Cout && ci < a.Cin) part[(long)co * a.Cin + ci] = v;
             }
         }
@@ -542,12 +548,25 @@ __global__ __launch_bounds__(256) void wgrad1x1_grp_reduce_kernel(const TdrWg1Gr
 }
 
 struct G1GroupPlan { int spi, tps, tpi, bpp; };
+struct G1Tile { int tmw, tnw; };
+
+// output tile of a grouped launch: 128 x 128 (128 x 64 for 64 input channels).  TDR_WG1_GRP_BIG=1: 256 x 256 / 256 x 128 where the channel
+// counts fill them -- half the split VALU and half the operand fetches per MFMA, but one wave per SIMD (16 accumulator tiles): measured
+// SLOWER in the step (64.4 -> 64.9 / 65.5 ms same box, profiles/r5/sweep_o.log), so opt-in
+G1Tile g1_group_tile(const TdrWgradDesc* d) {
+    static const bool big = getenv("TDR_WG1_GRP_BIG") && atoi(getenv("TDR_WG1_GRP_BIG")) == 1;
+    G1Tile t;
+    t.tmw = (big && d->Cout >= 256 && d->Cin > 64) ? 4 : 2;
+    t.tnw = d->Cin <= 64 ? 1 : ((t.tmw == 4 && d->Cin >= 256) ? 4 : 2);      // (instantiated: 4x4, 4x2, 2x2, 2x1)
+    return t;
+}
 
 G1GroupPlan g1_group_plan(const TdrWgradDesc* d, int nprob) {
     G1GroupPlan p;
     const long HW = (long)d->OH * d->OW;
     p.tpi = (int)(HW / G1_PX);
-    const long tiles = (long)tdr_cdiv(d->Cout, 128) * tdr_cdiv(d->Cin, d->Cin > 64 ? 128 : 64);
+    const G1Tile tl = g1_group_tile(d);
+    const long tiles = (long)tdr_cdiv(d->Cout, 64 * tl.tmw) * tdr_cdiv(d->Cin, 64 * tl.tnw);
     // one image per workgroup unless that leaves the chip short of workgroups (few problems / few tiles): then split the images,
     // never below 8 stages per workgroup
     static const long want = getenv("TDR_WG1_GRP_WANT") ? atol(getenv("TDR_WG1_GRP_WANT")) : 512;      // (256 / 512 / 1024 / 2048: 67.06 / 67.12 / 67.33 / 67.39 ms per step, profiles/r5/sweep_k.log)
@@ -559,13 +578,19 @@ G1GroupPlan g1_group_plan(const TdrWgradDesc* d, int nprob) {
     return p;
 }
 
-template <bool GATE, int SCH, int TNW>
+template <bool GATE, int SCH, int TNW, int TMW>
 int launch_grp(const WgArgs& a, int nprob, hipStream_t st) {
     constexpr int NS = SCH == G1_BX3 ? 3 : 2;
-    constexpr size_t lds = (size_t)2 * (NS * (128 + 64 * TNW) * 32 + 64);
+    constexpr size_t lds = (size_t)2 * (NS * (64 * TMW + 64 * TNW) * 32 + 64);
     const int T = a.tiles_x * a.tiles_y;
     dim3 grid((unsigned)tdr_cdiv(a.grp_pairs, 8) * 8 * T);
-    hipLaunchKernelGGL((wgrad1x1_sp_kernel<GATE, SCH, 1, true, TNW>), grid, dim3(256), lds, st, a);
+    auto kern = wgrad1x1_sp_kernel<GATE, SCH, 1, true, TNW, TMW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     TDR_LAUNCH_CHECK("wgrad1x1_sp_kernel<grouped>");
     return TDR_OK;
 }
@@ -596,8 +621,8 @@ extern "C" int tdr_wgrad1x1_group(const TdrWgradDesc* d, int nprob, const void* 
     a.in = nullptr; a.in_ns = d->in_ns; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
     a.gate_off = (long)d->Cin * d->H * d->W;
     a.dout = nullptr; a.dout_ns = d->dout_ns; a.Cout = d->Cout; a.OH = d->OH; a.OW = d->OW;
-    const bool wide = d->Cin > 64;
-    a.pad = 0; a.tw_log2 = 5; a.tiles_x = tdr_cdiv(d->Cout, 128); a.tiles_y = tdr_cdiv(d->Cin, wide ? 128 : 64);      // (grouped: the output tile grid)
+    const G1Tile tl = g1_group_tile(d);
+    a.pad = 0; a.tw_log2 = 5; a.tiles_x = tdr_cdiv(d->Cout, 64 * tl.tmw); a.tiles_y = tdr_cdiv(d->Cin, 64 * tl.tnw);      // (grouped: the output tile grid)
     a.tpi = p.tpi; a.tps = p.tps; a.spi = p.spi;
     a.part = nullptr; a.dbpart = nullptr;
     a.scheme = d->math == 2 ? 1 : 0;
@@ -605,10 +630,12 @@ extern "C" int tdr_wgrad1x1_group(const TdrWgradDesc* d, int nprob, const void* 
     hipStream_t st = (hipStream_t)stream;
     const bool g = d->gate != 0;
     int rc;
-    if (a.scheme == 1) rc = g ? (wide ? launch_grp<true, G1_HX2, 2>(a, nprob, st) : launch_grp<true, G1_HX2, 1>(a, nprob, st))
-                              : (wide ? launch_grp<false, G1_HX2, 2>(a, nprob, st) : launch_grp<false, G1_HX2, 1>(a, nprob, st));
-    else rc = g ? (wide ? launch_grp<true, G1_BX3, 2>(a, nprob, st) : launch_grp<true, G1_BX3, 1>(a, nprob, st))
-                : (wide ? launch_grp<false, G1_BX3, 2>(a, nprob, st) : launch_grp<false, G1_BX3, 1>(a, nprob, st));
+#define G1_GRP(GATE_, SCH_)                                                                                                       \
+    (tl.tmw == 4 ? (tl.tnw == 4 ? launch_grp<GATE_, SCH_, 4, 4>(a, nprob, st) : launch_grp<GATE_, SCH_, 2, 4>(a, nprob, st))      \
+                 : (tl.tnw == 2 ? launch_grp<GATE_, SCH_, 2, 2>(a, nprob, st) : launch_grp<GATE_, SCH_, 1, 2>(a, nprob, st)))
+    if (a.scheme == 1) rc = g ? G1_GRP(true, G1_HX2) : G1_GRP(false, G1_HX2);
+    else rc = g ? G1_GRP(true, G1_BX3) : G1_GRP(false, G1_BX3);
+#undef G1_GRP
     if (rc != TDR_OK) return rc;
     const long elems = (long)d->Cout * d->Cin;
     const int nb_main = tdr_cdiv(elems, 256), nb2 = tdr_cdiv(d->Cout, 256);
