@@ -581,7 +581,10 @@ G1GroupPlan g1_group_plan(const TdrWgradDesc* d, int nprob) {
 template <bool GATE, int SCH, int TNW, int TMW>
 int launch_grp(const WgArgs& a, int nprob, hipStream_t st) {
     constexpr int NS = SCH == G1_BX3 ? 3 : 2;
-    constexpr size_t lds = (size_t)2 * (NS * (64 * TMW + 64 * TNW) * 32 + 64);
+    constexpr size_t lds0 = (size_t)2 * (NS * (64 * TMW + 64 * TNW) * 32 + 64);
+    // TDR_WG1_GRP_LDS: pad the LDS request (bytes) to cap the workgroups resident per CU (tuning aid: fewer pairs in flight per XCD L2)
+    static const size_t pad = getenv("TDR_WG1_GRP_LDS") ? (size_t)atol(getenv("TDR_WG1_GRP_LDS")) : 0;
+    const size_t lds = lds0 < pad ? pad : lds0;
     const int T = a.tiles_x * a.tiles_y;
     dim3 grid((unsigned)tdr_cdiv(a.grp_pairs, 8) * 8 * T);
     auto kern = wgrad1x1_sp_kernel<GATE, SCH, 1, true, TNW, TMW>;
