@@ -69,7 +69,7 @@ LEAF_LANES = int(os.environ.get('TDR_LEAF_LANES', '1'))                 # HIP st
 # (kernels.wgrad1x1_group, csrc/tdr_wgrad_1x1.hip): no per-launch ramp / prologue / partial write / reduction launch, 1 / 8 of the partials
 GROUP_LEAVES = os.environ.get('TDR_GROUP_LEAVES', '1') == '1'
 EARLY_FLUSH = os.environ.get('TDR_EARLY_FLUSH', '0') == '1'            # flush_late_leaves() after the deepest encoder level: measured +0.2 ms (profiles/r5/sweep_m.log), off
-SERIAL_LEAVES = False    # measurement aid (bench.py's roofline leg): the deferred leaves on the CURRENT stream, before the main chain
+SERIAL_LEAVES = os.environ.get('TDR_SERIAL_LEAVES', '0') == '1'    # measurement aid (bench.py's roofline leg): the deferred leaves on the CURRENT stream, before the main chain
 _late = None            # [(prefix, closure -> {name: grad})] while a whole-network backward collects deferred leaves
 _late_pre = ''
 
