@@ -1006,8 +1006,6 @@ extern "C" int tdr_conv3x3_p16(const TdrConvP16Desc* d, void* stream) {
             case 307: return launch_p16<2, 1, 2, 4, true, 0, true, T>(a, N, st);     // 128 x (4 x 32), 8 waves
             case 308: return launch_p16<1, 2, 1, 4, true, 0, true, T>(a, N, st);     //  32 x (8 x 32), 4 waves (the C = 32 level)
             case 309: return launch_p16<1, 1, 1, 4, true, 0, true, T>(a, N, st);     //  32 x (4 x 32), 4 waves
-            case 310: return launch_p16<1, 2, 2, 4, true, 0, true, T>(a, N, st);     //  64 x (8 x 32), 8 waves
-            case 313: return launch_p16<1, 4, 2, 2, true, 0, true, T>(a, N, st);     //  64 x (8 x 32), 4 waves of 32 x (4 x 32)
             case 311: return launch_p16<2, 2, 1, 4, true, 0, false, T>(a, N, st);    // 301 without the interleaved issue order
             case 312: return launch_p16<2, 2, 2, 4, true, 0, false, T>(a, N, st);
             case 321: return launch_p16<2, 2, 1, 4, false, 0, false, T>(a, N, st);   // 301 without pipelined fragments
