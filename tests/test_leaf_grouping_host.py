@@ -105,3 +105,24 @@ def test_grouping_switched_off_runs_single_launches_in_the_deferred_pass(fake, m
         E.run_late_leaves(G, lambda: None)
     assert fake.group_calls == [] and [c[2] for c in fake.single_calls] == [1.0, 2.0]
     assert G['a.w'].flatten()[0].item() == 1.0 and G['b.w'].flatten()[0].item() == 2.0
+
+
+def test_level_mode_groups_inside_a_data_parallel_backward(fake):
+    """with a gradient exchange the leaves of a LEVEL are queued and run together at its end (level_end), on the current stream, and their
+    gradients reach the collector right there -- before the next level starts -- so the buckets still fill in arrival order"""
+    class Sink(dict):
+        class reducer:
+            collective = True
+    G = Sink()
+    with E.late_leaves(G, level_ok=True):
+        assert E._late == [] and E._level_mode
+        _queue(G, 'l3.a', 128, 256, 1)
+        _queue(G, 'l3.b', 128, 256, 2)
+        assert len(G) == 0
+        E.level_end(G)
+        assert set(G) == {'l3.a.w', 'l3.a.b', 'l3.b.w', 'l3.b.b'} and fake.group_calls == [(0, 2, True, [1.0, 2.0])]
+        _queue(G, 'l2.a', 128, 256, 3)
+        ran = []
+        E.run_late_leaves(G, lambda: ran.append('main'))        # flushes the last level, then the main chain; no lane, no join
+        assert ran == ['main'] and 'l2.a.w' in G and fake.joins == 0
+    assert [c[0] for c in fake.group_calls] == [0, 1] and not E._level_mode and E._late is None

@@ -68,6 +68,10 @@ LEAF_LANES = int(os.environ.get('TDR_LEAF_LANES', '1'))                 # HIP st
 # deferred 1x1 leaf weight gradients of one shape (a level's conv1 / conv4, its conv5) share ONE launch + ONE reduction
 # (kernels.wgrad1x1_group, csrc/tdr_wgrad_1x1.hip): no per-launch ramp / prologue / partial write / reduction launch, 1 / 8 of the partials
 GROUP_LEAVES = os.environ.get('TDR_GROUP_LEAVES', '1') == '1'
+# data-parallel runs: the leaves of a level queued and run (grouped) at the level's end instead of one launch per leaf inside the chain
+LEVEL_LEAVES = os.environ.get('TDR_LEVEL_LEAVES', '1') == '1'
+_level_mode = False
+FORCE_DP_SCHEDULE = os.environ.get('TDR_FORCE_DP_SCHEDULE', '0') == '1'    # measurement aid: schedule the leaves as a data-parallel run would, on one GPU
 EARLY_FLUSH = os.environ.get('TDR_EARLY_FLUSH', '0') == '1'            # flush_late_leaves() after the deepest encoder level: measured +0.2 ms (profiles/r5/sweep_m.log), off
 SERIAL_LEAVES = os.environ.get('TDR_SERIAL_LEAVES', '0') == '1'    # measurement aid (bench.py's roofline leg): the deferred leaves on the CURRENT stream, before the main chain
 _late = None            # [(prefix, closure -> {name: grad})] while a whole-network backward collects deferred leaves
@@ -116,22 +120,40 @@ def _leaf_wgrad1x1(keep, req, post, G, want_db=True):
 
 
 class late_leaves:
-    """`with late_leaves(G):` around a whole-network backward: leaves are queued (when allowed) until run_late_leaves()"""
+    """`with late_leaves(G):` around a whole-network backward: leaves are queued (when allowed) until run_late_leaves().
+    With a gradient exchange (G.reducer.collective) nothing is deferred to the end -- the buckets are cut in arrival order inside the
+    backward -- but a caller that marks its level boundaries (level_ok=True + level_end(G) after each level) still gets the leaves of
+    a LEVEL queued and run together at its end, on the current stream: the 1x1 weight gradients of the level as grouped launches."""
 
-    def __init__(self, G):
-        self.on = DEFER_WGRAD and not K.SIDE_WGRAD and not getattr(getattr(G, 'reducer', None), 'collective', False)
+    def __init__(self, G, level_ok=False):
+        coll = bool(getattr(getattr(G, 'reducer', None), 'collective', False)) or FORCE_DP_SCHEDULE
+        self.level = coll and level_ok and LEVEL_LEAVES
+        self.on = DEFER_WGRAD and not K.SIDE_WGRAD and (not coll or self.level)
 
     def __enter__(self):
-        global _late, _grp_seq
+        global _late, _grp_seq, _level_mode
         _late = [] if self.on else None
+        _level_mode = self.on and self.level
         _flushed.clear()
         _grp_seq = 0
         return self
 
     def __exit__(self, *exc):
-        global _late
+        global _late, _level_mode
         _late = None
+        _level_mode = False
         return False
+
+
+def level_end(G):
+    """level boundary of a backward pass that exchanges gradients: run what the level queued (grouped), hand its gradients over now"""
+    global _late
+    if not _level_mode or not _late:
+        return
+    late, _late = _late, []
+    for pre, g in _run_leaves(late, serial=True):
+        _put(G, pre, g)
+    late.clear()
 
 
 def set_late_prefix(pre):
@@ -143,11 +165,11 @@ _flushed = []           # (results, operands kept alive) of early flushes of the
 _grp_seq = 0            # grouped launches issued so far in this pass (the call-site index of their pinned pointer tables)
 
 
-def _run_leaves(late):
-    """the queued leaves on lane 0 (the current stream with SERIAL_LEAVES), 1x1 requests of one shape grouped -> [(prefix, grads)]"""
+def _run_leaves(late, serial=False):
+    """the queued leaves on lane 0 (the current stream if serial / SERIAL_LEAVES), 1x1 requests of one shape grouped -> [(prefix, grads)]"""
     global _grp_seq
     import contextlib
-    ctx = contextlib.nullcontext() if SERIAL_LEAVES else K.lane(0, sync=True)
+    ctx = contextlib.nullcontext() if (SERIAL_LEAVES or serial) else K.lane(0, sync=True)
     with ctx:
         groups, outs = {}, {}
         for i, (pre, fn, _) in enumerate(late):
@@ -175,6 +197,12 @@ def flush_late_leaves():
 def run_late_leaves(G, main_chain):
     """deferred leaves on lane 0, `main_chain()` on the current stream, join, then hand the gradients to the collector in order"""
     global _late, _grp_seq
+    if _level_mode:                 # gradient exchange: the remainder of the last level, then the main chain -- nothing runs beside it
+        level_end(G)
+        _late = None
+        _grp_seq = 0
+        main_chain()
+        return
     late, _late = _late, None
     flushed = list(_flushed)
     _flushed.clear()
@@ -881,7 +909,7 @@ def net_bwd(dout, P, cfg, saved, G=None):
 
 def _net_bwd(dout, P, cfg, saved, G):
     G = {} if G is None else G
-    with late_leaves(G):
+    with late_leaves(G, level_ok=True):
         return _net_bwd_body(dout, P, cfg, saved, G)
 
 
@@ -898,10 +926,12 @@ def _net_bwd_body(dout, P, cfg, saved, G):
     for lvl in reversed(range(len(cfg['dec_blk_nums']))):
         xin, sv_d = sv_dec[lvl]
         d = naf_seq_bwd(d, P, f'decoders.{lvl}.', cfg['dec_blk_nums'][lvl], sv_d, G)
+        level_end(G)
         dskips[n_enc - 1 - lvl] = d                    # gradient of `x + enc_skip` w.r.t. the skip
         d, _ = up_bwd(d, xin, P[f'ups.{lvl}.0.weight'], into=(G, f'ups.{lvl}.0.weight'))
     d = naf_seq_bwd(d, P, 'middle_blks.', cfg['middle_blk_num'], sv_m, G)
     dcat = naf_seq_bwd(d, P, 'masa_blk_middle.0.', cfg['reffusion_n_blocks'][n_enc], sv_fm, G)
+    level_end(G)
     dwarp = [None] * 5
     chan = dcat.shape[1] // 2
     dwarp[n_enc] = dcat[:, chan:]
@@ -913,6 +943,7 @@ def _net_bwd_body(dout, P, cfg, saved, G):
                            into=(G, f'downs.{lvl}.weight', f'downs.{lvl}.bias'))
         d = naf_seq_bwd(d, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl], sv_e, G)
         dcat = naf_seq_bwd(d, P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], sv_f, G)
+        level_end(G)
         if lvl == n_enc - 1:
             flush_late_leaves()
         chan = dcat.shape[1] // 2
