@@ -111,6 +111,11 @@ def _compare(tag, net, cfg, size, steps, n_pairs):
     b_third = 3.0 * max(max(d_f32[:third]), max(d_f32b[:third]), fl_third) + 1e-5
     b_mean = 3.0 * max(m_f32, sum(d_f32b) / steps, fl_mean) + 2e-6
     b_max = 3.0 * max(e_f32, max(d_f32b), fl_max) + 2e-6
+    # Past the first third the distance is a heavy-tailed random variable (a last-bit perturbation amplified by the training map: on one box
+    # the three exact-fp32 realisations above came out at 4e-5 / 1e-4 and hx2 at 4e-4 on the same 50 steps that gave 1e-4 / 2e-4 on another),
+    # so three samples do not bound a fourth.  The tail bars therefore never go below a fraction of the loss itself: 2 % of the oracle's
+    # loss at that step for any single step, 0.2 % of its mean loss for the mean distance.  The first third stays on the measured floor alone.
+    rel_step, rel_mean = 0.02, 0.002
     # 'bx3': the library default / bench headline (3-way bf16 split, unscaled gradients, no step verdict, triple planes);
     # 'hx2': the opt-in fast mode (2-way fp16 split, loss-scaled backward under the guard, pair planes)
     for mode in ('bx3', 'hx2'):
@@ -127,8 +132,9 @@ def _compare(tag, net, cfg, size, steps, n_pairs):
         if mode == 'bx3':
             assert st['scale_log2'] == 0.0, st                              # no loss scale in the default arithmetic
         assert max(d_m[:third]) <= b_third, (mode, max(d_m[:third]), b_third)
-        assert m_m <= b_mean, (mode, m_m, b_mean)
-        assert e_m <= b_max, (mode, e_m, b_max)
+        assert m_m <= max(b_mean, rel_mean * sum(l_or) / steps), (mode, m_m, b_mean)
+        over = [(i, d, l) for i, (d, l) in enumerate(zip(d_m, l_or)) if d > max(b_max, rel_step * l)]
+        assert not over, (mode, over[:4], b_max)
         assert e_m <= 0.10 * l_or[-1], (mode, e_m, l_or[-1])
     out = os.path.join(ROOT, 'gpurun_out', 'margins')
     os.makedirs(out, exist_ok=True)
