@@ -550,7 +550,8 @@ int tdr_token_match(const float* fl, const float* fr, const float* windows, int 
  * tdr_token_match */
 int tdr_transpose_f32(const float* src, int batch, int R, int C, float* dst, void* stream);
 /* nn.LayerNorm(D) over each of the P token rows (D % 4 == 0, D <= 1280); out_f16 0: fp32 [P][D]; 1: fp16 [P][D];
- * 2: the 2-way split, hi | lo fp16 planes [2][P][D] (hi = fp16(y), lo = fp16(y - hi)) */
+ * 2: the 2-way split, hi | lo fp16 planes [2][P][D] (hi = fp16(y), lo = fp16(y - hi));
+ * 3: the 3-way split, h | m | l bf16 planes [3][P][D] (h = bf16(y), m = bf16(y - h), l = bf16(y - h - m): y = h + m + l exactly) */
 int tdr_tok_layernorm(const float* x, const float* w, const float* b, int64_t P, int D, float eps, int out_f16, void* out,
                       void* stream);
 /* nn.Linear: acc = x16 [P][K] . w16 [N][K]^T in fp32 (N % 128 == 0, K % 64 == 0); bias may be NULL.
@@ -567,6 +568,14 @@ int tdr_tok16x2_gemm(const void* x16x2, const void* w16x2, const float* bias, in
                      float* out32, void* stream);
 /* fp32 channel-major src [C][P] -> token-major hi | lo planes dst16x2 [2][P][C] */
 int tdr_cm_to_tok16x2(const float* src, int C, int64_t P, void* dst16x2, void* stream);
+/* The same GEMM on 3-way split operands (the library's default arithmetic, TDR_MATH=bx3: x = h + m + l in bf16, exactly; six products
+ * per fragment pair, fp32 accumulate; any fp32 exponent): the frozen DINOv2 matcher (models/dino/block.py:42-113, attention.py:36-71)
+ * at its default arithmetic.  x16x3 [3][P][K], w16x3 [3][N][K] bf16 planes; epi / act as tdr_tok16x2_gemm (y16x3 [3][P][N]);
+ * ls (may be NULL): epi 2 adds ls[n] * (acc + bias) -- the LayerScale of the block's residual branches */
+int tdr_tok16x3_gemm(const void* x16x3, const void* w16x3, const float* bias, int64_t P, int N, int K, int epi, int act, void* y16x3,
+                     float* out32, const float* ls, void* stream);
+/* fp32 channel-major src [C][P] -> token-major h | m | l bf16 planes dst16x3 [3][P][C] */
+int tdr_cm_to_tok16x3(const float* src, int C, int64_t P, void* dst16x3, void* stream);
 /* softmax(q k^T * scale) v per head over the first T rows of each image: qkv16 [B][LD][3C] (q | k | v column blocks, head-major
  * inside each, head dim 64), out16 [B][LD][C]; rows T..LD-1 of out16 are zero */
 int tdr_tok16_attention(const void* qkv16, int B, int C, int heads, int T, int LD, float scale, void* out16, void* stream);

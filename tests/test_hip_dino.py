@@ -180,3 +180,91 @@ def test_single_product_linears_keep_every_match_decision():
               f'similarity margin {worst_margin:.4f}')
     finally:
         K.set_math(prev)
+
+
+def test_tok16x3_kernels_against_torch():
+    """csrc/tdr_tok16.hip on 3-way bf16 split planes (the default 'bx3' arithmetic): LayerNorm -> planes, the GEMM with its three
+    epilogues (+ LayerScale), channel-major -> planes, against fp64 torch on the fp32 values.  h + m + l IS the fp32 value, so the
+    planes are compared exactly; the GEMM bar is a few 2^-24 of the accumulated magnitude (sum |x||w|) -- fp32-class, not bf16."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    g = torch.Generator().manual_seed(8)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()
+    md = lambda a, b: (a.double() - b.double()).abs().max().item()
+    sum3 = lambda p: (p[0].float() + p[1].float()) + p[2].float()
+    P, D = 2 * 128 + 24, 768                                             # a ragged last row tile
+    t, w, b = r(P, D) * 2 + 0.5, r(D), r(D)
+    pl = K.tok_layernorm(t, w, b, 1e-6, planes=3)
+    y32 = K.tok_layernorm(t, w, b, 1e-6, out_f16=False)
+    assert pl.shape == (3, P, D) and pl.dtype == torch.bfloat16 and torch.equal(sum3(pl), y32)      # the split loses nothing
+    assert md(y32, torch.nn.functional.layer_norm(t.double(), (D,), w.double(), b.double(), 1e-6)) < 2e-6 * y32.abs().max().item()
+    a = r(96, 72) * torch.logspace(-30, 20, 72).cuda()                     # any fp32 exponent: no fp16 window
+    ap = K.cm_to_tok16x3(a)
+    assert torch.equal(sum3(ap), a.t().contiguous())
+    x = r(5, 7)
+    assert torch.equal(sum3(K.split_planes3(x)), x)
+    for Pn in (P, 4 * 1024 + 8):                                         # the 64-row tiles of a short launch / the 128-row tiles of a wide one
+        for N, Kd in ((384, 768), (768, 160)):
+            x, wt, bias, ls = r(Pn, Kd), r(N, Kd) * 0.05, r(N), r(N)
+            x3, w3 = K.split_planes3(x), K.split_planes3(wt)
+            acc = x.double() @ wt.double().t() + bias.double()
+            bar = 8 * 2 ** -24 * (x.abs().double() @ wt.abs().double().t()).max().item()
+            assert md(K.tok16x3_gemm(x3, w3, bias, epi=3), acc.t()) < bar
+            res = r(Pn, N)
+            assert md(K.tok16x3_gemm(x3, w3, bias, epi=2, out32=res.clone()), res.double() + acc) < bar + 1e-6
+            assert md(K.tok16x3_gemm(x3, w3, bias, epi=2, out32=res.clone(), ls=ls), res.double() + ls.double() * acc) < 4 * bar + 1e-6
+            for act, f in ((0, lambda v: v), (2, torch.nn.functional.gelu), (3, lambda v: v * torch.sigmoid(1.702 * v))):
+                y = K.tok16x3_gemm(x3, w3, bias, epi=4, act=act)
+                assert y.dtype == torch.bfloat16 and md(sum3(y), f(acc)) < 2 * bar + 2e-7 * acc.abs().max().item(), act
+            assert md(K.tok16x3_gemm(x3, w3, None, epi=3), (acc - bias.double()).t()) < bar
+    # operands far outside the fp16 range: the 3-way split has no window
+    x, wt = r(136, 64) * 1e6, r(128, 64) * 1e-9
+    acc = x.double() @ wt.double().t()
+    assert md(K.tok16x3_gemm(K.split_planes3(x), K.split_planes3(wt), None, epi=3), acc.t()) < 8 * 2 ** -24 * (x.abs().double() @ wt.abs().double().t()).max().item()
+
+
+def test_default_matcher_on_the_token_major_triple_planes():
+    """DinoMatcher at the library default (bx3) and ViT-B/14 geometry with TDR_DINO_TOK16X3=1: flat passes run the blocks on tdr_tok16x3_gemm (operands pre-split
+    into h | m | l bf16 planes, token-major).  One arithmetic, two layouts: tokens against the channel-major engines (the default)
+    and against the oracle at fp32-class bars, every window decision identical, and identical to the exact-fp32 matcher's."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as K
+    from textualdegremoval_amd.dino import DinoMatcher
+    prev = K.MATH
+    K.set_math('bx3')
+    try:
+        sd = D.synth_vit_params(768, 2, 12, seed=5)
+        os.environ['TDR_DINO_TOK16X3'] = '1'                               # opt-in path (measured neutral on the matcher-active step)
+        try:
+            m = DinoMatcher(sd, torch.device('cuda'), heads=12)
+        finally:
+            del os.environ['TDR_DINO_TOK16X3']
+        assert m.tok16x3 and not m.tok16 and m.linear_math is None
+        c = DinoMatcher(sd, torch.device('cuda'), heads=12)
+        assert not c.tok16x3
+        xs = images(3, 126, 98, seed=77)
+        (fm, Tm), (fc, Tc) = m.tokens(xs.cuda(), flat=True), c.tokens(xs.cuda(), flat=True)
+        ref = D.vit_patch_tokens(sd, xs, heads=12)                                  # [B, T, D]
+        tm = fm.reshape(3, 768, -1)[:, :, 1:Tm + 1].transpose(1, 2).cpu()
+        tc = fc.reshape(3, 768, -1)[:, :, 1:Tc + 1].transpose(1, 2).cpu()
+        e_mc, e_mo, e_co = (tm - tc).abs().max().item(), (tm - ref).abs().max().item(), (tc - ref).abs().max().item()
+        print(f'final-norm tokens: token-major planes vs channel-major {e_mc:.2e}; vs the oracle {e_mo:.2e} (channel-major vs the oracle {e_co:.2e})')
+        assert Tm == Tc and e_mc < 2e-5 * ref.abs().max().item() and e_mo < 1e-4
+        K.set_math('f32')
+        f = DinoMatcher(sd, torch.device('cuda'), heads=12, linear_math='f32')
+        K.set_math('bx3')
+        for seed in range(2):
+            big = images(2, 256, 256, seed=40 + seed)
+            for oy, ox in ((0, 0), (32, 96), (128, 64)):
+                lqc = (big[:, :, oy:oy + 128, ox:ox + 128] + 15 / 255 * torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(seed))).contiguous()
+                rm, im, cm = m.match(lqc.cuda(), big.cuda())
+                rc, ic, cc = c.match(lqc.cuda(), big.cuda())
+                K.set_math('f32')
+                rf, i_f, cf = f.match(lqc.cuda(), big.cuda())
+                K.set_math('bx3')
+                assert torch.equal(im, ic) and torch.equal(im, i_f) and torch.equal(rm, rc), (seed, oy, ox)
+                assert (cm - cf).abs().max().item() < 1e-4 and (cm - cc).abs().max().item() < 1e-5
+    finally:
+        K.set_math(prev)

@@ -226,6 +226,8 @@ SIGNATURES = {
     'tdr_tok16_gemm': (i32, [c_fp, c_fp, c_fp, i64, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     'tdr_tok16x2_gemm': (i32, [c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_cm_to_tok16x2': (i32, [c_fp, i32, i64, c_fp, c_fp]),
+    'tdr_tok16x3_gemm': (i32, [c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_cm_to_tok16x3': (i32, [c_fp, i32, i64, c_fp, c_fp]),
     'tdr_tok16_attention': (i32, [c_fp, i32, i32, i32, i32, i32, f32, c_fp, c_fp]),
     'tdr_optim_chunk': (i32, []),
     'tdr_multi_copy': (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),

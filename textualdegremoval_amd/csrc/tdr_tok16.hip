@@ -23,6 +23,7 @@
 
 typedef _Float16 vh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 vh4 __attribute__((ext_vector_type(4)));
+typedef __bf16 vb8 __attribute__((ext_vector_type(8)));
 
 // ---- transpose -------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int R, int C, float* __restrict__ dst) {
@@ -51,7 +52,7 @@ extern "C" int tdr_transpose_f32(const float* src, int batch, int R, int C, floa
 }
 
 // ---- LayerNorm over the row of a token ---------------------------------------------------------------------------------
-template <int OUT>         // 0: fp32 | 1: fp16 | 2: hi | lo fp16 planes (2-way split)
+template <int OUT>         // 0: fp32 | 1: fp16 | 2: hi | lo fp16 planes (2-way split) | 3: h | m | l bf16 planes (3-way split)
 __global__ __launch_bounds__(256) void tok_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                     int D, long P, float eps, void* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -83,7 +84,16 @@ __global__ __launch_bounds__(256) void tok_ln_kernel(const float* __restrict__ x
         const float4 g = reinterpret_cast<const float4*>(w)[c], h = reinterpret_cast<const float4*>(b)[c];
         const float y0 = (v[i].x - mean) * rstd * g.x + h.x, y1 = (v[i].y - mean) * rstd * g.y + h.y;
         const float y2 = (v[i].z - mean) * rstd * g.z + h.z, y3 = (v[i].w - mean) * rstd * g.w + h.w;
-        if constexpr (OUT >= 1) {
+        if constexpr (OUT == 3) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            tdr_split3_bf16(y0, y1, h0, m0, l0);
+            tdr_split3_bf16(y2, y3, h1, m1, l1);
+            uint2* o = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + tok * D) + c;
+            const long ps = P * D / 4;                          // plane stride in 8-byte pieces
+            o[0] = make_uint2(h0, h1);
+            o[ps] = make_uint2(m0, m1);
+            o[2 * ps] = make_uint2(l0, l1);
+        } else if constexpr (OUT >= 1) {
             const vh4 o = {(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
             reinterpret_cast<vh4*>(reinterpret_cast<_Float16*>(out) + tok * D)[c] = o;
             if constexpr (OUT == 2) {
@@ -100,9 +110,10 @@ extern "C" int tdr_tok_layernorm(const float* x, const float* w, const float* b,
                                  void* stream) {
     TDR_REQUIRE(x && w && b && out && P > 0, "tdr_tok_layernorm: bad argument");
     TDR_REQUIRE(D % 4 == 0 && D <= 1280, "tdr_tok_layernorm: D must be a multiple of 4, at most 1280 (got %d)", D);
-    TDR_REQUIRE(out_f16 >= 0 && out_f16 <= 2, "tdr_tok_layernorm: output mode %d", out_f16);
+    TDR_REQUIRE(out_f16 >= 0 && out_f16 <= 3, "tdr_tok_layernorm: output mode %d", out_f16);
     const dim3 grid(tdr_cdiv(P, 4));
-    if (out_f16 == 2) hipLaunchKernelGGL(tok_ln_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
+    if (out_f16 == 3) hipLaunchKernelGGL(tok_ln_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
+    else if (out_f16 == 2) hipLaunchKernelGGL(tok_ln_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
     else if (out_f16) hipLaunchKernelGGL(tok_ln_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
     else hipLaunchKernelGGL(tok_ln_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, D, (long)P, eps, out);
     TDR_LAUNCH_CHECK("tok_layernorm");
@@ -110,12 +121,14 @@ extern "C" int tdr_tok_layernorm(const float* x, const float* w, const float* b,
 }
 
 // ---- fp16 GEMM ---------------------------------------------------------------------------------------------------------
-// Two instances of one kernel:
-//   <BM 128, BK 64, X2 false>  plain fp16 operands (the DINOv2 matcher: 'h1' arithmetic), 27 000 token rows: 128 x 128 tiles
-//   <BM  64, BK 32, X2 true >  2-way split operands (hi / lo fp16 planes; the three products lo*hi + hi*lo + hi*hi per fragment
+// Three operand formats of one kernel:
+//   <BM 128, BK 64, NPL 1>     plain fp16 operands (the DINOv2 matcher: 'h1' arithmetic), 27 000 token rows: 128 x 128 tiles
+//   <BM  64, BK 32, NPL 2>     2-way split operands (hi / lo fp16 planes; the three products lo*hi + hi*lo + hi*hi per fragment
 //                              pair, fp32-faithful -- the frozen CLIP encoder of the stage-A trainers feeds a trained path):
 //                              ~1 150 token rows, so 64 x 128 tiles (180 - 720 workgroups) and 32-deep stages (61 KB of LDS,
 //                              two workgroups per CU)
+//   <BM 128, BK 16, NPL 3>     3-way split operands (h / m / l bf16 planes, six products per fragment pair: the default 'bx3'
+//                              arithmetic -- 24-bit operands on the whole fp32 exponent range; the matcher at its default)
 namespace {
 constexpr int BN = 128;
 
@@ -152,24 +165,32 @@ enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_RES = 2, EPI_CM_F32 = 3, EPI_ACT_PLANE
 // EPI_F16: y = acc + bias | EPI_GELU_F16: y = erf-GELU(acc + bias) | EPI_RES: res += ls * (acc + bias)
 // EPI_CM_F32: res[n][P] = acc + bias, fp32 channel-major (the input layout of tdr_attention_fwd_math)
 // EPI_ACT_PLANES: y = split(ACT(acc + bias)) as hi | lo planes; ACT 0 none, 2 erf-GELU, 3 quick_gelu
-template <int EPI, int BM, int BK, bool X2, int ACT, int OCC = 2>
+template <int EPI, int BM, int BK, int NPL, int ACT, int OCC = 2>
 __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
+    constexpr bool X2 = NPL == 2, X3 = NPL == 3;   // fp16 hi | lo planes (3 products) / bf16 h | m | l planes (6 products)
     constexpr int OS = BK + 8;                 // halves per operand row in LDS (144 B / 80 B): ds_read_b128 passes without bank conflicts
     constexpr int CS = EPI == EPI_CM_F32 ? BN + 5 : BN + 8;                      // floats per C row in LDS
-    constexpr int NP = X2 ? 2 : 1;             // operand planes
+    constexpr int NP = NPL;                    // operand planes
     constexpr int CPR = BK / 8, RPP = 256 / CPR, NA = BM / RPP, NB = BN / RPP;   // 16-byte chunks per row, rows per staging pass
     constexpr int MI = BM / 64;                // 32-row accumulator tiles per wave (waves 2 x 2, wave tile BM/2 x 64)
-    constexpr int EP = BM * CS * 4 <= 2 * (BM + BN) * OS * 2 * NP ? 1 : 2;       // epilogue passes (the C tile reuses the operand buffers)
+    // X3 with 32-deep stages at two workgroups per CU: ONE LDS buffer (61 KB), the next stage waits in registers
+    constexpr bool SB = X3 && BK == 32 && OCC == 2;
+    constexpr int NBUF = SB ? 1 : 2;
+    constexpr int EP = BM * CS * 4 <= NBUF * (BM + BN) * OS * 2 * NP ? 1 : 2;    // epilogue passes (the C tile reuses the operand buffers)
     constexpr int ER = BM / EP;                                                  // token rows per pass
-    static_assert(ER * CS * 4 <= 2 * (BM + BN) * OS * 2 * NP && (EP == 1 || BM == 128), "C tile must fit the operand buffers");
+    static_assert(ER * CS * 4 <= NBUF * (BM + BN) * OS * 2 * NP && (EP == 1 || BM == 128), "C tile must fit the operand buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char tok_smem[];
     _Float16* sA = reinterpret_cast<_Float16*>(tok_smem);        // [2 stages][NP][BM][OS]
-    _Float16* sB = sA + 2 * NP * BM * OS;                        // [2 stages][NP][BN][OS]
+    _Float16* sB = sA + NBUF * NP * BM * OS;                     // [2 stages][NP][BN][OS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
     // consecutive tiles (same token rows, neighbouring output columns) on ONE XCD: the X rows they share stay in that L2
     int id = blockIdx.x;
     const int total = gridDim.x;
     if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    else if constexpr (X3) {                                     // any grid size: XCD x takes a contiguous run of q (+ 1 for x < r) tiles
+        const int q = total >> 3, r = total & 7, xcd = id & 7;
+        id = xcd * q + (xcd < r ? xcd : r) + (id >> 3);
+    }
     const int tn = id % a.nt, tm = id / a.nt;
     const long m0 = (long)tm * BM;
     const int n0 = tn * BN, K = a.K;
@@ -228,11 +249,19 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    if constexpr (X2) {                     // small cross terms first
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][mi], fb[1][ni], acc[mi][ni], 0, 0, 0);
+                    if constexpr (X3) {                     // l h, h l, m m, m h, h m, h h: the library's 6-product order, small terms first
+                        constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vb8, fa[SA[q]][mi]),
+                                                                                  __builtin_bit_cast(vb8, fb[SB[q]][ni]), acc[mi][ni], 0, 0, 0);
+                    } else {
+                        if constexpr (X2) {                 // small cross terms first
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][mi], fb[1][ni], acc[mi][ni], 0, 0, 0);
+                        }
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
                     }
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
                 }
         }
     };
@@ -246,6 +275,16 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
     RegSet<NR> g0 = gload(next());
     sstore(g0, 0);
     RegSet<NR> g1 = gload(next());
+    if constexpr (SB) {
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();                                // stage kt is in LDS
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __syncthreads();                                // every wave is done reading it
+            sstore(g1, 0);
+            g1 = gload(next());
+        }
+    } else
     // stage s travels in register set s & 1 and lives in LDS buffer s & 1
     for (int kt = 0; kt < nk; kt += 2) {
         __syncthreads();                                    // stage kt is in LDS; every wave is done reading stage kt - 1
@@ -323,6 +362,15 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
                     r1.x += ls[4] * v[4]; r1.y += ls[5] * v[5]; r1.z += ls[6] * v[6]; r1.w += ls[7] * v[7];
                     rp[0] = r0;
                     rp[1] = r1;
+                } else if constexpr (X3) {
+                    static_assert(!X3 || EPI == EPI_ACT_PLANES, "bf16 triple planes: EPI_RES / EPI_CM_F32 / EPI_ACT_PLANES only");
+                    unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tdr_split3_bf16(v[2 * e], v[2 * e + 1], ph[e], pm[e], pl[e]);
+                    unsigned short* yb = reinterpret_cast<unsigned short*>(a.y);
+                    *reinterpret_cast<uint4*>(yb + m * a.N + n0 + c8) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                    *reinterpret_cast<uint4*>(yb + (a.P + m) * a.N + n0 + c8) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+                    *reinterpret_cast<uint4*>(yb + (2 * a.P + m) * a.N + n0 + c8) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
                 } else {
                     vh8 o, lo;
 #pragma unroll
@@ -339,10 +387,10 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
 }
 
 namespace {
-template <int EPI, int BM, int BK, bool X2, int ACT, int OCC = 2>
+template <int EPI, int BM, int BK, int NPL, int ACT, int OCC = 2>
 int launch_tok_gemm(const TokGemmArgs& a, hipStream_t st) {
-    constexpr int lds = 2 * (BM + BN) * (BK + 8) * 2 * (X2 ? 2 : 1);
-    auto kern = tok_gemm_kernel<EPI, BM, BK, X2, ACT, OCC>;
+    constexpr int lds = ((NPL == 3 && BK == 32 && OCC == 2) ? 1 : 2) * (BM + BN) * (BK + 8) * 2 * NPL;
+    auto kern = tok_gemm_kernel<EPI, BM, BK, NPL, ACT, OCC>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -361,9 +409,9 @@ extern "C" int tdr_tok16_gemm(const void* x16, const void* w16, const float* bia
     TDR_REQUIRE(epi == 2 ? res != nullptr : (y16 != nullptr && (epi == 0 || epi == 1)), "tdr_tok16_gemm: epilogue %d lacks its output", epi);
     TokGemmArgs a{(const _Float16*)x16, (const _Float16*)w16, bias, ls, (long)P, N, K, N / BN, (_Float16*)y16, res};
     hipStream_t st = (hipStream_t)stream;
-    if (epi == 0) return launch_tok_gemm<EPI_F16, 128, 64, false, 0>(a, st);
-    if (epi == 1) return launch_tok_gemm<EPI_GELU_F16, 128, 64, false, 0>(a, st);
-    return launch_tok_gemm<EPI_RES, 128, 64, false, 0>(a, st);
+    if (epi == 0) return launch_tok_gemm<EPI_F16, 128, 64, 1, 0>(a, st);
+    if (epi == 1) return launch_tok_gemm<EPI_GELU_F16, 128, 64, 1, 0>(a, st);
+    return launch_tok_gemm<EPI_RES, 128, 64, 1, 0>(a, st);
 }
 
 extern "C" int tdr_tok16x2_gemm(const void* x16x2, const void* w16x2, const float* bias, int64_t P, int N, int K, int epi, int act,
@@ -382,8 +430,8 @@ extern "C" int tdr_tok16x2_gemm(const void* x16x2, const void* w16x2, const floa
     const bool wide = (long)tdr_cdiv(P, 64) * (N / BN) > 512;
     const int cfg = wide ? 0 : (K % 64 == 0 ? 1 : 2);
 #define TOK_X2(EPI_, ACT_)                                                               \
-    (cfg == 0 ? launch_tok_gemm<EPI_, 128, 32, true, ACT_>(a, st)                        \
-              : cfg == 1 ? launch_tok_gemm<EPI_, 64, 64, true, ACT_>(a, st) : launch_tok_gemm<EPI_, 64, 32, true, ACT_>(a, st))
+    (cfg == 0 ? launch_tok_gemm<EPI_, 128, 32, 2, ACT_>(a, st)                        \
+              : cfg == 1 ? launch_tok_gemm<EPI_, 64, 64, 2, ACT_>(a, st) : launch_tok_gemm<EPI_, 64, 32, 2, ACT_>(a, st))
     if (epi == 2) return TOK_X2(EPI_RES, 0);
     if (epi == 3) return TOK_X2(EPI_CM_F32, 0);
     if (act == 2) return TOK_X2(EPI_ACT_PLANES, 2);
@@ -392,8 +440,39 @@ extern "C" int tdr_tok16x2_gemm(const void* x16x2, const void* w16x2, const floa
 #undef TOK_X2
 }
 
+// 3-way bf16 split planes (h | m | l, x = h + m + l exactly: the library's default 'bx3' arithmetic, 6 products per fragment pair):
+// x [3][P][K], w [3][N][K] bf16; epi 2: out32 [P][N] += acc + bias | 3: out32 [N][P] = acc + bias | 4: y [3][P][N] = split(act(acc + bias)).
+// Stage forms of the 128 x 128 tile (TDR_TOK3_STAGE, measured at the matcher's shapes, profiles/r5/probe_tok16x3_v2.log):
+//   2 (default) 32-deep stages in ONE LDS buffer (61 KB, two workgroups per CU), the next stage waiting in registers  131 - 154 TF
+//   1           32-deep, double-buffered: 120 KB, one workgroup per CU                                                113 - 136 TF
+//   0           16-deep, double-buffered: 72 KB, two per CU (32-byte row pieces: a quarter of every line fetched)     107 - 126 TF
+extern "C" int tdr_tok16x3_gemm(const void* x16x3, const void* w16x3, const float* bias, int64_t P, int N, int K, int epi, int act,
+                                void* y16x3, float* out32, const float* ls, void* stream) {
+    TDR_REQUIRE(x16x3 && w16x3 && P > 0 && N > 0 && K > 0, "tdr_tok16x3_gemm: bad argument");
+    TDR_REQUIRE(N % BN == 0 && K % 32 == 0 && P % 8 == 0, "tdr_tok16x3_gemm: N %% %d, K %% 32, P %% 8 must be 0 (got %d, %d, %lld)", BN, N, K,
+                (long long)P);
+    TDR_REQUIRE(epi == 4 ? (y16x3 != nullptr && (act == 0 || act == 2 || act == 3)) : ((epi == 2 || epi == 3) && out32 != nullptr),
+                "tdr_tok16x3_gemm: epilogue %d (act %d) lacks its output", epi, act);
+    TokGemmArgs a{(const _Float16*)x16x3, (const _Float16*)w16x3, bias, ls, (long)P, N, K, N / BN, (_Float16*)y16x3, out32};
+    hipStream_t st = (hipStream_t)stream;
+    static const int deep = getenv("TDR_TOK3_STAGE") ? atoi(getenv("TDR_TOK3_STAGE")) : 2;
+    const bool wide = (long)tdr_cdiv(P, 64) * (N / BN) > 512;
+    const int cfg = wide ? (deep == 2 ? 3 : (deep ? 1 : 0)) : 2;
+#define TOK_X3(EPI_, ACT_)                                                               \
+    (cfg == 0 ? launch_tok_gemm<EPI_, 128, 16, 3, ACT_, 2>(a, st)                        \
+              : cfg == 1 ? launch_tok_gemm<EPI_, 128, 32, 3, ACT_, 1>(a, st)             \
+                         : cfg == 3 ? launch_tok_gemm<EPI_, 128, 32, 3, ACT_, 2>(a, st) : launch_tok_gemm<EPI_, 64, 32, 3, ACT_, 1>(a, st))
+    if (epi == 2) return TOK_X3(EPI_RES, 0);
+    if (epi == 3) return TOK_X3(EPI_CM_F32, 0);
+    if (act == 2) return TOK_X3(EPI_ACT_PLANES, 2);
+    if (act == 3) return TOK_X3(EPI_ACT_PLANES, 3);
+    return TOK_X3(EPI_ACT_PLANES, 0);
+#undef TOK_X3
+}
+
 // ---- 2-way split planes: producers ----------------------------------------------------------------------------------------
 // fp32 channel-major [C][P] (the attention output) -> token-major hi | lo fp16 planes [2][P][C]
+template <int NPL>
 __global__ __launch_bounds__(256) void cm_to_planes_kernel(const float* __restrict__ src, int C, long P, _Float16* __restrict__ dst) {
     __shared__ float t[32][33];
     const long p0 = (long)blockIdx.x * 32;
@@ -411,18 +490,35 @@ __global__ __launch_bounds__(256) void cm_to_planes_kernel(const float* __restri
         const int c = c0 + tx;
         if (pp < P && c < C) {
             const float v = t[tx][ty + 8 * i];
-            const _Float16 h = (_Float16)v;
-            dst[pp * C + c] = h;
-            dst[(P + pp) * C + c] = (_Float16)(v - (float)h);
+            if constexpr (NPL == 3) {                       // h | m | l bf16 (the low halves of a tdr_split3_bf16 pair)
+                unsigned h, m, l;
+                tdr_split3_bf16(v, 0.f, h, m, l);
+                unsigned short* d = reinterpret_cast<unsigned short*>(dst);
+                d[pp * C + c] = (unsigned short)h;
+                d[(P + pp) * C + c] = (unsigned short)m;
+                d[(2 * P + pp) * C + c] = (unsigned short)l;
+            } else {
+                const _Float16 h = (_Float16)v;
+                dst[pp * C + c] = h;
+                dst[(P + pp) * C + c] = (_Float16)(v - (float)h);
+            }
         }
     }
 }
 
 extern "C" int tdr_cm_to_tok16x2(const float* src, int C, int64_t P, void* dst16x2, void* stream) {
     TDR_REQUIRE(src && dst16x2 && C > 0 && P > 0, "tdr_cm_to_tok16x2: bad argument");
-    hipLaunchKernelGGL(cm_to_planes_kernel, dim3(tdr_cdiv(P, 32), tdr_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, src, C, (long)P,
+    hipLaunchKernelGGL(cm_to_planes_kernel<2>, dim3(tdr_cdiv(P, 32), tdr_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, src, C, (long)P,
                        (_Float16*)dst16x2);
     TDR_LAUNCH_CHECK("cm_to_tok16x2");
+    return TDR_OK;
+}
+
+extern "C" int tdr_cm_to_tok16x3(const float* src, int C, int64_t P, void* dst16x3, void* stream) {
+    TDR_REQUIRE(src && dst16x3 && C > 0 && P > 0, "tdr_cm_to_tok16x3: bad argument");
+    hipLaunchKernelGGL(cm_to_planes_kernel<3>, dim3(tdr_cdiv(P, 32), tdr_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, src, C, (long)P,
+                       (_Float16*)dst16x3);
+    TDR_LAUNCH_CHECK("cm_to_tok16x3");
     return TDR_OK;
 }
 

@@ -61,6 +61,20 @@ class DinoMatcher:
         if self.tok16:
             self.W16 = {k: sd[k].to(device).to(torch.float16).contiguous() for k in sd if k.startswith('blocks.') and k.endswith('.weight')
                         and k.split('.')[-2] in ('qkv', 'proj', 'fc1', 'fc2')}
+        # Opt-in (TDR_DINO_TOK16X3=1): the default arithmetic ('bx3', 6 bf16 products per fp32 product) on the same token-major pipeline.
+        # Operands travel as three bf16 planes h | m | l (x = h + m + l exactly), split ONCE by their producers (LayerNorm, GEMM epilogue,
+        # the attention's output transpose) instead of once per consuming workgroup; the attention stays on tdr_attention_fwd_math (fp32
+        # channel-major q / k / v written by the qkv GEMM's epilogue).  Same numbers as the channel-major engines up to summation order
+        # (tests/test_hip_dino.py).  Measured neutral on the matcher-active step (115.9 / 118.0 against 117.7 / 117.3 ms, one box,
+        # profiles/r5/bench_dino640_tok16x3_ab.log): the Linears run at 131 - 154 fp32-equivalent TFLOP/s on planes against 125 - 147
+        # channel-major (probe_tok16x3_v2.log) -- with 64 x 64 wave tiles either layout reads one LDS fragment per two MFMAs, 75 % of the
+        # LDS port at the matrix pipe's full rate -- and the 12 attention launches (16 ms) are the same kernel in both.
+        eff = self.linear_math or K.MATH
+        self.tok16x3 = (eff == 'bx3' and K.MATH == 'bx3' and self.D % 128 == 0 and self.D <= 1280
+                        and os.environ.get('TDR_DINO_TOK16X3', '0') == '1' and os.environ.get('TDR_DINO_TOK16', '1') == '1')
+        if self.tok16x3:
+            self.W3 = {k: K.split_planes3(sd[k].to(device)) for k in sd if k.startswith('blocks.') and k.endswith('.weight')
+                       and k.split('.')[-2] in ('qkv', 'proj', 'fc1', 'fc2')}
 
     def _pack(self, key, w4):
         prev = K.set_pack_plan(None)                      # persistent buffers, not a per-step plan
@@ -104,6 +118,8 @@ class DinoMatcher:
         scale = (D // self.heads) ** -0.5
         if self.tok16 and flat:
             return self._blocks_tok16(t, B, T, scale), T
+        if self.tok16x3 and flat:
+            return self._blocks_tok16x3(t, B, T, scale), T
         for i in range(self.depth):
             p = f'blocks.{i}.'
             h, _, _ = K.layernorm2d_fwd(t, P[p + 'norm1.weight'], P[p + 'norm1.bias'], LN_EPS)
@@ -134,6 +150,26 @@ class DinoMatcher:
             h = K.tok_layernorm(x, P[p + 'norm2.weight'], P[p + 'norm2.bias'], LN_EPS)
             h = K.tok16_gemm(h, W16[p + 'mlp.fc1.weight'], P[p + 'mlp.fc1.bias'], epi=1)
             K.tok16_gemm(h, W16[p + 'mlp.fc2.weight'], P[p + 'mlp.fc2.bias'], epi=2, res=x, ls=P[p + 'ls2.gamma'])
+        f = K.tok_layernorm(x, P['norm.weight'], P['norm.bias'], LN_EPS, out_f16=False)
+        return K.transpose_f32(f.view(B, LD, D)).view(B, D, LD // 32, 32)
+
+    def _blocks_tok16x3(self, t, B, T, scale):
+        """the transformer blocks + final norm on the bf16 triple planes of csrc/tdr_tok16.hip (tdr_tok16x3_gemm): t [1, D, B*LD/32, 32]
+        (channel-major, batch-flattened) -> final-norm tokens [B, D, LD/32, 32].  Residual stream fp32 token-major [B*LD, D]."""
+        P, D, W3 = self.P, self.D, self.W3
+        Pn = t.shape[2] * t.shape[3]
+        LD = Pn // B
+        x = K.transpose_f32(t.view(1, D, Pn))[0]
+        for i in range(self.depth):
+            p = f'blocks.{i}.'
+            h = K.tok_layernorm(x, P[p + 'norm1.weight'], P[p + 'norm1.bias'], LN_EPS, planes=3)
+            qkv = K.tok16x3_gemm(h, W3[p + 'attn.qkv.weight'], P[p + 'attn.qkv.bias'], epi=3)
+            a = K.attention_fwd(qkv.view(1, 3 * D, Pn // 32, 32), self.heads, scale, T + 1, flat_batch=B)
+            K.tok16x3_gemm(K.cm_to_tok16x3(a.view(D, Pn)), W3[p + 'attn.proj.weight'], P[p + 'attn.proj.bias'], epi=2, out32=x,
+                           ls=P[p + 'ls1.gamma'])
+            h = K.tok_layernorm(x, P[p + 'norm2.weight'], P[p + 'norm2.bias'], LN_EPS, planes=3)
+            h = K.tok16x3_gemm(h, W3[p + 'mlp.fc1.weight'], P[p + 'mlp.fc1.bias'], epi=4, act=2)
+            K.tok16x3_gemm(h, W3[p + 'mlp.fc2.weight'], P[p + 'mlp.fc2.bias'], epi=2, out32=x, ls=P[p + 'ls2.gamma'])
         f = K.tok_layernorm(x, P['norm.weight'], P['norm.bias'], LN_EPS, out_f16=False)
         return K.transpose_f32(f.view(B, LD, D)).view(B, D, LD // 32, 32)
 

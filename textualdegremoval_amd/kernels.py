@@ -1271,14 +1271,18 @@ def transpose_f32(src):
 
 
 def tok_layernorm(x, w, b, eps, out_f16=True, planes=False):
-    """nn.LayerNorm over the rows of x [P, D] (fp32) -> fp16 (a GEMM operand), fp32 [P, D], or (planes) the 2-way split [2, P, D] fp16"""
+    """nn.LayerNorm over the rows of x [P, D] (fp32) -> fp16 (a GEMM operand), fp32 [P, D], or (planes) the 2-way split [2, P, D] fp16
+    (planes=True / 2) or the 3-way split [3, P, D] bf16 (planes=3)"""
     P, D = x.shape
     assert x.is_contiguous() and x.dtype == torch.float32
-    if planes:
+    planes = 2 if planes is True else int(planes)
+    if planes == 3:
+        out = torch.empty(3, P, D, dtype=torch.bfloat16, device=x.device)
+    elif planes:
         out = torch.empty(2, P, D, dtype=torch.float16, device=x.device)
     else:
         out = torch.empty(P, D, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
-    check(_lib.load().tdr_tok_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), P, D, float(eps), 2 if planes else (1 if out_f16 else 0),
+    check(_lib.load().tdr_tok_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), P, D, float(eps), planes if planes else (1 if out_f16 else 0),
                                         out.data_ptr(), _stream()), 'tdr_tok_layernorm')
     return out
 
@@ -1287,6 +1291,43 @@ def split_planes(w):
     """host-side 2-way split of a frozen fp32 matrix [N, K] -> hi | lo fp16 planes [2, N, K]"""
     hi = w.to(torch.float16)
     return torch.stack([hi, (w - hi.to(torch.float32)).to(torch.float16)]).contiguous()
+
+
+def split_planes3(w):
+    """host-side 3-way split of a frozen fp32 matrix [N, K] -> h | m | l bf16 planes [3, N, K] (round-to-nearest conversions, exact
+    fp32 subtractions: the bits of tdr_split3_bf16; h + m + l == w)"""
+    h = w.to(torch.bfloat16)
+    r = w - h.to(torch.float32)
+    m = r.to(torch.bfloat16)
+    return torch.stack([h, m, (r - m.to(torch.float32)).to(torch.bfloat16)]).contiguous()
+
+
+def tok16x3_gemm(x3, w3, bias, epi, act=0, out32=None, ls=None):
+    """x3 [3, P, K] . w3 [3, N, K]^T on the 3-way bf16 split (+ bias): epi 2 -> out32 [P, N] += ls * ., in place; 3 -> fp32 [N, P]
+    (channel-major); 4 -> split(act(.)) [3, P, N]"""
+    _, P, Kd = x3.shape
+    N = w3.shape[1]
+    assert x3.is_contiguous() and w3.is_contiguous() and x3.dtype == torch.bfloat16 and w3.dtype == torch.bfloat16 and w3.shape[2] == Kd
+    assert x3.shape[0] == 3 and w3.shape[0] == 3
+    y = None
+    if epi == 2:
+        assert out32 is not None and out32.is_contiguous() and out32.dtype == torch.float32 and tuple(out32.shape) == (P, N)
+    elif epi == 3:
+        out32 = torch.empty(N, P, dtype=torch.float32, device=x3.device)
+    else:
+        y = torch.empty(3, P, N, dtype=torch.bfloat16, device=x3.device)
+    check(_lib.load().tdr_tok16x3_gemm(x3.data_ptr(), w3.data_ptr(), _p(bias), P, N, Kd, int(epi), int(act), _p(y), _p(out32), _p(ls),
+                                       _stream()), 'tdr_tok16x3_gemm')
+    return y if epi == 4 else out32
+
+
+def cm_to_tok16x3(src):
+    """fp32 channel-major [C, P] -> token-major h | m | l bf16 planes [3, P, C]"""
+    Cc, P = src.shape
+    assert src.is_contiguous() and src.dtype == torch.float32
+    out = torch.empty(3, P, Cc, dtype=torch.bfloat16, device=src.device)
+    check(_lib.load().tdr_cm_to_tok16x3(src.data_ptr(), Cc, P, out.data_ptr(), _stream()), 'tdr_cm_to_tok16x3')
+    return out
 
 
 def tok16x2_gemm(x2, w2, bias, epi, act=0, out32=None):
