@@ -174,11 +174,13 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
     constexpr int CPR = BK / 8, RPP = 256 / CPR, NA = BM / RPP, NB = BN / RPP;   // 16-byte chunks per row, rows per staging pass
     constexpr int MI = BM / 64;                // 32-row accumulator tiles per wave (waves 2 x 2, wave tile BM/2 x 64)
     // X3 with 32-deep stages at two workgroups per CU: ONE LDS buffer (61 KB), the next stage waits in registers
-    constexpr bool SB = X3 && BK == 32 && OCC == 2;
+    // (BM 256: 128 x 64 wave tiles -- 18 instead of 24 fragment reads per 48 MFMAs -- always in one buffer)
+    constexpr bool SB = X3 && ((BK == 32 && OCC == 2) || BM == 256 || OCC == 3);
     constexpr int NBUF = SB ? 1 : 2;
-    constexpr int EP = BM * CS * 4 <= NBUF * (BM + BN) * OS * 2 * NP ? 1 : 2;    // epilogue passes (the C tile reuses the operand buffers)
+    constexpr int LDSB = NBUF * (BM + BN) * OS * 2 * NP;
+    constexpr int EP = BM * CS * 4 <= LDSB ? 1 : ((BM / 2) * CS * 4 <= LDSB ? 2 : 4);   // epilogue passes (the C tile reuses the operand buffers)
     constexpr int ER = BM / EP;                                                  // token rows per pass
-    static_assert(ER * CS * 4 <= NBUF * (BM + BN) * OS * 2 * NP && (EP == 1 || BM == 128), "C tile must fit the operand buffers");
+    static_assert(ER * CS * 4 <= LDSB && (EP == 1 || BM >= 128) && ER % 32 == 0, "C tile must fit the operand buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char tok_smem[];
     _Float16* sA = reinterpret_cast<_Float16*>(tok_smem);        // [2 stages][NP][BM][OS]
     _Float16* sB = sA + NBUF * NP * BM * OS;                     // [2 stages][NP][BN][OS]
@@ -304,7 +306,18 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
 #pragma unroll
     for (int ep = 0; ep < EP; ++ep) {
         __syncthreads();
-        if (EP == 1 || wm == ep) {
+        if constexpr (BM == 256) {                          // pass ep takes the 32-row tiles whose rows fall into [ep ER, (ep + 1) ER)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row0 = wm * (BM / 2) + mi * 32;
+                if (row0 / ER != ep) continue;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sC[(row0 - ep * ER + (r & 3) + 8 * (r >> 2) + 4 * kk) * CS + wn * 64 + ni * 32 + j] = acc[mi][ni][r];
+            }
+        } else if (EP == 1 || wm == ep) {
             const int rbase = EP == 1 ? wm * (BM / 2) : 0;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
 namespace {
 template <int EPI, int BM, int BK, int NPL, int ACT, int OCC = 2>
 int launch_tok_gemm(const TokGemmArgs& a, hipStream_t st) {
-    constexpr int lds = ((NPL == 3 && BK == 32 && OCC == 2) ? 1 : 2) * (BM + BN) * (BK + 8) * 2 * NPL;
+    constexpr int lds = ((NPL == 3 && ((BK == 32 && OCC == 2) || BM == 256 || OCC == 3)) ? 1 : 2) * (BM + BN) * (BK + 8) * 2 * NPL;
     auto kern = tok_gemm_kernel<EPI, BM, BK, NPL, ACT, OCC>;
     static bool attr = false;
     if (!attr) {
@@ -442,10 +455,14 @@ extern "C" int tdr_tok16x2_gemm(const void* x16x2, const void* w16x2, const floa
 
 // 3-way bf16 split planes (h | m | l, x = h + m + l exactly: the library's default 'bx3' arithmetic, 6 products per fragment pair):
 // x [3][P][K], w [3][N][K] bf16; epi 2: out32 [P][N] += acc + bias | 3: out32 [N][P] = acc + bias | 4: y [3][P][N] = split(act(acc + bias)).
-// Stage forms of the 128 x 128 tile (TDR_TOK3_STAGE, measured at the matcher's shapes, profiles/r5/probe_tok16x3_v2.log):
-//   2 (default) 32-deep stages in ONE LDS buffer (61 KB, two workgroups per CU), the next stage waiting in registers  131 - 154 TF
-//   1           32-deep, double-buffered: 120 KB, one workgroup per CU                                                113 - 136 TF
-//   0           16-deep, double-buffered: 72 KB, two per CU (32-byte row pieces: a quarter of every line fetched)     107 - 126 TF
+// Stage forms (TDR_TOK3_STAGE, measured at the matcher's shapes, profiles/r5/probe_tok16x3_v2.log / _v3.log):
+//   2 (default) 128 x 128 x 32 stages in ONE LDS buffer (61 KB, two workgroups per CU), the next stage waiting in registers  131 - 154 TF
+//   1           128 x 128 x 32, double-buffered: 120 KB, one workgroup per CU                                                113 - 136 TF
+//   0           128 x 128 x 16, double-buffered: 72 KB, two per CU (32-byte row pieces: half of every 64-byte request)       107 - 126 TF
+//   3 / 4       256 x 128 x 16 / x 32 in one buffer (128 x 64 wave tiles: 25 % fewer LDS fragment reads), two / one per CU   125 - 140 TF
+//   5           128 x 128 x 16 in one buffer, three per CU                                                                     96 - 114 TF
+// Counters (profiles/r5/pmc_tok16x3.txt): matrix pipe 42 % busy, LDS 34 %, waves 64 % of their cycles in s_waitcnt vmcnt -- the operand
+// stream (one register stage in flight per wave, 64-byte L1 -> L2 requests, 27 % of them past the 4 MB L2) is latency-bound in every form.
 extern "C" int tdr_tok16x3_gemm(const void* x16x3, const void* w16x3, const float* bias, int64_t P, int N, int K, int epi, int act,
                                 void* y16x3, float* out32, const float* ls, void* stream) {
     TDR_REQUIRE(x16x3 && w16x3 && P > 0 && N > 0 && K > 0, "tdr_tok16x3_gemm: bad argument");
@@ -457,9 +474,12 @@ extern "C" int tdr_tok16x3_gemm(const void* x16x3, const void* w16x3, const floa
     hipStream_t st = (hipStream_t)stream;
     static const int deep = getenv("TDR_TOK3_STAGE") ? atoi(getenv("TDR_TOK3_STAGE")) : 2;
     const bool wide = (long)tdr_cdiv(P, 64) * (N / BN) > 512;
-    const int cfg = wide ? (deep == 2 ? 3 : (deep ? 1 : 0)) : 2;
+    const int cfg = wide ? (deep == 2 ? 3 : (deep >= 3 ? deep + 1 : (deep ? 1 : 0))) : 2;
 #define TOK_X3(EPI_, ACT_)                                                               \
-    (cfg == 0 ? launch_tok_gemm<EPI_, 128, 16, 3, ACT_, 2>(a, st)                        \
+    (cfg == 6 ? launch_tok_gemm<EPI_, 128, 16, 3, ACT_, 3>(a, st)                        \
+     : cfg == 4 ? launch_tok_gemm<EPI_, 256, 16, 3, ACT_, 2>(a, st)                      \
+     : cfg == 5 ? launch_tok_gemm<EPI_, 256, 32, 3, ACT_, 1>(a, st)                      \
+     : cfg == 0 ? launch_tok_gemm<EPI_, 128, 16, 3, ACT_, 2>(a, st)                      \
               : cfg == 1 ? launch_tok_gemm<EPI_, 128, 32, 3, ACT_, 1>(a, st)             \
                          : cfg == 3 ? launch_tok_gemm<EPI_, 128, 32, 3, ACT_, 2>(a, st) : launch_tok_gemm<EPI_, 64, 32, 3, ACT_, 1>(a, st))
     if (epi == 2) return TOK_X3(EPI_RES, 0);
