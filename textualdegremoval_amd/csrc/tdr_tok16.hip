@@ -165,7 +165,7 @@ enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_RES = 2, EPI_CM_F32 = 3, EPI_ACT_PLANE
 // EPI_F16: y = acc + bias | EPI_GELU_F16: y = erf-GELU(acc + bias) | EPI_RES: res += ls * (acc + bias)
 // EPI_CM_F32: res[n][P] = acc + bias, fp32 channel-major (the input layout of tdr_attention_fwd_math)
 // EPI_ACT_PLANES: y = split(ACT(acc + bias)) as hi | lo planes; ACT 0 none, 2 erf-GELU, 3 quick_gelu
-template <int EPI, int BM, int BK, int NPL, int ACT, int OCC = 2>
+template <int EPI, int BM, int BK, int NPL, int ACT, int OCC = 2, bool PF2 = false>
 __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
     constexpr bool X2 = NPL == 2, X3 = NPL == 3;   // fp16 hi | lo planes (3 products) / bf16 h | m | l planes (6 products)
     constexpr int OS = BK + 8;                 // halves per operand row in LDS (144 B / 80 B): ds_read_b128 passes without bank conflicts
@@ -277,7 +277,24 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
     RegSet<NR> g0 = gload(next());
     sstore(g0, 0);
     RegSet<NR> g1 = gload(next());
-    if constexpr (SB) {
+    if constexpr (SB && PF2) {                              // two register stages in flight behind the one in LDS
+        g0 = gload(next());                                 // (stage 1 is in g1, stage 2 in g0)
+        for (int kt = 0; kt < nk; kt += 2) {
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __syncthreads();
+            sstore(g1, 0);
+            g1 = gload(next());
+            if (kt + 1 >= nk) break;
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __syncthreads();
+            sstore(g0, 0);
+            g0 = gload(next());
+        }
+    } else if constexpr (SB) {
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();                                // stage kt is in LDS
             __builtin_amdgcn_sched_barrier(0);
@@ -400,10 +417,10 @@ __global__ __launch_bounds__(256, OCC) void tok_gemm_kernel(TokGemmArgs a) {
 }
 
 namespace {
-template <int EPI, int BM, int BK, int NPL, int ACT, int OCC = 2>
+template <int EPI, int BM, int BK, int NPL, int ACT, int OCC = 2, bool PF2 = false>
 int launch_tok_gemm(const TokGemmArgs& a, hipStream_t st) {
     constexpr int lds = ((NPL == 3 && ((BK == 32 && OCC == 2) || BM == 256 || OCC == 3)) ? 1 : 2) * (BM + BN) * (BK + 8) * 2 * NPL;
-    auto kern = tok_gemm_kernel<EPI, BM, BK, NPL, ACT, OCC>;
+    auto kern = tok_gemm_kernel<EPI, BM, BK, NPL, ACT, OCC, PF2>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -461,8 +478,11 @@ extern "C" int tdr_tok16x2_gemm(const void* x16x2, const void* w16x2, const floa
 //   0           128 x 128 x 16, double-buffered: 72 KB, two per CU (32-byte row pieces: half of every 64-byte request)       107 - 126 TF
 //   3 / 4       256 x 128 x 16 / x 32 in one buffer (128 x 64 wave tiles: 25 % fewer LDS fragment reads), two / one per CU   125 - 140 TF
 //   5           128 x 128 x 16 in one buffer, three per CU                                                                     96 - 114 TF
+//   6           as 2 with TWO register stages in flight behind the one in LDS (226 VGPRs, no spill)                          flat (_v5.log)
 // Counters (profiles/r5/pmc_tok16x3.txt): matrix pipe 42 % busy, LDS 34 %, waves 64 % of their cycles in s_waitcnt vmcnt -- the operand
-// stream (one register stage in flight per wave, 64-byte L1 -> L2 requests, 27 % of them past the 4 MB L2) is latency-bound in every form.
+// stream (64-byte L1 -> L2 requests, 6.3 GB per fc1 launch at ~7 TB/s, 27 % of them past the 4 MB L2) bounds every form; a second register
+// stage in flight changes nothing, so it is the request throughput of that stream, not its latency: fewer operand bytes per product (256 x 256
+// block tiles on 8 waves) or full-line pieces are what is left.
 extern "C" int tdr_tok16x3_gemm(const void* x16x3, const void* w16x3, const float* bias, int64_t P, int N, int K, int epi, int act,
                                 void* y16x3, float* out32, const float* ls, void* stream) {
     TDR_REQUIRE(x16x3 && w16x3 && P > 0 && N > 0 && K > 0, "tdr_tok16x3_gemm: bad argument");
@@ -476,7 +496,8 @@ extern "C" int tdr_tok16x3_gemm(const void* x16x3, const void* w16x3, const floa
     const bool wide = (long)tdr_cdiv(P, 64) * (N / BN) > 512;
     const int cfg = wide ? (deep == 2 ? 3 : (deep >= 3 ? deep + 1 : (deep ? 1 : 0))) : 2;
 #define TOK_X3(EPI_, ACT_)                                                               \
-    (cfg == 6 ? launch_tok_gemm<EPI_, 128, 16, 3, ACT_, 3>(a, st)                        \
+    (cfg == 7 ? launch_tok_gemm<EPI_, 128, 32, 3, ACT_, 2, true>(a, st)                  \
+     : cfg == 6 ? launch_tok_gemm<EPI_, 128, 16, 3, ACT_, 3>(a, st)                      \
      : cfg == 4 ? launch_tok_gemm<EPI_, 256, 16, 3, ACT_, 2>(a, st)                      \
      : cfg == 5 ? launch_tok_gemm<EPI_, 256, 32, 3, ACT_, 1>(a, st)                      \
      : cfg == 0 ? launch_tok_gemm<EPI_, 128, 16, 3, ACT_, 2>(a, st)                      \

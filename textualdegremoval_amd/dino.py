@@ -67,7 +67,7 @@ class DinoMatcher:
         # channel-major q / k / v written by the qkv GEMM's epilogue).  Same numbers as the channel-major engines up to summation order
         # (tests/test_hip_dino.py).  Measured neutral on the matcher-active step (115.9 / 118.0 against 117.7 / 117.3 ms, one box,
         # profiles/r5/bench_dino640_tok16x3_ab.log): the Linears run at 131 - 154 fp32-equivalent TFLOP/s on planes against 125 - 147
-        # channel-major (probe_tok16x3_v2.log) -- either layout is latency-bound on its L2 -> LDS operand stream (profiles/r5/pmc_tok16x3.txt:
+        # channel-major (probe_tok16x3_v2.log) -- either layout is bound by the request throughput of its L2 -> LDS operand stream (profiles/r5/pmc_tok16x3.txt:
         # matrix pipe 42 % busy, waves 64 % of their cycles in s_waitcnt) -- and the 12 attention launches (16 ms) are the same kernel in both.
         eff = self.linear_math or K.MATH
         self.tok16x3 = (eff == 'bx3' and K.MATH == 'bx3' and self.D % 128 == 0 and self.D <= 1280
