@@ -268,3 +268,19 @@ def test_default_matcher_on_the_token_major_triple_planes():
                 assert (cm - cf).abs().max().item() < 1e-4 and (cm - cc).abs().max().item() < 1e-5
     finally:
         K.set_math(prev)
+
+
+@pytest.mark.parametrize('stage', ['0', '1', '3', '4', '5', '6'])
+def test_tok16x3_stage_forms(stage):
+    """the measurement forms of tdr_tok16x3_gemm (TDR_TOK3_STAGE, read once per process -> a child process each; 2 is the default the
+    tests above run): 16- / 32-deep double-buffered stages, 256-row tiles, three workgroups per CU, two register stages in flight --
+    the same kernel-level test"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (f'import sys; sys.path.insert(0, {root!r})\n'
+             'import tests.test_hip_dino as T\nT.test_tok16x3_kernels_against_torch()\nprint("STAGE OK")\n')
+    out = subprocess.run([sys.executable, '-c', child], capture_output=True, text=True, env=dict(os.environ, TDR_TOK3_STAGE=stage), timeout=600, cwd=root)
+    assert out.returncode == 0 and 'STAGE OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
