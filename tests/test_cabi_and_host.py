@@ -172,3 +172,21 @@ def test_dist_validation_runs_on_local_rank_zero_only(monkeypatch):
     m.opt['dist'] = False
     monkeypatch.setenv('LOCAL_RANK', '3')
     assert m.validation('loader', 10, None) == 31.5 and len(calls) == 2
+
+
+def test_host_side_plane_splits_lose_nothing():
+    """kernels.split_planes3 / split_planes (the frozen weights of the token-major GEMMs, split once on the host): three bf16 planes
+    sum to the fp32 value bit for bit on any exponent -- the same statement tests/test_hip_dino.py makes for the device-side producers
+    (tdr_split3_bf16) -- and the 2-way fp16 split carries 22 significand bits inside the fp16 window."""
+    import torch
+    from textualdegremoval_amd import kernels as K
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(64, 96, generator=g) * torch.logspace(-30, 30, 96)
+    p3 = K.split_planes3(w)
+    assert p3.shape == (3, 64, 96) and p3.dtype == torch.bfloat16 and p3.is_contiguous()
+    assert torch.equal((p3[0].float() + p3[1].float()) + p3[2].float(), w)
+    assert (p3[1].float().abs() <= p3[0].float().abs() * 2.0 ** -8 + 1e-45).all()            # each plane is a residual of the one before
+    v = torch.randn(32, 40, generator=g)
+    p2 = K.split_planes(v)
+    assert p2.shape == (2, 32, 40) and p2.dtype == torch.float16
+    assert ((p2[0].float() + p2[1].float()) - v).abs().max().item() <= 2.0 ** -21 * v.abs().max().item()
