@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-@pytest.fixture(scope='module', params=['f32', 'hx2'])
+@pytest.fixture(scope='module', params=['bx3', 'f32', 'hx2'])
 def DE(request):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')

@@ -174,3 +174,35 @@ def test_overflowing_backward_is_skipped_then_recovers(monkeypatch, graph, hx2_m
     assert g.scale == g0.scale * 2.0 ** (22 - skipped_seen)
     assert any(not torch.equal(w[k], v) for k, v in model.net_g.state_dict().items())
     assert model.skipped_steps == skipped_seen
+
+
+def test_hx2_full_range_fallback_keeps_the_verdict(monkeypatch, hx2_mode):
+    """TDR_MATH=hx2 with the surveyed full-range backward (`_bwd_full_range`: no loss scale, gradients on the bf16 split): the FORWARD
+    pass still runs inside the fp16 window, so the guard must keep its verdict -- a forward overflow between two surveys gives a
+    non-finite norm, and that step has to be skipped instead of poisoning the weights."""
+    from test_hip_step import make_opt
+    from oracle import nafnet_ref_oracle as O
+    from textualdegremoval_amd import kernels as K
+    from textualdegremoval_amd.models import create_model
+    assert K.MATH == 'hx2'
+    monkeypatch.setenv('TDR_GRAPH', '0')
+    monkeypatch.setenv('TDR_RANGE_CHECK', '0')                      # between two surveys
+    model = create_model(make_opt())
+    model._bwd_full_range = True
+    lq, gt, ref = O.synth_pair(1, 128, 128, seed=7)
+    data = {'lq': lq, 'gt': gt, 'ref': ref}
+    model.feed_train_data(data)
+    model.optimize_parameters(1)
+    g = model.optimizer_g.guard
+    assert not g.never_skip and g.read().scale == 1.0               # no loss scale, verdict still armed
+    w = copy.deepcopy({k: v.detach().clone() for k, v in model.net_g.state_dict().items()})
+    big = {k: v * 1e6 for k, v in data.items()}                     # operands beyond 65504 in the first convolutions
+    model.feed_train_data(big)
+    try:
+        model.optimize_parameters(2)
+    except RuntimeError:
+        pass                                                        # (a loud non-finite loss is fine too: the weights must not move)
+    gd = g.read()
+    if not gd.finite:
+        assert gd.skipped == 1
+    assert all(torch.equal(w[k], v) and torch.isfinite(v).all() for k, v in model.net_g.state_dict().items())

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-@pytest.fixture(scope='module', params=['hx2', 'f32'])
+@pytest.fixture(scope='module', params=['bx3', 'hx2', 'f32'])
 def K(request):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')

@@ -20,7 +20,8 @@ worst = 0.0
 # (N, Cin, Cout, H, W, gate, per_image): 32-pixel stages per image = H * W / 32
 for (N, Cin, Cout, H, W, gate, pi) in [(2, 128, 128, 32, 32, False, False), (1, 96, 72, 40, 40, False, False), (3, 128, 256, 24, 12, False, False),
                                        (2, 256, 512, 8, 12, False, False), (2, 128, 128, 16, 18, True, False), (3, 96, 80, 32, 40, True, True),
-                                       (2, 160, 136, 8, 20, False, True), (1, 128, 128, 8, 4, False, False)]:
+                                       (2, 160, 136, 8, 20, False, True), (1, 128, 128, 8, 4, False, False),
+                                       (2, 64, 64, 8, 4, False, True), (3, 128, 96, 16, 4, True, True)]:   # per-image with W < 8 (ADVICE r5)
     x = torch.randn(N, Cin * (2 if gate else 1), H, W, device='cuda') * 3e-4       # gradient-sized magnitudes: no fp16 window here
     d = torch.randn(N, Cout, H, W, device='cuda') * 2e-5
     g, db = K.conv_wgrad(x, d, Cout, Cin, 1, gate=gate, per_image=pi, want_db=True)

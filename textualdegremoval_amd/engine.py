@@ -110,6 +110,14 @@ def _leaf_wgrad1x1(keep, req, post, G, want_db=True):
     if _late is not None and GROUP_LEAVES:
         key = K.wgrad1x1_group_key(x, dout, Cout, Cin, gate)
         if key is not None:
+            if DEBUG_LEAVES:        # the same in-place check _leaf() installs, for the operands of a grouped request
+                stamp = [(t, t._version) for t in keep if torch.is_tensor(t)]
+                inner_post = post
+
+                def post(g, db):
+                    for t, v in stamp:
+                        assert t._version == v, 'a queued weight-gradient operand was modified in place before its grouped leaf ran'
+                    return inner_post(g, db)
             _late.append((_late_pre, ('grp', key + (want_db,), req + (want_db,), post), keep))
             return
 

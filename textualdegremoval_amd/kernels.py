@@ -666,16 +666,18 @@ def wgrad1x1_group_key(x, dout, Cout, Cin, gate):
 
 # Pinned pointer tables of the grouped launches, per call site (`seq` = index of the group within a backward pass) and size.  Allocated
 # in EAGER steps only (never inside a stream capture; every shape runs eagerly before it is captured).  The upload node of a hipGraph
-# re-reads its pinned block at every replay, so a block handed to a capture is never written again: captures take theirs from a ring of
-# GRP_CAP_RING blocks (only the newest graphs of a model are replayed), eager steps alternate between two blocks of their own.
-GRP_CAP_RING = 4
+# re-reads its pinned block at every replay, so a block handed to a capture is NEVER written again and never handed out twice: every
+# eager call of a call site tops its spare list up (to GRP_CAP_SPARE unused blocks), a capture consumes spares and records them with
+# the graph's other scratch references (workspace_capture), and a capture that finds no spare raises instead of aliasing a block a
+# live graph still reads.  Eager steps alternate between two blocks of their own.
+GRP_CAP_SPARE = 4
 _grp_pool = {}
 _grp_owner = 0
 
 
 def set_group_owner(token):
-    """the pinned-table rings of the grouped launches are per owner (a model passes id(self) at the start of its step): two models of
-    one process that replay their own captured graphs never share a ring"""
+    """the pinned-table pools of the grouped launches are per owner (a model passes id(self) at the start of its step): two models of
+    one process that replay their own captured graphs never share a pool"""
     global _grp_owner
     _grp_owner = token
 
@@ -688,11 +690,17 @@ def _grp_table(seq, nrows, capturing):
             raise RuntimeError('kernels.wgrad1x1_group: this backward pass is being captured before it ever ran eagerly (no pinned table for '
                                f'group {seq}); run one eager step of the shape first or set TDR_GROUP_LEAVES=0')
         ent = _grp_pool[key] = dict(eager=[torch.empty(nrows, dtype=torch.int64).pin_memory() for _ in range(2)], ev=[None, None], flip=0,
-                                    cap=[torch.empty(nrows, dtype=torch.int64).pin_memory() for _ in range(GRP_CAP_RING)], cap_i=0)
+                                    spare=[])
     if capturing:
-        host = ent['cap'][ent['cap_i'] % GRP_CAP_RING]
-        ent['cap_i'] += 1
+        if not ent['spare']:
+            raise RuntimeError(f'kernels.wgrad1x1_group: no unused pinned table left for group {seq} ({nrows} rows) -- the captured pass uses '
+                               'this call site more often than the eager warm-up steps of the shape did; set TDR_GROUP_LEAVES=0')
+        host = ent['spare'].pop()
+        if _ws_capture_refs is not None:
+            _ws_capture_refs.append(host)      # owned by the graph from here on (freed with it)
         return host, None
+    if len(ent['spare']) < GRP_CAP_SPARE:
+        ent['spare'].append(torch.empty(nrows, dtype=torch.int64).pin_memory())
     slot = ent['flip']
     ent['flip'] ^= 1
     if ent['ev'][slot] is not None:

@@ -252,9 +252,11 @@ class RefGuidedImageCleanModel(BaseModel):
             K.set_grad_scaled(gs != 1.0)
             guard = self.optimizer_g.ensure_guard(lq.device)
             if not torch.cuda.is_current_stream_capturing():
-                # without a loss scale (TDR_MATH=bx3 / f32, or the surveyed fall-back) there is no skip verdict either: the step is
-                # applied whatever the norm, as the reference does (:276-279); the struct only counts steps on the device
-                guard.set_never_skip(gs == 1.0)
+                # TDR_MATH=bx3 / f32 (fp32 range in BOTH passes): no skip verdict -- the step is applied whatever the norm, as the
+                # reference does (:276-279); the struct only counts steps on the device.  Under an fp16 arithmetic the verdict stays
+                # even without a loss scale (the surveyed full-range backward, TDR_GRAD_SCALE=0): the FORWARD pass still runs inside
+                # the fp16 window, and between surveys the guard is what keeps a forward overflow out of the weights
+                guard.set_never_skip(gs == 1.0 and not K.fp16_path())
                 guard.set_max_scale(gs)        # (host read; the capture pass reuses the value of the eager warm-up steps)
             self.grad_reducer.guard = guard
             self._pack_plan.run()              # all weights, all layouts, one launch (no-op on the recording step)
@@ -278,6 +280,19 @@ class RefGuidedImageCleanModel(BaseModel):
                 p.grad = grads[k]
             self._grads_bound = True
         return loss
+
+    @staticmethod
+    def _raise_on_uncovered(red, missing, where):
+        """An incomplete bucket was never GATHERED either: its arena slice still holds whatever an earlier step left there, and a
+        flat all-reduce of the arena would hand those stale numbers to AdamW on every replay (consistent across ranks, and wrong).
+        No silent fallback: a trainable parameter that receives no gradient is a configuration error (the reference's
+        `find_unused_parameters`, base_model.py:77-82, is served by `unused_parameter_prefixes`: those parameters are frozen)."""
+        if not missing:
+            return
+        names = [n for bi in missing for n in red.buckets[bi][2] if n not in getattr(red, '_pending', {})]
+        raise RuntimeError(f'{where}: gradient bucket(s) {missing} were not completed by the backward pass -- '
+                           f'no gradient arrived for {names[:8]}{" ..." if len(names) > 8 else ""}; freeze those parameters '
+                           '(requires_grad=False / unused_parameter_prefixes) or run with TDR_GRAPH_BUCKETS=0 / TDR_GRAPH=0')
 
     def _eager_step(self, lq, gt, ref_in):
         loss = self._fwd_bwd(lq, gt, ref_in)
@@ -303,7 +318,12 @@ class RefGuidedImageCleanModel(BaseModel):
         if st['segs'] is None:
             if st['eager_left'] > 0:
                 st['eager_left'] -= 1
-                return self._eager_step(self.lq, self.gt, self.ref_in)
+                loss = self._eager_step(self.lq, self.gt, self.ref_in)
+                if red.collective and os.environ.get('TDR_GRAPH_BUCKETS', '1') == '1':
+                    # the same check the capture pass makes, on the FIRST eager step of the shape: a trainable parameter without a
+                    # gradient is a configuration error of the run and should not surface two steps (and one capture) later
+                    self._raise_on_uncovered(red, red.uncovered_buckets(), 'eager warm-up step')
+                return loss
             st['lq'], st['gt'], st['ref'] = self.lq.clone(), self.gt.clone(), self.ref_in.clone()
             # what torch.cuda.graph() does on entry: hand the eager steps' cached blocks back, or the graphs' private pool has to
             # fit NEXT to them (PromptIR-ref 384x384 bs 8: 106 GB live + 180 GB cached = out of memory)
@@ -344,14 +364,7 @@ class RefGuidedImageCleanModel(BaseModel):
                     # the captured step never completes, is never exchanged on replay, and the replicas would silently diverge
                     seen = {bi for _, bi in segs if bi is not None}
                     missing = red.uncovered_buckets() or sorted(set(range(len(red.buckets))) - seen)
-                    if missing:
-                        # An incomplete bucket was never GATHERED either: its arena slice still holds whatever an earlier step left there,
-                        # and a flat all-reduce of the arena would hand those stale numbers to AdamW on every replay (consistent across
-                        # ranks, and wrong).  No silent fallback: a trainable parameter that receives no gradient is a configuration error.
-                        names = [n for bi in missing for n in red.buckets[bi][2] if n not in getattr(red, '_pending', {})]
-                        raise RuntimeError(f'captured step: gradient bucket(s) {missing} were not completed by the backward pass -- '
-                                           f'no gradient arrived for {names[:8]}{" ..." if len(names) > 8 else ""}; freeze those parameters '
-                                           '(requires_grad=False) or run with TDR_GRAPH_BUCKETS=0 / TDR_GRAPH=0')
+                    self._raise_on_uncovered(red, missing, 'captured step')
                 self.optimizer_g.prepare()
                 gB = torch.cuda.CUDAGraph()
                 gB.capture_begin(pool=pool, capture_error_mode='thread_local')
