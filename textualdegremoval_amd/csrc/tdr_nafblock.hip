@@ -50,6 +50,20 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&p)[Sch
 }
 
 constexpr int NPX = 64;                       // pixels per workgroup
+
+// Phase timeline (probe builds only: make probe -> libtdr_hip_probe.so with -DTDR_NB_PROBE; profiles/probe_nafblock_timeline.py):
+// s_memtime stamps of waves 0 and 5 of workgroups (0, 0) and (37, 2) at the phase boundaries of the chain kernels.
+#ifdef TDR_NB_PROBE
+__device__ unsigned long long nb_probe_buf[4 * 16];
+#define NB_STAMP(k)                                                                                         \
+    do {                                                                                                    \
+        const int wg_ = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : ((blockIdx.x == 37 && blockIdx.y == 2) ? 1 : -1); \
+        if (wg_ >= 0 && (wave == 0 || wave == 5) && lane == 0)                                              \
+            nb_probe_buf[(wg_ * 2 + (wave == 5)) * 16 + (k)] = __builtin_amdgcn_s_memtime();                \
+    } while (0)
+#else
+#define NB_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ int swz(int slot) { return slot ^ ((slot >> 4) & 3); }
 __device__ __forceinline__ int row_of(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
 
@@ -209,6 +223,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
     // row r of this lane: channel m0 + row_of(r, kk); element offset of (row r, pixel j of sub-tile tn) in an [*, HW] image
     auto off = [&](int r, int tn) { return (long)(m0 + row_of(r, kk)) * HW + 32 * tn; };
 
+    NB_STAMP(0);
     // ---- residual tile (inp) in accumulator layout: requested first, consumed after the first GEMM
     float xr[2][16];
     {
@@ -240,6 +255,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         bev[r] = a.beta[m0 + row_of(r, kk)];
     }
     __syncthreads();
+    NB_STAMP(1);
 
     // ---- conv3: y = (W3 (g*sca) + b3) * beta + inp
     f32x16 acc[1][2];
@@ -248,6 +264,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
     gemm_split<SCH, 1, NG, 2>(acc, a.w3, C / 32, [&](int) { return wave; }, sB, NOCT, lane, rot, [](int) {});
+    NB_STAMP(2);
 
     float yv[2][16];
     float psum[2] = {0.f, 0.f};
@@ -322,6 +339,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         }
     }
     __syncthreads();
+    NB_STAMP(3);
 
     // ---- conv4: t4 = W4 yn + b4 ; rows [32w, 32w+32) and their gate partners [C + 32w, C + 32w + 32)
     f32x16 acc4[2][2];
@@ -346,6 +364,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
             }
         });
     }
+    NB_STAMP(4);
     float b4v[2][16];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -372,6 +391,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
         gav[r] = m0 < a.c_out ? a.gamma[m0 + row_of(r, kk)] : 0.f;
     }
     __syncthreads();
+    NB_STAMP(5);
 
     // ---- conv5: out = (W5 gate + b5) * gamma + y ; the t4 tile leaves for HBM under its MFMAs.  Only the first c_out rows
     // exist (fusion blocks keep `[:, :chan]`): the waves above them just store their t4 tiles.
@@ -398,11 +418,13 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_fwd_kernel(TailArgs a) {
                 tp[(long)tm * C * HW + off(r, tn)] = acc4[tm][tn][r];
             }
         });
+        NB_STAMP(6);
         float* op = a.out + (long)n * a.out_ns + p0 + j;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) op[off(r, tn)] = (acc[0][tn][r] + b5v[r]) * gav[r] + yv[tn][r];
+        NB_STAMP(7);
     } else if constexpr (!EARLY_STORES) {
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -598,6 +620,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     auto off = [&](int r, int tn) { return (long)(m0 + row_of(r, kk)) * HW + 32 * tn; };
     const float one8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 
+    NB_STAMP(0);
     f32x16 acc[1][2];
     float da[HEAD ? 1 : 2][16], db[HEAD ? 1 : 2][16];
     float4 vh[(HEAD && KHALF) ? 8 : 1];                       // HEAD + KHALF: the second K half of dt1, requested before the first GEMM
@@ -649,6 +672,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
         stage_octet<SCH, true>(v, sc, sB, NOCT, oct, q);
     }
     __syncthreads();
+    NB_STAMP(1);
 
     // ---- conv5 data gradient: dg2 rows [32w, 32w + 32)
 #pragma unroll
@@ -657,6 +681,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
         for (int r = 0; r < 16; ++r) acc[0][tn][r] = 0.f;
     if (a.c_out == C) gemm_split<SCH, 1, C / 16, 2>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 8, lane, rot, [](int) {});
     else gemm_split<SCH, 1, C / 32, 2>(acc, a.w5t, C / 32, [&](int) { return wave; }, sB, C / 16, lane, rot, [](int) {});
+    NB_STAMP(2);
     __syncthreads();                                          // every wave is done with the dout planes
 
     // ---- SimpleGate backward; dt4 rows c -> octets [4w, 4w+4), rows C + c -> octets [C/8 + 4w, ...) of the K = 2C operand
@@ -700,6 +725,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
     constexpr bool LN_LATE = KHALF && !HEAD;
     if constexpr (!LN_LATE) load_ln_operands();
     __syncthreads();
+    NB_STAMP(3);
 
     // ---- conv4 data gradient: dyn rows [32w, 32w + 32), K = 2C ; the dt4 tile leaves for HBM under its MFMAs
 #pragma unroll
@@ -747,6 +773,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
             }
         });
     }
+    NB_STAMP(4);
     // ---- LayerNorm backward: g = dyn * w ; dx = (g - yhat * mean_c(g * yhat) - mean_c(g)) * rstd ; + dout
     float gv[2][16];
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -825,6 +852,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
                 tile_to_planes<SCH>(v, sB, C / 8, 4 * wave, 32 * tn + j, kk);
             }
             __syncthreads();
+            NB_STAMP(5);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -838,6 +866,7 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
                     dyp[off(r, tn)] = gv[tn][r];
                 }
             });
+            NB_STAMP(6);
             float sc[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = a.sca[(long)n * C + m0 + row_of(r, kk)];
@@ -846,11 +875,18 @@ __global__ __launch_bounds__(2 * C, 2) void naf_tail_bwd_kernel(TailBwdArgs a) {
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gp[off(r, tn)] = acc[0][tn][r] * sc[r];
+            NB_STAMP(7);
         }
     }
 }
 
 }  // namespace
+
+#ifdef TDR_NB_PROBE
+extern "C" int tdr_nb_probe_read(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(nb_probe_buf), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int tdr_naf_tail_supported(int C, int HW) { return ((C == 256 || C == 128 || C == 64 || C == 32) && HW % 64 == 0) ? 1 : 0; }
 
