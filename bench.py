@@ -257,7 +257,7 @@ def pmc_traffic(prefixes):
     import hashlib
     srcs = {'tdr_conv_bx3_sha256': 'tdr_conv_bx3.hip', 'tdr_conv_p16_sha256': 'tdr_conv_p16.hip'}
     pmc = path = None
-    for rnd in ('r5', 'r4', 'r3', 'r2'):           # newest collection first
+    for rnd in ('r6', 'r5', 'r4', 'r3', 'r2'):     # newest collection first
         cand = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')
         try:
             with open(cand) as fh:
@@ -288,7 +288,7 @@ def pmc_traffic(prefixes):
 
 def pmc_step_bytes():
     """measured HBM bytes of one whole train step from the same PMC collection (sum over every kernel of the step), or None"""
-    for rnd in ('r5', 'r4', 'r3'):
+    for rnd in ('r6', 'r5', 'r4', 'r3'):
         try:
             with open(os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')) as fh:
                 pmc = json.load(fh)
@@ -322,12 +322,20 @@ def main():
                          '(random-init weights); 0 = ref of the lq size, where the match is the identity')
     ap.add_argument('--bucket-mb', type=float, default=64.0, help='gradient all-reduce bucket size (MiB) of the data-parallel step')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (multi-process smoke test on one GPU)')
+    ap.add_argument('--rccl-dry-run', action='store_true',
+                    help='with --gpus N: bring the RCCL data plane up through the C ABI (tdr_comm_*), verify a broadcast and an all-reduce, time '
+                         'one 64 MiB exchange, print ONE JSON line and exit -- or fail loudly with the name of the bring-up stage that did')
+    ap.add_argument('--math', default=None, choices=['bx3', 'f32', 'hx2', 'h1'],
+                    help='arithmetic of the dense contractions (default: the library default bx3 -- except the BASELINE configs[4] workload, '
+                         '`--arch restormer --size 512 --batch 2`, whose config names fp16 MFMA: h1)')
     a = ap.parse_args()
     if a.batch is None:
         a.batch = 8 if a.arch in ('restormer', 'promptir', 'drsformer', 'drsformer_mefc') else 4
     if a.size is None:
         a.size = {'restormer': 256, 'promptir': 384, 'drsformer': 256, 'drsformer_mefc': 256}.get(a.arch, 512)
     enc = [int(v) for v in a.enc.split(',')]
+    if a.math is None and (a.arch, a.size, a.batch) == ('restormer', 512, 2) and 'TDR_MATH' not in os.environ:
+        a.math = 'h1'                  # BASELINE configs[4]: "Restormer-ref 512x512 bs=2/GPU ... fp16 MFMA"
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # called plainly: become the launcher (one rank per GPU; rank 0's JSON line and every rank's stderr pass through)
         import socket
@@ -344,7 +352,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local % torch.cuda.device_count())
-    if world > 1:
+    one_rank_dry = a.rccl_dry_run and world == 1 and os.environ.get('TDR_FORCE_COLLECTIVES') == '1'
+    if one_rank_dry:                    # a 1-GPU box exercising the same calls (tests/test_hip_dp_smoke.py)
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if world > 1 or one_rank_dry:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if a.backend == 'nccl':
             # the N-GPU line is an RCCL-through-the-C-ABI measurement or it is an error: no silent torch.distributed fallback
@@ -366,7 +379,89 @@ def main():
         raise
 
 
+def rccl_dry_run(a, world, rank):
+    """The first thing to run on a new multi-GPU node: every stage of the RCCL bring-up and one exchange of each kind, each stage named in
+    the failure message (reference: models/base_model.py:76-82 wraps the network in DistributedDataParallel; this is what stands in its
+    place).  Exit code 2 + one stderr line naming the stage on failure; one JSON line on success."""
+    from textualdegremoval_amd import parallel
+    stages, t_stage = [], time.perf_counter()
+
+    def done(name, **extra):
+        nonlocal t_stage
+        now = time.perf_counter()
+        stages.append(dict(stage=name, ok=True, ms=(now - t_stage) * 1e3, **extra))
+        t_stage = now
+
+    def fail(name, why):
+        sys.stderr.write(f"bench.py --rccl-dry-run: rank {rank}/{world}: FAILED at stage '{name}': {why}\n")
+        sys.stderr.flush()
+        if dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+        sys.exit(2)
+    done('torch.distributed rendezvous (side channel)', backend=dist.get_backend())
+    os.environ['TDR_COMM'] = 'rccl'                       # strict: a failed bring-up raises instead of falling back to torch collectives
+    try:
+        comm = parallel.data_plane()
+    except parallel.DataPlaneUnavailable as e:
+        fail('RCCL communicator bring-up (librccl resolves -> ncclGetUniqueId -> broadcast of the id -> ncclCommInitRank -> agreement)', str(e))
+    if comm is None:
+        fail('RCCL communicator bring-up', 'no communicator was created (world size 1 without TDR_FORCE_COLLECTIVES=1, or backend != nccl)')
+    from textualdegremoval_amd import _lib
+    seen = int(_lib.load().tdr_comm_world(comm.handle))
+    if seen != world:
+        fail('communicator size', f'tdr_comm_world = {seen}, launcher world = {world}')
+    done('tdr_comm_init (ncclCommInitRank through the C ABI)', ranks_seen=seen)
+    try:
+        t = torch.full((1 << 16,), float(rank + 1), device='cuda')
+        comm.broadcast(t, root=0)
+        torch.cuda.synchronize()
+        if not bool((t == 1.0).all()):
+            fail('tdr_comm_broadcast', f'rank {rank} holds {t[0].item()} after a broadcast of 1.0 from rank 0')
+        done('tdr_comm_broadcast (64 Ki floats from rank 0)')
+        t = torch.arange(1 << 16, device='cuda', dtype=torch.float32) * float(rank + 1)
+        comm.allreduce(t, average=True)
+        torch.cuda.synchronize()
+        want = torch.arange(1 << 16, device='cuda', dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        err = float((t - want).abs().max())
+        if err > 1e-3 * float(want.abs().max()) / 1e3:
+            fail('tdr_comm_allreduce (mean)', f'max |got - expected| = {err}')
+        done('tdr_comm_allreduce (mean of rank-dependent data, checked element-wise)', max_abs_err=err)
+        big = torch.ones(16 << 20, device='cuda')         # 64 MiB: one gradient bucket
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        comm.allreduce(big, average=True, stream=side.cuda_stream)      # warm-up (ring / channel set-up)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(5):
+            comm.allreduce(big, average=True, stream=side.cuda_stream)
+        e1.record(side)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        if not bool((big == 1.0).all()):
+            fail('64 MiB bucket all-reduce on the comm stream', 'the averaged ones are not ones')
+        done('64 MiB bucket all-reduce on a second HIP stream (x5)', ms_per_exchange=ms,
+             bus_GBps=(2.0 * (world - 1) / max(world, 1)) * big.numel() * 4 / (ms * 1e-3) / 1e9 if world > 1 else None)
+    except SystemExit:
+        raise
+    except Exception as e:  # noqa: BLE001
+        fail(f'after "{stages[-1]["stage"]}"', f'{type(e).__name__}: {e}')
+    allst = [None] * world
+    dist.all_gather_object(allst, stages)
+    if rank == 0:
+        print(json.dumps({'rccl_dry_run': 'ok', 'n_gpus': world, 'stages': stages,
+                          'slowest_rank_ms_by_stage': [max(r[i]['ms'] for r in allst) for i in range(len(stages))]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _main_body(a, world, rank, local, enc):
+    if a.rccl_dry_run:
+        if not dist.is_initialized():
+            sys.exit('bench.py --rccl-dry-run needs --gpus N > 1 (or TDR_FORCE_COLLECTIVES=1 under a one-rank launcher)')
+        return rccl_dry_run(a, world, rank)
     if a.arch in ('i2t', 'tr'):
         bench_i2t(a, world, rank, local)
         if world > 1:
@@ -376,6 +471,8 @@ def _main_body(a, world, rank, local, enc):
     from textualdegremoval_amd.models import create_model
     from textualdegremoval_amd.utils.synthetic import randomize_gates, synthetic_pair
     from textualdegremoval_amd import kernels as K
+    if a.math is not None:
+        K.set_math(a.math)
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
     opt = make_opt(a.width, enc, a.size, world > 1, a.arch, bucket_mb=a.bucket_mb)
@@ -470,10 +567,45 @@ def _main_body(a, world, rank, local, enc):
                 'ms_per_step_local': dt_local / a.steps * 1e3, 'exchange': tsum,
                 'grad_sum_after_allreduce': gsum, 'grad_abs_sum_after_allreduce': gabs, 'grad_sha1_16': ghash, 'param_sum': psum,
                 'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated() / 1e9}
+        # ---- what the exchange costs on the wall clock: the same captured step with every collective left out (dry_exchange), timed the
+        # same way.  Last thing this process does with the model: the replicas diverge from here on.
+        barrier()
+        red.dry_exchange = True
+        for _ in range(2):
+            it += 1
+            step(it)
+        barrier()
+        t1 = time.perf_counter()
+        n_dry = max(5, min(a.steps, 10))
+        for _ in range(n_dry):
+            it += 1
+            step(it)
+        torch.cuda.synchronize()
+        mine['compute_only_ms_per_step'] = (time.perf_counter() - t1) / n_dry * 1e3
+        red.dry_exchange = False
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         if rank == 0:
-            scale_diag = {'per_rank': allr,
+            t_meas = dt / a.steps * 1e3
+            t_comp = max(r['compute_only_ms_per_step'] for r in allr)
+            waited = max((r['exchange'].get('compute_stream_waited_ms') or 0.0) / 3.0 for r in allr)      # 3 instrumented steps
+            pred = t_comp + waited
+            scale_summary = {
+                'ms_per_step': t_meas, 'compute_only_ms_per_step_slowest_rank': t_comp,
+                'compute_only_ms_per_step_by_rank': [r['compute_only_ms_per_step'] for r in allr],
+                'exposed_exchange_ms_per_step': t_meas - t_comp,
+                'exposed_exchange_ms_per_step_by_events': waited,
+                'predicted_ms_per_step': pred, 'predicted_over_measured': pred / t_meas,
+                'efficiency_vs_own_compute': t_comp / t_meas,
+                'checks': {'prediction_within_10pct': abs(pred - t_meas) <= 0.10 * t_meas,
+                           'ranks_within_5pct_of_each_other': (max(r['ms_per_step_local'] for r in allr) <=
+                                                               1.05 * min(r['ms_per_step_local'] for r in allr)),
+                           'all_ranks_see_world': all(r['ranks_seen'] == world for r in allr)},
+                'note': 'compute_only = the captured data-parallel step replayed with every collective skipped (same graphs and stream '
+                        'dependencies); exposed = measured - compute_only; by_events = what the compute stream waited for the comm stream in 3 '
+                        'instrumented steps.  The driver computes scaling efficiency itself from the per-N values; this block only says where '
+                        'a shortfall comes from (compute imbalance between ranks vs exposed exchange time)'}
+            scale_diag = {'summary': scale_summary, 'per_rank': allr,
                           'gradients_identical_across_ranks': len({r['grad_sha1_16'] for r in allr}) == 1,
                           'parameters_identical_across_ranks': len({r['param_sum'] for r in allr}) == 1,
                           'all_ranks_see_world': all(r['ranks_seen'] == world for r in allr),
@@ -549,6 +681,51 @@ def _main_body(a, world, rank, local, enc):
                 by += 4.0 * (x.numel() + dout.numel())
             recs.append((fl, e0, e1, by, ('wgrad', 'g1'), len(reqs)))
             return out
+        # the fused NAFBlock chain kernels and the depthwise stencils (24 % + 6 % of the step): one record per launch, keyed by kernel and C
+        chain_orig = {n: getattr(K, n) for n in ('naf_head_fwd', 'naf_tail_fwd', 'naf_tail_bwd', 'naf_head_bwd', 'dwsg_fwd', 'dwsg_bwd')}
+
+        def _chain(name, work):
+            fn = chain_orig[name]
+
+            def wrapped(*args, **kw):
+                e0, e1 = _ev()
+                e0.record()
+                out = fn(*args, **kw)
+                e1.record()
+                fl, by, Cc = work(*args, **kw)
+                recs.append((fl, e0, e1, by, ('chain', name), Cc))
+                return out
+            return wrapped
+
+        def _w_head_fwd(x, *r, **kw):
+            n, c, h, w = x.shape
+            return 2.0 * n * h * w * 2 * c * c, 4.0 * n * h * w * 4 * c, c
+
+        def _w_tail_fwd(g, s_, x, *r, c_out=None, **kw):
+            n, c, h, w = g.shape
+            co = c if c_out is None else c_out
+            return 2.0 * n * h * w * (3 * c * c + co * c), 4.0 * n * h * w * (6 * c + co), c
+
+        def _w_tail_bwd(dout, gamma, t4, *r, w3tp=None, **kw):
+            n, co, h, w = dout.shape
+            c = t4.shape[1] // 2
+            return (2.0 * n * h * w * (c * co + 2 * c * c + (c * c if w3tp is not None else 0)),
+                    4.0 * n * h * w * (co + 6 * c + (c if w3tp is not None else 0)), c)
+
+        def _w_head_bwd(dt1, x, *r, **kw):
+            n, c, h, w = x.shape
+            return 2.0 * n * h * w * 2 * c * c, 4.0 * n * h * w * 5 * c, c
+
+        def _w_dw_fwd(t, *r, **kw):
+            n, c2, h, w = t.shape
+            return 0.0, 4.0 * n * h * w * (c2 + c2 // 2), c2 // 2
+
+        def _w_dw_bwd(dg, t, *r, **kw):
+            n, c2, h, w = t.shape
+            return 0.0, 4.0 * n * h * w * (c2 // 2 + 2 * c2), c2 // 2
+        for nm, wk in (('naf_head_fwd', _w_head_fwd), ('naf_tail_fwd', _w_tail_fwd), ('naf_tail_bwd', _w_tail_bwd), ('naf_head_bwd', _w_head_bwd),
+                       ('dwsg_fwd', _w_dw_fwd), ('dwsg_bwd', _w_dw_bwd)):
+            setattr(K, nm, _chain(nm, wk))
         K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16, K.wgrad1x1_group = timed, timed_p16, timed_wg, timed_wg16, timed_grp
         graph_was = getattr(model, 'use_hip_graph', False)
         model.use_hip_graph = False                       # instrumented step runs eagerly (a replayed graph makes no Python calls)
@@ -591,6 +768,8 @@ def _main_body(a, world, rank, local, enc):
             ev_overhead_ms = sorted(e0.elapsed_time(e1) for e0, e1 in empties)[len(empties) // 2]
         finally:
             K.conv_forward, K.conv3x3_p16, K.conv_wgrad, K.wgrad3x3_p16, K.wgrad1x1_group = orig, orig_p16, orig_wg, orig_wg16, orig_grp
+            for nm, fn in chain_orig.items():
+                setattr(K, nm, fn)
             model.use_hip_graph = graph_was
             _E.SERIAL_LEAVES = serial_was
         # The 3x3 / stride-1 forward + data-gradient launches of the step are run by two kernels since round 4 (conv3x3_p16_kernel on
@@ -668,6 +847,29 @@ def _main_body(a, world, rank, local, enc):
                 e['traffic'] = None if t_k is None else t_k + (t_r or 0.0)
             if k == 'g1':
                 e['problems'] = sum(r[5] for r in recs if r[4] == ('wgrad', 'g1'))
+            roof_other.append(e)
+        CHAIN = {'naf_head_fwd': 'naf_head_fwd_kernel (norm1 -> conv1, one workgroup = 64 pixels x all channels)',
+                 'naf_tail_fwd': 'naf_tail_fwd_kernel (conv3 -> +x -> norm2 -> conv4 -> SimpleGate -> conv5 -> +y)',
+                 'naf_tail_bwd': 'naf_tail_bwd_kernel<HEAD=false> (conv5^T -> gate bwd -> conv4^T -> norm2 bwd -> conv3^T)',
+                 'naf_head_bwd': 'naf_tail_bwd_kernel<HEAD=true> (conv1^T -> norm1 bwd + skip)',
+                 'dwsg_fwd': 'dwsg_stencil_kernel (depthwise 3x3 + SimpleGate + SCA pool partials)',
+                 'dwsg_bwd': 'dwsg_bwd_fused_kernel (one-pass depthwise + SimpleGate backward) + its parameter-gradient partials'}
+        pk_split = PEAK_HX2 if K.MATH in ('hx2', 'h1') else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32)
+        for nm in CHAIN:
+            rr = [r for r in recs if r[4] == ('chain', nm)]
+            if not rr:
+                continue
+            e = entry(rr, CHAIN[nm], pk_split, 'fp32-equivalent ceiling of the step\'s operand scheme (chain GEMMs); bytes = the fp32 tensors the '
+                      'launch reads and writes once (DESIGN 5)')
+            e['by_channels'] = []
+            for cc in sorted({r[5] for r in rr}):
+                sub = entry([r for r in rr if r[5] == cc], CHAIN[nm], pk_split, '')
+                e['by_channels'].append({'C': cc, 'launches': sub['launches'], 'avg_launch_ms': sub['avg_launch_ms'], 'bound': sub['bound'],
+                                         'frac': sub['frac'], 'frac_of_split_flop_ceiling': sub.get('frac_of_split_flop_ceiling', sub['frac']),
+                                         'hbm_frac': (sub['alg_bytes_per_launch'] / (sub['avg_launch_ms'] * 1e-3)) / PEAK_HBM})
+            e['traffic'] = pmc_traffic([{'naf_head_fwd': 'naf_head_fwd_kernel', 'naf_tail_fwd': 'naf_tail_fwd_kernel', 'naf_tail_bwd': 'naf_tail_bwd_kernel<',
+                                         'naf_head_bwd': 'naf_tail_bwd_kernel<', 'dwsg_fwd': 'dwsg_stencil_kernel', 'dwsg_bwd': 'dwsg_bwd_fused_kernel'}[nm]])[0] \
+                if nm not in ('naf_tail_bwd', 'naf_head_bwd') else None
             roof_other.append(e)
         for f in ([roof] if roof else []) + roof_other:
             f.pop('_total_ms', None)
@@ -781,6 +983,13 @@ def _main_body(a, world, rank, local, enc):
             line['roofline_step'] = {'achieved_hbm_frac': CFG3['B_alg'] * per_gpu / PEAK_HBM,
                                      'achieved_f32_flop_frac': CFG3['F_alg'] * per_gpu / PEAK_F32,
                                      'alg_bytes_per_image': CFG3['B_alg'], 'alg_flop_per_image': CFG3['F_alg']}
+            if K.MATH == 'h1':
+                # SURVEY 8(d) quotes cfg5's bytes on the fp32 basis "(/ 2 for fp16 activations)".  This library's h1 mode rounds the OPERANDS of
+                # the contractions to fp16 inside the kernels; the tensors in HBM stay fp32 (the backward pass, LayerNorm statistics and the
+                # optimiser read them), so the fp32 basis is the traffic this step really has -- the halved basis is given beside it
+                line['roofline_step']['achieved_hbm_frac_fp16_activation_basis'] = 0.5 * CFG3['B_alg'] * per_gpu / PEAK_HBM
+                line['roofline_step']['note'] = ('h1 = plain fp16 MFMA operands, fp32 accumulate, fp32 tensors in HBM: achieved_hbm_frac is on the '
+                                                 'fp32 byte basis the step actually moves; SURVEY 8d\'s halved (fp16-activation) basis beside it')
         if not a.no_f32_exact and world == 1 and K.MATH != 'f32':
             line['f32_exact'] = f32_exact_run(a)
             if K.MATH == 'bx3' and is_cfg2:

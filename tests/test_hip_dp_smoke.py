@@ -85,3 +85,20 @@ def test_single_rank_rccl_collectives_under_graph_capture():
                          env=dict(os.environ, TDR_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     assert 'RCCL_SINGLE_RANK_OK' in out.stdout
+
+
+def test_rccl_dry_run_one_rank():
+    """`bench.py --rccl-dry-run`: the staged RCCL bring-up + broadcast + all-reduce + a timed 64 MiB bucket exchange on
+    a second stream, here as a one-rank communicator on the GPU at hand (TDR_FORCE_COLLECTIVES=1); and its failure path names the stage."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(TDR_FORCE_COLLECTIVES='1', MASTER_PORT='29531')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--rccl-dry-run'], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert r['rccl_dry_run'] == 'ok' and all(s['ok'] for s in r['stages']) and len(r['stages']) == 5
+    # failure path: an injected fault inside the bring-up -> exit code 2 and ONE line naming the stage
+    env.update(TDR_FAULT='init:0', MASTER_PORT='29532')
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--rccl-dry-run'], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert bad.returncode == 2 and "FAILED at stage 'RCCL communicator bring-up" in bad.stderr, (bad.returncode, bad.stderr[-1500:])

@@ -38,6 +38,7 @@ def test_h1_forward_psnr_and_gradient_direction(arch):
     from textualdegremoval_amd.utils.synthetic import synthetic_pair
     data = {k: v.cuda() for k, v in synthetic_pair(2, 128, 128, seed=7).items()}
     outs, grads = {}, {}
+    prev = K.MATH
     try:
         for mode in ('hx2', 'h1'):
             m = _model(arch, mode)
@@ -47,7 +48,7 @@ def test_h1_forward_psnr_and_gradient_direction(arch):
             outs[mode] = m.output.detach().float().clone()
             grads[mode] = torch.cat([q.grad.flatten().double() for q in m.net_g.parameters() if q.grad is not None])
     finally:
-        K.set_math('hx2')
+        K.set_math(prev)
     assert torch.isfinite(outs['h1']).all()
     p = _psnr(outs['h1'].clamp(0, 1), outs['hx2'].clamp(0, 1))
     assert p > 55.0, f'fp16-MFMA output vs fp32-equivalent output: {p:.1f} dB'
@@ -61,6 +62,7 @@ def test_h1_short_training_run_tracks_the_fp32_equivalent_curve():
     from textualdegremoval_amd.utils.synthetic import synthetic_pair
     data = {k: v.cuda() for k, v in synthetic_pair(2, 128, 128, seed=11).items()}
     curves = {}
+    prev = K.MATH
     try:
         for mode in ('hx2', 'h1'):
             m = _model('nafnet', mode)
@@ -72,7 +74,7 @@ def test_h1_short_training_run_tracks_the_fp32_equivalent_curve():
                 losses.append(float(m.get_current_log()['l_pix']))
             curves[mode] = losses
     finally:
-        K.set_math('hx2')
+        K.set_math(prev)
     a, b = curves['hx2'], curves['h1']
     assert b[-1] < b[0]
     for x, y in zip(a, b):

@@ -727,6 +727,25 @@ def test_restormer_configs4_shapes_512_batch2(rworld, monkeypatch):
     assert diff.max().item() < 1e-4
     assert abs(psnr(out.cpu().clamp(0, 1), gt) - psnr(ro.clamp(0, 1), gt)) < 1e-3
     del out, saved
+    if K.MATH == 'bx3':
+        # ---- the arithmetic configs[4] itself names: plain fp16 MFMA, fp32 accumulate (TDR_MATH=h1; `bench.py --arch restormer --size 512
+        # --batch 2` runs it as that workload's primary line).  The config asks for PSNR parity: the restored image against the ORACLE's
+        # on the same pair -- PSNR to the ground truth within the north-star 1e-3 dB, and the two images more than 60 dB apart.
+        K.set_math('h1')
+        try:
+            out_h, saved_h = R.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
+            same = torch.equal(saved_h[6][4].cpu().long(), hip_index) and torch.equal(saved_h[6][7].cpu().long(), hip_index_all)
+            oh = out_h.cpu()
+        finally:
+            K.set_math('bx3')
+        p_gt_h, p_gt_o = psnr(oh.clamp(0, 1), gt), psnr(ro.clamp(0, 1), gt)
+        p_between = psnr(oh.clamp(0, 1), ro.clamp(0, 1))
+        _log(f'restormer 512x512 in the fp16-MFMA arithmetic of configs[4] (h1) vs oracle: PSNR to gt {p_gt_h:.4f} dB vs {p_gt_o:.4f} dB (oracle), '
+             f'image-to-image {p_between:.1f} dB, max |diff| {(oh - ro).abs().max().item():.2e}; match decisions equal to the default arithmetic: {same}')
+        _record_margin('restormer_cfg5_h1_psnr', dict(psnr_gt_h1=p_gt_h, psnr_gt_oracle=p_gt_o, psnr_h1_vs_oracle=p_between,
+                                                       max_abs=(oh - ro).abs().max().item(), match_decisions_equal=bool(same)))
+        assert torch.isfinite(oh).all() and abs(p_gt_h - p_gt_o) < 1e-3 and p_between > 60.0, (p_gt_h, p_gt_o, p_between)
+        del out_h, saved_h
     # ---- bs = 2 properties
     lq, gt, ref = O.synth_pair(2, S512, S512, seed=94)
     lq, ref, gtc = lq.cuda(), ref.cuda(), gt.cuda()

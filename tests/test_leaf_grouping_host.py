@@ -52,7 +52,6 @@ def fake(monkeypatch):
     monkeypatch.setattr(E, 'K', k)
     monkeypatch.setattr(E, 'DEFER_WGRAD', True)
     monkeypatch.setattr(E, 'GROUP_LEAVES', True)
-    monkeypatch.setattr(E, 'LEAF_LANES', 1)
     return k
 
 

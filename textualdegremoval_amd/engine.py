@@ -64,7 +64,6 @@ def maybe_join():
 # Only without a gradient exchange: with collectives the buckets are cut in arrival order inside the backward (parallel.GradAllReducer).
 DEFER_WGRAD = os.environ.get('TDR_DEFER_WGRAD', '1') == '1'
 DEFER_LN_FINISH = os.environ.get('TDR_DEFER_LN_FINISH', '1') == '1'     # also the reductions of the LayerNorm-gradient partials
-LEAF_LANES = int(os.environ.get('TDR_LEAF_LANES', '1'))                 # HIP streams the deferred leaves are spread over
 # deferred 1x1 leaf weight gradients of one shape (a level's conv1 / conv4, its conv5) share ONE launch + ONE reduction
 # (kernels.wgrad1x1_group, csrc/tdr_wgrad_1x1.hip): no per-launch ramp / prologue / partial write / reduction launch, 1 / 8 of the partials
 GROUP_LEAVES = os.environ.get('TDR_GROUP_LEAVES', '1') == '1'
@@ -72,7 +71,6 @@ GROUP_LEAVES = os.environ.get('TDR_GROUP_LEAVES', '1') == '1'
 LEVEL_LEAVES = os.environ.get('TDR_LEVEL_LEAVES', '1') == '1'
 _level_mode = False
 FORCE_DP_SCHEDULE = os.environ.get('TDR_FORCE_DP_SCHEDULE', '0') == '1'    # measurement aid: schedule the leaves as a data-parallel run would, on one GPU
-EARLY_FLUSH = os.environ.get('TDR_EARLY_FLUSH', '0') == '1'            # flush_late_leaves() after the deepest encoder level: measured +0.2 ms (profiles/r5/sweep_m.log), off
 SERIAL_LEAVES = os.environ.get('TDR_SERIAL_LEAVES', '0') == '1'    # measurement aid (bench.py's roofline leg): the deferred leaves on the CURRENT stream, before the main chain
 _late = None            # [(prefix, closure -> {name: grad})] while a whole-network backward collects deferred leaves
 _late_pre = ''
@@ -142,7 +140,6 @@ class late_leaves:
         global _late, _grp_seq, _level_mode
         _late = [] if self.on else None
         _level_mode = self.on and self.level
-        _flushed.clear()
         _grp_seq = 0
         return self
 
@@ -169,7 +166,6 @@ def set_late_prefix(pre):
     _late_pre = pre
 
 
-_flushed = []           # (results, operands kept alive) of early flushes of the pass being collected
 _grp_seq = 0            # grouped launches issued so far in this pass (the call-site index of their pinned pointer tables)
 
 
@@ -190,18 +186,6 @@ def _run_leaves(late, serial=False):
         return [(pre, fn[3](*outs[i]) if isinstance(fn, tuple) else fn()) for i, (pre, fn, _) in enumerate(late)]
 
 
-def flush_late_leaves():
-    """launch the leaves queued so far NOW, beside the rest of the data-gradient chain (their gradients are handed over at the end of
-    the pass, run_late_leaves).  Called once the deepest encoder level -- 28 of the 36 NAFBlocks of configs[1], 87 % of the leaf work --
-    has been back-propagated: its matrix-bound grouped weight gradients then overlap the HBM-bound chains of the shallower levels
-    instead of competing with the matrix-bound MASA-encoder backward at the end."""
-    global _late
-    if _late is None or not _late or not EARLY_FLUSH or LEAF_LANES > 1:
-        return
-    late, _late = _late, []
-    _flushed.append((_run_leaves(late), late))
-
-
 def run_late_leaves(G, main_chain):
     """deferred leaves on lane 0, `main_chain()` on the current stream, join, then hand the gradients to the collector in order"""
     global _late, _grp_seq
@@ -212,35 +196,17 @@ def run_late_leaves(G, main_chain):
         main_chain()
         return
     late, _late = _late, None
-    flushed = list(_flushed)
-    _flushed.clear()
-    if not late and not flushed:
+    if not late:
         _grp_seq = 0
         main_chain()
         return
-    if LEAF_LANES <= 1:
-        results = _run_leaves(late) if late else []
-    else:
-        def _single(f):
-            r = K.conv_wgrad(f[2][0], f[2][1], f[2][2], f[2][3], 1, gate=f[2][4], want_db=f[2][5])
-            return f[3](*r) if f[2][5] else f[3](r, None)
-        late = [(pre, (lambda f=fn: _single(f)) if isinstance(fn, tuple) else fn, keep) for pre, fn, keep in late]
-        # independent leaves round-robin over a few streams: the ramp / tail / split-K reduction of one overlaps the main loop of the next
-        results = []
-        for i, (pre, fn, _) in enumerate(late):
-            with K.lane(i % LEAF_LANES):
-                results.append((pre, fn()))
+    results = _run_leaves(late)
     _grp_seq = 0
     main_chain()
     K.lanes_join()
-    for res, _kept in flushed:
-        for pre, g in res:
-            _put(G, pre, g)
     for pre, g in results:
         _put(G, pre, g)
-    if late:
-        late.clear()      # (operands referenced until here: the allocator cannot recycle them under a running lane kernel)
-    flushed.clear()
+    late.clear()      # (operands referenced until here: the allocator cannot recycle them under a running lane kernel)
 
 
 # ---------------------------------------------------------------------------
@@ -952,8 +918,6 @@ def _net_bwd_body(dout, P, cfg, saved, G):
         d = naf_seq_bwd(d, P, f'encoders.{lvl}.', cfg['enc_blk_nums'][lvl], sv_e, G)
         dcat = naf_seq_bwd(d, P, f'masa_blk_enc.{lvl}.', cfg['reffusion_n_blocks'][lvl], sv_f, G)
         level_end(G)
-        if lvl == n_enc - 1:
-            flush_late_leaves()
         chan = dcat.shape[1] // 2
         dwarp[lvl] = dcat[:, chan:]
         d = dcat[:, :chan]                             # batch-strided view: every consumer takes an image stride

@@ -347,10 +347,15 @@ class GradAllReducer:
             if self.grad_unscale != 1.0:
                 dst.mul_(self.grad_unscale)
 
+    # measurement aid (bench.py --gpus N, after its timed region): the step with every exchange left out -- same graphs, same stream
+    # dependencies, no collective -- is what this rank's compute alone costs in the data-parallel schedule.  The replicas diverge from
+    # there on; never set inside a training run.
+    dry_exchange = False
+
     def allreduce_flat(self):
         """one all-reduce (mean) of the whole gradient arena on the current stream (few, large collectives
         suit the point-to-point xGMI links); no-op on one rank."""
-        if not self.collective or self.flat is None:
+        if not self.collective or self.flat is None or self.dry_exchange:
             return
         if self.comm is not None and self.flat.is_cuda:
             self.comm.allreduce(self.flat, average=True)
@@ -411,6 +416,8 @@ class GradAllReducer:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            if self.dry_exchange:
+                return
             self.bucket_launches += 1
             if self.comm is not None:
                 tm = self.timing
