@@ -279,7 +279,7 @@ def _check_gradients(tag, G, loss, fwd64, fwd32, P, gt, cache_key=None, pyr=None
          f'{w64["other"][0]:.2e} at {w64["other"][1]}; masa_enc.* {w64["relu_encoder"][0]:.2e} at {w64["relu_encoder"][1]}')
     assert w64['other'][0] < 1e-4, w64          # measured 8.5e-6 (NAFNet-ref) / 4.6e-5 (Restormer-ref: an attention temperature scalar)
     assert w64['relu_encoder'][0] < 1e-3, w64
-    if pyr is None:
+    if pyr is None or _math_tag() != 'bx3':          # (the default arithmetic; the fast mode keeps the blanket bound above)
         return
     forced = _forced_relu(_hip_relu_masks(pyr))
     with forced:
@@ -291,9 +291,11 @@ def _check_gradients(tag, G, loss, fwd64, fwd32, P, gt, cache_key=None, pyr=None
     _record_margin(tag.replace(' ', '_') + f'_relu_forced_{_math_tag()}', dict(flips=forced.flips, units=forced.units, max_abs_preactivation_at_flip=forced.max_abs_at_flip,
                    free_running=dict(other=w64['other'], relu_encoder=w64['relu_encoder']), forced=dict(other=wf['other'], relu_encoder=wf['relu_encoder'])))
     assert abs(loss - rlf) < 1e-6
-    assert frac < 1e-5 and forced.max_abs_at_flip < 1e-5, (forced.flips, forced.units, forced.max_abs_at_flip)
-    # bx3 (24-bit operands): the north-star 1e-4 on every tensor; the opt-in fast mode (22-bit operands, loss-scaled) gets its own 3e-4
-    assert max(wf['other'][0], wf['relu_encoder'][0]) < (1e-4 if _math_tag() == 'bx3' else 3e-4), wf
+    # measured (profiles/r6/margins/*_relu_forced_bx3.json): NAFNet-ref 13 of 162.5 M units differ, the largest |pre-activation| among them 6.5e-8,
+    # and with the decisions forced the worst masa_enc gradient drops from 3.4e-4 to 9.9e-7 of its tensor maximum (every tensor <= 1.3e-6);
+    # Restormer-ref 12 of 59.0 M, 1.2e-7, 8.1e-4 -> 1.8e-6 (outside the encoder 1.2e-5: an attention temperature scalar)
+    assert frac < 1e-6 and forced.max_abs_at_flip < 1e-6, (forced.flips, forced.units, forced.max_abs_at_flip)
+    assert wf['relu_encoder'][0] < 2e-5 and wf['other'][0] < 1e-4, wf
 
 
 def test_full_size_forward_against_oracle(world, monkeypatch):
