@@ -895,19 +895,39 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
 // many partial rows (the fused NAFBlock backward kernels emit one per 64 pixels: 16384 at 512 x 512, N = 4): a first stage
 // folds them 256-to-1 with a grid wide enough to fill the chip -- the single-stage kernel is only C / 64 x 2 workgroups.
 // part [nparts][2][C] -> mid [S][2][C], S = ceil(nparts / 256); row s sums rows s*256 .. in order (deterministic).
+// Narrow rows (C2 = 64 / 128: the C = 32 / 64 levels, where the partial rows are most numerous) would leave 3 / 4 or 1 / 2 of the block's
+// threads idle with 256 serial row reads each: there the block's 256 rows are cut into SL = 256 / C2 slices, one per thread group, and the
+// slice sums are combined through LDS in slice order (still a fixed order: deterministic).  32 -> ~10 us per launch at C = 32.
 __global__ __launch_bounds__(256) void pair_fold_partials_kernel(const float* __restrict__ part, int nparts, int C2,
                                                                 float* __restrict__ mid) {
-    const int e = blockIdx.x * 256 + threadIdx.x;            // element of the [2][C] row
-    if (e >= C2) return;
-    const int r0 = blockIdx.y * 256, r1 = min(r0 + 256, nparts);
+    __shared__ float red[256];
+    const int SL = C2 >= 256 ? 1 : 256 / C2;                 // (C2 is a power of two below 256 on this path, or >= 256)
+    const int el = SL > 1 ? (int)threadIdx.x % C2 : (int)threadIdx.x, sl = SL > 1 ? (int)threadIdx.x / C2 : 0;
+    const int e = SL > 1 ? el : blockIdx.x * 256 + el;       // element of the [2][C] row
+    const bool live = e < C2 && sl < SL;
+    const int per = 256 / SL;
+    const int r0 = blockIdx.y * 256 + sl * per, r1 = min(r0 + per, nparts);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = r0;
-    for (; r + 3 < r1; r += 4) {
-        s0 += part[(long)r * C2 + e]; s1 += part[(long)(r + 1) * C2 + e];
-        s2 += part[(long)(r + 2) * C2 + e]; s3 += part[(long)(r + 3) * C2 + e];
+    if (live) {
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            s0 += part[(long)r * C2 + e]; s1 += part[(long)(r + 1) * C2 + e];
+            s2 += part[(long)(r + 2) * C2 + e]; s3 += part[(long)(r + 3) * C2 + e];
+        }
+        for (; r < r1; ++r) s0 += part[(long)r * C2 + e];
     }
-    for (; r < r1; ++r) s0 += part[(long)r * C2 + e];
-    mid[(long)blockIdx.y * C2 + e] = (s0 + s1) + (s2 + s3);
+    const float t = (s0 + s1) + (s2 + s3);
+    if (SL == 1) {
+        if (live) mid[(long)blockIdx.y * C2 + e] = t;
+        return;
+    }
+    red[threadIdx.x] = live ? t : 0.f;
+    __syncthreads();
+    if (sl == 0 && e < C2) {
+        float a = 0.f;
+        for (int q = 0; q < SL; ++q) a += red[q * C2 + el];
+        mid[(long)blockIdx.y * C2 + e] = a;
+    }
 }
 
 extern "C" int64_t tdr_pair_sum_mid_floats(int nparts, int C) { return nparts > 1024 ? (int64_t)tdr_cdiv(nparts, 256) * 2 * C : 0; }
