@@ -911,7 +911,7 @@ def _main_body(a, world, rank, local, enc):
                             'the backward pass on gradients scaled by an exact power of two (dpred ~ 2^9, removed when the parameter '
                             'gradients are gathered); the 3x3 ResidualBlock convolutions of the MASA encoder (C >= 64) read and write their '
                             'activations / gradients pre-split (csrc/tdr_conv_p16.hip: the pair IS the stored tensor there, 22-23 significant '
-                            'bits incl. the residual stream; TDR_P16=0 restores fp32 tensors + per-consumer split); '
+                            'bits incl. the residual stream; engine.P16_ON = False restores fp32 tensors + per-consumer split); '
                             'per-image correlations as 3-way bf16 split / exact fp32: measured error of the split '
                             'schemes = that of the exact fp32 MFMA chain (profiles/r1/fp16x2_probe_mi355x.log, bf16x3_probe_mi355x.log, '
                             'grad_range_survey_cfg2.log); TDR_MATH=bx3 / f32 select the all-bf16-split / exact fp32 MFMA paths',
@@ -944,7 +944,7 @@ def _main_body(a, world, rank, local, enc):
                        'ranks_seen': ranks_seen,
                        'streams': ('2: the leaf 1x1 weight gradients of the blocks run deferred on a second HIP stream beside the MASA-encoder '
                                    'backward (engine.DEFER_WGRAD; the roofline leg times its launches on one stream)'
-                                   if a.arch in ('nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc') and world == 1 and os.environ.get('TDR_DEFER_WGRAD', '1') == '1' else '1'),
+                                   if a.arch in ('nafnet', 'restormer', 'promptir', 'drsformer', 'drsformer_mefc') and world == 1 and os.environ.get('TDR_FORCE_DP_SCHEDULE', '0') != '1' else '1'),
                        'grad_exchange': ('none' if world == 1 else
                                          (f'{len(red.buckets)} buckets of <= 64 MiB, each all-reduced on the comm stream between the segments of '
                                           f'the captured backward ({red.bucket_launches} bucket exchanges issued so far)'

@@ -120,12 +120,12 @@ def test_msfn_depthwise_on_the_stencils(shape, mult, relu, bias, Kk):
         assert float((db - br.grad).abs().max()) < 2e-5 * s * max(1.0, float(br.grad.abs().max()) / s)
     if Kk != 3:
         return
-    os.environ['TDR_DWK_GENERIC'] = '1'              # the LDS-tiled generic kernels of tdr_dwk.hip agree
+    K.DWK_GENERIC = True                             # the LDS-tiled generic kernels of tdr_dwk.hip agree
     try:
         y2 = K.dwk_fwd(x, w, b, relu=relu)
         dx2, dw2, _ = K.dwk_bwd(dy, y2 if relu else None, x, w, want_db=bias)
     finally:
-        os.environ.pop('TDR_DWK_GENERIC')
+        K.DWK_GENERIC = False
     assert float((y - y2).abs().max()) < 2e-5 and float((dx - dx2).abs().max()) < 5e-5
     assert float((dw - dw2).abs().max()) < 2e-5 * s * max(1.0, float(wr.grad.abs().max()) / s)
 

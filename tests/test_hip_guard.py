@@ -186,7 +186,7 @@ def test_hx2_full_range_fallback_keeps_the_verdict(monkeypatch, hx2_mode):
     from textualdegremoval_amd.models import create_model
     assert K.MATH == 'hx2'
     monkeypatch.setenv('TDR_GRAPH', '0')
-    monkeypatch.setenv('TDR_RANGE_CHECK', '0')                      # between two surveys
+    monkeypatch.setenv('TDR_RANGE_CHECK_EVERY', '0')                # between two surveys (0 = no survey steps)
     model = create_model(make_opt())
     model._bwd_full_range = True
     lq, gt, ref = O.synth_pair(1, 128, 128, seed=7)

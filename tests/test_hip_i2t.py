@@ -284,8 +284,7 @@ def test_clip_split_k_linears_match_the_single_launch(K):
     sd = IO.synth_clip_params(1024, 2048, 2, 14, 56, seed=9)          # cin 1024 / 2048 -> cout 1024: the split-K rule applies
     x = torch.rand(2, 3, 56, 56, generator=torch.Generator().manual_seed(1)).cuda()
     prev = ClipVisionEncoder.SPLITK
-    os.environ['TDR_CLIP_TOK16'] = '0'                                  # the channel-major engines (the token-major path has its own test)
-    try:
+    try:                                                                # (the channel-major engines: clip_vision.TOK16 is off by default)
         ClipVisionEncoder.SPLITK = 4
         a = ClipVisionEncoder(sd, 'cuda', 16)
         assert a.W['encoder.layers.0.out'][3] is not None and a.W['encoder.layers.0.mlp.fc2'][3] is not None and a.W['encoder.layers.0.qkv'][3] is None
@@ -295,7 +294,6 @@ def test_clip_split_k_linears_match_the_single_launch(K):
         yb, _ = b.tokens(x, flat=True)
     finally:
         ClipVisionEncoder.SPLITK = prev
-        del os.environ['TDR_CLIP_TOK16']
     ref = IO.clip_vision_tokens(sd, x.cpu(), 16)
     scale = ref.abs().max().item()
     assert maxdiff(ya, yb) < 1e-5 * scale
@@ -344,11 +342,12 @@ def test_clip_token_major_planes_match_the_channel_major_engines(K, hidden, inte
     from textualdegremoval_amd.clip_vision import ClipVisionEncoder
     sd = IO.synth_clip_params(hidden, inter, 2, 14, 56, seed=hidden)
     x = torch.rand(3, 3, 56, 56, generator=torch.Generator().manual_seed(1))
-    os.environ['TDR_CLIP_TOK16'] = '1'                                  # opt-in path (measured neutral on the stage-A step)
+    from textualdegremoval_amd import clip_vision as _cv
+    _cv.TOK16 = True                                                    # opt-in path (measured neutral on the stage-A step)
     try:
         enc = ClipVisionEncoder(sd, 'cuda', heads, act=act)
     finally:
-        del os.environ['TDR_CLIP_TOK16']
+        _cv.TOK16 = False
     assert enc.tok16
     f, Tn = enc.tokens(x.cuda(), flat=True)
     c, _ = enc.tokens(x.cuda())                                          # per-image layout: the channel-major engines

@@ -189,7 +189,7 @@ def test_module_surface_forward_backward_and_state_dict(E):
 
 
 def test_side_stream_weight_gradients_match(E):
-    """TDR_SIDE_WGRAD: weight gradients on a parallel stream give the same results (bit-identical except where the
+    """kernels.SIDE_WGRAD: weight gradients on a parallel stream give the same results (bit-identical except where the
     MASA transfer backward accumulates with float atomics, whose order varies from run to run anyway)."""
     from textualdegremoval_amd import kernels as K
     cfg = O.default_cfg(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])

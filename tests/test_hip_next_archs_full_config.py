@@ -28,7 +28,7 @@ def _compare(engine, fwd, params, cfg, monkeypatch, unused=(), out_tol=1e-4, gra
     from textualdegremoval_amd import kernels as K
     import os
     prev = K.MATH
-    K.set_math(os.environ.get('TDR_TEST_MATH', prev))
+    K.set_math(prev)
     try:
         out, saved = engine.net_fwd(Pc, cfg, lq.cuda(), ref.cuda())
         # a FIXED cotangent instead of the L1 gradient: sign(out - gt) flips wherever the residual is within rounding of zero, and

@@ -101,7 +101,7 @@ def test_forward_overflow_switches_off_the_fp16_split_and_protects_the_weights(m
 def test_unhandled_non_finite_loss_is_loud(monkeypatch, hx2_mode):
     """with the survey disabled the same overflow must surface as an exception when the log is read"""
     model, K = _model(monkeypatch)
-    monkeypatch.setenv('TDR_RANGE_CHECK', '0')
+    monkeypatch.setenv('TDR_RANGE_CHECK_EVERY', '0')
     lq, gt, ref = O.synth_pair(1, 128, 128, seed=5)
     _step(model, 1, {'lq': lq * 1e6, 'gt': gt * 1e6, 'ref': ref * 1e6})
     with pytest.raises(FloatingPointError):

@@ -20,6 +20,8 @@ def _strip(sd):
     return {(k[len('vision_model.'):] if k.startswith('vision_model.') else k): v.detach().to(torch.float32) for k, v in sd.items()}
 
 
+TOK16 = False           # module switch: token-major fp16 planes for the frozen CLIP encoder (parity-tested, measured neutral on the stage-A step)
+
 class ClipVisionEncoder:
     def __init__(self, state_dict, device, heads, act='quick_gelu', eps=1e-5):
         """heads / act / eps: CLIPVisionConfig.num_attention_heads / hidden_act / layer_norm_eps
@@ -54,14 +56,14 @@ class ClipVisionEncoder:
             for name in ('mlp.fc1', 'mlp.fc2'):
                 w = sd[p + name + '.weight']
                 self._pack(p + name, w.reshape(w.shape[0], w.shape[1], 1, 1))
-        # Opt-in (TDR_CLIP_TOK16=1): batch-flattened passes under TDR_MATH=hx2 run the blocks token-major on pre-split fp16 planes
+        # Opt-in (clip_vision.TOK16 = True): batch-flattened passes under TDR_MATH=hx2 run the blocks token-major on pre-split fp16 planes
         # (csrc/tdr_tok16.hip, tdr_tok16x2_gemm: the same 2-way split arithmetic, operands split once by their producers and fetched
         # as 16-byte fragments).  Measured neutral on the stage-A step (ViT-H 25.5 vs 25.0 ms, ViT-L 20.0 vs 20.5 ms, same box): over
         # ~1 150 token rows both layouts run the Linears at ~140 - 200 fp32-equivalent TFLOP/s, so the channel-major engines with
         # their split-K narrow Linears stay the default.
         inter = sd['encoder.layers.0.mlp.fc1.weight'].shape[0]
         self.tok16 = (K.MATH == 'hx2' and self.D % 128 == 0 and inter % 128 == 0 and self.D <= 1280
-                      and __import__('os').environ.get('TDR_CLIP_TOK16', '0') == '1')
+                      and TOK16)
         if self.tok16:
             self.W2 = {}
             for i in range(self.depth):
@@ -77,7 +79,7 @@ class ClipVisionEncoder:
     # work).  Their K chunks run as the "images" of ONE launch (input [1, K, .] viewed as [S, K/S, .], per-chunk packs via wp_ns) and
     # tdr_splitk_finish applies bias / residual / activation to the summed partials (profiles/probe_splitk_1x1.py: 49 -> 33 us and
     # 165 -> 65 us per launch with warm weights).  Batch-flattened layout only (the image axis is what carries the chunks).
-    SPLITK = int(__import__('os').environ.get('TDR_CLIP_SPLITK', '4'))
+    SPLITK = 4
 
     def _pack(self, key, w4):
         cout, cin = w4.shape[0], w4.shape[1]

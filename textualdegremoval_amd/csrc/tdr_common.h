@@ -34,6 +34,16 @@ int tdr_conv_forward_bx3(const TdrConvDesc* d, void* stream);   // tdr_conv_bx3.
 
 static inline int tdr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Launch-heuristic tuning / A-B switches (tile configurations, workgroup targets, ring depths, measurement forms of a kernel) exist only in
+// TUNING builds of the library (`make -C csrc variant VFILE=<file> VFLAGS=-DTDR_TUNING_KNOBS VOUT=...`): the shipped library reads none of
+// them -- every call returns "unset" and the heuristic's default stands.  tdr_tuning_build() tells a caller which kind it has loaded.
+#include <stdlib.h>
+#ifdef TDR_TUNING_KNOBS
+static inline const char* tdr_tune_env(const char* name) { return getenv(name); }
+#else
+static inline const char* tdr_tune_env(const char*) { return nullptr; }
+#endif
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 

@@ -558,9 +558,9 @@ int launch_c1_hx2(const ConvArgs& a, int N, hipStream_t st) {
 // workgroups of 256->256 @128x128 87 -> 96 us: with 64 KiB of LDS only two workgroups share a CU, and the many-round
 // launches want the four or five of the 16-channel pipeline of conv_bx3_kernel)
 inline bool c1_hx2_ok(const ConvArgs& a, int npx, int bm, int N) {
-    static const bool off = getenv("TDR_C1_OLD") != nullptr;
-    static const int min_stages = getenv("TDR_C1_STAGES") ? atoi(getenv("TDR_C1_STAGES")) : 4;
-    static const long max_blocks = getenv("TDR_C1_BLOCKS") ? atol(getenv("TDR_C1_BLOCKS")) : 512;
+    static const bool off = tdr_tune_env("TDR_C1_OLD") != nullptr;
+    static const int min_stages = tdr_tune_env("TDR_C1_STAGES") ? atoi(tdr_tune_env("TDR_C1_STAGES")) : 4;
+    static const long max_blocks = tdr_tune_env("TDR_C1_BLOCKS") ? atol(tdr_tune_env("TDR_C1_BLOCKS")) : 512;
     const int ks = 8192 / npx;
     const long blocks = (long)tdr_cdiv((long)a.OH * a.OW, npx) * tdr_cdiv(a.Cout, bm) * N;
     return !off && blocks <= max_blocks && (a.Cin + ks - 1) / ks >= min_stages && a.pad == 0 && a.W % 4 == 0 && a.in_ns % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
@@ -580,7 +580,7 @@ int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
     ConvArgs b = a;
     // short K loops (<= 2 channel groups) of the 3x3 kernels: one LDS buffer instead of two halves the 65 KB footprint, so
     // four workgroups instead of two share a CU and hide each other's load / store latencies (tuning aid: TDR_BX_SINGLE)
-    static const int single_env = getenv("TDR_BX_SINGLE") ? atoi(getenv("TDR_BX_SINGLE")) : 2;
+    static const int single_env = tdr_tune_env("TDR_BX_SINGLE") ? atoi(tdr_tune_env("TDR_BX_SINGLE")) : 2;
     b.single_buf = (KH == 3 && (a.Cin + 15) / 16 <= single_env) ? 1 : 0;
     size_t lds = (size_t)(b.single_buf ? 1 : 2) * (2 * NS) * LH * LW * 16;
     if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);   // the vector epilogue's four wave-private 32 x 36 patches
@@ -593,8 +593,8 @@ int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
     // Same-box step 59.1 -> 58.4 ms: 32 -> 32 @512^2 216 -> 196 us, 128 -> 128 @128^2 145 -> 129 us, 64 -> 64 @256^2 unchanged
     // (profiles/r3/tried_and_dropped.txt has the counterpart experiments); TDR_RING3=0 restores the double-buffered fragments.
     if constexpr (KH == 3 && S == 1 && SCH == SCH_HX2 && EPI == EPI_STD && !GATE) {
-        static const int ring3 = getenv("TDR_RING3") ? atoi(getenv("TDR_RING3")) : 1;
-        static const long ring_blocks3 = getenv("TDR_RING_BLOCKS") ? atol(getenv("TDR_RING_BLOCKS")) : 512;
+        static const int ring3 = tdr_tune_env("TDR_RING3") ? atoi(tdr_tune_env("TDR_RING3")) : 1;
+        static const long ring_blocks3 = tdr_tune_env("TDR_RING_BLOCKS") ? atol(tdr_tune_env("TDR_RING_BLOCKS")) : 512;
         if (ring3 && ((long)grid.x * N > ring_blocks3 || TM != 1)) {
             auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE, SCH, 3>;
             static bool attr_set = false;
@@ -608,7 +608,7 @@ int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
         }
     }
     if constexpr (KH == 3 && S == 1 && TM == 1 && SCH == SCH_HX2 && EPI == EPI_STD) {   // weight-fragment ring: single-round launches
-        static const long ring_blocks = getenv("TDR_RING_BLOCKS") ? atol(getenv("TDR_RING_BLOCKS")) : 512;
+        static const long ring_blocks = tdr_tune_env("TDR_RING_BLOCKS") ? atol(tdr_tune_env("TDR_RING_BLOCKS")) : 512;
         if ((long)grid.x * N <= ring_blocks) {
             auto kern = conv_bx3_kernel<KH, S, WM, TM, TN, EPI, GATE, SCH, 9>;
             static bool attr_set = false;
@@ -633,7 +633,7 @@ int launch_bx_cfg_s(const ConvArgs& a, int N, hipStream_t st) {
 }
 
 // tile-configuration override for profiles/autotune_conv.py: [0] 1x1 kernels, [1] 3x3 / 2x2 kernels; 0 = heuristic
-int g_force_cfg[2] = {getenv("TDR_BX_CFG1") ? atoi(getenv("TDR_BX_CFG1")) : 0, getenv("TDR_BX_CFG3") ? atoi(getenv("TDR_BX_CFG3")) : 0};
+int g_force_cfg[2] = {tdr_tune_env("TDR_BX_CFG1") ? atoi(tdr_tune_env("TDR_BX_CFG1")) : 0, tdr_tune_env("TDR_BX_CFG3") ? atoi(tdr_tune_env("TDR_BX_CFG3")) : 0};
 
 template <int KH, int S, int WM, int TM, int TN, int EPI, bool GATE>
 int launch_bx_cfg(const ConvArgs& a, int N, hipStream_t st) {

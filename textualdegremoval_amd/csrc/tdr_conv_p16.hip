@@ -694,7 +694,7 @@ int launch_p16_thin(const P16Args& a0, int N, hipStream_t st) {
     const int ngroups = a.Cin >> 4;
     const long ntiles = (long)a.tiles_x * a.tiles_y * N;
     const size_t lds = (size_t)(2 * BREG + ngroups * 9 * 128) * 16;
-    static const int wgs = getenv("TDR_P16_THIN_WGS") ? atoi(getenv("TDR_P16_THIN_WGS")) : 512;      // 2 resident workgroups x 256 CUs
+    static const int wgs = tdr_tune_env("TDR_P16_THIN_WGS") ? atoi(tdr_tune_env("TDR_P16_THIN_WGS")) : 512;      // 2 resident workgroups x 256 CUs
     const int grid = (int)(ntiles < wgs ? ntiles : wgs);
     auto kern = conv3x3_p16_thin_kernel<TN, ABL>;
     static bool attr_set = false;
@@ -820,7 +820,7 @@ int launch_p16_thin8(const P16Args& a0, int N, hipStream_t st) {
     a.mtiles = 1;
     const long ntiles = (long)a.tiles_x * a.tiles_y * N;
     const size_t lds = (size_t)(4 * BREG) * 16;
-    static const int wgs = getenv("TDR_P16_THIN8_WGS") ? atoi(getenv("TDR_P16_THIN8_WGS")) : 256;      // one resident workgroup per CU
+    static const int wgs = tdr_tune_env("TDR_P16_THIN8_WGS") ? atoi(tdr_tune_env("TDR_P16_THIN8_WGS")) : 256;      // one resident workgroup per CU
     const int grid = (int)(ntiles < wgs ? ntiles : wgs);
     auto kern = conv3x3_p16_thin8_kernel<TN, ABL>;
     static bool attr_set = false;
@@ -945,13 +945,13 @@ extern "C" int tdr_p16_to_f32(const void* src, int N, int C, int H, int W, float
 }
 
 static int p16_env_cfg() {
-    const int c = getenv("TDR_P16_CFG") ? atoi(getenv("TDR_P16_CFG")) : 0;
-    return (((c >= 100 && c < 300) || c >= 400) && !getenv("TDR_PROBES")) ? 0 : c;
+    const int c = tdr_tune_env("TDR_P16_CFG") ? atoi(tdr_tune_env("TDR_P16_CFG")) : 0;
+    return (((c >= 100 && c < 300) || c >= 400) && !tdr_tune_env("TDR_PROBES")) ? 0 : c;
 }
 static int g_p16_cfg = p16_env_cfg();
 extern "C" int tdr_conv3x3_p16_force_cfg(int cfg) {
     // 100 .. 299 are timing ablations that compute WRONG results (profiles/probe_conv_p16.py): never reachable from a product process
-    static const bool probes = getenv("TDR_PROBES") != nullptr;
+    static const bool probes = tdr_tune_env("TDR_PROBES") != nullptr;
     TDR_REQUIRE(probes || cfg < 100 || (cfg >= 300 && cfg < 400), "tdr_conv3x3_p16_force_cfg: configuration %d is a timing ablation (set TDR_PROBES=1)", cfg);
     g_p16_cfg = cfg;
     return TDR_OK;

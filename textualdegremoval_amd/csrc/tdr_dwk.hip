@@ -508,7 +508,7 @@ extern "C" int tdr_dwk_bwd(const float* dy, int64_t dy_ns, const float* yact, in
 
 // accumulate != 0: dx += (one-pass 5x5 kernel only; tdr_dwk_bwd_can_accumulate tells whether these arguments take it)
 extern "C" int tdr_dwk_bwd_can_accumulate(int W, int K, int dil, int64_t dy_ns, int64_t y_ns, int64_t x_ns, int64_t dx_ns) {
-    return K == 5 && dil == 1 && W % 4 == 0 && ((dy_ns | y_ns | x_ns | dx_ns) & 3) == 0 && getenv("TDR_DWK_TILED") == nullptr;
+    return K == 5 && dil == 1 && W % 4 == 0 && ((dy_ns | y_ns | x_ns | dx_ns) & 3) == 0 && tdr_tune_env("TDR_DWK_TILED") == nullptr;
 }
 
 extern "C" int tdr_dwk_bwd_acc(const float* dy, int64_t dy_ns, const float* yact, int64_t y_ns, const float* x, int64_t x_ns,
@@ -519,7 +519,7 @@ extern "C" int tdr_dwk_bwd_acc(const float* dy, int64_t dy_ns, const float* yact
     hipStream_t st = (hipStream_t)stream;
     const int tiles_x = tdr_cdiv(W, TW_), tiles_y = tdr_cdiv(H, TH_), tiles = tiles_x * tiles_y;
     const int tpb = 8, wtiles = tiles_x * tdr_cdiv(tiles_y, tpb);                          // weight-gradient workgroups per plane
-    static const bool tiled_only = getenv("TDR_DWK_TILED") != nullptr;                     // A/B aid: the two-kernel backward
+    static const bool tiled_only = tdr_tune_env("TDR_DWK_TILED") != nullptr;                     // A/B aid: the two-kernel backward
     if (K == 5 && dil == 1 && W % 4 == 0 && !tiled_only && ((dy_ns | y_ns | x_ns | dx_ns) & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
           reinterpret_cast<uintptr_t>(yact)) & 15) == 0) {

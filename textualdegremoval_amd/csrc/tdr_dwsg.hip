@@ -504,7 +504,7 @@ DwGeom dw_geom(int H, int W) {
 DwGeom dw_geom_fused(int H, int W) {
     DwGeom g = dw_geom(H, W);
     const int spb = 256 >> g.tprw_log2;
-    static const int cap = getenv("TDR_DWF_RPT") ? atoi(getenv("TDR_DWF_RPT")) : 16;     // tuning aid
+    static const int cap = tdr_tune_env("TDR_DWF_RPT") ? atoi(tdr_tune_env("TDR_DWF_RPT")) : 16;     // tuning aid
     int rpt = tdr_cdiv(H, spb);
     if (rpt > cap) rpt = cap;
     if (rpt < 1) rpt = 1;

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * KL) void pair_sum_partials_kernel(const float*
 }
 
 constexpr int LN_BWD_GRID = 1024;     // workspace rows (upper bound of the persistent grid)
-static const int ln_bwd_grid = getenv("TDR_LN_BWD_GRID") ? atoi(getenv("TDR_LN_BWD_GRID")) : 256;
+static const int ln_bwd_grid = tdr_tune_env("TDR_LN_BWD_GRID") ? atoi(tdr_tune_env("TDR_LN_BWD_GRID")) : 256;
 constexpr int LN_GEN_SPLITS = 16;
 
 // ===========================================================================
@@ -867,9 +867,9 @@ extern "C" int tdr_layernorm2d_bwd(const float* go, const float* x, int64_t x_ns
         else LN_BWD(8, 16);
 #undef LN_BWD
     } else {
-        static const bool fuse = getenv("TDR_LN_NOFUSE") == nullptr;
+        static const bool fuse = tdr_tune_env("TDR_LN_NOFUSE") == nullptr;
         if (tiles <= LN_BWD_GRID && fuse) {   // the workspace holds LN_BWD_GRID partial rows: one per 64-pixel block
-            static const bool cached = getenv("TDR_LN_NOCACHE") == nullptr;
+            static const bool cached = tdr_tune_env("TDR_LN_NOCACHE") == nullptr;
 #define LN_BWDC(P) hipLaunchKernelGGL(ln_bwd_cached_kernel<P>, dim3(tdr_cdiv(HW, 64), N), dim3(1024), 0, st, go, x, (long)x_ns, mu, rstd, w, add, (long)add_ns, add_C, center, C, HW, gx, ws)
             if (cached && C <= 256) LN_BWDC(16);
             else if (cached && C <= 512) LN_BWDC(32);
@@ -963,7 +963,7 @@ extern "C" int tdr_sca_bwd(const float* G3, const float* S3, const float* w3, co
                 "tdr_sca_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     float* ds = ws;          // [N][C]
-    static const bool split4 = getenv("TDR_SCA_SPLIT") != nullptr;     // the four separate launches (reference for the merged pair)
+    static const bool split4 = tdr_tune_env("TDR_SCA_SPLIT") != nullptr;     // the four separate launches (reference for the merged pair)
     if (split4) {
         hipLaunchKernelGGL(sca_bwd_rows_kernel, dim3(C), dim3(256), 0, st, G3, S3, w3, b3, beta, s, N, C, dw3, db3, dbeta);
         hipLaunchKernelGGL(sca_bwd_ds_kernel, dim3(tdr_cdiv(C, 64), N), dim3(1024), 0, st, G3, w3, beta, N, C, ds);

@@ -492,7 +492,7 @@ extern "C" int tdr_tok16x3_gemm(const void* x16x3, const void* w16x3, const floa
                 "tdr_tok16x3_gemm: epilogue %d (act %d) lacks its output", epi, act);
     TokGemmArgs a{(const _Float16*)x16x3, (const _Float16*)w16x3, bias, ls, (long)P, N, K, N / BN, (_Float16*)y16x3, out32};
     hipStream_t st = (hipStream_t)stream;
-    static const int deep = getenv("TDR_TOK3_STAGE") ? atoi(getenv("TDR_TOK3_STAGE")) : 2;
+    static const int deep = tdr_tune_env("TDR_TOK3_STAGE") ? atoi(tdr_tune_env("TDR_TOK3_STAGE")) : 2;
     const bool wide = (long)tdr_cdiv(P, 64) * (N / BN) > 512;
     const int cfg = wide ? (deep == 2 ? 3 : (deep >= 3 ? deep + 1 : (deep ? 1 : 0))) : 2;
 #define TOK_X3(EPI_, ACT_)                                                               \

@@ -675,7 +675,7 @@ static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st, 
         return TDR_OK;
     }
     if ((math == 2 || math == 3) && (hd == 80 || hd == 64 || hd == 32 || hd == 16)) {
-        static const int kt = getenv("TDR_ATTN_KT") ? atoi(getenv("TDR_ATTN_KT")) : 32;       // key tile (tuning aid)
+        static const int kt = tdr_tune_env("TDR_ATTN_KT") ? atoi(tdr_tune_env("TDR_ATTN_KT")) : 32;       // key tile (tuning aid)
         if (hd == 80) hipLaunchKernelGGL((attn_fwd_hx2_kernel<80, 32>), grid, dim3(256), 0, st, a);
         else if (hd == 64 && kt == 64) hipLaunchKernelGGL((attn_fwd_hx2_kernel<64, 64>), grid, dim3(256), 0, st, a);
         else if (hd == 64) hipLaunchKernelGGL((attn_fwd_hx2_kernel<64, 32>), grid, dim3(256), 0, st, a);

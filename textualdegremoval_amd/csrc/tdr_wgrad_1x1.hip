@@ -507,12 +507,12 @@ int g1_sp() {
     // there a 512-thread / 96 KiB workgroup shares a CU with nothing: the overlap that is worth 2.6 ms with a 256-thread / 64 KiB
     // kernel shrinks to 1.1 ms (68.3 -> 69.4 ms same box, profiles/r5/sweep_e.log).  The 4-wave form keeps the footprint of the
     // LDS-DMA kernel (256 threads, 49 KiB) and its overlap: 67.63 -> 67.31 ms (sweep_g.log).
-    static const int v = getenv("TDR_WG1_SP") ? atoi(getenv("TDR_WG1_SP")) : 2;
+    static const int v = tdr_tune_env("TDR_WG1_SP") ? atoi(tdr_tune_env("TDR_WG1_SP")) : 2;
     return v;
 }
 
 int g1_ring() {
-    static const int r = getenv("TDR_WG1_RING") ? atoi(getenv("TDR_WG1_RING")) : 2;
+    static const int r = tdr_tune_env("TDR_WG1_RING") ? atoi(tdr_tune_env("TDR_WG1_RING")) : 2;
     return r == 3 ? 3 : 2;
 }
 
@@ -554,7 +554,7 @@ struct G1Tile { int tmw, tnw; };
 // counts fill them -- half the split VALU and half the operand fetches per MFMA, but one wave per SIMD (16 accumulator tiles): measured
 // SLOWER in the step (64.4 -> 64.9 / 65.5 ms same box, profiles/r5/sweep_o.log), so opt-in
 G1Tile g1_group_tile(const TdrWgradDesc* d) {
-    static const bool big = getenv("TDR_WG1_GRP_BIG") && atoi(getenv("TDR_WG1_GRP_BIG")) == 1;
+    static const bool big = tdr_tune_env("TDR_WG1_GRP_BIG") && atoi(tdr_tune_env("TDR_WG1_GRP_BIG")) == 1;
     G1Tile t;
     t.tmw = (big && d->Cout >= 256 && d->Cin > 64) ? 4 : 2;
     t.tnw = d->Cin <= 64 ? 1 : ((t.tmw == 4 && d->Cin >= 256) ? 4 : 2);      // (instantiated: 4x4, 4x2, 2x2, 2x1)
@@ -569,7 +569,7 @@ G1GroupPlan g1_group_plan(const TdrWgradDesc* d, int nprob) {
     const long tiles = (long)tdr_cdiv(d->Cout, 64 * tl.tmw) * tdr_cdiv(d->Cin, 64 * tl.tnw);
     // one image per workgroup unless that leaves the chip short of workgroups (few problems / few tiles): then split the images,
     // never below 8 stages per workgroup
-    static const long want = getenv("TDR_WG1_GRP_WANT") ? atol(getenv("TDR_WG1_GRP_WANT")) : 512;      // (256 / 512 / 1024 / 2048: 67.06 / 67.12 / 67.33 / 67.39 ms per step, profiles/r5/sweep_k.log)
+    static const long want = tdr_tune_env("TDR_WG1_GRP_WANT") ? atol(tdr_tune_env("TDR_WG1_GRP_WANT")) : 512;      // (256 / 512 / 1024 / 2048: 67.06 / 67.12 / 67.33 / 67.39 ms per step, profiles/r5/sweep_k.log)
     long spi = 1;
     while ((long)nprob * d->N * spi * tiles < want && p.tpi / (spi * 2) >= 8) spi *= 2;
     p.tps = tdr_cdiv(p.tpi, spi);
@@ -583,7 +583,7 @@ int launch_grp(const WgArgs& a, int nprob, hipStream_t st) {
     constexpr int NS = SCH == G1_BX3 ? 3 : 2;
     constexpr size_t lds0 = (size_t)2 * (NS * (64 * TMW + 64 * TNW) * 32 + 64);
     // TDR_WG1_GRP_LDS: pad the LDS request (bytes) to cap the workgroups resident per CU (tuning aid: fewer pairs in flight per XCD L2)
-    static const size_t pad = getenv("TDR_WG1_GRP_LDS") ? (size_t)atol(getenv("TDR_WG1_GRP_LDS")) : 0;
+    static const size_t pad = tdr_tune_env("TDR_WG1_GRP_LDS") ? (size_t)atol(tdr_tune_env("TDR_WG1_GRP_LDS")) : 0;
     const size_t lds = lds0 < pad ? pad : lds0;
     const int T = a.tiles_x * a.tiles_y;
     dim3 grid((unsigned)tdr_cdiv(a.grp_pairs, 8) * 8 * T);
@@ -653,7 +653,7 @@ namespace {
 
 // 1x1 / stride 1 / pad 0 on a split scheme, rows of whole 32-pixel stages, channel counts that fill whole 64-row tiles
 bool tdr_wgrad_1x1_supported(const TdrWgradDesc* d) {
-    static const bool off = getenv("TDR_WG1") && atoi(getenv("TDR_WG1")) == 0;     // A/B aid: 0 = the staged kernel of rounds 1-4
+    static const bool off = tdr_tune_env("TDR_WG1") && atoi(tdr_tune_env("TDR_WG1")) == 0;     // A/B aid: 0 = the staged kernel of rounds 1-4
     if (off || (d->math != 1 && d->math != 2)) return false;
     if (d->KH != 1 || d->stride != 1 || d->pad != 0 || d->H != d->OH || d->W != d->OW) return false;
     const long HW = (long)d->OH * d->OW;
@@ -673,7 +673,7 @@ WgPlan tdr_wgrad_1x1_plan(const TdrWgradDesc* d) {
     p.tpi = p.tiles_x;                                           // "tiles" = 32-pixel stages of the flattened image
     const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
     // bx3: 256 blocks (one per CU; half the split-K partials: 68.66 -> 68.24 ms per step same box, profiles/r5/sweep_c.log); hx2: one round of 2 per CU
-    static const long want_env = getenv("TDR_WG1_WANT") ? atol(getenv("TDR_WG1_WANT")) : 0;
+    static const long want_env = tdr_tune_env("TDR_WG1_WANT") ? atol(tdr_tune_env("TDR_WG1_WANT")) : 0;
     const long want_total = want_env > 0 ? want_env : (d->math == 1 ? 256 : 512);
     long want = want_total / out_tiles;
     if (want < 1) want = 1;

@@ -512,7 +512,7 @@ WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d) {
     WgPlan p;
     p.tw_log2 = d->OW >= 24 ? 5 : (d->OW >= 12 ? 4 : 3);
     if (d->KH == 1) {
-        static const int force1 = getenv("TDR_WGB_CFG1X1") ? atoi(getenv("TDR_WGB_CFG1X1")) : -1;   // tuning aid: 0 | 1 | 5
+        static const int force1 = tdr_tune_env("TDR_WGB_CFG1X1") ? atoi(tdr_tune_env("TDR_WGB_CFG1X1")) : -1;   // tuning aid: 0 | 1 | 5
         if (force1 >= 0 && d->Cout >= 64 && d->Cin >= 64) p.cfg = force1;
         else if (d->Cout > 64 && d->Cin > 64) p.cfg = 0;
         else if (d->Cin <= 32 && d->Cout <= 32) p.cfg = 2;
@@ -534,7 +534,7 @@ WgPlan tdr_wgrad_bx3_plan(const TdrWgradDesc* d) {
     // split-K so that ONE round of blocks fills the chip (2 resident workgroups x 256 CUs): 768 (1.5 rounds) leaves a
     // half-empty tail round on every launch -- 94.7 vs 90.4 ms per cfg2 step; TDR_WG_WANT overrides (tuning aid)
     // (3-way bf16 split, round 5: 256 -- a block's matrix phase is twice as long there, half the split-K partials win: 68.8 -> 68.2 ms same box)
-    static const long want_env = getenv("TDR_WG_WANT") ? atol(getenv("TDR_WG_WANT")) : 0;
+    static const long want_env = tdr_tune_env("TDR_WG_WANT") ? atol(tdr_tune_env("TDR_WG_WANT")) : 0;
     const long want_total = want_env > 0 ? want_env : (d->math == 1 ? 256 : 512);
     long want = want_total / out_tiles;
     if (want < 1) want = 1;

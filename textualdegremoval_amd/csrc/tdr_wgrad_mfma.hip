@@ -308,7 +308,7 @@ extern "C" int tdr_conv_wgrad(const TdrWgradDesc* d, void* stream) {
     int rc = TDR_ERR_UNSUPPORTED;
     const int key = d->KH * 10 + d->stride;
     a.scheme = d->math == 3 ? 2 : (d->math == 2 ? 1 : 0);   // 3: plain fp16 (TDR_MATH=h1)
-    static const bool dbg = getenv("TDR_WG_DEBUG") != nullptr;   // which shapes miss the split kernel
+    static const bool dbg = tdr_tune_env("TDR_WG_DEBUG") != nullptr;   // which shapes miss the split kernel
     if (dbg && !(d->math >= 1 && tdr_wgrad_bx3_supported(d)) && !tdr_wgrad_s2_supported(d))
         fprintf(stderr, "[tdr] exact wgrad: math %d N %d %d->%d @%dx%d k%d s%d pad %d gate %d per_image %d in_ns %ld dout_ns %ld\n", d->math,
                 d->N, d->Cin, d->Cout, d->H, d->W, d->KH, d->stride, d->pad, d->gate, d->per_image, (long)d->in_ns, (long)d->dout_ns);

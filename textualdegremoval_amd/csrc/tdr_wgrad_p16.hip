@@ -281,7 +281,7 @@ WgP16Plan wgp_plan(const TdrWgradP16Desc* d) {
     const int rs = p.cfg == 1 ? 2 : 1;
     p.strips = tdr_cdiv(d->W, 32);
     const long out_tiles = (long)tdr_cdiv(d->Cout, p.bm) * tdr_cdiv(d->Cin, p.bn);
-    static const long want_total = getenv("TDR_WGP_WANT") ? atol(getenv("TDR_WGP_WANT")) : 512;
+    static const long want_total = tdr_tune_env("TDR_WGP_WANT") ? atol(tdr_tune_env("TDR_WGP_WANT")) : 512;
     long want = want_total / out_tiles;
     if (want < 1) want = 1;
     const long rows = (long)d->N * p.strips * d->H;

@@ -373,7 +373,7 @@ int launch_s2(const WgArgs& a, const WgPlan& p, int N, hipStream_t st) {
 }  // namespace
 
 bool tdr_wgrad_s2_supported(const TdrWgradDesc* d) {
-    static const bool off = getenv("TDR_WG_S2") && atoi(getenv("TDR_WG_S2")) == 0;   // A/B aid: 0 = exact-fp32 kernel as before
+    static const bool off = tdr_tune_env("TDR_WG_S2") && atoi(tdr_tune_env("TDR_WG_S2")) == 0;   // A/B aid: 0 = exact-fp32 kernel as before
     if (off || d->math < 1 || d->gate) return false;
     if (d->stride != 2 || !((d->KH == 3 && d->pad == 1) || (d->KH == 2 && d->pad == 0))) return false;
     if (d->H != 2 * d->OH || d->W != 2 * d->OW || d->OW < 8 || d->OW % 4 != 0) return false;
@@ -393,7 +393,7 @@ WgPlan tdr_wgrad_s2_plan(const TdrWgradDesc* d) {
     p.tpi = p.tiles_x * p.tiles_y;
     const long out_tiles = (long)tdr_cdiv(d->Cout, p.BMc) * tdr_cdiv(d->Cin, p.BNc);
     // one round of blocks: one 12-wave workgroup (125 KB of LDS) per CU, or two of the 6-wave workgroups of the Cin <= 32 variant (73 KB)
-    static const long want_env = getenv("TDR_WG_S2_WANT") ? atol(getenv("TDR_WG_S2_WANT")) : 0;
+    static const long want_env = tdr_tune_env("TDR_WG_S2_WANT") ? atol(tdr_tune_env("TDR_WG_S2_WANT")) : 0;
     const long want_total = want_env > 0 ? want_env : ((p.BNc == 32 && d->math != 1) ? 512 : 256);     // (three planes: 94 - 109 KB, one workgroup per CU)
     long want = want_total / out_tiles;
     if (want < 1) want = 1;

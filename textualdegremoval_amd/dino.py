@@ -19,18 +19,24 @@ from .kernels import PACK_FWD
 LN_EPS = 1e-6
 
 
+# module switches (tests and A/B runs set them; not environment knobs)
+LINEAR_MATH = None      # arithmetic of the matcher's Linears when it should differ from kernels.MATH
+TOK16 = True            # token-major fp16 pipeline under the fp16 arithmetics (csrc/tdr_tok16.hip)
+TOK16X3 = False         # token-major bf16 triple planes at the default arithmetic: built, parity-tested, measured neutral (profiles/r5)
+FLAT = True             # batch-flattened token layout
+
 class DinoMatcher:
     def __init__(self, state_dict, device, patch=14, heads=12, interpolate_offset=0.1, linear_math=None):
-        """linear_math: arithmetic of the frozen Linears and of the attention (TDR_DINO_MATH overrides; default: kernels.MATH,
+        """linear_math: arithmetic of the frozen Linears and of the attention (dino.LINEAR_MATH overrides; default: kernels.MATH,
         i.e. the fp32-faithful 2-way fp16 split under TDR_MATH=hx2).  'h1' runs them as ONE fp16 MFMA product per operand pair
         (11-bit operands, fp32 accumulate; the token-major pipeline of csrc/tdr_tok16.hip) instead of the 3 of the split: nothing
         but an arg-max over window similarities leaves this sub-graph, so it is admissible exactly as long as that
         index does not move.  That is pinned on the reference goldens and on a sweep with random-init weights
         (tests/test_hip_dino.py), NOT for trained DINOv2 weights on overlapping windows, where top-1 / top-2 margins can be
-        smaller than the ~1e-3 feature error -- hence opt-in (TDR_DINO_MATH=h1, 12 - 14 ms per step faster at ref 640^2)."""
-        self.linear_math = linear_math or os.environ.get('TDR_DINO_MATH') or None
+        smaller than the ~1e-3 feature error -- hence opt-in (linear_math='h1', 12 - 14 ms per step faster at ref 640^2)."""
+        self.linear_math = linear_math or LINEAR_MATH
         if self.linear_math not in (None, 'h1', 'hx2', 'bx3', 'f32'):
-            raise ValueError(f'TDR_DINO_MATH / linear_math: {self.linear_math!r}')
+            raise ValueError(f'dino.LINEAR_MATH / linear_math: {self.linear_math!r}')
         self.tok16 = False          # set below: the token-major fp16 pipeline (csrc/tdr_tok16.hip), the same 'h1' arithmetic
         sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
         need = ['cls_token', 'pos_embed', 'patch_embed.proj.weight', 'patch_embed.proj.bias', 'norm.weight', 'norm.bias']
@@ -55,13 +61,13 @@ class DinoMatcher:
                 w = sd[p + name + '.weight']
                 self._pack(p + name, w.reshape(w.shape[0], w.shape[1], 1, 1))
         # 'h1' at ViT-B geometry (head dim 64, widths in GEMM tiles): the blocks run token-major with fp16 operands produced once
-        # (TDR_DINO_TOK16=0 keeps them on the channel-major engines)
+        # (dino.TOK16 = False keeps them on the channel-major engines)
         self.tok16 = (self.linear_math == 'h1' and self.D == 64 * heads and self.D % 128 == 0 and self.D <= 1024
-                      and os.environ.get('TDR_DINO_TOK16', '1') == '1')
+                      and TOK16)
         if self.tok16:
             self.W16 = {k: sd[k].to(device).to(torch.float16).contiguous() for k in sd if k.startswith('blocks.') and k.endswith('.weight')
                         and k.split('.')[-2] in ('qkv', 'proj', 'fc1', 'fc2')}
-        # Opt-in (TDR_DINO_TOK16X3=1): the default arithmetic ('bx3', 6 bf16 products per fp32 product) on the same token-major pipeline.
+        # Opt-in (dino.TOK16X3 = True): the default arithmetic ('bx3', 6 bf16 products per fp32 product) on the same token-major pipeline.
         # Operands travel as three bf16 planes h | m | l (x = h + m + l exactly), split ONCE by their producers (LayerNorm, GEMM epilogue,
         # the attention's output transpose) instead of once per consuming workgroup; the attention stays on tdr_attention_fwd_math (fp32
         # channel-major q / k / v written by the qkv GEMM's epilogue).  Same numbers as the channel-major engines up to summation order
@@ -71,7 +77,7 @@ class DinoMatcher:
         # matrix pipe 42 % busy, waves 64 % of their cycles in s_waitcnt) -- and the 12 attention launches (16 ms) are the same kernel in both.
         eff = self.linear_math or K.MATH
         self.tok16x3 = (eff == 'bx3' and K.MATH == 'bx3' and self.D % 128 == 0 and self.D <= 1280
-                        and os.environ.get('TDR_DINO_TOK16X3', '0') == '1' and os.environ.get('TDR_DINO_TOK16', '1') == '1')
+                        and TOK16X3 and TOK16)
         if self.tok16x3:
             self.W3 = {k: K.split_planes3(sd[k].to(device)) for k in sd if k.startswith('blocks.') and k.endswith('.weight')
                        and k.split('.')[-2] in ('qkv', 'proj', 'fc1', 'fc2')}
@@ -186,7 +192,7 @@ class DinoMatcher:
         # one ViT pass over the B images and their B * N windows (the reference runs two, :224-231): every kernel works per image,
         # so the features are the same, and the 4-image pass alone ran its GEMMs / attention at 60 - 75 % of the batched rate
         both = torch.cat([K.resize_bilinear(lq.contiguous(), Hd, Wd), K.resize_bilinear(windows, Hd, Wd)], dim=0)
-        f, T = self.tokens(both, flat=os.environ.get('TDR_DINO_FLAT', '1') == '1')
+        f, T = self.tokens(both, flat=FLAT)
         fl, fr = f[:B], f[B:]
         corr, index, ref_in = K.token_match(fl, fr, windows, N, T + 1)
         return ref_in, index, corr

@@ -66,8 +66,8 @@ def attn_bwd(dy, P, heads, saved, G):
 
 def _split_ok(t2, h):
     """the in-place cross-concatenation needs 16-byte aligned plane slices and the 3x3 stencil route (W % 4 == 0)"""
-    return t2.shape[-1] % 4 == 0 and (h * t2.shape[2] * t2.shape[3]) % 4 == 0 and os.environ.get('TDR_DWK_GENERIC', '0') != '1' and \
-        os.environ.get('TDR_DWSG_TWO_PASS', '0') != '1' and os.environ.get('TDR_MSFN_COPY', '0') != '1'
+    return t2.shape[-1] % 4 == 0 and (h * t2.shape[2] * t2.shape[3]) % 4 == 0 and not K.DWK_GENERIC and \
+        os.environ.get('TDR_DWSG_TWO_PASS', '0') != '1'
 
 
 def ffn_fwd(yn, P, res=None):

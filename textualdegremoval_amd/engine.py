@@ -14,10 +14,10 @@ from . import kernels as K
 from .kernels import (EPI_GATEBWD, EPI_PSHUF, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2, PACK_DGRAD_S1, PACK_FWD)
 
 LN_EPS = 1e-6
-# fused NAFBlock halves (csrc/tdr_nafblock.hip) where the shape allows; TDR_FUSE_NAF=0 keeps the per-op launches
-FUSE_TAIL = os.environ.get('TDR_FUSE_NAF', '1') == '1'
-FUSE_HEAD = FUSE_TAIL and os.environ.get('TDR_FUSE_HEAD', '1') == '1'      # norm1 -> conv1 (forward)
-FUSE_CONV3_DGRAD = os.environ.get('TDR_FUSE_CONV3_DGRAD', '1') == '1'     # conv3's data gradient at the end of the tail backward
+# fused NAFBlock halves (csrc/tdr_nafblock.hip) where the shape allows (module switches -- tests and probes set them; none is an environment knob)
+FUSE_TAIL = True
+FUSE_HEAD = True                                                          # norm1 -> conv1 (forward)
+FUSE_CONV3_DGRAD = True                                                   # conv3's data gradient at the end of the tail backward
 
 
 def _sub(P, pre):
@@ -62,24 +62,24 @@ def maybe_join():
 # bound launches of 256 - 2048 large ones -- complementary resources, where the NAFBlock chain itself (135 KB of LDS per workgroup) leaves
 # no room for a second kernel.  The operands stay referenced until the join (288 GB of HBM: ~14 GB of gradient operands kept alive).
 # Only without a gradient exchange: with collectives the buckets are cut in arrival order inside the backward (parallel.GradAllReducer).
-DEFER_WGRAD = os.environ.get('TDR_DEFER_WGRAD', '1') == '1'
-DEFER_LN_FINISH = os.environ.get('TDR_DEFER_LN_FINISH', '1') == '1'     # also the reductions of the LayerNorm-gradient partials
+DEFER_WGRAD = True
+DEFER_LN_FINISH = True                                                  # also the reductions of the LayerNorm-gradient partials
 # deferred 1x1 leaf weight gradients of one shape (a level's conv1 / conv4, its conv5) share ONE launch + ONE reduction
 # (kernels.wgrad1x1_group, csrc/tdr_wgrad_1x1.hip): no per-launch ramp / prologue / partial write / reduction launch, 1 / 8 of the partials
-GROUP_LEAVES = os.environ.get('TDR_GROUP_LEAVES', '1') == '1'
+GROUP_LEAVES = True
 # data-parallel runs: the leaves of a level queued and run (grouped) at the level's end instead of one launch per leaf inside the chain
-LEVEL_LEAVES = os.environ.get('TDR_LEVEL_LEAVES', '1') == '1'
+LEVEL_LEAVES = True
 _level_mode = False
 FORCE_DP_SCHEDULE = os.environ.get('TDR_FORCE_DP_SCHEDULE', '0') == '1'    # measurement aid: schedule the leaves as a data-parallel run would, on one GPU
-SERIAL_LEAVES = os.environ.get('TDR_SERIAL_LEAVES', '0') == '1'    # measurement aid (bench.py's roofline leg): the deferred leaves on the CURRENT stream, before the main chain
+SERIAL_LEAVES = False    # measurement aid (bench.py's roofline leg): the deferred leaves on the CURRENT stream, before the main chain
 _late = None            # [(prefix, closure -> {name: grad})] while a whole-network backward collects deferred leaves
 _late_pre = ''
 
 
 # RULE for queued leaves: a leaf reads its operands (`keep`, and whatever its closure names) when run_late_leaves() runs it -- after
 # the whole main backward chain.  Nothing may write those tensors in place (K.add_ and friends) or rebind the closure's names between
-# queueing and the run; every operand must be listed in `keep`.  TDR_DEBUG_LEAVES=1 checks the tensors' version counters at run time.
-DEBUG_LEAVES = os.environ.get('TDR_DEBUG_LEAVES', '0') == '1'
+# queueing and the run; every operand must be listed in `keep`.  engine.DEBUG_LEAVES = True checks the tensors' version counters at run time.
+DEBUG_LEAVES = False        # (module switch)
 
 
 def _leaf(keep, fn, G):
@@ -482,12 +482,12 @@ def _enc_counts(ext):
 # both weight gradients read them through transposed LDS reads, and the ReLU masks are the sign of the head plane.  A level
 # enters the format through one conversion of conv_L's output (forward) and of the incoming feature gradient (backward) and
 # leaves it as fp32 (feats[lvl] for the MASA kernels / the next conv_L, the gradient for conv_L's backward).
-# TDR_P16=0 keeps the fp32 tensors + per-consumer split of rounds 1-3.
-P16_ON = os.environ.get('TDR_P16', '1') == '1'
+# (P16_ON = False keeps the fp32 tensors + per-consumer split of rounds 1-3.)
+P16_ON = True
 # narrower levels (C = 32: one 32-row m-tile, 18 (group, tap) steps) keep the fp32 kernels until the weights-stationary variant exists
 # (bf16 triple planes, TDR_MATH=bx3: the C = 32 level too -- its convolution is a wash at 6 bytes per element (292 vs 283 us per launch), its
 # weight gradient is not (232 vs 273 us): -0.5 ms per step, same-box A/B profiles/r5/sweep_a.log)
-P16_MIN_C = int(os.environ['TDR_P16_MIN_C']) if 'TDR_P16_MIN_C' in os.environ else None
+P16_MIN_C = None
 
 
 def _p16_level(Cc, n_blocks):

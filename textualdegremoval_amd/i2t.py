@@ -62,7 +62,7 @@ def mlp_bwd(dout, P, pre, saved, G):
         d, G[f'{pre}{j}.weight'], G[f'{pre}{j}.bias'] = _lin_bwd(dz, x, P[f'{pre}{j}.weight'], j > 0)
 
 
-LANES = int(__import__('os').environ.get('TDR_MAPPER_LANES', '4'))   # HIP streams the 2 x num_words independent MLPs are spread over
+LANES = 4   # HIP streams the 2 x num_words independent MLPs are spread over
 
 
 def mapper_fwd(tok, T, P, num_words):

@@ -29,7 +29,7 @@ PACK_FWD, PACK_DGRAD_S1, PACK_DGRAD_2X2S2, PACK_DGRAD_3X3S2 = 0, 1, 2, 3
 # fp16 window, loss-scaled backward with a device-resident guard): TDR_MATH=hx2.
 MATH = os.environ.get('TDR_MATH', 'bx3')
 # weight gradients of 1x1 convs on the split-bf16 kernel as well (0: exact fp32 kernel)
-WGRAD_1X1_BX3 = os.environ.get('TDR_WGRAD_1X1_BX3', '1') == '1'
+WGRAD_1X1_BX3 = True          # (module switch for A/B runs; not an environment knob)
 FMT_F32, FMT_BX3, FMT_HX2, FMT_H1 = 0, 1, 2, 3
 
 
@@ -123,10 +123,12 @@ class PackedWeights:
 # issued so far on the current stream; allocations still come from the current stream's pool, and every tensor the
 # side kernels touch is kept referenced until side_join() (the current stream waits for the side stream), so memory
 # is never recycled under a running side kernel.  Under hipGraph capture this becomes a parallel branch of the graph.
-# Opt-in (TDR_SIDE_WGRAD=1): measured +1.2 % (NAFNet-ref cfg2) / +2 % (Restormer-ref cfg3) -- the MFMA kernels hold
+# Opt-in (kernels.SIDE_WGRAD = True): measured +1.2 % (NAFNet-ref cfg2) / +2 % (Restormer-ref cfg3) -- the MFMA kernels hold
 # their LDS / wave slots while resident, so two of them barely co-run -- and per-kernel profiles of overlapped launches
 # are no longer comparable with the serial ones, so the default keeps the backward on one stream.
-SIDE_WGRAD = os.environ.get('TDR_SIDE_WGRAD', '0') == '1'
+ATTN_F32 = False              # exact-fp32 attention products inside an fp16 arithmetic (module switch)
+DWK_GENERIC = False           # the LDS-tiled generic depthwise kernels instead of the register-window ones (module switch: cross-check tests)
+SIDE_WGRAD = False            # (module switch: tests/test_hip_network.py::test_side_stream_weight_gradients_match)
 _side_stream = None
 _side_active = False
 _side_dirty = False
@@ -688,13 +690,13 @@ def _grp_table(seq, nrows, capturing):
     if ent is None:
         if capturing:
             raise RuntimeError('kernels.wgrad1x1_group: this backward pass is being captured before it ever ran eagerly (no pinned table for '
-                               f'group {seq}); run one eager step of the shape first or set TDR_GROUP_LEAVES=0')
+                               f'group {seq}); run one eager step of the shape first or set engine.GROUP_LEAVES = False')
         ent = _grp_pool[key] = dict(eager=[torch.empty(nrows, dtype=torch.int64).pin_memory() for _ in range(2)], ev=[None, None], flip=0,
                                     spare=[])
     if capturing:
         if not ent['spare']:
             raise RuntimeError(f'kernels.wgrad1x1_group: no unused pinned table left for group {seq} ({nrows} rows) -- the captured pass uses '
-                               'this call site more often than the eager warm-up steps of the shape did; set TDR_GROUP_LEAVES=0')
+                               'this call site more often than the eager warm-up steps of the shape did; set engine.GROUP_LEAVES = False')
         host = ent['spare'].pop()
         if _ws_capture_refs is not None:
             _ws_capture_refs.append(host)      # owned by the graph from here on (freed with it)
@@ -1259,7 +1261,7 @@ def attention_fwd(qkv, heads, scale, T1, flat_batch=0, single_product=False):
     assert qkv.is_contiguous()
     out = torch.empty(qkv.shape[0], Cc, qkv.shape[2], qkv.shape[3], dtype=torch.float32, device=qkv.device)
     # the frozen ViTs (no gradient flows through this attention): on the fp16 split whenever the dense contractions are
-    math = 2 if (MATH in ('hx2', 'h1') and os.environ.get('TDR_ATTN_F32', '0') != '1') else 0
+    math = 2 if (MATH in ('hx2', 'h1') and not ATTN_F32) else 0
     if single_product and math == 2 and Cc // heads in (16, 32, 64):
         math = 3          # plain fp16 products (the DINOv2 matcher: only an arg-max leaves it)
     check(_lib.load().tdr_attention_fwd_math(qkv.data_ptr(), B, Cc, heads, T1, LD, float(scale), math, 1 if flat_batch else 0, out.data_ptr(),
@@ -1874,13 +1876,13 @@ def tksa_bwd(G, ss, temp, am, dA, heads):
 def _dw3_plain(x, w, dil):
     Cout, mult, Kk, _ = w.shape
     return Kk == 3 and mult == 1 and dil == 1 and Cout % 2 == 0 and x.shape[-1] % 4 == 0 and x.is_contiguous() and \
-        os.environ.get('TDR_DWK_GENERIC', '0') != '1'
+        not DWK_GENERIC
 
 
 def _dw3_pair(x, w, dil):
     Cout, mult, Kk, _ = w.shape
     return Kk == 3 and mult == 2 and dil == 1 and x.shape[-1] % 4 == 0 and x.is_contiguous() and \
-        os.environ.get('TDR_DWK_GENERIC', '0') != '1'
+        not DWK_GENERIC
 
 
 def _DW_TWO_PASS():

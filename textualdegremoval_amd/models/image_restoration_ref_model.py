@@ -26,6 +26,8 @@ from .archs import define_network
 from .base_model import BaseModel, logger
 
 
+GRAD_SCALE = True       # module switch: the exact power-of-two loss scale of the fp16 arithmetics (hx2 / h1)
+
 class RefGuidedImageCleanModel(BaseModel):
     def __init__(self, opt):
         super().__init__(opt)
@@ -180,7 +182,7 @@ class RefGuidedImageCleanModel(BaseModel):
     FWD_MAX_EXP = 14
 
     def _survey_due(self, current_iter):
-        if not K.fp16_path() or os.environ.get('TDR_RANGE_CHECK', '1') != '1':
+        if not K.fp16_path() or int(os.environ.get('TDR_RANGE_CHECK_EVERY', '1000')) <= 0:
             return False
         every = int(os.environ.get('TDR_RANGE_CHECK_EVERY', '1000'))
         last = getattr(self, '_last_survey_iter', None)
@@ -244,7 +246,7 @@ class RefGuidedImageCleanModel(BaseModel):
             # The scale lives in the optimiser's device-resident StepGuard: a non-finite gradient norm (an operand left the
             # fp16 range) skips that step and halves it, 1000 finite steps double it again up to this starting value.
             gs = 1.0
-            if K.fp16_path() and os.environ.get('TDR_GRAD_SCALE', '1') == '1' and lw > 0 and \
+            if K.fp16_path() and GRAD_SCALE and lw > 0 and \
                     not getattr(self, '_bwd_full_range', False):
                 # PSNRLoss: dpred ~ lw*(10/ln10)*2d / (N*CHW*mse_n), ~2^8 above an L1 gradient at d ~ 0.1: start lower
                 gs = 2.0 ** (math.floor(math.log2(512.0 * lq.shape[0] * 3 * lq.shape[2] * lq.shape[3] / lw)) +
@@ -254,7 +256,7 @@ class RefGuidedImageCleanModel(BaseModel):
             if not torch.cuda.is_current_stream_capturing():
                 # TDR_MATH=bx3 / f32 (fp32 range in BOTH passes): no skip verdict -- the step is applied whatever the norm, as the
                 # reference does (:276-279); the struct only counts steps on the device.  Under an fp16 arithmetic the verdict stays
-                # even without a loss scale (the surveyed full-range backward, TDR_GRAD_SCALE=0): the FORWARD pass still runs inside
+                # even without a loss scale (the surveyed full-range backward, GRAD_SCALE = False): the FORWARD pass still runs inside
                 # the fp16 window, and between surveys the guard is what keeps a forward overflow out of the weights
                 guard.set_never_skip(gs == 1.0 and not K.fp16_path())
                 guard.set_max_scale(gs)        # (host read; the capture pass reuses the value of the eager warm-up steps)

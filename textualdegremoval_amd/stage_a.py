@@ -95,6 +95,10 @@ def _w4(w):
     return w.reshape(w.shape[0], w.shape[1], 1, 1).contiguous()
 
 
+# module switches (A/B runs; not environment knobs)
+GRAD_SCALE = False            # loss-scaled fp16-split backward of the stage-A step
+MAPPER_GROUPED = True          # the Mapper's MLPs as grouped GEMMs
+
 class _Frozen:
     """persistent packs of a frozen Linear: forward (and, on request, the transposed pack of its data gradient)"""
 
@@ -166,10 +170,10 @@ class I2TMappingTrainer:
         self.reducer = GradAllReducer(list(zip(self.names, self.params)), bucket_mb=bucket_mb,
                                       local_only=not self.dist and os.environ.get('TDR_FORCE_COLLECTIVES') != '1')
         self._plan = K.PackPlan()
-        # the Mapper as G-way grouped GEMMs over batch-flattened tokens (i2t.mapper_fwd_grouped); TDR_MAPPER_GROUPED=0 keeps the
+        # the Mapper as G-way grouped GEMMs over batch-flattened tokens (i2t.mapper_fwd_grouped); stage_a.MAPPER_GROUPED = False keeps the
         # 2 x num_words chains of small launches on four stream lanes
-        self.grad_scale = os.environ.get('TDR_I2T_GRAD_SCALE', '0') == '1'
-        self.grouped = os.environ.get('TDR_MAPPER_GROUPED', '1') == '1'
+        self.grad_scale = GRAD_SCALE
+        self.grouped = MAPPER_GROUPED
         self.stacks = i2t.MapperStacks(self.mapper) if self.grouped else None
         # frozen stand-ins, packed once
         self.vae = _Frozen(S['vae.weight'] * (VAE_SCALE / 64.0))              # average pool = block sum / 64, folded in
@@ -213,7 +217,7 @@ class I2TMappingTrainer:
         prev_plan = K.set_pack_plan(self._plan)
         prev_scaled = K.GRAD_SCALED
         try:
-            # Optional loss-scaled backward (TDR_I2T_GRAD_SCALE=1; off by default): under TDR_MATH=hx2 the gradient GEMMs may take the
+            # Optional loss-scaled backward (stage_a.GRAD_SCALE = True; off by default): under TDR_MATH=hx2 the gradient GEMMs may take the
             # 2-way fp16 split (3 products instead of the 6 of the 3-way bf16 split) if their operands sit in the fp16 window.
             # Unlike the restoration step this backward spans ~2^20: dpred = 2 (pred - noise) / numel ~ 2^-14 while dk / dv sum over
             # 4096 queries and reach ~2^5, so the exact power-of-two scale is S = numel / 256 (2^8 at bs 4): the largest operands
@@ -379,7 +383,7 @@ class TRMappingTrainer(I2TMappingTrainer):
 
     def _words_fwd(self, tok, T, B, P):
         if not self.grouped:
-            raise NotImplementedError('TRMappingTrainer runs the grouped kernels (TDR_MAPPER_GROUPED=1)')
+            raise NotImplementedError('TRMappingTrainer runs the grouped kernels (stage_a.MAPPER_GROUPED)')
         inj, _ = i2t.mapper_fwd_grouped(tok, B, T, self.stacks)      # frozen: nothing kept for a backward pass
         return i2t.clean_mapper_fwd_grouped(inj, self.clean_mapper.stacks())
 
