@@ -92,17 +92,15 @@ def _cpu_baseline_worker(width, enc, H, batch, budget):
     while True:
         tr.step(lq, gt, ref)
         n += 1
-        if n >= 2 and (time.time() - t0 > budget or n >= 4):
+        if time.time() - t0 > budget or n >= 4:
             break
     print(json.dumps({'n': n, 'dt': time.time() - t0, 'threads': threads, 'probe': {str(k): round(v, 3) for k, v in probe.items()}}))
 
 
-def cpu_baseline(width, enc, size, batch, budget=20.0, hard_timeout=300.0):
+def cpu_baseline(width, enc, size, batch, budget=20.0, hard_timeout=480.0):
     """Reported baseline only (never the thing shipped): `oracle/` timed on this host's cores in a child process with a
-    hard timeout, on a bounded sample of the metric's workload: whole train steps of the same network on ONE size x size
-    pair (a quarter of the per-GPU batch; the CPU path is per-sample work, so img/s does not depend on the batch),
-    1 warm-up + >= 2 timed steps."""
-    batch = 1
+    hard timeout, on a bounded sample of the metric's workload: whole train steps of the same network on the metric's OWN per-GPU
+    batch (`batch` x size x size pairs; round 6 -- rounds 1-5 timed one pair), 1 warm-up + 1..4 timed steps (about 20 - 40 s)."""
     import subprocess
     code = (f'import sys; sys.path.insert(0, {ROOT!r}); import bench; '
             f'bench._cpu_baseline_worker({width}, {enc!r}, {size}, {batch}, {budget})')
@@ -114,8 +112,8 @@ def cpu_baseline(width, enc, size, batch, budget=20.0, hard_timeout=300.0):
         return {'value': None, 'unit': 'images/sec', 'cores': None, 'kind': 'port', 'sample': f'failed: {type(e).__name__}'}
     return {'value': r['n'] * batch / r['dt'], 'unit': 'images/sec', 'cores': r['threads'], 'kind': 'port',
             'host_cpus': os.cpu_count(),
-            'sample': f"1 warm-up + {r['n']} timed train steps of the same network on {batch} x {size}x{size} pair(s) (the metric's "
-                      f"per-GPU batch is 4 of them) in {r['dt']:.1f} s, torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py); threads chosen by a scaling probe "
+            'sample': f"1 warm-up + {r['n']} timed train step(s) of the same network on the metric's own per-GPU batch ({batch} x {size}x{size} "
+                      f"pairs) in {r['dt']:.1f} s, torch-CPU fp32 oracle (oracle/nafnet_ref_oracle.py); threads chosen by a scaling probe "
                       f"(seconds per 128x128 step by thread count: {r['probe']})"}
 
 

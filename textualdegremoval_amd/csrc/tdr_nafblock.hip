@@ -935,7 +935,7 @@ extern "C" int tdr_naf_tail_fwd(const TdrNafTailDesc* d, void* stream) {
     a.c_out = d->c_out > 0 ? d->c_out : d->C;
     TDR_REQUIRE(a.c_out == d->C || (a.c_out * 2 == d->C && a.c_out % 32 == 0), "tdr_naf_tail_fwd: c_out must be C or C / 2 (a multiple of 32)");
     const bool bx = d->w_fmt == 1;
-    const size_t lds = (size_t)(bx ? 3 : 2) * (d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    const size_t lds = (size_t)(bx ? 3 : 2) * (d->C / 8) * NPX * 16 + (size_t)2 * (d->C / 32) * NPX * sizeof(float);      // planes + red[2][C / 32 waves][64 px]
     NAF_DISPATCH_CS(naf_tail_fwd_kernel, , lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_tail_fwd_kernel");
     return TDR_OK;
@@ -950,7 +950,7 @@ extern "C" int tdr_naf_head_fwd(const TdrNafHeadFwdDesc* d, void* stream) {
     a.w1 = reinterpret_cast<const uint4*>(d->w1); a.b1 = d->b1;
     a.mu = d->mu; a.rs = d->rs; a.xn = d->xn; a.xn_ns = d->xn_ns; a.t1 = d->t1; a.t1_ns = d->t1_ns; a.HW = d->HW;
     const bool bx = d->w_fmt == 1;
-    const size_t lds = (size_t)(bx ? 3 : 2) * (d->C / 8) * NPX * 16 + 16 * NPX * sizeof(float);
+    const size_t lds = (size_t)(bx ? 3 : 2) * (d->C / 8) * NPX * 16 + (size_t)2 * (d->C / 32) * NPX * sizeof(float);      // planes + red[2][C / 32 waves][64 px]
     NAF_DISPATCH_CS(naf_head_fwd_kernel, , lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_head_fwd_kernel");
     return TDR_OK;
@@ -979,7 +979,7 @@ extern "C" int tdr_naf_tail_bwd(const TdrNafTailBwdDesc* d, void* stream) {
     a.w3t = reinterpret_cast<const uint4*>(d->w3t); a.beta = d->beta; a.sca = d->sca; a.dgp = d->dgp; a.dgp_ns = d->dgp_ns;
     TDR_REQUIRE(!d->w3t || (d->beta && d->sca && d->dgp), "tdr_naf_tail_bwd: the conv3 stage needs beta, sca and dgp");
     const bool bx = d->w_fmt == 1;       // three planes: one K half (C / 8 octets) resident at a time
-    const size_t lds = (size_t)(bx ? 3 * (d->C / 8) : 2 * (2 * d->C / 8)) * NPX * 16 + 16 * NPX * sizeof(float);
+    const size_t lds = (size_t)(bx ? 3 * (d->C / 8) : 2 * (2 * d->C / 8)) * NPX * 16 + (size_t)2 * (d->C / 32) * NPX * sizeof(float);      // planes + red[2][C / 32 waves][64 px]
     NAF_DISPATCH_CS(naf_tail_bwd_kernel, NAF_COMMA false, lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_tail_bwd_kernel");
     if (!d->gw) return TDR_OK;            // the caller finishes the LayerNorm parameter gradients itself (tdr_pair_sum_partials on ws)
@@ -1000,7 +1000,7 @@ extern "C" int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream) {
     a.c_out = d->C;
     a.w3t = nullptr; a.beta = nullptr; a.sca = nullptr; a.dgp = nullptr; a.dgp_ns = 0;
     const bool bx = d->w_fmt == 1;
-    const size_t lds = (size_t)(bx ? 3 * (d->C / 8) : 2 * (2 * d->C / 8)) * NPX * 16 + 16 * NPX * sizeof(float);
+    const size_t lds = (size_t)(bx ? 3 * (d->C / 8) : 2 * (2 * d->C / 8)) * NPX * 16 + (size_t)2 * (d->C / 32) * NPX * sizeof(float);      // planes + red[2][C / 32 waves][64 px]
     NAF_DISPATCH_CS(naf_tail_bwd_kernel, NAF_COMMA true, lds, a, d, stream);
     TDR_LAUNCH_CHECK("naf_head_bwd_kernel");
     if (!d->gw) return TDR_OK;
