@@ -22,7 +22,7 @@ extern "C" {
 
 /* C-ABI version: bumped with every incompatible change of this header (100 rounds 1-2, 101 round 3, 102 round 4); the
  * binding (textualdegremoval_amd/_lib.py) refuses a library whose version differs from the one it was written against. */
-#define TDR_ABI_VERSION 104
+#define TDR_ABI_VERSION 105
 int tdr_version(void);
 const char* tdr_last_error(void);
 
@@ -806,6 +806,66 @@ int tdr_adamw_step_guarded(float* const* params, const float* const* grads, floa
                            int n_chunks, const double* sumsq, const float* hp, const TdrStepGuard* guard, float max_norm,
                            int use_clip, int coupled_decay, float beta1, float beta2, float eps, float weight_decay,
                            void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Un-guided SFNet (models/archs/network_sfnet_guided_arch.py:320-407, sfnet_arch_utils.py:76-265), training-mode
+ * semantics.  The convolutions run on tdr_conv_forward / tdr_conv_wgrad; these are the operators around them (csrc/tdr_sfnet.hip).
+ * --------------------------------------------------------------------------- */
+/* exact-erf GELU after a convolution (BasicConv, sfnet_arch_utils.py:76-98): z = x + bias[channel] (bias may be NULL; C / HW give the
+ * channel of element i as (i / HW) % C), y = gelu(z); z_out (may be NULL, may alias x) receives z for the backward pass: dz = dy * gelu'(z) */
+int tdr_gelu_fwd(const float* x, const float* bias, int C, int HW, float* z_out, float* y, int64_t n, void* stream);
+int tdr_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* stream);
+/* F.interpolate(scale_factor=0.5) in its default nearest mode (:368-369): y[., i, j] = x[., 2i, 2j]; planes = N * C */
+int tdr_subsample2(const float* x, int planes, int H, int W, float* y, void* stream);
+/* InstanceNorm2d(C, affine=True) (SCM, :208): per (image, channel) plane; mu / rs [N * C] kept for the backward pass.  ws: 2 N C floats */
+int tdr_instnorm_fwd(const float* x, const float* w, const float* b, float eps, int N, int C, int HW, float* y, float* mu, float* rs, void* stream);
+int tdr_instnorm_bwd(const float* dy, const float* x, const float* mu, const float* rs, const float* w, int N, int C, int HW, float* dx,
+                     float* dw, float* db, float* ws, void* stream);
+/* Gap (sfnet_arch_utils.py:101-117; q = 1, shift = 1: ph = fscale_h, pl = fscale_d) and Patch_ap (:239-265; q = 2: the four quadrants
+ * of the plane, shift = 0: ph = h, pl = l), parameters [C * q * q] in the reference's `(c p1 p2)` order:
+ *   y = x * A + mean_region(x) * B,   A = ph + shift,  B = pl - A
+ * on channel slices addressed by an image stride; mean [N][C][q * q] is kept.  Backward: dx and the parameter gradients dph, dpl.
+ * ws: 2 N C q q floats */
+int tdr_region_affine_fwd(const float* x, int64_t x_ns, const float* ph, const float* pl, float shift, int q, int N, int C, int H, int W,
+                          float* y, int64_t y_ns, float* mean, void* stream);
+int tdr_region_affine_bwd(const float* dy, int64_t dy_ns, const float* x, int64_t x_ns, const float* ph, const float* pl, float shift,
+                          const float* mean, int q, int N, int C, int H, int W, float* dx, int64_t dx_ns, float* dph, float* dpl, float* ws,
+                          void* stream);
+/* (the pooled vectors come from tdr_plane_mean above) */
+/* dynamic_filter (:152-192) + SFconv (:195-236) on the pooled vectors ap [N][c], one workgroup:
+ *   taps [N][G * KK] = softmax over the KK = k * k taps of each (image, group) of BatchNorm2d_train(conv1x1(ap)) -- the running buffers and
+ *   num_batches_tracked are moved in place --;  [ah ; al] [N][c] each = softmax over all 2c entries of [fcs0(fc(ap)) ; fcs1(fc(ap))].
+ * xhat [N][GK], rstd [GK], z [N][d], att [N][2c] are what the backward pass needs. */
+typedef struct TdrSfDynVecDesc {
+    int N, c, GK, KK, d;
+    float eps, momentum;
+    const float *ap, *wconv, *bn_w, *bn_b, *fc_w, *fc_b, *f0_w, *f0_b, *f1_w, *f1_b;
+    float *run_mean, *run_var; int64_t* nbt;
+    float *taps, *ah, *al, *xhat, *rstd, *z, *att;
+} TdrSfDynVecDesc;
+int tdr_sf_dyn_vec_fwd(const TdrSfDynVecDesc* d, void* stream);
+typedef struct TdrSfDynVecBwdDesc {
+    int N, c, GK, KK, d;
+    const float *ap, *wconv, *bn_w, *fc_w, *f0_w, *f1_w, *taps, *xhat, *rstd, *z, *att, *dtaps, *dah, *dal;
+    float *dap, *g_wconv, *g_bn_w, *g_bn_b, *g_fc_w, *g_fc_b, *g_f0_w, *g_f0_b, *g_f1_w, *g_f1_b;
+    float* ws;                               /* N * (2c + d + GK) floats */
+} TdrSfDynVecBwdDesc;
+int tdr_sf_dyn_vec_bwd(const TdrSfDynVecBwdDesc* d, void* stream);
+/* low = k x k stencil of the reflection-padded planes with taps[n][c / (C / groups)]; mix = x * ah[n][c] + low * (al - ah)[n][c]
+ * (= high * ah + low * al with high = x - low): the operand of SFconv's `out` convolution */
+int tdr_sf_dynfilt_fwd(const float* x, int64_t x_ns, const float* taps, const float* ah, const float* al, int N, int C, int groups, int H,
+                       int W, int k, float* low, float* mix, void* stream);
+/* backward, reductions: dah[n][c] = sum dmix * (x - low), dal = sum dmix * low, dtaps[n][g][t] = sum_{c in g} (al - ah) sum_px dmix * xpad(t) */
+int tdr_sf_dynfilt_bwd_reduce(const float* dmix, const float* x, int64_t x_ns, const float* low, const float* ah, const float* al, int N, int C,
+                              int groups, int H, int W, int k, float* dah, float* dal, float* dtaps, void* stream);
+/* backward, data: dx = dmix * ah + (al - ah) * stencil^T(dmix; taps) + dap[n][c] / (H W)   (dap: gradient of the pooled vector) */
+int tdr_sf_dynfilt_bwd_dx(const float* dmix, const float* taps, const float* ah, const float* al, const float* dap, int N, int C, int groups,
+                          int H, int W, int k, float* dx, int64_t dx_ns, void* stream);
+/* ConvTranspose2d(Cin, Cout, 4, stride 2, padding 1) (BasicConv(transpose=True), :87) == 3x3 / pad 1 convolution to 4 Cout channels
+ * (channel co * 4 + a * 2 + b = output parity (a, b)) + PixelShuffle(2): w [Cin][Cout][4][4] -> w3 [4 Cout][Cin][3][3], b -> b4 [4 Cout];
+ * and the gradients back (dw3 -> dw, db4 -> db summed over the four parities). */
+int tdr_convt4_weight_to_3x3(const float* w, const float* b, int Cin, int Cout, float* w3, float* b4, void* stream);
+int tdr_convt4_grad_from_3x3(const float* dw3, const float* db4, int Cin, int Cout, float* dw, float* db, void* stream);
 
 #ifdef __cplusplus
 }

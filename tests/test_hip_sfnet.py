@@ -1,0 +1,208 @@
+"""GPU parity of the un-guided SFNet (reference models/archs/network_sfnet_guided_arch.py:320-407,
+sfnet_arch_utils.py:76-265) through the C ABI: the new operators against torch on the CPU, dynamic_filter and the whole network --
+forward at the three scales, every parameter gradient, the BatchNorm buffers after a training-mode pass -- against the goldens the
+REFERENCE classes produced (tests/golden/sfnet.npz) and against the oracle, in the library default arithmetic and in exact fp32; the
+nn.Module mirror end to end (state-dict layout, autograd).  Path target: 1e-4 max-abs on O(1) fp32 outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sfnet_oracle as SO
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sfnet.npz')
+
+
+@pytest.fixture(scope='module', params=['bx3', 'f32'])
+def K(request):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels
+    prev = kernels.MATH
+    kernels.set_math(request.param)
+    yield kernels
+    kernels.set_math(prev)
+
+
+@pytest.fixture(scope='module')
+def g():
+    return np.load(GOLDEN, allow_pickle=False)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def md(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def test_gelu_subsample_instnorm(K):
+    x = rnd(2, 5, 12, 20, seed=1)
+    b = rnd(5, seed=2)
+    xr = x.clone().requires_grad_(True)
+    yr = F.gelu(xr + b.view(1, -1, 1, 1))
+    go = rnd(*x.shape, seed=3)
+    (yr * go).sum().backward()
+    z, y = K.gelu_fwd(x.cuda(), bias=b.cuda())
+    assert md(y, yr) < 2e-6 and md(z, x + b.view(1, -1, 1, 1)) < 1e-6
+    assert md(K.gelu_bwd(go.cuda(), z), xr.grad) < 2e-6
+    assert md(K.subsample2(x.cuda()), x[:, :, ::2, ::2]) == 0.0
+    w, bb = 1 + 0.3 * rnd(5, seed=4), rnd(5, seed=5)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), bb.clone().requires_grad_(True)
+    yr = F.instance_norm(xr, weight=wr, bias=br, eps=1e-5)
+    (yr * go).sum().backward()
+    y, mu, rs = K.instnorm_fwd(x.cuda(), w.cuda(), bb.cuda())
+    dx, dw, db = K.instnorm_bwd(go.cuda(), x.cuda(), mu, rs, w.cuda())
+    assert md(y, yr) < 5e-6 and md(dx, xr.grad) < 2e-5 and md(dw, wr.grad) < 2e-4 and md(db, br.grad) < 2e-4
+
+
+@pytest.mark.parametrize('q', [1, 2])
+def test_region_affine_on_channel_slices(K, q):
+    """Gap (q = 1, shift 1) / Patch_ap (q = 2, shift 0) against the oracle's restatement, reading and writing channel SLICES of bigger buffers"""
+    N, C, H, W = 3, 6, 8, 12
+    big = rnd(N, 2 * C, H, W, seed=11)
+    ph, pl = rnd(C * q * q, seed=12, scale=0.5), rnd(C * q * q, seed=13, scale=0.5)
+    shift = 1.0 if q == 1 else 0.0
+    xr = big[:, C:].clone().requires_grad_(True)
+    phr, plr = ph.clone().requires_grad_(True), pl.clone().requires_grad_(True)
+    yr = SO.region_affine(xr, phr + shift, plr - phr - shift, q)
+    go = rnd(N, C, H, W, seed=14)
+    (yr * go).sum().backward()
+    bg = big.cuda()
+    out = torch.zeros(N, 2 * C, H, W, device='cuda')
+    mean = K.region_affine_fwd(bg[:, C:], ph.cuda(), pl.cuda(), shift, q, out[:, :C])
+    assert md(out[:, :C], yr) < 2e-6 and float(out[:, C:].abs().max()) == 0.0
+    dbig = torch.zeros(N, 2 * C, H, W, device='cuda')
+    gobig = torch.zeros(N, 2 * C, H, W, device='cuda')
+    gobig[:, C:] = go.cuda()
+    dph, dpl = K.region_affine_bwd(gobig[:, C:], bg[:, C:], ph.cuda(), pl.cuda(), shift, mean, q, dbig[:, :C])
+    assert md(dbig[:, :C], xr.grad) < 2e-6 and md(dph, phr.grad) < 2e-4 and md(dpl, plr.grad) < 2e-4
+
+
+def test_transposed_conv_as_pixelshuffled_3x3(K):
+    """ConvTranspose2d(4, stride 2, padding 1) + bias + GELU through the weight re-tiling + PixelShuffle epilogue, forward and backward"""
+    from textualdegremoval_amd import sfnet_engine as SE
+    Cin, Cout, N, H, W = 64, 32, 2, 8, 12
+    w, b = rnd(Cin, Cout, 4, 4, seed=21, scale=1.0 / (Cin * 4) ** 0.5), rnd(Cout, seed=22, scale=0.2)
+    x = rnd(N, Cin, H, W, seed=23)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.gelu(F.conv_transpose2d(xr, wr, br, stride=2, padding=1))
+    go = rnd(*yr.shape, seed=24)
+    (yr * go).sum().backward()
+    P = {'t.main.0.weight': w.cuda(), 't.main.0.bias': b.cuda()}
+    y, sv = SE.convt_fwd(x.cuda(), P, 't.')
+    assert y.shape == yr.shape and md(y, yr) < 1e-5
+    G = {}
+    dx = SE.convt_bwd(go.cuda(), P, 't.', sv, G)
+    torch.cuda.synchronize()
+    assert md(dx, xr.grad) < 2e-5
+    assert md(G['t.main.0.weight'], wr.grad) < 2e-4 * max(1.0, wr.grad.abs().max().item())
+    assert md(G['t.main.0.bias'], br.grad) < 2e-4 * max(1.0, br.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('tag', ['dyn3', 'dyn5'])
+def test_dynamic_filter_against_the_reference_golden(K, g, tag):
+    from textualdegremoval_amd import sfnet_engine as SE
+    c, k, n, h, w = (int(v) for v in g[tag + '_cfg'])
+    P = {key.split('::', 1)[1]: torch.from_numpy(g[key]).clone().cuda() for key in g.files if key.startswith(tag + '_p::')}
+    x = torch.from_numpy(g[tag + '_x']).cuda()
+    big = torch.zeros(n, 2 * c, h, w, device='cuda')                       # operate on channel slices, as the ResBlock does
+    big[:, c:] = x
+    out = torch.zeros(n, 2 * c, h, w, device='cuda')
+    sv = SE.dyn_fwd(big[:, c:], P, '', k, out[:, :c])
+    assert md(out[:, :c], torch.from_numpy(g[tag + '_y'])) < 1e-5
+    for key in g.files:                                                     # BatchNorm buffers after the training-mode pass
+        if key.startswith(tag + '_buf::'):
+            kk = key.split('::', 1)[1]
+            want = torch.from_numpy(g[key]).double()
+            assert (P[kk].cpu().double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), kk
+    dy = torch.zeros(n, 2 * c, h, w, device='cuda')
+    dy[:, :c] = torch.from_numpy(g[tag + '_go']).cuda()
+    dx = torch.zeros(n, 2 * c, h, w, device='cuda')
+    G = {}
+    SE.dyn_bwd(dy[:, :c], P, '', k, sv, dx[:, c:], G)
+    torch.cuda.synchronize()
+    want = torch.from_numpy(g[tag + '_dx'])
+    assert md(dx[:, c:], want) <= 1e-4 * want.abs().max().item()
+    for key in g.files:
+        if key.startswith(tag + '_g::'):
+            kk = key.split('::', 1)[1]
+            wg = torch.from_numpy(g[key])
+            assert md(G[kk].reshape(wg.shape), wg) <= 5e-4 * wg.abs().max().item() + 1e-7, kk
+
+
+@pytest.mark.parametrize('tag', ['net_r2', 'net_r1_rect'])
+def test_whole_network_against_the_reference_golden(K, g, tag):
+    from textualdegremoval_amd import sfnet_engine as SE
+    num_res, seed, n, h, w = (int(v) for v in g[tag + '_cfg'])
+    sd = SO.synth_state(num_res, seed)
+    P = {k: v.clone().cuda() for k, v in sd.items()}
+    x = torch.from_numpy(g[tag + '_x']).cuda()
+    outs, saved = SE.net_fwd(P, x, num_res)
+    for i, o in enumerate(outs):
+        want = torch.from_numpy(g[f'{tag}_out{i}'])
+        assert o.shape == want.shape and md(o, want) < 1e-4, (i, md(o, want))
+    for key in g.files:
+        if key.startswith(tag + '_buf::'):
+            kk = key.split('::', 1)[1]
+            want = torch.from_numpy(g[key]).double()
+            assert (P[kk].cpu().double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), kk
+    G = SE.net_bwd([torch.from_numpy(g[f'{tag}_go{i}']).cuda() for i in range(3)], P, saved)
+    torch.cuda.synchronize()
+    names = [str(s) for s in g[tag + '_names']]
+    worst = (0.0, None)
+    for k, gn, gm in zip(names, g[tag + '_gnorm'], g[tag + '_gmax']):
+        if gn < 0:
+            assert k not in G, k                                          # lamb_l / lamb_h: no gradient in the reference either
+            continue
+        if k.endswith('main.3.main.0.bias') and k.startswith('SCM'):
+            continue                                                      # true gradient zero (bias in front of InstanceNorm): rounding residue
+        gr = G[k].double().cpu()
+        rel = abs(gr.norm().item() - gn) / gn
+        worst = max(worst, (rel, k))
+        assert rel <= 2e-3 and abs(gr.abs().max().item() - gm) <= 5e-3 * gm + 1e-7, (k, gr.norm().item(), gn, gr.abs().max().item(), gm)
+    for key in g.files:
+        if key.startswith(tag + '_grad::'):
+            k = key.split('::', 1)[1]
+            want = torch.from_numpy(g[key])
+            assert md(G[k].reshape(want.shape), want) <= 2e-3 * want.abs().max().item() + 1e-7, k
+    print(f'{tag} [{K.MATH}]: worst relative gradient-norm difference {worst[0]:.2e} at {worst[1]}')
+
+
+def test_module_mirror_trains_like_the_oracle(K):
+    """the nn.Module (reference constructor, state-dict layout) end to end: load a seeded state, forward + backward through autograd,
+    outputs / gradients / moved BatchNorm buffers against the oracle on the same state"""
+    from textualdegremoval_amd.models.archs import define_network
+    num_res = 1
+    net = define_network(dict(type='SFNet', mode=['train', 'Indoor'], num_res=num_res)).cuda()
+    sd = SO.synth_state(num_res, seed=5)
+    assert list(net.state_dict()) == list(sd)
+    net.load_state_dict(sd)
+    net.train()
+    x = torch.rand(2, 3, 32, 48, generator=torch.Generator().manual_seed(6))
+    outs = net(x.cuda())
+    gos = [rnd(*o.shape, seed=30 + i) for i, o in enumerate(outs)]
+    sum((o * go.cuda()).sum() for o, go in zip(outs, gos)).backward()
+    P = {k: (v.clone().requires_grad_(True) if not SO.is_buffer(k) else v.clone()) for k, v in sd.items()}
+    bufs = {}
+    ro = SO.sfnet_forward(P, x, num_res, bufs)
+    sum((o * go).sum() for o, go in zip(ro, gos)).backward()
+    for a, b in zip(outs, ro):
+        assert md(a, b) < 1e-4
+    after = net.state_dict()
+    for k, v in bufs.items():
+        assert (after[k].cpu().double() - v.double()).abs().max().item() <= 1e-5 * max(1.0, v.double().abs().max().item()), k
+    for k, p in net.named_parameters():
+        if P[k].grad is None:
+            assert p.grad is None, k
+            continue
+        if k.endswith('main.3.main.0.bias') and k.startswith('SCM'):
+            continue
+        assert md(p.grad, P[k].grad) <= 2e-3 * P[k].grad.abs().max().item() + 1e-7, k
+    with pytest.raises(NotImplementedError):
+        define_network(dict(type='SFNet', mode=['test', 'Indoor'], num_res=1))

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (import order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TDR_LIB_PATH', os.path.join(_HERE, 'libtdr_hip.so'))   # override: profiling probe builds
 
-ABI_VERSION = 104      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
+ABI_VERSION = 105      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
 c_fp = C.c_void_p      # device pointers travel as integers
 i32, i64, f32 = C.c_int, C.c_int64, C.c_float
 
@@ -114,6 +114,18 @@ class TdrNafHeadFwdDesc(C.Structure):
                 ('mu', c_fp), ('rs', c_fp), ('xn', c_fp), ('xn_ns', i64), ('t1', c_fp), ('t1_ns', i64)]
 
 
+class TdrSfDynVecDesc(C.Structure):
+    _fields_ = [('N', i32), ('c', i32), ('GK', i32), ('KK', i32), ('d', i32), ('eps', f32), ('momentum', f32)] + \
+               [(k, c_fp) for k in ('ap', 'wconv', 'bn_w', 'bn_b', 'fc_w', 'fc_b', 'f0_w', 'f0_b', 'f1_w', 'f1_b', 'run_mean', 'run_var', 'nbt',
+                                    'taps', 'ah', 'al', 'xhat', 'rstd', 'z', 'att')]
+
+
+class TdrSfDynVecBwdDesc(C.Structure):
+    _fields_ = [('N', i32), ('c', i32), ('GK', i32), ('KK', i32), ('d', i32)] + \
+               [(k, c_fp) for k in ('ap', 'wconv', 'bn_w', 'fc_w', 'f0_w', 'f1_w', 'taps', 'xhat', 'rstd', 'z', 'att', 'dtaps', 'dah', 'dal',
+                                    'dap', 'g_wconv', 'g_bn_w', 'g_bn_b', 'g_fc_w', 'g_fc_b', 'g_f0_w', 'g_f0_b', 'g_f1_w', 'g_f1_b', 'ws')]
+
+
 class TdrStepGuard(C.Structure):
     _fields_ = [('scale', f32), ('inv_scale', f32), ('max_scale', f32), ('good', i32), ('growth_interval', i32),
                 ('step', i32), ('skipped', i32), ('finite', i32), ('bc1', f32), ('bc2_sqrt', f32)]
@@ -193,6 +205,21 @@ SIGNATURES = {
     'tdr_pack_weights_bx3_batch': (i32, [c_fp, i64, i32, i32, i32, i32, i32, c_fp, c_fp]),
     'tdr_sca_fwd': (i32, [c_fp, c_fp, c_fp, i32, i32, c_fp, c_fp]),
     'tdr_sca_bwd': (i32, [c_fp] * 8 + [i32, i32] + [c_fp] * 7 + [c_fp]),
+    # ---- un-guided SFNet (csrc/tdr_sfnet.hip)
+    'tdr_gelu_fwd': (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, i64, c_fp]),
+    'tdr_gelu_bwd': (i32, [c_fp, c_fp, c_fp, i64, c_fp]),
+    'tdr_subsample2': (i32, [c_fp, i32, i32, i32, c_fp, c_fp]),
+    'tdr_instnorm_fwd': (i32, [c_fp, c_fp, c_fp, f32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_instnorm_bwd': (i32, [c_fp] * 5 + [i32, i32, i32] + [c_fp] * 5),
+    'tdr_region_affine_fwd': (i32, [c_fp, i64, c_fp, c_fp, f32, i32, i32, i32, i32, i32, c_fp, i64, c_fp, c_fp]),
+    'tdr_region_affine_bwd': (i32, [c_fp, i64, c_fp, i64, c_fp, c_fp, f32, c_fp, i32, i32, i32, i32, i32, c_fp, i64, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_sf_dyn_vec_fwd': (i32, [C.POINTER(TdrSfDynVecDesc), c_fp]),
+    'tdr_sf_dyn_vec_bwd': (i32, [C.POINTER(TdrSfDynVecBwdDesc), c_fp]),
+    'tdr_sf_dynfilt_fwd': (i32, [c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_sf_dynfilt_bwd_reduce': (i32, [c_fp, c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
+    'tdr_sf_dynfilt_bwd_dx': (i32, [c_fp] * 5 + [i32] * 6 + [c_fp, i64, c_fp]),
+    'tdr_convt4_weight_to_3x3': (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_convt4_grad_from_3x3': (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_scaled_conv_param_grads': (i32, [c_fp] * 5 + [i32, i32] + [c_fp] * 3 + [c_fp]),
     'tdr_chansum_ws_floats': (i64, [i32, i32, i32]),
     'tdr_channel_sum': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp, c_fp]),

@@ -2017,3 +2017,174 @@ def add_relu(a, b):
     out = torch.empty_like(a)
     check(_lib.load().tdr_add_relu(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()), 'tdr_add_relu')
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# un-guided SFNet (csrc/tdr_sfnet.hip; models/archs/sfnet_arch_utils.py:76-265 of the reference)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def gelu_fwd(x, bias=None):
+    """-> (z, y): z = x + bias[channel] (x itself without a bias), y = gelu(z) (exact erf).  x [N, C, H, W] dense."""
+    N, Cc, H, W = x.shape
+    y = torch.empty_like(x)
+    z = x if bias is None else torch.empty_like(x)
+    check(_lib.load().tdr_gelu_fwd(x.data_ptr(), _p(bias), Cc, H * W, z.data_ptr() if bias is not None else 0, y.data_ptr(), x.numel(),
+                                   _stream()), 'tdr_gelu_fwd')
+    return z, y
+
+
+def gelu_bwd(dy, z):
+    dz = torch.empty_like(z)
+    check(_lib.load().tdr_gelu_bwd(dy.data_ptr(), z.data_ptr(), dz.data_ptr(), z.numel(), _stream()), 'tdr_gelu_bwd')
+    return dz
+
+
+def subsample2(x):
+    """F.interpolate(scale_factor=0.5), nearest: x[..., ::2, ::2]"""
+    N, Cc, H, W = x.shape
+    y = torch.empty(N, Cc, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_subsample2(x.data_ptr(), N * Cc, H, W, y.data_ptr(), _stream()), 'tdr_subsample2')
+    return y
+
+
+def instnorm_fwd(x, w, b, eps=1e-5):
+    N, Cc, H, W = x.shape
+    y = torch.empty_like(x)
+    mu = torch.empty(N * Cc, dtype=torch.float32, device=x.device)
+    rs = torch.empty_like(mu)
+    check(_lib.load().tdr_instnorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps), N, Cc, H * W, y.data_ptr(), mu.data_ptr(),
+                                       rs.data_ptr(), _stream()), 'tdr_instnorm_fwd')
+    return y, mu, rs
+
+
+def instnorm_bwd(dy, x, mu, rs, w):
+    N, Cc, H, W = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dw)
+    ws = torch.empty(2 * N * Cc, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_instnorm_bwd(dy.data_ptr(), x.data_ptr(), mu.data_ptr(), rs.data_ptr(), w.data_ptr(), N, Cc, H * W, dx.data_ptr(),
+                                       dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream()), 'tdr_instnorm_bwd')
+    return dx, dw, db
+
+
+def region_affine_fwd(x, ph, pl, shift, q, out):
+    """out = x * A + mean_region(x) * B with A = ph + shift, B = pl - A over the q x q equal blocks of the plane (Gap: q = 1, shift = 1,
+    (fscale_h, fscale_d); Patch_ap: q = 2, shift = 0, (h, l)); x / out: dense-NCHW views (channel slices of bigger buffers are fine).
+    Returns the region means [N, C, q * q] (kept for the backward pass)."""
+    N, Cc, H, W = x.shape
+    mean = torch.empty(N, Cc, q * q, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_region_affine_fwd(x.data_ptr(), _dense_nchw(x), ph.data_ptr(), pl.data_ptr(), float(shift), q, N, Cc, H, W,
+                                            out.data_ptr(), _dense_nchw(out), mean.data_ptr(), _stream()), 'tdr_region_affine_fwd')
+    return mean
+
+
+def region_affine_bwd(dy, x, ph, pl, shift, mean, q, dx):
+    """-> (dph, dpl) [C * q * q]; dx (a dense-NCHW view) receives the data gradient"""
+    N, Cc, H, W = x.shape
+    J = Cc * q * q
+    dph = torch.empty(J, dtype=torch.float32, device=x.device)
+    dpl = torch.empty_like(dph)
+    ws = torch.empty(2 * N * J, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_region_affine_bwd(dy.data_ptr(), _dense_nchw(dy), x.data_ptr(), _dense_nchw(x), ph.data_ptr(), pl.data_ptr(),
+                                            float(shift), mean.data_ptr(), q, N, Cc, H, W, dx.data_ptr(), _dense_nchw(dx), dph.data_ptr(),
+                                            dpl.data_ptr(), ws.data_ptr(), _stream()), 'tdr_region_affine_bwd')
+    return dph, dpl
+
+
+def sf_dyn_vec_fwd(ap, P, pre, k, groups=8):
+    """the pooled-vector pipeline of dynamic_filter + SFconv (one workgroup): -> (taps [N, G k k], ah [N, c], al [N, c], saved).
+    P[pre + 'bn.running_mean' / 'running_var' / 'num_batches_tracked'] are moved in place (training-mode BatchNorm)."""
+    N, c = ap.shape
+    KK, GK = k * k, groups * k * k
+    dd = P[pre + 'modulate.fc.weight'].shape[0]
+    dev = ap.device
+    taps = torch.empty(N, GK, dtype=torch.float32, device=dev)
+    ah = torch.empty(N, c, dtype=torch.float32, device=dev)
+    al = torch.empty_like(ah)
+    xhat = torch.empty(N, GK, dtype=torch.float32, device=dev)
+    rstd = torch.empty(GK, dtype=torch.float32, device=dev)
+    z = torch.empty(N, dd, dtype=torch.float32, device=dev)
+    att = torch.empty(N, 2 * c, dtype=torch.float32, device=dev)
+    d = _lib.TdrSfDynVecDesc()
+    d.N, d.c, d.GK, d.KK, d.d, d.eps, d.momentum = N, c, GK, KK, dd, 1e-5, 0.1
+    d.ap, d.wconv, d.bn_w, d.bn_b = ap.data_ptr(), P[pre + 'conv.weight'].data_ptr(), P[pre + 'bn.weight'].data_ptr(), P[pre + 'bn.bias'].data_ptr()
+    d.fc_w, d.fc_b = P[pre + 'modulate.fc.weight'].data_ptr(), P[pre + 'modulate.fc.bias'].data_ptr()
+    d.f0_w, d.f0_b = P[pre + 'modulate.fcs.0.weight'].data_ptr(), P[pre + 'modulate.fcs.0.bias'].data_ptr()
+    d.f1_w, d.f1_b = P[pre + 'modulate.fcs.1.weight'].data_ptr(), P[pre + 'modulate.fcs.1.bias'].data_ptr()
+    d.run_mean, d.run_var = P[pre + 'bn.running_mean'].data_ptr(), P[pre + 'bn.running_var'].data_ptr()
+    nbt = P.get(pre + 'bn.num_batches_tracked')
+    d.nbt = nbt.data_ptr() if nbt is not None and nbt.is_cuda else 0
+    d.taps, d.ah, d.al, d.xhat, d.rstd, d.z, d.att = (t.data_ptr() for t in (taps, ah, al, xhat, rstd, z, att))
+    check(_lib.load().tdr_sf_dyn_vec_fwd(C.byref(d), _stream()), 'tdr_sf_dyn_vec_fwd')
+    return taps, ah, al, (ap, taps, xhat, rstd, z, att)
+
+
+def sf_dyn_vec_bwd(dtaps, dah, dal, P, pre, k, saved, groups=8):
+    """-> (dap [N, c], {parameter name (without pre): gradient})"""
+    ap, taps, xhat, rstd, z, att = saved
+    N, c = ap.shape
+    KK, GK = k * k, groups * k * k
+    dd = z.shape[1]
+    dev = ap.device
+    dap = torch.empty(N, c, dtype=torch.float32, device=dev)
+    G = {n: torch.empty_like(P[pre + n]) for n in ('conv.weight', 'bn.weight', 'bn.bias', 'modulate.fc.weight', 'modulate.fc.bias',
+                                                   'modulate.fcs.0.weight', 'modulate.fcs.0.bias', 'modulate.fcs.1.weight', 'modulate.fcs.1.bias')}
+    ws = torch.empty(N * (2 * c + dd + GK), dtype=torch.float32, device=dev)
+    d = _lib.TdrSfDynVecBwdDesc()
+    d.N, d.c, d.GK, d.KK, d.d = N, c, GK, KK, dd
+    d.ap, d.wconv, d.bn_w, d.fc_w = ap.data_ptr(), P[pre + 'conv.weight'].data_ptr(), P[pre + 'bn.weight'].data_ptr(), P[pre + 'modulate.fc.weight'].data_ptr()
+    d.f0_w, d.f1_w = P[pre + 'modulate.fcs.0.weight'].data_ptr(), P[pre + 'modulate.fcs.1.weight'].data_ptr()
+    d.taps, d.xhat, d.rstd, d.z, d.att = taps.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), z.data_ptr(), att.data_ptr()
+    d.dtaps, d.dah, d.dal, d.dap = dtaps.data_ptr(), dah.data_ptr(), dal.data_ptr(), dap.data_ptr()
+    d.g_wconv, d.g_bn_w, d.g_bn_b = G['conv.weight'].data_ptr(), G['bn.weight'].data_ptr(), G['bn.bias'].data_ptr()
+    d.g_fc_w, d.g_fc_b = G['modulate.fc.weight'].data_ptr(), G['modulate.fc.bias'].data_ptr()
+    d.g_f0_w, d.g_f0_b = G['modulate.fcs.0.weight'].data_ptr(), G['modulate.fcs.0.bias'].data_ptr()
+    d.g_f1_w, d.g_f1_b = G['modulate.fcs.1.weight'].data_ptr(), G['modulate.fcs.1.bias'].data_ptr()
+    d.ws = ws.data_ptr()
+    check(_lib.load().tdr_sf_dyn_vec_bwd(C.byref(d), _stream()), 'tdr_sf_dyn_vec_bwd')
+    return dap, G
+
+
+def sf_dynfilt_fwd(x, taps, ah, al, k, groups=8):
+    """x: dense-NCHW view -> (low, mix) dense [N, C, H, W]"""
+    N, Cc, H, W = x.shape
+    low = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x.device)
+    mix = torch.empty_like(low)
+    check(_lib.load().tdr_sf_dynfilt_fwd(x.data_ptr(), _dense_nchw(x), taps.data_ptr(), ah.data_ptr(), al.data_ptr(), N, Cc, groups, H, W, k,
+                                         low.data_ptr(), mix.data_ptr(), _stream()), 'tdr_sf_dynfilt_fwd')
+    return low, mix
+
+
+def sf_dynfilt_bwd_reduce(dmix, x, low, ah, al, k, groups=8):
+    N, Cc, H, W = x.shape
+    dah = torch.empty(N, Cc, dtype=torch.float32, device=x.device)
+    dal = torch.empty_like(dah)
+    dtaps = torch.empty(N, groups * k * k, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_sf_dynfilt_bwd_reduce(dmix.data_ptr(), x.data_ptr(), _dense_nchw(x), low.data_ptr(), ah.data_ptr(), al.data_ptr(), N,
+                                                Cc, groups, H, W, k, dah.data_ptr(), dal.data_ptr(), dtaps.data_ptr(), _stream()),
+          'tdr_sf_dynfilt_bwd_reduce')
+    return dah, dal, dtaps
+
+
+def sf_dynfilt_bwd_dx(dmix, taps, ah, al, dap, k, dx, groups=8):
+    N, Cc, H, W = dmix.shape
+    check(_lib.load().tdr_sf_dynfilt_bwd_dx(dmix.data_ptr(), taps.data_ptr(), ah.data_ptr(), al.data_ptr(), dap.data_ptr(), N, Cc, groups, H,
+                                            W, k, dx.data_ptr(), _dense_nchw(dx), _stream()), 'tdr_sf_dynfilt_bwd_dx')
+    return dx
+
+
+def convt4_weight_to_3x3(w, b):
+    """ConvTranspose2d(4, 2, 1) weight [Cin, Cout, 4, 4] (+ bias) -> the 3x3 / pad 1 convolution [4 Cout, Cin, 3, 3] whose PixelShuffle(2)
+    is the transposed convolution (+ bias repeated per parity)"""
+    Cin, Cout = w.shape[0], w.shape[1]
+    w3 = torch.empty(4 * Cout, Cin, 3, 3, dtype=torch.float32, device=w.device)
+    b4 = torch.empty(4 * Cout, dtype=torch.float32, device=w.device) if b is not None else None
+    check(_lib.load().tdr_convt4_weight_to_3x3(w.data_ptr(), _p(b), Cin, Cout, w3.data_ptr(), _p(b4), _stream()), 'tdr_convt4_weight_to_3x3')
+    return w3, b4
+
+
+def convt4_grad_from_3x3(dw3, db4, Cin, Cout):
+    dw = torch.empty(Cin, Cout, 4, 4, dtype=torch.float32, device=dw3.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=dw3.device) if db4 is not None else None
+    check(_lib.load().tdr_convt4_grad_from_3x3(dw3.data_ptr(), _p(db4), Cin, Cout, dw.data_ptr(), _p(db), _stream()), 'tdr_convt4_grad_from_3x3')
+    return dw, db
