@@ -206,3 +206,46 @@ def test_module_mirror_trains_like_the_oracle(K):
         assert md(p.grad, P[k].grad) <= 2e-3 * P[k].grad.abs().max().item() + 1e-7, k
     with pytest.raises(NotImplementedError):
         define_network(dict(type='SFNet', mode=['test', 'Indoor'], num_res=1))
+
+
+def test_reference_default_depth_num_res_16_against_the_oracle():
+    """the reference's default depth -- num_res = 16: 96 ResBlocks (six with the dynamic filter pair), 192 3x3 convolutions in series -- at
+    2 x 128x128 in the library default arithmetic, straight against the float64 oracle's autograd: outputs at the three scales (1e-4),
+    the moved BatchNorm buffers, every parameter gradient (5e-3 of its tensor maximum; measured margins are printed)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import kernels as KK, sfnet_engine as SE
+    assert KK.MATH == 'bx3'
+    torch.set_num_threads(16)
+    num_res = 16
+    sd = SO.synth_state(num_res, seed=41)
+    # (depth 16 with O(1)-gain random blocks: keep the residual branches small so that activations stay O(1) through 96 blocks)
+    for k in sd:
+        if k.endswith('conv2.main.0.weight'):
+            sd[k] = sd[k] * 0.2
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(42))
+    P = {k: v.clone().cuda() for k, v in sd.items()}
+    outs, saved = SE.net_fwd(P, x.cuda(), num_res)
+    gos = [rnd(*o.shape, seed=50 + i) / o.numel() for i, o in enumerate(outs)]
+    G = SE.net_bwd([go.cuda() for go in gos], P, saved)
+    torch.cuda.synchronize()
+    Pr = {k: (v.clone().double().requires_grad_(True) if not SO.is_buffer(k) else (v.clone().double() if v.dtype.is_floating_point else v.clone()))
+          for k, v in sd.items()}
+    bufs = {}
+    ro = SO.sfnet_forward(Pr, x.double(), num_res, bufs)
+    sum((o * go.double()).sum() for o, go in zip(ro, gos)).backward()
+    eo = max(md(a, b) for a, b in zip(outs, ro))
+    for k, v in bufs.items():
+        assert (P[k].cpu().double() - v.double()).abs().max().item() <= 1e-5 * max(1.0, v.double().abs().max().item()), k
+    worst = (0.0, None)
+    for k, p in Pr.items():
+        if SO.is_buffer(k) or p.grad is None or (k.endswith('main.3.main.0.bias') and k.startswith('SCM')):
+            continue
+        e = md(G[k].reshape(p.shape), p.grad) / max(p.grad.abs().max().item(), 1e-300)
+        worst = max(worst, (e, k))
+    print(f'SFNet num_res=16, 2 x 128x128 [bx3] vs float64 oracle: outputs {eo:.2e}; worst parameter gradient {worst[0]:.2e} of its tensor maximum at {worst[1]}')
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'margins')
+    os.makedirs(root, exist_ok=True)
+    with open(os.path.join(root, 'sfnet_num_res16.txt'), 'w') as fh:
+        fh.write(f'outputs max-abs {eo:.3e}; worst gradient {worst[0]:.3e} of its tensor maximum at {worst[1]}\n')
+    assert eo < 1e-4 and worst[0] < 5e-3, (eo, worst)
