@@ -206,34 +206,46 @@ def test_1100_steps_w8_128_cross_the_range_survey():
 # same pair, and the parameter UPDATES are compared -- 300 times along the oracle's own trajectory, so the arithmetic is probed at 300
 # different points of the training run (moments with history, decayed learning rates) and no error is carried from one step to the next.
 # ---------------------------------------------------------------------------------------------------------------------------------
-def _teacher_forced(mode, net, cfg, seed, data, steps):
+def _oracle_trajectory(cfg, seed, data, steps):
+    """the oracle trainer's own run, recorded once: per step the state BEFORE it (parameters, both AdamW moments), the loss and the parameters after"""
+    tr = O.OracleTrainer(O.synth_params(cfg, seed=seed), cfg)
+    traj = []
+    for it in range(1, steps + 1):
+        t = it - 1
+        tr.set_lrs(O.cosine_restart_cyclic_lr(t, 2e-4, PERIODS, RW, EM), O.cosine_restart_cyclic_lr(t, 1e-4, PERIODS, RW, EM))
+        before = {k: v.detach().clone() for k, v in tr.P.items()}
+        m = {k: v.clone() for k, v in tr.m.items()}
+        v2 = {k: v.clone() for k, v in tr.v.items()}
+        lq, gt, ref = data[t % len(data)]
+        loss = tr.step(lq, gt, ref)[0]
+        traj.append((before, m, v2, loss, {k: v.detach().clone() for k, v in tr.P.items()}))
+    return traj
+
+
+def _teacher_forced(mode, net, traj, data):
     from textualdegremoval_amd import kernels as K
     from textualdegremoval_amd.models import create_model
     prev = K.MATH
     K.set_math(mode)
     try:
         model = create_model(_opt(net))
-        tr = O.OracleTrainer(O.synth_params(cfg, seed=seed), cfg)
         named = dict(model.net_g.named_parameters())
-        assert set(named) == set(tr.P), 'the mirror and the oracle name the same parameters'
+        assert set(named) == set(traj[0][0]), 'the mirror and the oracle name the same parameters'
         opt = model.optimizer_g
         rel_l2, rel_max, loss_d, worst = [], [], [], ('', 0.0)
-        for it in range(1, steps + 1):
+        for it, (before, m_or, v_or, l_or, after) in enumerate(traj, start=1):
             t = it - 1
-            tr.set_lrs(O.cosine_restart_cyclic_lr(t, 2e-4, PERIODS, RW, EM), O.cosine_restart_cyclic_lr(t, 1e-4, PERIODS, RW, EM))
             # ---- teacher forcing: parameters, both moments and the step count of the oracle, in place (the captured graph keeps its pointers)
             with torch.no_grad():
                 for k, p in named.items():
-                    p.copy_(tr.P[k].detach())
+                    p.copy_(before[k])
                     st = opt.state.get(p)
                     if st and 'exp_avg' in st:
-                        st['exp_avg'].copy_(tr.m[k])
-                        st['exp_avg_sq'].copy_(tr.v[k])
+                        st['exp_avg'].copy_(m_or[k])
+                        st['exp_avg_sq'].copy_(v_or[k])
             if opt.guard is not None:
                 opt.guard.write(step=t)
-            before = {k: v.detach().clone() for k, v in tr.P.items()}
             lq, gt, ref = data[t % len(data)]
-            l_or = tr.step(lq, gt, ref)[0]
             model.update_learning_rate(it, warmup_iter=-1)
             model.feed_train_data({'lq': lq, 'gt': gt, 'ref': ref})
             model.optimize_parameters(it)
@@ -241,7 +253,7 @@ def _teacher_forced(mode, net, cfg, seed, data, steps):
             num = den = 0.0
             mx = 0.0
             for k, p in named.items():
-                d_or = (tr.P[k].detach() - before[k]).double()
+                d_or = (after[k] - before[k]).double()
                 d_hip = (p.detach().cpu() - before[k]).double()
                 num += float(((d_hip - d_or) ** 2).sum())
                 den += float((d_or ** 2).sum())
@@ -279,7 +291,8 @@ def test_teacher_forced_300_steps_w8_128():
     cfg = O.default_cfg(width=8, nf=8, ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
     data = [O.synth_pair(1, 128, 128, seed=4000 + i) for i in range(8)]
     steps = 300
-    res = {m: _teacher_forced(m, net, cfg, 3, data, steps) for m in ('f32', 'bx3')}
+    traj = _oracle_trajectory(cfg, 3, data, steps)                # (one oracle run serves both arithmetics)
+    res = {m: _teacher_forced(m, net, traj, data) for m in ('f32', 'bx3')}
     out = os.path.join(ROOT, 'gpurun_out', 'margins')
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, 'teacher_forced_w8_128.json'), 'w') as fh:

@@ -215,7 +215,15 @@ def test_reference_default_depth_num_res_16_against_the_oracle():
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from textualdegremoval_amd import kernels as KK, sfnet_engine as SE
-    assert KK.MATH == 'bx3'
+    prev = KK.MATH
+    KK.set_math('bx3')
+    try:
+        _num_res_16_body(KK, SE)
+    finally:
+        KK.set_math(prev)
+
+
+def _num_res_16_body(KK, SE):
     torch.set_num_threads(16)
     num_res = 16
     sd = SO.synth_state(num_res, seed=41)
