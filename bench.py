@@ -780,6 +780,9 @@ def _main_body(a, world, rank, local, enc):
                     PEAK_BX3, '2.5 PFLOP/s dense bf16 MFMA / 6 cross products = fp32-equivalent peak of the split scheme'),
                 2: ('conv_bx3_kernel<KH=3,S=1,SCH_HX2> (fp32 tensors in, 2-way fp16 split per consumer, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)',
                     PEAK_HX2, '2.5 PFLOP/s dense f16 MFMA / 3 cross products = fp32-equivalent peak of the split scheme'),
+                3: ('conv_bx3_kernel<KH=3,S=1,H1> (fp32 tensors in, operands rounded to ONE fp16 plane per consumer, 1 x v_mfma_f32_32x32x16_f16 per '
+                    'product, fp32 accumulate -- the plain fp16-MFMA arithmetic of BASELINE configs[4])',
+                    PEAK_BF16, '2.5 PFLOP/s dense f16 MFMA (one product per multiply)'),
                 'p16': ('conv3x3_p16_kernel (pre-split fp16 pair planes in and out, both operands by LDS-DMA, 3 x v_mfma_f32_32x32x16_f16 per fp32 product)',
                         PEAK_HX2, '2.5 PFLOP/s dense f16 MFMA / 3 cross products = fp32-equivalent peak of the split scheme'),
                 'p24': ('conv3x3_p16_kernel<PF_TRI> (pre-split bf16 TRIPLE planes in and out -- h + m + l == the fp32 value exactly --, both operands by '
@@ -810,7 +813,7 @@ def _main_body(a, world, rank, local, enc):
             # rounds 1-3 reported (one kernel ran the whole family then), priced against the ceiling of the scheme that carries most of it.
             lead = max(subs, key=lambda k: subs[k]['_total_ms'])
             split = [k for k in subs if CONV[k][1] == CONV[lead][1]]          # kernels priced against the same ceiling
-            prefixes = {0: 'conv_mfma_kernel<3, 1, 1,', 1: 'conv_bx3_kernel<3, 1,', 2: 'conv_bx3_kernel<3, 1,', 'p16': 'conv3x3_p16_kernel',
+            prefixes = {0: 'conv_mfma_kernel<3, 1, 1,', 1: 'conv_bx3_kernel<3, 1,', 2: 'conv_bx3_kernel<3, 1,', 3: 'conv_bx3_kernel<3, 1,', 'p16': 'conv3x3_p16_kernel',
                         'p24': 'conv3x3_p16_kernel'}
             for k in subs:
                 subs[k]['traffic'] = pmc_traffic([prefixes[k]])[0]
@@ -834,7 +837,7 @@ def _main_body(a, world, rank, local, enc):
                     '`problems` = weight gradients they carry)'}
         for k in sorted({r[4][1] for r in recs if r[4][0] == 'wgrad'}, key=str):
             e = entry([r for r in recs if r[4] == ('wgrad', k)], WG.get(k, f'wgrad KH={k}'),
-                      PEAK_HX2 if K.MATH in ('hx2', 'h1') else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32),
+                      PEAK_BF16 if K.MATH == 'h1' else (PEAK_HX2 if K.MATH == 'hx2' else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32)),
                       'fp32-equivalent ceiling of the step\'s operand scheme; time = kernel + its fixed-order split-K reduction (HIP events around both)')
             # measured bytes per launch: the kernel's own traffic plus its split-K reduction's (one reduction per weight-gradient launch)
             wpre = {3: ('wgrad_bx3_kernel<3,', 'wgrad_reduce_kernel'), 1: ('wgrad1x1_', 'wgrad_reduce_kernel'),
@@ -852,7 +855,7 @@ def _main_body(a, world, rank, local, enc):
                  'naf_head_bwd': 'naf_tail_bwd_kernel<HEAD=true> (conv1^T -> norm1 bwd + skip)',
                  'dwsg_fwd': 'dwsg_stencil_kernel (depthwise 3x3 + SimpleGate + SCA pool partials)',
                  'dwsg_bwd': 'dwsg_bwd_fused_kernel (one-pass depthwise + SimpleGate backward) + its parameter-gradient partials'}
-        pk_split = PEAK_HX2 if K.MATH in ('hx2', 'h1') else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32)
+        pk_split = PEAK_BF16 if K.MATH == 'h1' else (PEAK_HX2 if K.MATH == 'hx2' else (PEAK_BX3 if K.MATH == 'bx3' else PEAK_F32))
         for nm in CHAIN:
             rr = [r for r in recs if r[4] == ('chain', nm)]
             if not rr:
