@@ -531,7 +531,8 @@ int tdr_vit_assemble(float* tok, const float* cls, const float* pos, int B, int 
 /* multi-head softmax(q k^T scale) v over the first T columns; qkv [B][3C][LD] -> out [B][C][LD] (padding columns zeroed);
  * head dim C/heads in {16,32,64} (attention.py:56-71) */
 int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int T, int LD, float scale, float* out, void* stream);
-/* the same with the arithmetic named: math 0 = exact fp32 MFMA (what tdr_attention_fwd runs), 2 = 2-way fp16 split (3 f16 MFMA
+/* the same with the arithmetic named: math 0 = exact fp32 MFMA (what tdr_attention_fwd runs), 1 = 3-way bf16 split (q, k, v and P as three bf16
+ * planes, 6 bf16 MFMA products per fp32 product, fp32 accumulate and softmax: the default arithmetic, any fp32 exponent), 2 = 2-way fp16 split (3 f16 MFMA
  * products per fp32 product, fp32 accumulate and softmax) for the frozen no-grad ViTs -- q, k, v must lie in the fp16 range;
  * 3 = plain fp16 MFMA (one product, reduced precision) for the DINOv2 window matcher only: its sole output is an arg-max */
 int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, int flat,

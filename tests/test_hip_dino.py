@@ -270,3 +270,29 @@ def test_default_matcher_on_the_token_major_triple_planes():
                 assert (cm - cf).abs().max().item() < 1e-4 and (cm - cc).abs().max().item() < 1e-5
     finally:
         K.set_math(prev)
+
+
+@pytest.mark.parametrize('shape', [(3, 12, 64, 300), (2, 16, 80, 257), (2, 2, 32, 97), (1, 4, 16, 64)])
+def test_attention_on_the_bf16_split_against_float64(shape):
+    """tdr_attention_fwd_math code 1 (round 6: the frozen ViTs' attention in the default arithmetic -- q, k, v and P as three bf16 planes,
+    six products, fp32 softmax) against a float64 reference and beside the exact fp32 MFMA kernel it replaces there: at least as close to
+    float64 as the exact kernel (measured 8.4e-6 against 1.4e-5 at the matcher's shape), padding columns zero, ragged token counts"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from textualdegremoval_amd import _lib, kernels as K
+    lib = _lib.load()
+    B, heads, hd, T = shape
+    LD = (T + 31) // 32 * 32
+    g = torch.Generator().manual_seed(hd + T)
+    qkv = (torch.randn(B, 3 * heads * hd, LD, generator=g) * 1.5).cuda()
+    scale = hd ** -0.5
+    outs = {}
+    for math in (0, 1):
+        out = torch.full((B, heads * hd, LD), 7.0, device='cuda')
+        _lib.check(lib.tdr_attention_fwd_math(qkv.data_ptr(), B, heads * hd, heads, T, LD, scale, math, 0, out.data_ptr(), K._stream()), 'attn')
+        outs[math] = out.cpu().double()
+    q, k, v = (t.double().cpu().view(B, heads, hd, LD)[..., :T] for t in qkv.chunk(3, 1))
+    ref = torch.einsum('bhqk,bhdk->bhdq', torch.softmax(torch.einsum('bhdq,bhdk->bhqk', q, k) * scale, -1), v).reshape(B, heads * hd, T)
+    e0, e1 = (outs[0][..., :T] - ref).abs().max().item(), (outs[1][..., :T] - ref).abs().max().item()
+    assert e1 < 2e-5 and e1 <= 1.5 * e0 + 2e-6, (e0, e1)
+    assert float(outs[1][..., T:].abs().max()) == 0.0 if LD > T else True

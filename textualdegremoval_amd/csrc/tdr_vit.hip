@@ -376,6 +376,183 @@ __global__ __launch_bounds__(256) void attn_fwd_hx2_kernel(AttnArgs a) {
     }
 }
 
+// ---- the same skeleton in the DEFAULT arithmetic (TDR_MATH=bx3; round 6): q, k, v and P as three bf16 planes (h + m + l = the fp32 value
+// to 24+ bits on fp32's exponent range), six v_mfma_f32_32x32x16_bf16 products per operand pair (lh hl mm mh hm hh, small cross terms first),
+// fp32 accumulation and softmax -- the frozen ViTs' attention (DINOv2 window matcher, CLIP image encoder) ran on the exact fp32 MFMA kernel
+// in this mode (157 TF peak: 1.37 ms per matcher launch at 84 TF); the 6-product ceiling is 417 TF.  Planes are packed pairwise by
+// tdr_split3_bf16 (two values per dword); an A / B fragment is four dwords = 8 bf16.
+typedef __bf16 vb8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ vb8 as_vb8(uint4 u) { return __builtin_bit_cast(vb8, u); }
+
+template <int HD, int KT>
+__global__ __launch_bounds__(256) void attn_fwd_bx3_kernel(AttnArgs a) {
+    constexpr int NDT = (HD + 31) / 32, KS = HD / 16, NOCT = HD / 8, NKB = KT / 32;
+    constexpr int VP = KT + 8;                              // 16-bit elements per d row of the V tile
+    constexpr int KIT = (NOCT * KT + 255) / 256;            // K slots (8 d x 1 key, 16 bytes per plane) per thread and tile
+    constexpr int VIT = HD * KT / 256;                      // V elements per thread and tile (even)
+    static_assert(HD % 16 == 0 && (KT == 32 || KT == 64) && VIT % 2 == 0, "head dim a multiple of 16, key tile 32 or 64");
+    __shared__ __attribute__((aligned(16))) uint4 sK[3][NOCT][KT];                 // [plane][d octet][key]: one fragment per slot
+    __shared__ __attribute__((aligned(16))) unsigned short sV[3][NDT * 32][VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
+    const int T = a.Tk, LDq = a.LDq;
+    float* out = a.out;
+    const float* Q = a.q + (long)b * a.q_bs + (long)h * HD * a.qcs;
+    const float* Kp = a.k + (long)b * a.kv_bs + (long)h * HD * a.kcs;
+    const float* Vp = a.v + (long)b * a.kv_bs + (long)h * HD * a.kcs;
+    const bool qok = q0 + j < a.Tq;
+    constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};          // (A plane, B plane): lh hl mm mh hm hh
+    uint4 qp[3][KS];                                        // B operand of S^T: Q[q = j][d = 16 s + 8 kk + i] * scale, three planes
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        unsigned pl[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v0 = qok ? Q[(long)(16 * s + 8 * kk + 2 * i) * a.qcs + q0 + j] * a.scale : 0.f;
+            const float v1 = qok ? Q[(long)(16 * s + 8 * kk + 2 * i + 1) * a.qcs + q0 + j] * a.scale : 0.f;
+            tdr_split3_bf16(v0, v1, pl[0][i], pl[1][i], pl[2][i]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) qp[p][s] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+    }
+    for (int e = tid; e < 3 * (NDT * 32 - HD) * VP; e += 256)   // d rows beyond the head dim (HD = 16, 80): zero once
+        (&sV[0][0][0])[(e / ((NDT * 32 - HD) * VP)) * (NDT * 32 * VP) + HD * VP + e % ((NDT * 32 - HD) * VP)] = 0;
+    float rk[KIT][8], rv[VIT];
+    auto load_tile = [&](int key0) {
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int slot = tid + 256 * it, oc = slot / KT, kx = slot % KT;
+            const bool ok = oc < NOCT && key0 + kx < T;
+            const int kc = key0 + kx < T ? key0 + kx : T - 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rk[it][i] = ok ? Kp[(long)(8 * (oc < NOCT ? oc : 0) + i) * a.kcs + kc] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int e = tid + 256 * it, d = e / KT, kx = e % KT;
+            const int kc = key0 + kx < T ? key0 + kx : T - 1;
+            const float vv = Vp[(long)d * a.kcs + kc];
+            rv[it] = key0 + kx < T ? vv : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int slot = tid + 256 * it, oc = slot / KT, kx = slot % KT;
+            unsigned pl[3][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tdr_split3_bf16(rk[it][2 * i], rk[it][2 * i + 1], pl[0][i], pl[1][i], pl[2][i]);
+            if (oc < NOCT) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) sK[p][oc][kx] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; it += 2) {
+            const int e0 = tid + 256 * it, e1 = tid + 256 * (it + 1);
+            unsigned pl[3];
+            tdr_split3_bf16(rv[it], rv[it + 1], pl[0], pl[1], pl[2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                sV[p][e0 / KT][e0 % KT] = (unsigned short)(pl[p] & 0xffffu);
+                sV[p][e1 / KT][e1 % KT] = (unsigned short)(pl[p] >> 16);
+            }
+        }
+    };
+    f32x16 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    load_tile(0);
+    for (int key0 = 0; key0 < T; key0 += KT) {
+        __syncthreads();                                   // everyone is done with the previous K/V tile
+        store_tile();
+        __syncthreads();
+        if (key0 + KT < T) load_tile(key0 + KT);
+        f32x16 st[NKB];
+        float mx = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                uint4 kf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) kf[p] = sK[p][2 * s + kk][kb * 32 + j];
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_vb8(kf[SA[q]]), as_vb8(qp[SB[q]][s]), st[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                st[kb][r] = key < T ? st[kb][r] : -1e30f;
+                mx = fmaxf(mx, st[kb][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                st[kb][r] = key < T ? __expf(st[kb][r] - mnew) : 0.f;
+                sum += st[kb][r];
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float alpha = __expf(m - mnew);
+        l = l * alpha + sum;
+        m = mnew;
+        uint4 pp[3][2 * NKB];                               // P^T in 16-key steps, in the accumulator's row order, three planes
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                unsigned pl[3][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tdr_split3_bf16(st[kb][8 * s + 2 * i], st[kb][8 * s + 2 * i + 1], pl[0][i], pl[1][i], pl[2][i]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pp[p][2 * kb + s] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+            }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            const int d = dt * 32 + j;
+#pragma unroll
+            for (int s = 0; s < 2 * NKB; ++s) {
+                const int kb = (s >> 1) * 32 + 16 * (s & 1) + 4 * kk;
+                uint4 vf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const uint2 a0 = *reinterpret_cast<const uint2*>(&sV[p][d][kb]), a1 = *reinterpret_cast<const uint2*>(&sV[p][d][kb + 8]);
+                    vf[p] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_vb8(vf[SA[q]]), as_vb8(pp[SB[q]][s]), o[dt], 0, 0, 0);
+            }
+        }
+    }
+    const float inv = 1.f / l;
+    if (q0 + j < LDq) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (d < HD) out[(long)b * a.out_bs + (long)(h * HD + d) * a.qcs + q0 + j] = qok ? o[dt][r] * inv : 0.f;
+            }
+        if (a.lse && kk == 0) a.lse[((long)b * gridDim.y + h) * LDq + q0 + j] = qok ? m + __logf(l) : 0.f;
+    }
+}
+
 // ---- backward (injected cross-attention of the stage-A trainers, main_train_i2t_mapping.py:197-233) ----------------
 // Two deterministic passes instead of one with atomics:
 //   attn_bwd_dq : one wave per 32 queries, walks the key tiles (same skeleton as the forward: S^T, then dP^T = V dO^T
@@ -674,6 +851,14 @@ static int attn_fwd_launch(const AttnArgs& a, int B, int heads, hipStream_t st, 
         TDR_LAUNCH_CHECK("attention_fwd_h1");
         return TDR_OK;
     }
+    if (math == 1 && (hd == 80 || hd == 64 || hd == 32 || hd == 16)) {      // 3-way bf16 split: the default arithmetic (TDR_MATH=bx3)
+        if (hd == 80) hipLaunchKernelGGL((attn_fwd_bx3_kernel<80, 32>), grid, dim3(256), 0, st, a);
+        else if (hd == 64) hipLaunchKernelGGL((attn_fwd_bx3_kernel<64, 32>), grid, dim3(256), 0, st, a);     // (64-key tiles: 919 vs 740 us at the matcher's shape)
+        else if (hd == 32) hipLaunchKernelGGL((attn_fwd_bx3_kernel<32, 32>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_bx3_kernel<16, 32>), grid, dim3(256), 0, st, a);
+        TDR_LAUNCH_CHECK("attention_fwd_bx3");
+        return TDR_OK;
+    }
     if ((math == 2 || math == 3) && (hd == 80 || hd == 64 || hd == 32 || hd == 16)) {
         static const int kt = tdr_tune_env("TDR_ATTN_KT") ? atoi(tdr_tune_env("TDR_ATTN_KT")) : 32;       // key tile (tuning aid)
         if (hd == 80) hipLaunchKernelGGL((attn_fwd_hx2_kernel<80, 32>), grid, dim3(256), 0, st, a);
@@ -697,11 +882,12 @@ extern "C" int tdr_attention_fwd(const float* qkv, int B, int C, int heads, int 
     return tdr_attention_fwd_math(qkv, B, C, heads, T, LD, scale, 0, 0, out, stream);
 }
 
-// math 0: exact fp32 MFMA; 2: 2-way fp16 split (operands within the fp16 range: LayerNorm-ed ViT activations);
+// math 0: exact fp32 MFMA; 1: 3-way bf16 split (24-bit operands, fp32 range: the default arithmetic); 2: 2-way fp16 split (operands within
+// the fp16 range: LayerNorm-ed ViT activations);
 // 3: plain fp16, one product (reduced precision: the DINOv2 matcher, whose only output is an arg-max pinned by its tests)
 extern "C" int tdr_attention_fwd_math(const float* qkv, int B, int C, int heads, int T, int LD, float scale, int math, int flat,
                                       float* out, void* stream) {
-    TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T && (math == 0 || math == 2 || math == 3), "tdr_attention_fwd: bad argument");
+    TDR_REQUIRE(qkv && out && heads > 0 && C % heads == 0 && LD >= T && (math >= 0 && math <= 3), "tdr_attention_fwd: bad argument");
     AttnArgs a{qkv, 3L * C * LD, LD, T, qkv + (long)C * LD, qkv + 2L * C * LD, 3L * C * LD, LD, T, C, scale, out, nullptr, LD, LD, (long)C * LD};
     if (flat) {      // [3C][B*LD]: image b at column offset b*LD, channel stride B*LD; out [C][B*LD]
         const long cs = (long)B * LD;

@@ -127,6 +127,7 @@ class PackedWeights:
 # their LDS / wave slots while resident, so two of them barely co-run -- and per-kernel profiles of overlapped launches
 # are no longer comparable with the serial ones, so the default keeps the backward on one stream.
 ATTN_F32 = False              # exact-fp32 attention products inside an fp16 arithmetic (module switch)
+ATTN_BX3 = True               # TDR_MATH=bx3: the frozen ViTs' attention on the 3-way bf16 split (False: exact fp32 MFMA, as in rounds 1 - 5)
 DWK_GENERIC = False           # the LDS-tiled generic depthwise kernels instead of the register-window ones (module switch: cross-check tests)
 SIDE_WGRAD = False            # (module switch: tests/test_hip_network.py::test_side_stream_weight_gradients_match)
 _side_stream = None
@@ -1261,7 +1262,7 @@ def attention_fwd(qkv, heads, scale, T1, flat_batch=0, single_product=False):
     assert qkv.is_contiguous()
     out = torch.empty(qkv.shape[0], Cc, qkv.shape[2], qkv.shape[3], dtype=torch.float32, device=qkv.device)
     # the frozen ViTs (no gradient flows through this attention): on the fp16 split whenever the dense contractions are
-    math = 2 if (MATH in ('hx2', 'h1') and not ATTN_F32) else 0
+    math = 2 if (MATH in ('hx2', 'h1') and not ATTN_F32) else (1 if (MATH == 'bx3' and ATTN_BX3) else 0)
     if single_product and math == 2 and Cc // heads in (16, 32, 64):
         math = 3          # plain fp16 products (the DINOv2 matcher: only an arg-max leaves it)
     check(_lib.load().tdr_attention_fwd_math(qkv.data_ptr(), B, Cc, heads, T1, LD, float(scale), math, 1 if flat_batch else 0, out.data_ptr(),
