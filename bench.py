@@ -284,6 +284,29 @@ def pmc_traffic(prefixes):
                      f'on copies of known size, {path}; collected on this revision of the kernel sources)')
 
 
+def pmc_clock(prefix):
+    """effective shader clock and matrix-pipe busy share (in CYCLES) of a kernel family under its own load, from the committed counter pass
+    (profiles/pmc_clock.sh -> profiles/r<N>/pmc_clock.json: GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES, dispatch timestamps of the same pass).
+    The roofline peak is the guide's 2.4 GHz figure; the chip clocks MFMA-dense kernels at 1.8 - 2.0 GHz (MI355X_MICROARCH.md, DVFS give-back), so
+    `frac` understates how busy the matrix pipes are per cycle.  Context only -- `frac` stays priced against the nominal peak."""
+    for rnd in ('r6',):
+        try:
+            with open(os.path.join(ROOT, 'profiles', rnd, 'pmc_clock.json')) as fh:
+                js = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        rows = [k for k in js.get('kernels', []) if k['kernel'].startswith(prefix)]
+        w = sum(k['launches'] * k['avg_us'] for k in rows)
+        if not w:
+            return None
+        return {'effective_ghz': sum(k['effective_ghz'] * k['launches'] * k['avg_us'] for k in rows) / w,
+                'mfma_busy_cycle_frac': sum(k['mfma_busy_cycle_frac'] * k['launches'] * k['avg_us'] for k in rows) / w,
+                'by_instantiation': [{'kernel': k['kernel'], 'grid': k['grid'], 'avg_us': round(k['avg_us'], 1), 'effective_ghz': round(k['effective_ghz'], 3),
+                                      'mfma_busy_cycle_frac': round(k['mfma_busy_cycle_frac'], 3)} for k in rows],
+                'source': f'profiles/{rnd}/pmc_clock.json (time-weighted over the instantiations; kernels serialised by the counter pass; nominal peak = 2.4 GHz)'}
+    return None
+
+
 def pmc_step_bytes():
     """measured HBM bytes of one whole train step from the same PMC collection (sum over every kernel of the step), or None"""
     for rnd in ('r6', 'r5', 'r4', 'r3'):
@@ -819,6 +842,7 @@ def _main_body(a, world, rank, local, enc):
                 subs[k]['traffic'] = pmc_traffic([prefixes[k]])[0]
             roof = dict(subs[lead])
             roof['traffic_unit'] = pmc_traffic([prefixes[lead]])[1]
+            roof['clock'] = pmc_clock(prefixes[lead].split('<')[0])
             fam = entry([r for r in conv if r[4][1] in split], ' + '.join(CONV[k][0] for k in split), CONV[lead][1], CONV[lead][2])
             fam['traffic'] = pmc_traffic(sorted({prefixes[k] for k in split}))[0]
             fam['by_kernel'] = [{kk: vv for kk, vv in subs[k].items() if kk != '_total_ms'} for k in split]
