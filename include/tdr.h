@@ -22,7 +22,7 @@ extern "C" {
 
 /* C-ABI version: bumped with every incompatible change of this header (100 rounds 1-2, 101 round 3, 102 round 4); the
  * binding (textualdegremoval_amd/_lib.py) refuses a library whose version differs from the one it was written against. */
-#define TDR_ABI_VERSION 105
+#define TDR_ABI_VERSION 106
 int tdr_version(void);
 const char* tdr_last_error(void);
 
@@ -843,6 +843,7 @@ typedef struct TdrSfDynVecDesc {
     const float *ap, *wconv, *bn_w, *bn_b, *fc_w, *fc_b, *f0_w, *f0_b, *f1_w, *f1_b;
     float *run_mean, *run_var; int64_t* nbt;
     float *taps, *ah, *al, *xhat, *rstd, *z, *att;
+    int use_running;                         /* 1: inference-mode BatchNorm (module.eval()): normalise with run_mean / run_var, buffers untouched */
 } TdrSfDynVecDesc;
 int tdr_sf_dyn_vec_fwd(const TdrSfDynVecDesc* d, void* stream);
 typedef struct TdrSfDynVecBwdDesc {

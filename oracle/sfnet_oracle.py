@@ -155,6 +155,12 @@ def patch_ap(x, P, pre):
     return region_affine(x, h, l - h, 2)
 
 
+def batch_norm_eval(v, P, pre):
+    """BatchNorm2d after module.eval(): the running statistics normalise, nothing moves"""
+    mu, var = P[pre + 'running_mean'].view(1, -1, 1, 1), P[pre + 'running_var'].view(1, -1, 1, 1)
+    return (v - mu) / torch.sqrt(var + BN_EPS) * P[pre + 'weight'].view(1, -1, 1, 1) + P[pre + 'bias'].view(1, -1, 1, 1)
+
+
 def batch_norm_train(v, P, pre, new_buffers=None):
     """BatchNorm2d in training mode on [N, C, 1, 1]: batch statistics (biased variance) normalise, the running buffers move with
     momentum 0.1 towards the batch mean and the UNBIASED batch variance"""
@@ -169,11 +175,11 @@ def batch_norm_train(v, P, pre, new_buffers=None):
     return (v - mu) / torch.sqrt(var + BN_EPS) * P[pre + 'weight'].view(1, -1, 1, 1) + P[pre + 'bias'].view(1, -1, 1, 1)
 
 
-def dynamic_filter(x, P, pre, k, new_buffers=None):
+def dynamic_filter(x, P, pre, k, new_buffers=None, training=True):
     n, c, h, w = x.shape
     ap = x.mean((2, 3), keepdim=True)
     lf = F.conv2d(ap, P[pre + 'conv.weight'])
-    lf = batch_norm_train(lf, P, pre + 'bn.', new_buffers)
+    lf = batch_norm_train(lf, P, pre + 'bn.', new_buffers) if training else batch_norm_eval(lf, P, pre + 'bn.')
     taps = torch.softmax(lf.view(n, GROUP, k * k), dim=2)                       # [N, G, k*k]
     xp = F.pad(x, (k // 2,) * 4, mode='reflect')
     low = torch.zeros_like(x)
@@ -191,19 +197,19 @@ def dynamic_filter(x, P, pre, k, new_buffers=None):
     return F.conv2d(high * a_h + low * a_l, P[pre + 'modulate.out.weight'], P[pre + 'modulate.out.bias'])
 
 
-def res_block(x, P, pre, filt, new_buffers=None):
+def res_block(x, P, pre, filt, new_buffers=None, training=True):
     out = basic_conv(x, P, pre + 'conv1.', 3)
     c = out.shape[1]
     if filt:
-        out = torch.cat([dynamic_filter(out[:, :c // 2], P, pre + 'dyna.', 3, new_buffers),
-                         dynamic_filter(out[:, c // 2:], P, pre + 'dyna_2.', 5, new_buffers)], 1)
+        out = torch.cat([dynamic_filter(out[:, :c // 2], P, pre + 'dyna.', 3, new_buffers, training),
+                         dynamic_filter(out[:, c // 2:], P, pre + 'dyna_2.', 5, new_buffers, training)], 1)
     out = torch.cat([gap_module(out[:, :c // 2], P, pre + 'global_ap.'), patch_ap(out[:, c // 2:], P, pre + 'localap.')], 1)
     return basic_conv(out, P, pre + 'conv2.', 3, act=False) + x
 
 
-def blocks(x, P, pre, num_res, new_buffers=None):
+def blocks(x, P, pre, num_res, new_buffers=None, training=True):
     for r in range(num_res):
-        x = res_block(x, P, f'{pre}layers.{r}.', r == num_res - 1, new_buffers)
+        x = res_block(x, P, f'{pre}layers.{r}.', r == num_res - 1, new_buffers, training)
     return x
 
 
@@ -219,29 +225,29 @@ def fam(x1, x2, P, pre):
     return basic_conv(torch.cat([x1, x2], 1), P, pre + 'merge.', 3, act=False)
 
 
-def sfnet_forward(P, x, num_res, new_buffers=None):
+def sfnet_forward(P, x, num_res, new_buffers=None, training=True):
     """-> [out at 1/4, out at 1/2, out at full size] (reference :366-407).  new_buffers: dict that receives the BatchNorm buffers after
-    this training-mode forward pass"""
+    this training-mode forward pass; training=False: the network after .eval() (BatchNorm2d on its running statistics)"""
     x_2 = x[:, :, ::2, ::2]                        # F.interpolate(scale_factor=0.5), mode 'nearest'
     x_4 = x_2[:, :, ::2, ::2]
     z2 = scm(x_2, P, 'SCM2.')
     z4 = scm(x_4, P, 'SCM1.')
     x_ = basic_conv(x, P, 'feat_extract.0.', 3)
-    res1 = blocks(x_, P, 'Encoder.0.', num_res, new_buffers)
+    res1 = blocks(x_, P, 'Encoder.0.', num_res, new_buffers, training)
     z = basic_conv(res1, P, 'feat_extract.1.', 3, stride=2)
     z = fam(z, z2, P, 'FAM2.')
-    res2 = blocks(z, P, 'Encoder.1.', num_res, new_buffers)
+    res2 = blocks(z, P, 'Encoder.1.', num_res, new_buffers, training)
     z = basic_conv(res2, P, 'feat_extract.2.', 3, stride=2)
     z = fam(z, z4, P, 'FAM1.')
-    z = blocks(z, P, 'Encoder.2.', num_res, new_buffers)
-    z = blocks(z, P, 'Decoder.0.', num_res, new_buffers)
+    z = blocks(z, P, 'Encoder.2.', num_res, new_buffers, training)
+    z = blocks(z, P, 'Decoder.0.', num_res, new_buffers, training)
     o4 = basic_conv(z, P, 'ConvsOut.0.', 3, act=False) + x_4
     z = basic_conv(z, P, 'feat_extract.3.', 4, stride=2, transpose=True)
     z = basic_conv(torch.cat([z, res2], 1), P, 'Convs.0.', 1)
-    z = blocks(z, P, 'Decoder.1.', num_res, new_buffers)
+    z = blocks(z, P, 'Decoder.1.', num_res, new_buffers, training)
     o2 = basic_conv(z, P, 'ConvsOut.1.', 3, act=False) + x_2
     z = basic_conv(z, P, 'feat_extract.4.', 4, stride=2, transpose=True)
     z = basic_conv(torch.cat([z, res1], 1), P, 'Convs.1.', 1)
-    z = blocks(z, P, 'Decoder.2.', num_res, new_buffers)
+    z = blocks(z, P, 'Decoder.2.', num_res, new_buffers, training)
     o1 = basic_conv(z, P, 'feat_extract.5.', 3, act=False) + x
     return [o4, o2, o1]

@@ -1,8 +1,8 @@
 """Golden vectors of the UN-GUIDED `SFNet` (models/archs/network_sfnet_guided_arch.py:320-407) and of its `dynamic_filter` / `ResBlock`
 operators (models/archs/sfnet_arch_utils.py:120-236), by running the REFERENCE classes on CPU in training mode.
 
-Run in the build container only:   python tests/golden/make_golden_sfnet.py
-Writes tests/golden/sfnet.npz (data only).  Weights are oracle.sfnet_oracle.synth_state(num_res, seed) -- regenerated from the seed by
+Run in the build container only:   python tests/golden/make_golden_sfnet.py      (--eval-only: only the second file)
+Writes tests/golden/sfnet.npz and tests/golden/sfnet_eval.npz (the network after .eval(): outputs only) -- data only.  Weights are oracle.sfnet_oracle.synth_state(num_res, seed) -- regenerated from the seed by
 the tests, not stored; the generator first checks that the reference class registers exactly the names / shapes / order the oracle
 lists.  Stored per case: input, the three outputs, the cotangents, every parameter's gradient norm and maximum (-1 where the reference
 leaves .grad None: the unused lamb_l / lamb_h), a few full gradients, and the BatchNorm buffers after the training-mode forward."""
@@ -66,6 +66,24 @@ def whole_net(mod, tag, num_res, seed, n, h, w, d):
     print(tag, [tuple(o.shape) for o in outs], 'params', len(names), 'without grad', int((d[tag + '_gnorm'] < 0).sum()))
 
 
+def eval_net(mod, tag, num_res, seed, n, h, w, d):
+    """the same network after .eval() (the trainer's validation pass): BatchNorm2d on its running statistics, no buffer moves"""
+    net = mod.SFNet(mode=['train', 'Indoor'], num_res=num_res)
+    P = SO.synth_state(num_res, seed)
+    net.load_state_dict(P)
+    net.eval()
+    x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(seed + 1))
+    with torch.no_grad():
+        outs = net(x)
+    d[tag + '_x'] = x.numpy()
+    for i, o in enumerate(outs):
+        d[f'{tag}_out{i}'] = o.numpy()
+    after = net.state_dict()
+    assert all(torch.equal(after[k], P[k]) for k in after if SO.is_buffer(k)), 'eval moved a buffer'
+    d[tag + '_cfg'] = np.array([num_res, seed, n, h, w])
+    print(tag, [tuple(o.shape) for o in outs])
+
+
 def dyn_filter_case(utils, tag, c, k, n, h, w, seed, d):
     m = utils.dynamic_filter(c, ['train', 'Indoor'], kernel_size=k)
     g = torch.Generator().manual_seed(seed)
@@ -107,8 +125,14 @@ def main():
     whole_net(mod, 'net_r1_rect', 1, 22, 3, 48, 80, d)              # non-square, odd batch (BatchNorm over 3 samples)
     dyn_filter_case(utils, 'dyn3', 16, 3, 2, 16, 24, 31, d)
     dyn_filter_case(utils, 'dyn5', 32, 5, 3, 12, 8, 32, d)
-    np.savez_compressed(os.path.join(HERE, 'sfnet.npz'), **d)
-    print('wrote', os.path.join(HERE, 'sfnet.npz'), len(d), 'arrays')
+    if '--eval-only' not in sys.argv:
+        np.savez_compressed(os.path.join(HERE, 'sfnet.npz'), **d)
+        print('wrote', os.path.join(HERE, 'sfnet.npz'), len(d), 'arrays')
+    e = {}
+    eval_net(mod, 'eval_r2', 2, 23, 2, 64, 64, e)
+    eval_net(mod, 'eval_r1_one', 1, 24, 1, 40, 72, e)               # one image: what a validation loader feeds
+    np.savez_compressed(os.path.join(HERE, 'sfnet_eval.npz'), **e)
+    print('wrote', os.path.join(HERE, 'sfnet_eval.npz'), len(e), 'arrays')
 
 
 if __name__ == '__main__':

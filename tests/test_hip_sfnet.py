@@ -174,6 +174,35 @@ def test_whole_network_against_the_reference_golden(K, g, tag):
     print(f'{tag} [{K.MATH}]: worst relative gradient-norm difference {worst[0]:.2e} at {worst[1]}')
 
 
+@pytest.mark.parametrize('tag', ['eval_r2', 'eval_r1_one'])
+def test_whole_network_after_eval_against_the_reference_golden(K, tag):
+    """module.eval() -- the validation pass: BatchNorm2d on its running statistics, no buffer moves (tests/golden/sfnet_eval.npz, made by the
+    reference class after .eval()); through the engine and through the nn.Module mirror"""
+    from textualdegremoval_amd import sfnet_engine as SE
+    from textualdegremoval_amd.models.archs import define_network
+    ge = np.load(GOLDEN.replace('sfnet.npz', 'sfnet_eval.npz'), allow_pickle=False)
+    num_res, seed, n, h, w = (int(v) for v in ge[tag + '_cfg'])
+    sd = SO.synth_state(num_res, seed)
+    P = {k: v.clone().cuda() for k, v in sd.items()}
+    x = torch.from_numpy(ge[tag + '_x']).cuda()
+    outs, _ = SE.net_fwd(P, x, num_res, training=False)
+    for i, o in enumerate(outs):
+        want = torch.from_numpy(ge[f'{tag}_out{i}'])
+        assert o.shape == want.shape and md(o, want) < 1e-4, (i, md(o, want))
+    assert all(torch.equal(P[k].cpu(), sd[k]) for k in sd if SO.is_buffer(k))
+    net = define_network(dict(type='SFNet', mode=['train', 'Indoor'], num_res=num_res)).cuda()
+    net.load_state_dict(sd)
+    net.eval()
+    with torch.no_grad():
+        mo = net(x)
+    for a, b in zip(mo, outs):
+        assert torch.equal(a, b)
+    assert all(torch.equal(v.cpu(), sd[k]) for k, v in net.state_dict().items())
+    if n > 1:                                       # the training-mode pass of the same state differs (batch statistics): the flag is live
+        tr, _ = SE.net_fwd({k: v.clone().cuda() for k, v in sd.items()}, x, num_res)
+        assert md(tr[2], outs[2]) > 1e-3
+
+
 def test_module_mirror_trains_like_the_oracle(K):
     """the nn.Module (reference constructor, state-dict layout) end to end: load a seeded state, forward + backward through autograd,
     outputs / gradients / moved BatchNorm buffers against the oracle on the same state"""

@@ -56,6 +56,25 @@ def test_whole_network_forward_backward_and_buffers(g, tag):
             assert (bufs[k].double() - want.double()).abs().max().item() <= 1e-5 * max(1.0, want.double().abs().max().item()), k
 
 
+@pytest.mark.parametrize('tag', ['eval_r2', 'eval_r1_one'])
+def test_whole_network_after_eval(tag):
+    """the network after .eval() (the trainer's validation pass): BatchNorm2d on its running statistics (tests/golden/sfnet_eval.npz)"""
+    g = np.load(GOLDEN.replace('sfnet.npz', 'sfnet_eval.npz'), allow_pickle=False)
+    num_res, seed, n, h, w = (int(v) for v in g[tag + '_cfg'])
+    P = SO.synth_state(num_res, seed)
+    before = {k: v.clone() for k, v in P.items()}
+    with torch.no_grad():
+        outs = SO.sfnet_forward(P, torch.from_numpy(g[tag + '_x']), num_res, training=False)
+    for i, o in enumerate(outs):
+        want = torch.from_numpy(g[f'{tag}_out{i}'])
+        assert o.shape == want.shape and (o - want).abs().max().item() < 2e-5, (i, (o - want).abs().max().item())
+    assert all(torch.equal(P[k], before[k]) for k in P)
+    # and the two modes do differ on this state (running statistics != batch statistics): the test would notice a swapped flag
+    with torch.no_grad():
+        tr = SO.sfnet_forward(P, torch.from_numpy(g[tag + '_x']), num_res, training=True)
+    assert n == 1 or (tr[2] - outs[2]).abs().max().item() > 1e-3
+
+
 @pytest.mark.parametrize('tag', ['dyn3', 'dyn5'])
 def test_dynamic_filter(g, tag):
     c, k, n, h, w = (int(v) for v in g[tag + '_cfg'])

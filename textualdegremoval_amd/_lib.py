@@ -15,7 +15,7 @@ import torch  # noqa: F401  (import order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TDR_LIB_PATH', os.path.join(_HERE, 'libtdr_hip.so'))   # override: profiling probe builds
 
-ABI_VERSION = 105      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
+ABI_VERSION = 106      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
 c_fp = C.c_void_p      # device pointers travel as integers
 i32, i64, f32 = C.c_int, C.c_int64, C.c_float
 
@@ -117,7 +117,7 @@ class TdrNafHeadFwdDesc(C.Structure):
 class TdrSfDynVecDesc(C.Structure):
     _fields_ = [('N', i32), ('c', i32), ('GK', i32), ('KK', i32), ('d', i32), ('eps', f32), ('momentum', f32)] + \
                [(k, c_fp) for k in ('ap', 'wconv', 'bn_w', 'bn_b', 'fc_w', 'fc_b', 'f0_w', 'f0_b', 'f1_w', 'f1_b', 'run_mean', 'run_var', 'nbt',
-                                    'taps', 'ah', 'al', 'xhat', 'rstd', 'z', 'att')]
+                                    'taps', 'ah', 'al', 'xhat', 'rstd', 'z', 'att')] + [('use_running', i32)]
 
 
 class TdrSfDynVecBwdDesc(C.Structure):

@@ -271,6 +271,7 @@ struct DynVecArgs {
     float *xhat, *rstd, *z, *att;          // saved: [N][GK], [GK], [N][d], [N][2c]
     int N, c, GK, KK, d;
     float eps, mom;
+    int use_running;
 };
 #define FOR_T(i, n) for (int i = threadIdx.x; i < (n); i += blockDim.x)
 __global__ __launch_bounds__(256) void dyn_vec_fwd_kernel(DynVecArgs a) {
@@ -285,23 +286,29 @@ __global__ __launch_bounds__(256) void dyn_vec_fwd_kernel(DynVecArgs a) {
     __syncthreads();
     // BatchNorm over the batch (biased variance normalises; the running buffers move towards the batch mean / UNBIASED variance)
     FOR_T(j, GK) {
-        float m = 0.f;
-        for (int n = 0; n < N; ++n) m += a.xhat[(long)n * GK + j];
-        m /= N;
-        float v = 0.f;
-        for (int n = 0; n < N; ++n) { const float e = a.xhat[(long)n * GK + j] - m; v += e * e; }
-        v /= N;
+        float m = 0.f, v = 0.f;
+        if (a.use_running) {                                   // module.eval(): the running statistics normalise, nothing is updated
+            m = a.run_mean[j];
+            v = a.run_var[j];
+        } else {
+            for (int n = 0; n < N; ++n) m += a.xhat[(long)n * GK + j];
+            m /= N;
+            for (int n = 0; n < N; ++n) { const float e = a.xhat[(long)n * GK + j] - m; v += e * e; }
+            v /= N;
+        }
         const float r = 1.f / sqrtf(v + a.eps);
         a.rstd[j] = r;
-        a.run_mean[j] = (1.f - a.mom) * a.run_mean[j] + a.mom * m;
-        a.run_var[j] = (1.f - a.mom) * a.run_var[j] + a.mom * v * N / (N > 1 ? N - 1 : 1);
+        if (!a.use_running) {
+            a.run_mean[j] = (1.f - a.mom) * a.run_mean[j] + a.mom * m;
+            a.run_var[j] = (1.f - a.mom) * a.run_var[j] + a.mom * v * N / (N > 1 ? N - 1 : 1);
+        }
         for (int n = 0; n < N; ++n) {
             const float xh = (a.xhat[(long)n * GK + j] - m) * r;
             a.xhat[(long)n * GK + j] = xh;
             a.taps[(long)n * GK + j] = xh * a.bn_w[j] + a.bn_b[j];          // (logits for now)
         }
     }
-    if (threadIdx.x == 0 && a.nbt) *a.nbt += 1;
+    if (threadIdx.x == 0 && a.nbt && !a.use_running) *a.nbt += 1;
     __syncthreads();
     // softmax over the KK taps of every (image, group)
     FOR_T(i, N * GK / KK) {
@@ -516,6 +523,7 @@ extern "C" int tdr_sf_dyn_vec_fwd(const TdrSfDynVecDesc* d, void* stream) {
     a.f1_w = d->f1_w; a.f1_b = d->f1_b; a.run_mean = d->run_mean; a.run_var = d->run_var; a.nbt = reinterpret_cast<long long*>(d->nbt);
     a.taps = d->taps; a.ah = d->ah; a.al = d->al; a.xhat = d->xhat; a.rstd = d->rstd; a.z = d->z; a.att = d->att;
     a.N = d->N; a.c = d->c; a.GK = d->GK; a.KK = d->KK; a.d = d->d; a.eps = d->eps; a.mom = d->momentum;
+    a.use_running = d->use_running;
     hipLaunchKernelGGL(dyn_vec_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     TDR_LAUNCH_CHECK("dyn_vec_fwd_kernel");
     return TDR_OK;

@@ -2092,9 +2092,10 @@ def region_affine_bwd(dy, x, ph, pl, shift, mean, q, dx):
     return dph, dpl
 
 
-def sf_dyn_vec_fwd(ap, P, pre, k, groups=8):
+def sf_dyn_vec_fwd(ap, P, pre, k, groups=8, training=True):
     """the pooled-vector pipeline of dynamic_filter + SFconv (one workgroup): -> (taps [N, G k k], ah [N, c], al [N, c], saved).
-    P[pre + 'bn.running_mean' / 'running_var' / 'num_batches_tracked'] are moved in place (training-mode BatchNorm)."""
+    training: P[pre + 'bn.running_mean' / 'running_var' / 'num_batches_tracked'] are moved in place (training-mode BatchNorm);
+    not training (module.eval()): the running statistics normalise and nothing is updated."""
     N, c = ap.shape
     KK, GK = k * k, groups * k * k
     dd = P[pre + 'modulate.fc.weight'].shape[0]
@@ -2115,6 +2116,7 @@ def sf_dyn_vec_fwd(ap, P, pre, k, groups=8):
     d.run_mean, d.run_var = P[pre + 'bn.running_mean'].data_ptr(), P[pre + 'bn.running_var'].data_ptr()
     nbt = P.get(pre + 'bn.num_batches_tracked')
     d.nbt = nbt.data_ptr() if nbt is not None and nbt.is_cuda else 0
+    d.use_running = 0 if training else 1
     d.taps, d.ah, d.al, d.xhat, d.rstd, d.z, d.att = (t.data_ptr() for t in (taps, ah, al, xhat, rstd, z, att))
     check(_lib.load().tdr_sf_dyn_vec_fwd(C.byref(d), _stream()), 'tdr_sf_dyn_vec_fwd')
     return taps, ah, al, (ap, taps, xhat, rstd, z, att)

@@ -3,7 +3,8 @@
 `SFNet` (:320-407) -- the un-guided network -- is built here: same constructor (`mode`, `num_res`), same module tree, registration
 order, parameter / buffer names and default initialisation (the layers below are ordinary torch modules used as PARAMETER CONTAINERS; no
 torch operator runs in the forward or backward pass: both go through textualdegremoval_amd/sfnet_engine.py on the HIP kernels).  Only
-mode[0] == 'train' is supported (global average pools, BatchNorm2d on batch statistics): mode 'test' swaps every pooling for the TLSC
+mode[0] == 'train' is supported (global average pools) -- in training mode (BatchNorm2d on batch statistics, running buffers moved) and
+after .eval() (BatchNorm2d on its running statistics: the validation pass of the trainer); mode 'test' swaps every pooling for the TLSC
 box filter with Indoor / Outdoor base sizes (sfnet_arch_utils.py:108-113) and is not built.
 
 `SFNetRefFusion` (:410-797) is registered so that the shipped YAML's `type: SFNetRefFusion` resolves, but there is no network behind it,
@@ -118,12 +119,17 @@ class SFNet(nn.Module):
 
     def forward(self, x):
         """-> [out at 1/4, out at 1/2, out at full size] (reference :366-407); H and W multiples of 8 (two stride-2 levels, quadrants)"""
-        if not self.training:
-            raise NotImplementedError('SFNet on the HIP path runs in training mode (BatchNorm2d on batch statistics, global pools)')
         if x.shape[2] % 8 or x.shape[3] % 8:
             raise ValueError('SFNet: image height and width must be multiples of 8')
         named = list(self.named_parameters())
         buffers = {k: v for k, v in self.named_buffers()}
+        if not self.training:
+            # module.eval() (the trainer's validation pass): BatchNorm2d on its running statistics, no buffer moves; forward only --
+            # the outputs carry no autograd graph (validation runs under torch.no_grad() in the reference, base_model / image_restoration_model)
+            from ... import sfnet_engine as SE
+            P = {k: p.detach() for k, p in named}
+            P.update(buffers)
+            return list(SE.net_fwd(P, x.detach(), self.num_res, training=False)[0])
         return list(_SFNetFn.apply(x, self.num_res, [k for k, _ in named], buffers, *[p for _, p in named]))
 
 

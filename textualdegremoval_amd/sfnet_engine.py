@@ -59,10 +59,13 @@ def convt_bwd(dy, P, pre, saved, G):
 
 
 # ------------------------------------------------------------------------------------------------- dynamic_filter + SFconv (:152-236)
+_training = True        # set by net_fwd for the pass it runs
+
+
 def dyn_fwd(x, P, pre, k, out):
     """x, out: channel-slice views [N, c, H, W]"""
     ap = K.plane_mean(x)
-    taps, ah, al, sv = K.sf_dyn_vec_fwd(ap, P, pre, k, GROUPS)
+    taps, ah, al, sv = K.sf_dyn_vec_fwd(ap, P, pre, k, GROUPS, training=_training)
     low, mix = K.sf_dynfilt_fwd(x, taps, ah, al, k, GROUPS)
     E.conv_fwd(mix, P[pre + 'modulate.out.weight'], P[pre + 'modulate.out.bias'], 1, 0, out=out)
     return (x, low, mix, taps, ah, al, sv)
@@ -160,7 +163,11 @@ def cat_conv_bwd(dy, P, pre, saved, G):
 
 
 # ------------------------------------------------------------------------------------------------- SFNet.forward (:366-407)
-def net_fwd(P, x, num_res):
+def net_fwd(P, x, num_res, training=True):
+    """training=False: module.eval() -- BatchNorm2d on its running statistics, buffers untouched (InstanceNorm2d and the global pools are
+    the same in both modes: the reference builds them without running statistics, sfnet_arch_utils.py:208, :108)"""
+    global _training
+    _training = bool(training)
     x = x.contiguous()
     x_2 = K.subsample2(x)
     x_4 = K.subsample2(x_2)
