@@ -868,6 +868,17 @@ int tdr_sf_dynfilt_bwd_dx(const float* dmix, const float* taps, const float* ah,
  * and the gradients back (dw3 -> dw, db4 -> db summed over the four parities). */
 int tdr_convt4_weight_to_3x3(const float* w, const float* b, int Cin, int Cout, float* w3, float* b4, void* stream);
 int tdr_convt4_grad_from_3x3(const float* dw3, const float* db4, int Cin, int Cout, float* dw, float* db, void* stream);
+/* mode[0] == 'test' of the same network (inference with TLSC pooling, sfnet_arch_utils.py:108-113, :226-229, :247-250; forward only): the pooled
+ * operand of Gap / Patch_ap / SFconv is the box-mean MAP of tdr_local_avgpool.
+ * region_split: out [N][(c q + p1) q + p2][H / q][W / q] = the q x q region planes of a dense-NCHW view (q = 1: dense copy of a channel slice);
+ * local_affine: y = m * pl[J] + (x - m) * (ph[J] + shift), m [N][C q q][H / q][W / q] the box-mean map of the region planes (Gap: q 1, shift 1,
+ *   (fscale_h, fscale_d); Patch_ap: q 2, shift 0, (h, l));  emerge: out = low + (x - low) (SFconv, :218);
+ * softmax_mix: per pixel softmax over the 2C logits [lh ; ll], mix = (x - low) * a_high + low * a_low (:226-232). */
+int tdr_sf_region_split(const float* x, int64_t x_ns, int q, int N, int C, int H, int W, float* out, void* stream);
+int tdr_sf_local_affine(const float* x, int64_t x_ns, const float* m, const float* ph, const float* pl, float shift, int q, int N, int C, int H, int W,
+                        float* y, int64_t y_ns, void* stream);
+int tdr_sf_emerge(const float* x, int64_t x_ns, const float* low, int N, int C, int HW, float* out, void* stream);
+int tdr_sf_softmax_mix(const float* x, int64_t x_ns, const float* low, const float* lh, const float* ll, int N, int C, int HW, float* mix, void* stream);
 
 #ifdef __cplusplus
 }

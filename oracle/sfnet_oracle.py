@@ -145,13 +145,37 @@ def region_affine(x, A, B, q):
     return (xr * Ar + m * Br).reshape(n, c, h, w)
 
 
-def gap_module(x, P, pre):
+TLSC_TRAIN_SIZE = 256          # sfnet_arch_utils.py:8
+TLSC_BASE = {'Indoor': 246, 'Outdoor': 210}     # :110-113, :226-229, :247-250
+
+
+def tlsc_avgpool(x, base):
+    """AvgPool2d(base_size=base) of mode[0] == 'test' (sfnet_arch_utils.py:11-70, the exact branch): the mean over a k1 x k2 window,
+    k = size * base // 256 taken from the input it runs on, every valid window position, replicate-padded back to the input size.
+    (The reference caches k from the FIRST input a module instance sees; one kernel size per call is what a fresh network does.)"""
+    n, c, h, w = x.shape
+    k1, k2 = min(h, h * base // TLSC_TRAIN_SIZE), min(w, w * base // TLSC_TRAIN_SIZE)
+    out = F.avg_pool2d(x, (k1, k2), stride=1)
+    _h, _w = out.shape[2:]
+    return F.pad(out, ((w - _w) // 2, (w - _w + 1) // 2, (h - _h) // 2, (h - _h + 1) // 2), mode='replicate')
+
+
+def gap_module(x, P, pre, tlsc=None):
     fd, fh = P[pre + 'fscale_d'], P[pre + 'fscale_h']
+    if tlsc is not None:                            # :115-119 with the local box mean
+        x_d = tlsc_avgpool(x, tlsc)
+        return x_d * fd.view(1, -1, 1, 1) + (x - x_d) * (fh.view(1, -1, 1, 1) + 1.0)
     return region_affine(x, fh + 1.0, fd - fh - 1.0, 1)
 
 
-def patch_ap(x, P, pre):
+def patch_ap(x, P, pre, tlsc=None):
     h, l = P[pre + 'h'], P[pre + 'l']
+    if tlsc is not None:                            # :256-265: the box mean runs on the [b, (c p1 p2), H / 2, W / 2] quadrant planes
+        n, c, H, W = x.shape
+        px = x.view(n, c, 2, H // 2, 2, W // 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c * 4, H // 2, W // 2)
+        low = tlsc_avgpool(px, tlsc)
+        out = (px - low) * h.view(1, -1, 1, 1) + low * l.view(1, -1, 1, 1)
+        return out.view(n, c, 2, 2, H // 2, W // 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, H, W)
     return region_affine(x, h, l - h, 2)
 
 
@@ -175,7 +199,7 @@ def batch_norm_train(v, P, pre, new_buffers=None):
     return (v - mu) / torch.sqrt(var + BN_EPS) * P[pre + 'weight'].view(1, -1, 1, 1) + P[pre + 'bias'].view(1, -1, 1, 1)
 
 
-def dynamic_filter(x, P, pre, k, new_buffers=None, training=True):
+def dynamic_filter(x, P, pre, k, new_buffers=None, training=True, tlsc=None):
     n, c, h, w = x.shape
     ap = x.mean((2, 3), keepdim=True)
     lf = F.conv2d(ap, P[pre + 'conv.weight'])
@@ -189,7 +213,9 @@ def dynamic_filter(x, P, pre, k, new_buffers=None, training=True):
         low = low + xp[:, :, dy:dy + h, dx:dx + w] * taps[:, :, t].repeat_interleave(cg, dim=1).view(n, c, 1, 1)
     high = x - low
     # SFconv (modulate)
-    z = F.conv2d((low + high).mean((2, 3), keepdim=True), P[pre + 'modulate.fc.weight'], P[pre + 'modulate.fc.bias'])
+    emerge = low + high
+    emerge = emerge.mean((2, 3), keepdim=True) if tlsc is None else tlsc_avgpool(emerge, tlsc)     # SFconv.gap (:212-218); dynamic_filter.ap above stays global
+    z = F.conv2d(emerge, P[pre + 'modulate.fc.weight'], P[pre + 'modulate.fc.bias'])
     a_h = F.conv2d(z, P[pre + 'modulate.fcs.0.weight'], P[pre + 'modulate.fcs.0.bias'])
     a_l = F.conv2d(z, P[pre + 'modulate.fcs.1.weight'], P[pre + 'modulate.fcs.1.bias'])
     att = torch.softmax(torch.cat([a_h, a_l], 1), dim=1)
@@ -197,19 +223,19 @@ def dynamic_filter(x, P, pre, k, new_buffers=None, training=True):
     return F.conv2d(high * a_h + low * a_l, P[pre + 'modulate.out.weight'], P[pre + 'modulate.out.bias'])
 
 
-def res_block(x, P, pre, filt, new_buffers=None, training=True):
+def res_block(x, P, pre, filt, new_buffers=None, training=True, tlsc=None):
     out = basic_conv(x, P, pre + 'conv1.', 3)
     c = out.shape[1]
     if filt:
-        out = torch.cat([dynamic_filter(out[:, :c // 2], P, pre + 'dyna.', 3, new_buffers, training),
-                         dynamic_filter(out[:, c // 2:], P, pre + 'dyna_2.', 5, new_buffers, training)], 1)
-    out = torch.cat([gap_module(out[:, :c // 2], P, pre + 'global_ap.'), patch_ap(out[:, c // 2:], P, pre + 'localap.')], 1)
+        out = torch.cat([dynamic_filter(out[:, :c // 2], P, pre + 'dyna.', 3, new_buffers, training, tlsc),
+                         dynamic_filter(out[:, c // 2:], P, pre + 'dyna_2.', 5, new_buffers, training, tlsc)], 1)
+    out = torch.cat([gap_module(out[:, :c // 2], P, pre + 'global_ap.', tlsc), patch_ap(out[:, c // 2:], P, pre + 'localap.', tlsc)], 1)
     return basic_conv(out, P, pre + 'conv2.', 3, act=False) + x
 
 
-def blocks(x, P, pre, num_res, new_buffers=None, training=True):
+def blocks(x, P, pre, num_res, new_buffers=None, training=True, tlsc=None):
     for r in range(num_res):
-        x = res_block(x, P, f'{pre}layers.{r}.', r == num_res - 1, new_buffers, training)
+        x = res_block(x, P, f'{pre}layers.{r}.', r == num_res - 1, new_buffers, training, tlsc)
     return x
 
 
@@ -225,29 +251,30 @@ def fam(x1, x2, P, pre):
     return basic_conv(torch.cat([x1, x2], 1), P, pre + 'merge.', 3, act=False)
 
 
-def sfnet_forward(P, x, num_res, new_buffers=None, training=True):
+def sfnet_forward(P, x, num_res, new_buffers=None, training=True, tlsc=None):
     """-> [out at 1/4, out at 1/2, out at full size] (reference :366-407).  new_buffers: dict that receives the BatchNorm buffers after
-    this training-mode forward pass; training=False: the network after .eval() (BatchNorm2d on its running statistics)"""
+    this training-mode forward pass; training=False: the network after .eval() (BatchNorm2d on its running statistics); tlsc = TLSC_BASE[mode[1]]: the
+    mode[0] == 'test' network (Gap, Patch_ap and SFconv pool with the local box mean instead of the global average)"""
     x_2 = x[:, :, ::2, ::2]                        # F.interpolate(scale_factor=0.5), mode 'nearest'
     x_4 = x_2[:, :, ::2, ::2]
     z2 = scm(x_2, P, 'SCM2.')
     z4 = scm(x_4, P, 'SCM1.')
     x_ = basic_conv(x, P, 'feat_extract.0.', 3)
-    res1 = blocks(x_, P, 'Encoder.0.', num_res, new_buffers, training)
+    res1 = blocks(x_, P, 'Encoder.0.', num_res, new_buffers, training, tlsc)
     z = basic_conv(res1, P, 'feat_extract.1.', 3, stride=2)
     z = fam(z, z2, P, 'FAM2.')
-    res2 = blocks(z, P, 'Encoder.1.', num_res, new_buffers, training)
+    res2 = blocks(z, P, 'Encoder.1.', num_res, new_buffers, training, tlsc)
     z = basic_conv(res2, P, 'feat_extract.2.', 3, stride=2)
     z = fam(z, z4, P, 'FAM1.')
-    z = blocks(z, P, 'Encoder.2.', num_res, new_buffers, training)
-    z = blocks(z, P, 'Decoder.0.', num_res, new_buffers, training)
+    z = blocks(z, P, 'Encoder.2.', num_res, new_buffers, training, tlsc)
+    z = blocks(z, P, 'Decoder.0.', num_res, new_buffers, training, tlsc)
     o4 = basic_conv(z, P, 'ConvsOut.0.', 3, act=False) + x_4
     z = basic_conv(z, P, 'feat_extract.3.', 4, stride=2, transpose=True)
     z = basic_conv(torch.cat([z, res2], 1), P, 'Convs.0.', 1)
-    z = blocks(z, P, 'Decoder.1.', num_res, new_buffers, training)
+    z = blocks(z, P, 'Decoder.1.', num_res, new_buffers, training, tlsc)
     o2 = basic_conv(z, P, 'ConvsOut.1.', 3, act=False) + x_2
     z = basic_conv(z, P, 'feat_extract.4.', 4, stride=2, transpose=True)
     z = basic_conv(torch.cat([z, res1], 1), P, 'Convs.1.', 1)
-    z = blocks(z, P, 'Decoder.2.', num_res, new_buffers, training)
+    z = blocks(z, P, 'Decoder.2.', num_res, new_buffers, training, tlsc)
     o1 = basic_conv(z, P, 'feat_extract.5.', 3, act=False) + x
     return [o4, o2, o1]

@@ -66,9 +66,10 @@ def whole_net(mod, tag, num_res, seed, n, h, w, d):
     print(tag, [tuple(o.shape) for o in outs], 'params', len(names), 'without grad', int((d[tag + '_gnorm'] < 0).sum()))
 
 
-def eval_net(mod, tag, num_res, seed, n, h, w, d):
-    """the same network after .eval() (the trainer's validation pass): BatchNorm2d on its running statistics, no buffer moves"""
-    net = mod.SFNet(mode=['train', 'Indoor'], num_res=num_res)
+def eval_net(mod, tag, num_res, seed, n, h, w, d, mode=('train', 'Indoor')):
+    """the same network after .eval() (the trainer's validation pass): BatchNorm2d on its running statistics, no buffer moves.
+    mode[0] == 'test': the inference network of the reference -- Gap / Patch_ap / SFconv pool with the TLSC box mean (:108-113, :226-229, :247-250)"""
+    net = mod.SFNet(mode=list(mode), num_res=num_res)
     P = SO.synth_state(num_res, seed)
     net.load_state_dict(P)
     net.eval()
@@ -131,6 +132,8 @@ def main():
     e = {}
     eval_net(mod, 'eval_r2', 2, 23, 2, 64, 64, e)
     eval_net(mod, 'eval_r1_one', 1, 24, 1, 40, 72, e)               # one image: what a validation loader feeds
+    eval_net(mod, 'test_indoor_r2', 2, 25, 1, 64, 96, e, mode=('test', 'Indoor'))
+    eval_net(mod, 'test_outdoor_r1', 1, 26, 2, 48, 40, e, mode=('test', 'Outdoor'))
     np.savez_compressed(os.path.join(HERE, 'sfnet_eval.npz'), **e)
     print('wrote', os.path.join(HERE, 'sfnet_eval.npz'), len(e), 'arrays')
 

@@ -233,8 +233,33 @@ def test_module_mirror_trains_like_the_oracle(K):
         if k.endswith('main.3.main.0.bias') and k.startswith('SCM'):
             continue
         assert md(p.grad, P[k].grad) <= 2e-3 * P[k].grad.abs().max().item() + 1e-7, k
-    with pytest.raises(NotImplementedError):
-        define_network(dict(type='SFNet', mode=['test', 'Indoor'], num_res=1))
+    with pytest.raises(ValueError):
+        define_network(dict(type='SFNet', mode=['test', 'Underwater'], num_res=1))
+    with pytest.raises(NotImplementedError):                         # the reference's inference network: no training pass
+        define_network(dict(type='SFNet', mode=['test', 'Indoor'], num_res=1)).cuda().train()(x.cuda())
+
+
+@pytest.mark.parametrize('tag,mode', [('test_indoor_r2', 'Indoor'), ('test_outdoor_r1', 'Outdoor')])
+def test_inference_network_with_tlsc_pooling_against_the_reference_golden(K, tag, mode):
+    """mode = ['test', Indoor | Outdoor] (sfnet_arch_utils.py:108-113, :226-229, :247-250): Gap / Patch_ap / SFconv on the box-mean map;
+    the nn.Module after .eval() against what the reference class produced (tests/golden/sfnet_eval.npz) and against the oracle"""
+    from textualdegremoval_amd.models.archs import define_network
+    ge = np.load(GOLDEN.replace('sfnet.npz', 'sfnet_eval.npz'), allow_pickle=False)
+    num_res, seed, n, h, w = (int(v) for v in ge[tag + '_cfg'])
+    sd = SO.synth_state(num_res, seed)
+    net = define_network(dict(type='SFNet', mode=['test', mode], num_res=num_res)).cuda()
+    net.load_state_dict(sd)
+    net.eval()
+    x = torch.from_numpy(ge[tag + '_x'])
+    with torch.no_grad():
+        outs = net(x.cuda())
+        ro = SO.sfnet_forward(sd, x, num_res, training=False, tlsc=SO.TLSC_BASE[mode])
+        glob = SO.sfnet_forward(sd, x, num_res, training=False)
+    for i, o in enumerate(outs):
+        want = torch.from_numpy(ge[f'{tag}_out{i}'])
+        assert o.shape == want.shape and md(o, want) < 1e-4 and md(o, ro[i]) < 1e-4, (i, md(o, want), md(o, ro[i]))
+    assert md(outs[2], glob[2]) > 3 * md(outs[2], ro[2])            # and it is not the global-pool network
+    assert all(torch.equal(v.cpu(), sd[k]) for k, v in net.state_dict().items())
 
 
 def test_reference_default_depth_num_res_16_against_the_oracle():

@@ -75,6 +75,33 @@ def test_whole_network_after_eval(tag):
     assert n == 1 or (tr[2] - outs[2]).abs().max().item() > 1e-3
 
 
+@pytest.mark.parametrize('tag,mode', [('test_indoor_r2', 'Indoor'), ('test_outdoor_r1', 'Outdoor')])
+def test_inference_network_with_tlsc_pooling(tag, mode):
+    """mode = ['test', Indoor | Outdoor]: Gap / Patch_ap / SFconv pool with the TLSC box mean (sfnet_arch_utils.py:11-70, :108-113, :226-229, :247-250)"""
+    g = np.load(GOLDEN.replace('sfnet.npz', 'sfnet_eval.npz'), allow_pickle=False)
+    num_res, seed, n, h, w = (int(v) for v in g[tag + '_cfg'])
+    P = SO.synth_state(num_res, seed)
+    with torch.no_grad():
+        outs = SO.sfnet_forward(P, torch.from_numpy(g[tag + '_x']), num_res, training=False, tlsc=SO.TLSC_BASE[mode])
+        glob = SO.sfnet_forward(P, torch.from_numpy(g[tag + '_x']), num_res, training=False)
+    for i, o in enumerate(outs):
+        want = torch.from_numpy(g[f'{tag}_out{i}'])
+        assert o.shape == want.shape and (o - want).abs().max().item() < 2e-5, (i, (o - want).abs().max().item())
+    assert (outs[2] - glob[2]).abs().max().item() > 2e-4             # the global-pool network is a different function
+
+
+def test_tlsc_box_mean_against_its_integral_image_form():
+    """tlsc_avgpool restates AvgPool2d's exact branch (:55-63: cumsum / cumsum, four-corner difference, replicate pad) as a window mean"""
+    x = torch.rand(2, 3, 20, 28, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    for base in (246, 210, 128):
+        k1, k2 = 20 * base // 256, 28 * base // 256
+        s = torch.nn.functional.pad(x.cumsum(-1).cumsum(-2), (1, 0, 1, 0))
+        ref = (s[:, :, k1:, k2:] + s[:, :, :-k1, :-k2] - s[:, :, :-k1, k2:] - s[:, :, k1:, :-k2]) / (k1 * k2)
+        _h, _w = ref.shape[2:]
+        ref = torch.nn.functional.pad(ref, ((28 - _w) // 2, (28 - _w + 1) // 2, (20 - _h) // 2, (20 - _h + 1) // 2), mode='replicate')
+        assert (SO.tlsc_avgpool(x, base) - ref).abs().max().item() < 1e-12
+
+
 @pytest.mark.parametrize('tag', ['dyn3', 'dyn5'])
 def test_dynamic_filter(g, tag):
     c, k, n, h, w = (int(v) for v in g[tag + '_cfg'])

@@ -220,6 +220,10 @@ SIGNATURES = {
     'tdr_sf_dynfilt_bwd_dx': (i32, [c_fp] * 5 + [i32] * 6 + [c_fp, i64, c_fp]),
     'tdr_convt4_weight_to_3x3': (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_convt4_grad_from_3x3': (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp, c_fp]),
+    'tdr_sf_region_split': (i32, [c_fp, i64, i32, i32, i32, i32, i32, c_fp, c_fp]),
+    'tdr_sf_local_affine': (i32, [c_fp, i64, c_fp, c_fp, c_fp, f32, i32, i32, i32, i32, i32, c_fp, i64, c_fp]),
+    'tdr_sf_emerge': (i32, [c_fp, i64, c_fp, i32, i32, i32, c_fp, c_fp]),
+    'tdr_sf_softmax_mix': (i32, [c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp]),
     'tdr_scaled_conv_param_grads': (i32, [c_fp] * 5 + [i32, i32] + [c_fp] * 3 + [c_fp]),
     'tdr_chansum_ws_floats': (i64, [i32, i32, i32]),
     'tdr_channel_sum': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp, c_fp]),

@@ -455,6 +455,65 @@ __global__ void repeat4_kernel(const float* __restrict__ b, int Cout, float* __r
     else const_cast<float*>(b)[i] = (b4[4 * i] + b4[4 * i + 1]) + (b4[4 * i + 2] + b4[4 * i + 3]);
 }
 
+// ---- mode[0] == 'test' (inference with TLSC pooling, sfnet_arch_utils.py:108-113, :226-229, :247-250): the pooled operand of Gap / Patch_ap /
+// SFconv is a per-pixel box-mean MAP (tdr_local_avgpool, csrc/tdr_tlsc.hip) instead of one number per plane.  Forward only.
+// region planes of a dense-NCHW view as their own tensor: out [N][(c q + p1) q + p2][H / q][W / q] = x[n][c][p1 H / q + i][p2 W / q + j]
+// (q = 1: a dense copy of a channel slice; q = 2: Patch_ap's `b c (p1 w1) (p2 w2) -> b (c p1 p2) w1 w2`)
+__global__ __launch_bounds__(256) void region_split_kernel(const float* __restrict__ x, long x_ns, int q, int C, int H, int W, float* __restrict__ out) {
+    const int Hq = H / q, Wq = W / q;
+    const int J = blockIdx.y, n = blockIdx.z;
+    const int c = J / (q * q), p1 = (J / q) % q, p2 = J % q;
+    const float* src = x + (long)n * x_ns + (long)c * H * W + (long)p1 * Hq * W + (long)p2 * Wq;
+    float* dst = out + ((long)n * C * q * q + J) * Hq * Wq;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Hq * Wq; i += gridDim.x * 256) dst[i] = src[(long)(i / Wq) * W + i % Wq];
+}
+// y = m * pl[J] + (x - m) * (ph[J] + shift), m = the box-mean map of the pixel's region plane (the reference's own operation order:
+// Gap x_d * fscale_d + (x - x_d) * (fscale_h + 1), :117-119; Patch_ap (patch_x - low) * h + low * l, :262-263)
+__global__ __launch_bounds__(256) void local_affine_kernel(const float* __restrict__ x, long x_ns, const float* __restrict__ m, const float* __restrict__ ph,
+                                                           const float* __restrict__ pl, float shift, int q, int C, int H, int W,
+                                                           float* __restrict__ y, long y_ns) {
+    const int Hq = H / q, Wq = W / q;
+    const int J = blockIdx.y, n = blockIdx.z;
+    const int c = J / (q * q), p1 = (J / q) % q, p2 = J % q;
+    const long off = (long)c * H * W + (long)p1 * Hq * W + (long)p2 * Wq;
+    const float* src = x + (long)n * x_ns + off;
+    float* dst = y + (long)n * y_ns + off;
+    const float* mm = m + ((long)n * C * q * q + J) * Hq * Wq;
+    const float a = ph[J] + shift, b = pl[J];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Hq * Wq; i += gridDim.x * 256) {
+        const long o = (long)(i / Wq) * W + i % Wq;
+        const float lo = mm[i];
+        dst[o] = lo * b + (src[o] - lo) * a;
+    }
+}
+// SFconv's `emerge = low + high` with high = x - low (:218; one rounding away from x, kept as the reference computes it)
+__global__ __launch_bounds__(256) void emerge_kernel(const float* __restrict__ x, long x_ns, const float* __restrict__ low, int CHW, float* __restrict__ out) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < CHW; i += gridDim.x * 256) {
+        const float l = low[(long)n * CHW + i];
+        out[(long)n * CHW + i] = l + (x[(long)n * x_ns + i] - l);
+    }
+}
+// per pixel: softmax over the 2c logits [lh[:, p] ; ll[:, p]] (nn.Softmax(dim=1) on the concatenation, :226-227), mix = (x - low) * a_high + low * a_low
+__global__ __launch_bounds__(256) void softmax_mix_kernel(const float* __restrict__ x, long x_ns, const float* __restrict__ low, const float* __restrict__ lh,
+                                                          const float* __restrict__ ll, int c, int HW, float* __restrict__ mix) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float* ph = lh + (long)n * c * HW + p;
+    const float* pl = ll + (long)n * c * HW + p;
+    float mx = ph[0];
+    for (int k = 0; k < c; ++k) mx = fmaxf(mx, fmaxf(ph[(long)k * HW], pl[(long)k * HW]));
+    float s = 0.f;
+    for (int k = 0; k < c; ++k) s += __expf(ph[(long)k * HW] - mx) + __expf(pl[(long)k * HW] - mx);
+    const float inv = 1.f / s;
+    for (int k = 0; k < c; ++k) {
+        const float lo = low[((long)n * c + k) * HW + p];
+        const float hi = x[(long)n * x_ns + (long)k * HW + p] - lo;
+        mix[((long)n * c + k) * HW + p] = hi * (__expf(ph[(long)k * HW] - mx) * inv) + lo * (__expf(pl[(long)k * HW] - mx) * inv);
+    }
+}
+
 }  // namespace
 
 extern "C" int tdr_gelu_fwd(const float* x, const float* bias, int C, int HW, float* z_out, float* y, int64_t n, void* stream) {
@@ -584,5 +643,34 @@ extern "C" int tdr_convt4_grad_from_3x3(const float* dw3, const float* db4, int 
     hipLaunchKernelGGL(convt4_to_3x3_kernel, dim3(tdr_cdiv((long)36 * Cout * Cin, 256)), dim3(256), 0, st, dw, Cin, Cout, const_cast<float*>(dw3), 1);
     if (db && db4) hipLaunchKernelGGL(repeat4_kernel, dim3(tdr_cdiv(Cout, 256)), dim3(256), 0, st, db, Cout, const_cast<float*>(db4), 1);
     TDR_LAUNCH_CHECK("convt4_grad_from_3x3");
+    return TDR_OK;
+}
+
+extern "C" int tdr_sf_region_split(const float* x, int64_t x_ns, int q, int N, int C, int H, int W, float* out, void* stream) {
+    TDR_REQUIRE(x && out && (q == 1 || q == 2) && H % q == 0 && W % q == 0 && N > 0 && C > 0, "tdr_sf_region_split: bad argument");
+    hipLaunchKernelGGL(region_split_kernel, dim3(tdr_cdiv((long)(H / q) * (W / q), 1024), C * q * q, N), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns,
+                       q, C, H, W, out);
+    TDR_LAUNCH_CHECK("region_split_kernel");
+    return TDR_OK;
+}
+extern "C" int tdr_sf_local_affine(const float* x, int64_t x_ns, const float* m, const float* ph, const float* pl, float shift, int q, int N, int C,
+                                   int H, int W, float* y, int64_t y_ns, void* stream) {
+    TDR_REQUIRE(x && m && ph && pl && y && (q == 1 || q == 2) && H % q == 0 && W % q == 0, "tdr_sf_local_affine: bad argument");
+    hipLaunchKernelGGL(local_affine_kernel, dim3(tdr_cdiv((long)(H / q) * (W / q), 1024), C * q * q, N), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns,
+                       m, ph, pl, shift, q, C, H, W, y, (long)y_ns);
+    TDR_LAUNCH_CHECK("local_affine_kernel");
+    return TDR_OK;
+}
+extern "C" int tdr_sf_emerge(const float* x, int64_t x_ns, const float* low, int N, int C, int HW, float* out, void* stream) {
+    TDR_REQUIRE(x && low && out && N > 0 && C > 0 && HW > 0, "tdr_sf_emerge: bad argument");
+    hipLaunchKernelGGL(emerge_kernel, dim3(tdr_cdiv((long)C * HW, 1024), N), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, low, C * HW, out);
+    TDR_LAUNCH_CHECK("emerge_kernel");
+    return TDR_OK;
+}
+extern "C" int tdr_sf_softmax_mix(const float* x, int64_t x_ns, const float* low, const float* lh, const float* ll, int N, int C, int HW, float* mix,
+                                  void* stream) {
+    TDR_REQUIRE(x && low && lh && ll && mix && N > 0 && C > 0 && HW > 0, "tdr_sf_softmax_mix: bad argument");
+    hipLaunchKernelGGL(softmax_mix_kernel, dim3(tdr_cdiv(HW, 256), N), dim3(256), 0, (hipStream_t)stream, x, (long)x_ns, low, lh, ll, C, HW, mix);
+    TDR_LAUNCH_CHECK("softmax_mix_kernel");
     return TDR_OK;
 }

@@ -2091,6 +2091,40 @@ def region_affine_bwd(dy, x, ph, pl, shift, mean, q, dx):
                                             dpl.data_ptr(), ws.data_ptr(), _stream()), 'tdr_region_affine_bwd')
     return dph, dpl
 
+def sf_region_split(x, q):
+    """the q x q region planes of a dense-NCHW view as a contiguous [N, C q q, H / q, W / q] tensor (q = 1: a dense copy of a channel slice)"""
+    N, Cc, H, W = x.shape
+    out = torch.empty(N, Cc * q * q, H // q, W // q, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_sf_region_split(x.data_ptr(), _dense_nchw(x), q, N, Cc, H, W, out.data_ptr(), _stream()), 'tdr_sf_region_split')
+    return out
+
+
+def sf_local_affine(x, m, ph, pl, shift, q, out):
+    """out = m * pl + (x - m) * (ph + shift) with m [N, C q q, H / q, W / q] the TLSC box-mean map of x's region planes (SFNet mode 'test')"""
+    N, Cc, H, W = x.shape
+    assert m.is_contiguous() and m.shape == (N, Cc * q * q, H // q, W // q)
+    check(_lib.load().tdr_sf_local_affine(x.data_ptr(), _dense_nchw(x), m.data_ptr(), ph.data_ptr(), pl.data_ptr(), float(shift), q, N, Cc, H, W,
+                                          out.data_ptr(), _dense_nchw(out), _stream()), 'tdr_sf_local_affine')
+    return out
+
+
+def sf_emerge(x, low):
+    N, Cc, H, W = x.shape
+    out = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_sf_emerge(x.data_ptr(), _dense_nchw(x), low.data_ptr(), N, Cc, H * W, out.data_ptr(), _stream()), 'tdr_sf_emerge')
+    return out
+
+
+def sf_softmax_mix(x, low, lh, ll):
+    """per pixel: softmax over the 2c logits [lh ; ll], mix = (x - low) * a_high + low * a_low"""
+    N, Cc, H, W = x.shape
+    assert low.is_contiguous() and lh.is_contiguous() and ll.is_contiguous()
+    mix = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x.device)
+    check(_lib.load().tdr_sf_softmax_mix(x.data_ptr(), _dense_nchw(x), low.data_ptr(), lh.data_ptr(), ll.data_ptr(), N, Cc, H * W, mix.data_ptr(),
+                                         _stream()), 'tdr_sf_softmax_mix')
+    return mix
+
+
 
 def sf_dyn_vec_fwd(ap, P, pre, k, groups=8, training=True):
     """the pooled-vector pipeline of dynamic_filter + SFconv (one workgroup): -> (taps [N, G k k], ah [N, c], al [N, c], saved).

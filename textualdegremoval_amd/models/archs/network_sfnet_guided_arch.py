@@ -3,9 +3,11 @@
 `SFNet` (:320-407) -- the un-guided network -- is built here: same constructor (`mode`, `num_res`), same module tree, registration
 order, parameter / buffer names and default initialisation (the layers below are ordinary torch modules used as PARAMETER CONTAINERS; no
 torch operator runs in the forward or backward pass: both go through textualdegremoval_amd/sfnet_engine.py on the HIP kernels).  Only
-mode[0] == 'train' is supported (global average pools) -- in training mode (BatchNorm2d on batch statistics, running buffers moved) and
-after .eval() (BatchNorm2d on its running statistics: the validation pass of the trainer); mode 'test' swaps every pooling for the TLSC
-box filter with Indoor / Outdoor base sizes (sfnet_arch_utils.py:108-113) and is not built.
+mode[0] == 'train' (global average pools) runs in training mode (BatchNorm2d on batch statistics, running buffers moved) and after .eval()
+(BatchNorm2d on its running statistics: the validation pass of the trainer); mode[0] == 'test' -- the reference's inference network, where Gap,
+Patch_ap and SFconv pool with the TLSC box mean of the Indoor / Outdoor base size (sfnet_arch_utils.py:108-113, :226-229, :247-250) -- runs
+after .eval(), forward only.  (The reference caches each pooling window from the first input a module instance sees; here the window follows
+the input of the call, which is the same thing for a fresh network or inputs of one size.)
 
 `SFNetRefFusion` (:410-797) is registered so that the shipped YAML's `type: SFNetRefFusion` resolves, but there is no network behind it,
 because there is none in the reference either (defect R8, recorded by tests/golden/make_golden_defects.py by running the reference): the
@@ -101,8 +103,10 @@ class _SFNetFn(torch.autograd.Function):
 class SFNet(nn.Module):
     def __init__(self, mode, num_res=16):
         super().__init__()
-        if mode[0] != 'train':
-            raise NotImplementedError("SFNet on the HIP path: mode[0] == 'train' only (the 'test' mode's TLSC pooling is not built)")
+        if mode[0] not in ('train', 'test') or (mode[0] == 'test' and mode[1] not in ('Indoor', 'Outdoor')):
+            raise ValueError(f"SFNet: mode {mode!r} (['train', ...] or ['test', 'Indoor' | 'Outdoor'], sfnet_arch_utils.py:108-113)")
+        # mode[0] == 'test': Gap / Patch_ap / SFconv pool with the TLSC box mean (base size 246 Indoor / 210 Outdoor); same parameters
+        self.tlsc = {'Indoor': 246, 'Outdoor': 210}[mode[1]] if mode[0] == 'test' else None
         b = BASE
         self.num_res = num_res
         self.Encoder = nn.ModuleList([_block(b, num_res), _block(2 * b, num_res), _block(4 * b, num_res)])
@@ -129,7 +133,9 @@ class SFNet(nn.Module):
             from ... import sfnet_engine as SE
             P = {k: p.detach() for k, p in named}
             P.update(buffers)
-            return list(SE.net_fwd(P, x.detach(), self.num_res, training=False)[0])
+            return list(SE.net_fwd(P, x.detach(), self.num_res, training=False, tlsc=self.tlsc)[0])
+        if self.tlsc is not None:
+            raise NotImplementedError("SFNet mode 'test' is the reference's inference network: call .eval() first (no training pass is built for it)")
         return list(_SFNetFn.apply(x, self.num_res, [k for k, _ in named], buffers, *[p for _, p in named]))
 
 

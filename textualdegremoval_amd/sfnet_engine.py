@@ -60,6 +60,13 @@ def convt_bwd(dy, P, pre, saved, G):
 
 # ------------------------------------------------------------------------------------------------- dynamic_filter + SFconv (:152-236)
 _training = True        # set by net_fwd for the pass it runs
+_tlsc = None            # mode[0] == 'test': the TLSC base size (246 Indoor / 210 Outdoor); forward only
+TLSC_BASE = {'Indoor': 246, 'Outdoor': 210}       # sfnet_arch_utils.py:110-113
+
+
+def _box(x, H, W):
+    """AvgPool2d(base_size) of the reference's test mode on a contiguous [N, C, H, W]: k = size * base // 256 (:33-34), replicate-padded back"""
+    return K.local_avgpool(x, min(H, H * _tlsc // 256), min(W, W * _tlsc // 256))
 
 
 def dyn_fwd(x, P, pre, k, out):
@@ -67,6 +74,13 @@ def dyn_fwd(x, P, pre, k, out):
     ap = K.plane_mean(x)
     taps, ah, al, sv = K.sf_dyn_vec_fwd(ap, P, pre, k, GROUPS, training=_training)
     low, mix = K.sf_dynfilt_fwd(x, taps, ah, al, k, GROUPS)
+    if _tlsc is not None:
+        # SFconv.gap is the box mean: per-pixel attention (dynamic_filter.ap above stays global, :171); 1x1 convolutions on the map
+        H, W = x.shape[2:]
+        z = E.conv_fwd(_box(K.sf_emerge(x, low), H, W), P[pre + 'modulate.fc.weight'], P[pre + 'modulate.fc.bias'], 1, 0)
+        lh = E.conv_fwd(z, P[pre + 'modulate.fcs.0.weight'], P[pre + 'modulate.fcs.0.bias'], 1, 0)
+        ll = E.conv_fwd(z, P[pre + 'modulate.fcs.1.weight'], P[pre + 'modulate.fcs.1.bias'], 1, 0)
+        mix = K.sf_softmax_mix(x, low, lh, ll)
     E.conv_fwd(mix, P[pre + 'modulate.out.weight'], P[pre + 'modulate.out.bias'], 1, 0, out=out)
     return (x, low, mix, taps, ah, al, sv)
 
@@ -92,6 +106,11 @@ def res_fwd(x, P, pre, filt):
         cur = torch.empty_like(y1)
         svd = (dyn_fwd(y1[:, :h], P, pre + 'dyna.', 3, cur[:, :h]), dyn_fwd(y1[:, h:], P, pre + 'dyna_2.', 5, cur[:, h:]))
     r = torch.empty_like(cur)
+    if _tlsc is not None:
+        K.sf_local_affine(cur[:, :h], _box(K.sf_region_split(cur[:, :h], 1), H, W), P[pre + 'global_ap.fscale_h'], P[pre + 'global_ap.fscale_d'], 1.0, 1, r[:, :h])
+        K.sf_local_affine(cur[:, h:], _box(K.sf_region_split(cur[:, h:], 2), H // 2, W // 2), P[pre + 'localap.h'], P[pre + 'localap.l'], 0.0, 2, r[:, h:])
+        out, _ = conv_fwd(r, P, pre + 'conv2.', 3, act=False, res=x)
+        return out, None
     mg = K.region_affine_fwd(cur[:, :h], P[pre + 'global_ap.fscale_h'], P[pre + 'global_ap.fscale_d'], 1.0, 1, r[:, :h])
     mp = K.region_affine_fwd(cur[:, h:], P[pre + 'localap.h'], P[pre + 'localap.l'], 0.0, 2, r[:, h:])
     out, sv2 = conv_fwd(r, P, pre + 'conv2.', 3, act=False, res=x)
@@ -163,11 +182,22 @@ def cat_conv_bwd(dy, P, pre, saved, G):
 
 
 # ------------------------------------------------------------------------------------------------- SFNet.forward (:366-407)
-def net_fwd(P, x, num_res, training=True):
+def net_fwd(P, x, num_res, training=True, tlsc=None):
     """training=False: module.eval() -- BatchNorm2d on its running statistics, buffers untouched (InstanceNorm2d and the global pools are
-    the same in both modes: the reference builds them without running statistics, sfnet_arch_utils.py:208, :108)"""
-    global _training
-    _training = bool(training)
+    the same in both modes: the reference builds them without running statistics, sfnet_arch_utils.py:208, :108).
+    tlsc = TLSC_BASE[mode[1]]: the mode[0] == 'test' network -- Gap / Patch_ap / SFconv pool with the box mean of that base size;
+    inference only (nothing is kept for a backward pass)"""
+    global _training, _tlsc
+    if tlsc is not None and training:
+        raise ValueError("SFNet mode 'test' is an inference network: training=False")
+    _training, _tlsc = bool(training), tlsc
+    try:
+        return _net_fwd(P, x, num_res)
+    finally:
+        _training, _tlsc = True, None           # (the operator-level entry points default to the training pass)
+
+
+def _net_fwd(P, x, num_res):
     x = x.contiguous()
     x_2 = K.subsample2(x)
     x_4 = K.subsample2(x_2)
