@@ -355,6 +355,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const TdrPackJob* __res
     if (i >= jb.total) return;
     if (jb.fmt == 0)
         reinterpret_cast<float*>(jb.wp)[i] = tdr_pack_f32_elem(jb.w, jb.Cin, jb.KH, jb.mode, jb.CK, jb.M, jb.Kch, jb.KHe, jb.Mx, i);
+    else if (jb.fmt == 1 && jb.KHe == 3 && jb.mode == 0)   // 3x3: one thread per (group, m-tile, lane), all nine taps (tdr_pack_job_init sizes `total`)
+        tdr_pack_bx3_alltaps9<0>(jb.w, jb.Cin, jb.M, jb.Kch, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
+    else if (jb.fmt == 1 && jb.KHe == 3 && jb.mode == 1)
+        tdr_pack_bx3_alltaps9<1>(jb.w, jb.Cin, jb.M, jb.Kch, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
     else if (jb.fmt == 1)
         tdr_pack_bx3_frag(jb.w, jb.Cin, jb.KH, jb.mode, jb.M, jb.Kch, jb.KHe, jb.Mx, i, reinterpret_cast<uint4*>(jb.wp));
     else if (jb.mode == 0 && jb.KHe == 1)            // forward layout: one thread per (group, m-tile, lane), all taps (tdr_pack_job_init sizes `total`)
@@ -388,6 +392,8 @@ extern "C" int tdr_pack_job_init(TdrPackJob* job, const float* w, int Cout, int 
         job->total = (long)((Kch + 15) / 16) * KHe * KHe * job->Mx * 64;
         // hx2 forward layout: one thread makes the fragments of all taps (tdr_pack_hx2_fwd_alltaps)
         if (fmt == 2 && mode == 0 && KHe >= 1 && KHe <= 3) job->total = (long)((Kch + 15) / 16) * job->Mx * 64;
+        // bx3, 3x3 forward / stride-1 data-gradient layouts: likewise (tdr_pack_bx3_alltaps9)
+        if (fmt == 1 && KHe == 3 && mode <= 1) job->total = (long)((Kch + 15) / 16) * job->Mx * 64;
     }
     job->first_block = 0;
     return TDR_OK;

@@ -64,6 +64,57 @@ __device__ __forceinline__ void tdr_pack_bx3_frag(const float* __restrict__ w, i
     o[0] = h.u; o[64] = mm.u; o[128] = l.u;
 }
 
+// 3x3 weights, forward (MODE 0) or stride-1 data-gradient layout (MODE 1), with ONE thread per (group, m-tile, lane) producing the triple-plane
+// fragments of ALL nine taps (i = (grp * MT + mt) * 64 + lane; same bits as tdr_pack_bx3_frag).  One thread per (fragment, tap) gathers 8 scalars
+// 36 bytes apart (forward) or whole rows apart (data gradient) NINE times over -- once per tap -- through different workgroups: 9 x the sector
+// traffic of the 27 M 3x3 weights of the headline network.  Here a lane's 72 forward weights are one contiguous run (16-byte loads), and the nine
+// taps of a data-gradient channel are nine consecutive floats read back to back.
+template <int MODE>
+__device__ __forceinline__ void tdr_pack_bx3_alltaps9(const float* __restrict__ w, int Cin, int M, int Kch, int MT, long i, uint4* __restrict__ wp) {
+    constexpr int TAPS = 9;
+    const int lane = (int)(i & 63);
+    const long r = i >> 6;
+    const int mt = (int)(r % MT);
+    const int grp = (int)(r / MT);
+    const int m = mt * 32 + (lane & 31);
+    const int c0 = grp * 16 + 8 * (lane >> 5);
+    float v[8 * TAPS];                       // v[e * TAPS + t] = tdr_pack_value(w, Cin, 3, MODE, m, c0 + e, t)
+    if (MODE == 0) {
+        const long base = ((long)m * Cin + c0) * TAPS;
+        if (m < M && c0 + 8 <= Kch && ((reinterpret_cast<uintptr_t>(w + base) & 15) == 0)) {
+#pragma unroll
+            for (int q = 0; q < 2 * TAPS; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(w + base + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) v[e * TAPS + t] = (m < M && c0 + e < Kch) ? w[base + e * TAPS + t] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long base = ((long)(c0 + e) * Cin + m) * TAPS;          // w[c][m][:]: transposed; the taps are flipped below
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) v[e * TAPS + t] = (m < M && c0 + e < Kch) ? w[base + (TAPS - 1 - t)] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        TdrFrag h, mm, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 a0, a1, a2;
+            tdr_split3(v[e * TAPS + t], a0, a1, a2);
+            h.v[e] = a0; mm.v[e] = a1; l.v[e] = a2;
+        }
+        uint4* o = wp + ((((long)grp * TAPS + t) * MT + mt) * 3) * 64 + lane;
+        o[0] = h.u; o[64] = mm.u; o[128] = l.u;
+    }
+}
+
 // the same fragment in the 2-way fp16 split layout Wp2[group][tap][mt][split(h, m)][lane][8 x f16]
 typedef _Float16 tdr_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void tdr_pack_hx2_frag(const float* __restrict__ w, int Cin, int KH, int mode, int M, int Kch,
