@@ -22,7 +22,7 @@ extern "C" {
 
 /* C-ABI version: bumped with every incompatible change of this header (100 rounds 1-2, 101 round 3, 102 round 4); the
  * binding (textualdegremoval_amd/_lib.py) refuses a library whose version differs from the one it was written against. */
-#define TDR_ABI_VERSION 106
+#define TDR_ABI_VERSION 107
 int tdr_version(void);
 const char* tdr_last_error(void);
 
@@ -767,6 +767,16 @@ int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream);
  * mid: scratch of tdr_pair_sum_mid_floats(nparts, C) floats (a 256-to-1 first stage above 1024 rows; may be NULL when 0) */
 int64_t tdr_pair_sum_mid_floats(int nparts, int C);
 int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float* o1, float* mid, void* stream);
+/* Table-driven forms of three small finishing reductions (ABI 107): the deferred leaves of a NAFBlock level are dozens of problems of ONE
+ * shape (28 blocks at the 64x64 level: 56 LayerNorm-partial reductions, 28 depthwise parameter finishes, 28 conv5 / gamma parameter
+ * gradients), each a 6 us launch; one launch per kind takes a table of device pointers (64-bit words, DEVICE memory) instead.  Per problem the
+ * summation order of the single-problem entry point: bit-identical results.
+ *   tdr_pair_sum_partials_multi:       rows {part, o0, o1};  nparts <= 1024 (the one-stage reduction)
+ *   tdr_dw_param_finish_multi:         rows {ws, dw, db}
+ *   tdr_scaled_conv_param_grads_multi: rows {G, S, w, b, gamma, dw, db, dgamma} */
+int tdr_pair_sum_partials_multi(const void* table, int nprob, int nparts, int C, void* stream);
+int tdr_dw_param_finish_multi(const void* table, int nprob, int N, int C, int H, int W, void* stream);
+int tdr_scaled_conv_param_grads_multi(const void* table, int nprob, int Cout, int Cin, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Data-parallel exchange over RCCL / xGMI: replaces DistributedDataParallel's gradient all-reduce and

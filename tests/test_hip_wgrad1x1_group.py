@@ -76,3 +76,59 @@ def test_network_backward_grouped_equals_ungrouped(K):
         worst = max(worst, (res[True][k] - g).abs().max().item() / max(g.abs().max().item(), 1e-30))
     # the grouped launch cuts the pixel sum of a weight gradient differently (whole images instead of 32 slices): rounding only
     assert worst < 5e-6, worst
+
+
+def test_finishing_reductions_batched_are_bit_identical(K):
+    """the table-driven forms of the three small finishing reductions (kernels.pair_sum_partials_multi / dw_param_finish_multi /
+    scaled_conv_param_grads_multi) write, per problem, exactly what the single-problem entry points write"""
+    lib = __import__('textualdegremoval_amd._lib', fromlist=['load']).load()
+    g = torch.Generator().manual_seed(11)
+    # LayerNorm-gradient partials [nparts][2][C]
+    for nparts, Cc, n in ((256, 256, 5), (37, 96, 3), (1024, 32, 2)):
+        wss = [torch.randn(nparts * 2 * Cc, generator=g).cuda() for _ in range(n)]
+        got = K.pair_sum_partials_multi([(w, nparts, Cc) for w in wss], seq=900)
+        for w, (gw, gb) in zip(wss, got):
+            rw, rb = torch.empty(Cc, device='cuda'), torch.empty(Cc, device='cuda')
+            K.check(lib.tdr_pair_sum_partials(w.data_ptr(), nparts, Cc, rw.data_ptr(), rb.data_ptr(), 0, K._stream()), 'pair_sum')
+            assert torch.equal(gw, rw) and torch.equal(gb, rb)
+            assert (gw.double().cpu() - w.view(nparts, 2, Cc)[:, 0].double().sum(0).cpu()).abs().max() < 1e-3
+    # depthwise parameter partials
+    for N, Cc, H, W, n in ((4, 64, 64, 64, 4), (2, 24, 32, 48, 3)):
+        nws = int(lib.tdr_dwsg_ws_floats(N, Cc, H, W))
+        wss = [torch.randn(nws, generator=g).cuda() for _ in range(n)]
+        got = K.dw_param_finish_multi([(w, N, Cc, H, W) for w in wss], seq=901)
+        for w, (dw, db) in zip(wss, got):
+            rw, rb = torch.empty(2 * Cc, 1, 3, 3, device='cuda'), torch.empty(2 * Cc, device='cuda')
+            K.check(lib.tdr_dw_param_finish(w.data_ptr(), N, Cc, H, W, rw.data_ptr(), rb.data_ptr(), K._stream()), 'dw_finish')
+            assert torch.equal(dw, rw) and torch.equal(db, rb)
+    # conv5 / gamma parameter gradients
+    for Cout, Cin, n in ((256, 256, 6), (128, 256, 2), (40, 72, 3)):
+        items = [tuple(torch.randn(*shp, generator=g).cuda() for shp in ((Cout, Cin), (Cout,), (Cout, Cin), (Cout,), (Cout,))) for _ in range(n)]
+        got = K.scaled_conv_param_grads_multi(items, seq=902)
+        for it, r3 in zip(items, got):
+            ref = K.scaled_conv_param_grads(*it)
+            assert all(torch.equal(a, b) for a, b in zip(r3, ref))
+
+
+def test_network_backward_with_batched_finishers_is_bit_identical(K):
+    """engine.BATCH_FINISH on / off through the whole guided network (deferred leaves): the same gradients bit for bit"""
+    from oracle import nafnet_ref_oracle as O
+    from textualdegremoval_amd import engine as E
+    cfg = O.default_cfg(width=32, nf=32, enc_blk_nums=[1, 1, 1, 3], ext_n_blocks=[1, 1, 1, 1], reffusion_n_blocks=[1, 1, 1, 1, 1])
+    P = {k: v.cuda() for k, v in O.synth_params(cfg, seed=7).items()}
+    lq, gt, ref = (t.cuda() for t in O.synth_pair(2, 128, 128, seed=8))
+    res = {}
+    was = E.BATCH_FINISH, E.FORCE_DP_SCHEDULE, K.DETERMINISTIC
+    K.DETERMINISTIC = True                 # (the MASA transfer's scatter in fixed point: otherwise two runs of ONE setting differ in the last bit)
+    try:
+        for dp in (False, True):
+            for mode in (True, False):
+                E.BATCH_FINISH, E.FORCE_DP_SCHEDULE = mode, dp
+                out, saved = E.net_fwd(P, cfg, lq, ref)
+                _, dpred = K.l1_loss(out.contiguous(), gt)
+                res[dp, mode] = {k: v.clone() for k, v in E.net_bwd(dpred, P, cfg, saved).items()}
+            assert res[dp, True].keys() == res[dp, False].keys()
+            for k, gr in res[dp, False].items():
+                assert torch.equal(res[dp, True][k], gr), (dp, k)
+    finally:
+        E.BATCH_FINISH, E.FORCE_DP_SCHEDULE, K.DETERMINISTIC = was

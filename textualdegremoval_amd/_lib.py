@@ -15,7 +15,7 @@ import torch  # noqa: F401  (import order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TDR_LIB_PATH', os.path.join(_HERE, 'libtdr_hip.so'))   # override: profiling probe builds
 
-ABI_VERSION = 106      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
+ABI_VERSION = 107      # csrc/tdr_error.cpp: bumped with every incompatible change of include/tdr.h
 c_fp = C.c_void_p      # device pointers travel as integers
 i32, i64, f32 = C.c_int, C.c_int64, C.c_float
 
@@ -225,6 +225,9 @@ SIGNATURES = {
     'tdr_sf_emerge': (i32, [c_fp, i64, c_fp, i32, i32, i32, c_fp, c_fp]),
     'tdr_sf_softmax_mix': (i32, [c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp]),
     'tdr_scaled_conv_param_grads': (i32, [c_fp] * 5 + [i32, i32] + [c_fp] * 3 + [c_fp]),
+    'tdr_pair_sum_partials_multi': (i32, [c_fp, i32, i32, i32, c_fp]),
+    'tdr_dw_param_finish_multi': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp]),
+    'tdr_scaled_conv_param_grads_multi': (i32, [c_fp, i32, i32, i32, c_fp]),
     'tdr_chansum_ws_floats': (i64, [i32, i32, i32]),
     'tdr_channel_sum': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_copy_rows': (i32, [c_fp, i64, c_fp, i64, i32, i64, c_fp]),

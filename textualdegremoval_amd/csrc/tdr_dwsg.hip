@@ -474,6 +474,23 @@ __global__ void dw_param_finish_kernel(const float* __restrict__ part, int N, in
     else if (db) db[ch] = sacc;
 }
 
+// many problems of one (N, C, nb): table rows {part, dw, db}, blockIdx.y = problem; dw_param_finish_kernel's order
+__global__ void dw_param_finish_multi_kernel(const long long* __restrict__ tab, int N, int C, int nb) {
+    const long long* row = tab + 3L * blockIdx.y;
+    const float* part = reinterpret_cast<const float*>(row[0]);
+    float* dw = reinterpret_cast<float*>(row[1]);
+    float* db = reinterpret_cast<float*>(row[2]);
+    const int c = blockIdx.x, tid = threadIdx.x;
+    if (tid >= 20) return;
+    float sacc = 0.f;
+    for (int m = 0; m < N; ++m)
+        for (int g = 0; g < nb; ++g) sacc += part[(((long)m * C + c) * nb + g) * 20 + tid];
+    const int kk = tid % 10;
+    const int ch = tid < 10 ? c : c + C;
+    if (kk < 9) dw[ch * 9 + kk] = sacc;
+    else db[ch] = sacc;
+}
+
 __global__ void dw_pool_finish_kernel(const float* __restrict__ part, int NC, int nb, float inv_hw, float* __restrict__ pooled) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NC) return;
@@ -566,6 +583,15 @@ extern "C" int tdr_dw_param_finish(const float* ws, int N, int C, int H, int W, 
     const DwGeom q = dw_geom_fused(H, W);
     hipLaunchKernelGGL(dw_param_finish_kernel, dim3(C), dim3(32), 0, (hipStream_t)stream, const_cast<float*>(ws), N, C, q.nb, dw, db, 0);
     TDR_LAUNCH_CHECK("dw_param_finish_kernel");
+    return TDR_OK;
+}
+
+// table [nprob][3] of device pointers {ws, dw, db} in DEVICE memory; every problem has the same (N, C, H, W)
+extern "C" int tdr_dw_param_finish_multi(const void* table, int nprob, int N, int C, int H, int W, void* stream) {
+    TDR_REQUIRE(table && nprob > 0 && N > 0 && C > 0, "tdr_dw_param_finish_multi: bad argument");
+    const DwGeom q = dw_geom_fused(H, W);
+    hipLaunchKernelGGL(dw_param_finish_multi_kernel, dim3(C, nprob), dim3(32), 0, (hipStream_t)stream, static_cast<const long long*>(table), N, C, q.nb);
+    TDR_LAUNCH_CHECK("dw_param_finish_multi_kernel");
     return TDR_OK;
 }
 

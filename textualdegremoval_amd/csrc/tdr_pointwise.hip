@@ -419,6 +419,33 @@ __global__ __launch_bounds__(64 * KL) void pair_sum_partials_kernel(const float*
     }
 }
 
+// the same reduction for MANY problems of one (nparts, C) in one launch: table rows {part, o0, o1} (device pointers as 64-bit words),
+// blockIdx.z = problem; per problem exactly pair_sum_partials_kernel's summation order (bit-identical results)
+template <int KL>
+__global__ __launch_bounds__(64 * KL) void pair_sum_partials_multi_kernel(const long long* __restrict__ tab, int nparts, int C) {
+    __shared__ float red[KL][64];
+    const long long* row = tab + 3L * blockIdx.z;
+    const float* part = reinterpret_cast<const float*>(row[0]);
+    float* o = reinterpret_cast<float*>(blockIdx.y ? row[2] : row[1]);
+    const int lane = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int ec = e < C ? e : C - 1;
+    const float* p = part + (long)blockIdx.y * C + ec;
+    const long stride = 2L * C;
+    float s0 = 0.f, s1 = 0.f;
+    int k = kl;
+    for (; k + KL < nparts; k += 2 * KL) { s0 += p[(long)k * stride]; s1 += p[(long)(k + KL) * stride]; }
+    if (k < nparts) s0 += p[(long)k * stride];
+    red[kl][lane] = s0 + s1;
+    __syncthreads();
+    if (kl == 0 && e < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < KL; ++q) t += red[q][lane];
+        o[e] = t;
+    }
+}
+
 constexpr int LN_BWD_GRID = 1024;     // workspace rows (upper bound of the persistent grid)
 static const int ln_bwd_grid = tdr_tune_env("TDR_LN_BWD_GRID") ? atoi(tdr_tune_env("TDR_LN_BWD_GRID")) : 256;
 constexpr int LN_GEN_SPLITS = 16;
@@ -608,6 +635,35 @@ __global__ __launch_bounds__(256) void scaled_conv_param_kernel(const float* __r
                                                                float* __restrict__ dw, float* __restrict__ db,
                                                                float* __restrict__ dgamma) {
     __shared__ float red[4];
+    const int co = blockIdx.x;
+    const float gm = gamma[co];
+    float acc = 0.f;
+    for (int ci = threadIdx.x; ci < Cin; ci += 256) {
+        const float gv = G[(long)co * Cin + ci];
+        dw[(long)co * Cin + ci] = gm * gv;
+        acc += w[(long)co * Cin + ci] * gv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        db[co] = gm * S[co];
+        dgamma[co] = (red[0] + red[1]) + (red[2] + red[3]) + b[co] * S[co];
+    }
+}
+
+// many problems of one (Cout, Cin): table rows {G, S, w, b, gamma, dw, db, dgamma}, blockIdx.y = problem; scaled_conv_param_kernel's order
+__global__ __launch_bounds__(256) void scaled_conv_param_multi_kernel(const long long* __restrict__ tab, int Cin) {
+    __shared__ float red[4];
+    const long long* row = tab + 8L * blockIdx.y;
+    const float* G = reinterpret_cast<const float*>(row[0]);
+    const float* S = reinterpret_cast<const float*>(row[1]);
+    const float* w = reinterpret_cast<const float*>(row[2]);
+    const float* b = reinterpret_cast<const float*>(row[3]);
+    const float* gamma = reinterpret_cast<const float*>(row[4]);
+    float* dw = reinterpret_cast<float*>(row[5]);
+    float* db = reinterpret_cast<float*>(row[6]);
+    float* dgamma = reinterpret_cast<float*>(row[7]);
     const int co = blockIdx.x;
     const float gm = gamma[co];
     float acc = 0.f;
@@ -945,6 +1001,23 @@ extern "C" int tdr_pair_sum_partials(const float* part, int nparts, int C, float
     }
     hipLaunchKernelGGL(pair_sum_partials_kernel<16>, dim3(tdr_cdiv(C, 64), 2), dim3(1024), 0, st, part, nparts, C, o0, o1);
     TDR_LAUNCH_CHECK("pair_sum_partials");
+    return TDR_OK;
+}
+
+// table [nprob][3] of device pointers {part, o0, o1} in DEVICE memory; every problem has the same (nparts <= 1024, C)
+extern "C" int tdr_pair_sum_partials_multi(const void* table, int nprob, int nparts, int C, void* stream) {
+    TDR_REQUIRE(table && nprob > 0 && nparts > 0 && nparts <= 1024 && C > 0, "tdr_pair_sum_partials_multi: bad argument (one-stage reductions only: nparts <= 1024)");
+    hipLaunchKernelGGL(pair_sum_partials_multi_kernel<16>, dim3(tdr_cdiv(C, 64), 2, nprob), dim3(1024), 0, (hipStream_t)stream,
+                       static_cast<const long long*>(table), nparts, C);
+    TDR_LAUNCH_CHECK("pair_sum_partials_multi");
+    return TDR_OK;
+}
+
+// table [nprob][8] of device pointers {G, S, w, b, gamma, dw, db, dgamma} in DEVICE memory; every problem has the same (Cout, Cin)
+extern "C" int tdr_scaled_conv_param_grads_multi(const void* table, int nprob, int Cout, int Cin, void* stream) {
+    TDR_REQUIRE(table && nprob > 0 && Cout > 0 && Cin > 0, "tdr_scaled_conv_param_grads_multi: bad argument");
+    hipLaunchKernelGGL(scaled_conv_param_multi_kernel, dim3(Cout, nprob), dim3(256), 0, (hipStream_t)stream, static_cast<const long long*>(table), Cin);
+    TDR_LAUNCH_CHECK("scaled_conv_param_multi_kernel");
     return TDR_OK;
 }
 

@@ -67,6 +67,11 @@ DEFER_LN_FINISH = True                                                  # also t
 # deferred 1x1 leaf weight gradients of one shape (a level's conv1 / conv4, its conv5) share ONE launch + ONE reduction
 # (kernels.wgrad1x1_group, csrc/tdr_wgrad_1x1.hip): no per-launch ramp / prologue / partial write / reduction launch, 1 / 8 of the partials
 GROUP_LEAVES = True
+# ... and the small finishing reductions queued with them (LayerNorm-gradient partials, depthwise parameter partials, the conv5 / gamma
+# parameter gradients behind a grouped weight gradient) run as ONE table-driven launch per kind and shape (kernels.*_multi): 112 of the 184
+# finishing launches of the headline step are the 28 blocks of one level -- beside the MASA-encoder backward they hide, in the data-parallel
+# leaf schedule they are serial launches at the level's end
+BATCH_FINISH = True
 # data-parallel runs: the leaves of a level queued and run (grouped) at the level's end instead of one launch per leaf inside the chain
 LEVEL_LEAVES = True
 _level_mode = False
@@ -98,6 +103,16 @@ def _leaf(keep, fn, G):
     with K.on_side(*keep):
         for k, v in fn().items():
             G[k] = v                    # (item by item: a GradSink collector acts on __setitem__)
+
+
+def _leaf_fin(names, fin, G):
+    """a leaf that reduces per-workgroup partials: fin() -> the gradients of `names`.  Finishers that carry a `batch` description
+    (kernels._ln_partials_finish, kernels.dwsg_bwd) are queued as requests, so that _run_leaves can run all of one shape as one launch"""
+    b = getattr(fin, 'batch', None)
+    if _late is not None and BATCH_FINISH and b is not None:
+        _late.append((_late_pre, ('fin', (b[0],) + tuple(b[2:]), b, names, fin), (b[1],)))
+        return
+    _leaf((), lambda: dict(zip(names, fin())), G)
 
 
 def _leaf_wgrad1x1(keep, req, post, G, want_db=True):
@@ -170,20 +185,43 @@ _grp_seq = 0            # grouped launches issued so far in this pass (the call-
 
 
 def _run_leaves(late, serial=False):
-    """the queued leaves on lane 0 (the current stream if serial / SERIAL_LEAVES), 1x1 requests of one shape grouped -> [(prefix, grads)]"""
+    """the queued leaves on lane 0 (the current stream if serial / SERIAL_LEAVES), 1x1 requests of one shape grouped -> [(prefix, grads)].
+    Queue entries: a closure -> {name: grad}; ('grp', key, request, post) -- a 1x1 weight gradient, post(g, db) -> {..}; ('fin', key, batch,
+    names, fin) -- a finishing reduction (_leaf_fin)"""
     global _grp_seq
     import contextlib
     ctx = contextlib.nullcontext() if (SERIAL_LEAVES or serial) else K.lane(0, sync=True)
     with ctx:
-        groups, outs = {}, {}
+        groups, fins, outs = {}, {}, {}
         for i, (pre, fn, _) in enumerate(late):
             if isinstance(fn, tuple):
-                groups.setdefault(fn[1], []).append(i)
+                (fins if fn[0] == 'fin' else groups).setdefault(fn[1], []).append(i)
         for key, idxs in groups.items():                         # one launch + one reduction per shape
-            for i, r in zip(idxs, K.wgrad1x1_group([late[i][1][2][:5] for i in idxs], seq=_grp_seq, want_db=key[-1])):
-                outs[i] = r
+            res = K.wgrad1x1_group([late[i][1][2][:5] for i in idxs], seq=_grp_seq, want_db=key[-1])
             _grp_seq += 1
-        return [(pre, fn[3](*outs[i]) if isinstance(fn, tuple) else fn()) for i, (pre, fn, _) in enumerate(late)]
+            # posts that are a scaled_conv_param_grads call on the result (conv5 / gamma: naf_bwd's post5.scp) share one launch too
+            scp = [(i, r) for i, r in zip(idxs, res) if BATCH_FINISH and getattr(late[i][1][3], 'scp', None) is not None]
+            if len(scp) > 1:
+                items = []
+                for i, (g5, s5) in scp:
+                    w5, b5, gam, c_out, c, _fmt = late[i][1][3].scp
+                    items.append((g5.view(c_out, c), s5, w5, b5, gam))
+                for (i, _r), r3 in zip(scp, K.scaled_conv_param_grads_multi(items, seq=_grp_seq)):
+                    outs[i] = late[i][1][3].scp[5](*K.side_keep(*r3))
+                _grp_seq += 1
+            for i, r in zip(idxs, res):
+                if i not in outs:
+                    outs[i] = late[i][1][3](*r)
+        for key, idxs in fins.items():                           # finishing reductions: one table-driven launch per kind and shape
+            if len(idxs) == 1:
+                i = idxs[0]
+                outs[i] = dict(zip(late[i][1][3], late[i][1][4]()))
+                continue
+            multi = K.pair_sum_partials_multi if key[0] == 'ln' else K.dw_param_finish_multi
+            for i, r in zip(idxs, multi([late[i][1][2][1:] for i in idxs], seq=_grp_seq)):
+                outs[i] = dict(zip(late[i][1][3], r))
+            _grp_seq += 1
+        return [(pre, outs[i] if isinstance(fn, tuple) else fn()) for i, (pre, fn, _) in enumerate(late)]
 
 
 def run_late_leaves(G, main_chain):
@@ -264,9 +302,8 @@ def naf_bwd(dout, P, saved):
     beta, gamma = P['beta'].view(-1), P['gamma'].view(-1)
     late = _late is not None and DEFER_LN_FINISH
     # ---- conv5 / gamma chain (parameter gradients only: a leaf off the data-gradient chain)
-    def post5(G5, S5):
+    def fmt5(dw5, db5, dgam):
         g = {}
-        dw5, db5, dgam = K.side_keep(*K.scaled_conv_param_grads(G5.view(c_out, c), S5, P['conv5.weight'], P['conv5.bias'], gamma))
         if c_out == c:
             g['conv5.weight'], g['conv5.bias'], g['gamma'] = dw5.view(c, c, 1, 1), db5, dgam.view(1, c, 1, 1)
         else:
@@ -278,6 +315,10 @@ def naf_bwd(dout, P, saved):
             K.copy_rows(dgam, 0, fg, 0, 1, c_out)
             g['conv5.weight'], g['conv5.bias'], g['gamma'] = fw, fb, fg
         return g
+
+    def post5(G5, S5):
+        return fmt5(*K.side_keep(*K.scaled_conv_param_grads(G5.view(c_out, c), S5, P['conv5.weight'], P['conv5.bias'], gamma)))
+    post5.scp = (P['conv5.weight'], P['conv5.bias'], gamma, c_out, c, fmt5)      # (what _run_leaves needs to batch it with its level's others)
     _leaf_wgrad1x1((t4, dout), (t4, dout, c_out, c, True), post5, G)
     fused = FUSE_TAIL and K.naf_tail_supported(c, H * W, c_out) and dout.is_contiguous() and \
         _dgrad_fused_ok()
@@ -291,7 +332,7 @@ def naf_bwd(dout, P, saved):
         else:
             dy, dt4, gw2, gb2 = K.naf_tail_bwd(dout, gamma, t4, y, mu2, rs2, P['norm2.weight'], w5t, w4t, defer_finish=late)
         if late:        # the reduction of the per-workgroup LayerNorm-gradient partials is a leaf too (gw2: closure over its private buffer)
-            _leaf((), lambda: dict(zip(('norm2.weight', 'norm2.bias'), gw2())), G)
+            _leaf_fin(('norm2.weight', 'norm2.bias'), gw2, G)
         else:
             G['norm2.weight'], G['norm2.bias'] = gw2, gb2
     else:
@@ -321,7 +362,7 @@ def naf_bwd(dout, P, saved):
         dg = K.conv_forward(dy, wp, mp, c, 1, kscale=beta, scale=s, bias2=dpooled, bias2_mul=1.0 / (H * W))
         dt1, gdw, gdb = K.dwsg_bwd(dg, t1, P['conv2.weight'], P['conv2.bias'], defer_finish=late)
     if callable(gdw):       # the finish of the depthwise parameter gradients: one more leaf
-        _leaf((), lambda: dict(zip(('conv2.weight', 'conv2.bias'), gdw())), G)
+        _leaf_fin(('conv2.weight', 'conv2.bias'), gdw, G)
     else:
         G['conv2.weight'], G['conv2.bias'] = gdw, gdb
     # ---- conv1
@@ -332,7 +373,7 @@ def naf_bwd(dout, P, saved):
         w1t = K.pack_weights(P['conv1.weight'], PACK_DGRAD_S1)[0]
         dx, gw1, gb1 = K.naf_head_bwd(dt1, x, mu1, rs1, P['norm1.weight'], w1t, dy, defer_finish=late)
         if late:
-            _leaf((), lambda: dict(zip(('norm1.weight', 'norm1.bias'), gw1())), G)
+            _leaf_fin(('norm1.weight', 'norm1.bias'), gw1, G)
         else:
             G['norm1.weight'], G['norm1.bias'] = gw1, gb1
     else:

@@ -711,6 +711,73 @@ def _grp_table(seq, nrows, capturing):
     return ent['eager'][slot], (ent, slot)
 
 
+def _upload_table(rows, seq, dev):
+    """the pointer table of a table-driven launch (call site `seq` of the pass) -> device tensor of 64-bit words, through a pinned host
+    block that a captured graph can re-read on replay (_grp_table)"""
+    capturing = torch.cuda.is_current_stream_capturing()
+    host, eager_slot = _grp_table(seq, len(rows), capturing)
+    host.copy_(torch.tensor(rows, dtype=torch.int64))
+    tab = torch.empty(len(rows), dtype=torch.int64, device=dev)
+    tab.copy_(host, non_blocking=True)
+    if eager_slot is not None:
+        ent, slot = eager_slot
+        ent['ev'][slot] = torch.cuda.Event()
+        ent['ev'][slot].record()
+    return tab
+
+
+# ---- table-driven forms of the small finishing reductions of the deferred leaves (one launch per kind and shape instead of one per block;
+# ---- per problem bit-identical to the single-problem entry points)
+def pair_sum_partials_multi(items, seq=0):
+    """items: [(ws, nparts, C)] of ONE (nparts <= 1024, C) -- the per-workgroup LayerNorm-gradient partials of fused NAFBlock backward
+    launches (naf_tail_bwd / naf_head_bwd with defer_finish) -> [(gw, gb)]"""
+    ws0, nparts, Cc = items[0]
+    dev = ws0.device
+    n = len(items)
+    out = torch.empty(n, 2, Cc, dtype=torch.float32, device=dev)
+    rows = []
+    for i, (ws, npt, cc) in enumerate(items):
+        assert (npt, cc) == (nparts, Cc)
+        rows += [ws.data_ptr(), out.data_ptr() + 4 * 2 * Cc * i, out.data_ptr() + 4 * (2 * Cc * i + Cc)]
+    tab = _upload_table(rows, seq, dev)
+    check(_lib.load().tdr_pair_sum_partials_multi(tab.data_ptr(), n, nparts, Cc, _stream()), 'tdr_pair_sum_partials_multi')
+    return [(out[i, 0], out[i, 1]) for i in range(n)]
+
+
+def dw_param_finish_multi(items, seq=0):
+    """items: [(ws, N, C, H, W)] of ONE shape (dwsg_bwd with defer_finish) -> [(dw [2C, 1, 3, 3], db [2C])]"""
+    ws0, N, Cc, H, W = items[0]
+    dev = ws0.device
+    n = len(items)
+    dw = torch.empty(n, 2 * Cc, 1, 3, 3, dtype=torch.float32, device=dev)
+    db = torch.empty(n, 2 * Cc, dtype=torch.float32, device=dev)
+    rows = []
+    for i, it in enumerate(items):
+        assert tuple(it[1:]) == (N, Cc, H, W)
+        rows += [it[0].data_ptr(), dw.data_ptr() + 4 * 18 * Cc * i, db.data_ptr() + 4 * 2 * Cc * i]
+    tab = _upload_table(rows, seq, dev)
+    check(_lib.load().tdr_dw_param_finish_multi(tab.data_ptr(), n, N, Cc, H, W, _stream()), 'tdr_dw_param_finish_multi')
+    return [(dw[i], db[i]) for i in range(n)]
+
+
+def scaled_conv_param_grads_multi(items, seq=0):
+    """items: [(G [Cout, Cin], S [Cout], w, b, gamma)] of ONE (Cout, Cin) -> [(dw, db, dgamma)] (scaled_conv_param_grads per item)"""
+    G0 = items[0][0]
+    Cout, Cin = G0.shape[-2], G0.shape[-1]
+    dev = G0.device
+    n = len(items)
+    dw = torch.empty(n, Cout, Cin, dtype=torch.float32, device=dev)
+    dbg = torch.empty(n, 2, Cout, dtype=torch.float32, device=dev)
+    rows = []
+    for i, (G, S, w, b, gamma) in enumerate(items):
+        assert (G.shape[-2], G.shape[-1]) == (Cout, Cin) and G.is_contiguous()
+        rows += [G.data_ptr(), S.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), dw.data_ptr() + 4 * Cout * Cin * i,
+                 dbg.data_ptr() + 4 * 2 * Cout * i, dbg.data_ptr() + 4 * (2 * Cout * i + Cout)]
+    tab = _upload_table(rows, seq, dev)
+    check(_lib.load().tdr_scaled_conv_param_grads_multi(tab.data_ptr(), n, Cout, Cin, _stream()), 'tdr_scaled_conv_param_grads_multi')
+    return [(dw[i], dbg[i, 0], dbg[i, 1]) for i in range(n)]
+
+
 def wgrad1x1_group(reqs, seq=0, want_db=True):
     """reqs: [(x, dout, Cout, Cin, gate)] of ONE wgrad1x1_group_key.  One launch + one fixed-order reduction for all of them.
     Returns [(g [1, Cout, Cin, 1, 1], db [Cout] or None)] in request order."""
@@ -729,15 +796,7 @@ def wgrad1x1_group(reqs, seq=0, want_db=True):
         part = ws.data_ptr() + 4 * per * i
         rows += [x.data_ptr(), do.data_ptr(), part, part + 4 * bpp * Cout * Cin if want_db else 0, g.data_ptr() + 4 * Cout * Cin * i,
                  db.data_ptr() + 4 * Cout * i if want_db else 0]
-    capturing = torch.cuda.is_current_stream_capturing()
-    host, eager_slot = _grp_table(seq, len(rows), capturing)
-    host.copy_(torch.tensor(rows, dtype=torch.int64))
-    tab = torch.empty(len(rows), dtype=torch.int64, device=dev)
-    tab.copy_(host, non_blocking=True)
-    if eager_slot is not None:
-        ent, slot = eager_slot
-        ent['ev'][slot] = torch.cuda.Event()
-        ent['ev'][slot].record()
+    tab = _upload_table(rows, seq, dev)
     if _survey is not None and d.math >= 2:
         for (_x, do, *_r) in reqs:
             _survey.probe(do, 'grad')
@@ -807,6 +866,7 @@ def dwsg_bwd(dg, t, w, b, dg_bias=None, dg_bias_mul=1.0, defer_finish=False):
             db = torch.empty(C2, dtype=torch.float32, device=dev)
             check(lib.tdr_dw_param_finish(ws.data_ptr(), N, Cc, H, W, dw.data_ptr(), db.data_ptr(), _stream()), 'tdr_dw_param_finish')
             return dw, db
+        fin.batch = ('dw', ws, N, Cc, H, W)
         return dt, fin, None
     dw = torch.empty(C2, 1, 3, 3, dtype=torch.float32, device=dev)
     db = torch.empty(C2, dtype=torch.float32, device=dev)
@@ -862,6 +922,8 @@ def _ln_partials_finish(ws, nparts, Cc):
         check(_lib.load().tdr_pair_sum_partials(ws.data_ptr(), nparts, Cc, gw.data_ptr(), gb.data_ptr(),
                                                 ws.data_ptr() + 4 * nparts * 2 * Cc, _stream()), 'tdr_pair_sum_partials')
         return gw, gb
+    if nparts <= 1024:                       # (the one-stage reduction: what pair_sum_partials_multi batches)
+        fin.batch = ('ln', ws, nparts, Cc)
     return fin
 
 
