@@ -10,6 +10,8 @@ bash profiles/pmc_collect.sh gpurun_out/r6m/pmc_traffic.json > gpurun_out/r6m/pm
 cp gpurun_out/r6m/pmc_traffic.json profiles/r6/pmc_traffic.json
 bash profiles/pmc_run.sh gpurun_out/r6m/sq_a.txt "kernel" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" -- python /root/repo/profiles/pmc_workload.py
 bash profiles/pmc_run.sh gpurun_out/r6m/sq_b.txt "kernel" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM" -- python /root/repo/profiles/pmc_workload.py
+bash profiles/pmc_clock.sh gpurun_out/r6m/pmc_clock.txt -- python /root/repo/profiles/pmc_workload.py
+cp gpurun_out/r6m/pmc_clock.txt.json profiles/r6/pmc_clock.json
 bash profiles/rocprof_run.sh gpurun_out/r6m/rocprofv3_kernel_summary_bench.txt 18 -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-exact --no-matcher-active
 cp /tmp/tdr_prof_cmd.log gpurun_out/r6m/bench_under_rocprof.log
 bash profiles/rocprof_run.sh gpurun_out/r6m/rocprofv3_kernel_summary_steps.txt 27 -- python /root/repo/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-f32-exact --no-roofline --no-matcher-active
