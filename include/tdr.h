@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-/* C-ABI version: bumped with every incompatible change of this header (100 rounds 1-2, 101 round 3, 102 round 4); the
+/* C-ABI version: bumped with every incompatible change of this header (100 rounds 1-2, 101 round 3, 102 round 4, 103 - 104
+ * round 5, 105 - 107 round 6: the SFNet operators, their inference modes, the table-driven finishing reductions); the
  * binding (textualdegremoval_amd/_lib.py) refuses a library whose version differs from the one it was written against. */
 #define TDR_ABI_VERSION 107
 int tdr_version(void);
