@@ -343,6 +343,7 @@ def main():
                          '(random-init weights); 0 = ref of the lq size, where the match is the identity')
     ap.add_argument('--bucket-mb', type=float, default=64.0, help='gradient all-reduce bucket size (MiB) of the data-parallel step')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL over xGMI; default) | gloo (multi-process smoke test on one GPU)')
+    ap.add_argument('--pg-timeout', type=float, default=120.0, help='seconds the torch.distributed rendezvous may take')
     ap.add_argument('--rccl-dry-run', action='store_true',
                     help='with --gpus N: bring the RCCL data plane up through the C ABI (tdr_comm_*), verify a broadcast and an all-reduce, time '
                          'one 64 MiB exchange, print ONE JSON line and exit -- or fail loudly with the name of the bring-up stage that did')
@@ -385,7 +386,7 @@ def main():
             os.environ.setdefault('TDR_COMM', 'rccl')
         import datetime
         try:
-            dist.init_process_group(a.backend, timeout=datetime.timedelta(seconds=float(os.environ.get('TDR_PG_TIMEOUT', '120'))))
+            dist.init_process_group(a.backend, timeout=datetime.timedelta(seconds=float(a.pg_timeout)))
         except Exception as e:  # noqa: BLE001
             sys.stderr.write(f'bench.py: rank {rank}/{world}: torch.distributed rendezvous failed ({type(e).__name__}: {e})\n')
             sys.exit(2)
@@ -772,11 +773,7 @@ def _main_body(a, world, rank, local, enc):
             per_cycle_ms = max(c0.elapsed_time(c1), 1e-3) / 20_000_000
             torch.cuda._sleep(int(min(1500.0, 12 * (dt / a.steps * 1e3)) / per_cycle_ms))
             it += 1
-            _t_host = time.time()
             step(it)
-            _t_host = time.time() - _t_host
-            if os.environ.get('TDR_BENCH_DEBUG'):
-                sys.stderr.write(f'bench.py: instrumented eager step issued in {_t_host * 1e3:.0f} ms of host time\n')
             # what an event pair costs by itself on this queue (two marker packets back to back, nothing between them): subtracted
             # from every pair below, so that avg_launch_ms is the kernel's duration as rocprofv3 --kernel-trace reports it
             empties = []
