@@ -768,16 +768,18 @@ int tdr_naf_head_bwd(const TdrNafHeadBwdDesc* d, void* stream);
  * mid: scratch of tdr_pair_sum_mid_floats(nparts, C) floats (a 256-to-1 first stage above 1024 rows; may be NULL when 0) */
 int64_t tdr_pair_sum_mid_floats(int nparts, int C);
 int tdr_pair_sum_partials(const float* part, int nparts, int C, float* o0, float* o1, float* mid, void* stream);
-/* Table-driven forms of three small finishing reductions (ABI 107): the deferred leaves of a NAFBlock level are dozens of problems of ONE
- * shape (28 blocks at the 64x64 level: 56 LayerNorm-partial reductions, 28 depthwise parameter finishes, 28 conv5 / gamma parameter
- * gradients), each a 6 us launch; one launch per kind takes a table of device pointers (64-bit words, DEVICE memory) instead.  Per problem the
- * summation order of the single-problem entry point: bit-identical results.
- *   tdr_pair_sum_partials_multi:       rows {part, o0, o1};  nparts <= 1024 (the one-stage reduction)
- *   tdr_dw_param_finish_multi:         rows {ws, dw, db}
- *   tdr_scaled_conv_param_grads_multi: rows {G, S, w, b, gamma, dw, db, dgamma} */
-int tdr_pair_sum_partials_multi(const void* table, int nprob, int nparts, int C, void* stream);
-int tdr_dw_param_finish_multi(const void* table, int nprob, int N, int C, int H, int W, void* stream);
-int tdr_scaled_conv_param_grads_multi(const void* table, int nprob, int Cout, int Cin, void* stream);
+/* Table-driven forms of three small finishing reductions (ABI 107): the deferred leaves of the NAFBlock levels are dozens of small problems
+ * (28 blocks at the 64x64 level alone: 56 LayerNorm-partial reductions, 28 depthwise parameter finishes, 28 conv5 / gamma parameter
+ * gradients), each a 6 us launch; one launch per kind takes a table of 64-bit words in DEVICE memory instead -- device pointers followed by the
+ * problem's shape, so problems of different shapes share the launch (the grid is sized for the widest, `max_*`).  Per problem the summation
+ * order of the single-problem entry point: bit-identical results.
+ *   tdr_pair_sum_partials_multi:       rows {part, o0, o1, nparts, C};  nparts <= 1024 (the one-stage reduction)
+ *   tdr_dw_param_finish_multi:         rows {ws, dw, db, N, C, nb};     nb = tdr_dw_param_finish_nb(H, W)
+ *   tdr_scaled_conv_param_grads_multi: rows {G, S, w, b, gamma, dw, db, dgamma, Cout, Cin} */
+int tdr_pair_sum_partials_multi(const void* table, int nprob, int max_C, void* stream);
+int tdr_dw_param_finish_nb(int H, int W);
+int tdr_dw_param_finish_multi(const void* table, int nprob, int max_C, void* stream);
+int tdr_scaled_conv_param_grads_multi(const void* table, int nprob, int max_Cout, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Data-parallel exchange over RCCL / xGMI: replaces DistributedDataParallel's gradient all-reduce and

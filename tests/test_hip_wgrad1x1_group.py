@@ -80,34 +80,31 @@ def test_network_backward_grouped_equals_ungrouped(K):
 
 def test_finishing_reductions_batched_are_bit_identical(K):
     """the table-driven forms of the three small finishing reductions (kernels.pair_sum_partials_multi / dw_param_finish_multi /
-    scaled_conv_param_grads_multi) write, per problem, exactly what the single-problem entry points write"""
+    scaled_conv_param_grads_multi) write, per problem, exactly what the single-problem entry points write -- problems of different
+    shapes in ONE launch"""
     lib = __import__('textualdegremoval_amd._lib', fromlist=['load']).load()
     g = torch.Generator().manual_seed(11)
     # LayerNorm-gradient partials [nparts][2][C]
-    for nparts, Cc, n in ((256, 256, 5), (37, 96, 3), (1024, 32, 2)):
-        wss = [torch.randn(nparts * 2 * Cc, generator=g).cuda() for _ in range(n)]
-        got = K.pair_sum_partials_multi([(w, nparts, Cc) for w in wss], seq=900)
-        for w, (gw, gb) in zip(wss, got):
-            rw, rb = torch.empty(Cc, device='cuda'), torch.empty(Cc, device='cuda')
-            K.check(lib.tdr_pair_sum_partials(w.data_ptr(), nparts, Cc, rw.data_ptr(), rb.data_ptr(), 0, K._stream()), 'pair_sum')
-            assert torch.equal(gw, rw) and torch.equal(gb, rb)
-            assert (gw.double().cpu() - w.view(nparts, 2, Cc)[:, 0].double().sum(0).cpu()).abs().max() < 1e-3
+    items = [(torch.randn(nparts * 2 * Cc, generator=g).cuda(), nparts, Cc)
+             for nparts, Cc, n in ((256, 256, 5), (37, 96, 3), (1024, 32, 2), (1, 128, 1)) for _ in range(n)]
+    for (w, nparts, Cc), (gw, gb) in zip(items, K.pair_sum_partials_multi(items, seq=900)):
+        rw, rb = torch.empty(Cc, device='cuda'), torch.empty(Cc, device='cuda')
+        K.check(lib.tdr_pair_sum_partials(w.data_ptr(), nparts, Cc, rw.data_ptr(), rb.data_ptr(), 0, K._stream()), 'pair_sum')
+        assert torch.equal(gw, rw) and torch.equal(gb, rb)
+        assert (gw.double().cpu() - w.view(nparts, 2, Cc)[:, 0].double().sum(0).cpu()).abs().max() < 1e-3
     # depthwise parameter partials
-    for N, Cc, H, W, n in ((4, 64, 64, 64, 4), (2, 24, 32, 48, 3)):
-        nws = int(lib.tdr_dwsg_ws_floats(N, Cc, H, W))
-        wss = [torch.randn(nws, generator=g).cuda() for _ in range(n)]
-        got = K.dw_param_finish_multi([(w, N, Cc, H, W) for w in wss], seq=901)
-        for w, (dw, db) in zip(wss, got):
-            rw, rb = torch.empty(2 * Cc, 1, 3, 3, device='cuda'), torch.empty(2 * Cc, device='cuda')
-            K.check(lib.tdr_dw_param_finish(w.data_ptr(), N, Cc, H, W, rw.data_ptr(), rb.data_ptr(), K._stream()), 'dw_finish')
-            assert torch.equal(dw, rw) and torch.equal(db, rb)
+    items = [(torch.randn(int(lib.tdr_dwsg_ws_floats(N, Cc, H, W)), generator=g).cuda(), N, Cc, H, W)
+             for N, Cc, H, W, n in ((4, 64, 64, 64, 4), (2, 24, 32, 48, 3), (4, 256, 16, 16, 2)) for _ in range(n)]
+    for (w, N, Cc, H, W), (dw, db) in zip(items, K.dw_param_finish_multi(items, seq=901)):
+        rw, rb = torch.empty(2 * Cc, 1, 3, 3, device='cuda'), torch.empty(2 * Cc, device='cuda')
+        K.check(lib.tdr_dw_param_finish(w.data_ptr(), N, Cc, H, W, rw.data_ptr(), rb.data_ptr(), K._stream()), 'dw_finish')
+        assert torch.equal(dw, rw) and torch.equal(db, rb)
     # conv5 / gamma parameter gradients
-    for Cout, Cin, n in ((256, 256, 6), (128, 256, 2), (40, 72, 3)):
-        items = [tuple(torch.randn(*shp, generator=g).cuda() for shp in ((Cout, Cin), (Cout,), (Cout, Cin), (Cout,), (Cout,))) for _ in range(n)]
-        got = K.scaled_conv_param_grads_multi(items, seq=902)
-        for it, r3 in zip(items, got):
-            ref = K.scaled_conv_param_grads(*it)
-            assert all(torch.equal(a, b) for a, b in zip(r3, ref))
+    items = [tuple(torch.randn(*shp, generator=g).cuda() for shp in ((Cout, Cin), (Cout,), (Cout, Cin), (Cout,), (Cout,)))
+             for Cout, Cin, n in ((256, 256, 6), (128, 256, 2), (40, 72, 3)) for _ in range(n)]
+    for it, r3 in zip(items, K.scaled_conv_param_grads_multi(items, seq=902)):
+        ref = K.scaled_conv_param_grads(*it)
+        assert all(torch.equal(a, b) for a, b in zip(r3, ref))
 
 
 def test_network_backward_with_batched_finishers_is_bit_identical(K):

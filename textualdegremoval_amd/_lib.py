@@ -225,9 +225,10 @@ SIGNATURES = {
     'tdr_sf_emerge': (i32, [c_fp, i64, c_fp, i32, i32, i32, c_fp, c_fp]),
     'tdr_sf_softmax_mix': (i32, [c_fp, i64, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp]),
     'tdr_scaled_conv_param_grads': (i32, [c_fp] * 5 + [i32, i32] + [c_fp] * 3 + [c_fp]),
-    'tdr_pair_sum_partials_multi': (i32, [c_fp, i32, i32, i32, c_fp]),
-    'tdr_dw_param_finish_multi': (i32, [c_fp, i32, i32, i32, i32, i32, c_fp]),
-    'tdr_scaled_conv_param_grads_multi': (i32, [c_fp, i32, i32, i32, c_fp]),
+    'tdr_pair_sum_partials_multi': (i32, [c_fp, i32, i32, c_fp]),
+    'tdr_dw_param_finish_nb': (i32, [i32, i32]),
+    'tdr_dw_param_finish_multi': (i32, [c_fp, i32, i32, c_fp]),
+    'tdr_scaled_conv_param_grads_multi': (i32, [c_fp, i32, i32, c_fp]),
     'tdr_chansum_ws_floats': (i64, [i32, i32, i32]),
     'tdr_channel_sum': (i32, [c_fp, i64, i32, i32, i32, c_fp, c_fp, c_fp]),
     'tdr_copy_rows': (i32, [c_fp, i64, c_fp, i64, i32, i64, c_fp]),

@@ -474,9 +474,11 @@ __global__ void dw_param_finish_kernel(const float* __restrict__ part, int N, in
     else if (db) db[ch] = sacc;
 }
 
-// many problems of one (N, C, nb): table rows {part, dw, db}, blockIdx.y = problem; dw_param_finish_kernel's order
-__global__ void dw_param_finish_multi_kernel(const long long* __restrict__ tab, int N, int C, int nb) {
-    const long long* row = tab + 3L * blockIdx.y;
+// many problems: table rows {part, dw, db, N, C, nb}, blockIdx.y = problem, grid.x sized for the widest one; dw_param_finish_kernel's order
+__global__ void dw_param_finish_multi_kernel(const long long* __restrict__ tab) {
+    const long long* row = tab + 6L * blockIdx.y;
+    const int N = (int)row[3], C = (int)row[4], nb = (int)row[5];
+    if ((int)blockIdx.x >= C) return;
     const float* part = reinterpret_cast<const float*>(row[0]);
     float* dw = reinterpret_cast<float*>(row[1]);
     float* db = reinterpret_cast<float*>(row[2]);
@@ -586,11 +588,13 @@ extern "C" int tdr_dw_param_finish(const float* ws, int N, int C, int H, int W, 
     return TDR_OK;
 }
 
-// table [nprob][3] of device pointers {ws, dw, db} in DEVICE memory; every problem has the same (N, C, H, W)
-extern "C" int tdr_dw_param_finish_multi(const void* table, int nprob, int N, int C, int H, int W, void* stream) {
-    TDR_REQUIRE(table && nprob > 0 && N > 0 && C > 0, "tdr_dw_param_finish_multi: bad argument");
-    const DwGeom q = dw_geom_fused(H, W);
-    hipLaunchKernelGGL(dw_param_finish_multi_kernel, dim3(C, nprob), dim3(32), 0, (hipStream_t)stream, static_cast<const long long*>(table), N, C, q.nb);
+// partial-row blocks per plane of a (H, W) problem: the `nb` word of its table row
+extern "C" int tdr_dw_param_finish_nb(int H, int W) { return dw_geom_fused(H, W).nb; }
+
+// table [nprob][6] of 64-bit words {ws, dw, db, N, C, nb = tdr_dw_param_finish_nb(H, W)} in DEVICE memory; max_C = the widest problem
+extern "C" int tdr_dw_param_finish_multi(const void* table, int nprob, int max_C, void* stream) {
+    TDR_REQUIRE(table && nprob > 0 && max_C > 0, "tdr_dw_param_finish_multi: bad argument");
+    hipLaunchKernelGGL(dw_param_finish_multi_kernel, dim3(max_C, nprob), dim3(32), 0, (hipStream_t)stream, static_cast<const long long*>(table));
     TDR_LAUNCH_CHECK("dw_param_finish_multi_kernel");
     return TDR_OK;
 }

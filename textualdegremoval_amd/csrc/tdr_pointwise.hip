@@ -419,12 +419,14 @@ __global__ __launch_bounds__(64 * KL) void pair_sum_partials_kernel(const float*
     }
 }
 
-// the same reduction for MANY problems of one (nparts, C) in one launch: table rows {part, o0, o1} (device pointers as 64-bit words),
-// blockIdx.z = problem; per problem exactly pair_sum_partials_kernel's summation order (bit-identical results)
+// the same reduction for MANY problems in one launch: table rows {part, o0, o1, nparts, C} (64-bit words: device pointers and the problem's
+// shape), blockIdx.z = problem, grid.x sized for the widest one; per problem exactly pair_sum_partials_kernel's summation order (bit-identical)
 template <int KL>
-__global__ __launch_bounds__(64 * KL) void pair_sum_partials_multi_kernel(const long long* __restrict__ tab, int nparts, int C) {
+__global__ __launch_bounds__(64 * KL) void pair_sum_partials_multi_kernel(const long long* __restrict__ tab) {
     __shared__ float red[KL][64];
-    const long long* row = tab + 3L * blockIdx.z;
+    const long long* row = tab + 5L * blockIdx.z;
+    const int nparts = (int)row[3], C = (int)row[4];
+    if ((int)blockIdx.x * 64 >= C) return;                   // (uniform per workgroup: before any barrier)
     const float* part = reinterpret_cast<const float*>(row[0]);
     float* o = reinterpret_cast<float*>(blockIdx.y ? row[2] : row[1]);
     const int lane = threadIdx.x & 63, kl = threadIdx.x >> 6;
@@ -652,10 +654,13 @@ __global__ __launch_bounds__(256) void scaled_conv_param_kernel(const float* __r
     }
 }
 
-// many problems of one (Cout, Cin): table rows {G, S, w, b, gamma, dw, db, dgamma}, blockIdx.y = problem; scaled_conv_param_kernel's order
-__global__ __launch_bounds__(256) void scaled_conv_param_multi_kernel(const long long* __restrict__ tab, int Cin) {
+// many problems: table rows {G, S, w, b, gamma, dw, db, dgamma, Cout, Cin}, blockIdx.y = problem, grid.x sized for the widest one;
+// scaled_conv_param_kernel's order
+__global__ __launch_bounds__(256) void scaled_conv_param_multi_kernel(const long long* __restrict__ tab) {
     __shared__ float red[4];
-    const long long* row = tab + 8L * blockIdx.y;
+    const long long* row = tab + 10L * blockIdx.y;
+    const int Cin = (int)row[9];
+    if ((int)blockIdx.x >= (int)row[8]) return;
     const float* G = reinterpret_cast<const float*>(row[0]);
     const float* S = reinterpret_cast<const float*>(row[1]);
     const float* w = reinterpret_cast<const float*>(row[2]);
@@ -1004,19 +1009,20 @@ extern "C" int tdr_pair_sum_partials(const float* part, int nparts, int C, float
     return TDR_OK;
 }
 
-// table [nprob][3] of device pointers {part, o0, o1} in DEVICE memory; every problem has the same (nparts <= 1024, C)
-extern "C" int tdr_pair_sum_partials_multi(const void* table, int nprob, int nparts, int C, void* stream) {
-    TDR_REQUIRE(table && nprob > 0 && nparts > 0 && nparts <= 1024 && C > 0, "tdr_pair_sum_partials_multi: bad argument (one-stage reductions only: nparts <= 1024)");
-    hipLaunchKernelGGL(pair_sum_partials_multi_kernel<16>, dim3(tdr_cdiv(C, 64), 2, nprob), dim3(1024), 0, (hipStream_t)stream,
-                       static_cast<const long long*>(table), nparts, C);
+// table [nprob][5] of 64-bit words {part, o0, o1, nparts, C} in DEVICE memory; every problem a one-stage reduction (nparts <= 1024: the caller's
+// contract -- the table is not readable here), max_C = the widest problem
+extern "C" int tdr_pair_sum_partials_multi(const void* table, int nprob, int max_C, void* stream) {
+    TDR_REQUIRE(table && nprob > 0 && max_C > 0, "tdr_pair_sum_partials_multi: bad argument");
+    hipLaunchKernelGGL(pair_sum_partials_multi_kernel<16>, dim3(tdr_cdiv(max_C, 64), 2, nprob), dim3(1024), 0, (hipStream_t)stream,
+                       static_cast<const long long*>(table));
     TDR_LAUNCH_CHECK("pair_sum_partials_multi");
     return TDR_OK;
 }
 
-// table [nprob][8] of device pointers {G, S, w, b, gamma, dw, db, dgamma} in DEVICE memory; every problem has the same (Cout, Cin)
-extern "C" int tdr_scaled_conv_param_grads_multi(const void* table, int nprob, int Cout, int Cin, void* stream) {
-    TDR_REQUIRE(table && nprob > 0 && Cout > 0 && Cin > 0, "tdr_scaled_conv_param_grads_multi: bad argument");
-    hipLaunchKernelGGL(scaled_conv_param_multi_kernel, dim3(Cout, nprob), dim3(256), 0, (hipStream_t)stream, static_cast<const long long*>(table), Cin);
+// table [nprob][10] of 64-bit words {G, S, w, b, gamma, dw, db, dgamma, Cout, Cin} in DEVICE memory; max_Cout = the widest problem
+extern "C" int tdr_scaled_conv_param_grads_multi(const void* table, int nprob, int max_Cout, void* stream) {
+    TDR_REQUIRE(table && nprob > 0 && max_Cout > 0, "tdr_scaled_conv_param_grads_multi: bad argument");
+    hipLaunchKernelGGL(scaled_conv_param_multi_kernel, dim3(max_Cout, nprob), dim3(256), 0, (hipStream_t)stream, static_cast<const long long*>(table));
     TDR_LAUNCH_CHECK("scaled_conv_param_multi_kernel");
     return TDR_OK;
 }

@@ -68,7 +68,7 @@ DEFER_LN_FINISH = True                                                  # also t
 # (kernels.wgrad1x1_group, csrc/tdr_wgrad_1x1.hip): no per-launch ramp / prologue / partial write / reduction launch, 1 / 8 of the partials
 GROUP_LEAVES = True
 # ... and the small finishing reductions queued with them (LayerNorm-gradient partials, depthwise parameter partials, the conv5 / gamma
-# parameter gradients behind a grouped weight gradient) run as ONE table-driven launch per kind and shape (kernels.*_multi): 112 of the 184
+# parameter gradients behind a grouped weight gradient) run as ONE table-driven launch per kind (kernels.*_multi; the shapes travel in the table): 112 of the 184
 # finishing launches of the headline step are the 28 blocks of one level -- beside the MASA-encoder backward they hide, in the data-parallel
 # leaf schedule they are serial launches at the level's end
 BATCH_FINISH = True
@@ -110,7 +110,7 @@ def _leaf_fin(names, fin, G):
     (kernels._ln_partials_finish, kernels.dwsg_bwd) are queued as requests, so that _run_leaves can run all of one shape as one launch"""
     b = getattr(fin, 'batch', None)
     if _late is not None and BATCH_FINISH and b is not None:
-        _late.append((_late_pre, ('fin', (b[0],) + tuple(b[2:]), b, names, fin), (b[1],)))
+        _late.append((_late_pre, ('fin', b[0], b, names, fin), (b[1],)))
         return
     _leaf((), lambda: dict(zip(names, fin())), G)
 
@@ -196,28 +196,32 @@ def _run_leaves(late, serial=False):
         for i, (pre, fn, _) in enumerate(late):
             if isinstance(fn, tuple):
                 (fins if fn[0] == 'fin' else groups).setdefault(fn[1], []).append(i)
+        scp = []                                                 # posts that are a scaled_conv_param_grads call on a group's result
         for key, idxs in groups.items():                         # one launch + one reduction per shape
             res = K.wgrad1x1_group([late[i][1][2][:5] for i in idxs], seq=_grp_seq, want_db=key[-1])
             _grp_seq += 1
-            # posts that are a scaled_conv_param_grads call on the result (conv5 / gamma: naf_bwd's post5.scp) share one launch too
-            scp = [(i, r) for i, r in zip(idxs, res) if BATCH_FINISH and getattr(late[i][1][3], 'scp', None) is not None]
-            if len(scp) > 1:
-                items = []
-                for i, (g5, s5) in scp:
-                    w5, b5, gam, c_out, c, _fmt = late[i][1][3].scp
-                    items.append((g5.view(c_out, c), s5, w5, b5, gam))
-                for (i, _r), r3 in zip(scp, K.scaled_conv_param_grads_multi(items, seq=_grp_seq)):
-                    outs[i] = late[i][1][3].scp[5](*K.side_keep(*r3))
-                _grp_seq += 1
             for i, r in zip(idxs, res):
-                if i not in outs:
+                if BATCH_FINISH and getattr(late[i][1][3], 'scp', None) is not None:
+                    scp.append((i, r))                           # (conv5 / gamma: naf_bwd's post5.scp) -- one launch for all of them below
+                else:
                     outs[i] = late[i][1][3](*r)
-        for key, idxs in fins.items():                           # finishing reductions: one table-driven launch per kind and shape
+        if len(scp) > 1:
+            items = []
+            for i, (g5, s5) in scp:
+                w5, b5, gam, c_out, c, _fmt = late[i][1][3].scp
+                items.append((g5.view(c_out, c), s5, w5, b5, gam))
+            for (i, _r), r3 in zip(scp, K.scaled_conv_param_grads_multi(items, seq=_grp_seq)):
+                outs[i] = late[i][1][3].scp[5](*K.side_keep(*r3))
+            _grp_seq += 1
+        else:
+            for i, r in scp:
+                outs[i] = late[i][1][3](*r)
+        for kind, idxs in fins.items():                          # finishing reductions: one table-driven launch per kind (shapes in the table)
             if len(idxs) == 1:
                 i = idxs[0]
                 outs[i] = dict(zip(late[i][1][3], late[i][1][4]()))
                 continue
-            multi = K.pair_sum_partials_multi if key[0] == 'ln' else K.dw_param_finish_multi
+            multi = K.pair_sum_partials_multi if kind == 'ln' else K.dw_param_finish_multi
             for i, r in zip(idxs, multi([late[i][1][2][1:] for i in idxs], seq=_grp_seq)):
                 outs[i] = dict(zip(late[i][1][3], r))
             _grp_seq += 1

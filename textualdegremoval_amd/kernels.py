@@ -726,56 +726,55 @@ def _upload_table(rows, seq, dev):
     return tab
 
 
-# ---- table-driven forms of the small finishing reductions of the deferred leaves (one launch per kind and shape instead of one per block;
+# ---- table-driven forms of the small finishing reductions of the deferred leaves (one launch per kind instead of one per block;
 # ---- per problem bit-identical to the single-problem entry points)
 def pair_sum_partials_multi(items, seq=0):
-    """items: [(ws, nparts, C)] of ONE (nparts <= 1024, C) -- the per-workgroup LayerNorm-gradient partials of fused NAFBlock backward
-    launches (naf_tail_bwd / naf_head_bwd with defer_finish) -> [(gw, gb)]"""
-    ws0, nparts, Cc = items[0]
-    dev = ws0.device
-    n = len(items)
-    out = torch.empty(n, 2, Cc, dtype=torch.float32, device=dev)
-    rows = []
-    for i, (ws, npt, cc) in enumerate(items):
-        assert (npt, cc) == (nparts, Cc)
-        rows += [ws.data_ptr(), out.data_ptr() + 4 * 2 * Cc * i, out.data_ptr() + 4 * (2 * Cc * i + Cc)]
+    """items: [(ws, nparts, C)], nparts <= 1024 each (any mix of shapes) -- the per-workgroup LayerNorm-gradient partials of fused NAFBlock
+    backward launches (naf_tail_bwd / naf_head_bwd with defer_finish) -> [(gw, gb)]"""
+    dev = items[0][0].device
+    out = torch.empty(sum(2 * cc for _, _, cc in items), dtype=torch.float32, device=dev)
+    rows, res, off = [], [], 0
+    for ws, npt, cc in items:
+        assert 0 < npt <= 1024
+        rows += [ws.data_ptr(), out.data_ptr() + 4 * off, out.data_ptr() + 4 * (off + cc), npt, cc]
+        res.append((out[off:off + cc], out[off + cc:off + 2 * cc]))
+        off += 2 * cc
     tab = _upload_table(rows, seq, dev)
-    check(_lib.load().tdr_pair_sum_partials_multi(tab.data_ptr(), n, nparts, Cc, _stream()), 'tdr_pair_sum_partials_multi')
-    return [(out[i, 0], out[i, 1]) for i in range(n)]
+    check(_lib.load().tdr_pair_sum_partials_multi(tab.data_ptr(), len(items), max(cc for _, _, cc in items), _stream()), 'tdr_pair_sum_partials_multi')
+    return res
 
 
 def dw_param_finish_multi(items, seq=0):
-    """items: [(ws, N, C, H, W)] of ONE shape (dwsg_bwd with defer_finish) -> [(dw [2C, 1, 3, 3], db [2C])]"""
-    ws0, N, Cc, H, W = items[0]
-    dev = ws0.device
-    n = len(items)
-    dw = torch.empty(n, 2 * Cc, 1, 3, 3, dtype=torch.float32, device=dev)
-    db = torch.empty(n, 2 * Cc, dtype=torch.float32, device=dev)
-    rows = []
-    for i, it in enumerate(items):
-        assert tuple(it[1:]) == (N, Cc, H, W)
-        rows += [it[0].data_ptr(), dw.data_ptr() + 4 * 18 * Cc * i, db.data_ptr() + 4 * 2 * Cc * i]
+    """items: [(ws, N, C, H, W)] (any mix of shapes; dwsg_bwd with defer_finish) -> [(dw [2C, 1, 3, 3], db [2C])]"""
+    lib = _lib.load()
+    dev = items[0][0].device
+    out = torch.empty(sum(20 * cc for _, _, cc, _, _ in items), dtype=torch.float32, device=dev)
+    rows, res, off = [], [], 0
+    for ws, N, cc, H, W in items:
+        rows += [ws.data_ptr(), out.data_ptr() + 4 * off, out.data_ptr() + 4 * (off + 18 * cc), N, cc, int(lib.tdr_dw_param_finish_nb(H, W))]
+        res.append((out[off:off + 18 * cc].view(2 * cc, 1, 3, 3), out[off + 18 * cc:off + 20 * cc]))
+        off += 20 * cc
     tab = _upload_table(rows, seq, dev)
-    check(_lib.load().tdr_dw_param_finish_multi(tab.data_ptr(), n, N, Cc, H, W, _stream()), 'tdr_dw_param_finish_multi')
-    return [(dw[i], db[i]) for i in range(n)]
+    check(lib.tdr_dw_param_finish_multi(tab.data_ptr(), len(items), max(it[2] for it in items), _stream()), 'tdr_dw_param_finish_multi')
+    return res
 
 
 def scaled_conv_param_grads_multi(items, seq=0):
-    """items: [(G [Cout, Cin], S [Cout], w, b, gamma)] of ONE (Cout, Cin) -> [(dw, db, dgamma)] (scaled_conv_param_grads per item)"""
-    G0 = items[0][0]
-    Cout, Cin = G0.shape[-2], G0.shape[-1]
-    dev = G0.device
-    n = len(items)
-    dw = torch.empty(n, Cout, Cin, dtype=torch.float32, device=dev)
-    dbg = torch.empty(n, 2, Cout, dtype=torch.float32, device=dev)
-    rows = []
-    for i, (G, S, w, b, gamma) in enumerate(items):
-        assert (G.shape[-2], G.shape[-1]) == (Cout, Cin) and G.is_contiguous()
-        rows += [G.data_ptr(), S.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), dw.data_ptr() + 4 * Cout * Cin * i,
-                 dbg.data_ptr() + 4 * 2 * Cout * i, dbg.data_ptr() + 4 * (2 * Cout * i + Cout)]
+    """items: [(G [Cout, Cin], S [Cout], w, b, gamma)] (any mix of shapes) -> [(dw, db, dgamma)] (scaled_conv_param_grads per item)"""
+    dev = items[0][0].device
+    shapes = [(it[0].shape[-2], it[0].shape[-1]) for it in items]
+    out = torch.empty(sum(co * ci + 2 * co for co, ci in shapes), dtype=torch.float32, device=dev)
+    rows, res, off = [], [], 0
+    for (G, S, w, b, gamma), (co, ci) in zip(items, shapes):
+        assert G.is_contiguous()
+        base = out.data_ptr() + 4 * off
+        rows += [G.data_ptr(), S.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), base, base + 4 * co * ci, base + 4 * (co * ci + co), co, ci]
+        res.append((out[off:off + co * ci].view(co, ci), out[off + co * ci:off + co * ci + co], out[off + co * ci + co:off + co * ci + 2 * co]))
+        off += co * ci + 2 * co
     tab = _upload_table(rows, seq, dev)
-    check(_lib.load().tdr_scaled_conv_param_grads_multi(tab.data_ptr(), n, Cout, Cin, _stream()), 'tdr_scaled_conv_param_grads_multi')
-    return [(dw[i], dbg[i, 0], dbg[i, 1]) for i in range(n)]
+    check(_lib.load().tdr_scaled_conv_param_grads_multi(tab.data_ptr(), len(items), max(co for co, _ in shapes), _stream()),
+          'tdr_scaled_conv_param_grads_multi')
+    return res
 
 
 def wgrad1x1_group(reqs, seq=0, want_db=True):
